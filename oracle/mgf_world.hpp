@@ -1,0 +1,181 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see mgf_math.hpp header).
+// CPU restatement of
+//   src/mesh.rs:32-139        Mesh (static triangle soup + BVH over faces) and Mesh::contacts
+//   src/collision.rs:1490-1506 LocalContacts<Mesh> for Moving<Component>
+//   mgf_demo/world.rs:178-184  World::add_body (fat margin 0.25)
+//   mgf_demo/world.rs:227-294  World::step — the tick
+// Constraint insertion order modes:
+//   ORDER_DEMO      — exactly world.rs: for each body i, terrain contacts in mesh-BVH
+//                     DFS order, then partners j<i in world-BVH DFS order (the BVH is
+//                     mutated inside the loop, world.rs:235-238).
+//   ORDER_CANONICAL — same terrain order; partners j<i sorted ascending.  The set of
+//                     constraints is identical (the narrowphase decides), only the
+//                     order among body i's partners differs.  This is the order the
+//                     HIP path emits.
+// PARITY STATUS: World::step has no reference test ("parity unpinned").
+#pragma once
+#include <algorithm>
+#include <array>
+#include <chrono>
+
+#include "mgf_bvh.hpp"
+#include "mgf_physics.hpp"
+
+namespace mgfo {
+
+struct Mesh {  // mesh.rs:32-37
+  V3 x = v3(0, 0, 0);
+  std::vector<V3> verts;
+  std::vector<std::array<size_t, 3>> faces;
+  BVH<size_t> bvh;
+
+  size_t push_vert(V3 p) { verts.push_back(p); return verts.size() - 1; }  // mesh.rs:58-62
+  size_t push_face(size_t a, size_t b, size_t c) {                         // mesh.rs:64-73
+    Triangle tri{verts[a], verts[b], verts[c]};
+    size_t index = faces.size();
+    faces.push_back({a, b, c});
+    bvh.insert(bounds(tri), index);
+    return index;
+  }
+  V3 center() const { return x; }                      // mesh.rs:89-91
+  void set_pos(V3 p) { V3 disp = p - center(); x += disp; }  // geom.rs:459-462 + mesh.rs:76-80
+
+  // Contacts<RHS> for Mesh, RHS = Moving<Component>  mesh.rs:115-139
+  template <class F>
+  bool contacts(const Moving<Component>& rhs, F&& cb) const {
+    bool collided = false;
+    bvh.query(bounds(rhs) - x, [&](size_t face_index) {
+      const auto& f = faces[face_index];
+      V3 a = verts[f[0]] + x, b = verts[f[1]] + x, c = verts[f[2]] + x;
+      Triangle tri{a, b, c};
+      mgfo::contacts(rhs, tri, [&](const Contact& k) {
+        collided = true;
+        cb(Contact{k.b, k.a, -k.n, k.t});
+      });
+    });
+    return collided;
+  }
+};
+
+// LocalContacts<Arg = Mesh> for Moving<Recv = Component>  collision.rs:1490-1506
+template <class F>
+static inline bool local_contacts(const Moving<Component>& self, const Mesh& rhs, F&& cb) {
+  return rhs.contacts(self, [&](const Contact& c) {
+    V3 a_c = center(self.shape) + self.vel * c.t;
+    V3 b_c = rhs.center();
+    cb(LocalContact{c.b + -a_c, c.a + -b_c, neg(c)});
+  });
+}
+
+enum OrderMode : int { ORDER_DEMO = 0, ORDER_CANONICAL = 1 };
+
+struct StepStats {
+  uint64_t n_constraints = 0;
+  uint64_t n_terrain_constraints = 0;
+  uint64_t n_pair_candidates = 0;  // broadphase hits with j < i
+  uint64_t n_refits = 0;
+  double t_integrate = 0, t_collide = 0, t_solve = 0;  // seconds
+};
+
+struct World {
+  RigidBodyVec bodies;
+  std::vector<size_t> bvh_ids;
+  BVH<size_t> bvh;
+  Mesh terrain;
+  int order_mode = ORDER_DEMO;
+  float fat_margin = 0.25f;  // world.rs:181,237
+  ContactConstraintParams params;
+  Solver solver;  // last step's solver (kept for inspection)
+  StepStats stats;
+
+  // world.rs:178-184
+  bool add_body(const Component& col, float mass, float rest, float fric, V3 world_force, size_t* id_out) {
+    size_t id;
+    if (!bodies.add_body(col, mass, rest, fric, world_force, &id)) return false;
+    AABB b = bounds(bodies.collider[id]);
+    size_t bvh_id = bvh.insert(b + fat_margin, id);
+    bvh_ids.push_back(bvh_id);
+    if (id_out) *id_out = id;
+    return true;
+  }
+
+  // world.rs:227-294 up to (not including) solver.solve
+  void build_constraints(float dt) {
+    using clk = std::chrono::steady_clock;
+    solver = Solver();
+    stats = StepStats();
+    auto t0 = clk::now();
+    bodies.complete_motion();
+    bodies.integrate(dt);
+    auto t1 = clk::now();
+    std::vector<size_t> hits;
+    const size_t n = bodies.len();
+    for (size_t i = 0; i < n; ++i) {
+      const Moving<Component> collider = bodies.collider[i];
+      AABB b = bounds(collider);
+      if (!aabb_contains(bvh[bvh_ids[i]], b)) {
+        bvh.remove(bvh_ids[i]);
+        bvh_ids[i] = bvh.insert(b + fat_margin, i);
+        stats.n_refits++;
+      }
+      local_contacts(collider, terrain, [&](const LocalContact& lc) {
+        solver.add_constraint(ContactConstraint::make(bodies, dynamic_ref(i), static_ref(terrain.center(), 0.0f),
+                                                      manifold_from(lc), dt, params));
+        stats.n_terrain_constraints++;
+      });
+      if (i == 0) continue;
+      auto on_hit = [&](size_t j) {
+        ContactPruner pruner;
+        local_contacts(collider, bodies.collider[j], [&](const LocalContact& lc) { pruner.push(lc); });
+        Manifold manifold = manifold_from(pruner);
+        if (manifold.len() == 0) return;
+        solver.add_constraint(ContactConstraint::make(bodies, dynamic_ref(i), dynamic_ref(j), manifold, dt, params));
+      };
+      if (order_mode == ORDER_DEMO) {
+        bvh.query(b, [&](size_t j) {
+          if (j >= i) return;
+          stats.n_pair_candidates++;
+          on_hit(j);
+        });
+      } else {
+        hits.clear();
+        bvh.query(b, [&](size_t j) { if (j < i) hits.push_back(j); });
+        std::sort(hits.begin(), hits.end());
+        stats.n_pair_candidates += hits.size();
+        for (size_t j : hits) on_hit(j);
+      }
+    }
+    auto t2 = clk::now();
+    stats.n_constraints = solver.len();
+    stats.t_integrate = std::chrono::duration<double>(t1 - t0).count();
+    stats.t_collide = std::chrono::duration<double>(t2 - t1).count();
+  }
+
+  void step(float dt, size_t iters) {
+    using clk = std::chrono::steady_clock;
+    build_constraints(dt);
+    auto t2 = clk::now();
+    solver.solve(bodies, iters);  // world.rs:293 (the demo passes 20)
+    auto t3 = clk::now();
+    stats.t_solve = std::chrono::duration<double>(t3 - t2).count();
+  }
+
+  // Depth of the order-preserving dependency DAG of the current constraint list
+  // (level(c) = 1 + max level of the previous constraint touching either body).
+  // Analysis only; not a reference function.
+  uint32_t constraint_depth() const {
+    std::vector<uint32_t> last(bodies.len(), 0);
+    uint32_t depth = 0;
+    for (const ContactConstraint& c : solver.constraints) {
+      uint32_t la = c.obj_a.is_static ? 0 : last[c.obj_a.index];
+      uint32_t lb = c.obj_b.is_static ? 0 : last[c.obj_b.index];
+      uint32_t l = 1 + std::max(la, lb);
+      if (!c.obj_a.is_static) last[c.obj_a.index] = l;
+      if (!c.obj_b.is_static) last[c.obj_b.index] = l;
+      depth = std::max(depth, l);
+    }
+    return depth;
+  }
+};
+
+}  // namespace mgfo

@@ -1,0 +1,363 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/libmgf_oracle.so (the CPU restatement of mgf's hot path).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  Nothing under mgf_amd/ imports it; the product path fails loudly when the
+HIP extension is missing instead of falling back to this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmgf_oracle.so")
+
+
+def build(force=False):
+    """Compile the oracle with g++ (no GPU needed)."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".hpp", ".cpp"))]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libmgf_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+    def tup(self):
+        return (self.x, self.y, self.z)
+
+
+class Quat(C.Structure):
+    _fields_ = [("s", C.c_float), ("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class Aabb(C.Structure):
+    _fields_ = [("c", Vec3), ("r", Vec3)]
+
+
+class Contact(C.Structure):
+    _fields_ = [("a", Vec3), ("b", Vec3), ("n", Vec3), ("t", C.c_float)]
+
+
+class LocalContact(C.Structure):
+    _fields_ = [("local_a", Vec3), ("local_b", Vec3), ("glob", Contact)]
+
+
+class Shape(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("v", C.c_float * 12)]
+
+
+class Component(C.Structure):
+    _fields_ = [("tag", C.c_int32), ("p", Vec3), ("d", Vec3), ("r", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_constraints", C.c_uint64), ("n_terrain_constraints", C.c_uint64),
+                ("n_pair_candidates", C.c_uint64), ("n_refits", C.c_uint64),
+                ("t_integrate", C.c_double), ("t_collide", C.c_double), ("t_solve", C.c_double)]
+
+
+class Constraint(C.Structure):
+    _fields_ = [("a", C.c_int32), ("b", C.c_int32), ("n_contacts", C.c_int32),
+                ("normal", Vec3), ("t0", Vec3), ("t1", Vec3), ("ra", Vec3), ("rb", Vec3),
+                ("bias", C.c_float), ("normal_mass", C.c_float), ("tangent_mass0", C.c_float),
+                ("tangent_mass1", C.c_float), ("normal_impulse", C.c_float), ("friction", C.c_float)]
+
+
+# numpy views of the PODs (same memory layout)
+COMPONENT_DTYPE = np.dtype([("tag", "<i4"), ("p", "<f4", 3), ("d", "<f4", 3), ("r", "<f4")])
+CONSTRAINT_DTYPE = np.dtype([("a", "<i4"), ("b", "<i4"), ("n_contacts", "<i4"),
+                             ("normal", "<f4", 3), ("t0", "<f4", 3), ("t1", "<f4", 3),
+                             ("ra", "<f4", 3), ("rb", "<f4", 3),
+                             ("bias", "<f4"), ("normal_mass", "<f4"), ("tangent_mass0", "<f4"),
+                             ("tangent_mass1", "<f4"), ("normal_impulse", "<f4"), ("friction", "<f4")])
+assert COMPONENT_DTYPE.itemsize == C.sizeof(Component)
+assert CONSTRAINT_DTYPE.itemsize == C.sizeof(Constraint)
+
+SPHERE, CAPSULE, TRIANGLE, RECTANGLE, PLANE = 0, 1, 2, 3, 4
+ORDER_DEMO, ORDER_CANONICAL = 0, 1
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        P = C.POINTER
+        L.mgfo_contacts.argtypes = [P(Shape), P(Vec3), P(Shape), P(Vec3), P(Contact), C.c_int]
+        L.mgfo_contacts.restype = C.c_int
+        L.mgfo_local_contacts_pair.argtypes = [P(Component), P(Vec3), P(Component), P(Vec3), P(LocalContact), C.c_int]
+        L.mgfo_local_contacts_pair.restype = C.c_int
+        for f in (L.mgfo_ray_capsule, L.mgfo_ray_sphere):
+            f.argtypes = [P(Vec3), P(Vec3), P(Shape), P(Vec3), P(C.c_float)]
+            f.restype = C.c_int
+        L.mgfo_tri_closest_point.argtypes = [P(Shape), P(Vec3), P(Vec3)]
+        L.mgfo_compute_basis.argtypes = [P(Vec3), P(Vec3)]
+        L.mgfo_quat_from_arc.argtypes = [P(Vec3), P(Vec3), P(Quat)]
+        L.mgfo_rotate_vector.argtypes = [P(Quat), P(Vec3), P(Vec3)]
+        L.mgfo_tensor.argtypes = [P(Component), C.c_float, P(C.c_float)]
+        L.mgfo_component_bounds.argtypes = [P(Component), P(Vec3), P(Aabb)]
+        L.mgfo_aabb_combine.argtypes = [P(Aabb), P(Aabb), P(Aabb)]
+        L.mgfo_aabb_overlaps.argtypes = [P(Aabb), P(Aabb)]
+        L.mgfo_aabb_overlaps.restype = C.c_int
+        L.mgfo_aabb_contains.argtypes = [P(Aabb), P(Aabb)]
+        L.mgfo_aabb_contains.restype = C.c_int
+        L.mgfo_pool_new.restype = C.c_void_p
+        L.mgfo_pool_free.argtypes = [C.c_void_p]
+        L.mgfo_pool_push.argtypes = [C.c_void_p, C.c_uint64]
+        L.mgfo_pool_push.restype = C.c_int64
+        L.mgfo_pool_remove.argtypes = [C.c_void_p, C.c_uint64, P(C.c_uint64)]
+        L.mgfo_pool_remove.restype = C.c_int
+        L.mgfo_pool_get.argtypes = [C.c_void_p, C.c_uint64, P(C.c_uint64)]
+        L.mgfo_pool_get.restype = C.c_int
+        L.mgfo_pool_iter.argtypes = [C.c_void_p, P(C.c_uint64), P(C.c_uint64), C.c_int64]
+        L.mgfo_pool_iter.restype = C.c_int64
+        L.mgfo_bvh_new.restype = C.c_void_p
+        L.mgfo_bvh_free.argtypes = [C.c_void_p]
+        L.mgfo_bvh_insert.argtypes = [C.c_void_p, P(Aabb), C.c_uint64]
+        L.mgfo_bvh_insert.restype = C.c_int64
+        L.mgfo_bvh_remove.argtypes = [C.c_void_p, C.c_uint64]
+        L.mgfo_bvh_remove.restype = C.c_int
+        L.mgfo_bvh_root.argtypes = [C.c_void_p]
+        L.mgfo_bvh_root.restype = C.c_int64
+        L.mgfo_bvh_bounds.argtypes = [C.c_void_p, C.c_uint64, P(Aabb)]
+        L.mgfo_bvh_bounds.restype = C.c_int
+        L.mgfo_bvh_get_leaf.argtypes = [C.c_void_p, C.c_uint64, P(C.c_uint64)]
+        L.mgfo_bvh_get_leaf.restype = C.c_int
+        L.mgfo_bvh_query.argtypes = [C.c_void_p, P(Aabb), P(C.c_uint64), C.c_int64]
+        L.mgfo_bvh_query.restype = C.c_int64
+        L.mgfo_bvh_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.mgfo_bvh_dump.restype = C.c_int64
+        L.mgfo_world_new.argtypes = [C.c_int]
+        L.mgfo_world_new.restype = C.c_void_p
+        L.mgfo_world_free.argtypes = [C.c_void_p]
+        L.mgfo_world_set_params.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L.mgfo_world_set_terrain.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, P(Vec3)]
+        L.mgfo_world_add_bodies.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mgfo_world_add_bodies.restype = C.c_int64
+        L.mgfo_world_len.argtypes = [C.c_void_p]
+        L.mgfo_world_len.restype = C.c_int64
+        L.mgfo_world_step.argtypes = [C.c_void_p, C.c_float, C.c_int64, P(Stats)]
+        L.mgfo_world_build_constraints.argtypes = [C.c_void_p, C.c_float, P(Stats)]
+        L.mgfo_world_solve.argtypes = [C.c_void_p, C.c_int64]
+        L.mgfo_world_constraint_depth.argtypes = [C.c_void_p]
+        L.mgfo_world_constraint_depth.restype = C.c_uint32
+        L.mgfo_world_get_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.mgfo_world_get_constraints.restype = C.c_int64
+        L.mgfo_world_get_state.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        L.mgfo_world_set_state.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        L.mgfo_world_get_colliders.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mgfo_world_get_inv_moment.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mgfo_world_set_velocity.argtypes = [C.c_void_p, C.c_int64, P(Vec3), P(Vec3)]
+        L.mgfo_world_terrain_contacts.argtypes = [C.c_void_p, C.c_int64, P(LocalContact), C.c_int64]
+        L.mgfo_world_terrain_contacts.restype = C.c_int64
+        L.mgfo_world_terrain_bvh.argtypes = [C.c_void_p]
+        L.mgfo_world_terrain_bvh.restype = C.c_void_p
+        L.mgfo_world_bvh.argtypes = [C.c_void_p]
+        L.mgfo_world_bvh.restype = C.c_void_p
+        _lib = L
+    return _lib
+
+
+def vec3(v):
+    return Vec3(float(v[0]), float(v[1]), float(v[2]))
+
+
+def shape(kind, *vals):
+    s = Shape()
+    s.kind = kind
+    flat = []
+    for v in vals:
+        if isinstance(v, (int, float)):
+            flat.append(float(v))
+        else:
+            flat.extend(float(x) for x in v)
+    for i, x in enumerate(flat):
+        s.v[i] = x
+    return s
+
+
+def shape_from_dict(d):
+    k = d["kind"]
+    if k == "sphere":
+        return shape(SPHERE, d["c"], d["r"])
+    if k == "capsule":
+        return shape(CAPSULE, d["a"], d["d"], d["r"])
+    if k == "triangle":
+        return shape(TRIANGLE, d["a"], d["b"], d["c"])
+    if k == "rectangle":
+        return shape(RECTANGLE, d["c"], d["u0"], d["u1"], d["e"][0], d["e"][1])
+    if k == "plane":
+        return shape(PLANE, d["n"], d["d"])
+    raise ValueError(k)
+
+
+def contacts(a, vel_a, b, vel_b, cap=8):
+    """Contacts::contacts of the reference for (a [moving at vel_a]) vs (b [moving at vel_b])."""
+    out = (Contact * cap)()
+    va = C.byref(vec3(vel_a)) if vel_a is not None else None
+    vb = C.byref(vec3(vel_b)) if vel_b is not None else None
+    n = lib().mgfo_contacts(C.byref(a), va, C.byref(b), vb, out, cap)
+    if n < 0:
+        raise ValueError("unsupported shape pair")
+    return [dict(a=out[i].a.tup(), b=out[i].b.tup(), n=out[i].n.tup(), t=out[i].t) for i in range(min(n, cap))]
+
+
+def component(tag, p, d, r):
+    return Component(tag, vec3(p), vec3(d), float(r))
+
+
+def local_contacts_pair(ca, da, cb, db, cap=8):
+    out = (LocalContact * cap)()
+    n = lib().mgfo_local_contacts_pair(C.byref(ca), C.byref(vec3(da)), C.byref(cb), C.byref(vec3(db)), out, cap)
+    return [dict(local_a=out[i].local_a.tup(), local_b=out[i].local_b.tup(), a=out[i].glob.a.tup(),
+                 b=out[i].glob.b.tup(), n=out[i].glob.n.tup(), t=out[i].glob.t) for i in range(min(n, cap))]
+
+
+class Bvh:
+    """BVH<AABB, usize> of the reference (bvh.rs) — oracle copy."""
+
+    def __init__(self, handle=None):
+        self._own = handle is None
+        self.h = lib().mgfo_bvh_new() if handle is None else handle
+
+    def __del__(self):
+        if getattr(self, "_own", False) and self.h:
+            lib().mgfo_bvh_free(self.h)
+            self.h = None
+
+    @staticmethod
+    def _aabb(c, r):
+        return Aabb(vec3(c), vec3(r))
+
+    def insert(self, c, r, val):
+        return lib().mgfo_bvh_insert(self.h, C.byref(self._aabb(c, r)), val)
+
+    def remove(self, node):
+        return lib().mgfo_bvh_remove(self.h, node)
+
+    def root(self):
+        return lib().mgfo_bvh_root(self.h)
+
+    def query(self, c, r, cap=4096):
+        out = (C.c_uint64 * cap)()
+        n = lib().mgfo_bvh_query(self.h, C.byref(self._aabb(c, r)), out, cap)
+        return [out[i] for i in range(min(n, cap))]
+
+    def dump(self):
+        n = lib().mgfo_bvh_dump(self.h, None, None, 0)
+        nodes = np.zeros((max(n, 1), 6), dtype=np.int64)
+        bounds = np.zeros((max(n, 1), 6), dtype=np.float32)
+        lib().mgfo_bvh_dump(self.h, nodes.ctypes.data, bounds.ctypes.data, n)
+        return nodes[:n], bounds[:n]
+
+
+class World:
+    """World::step harness of mgf_demo/world.rs — oracle copy."""
+
+    def __init__(self, order=ORDER_CANONICAL):
+        self.h = lib().mgfo_world_new(order)
+        self.stats = Stats()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().mgfo_world_free(self.h)
+            self.h = None
+
+    def set_terrain(self, verts, faces, pos):
+        verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+        faces = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
+        lib().mgfo_world_set_terrain(self.h, verts.ctypes.data, len(verts), faces.ctypes.data, len(faces),
+                                     C.byref(vec3(pos)))
+
+    def add_bodies(self, comps, mass, rest, fric, force):
+        comps = np.ascontiguousarray(comps, dtype=COMPONENT_DTYPE)
+        n = len(comps)
+        mass = np.ascontiguousarray(np.broadcast_to(np.asarray(mass, np.float32), (n,)))
+        rest = np.ascontiguousarray(np.broadcast_to(np.asarray(rest, np.float32), (n,)))
+        fric = np.ascontiguousarray(np.broadcast_to(np.asarray(fric, np.float32), (n,)))
+        force = np.ascontiguousarray(np.broadcast_to(np.asarray(force, np.float32), (n, 3)))
+        r = lib().mgfo_world_add_bodies(self.h, comps.ctypes.data, n, mass.ctypes.data, rest.ctypes.data,
+                                        fric.ctypes.data, force.ctypes.data)
+        if r < 0:
+            raise ValueError("singular inertia tensor (reference panics, physics.rs:212)")
+        return r
+
+    def __len__(self):
+        return lib().mgfo_world_len(self.h)
+
+    def step(self, dt, iters):
+        lib().mgfo_world_step(self.h, dt, iters, C.byref(self.stats))
+        return self.stats
+
+    def build_constraints(self, dt):
+        lib().mgfo_world_build_constraints(self.h, dt, C.byref(self.stats))
+        return self.stats
+
+    def solve(self, iters):
+        lib().mgfo_world_solve(self.h, iters)
+
+    def constraint_depth(self):
+        return lib().mgfo_world_constraint_depth(self.h)
+
+    def constraints(self):
+        n = lib().mgfo_world_get_constraints(self.h, None, 0)
+        out = np.zeros(max(n, 1), dtype=CONSTRAINT_DTYPE)
+        lib().mgfo_world_get_constraints(self.h, out.ctypes.data, n)
+        return out[:n]
+
+    def state(self):
+        n = len(self)
+        x = np.zeros((n, 3), np.float32)
+        q = np.zeros((n, 4), np.float32)
+        v = np.zeros((n, 3), np.float32)
+        w = np.zeros((n, 3), np.float32)
+        d = np.zeros((n, 3), np.float32)
+        lib().mgfo_world_get_state(self.h, x.ctypes.data, q.ctypes.data, v.ctypes.data, w.ctypes.data, d.ctypes.data)
+        return dict(x=x, q=q, v=v, omega=w, delta=d)
+
+    def set_state(self, x=None, q=None, v=None, omega=None, delta=None):
+        def p(a, k):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1, k)
+            keep.append(a)
+            return a.ctypes.data
+        keep = []
+        lib().mgfo_world_set_state(self.h, p(x, 3), p(q, 4), p(v, 3), p(omega, 3), p(delta, 3))
+
+    def colliders(self):
+        n = len(self)
+        comps = np.zeros(n, dtype=COMPONENT_DTYPE)
+        d = np.zeros((n, 3), np.float32)
+        lib().mgfo_world_get_colliders(self.h, comps.ctypes.data, d.ctypes.data)
+        return comps, d
+
+    def inv_moment(self):
+        n = len(self)
+        b = np.zeros((n, 9), np.float32)
+        w = np.zeros((n, 9), np.float32)
+        lib().mgfo_world_get_inv_moment(self.h, b.ctypes.data, w.ctypes.data)
+        return b, w
+
+    def set_velocity(self, i, lin, ang):
+        lib().mgfo_world_set_velocity(self.h, i, C.byref(vec3(lin)), C.byref(vec3(ang)))
+
+    def terrain_contacts(self, i, cap=16):
+        out = (LocalContact * cap)()
+        n = lib().mgfo_world_terrain_contacts(self.h, i, out, cap)
+        return [dict(local_a=out[k].local_a.tup(), local_b=out[k].local_b.tup(), a=out[k].glob.a.tup(),
+                     b=out[k].glob.b.tup(), n=out[k].glob.n.tup(), t=out[k].glob.t) for k in range(min(n, cap))]
+
+    def terrain_bvh(self):
+        return Bvh(lib().mgfo_world_terrain_bvh(self.h))
+
+    def world_bvh(self):
+        return Bvh(lib().mgfo_world_bvh(self.h))
