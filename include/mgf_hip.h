@@ -1,0 +1,215 @@
+/*
+ * mgf_hip.h — C-ABI of the MI355X-native rigid-body step behind mgf's API.
+ *
+ * The reference (maplant/mgf) is a pure-Rust crate with no FFI; its boundary for the
+ * per-tick hot path is the public Rust API re-exported at src/lib.rs:117-150 and the
+ * tick assembled in mgf_demo/world.rs:227-294.  Every entry point below cites the
+ * reference item it replaces.  A Rust `extern "C"` shim binds these
+ * one-to-one and turns non-OK statuses back into the panics the reference raises.
+ *
+ * Conventions
+ *  - plain C, no torch types; opaque handles; (ptr,len) slices borrowed for the call;
+ *    outputs into caller buffers with capacity + out-count (MGF_ERR_CAPACITY on overflow,
+ *    out-count still reports the number required);
+ *  - every call is synchronous: the context's HIP stream is drained before return, so
+ *    Rust `&mut self` semantics hold; one handle = one thread at a time (Send, not Sync);
+ *  - one mgf_ctx per GPU; all arithmetic is IEEE f32 with no FMA contraction, in the
+ *    reference's operation order;
+ *  - there is NO CPU fallback: without a HIP device every compute entry point returns
+ *    MGF_ERR_HIP.
+ */
+#ifndef MGF_HIP_H
+#define MGF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGF_API __attribute__((visibility("default")))
+
+/* Rust panics on this path, mapped to status codes (SURVEY.md §8b "Errors"). */
+typedef enum mgf_status {
+  MGF_OK = 0,
+  MGF_ERR_EMPTY = 1,        /* BVH::root on empty tree            bvh.rs:265          */
+  MGF_ERR_NOT_OCCUPIED = 2, /* Pool index not occupied            pool.rs:111,160,170 */
+  MGF_ERR_NOT_LEAF = 3,     /* BVH::get_leaf on a parent          bvh.rs:274          */
+  MGF_ERR_STATIC_REF = 4,   /* RigidBodyRef::into() on Static     physics.rs:174      */
+  MGF_ERR_SINGULAR = 5,     /* inertia tensor .invert().unwrap()  physics.rs:212      */
+  MGF_ERR_INVALID = 6,      /* bad argument / radius assert       geom.rs:300,328     */
+  MGF_ERR_CAPACITY = 7,     /* caller buffer too small                                 */
+  MGF_ERR_HIP = 8,          /* HIP runtime failure or no device                        */
+  MGF_ERR_OOM = 9
+} mgf_status;
+
+/* ---- POD mirrors of the reference's Copy types --------------------------------- */
+typedef struct mgf_vec3 { float x, y, z; } mgf_vec3;               /* cgmath Vector3/Point3<f32> */
+typedef struct mgf_quat { float s, x, y, z; } mgf_quat;            /* cgmath Quaternion<f32> {s, v} */
+typedef struct mgf_aabb { mgf_vec3 c, r; } mgf_aabb;               /* geom.rs:257-260 centre + half extents */
+
+/* Component (compound.rs:33): tag 0 = Sphere{c = p, r}; tag 1 = Capsule{a = p, d, r}. */
+enum { MGF_SPHERE = 0, MGF_CAPSULE = 1, MGF_TRIANGLE = 2, MGF_RECTANGLE = 3, MGF_PLANE = 4 };
+typedef struct mgf_component { int32_t tag; mgf_vec3 p; mgf_vec3 d; float r; } mgf_component;
+/* Moving<Component> (geom.rs:357): shape + per-step displacement. */
+typedef struct mgf_moving_component { mgf_component shape; mgf_vec3 delta; } mgf_moving_component;
+
+/* Generic shape operand for the single-shot narrowphase entry point:
+ *   MGF_SPHERE   v = {c.xyz, r}            MGF_CAPSULE  v = {a.xyz, d.xyz, r}
+ *   MGF_TRIANGLE v = {a.xyz, b.xyz, c.xyz} MGF_PLANE    v = {n.xyz, d}
+ * (MGF_RECTANGLE is not on the hot path: MGF_ERR_INVALID.) */
+typedef struct mgf_shape { int32_t kind; float v[12]; } mgf_shape;
+
+typedef struct mgf_contact { mgf_vec3 a, b, n; float t; } mgf_contact;                 /* collision.rs:431-442 */
+typedef struct mgf_local_contact { mgf_vec3 local_a, local_b; mgf_contact global; } mgf_local_contact; /* :1410-1419 */
+
+/* RigidBodyRef (physics.rs:158-162): tag 0 Dynamic(index), tag 1 Static{center, friction}. */
+typedef struct mgf_body_ref { int32_t tag; uint32_t index; mgf_vec3 center; float friction; } mgf_body_ref;
+typedef struct mgf_velocity { mgf_vec3 linear, angular; } mgf_velocity;                /* physics.rs:133-137 */
+typedef struct mgf_rigid_body_info {                                                   /* physics.rs:124-130 */
+  mgf_vec3 x; float restitution, friction, inv_mass; float inv_moment[9]; /* column-major */
+} mgf_rigid_body_info;
+
+/* Compile-time trait constants of the reference, as run-time parameters. */
+typedef struct mgf_params {
+  float baumgarte;               /* solver.rs:278   0.2  */
+  float penetration_slop;        /* solver.rs:277   0.05 */
+  float persistent_threshold_sq; /* manifold.rs:38  0.5  */
+  float collision_epsilon;       /* geom.rs:27      1e-6 (informational: baked into the kernels) */
+  float fat_margin;              /* world.rs:181    0.25 */
+} mgf_params;
+
+/* One contact constraint as the solver holds it (solver.rs:82-93, 256-262), flattened for
+ * the single-contact manifolds this path produces.  Read-back/debug and bulk-insert format. */
+typedef struct mgf_constraint {
+  int32_t a, b;                 /* body indices; b = -1 for RigidBodyRef::Static */
+  int32_t n_contacts;
+  mgf_vec3 normal, t0, t1, ra, rb;
+  float bias, normal_mass, tangent_mass0, tangent_mass1, normal_impulse, friction;
+} mgf_constraint;
+
+typedef struct mgf_step_stats {
+  uint64_t n_bodies;
+  uint64_t n_constraints;          /* ContactConstraints handed to the Solver this tick            */
+  uint64_t n_terrain_constraints;  /* of which body-vs-Mesh (one per terrain contact, world.rs:243) */
+  uint64_t n_pair_candidates;      /* broadphase hits (j < i, tight_i overlaps fat_j)               */
+  uint64_t n_terrain_candidates;   /* mesh-BVH face hits                                            */
+  uint64_t n_refits;               /* bodies whose swept AABB left their fat AABB (world.rs:235)    */
+  uint32_t n_levels;               /* depth of the order-preserving dependency DAG                  */
+  uint32_t iters;
+  float ms_integrate, ms_broadphase, ms_narrowphase, ms_setup, ms_solve, ms_total; /* HIP-event times */
+  uint64_t solver_kernel_launches; /* number of solver kernel launches this tick     */
+  float ms_solver_kernels;         /* sum of their HIP-event durations (0 if not timed) */
+} mgf_step_stats;
+
+typedef struct mgf_ctx mgf_ctx;
+typedef struct mgf_mesh mgf_mesh;
+typedef struct mgf_bvh mgf_bvh;
+typedef struct mgf_world mgf_world;
+
+/* ---- context ---------------------------------------------------------------------- */
+MGF_API mgf_status mgf_ctx_create(int device, mgf_ctx** out);
+MGF_API void mgf_ctx_destroy(mgf_ctx* ctx);
+MGF_API const char* mgf_last_error(void);        /* thread-local message for the last non-OK status */
+MGF_API mgf_params mgf_default_params(void);     /* DefaultContactConstraintParams / DefaultPruningParams */
+MGF_API const char* mgf_version(void);
+
+/* ---- single-shot narrowphase (unit parity; runs the same device functions as the step) ---
+ * Contacts::contacts (collision.rs:471-482) for `a` [moving by vel_a] vs `b` [moving by vel_b];
+ * NULL velocity = static operand.  Dispatch follows the reference's trait resolution
+ * (collision.rs:484-494, 521-1401).  *count = number of contacts emitted. */
+MGF_API mgf_status mgf_contacts(mgf_ctx* ctx, const mgf_shape* a, const mgf_vec3* vel_a, const mgf_shape* b,
+                                const mgf_vec3* vel_b, mgf_contact* out, int32_t cap, int32_t* count);
+/* Batched form: n independent (a, vel_a, b, vel_b) problems; has_vel bit0 = a moving, bit1 = b moving.
+ * out holds 2 slots per problem (no pair on this path emits more), counts[n]. */
+MGF_API mgf_status mgf_contacts_batch(mgf_ctx* ctx, int64_t n, const mgf_shape* a, const mgf_vec3* vel_a,
+                                      const mgf_shape* b, const mgf_vec3* vel_b, const uint8_t* has_vel,
+                                      mgf_contact* out, int32_t* counts);
+/* LocalContacts<Moving<Component>> for Moving<Component> (compound.rs:192-207). */
+MGF_API mgf_status mgf_local_contacts_pair(mgf_ctx* ctx, const mgf_moving_component* a, const mgf_moving_component* b,
+                                           mgf_local_contact* out, int32_t cap, int32_t* count);
+/* Intersects<Capsule>/<Sphere> for Ray (collision.rs:249-359); *hit = 0/1. */
+MGF_API mgf_status mgf_ray_capsule(mgf_ctx* ctx, const mgf_vec3* p, const mgf_vec3* d, const mgf_shape* capsule,
+                                   mgf_vec3* ip, float* t, int32_t* hit);
+/* Inertia::tensor (physics.rs:26-93), column-major 3x3. */
+MGF_API mgf_status mgf_inertia_tensor(const mgf_component* c, float mass, float out9[9]);
+
+/* ---- Mesh (mesh.rs:32-73, geom.rs:459): static triangle soup + BVH<AABB,usize> over faces ---- */
+MGF_API mgf_status mgf_mesh_new(mgf_ctx* ctx, mgf_mesh** out);                        /* Mesh::new         mesh.rs:40 */
+MGF_API void mgf_mesh_free(mgf_mesh* m);
+MGF_API mgf_status mgf_mesh_push_vert(mgf_mesh* m, mgf_vec3 p, uint64_t* id);         /* Mesh::push_vert   mesh.rs:58 */
+MGF_API mgf_status mgf_mesh_push_face(mgf_mesh* m, uint64_t a, uint64_t b, uint64_t c, uint64_t* id); /* mesh.rs:64 */
+MGF_API mgf_status mgf_mesh_set_pos(mgf_mesh* m, mgf_vec3 p);                         /* Shape::set_pos    geom.rs:459 */
+MGF_API mgf_status mgf_mesh_build(mgf_mesh* m, const mgf_vec3* verts, int64_t nverts, const uint32_t* faces,
+                                  int64_t nfaces);                                    /* bulk push_vert/push_face */
+/* LocalContacts<Mesh> for Moving<Component> (collision.rs:1490-1506 over mesh.rs:115-139),
+ * contacts in mesh-BVH DFS order. */
+MGF_API mgf_status mgf_local_contacts_mesh(mgf_ctx* ctx, const mgf_moving_component* body, const mgf_mesh* mesh,
+                                           mgf_local_contact* out, int32_t cap, int32_t* count);
+
+/* ---- BVH<AABB, usize> (bvh.rs:30-310): reference-faithful dynamic tree (insert/remove/balance
+ * are inherently sequential and run on the host); queries traverse the uploaded tree on the GPU
+ * with the reference's stack discipline, so hit order equals the reference's DFS order. ---- */
+MGF_API mgf_status mgf_bvh_new(mgf_ctx* ctx, mgf_bvh** out);                          /* BVH::new            bvh.rs:88  */
+MGF_API mgf_status mgf_bvh_with_capacity(mgf_ctx* ctx, uint64_t cap, mgf_bvh** out);  /* BVH::with_capacity  bvh.rs:96  */
+MGF_API void mgf_bvh_free(mgf_bvh* b);
+MGF_API int32_t mgf_bvh_empty(const mgf_bvh* b);                                      /* BVH::empty          bvh.rs:104 */
+MGF_API mgf_status mgf_bvh_clear(mgf_bvh* b);                                         /* BVH::clear          bvh.rs:109 */
+MGF_API mgf_status mgf_bvh_insert(mgf_bvh* b, const mgf_aabb* key, uint64_t val, uint64_t* id); /* bvh.rs:125 */
+MGF_API mgf_status mgf_bvh_remove(mgf_bvh* b, uint64_t id);                           /* BVH::remove         bvh.rs:220 */
+MGF_API mgf_status mgf_bvh_root(const mgf_bvh* b, uint64_t* id);                      /* BVH::root           bvh.rs:263 */
+MGF_API mgf_status mgf_bvh_get_leaf(const mgf_bvh* b, uint64_t id, uint64_t* val);    /* BVH::get_leaf       bvh.rs:270 */
+MGF_API mgf_status mgf_bvh_bounds(const mgf_bvh* b, uint64_t id, mgf_aabb* out);      /* Index<usize>        bvh.rs:483 */
+typedef void (*mgf_bvh_hit_fn)(const uint64_t* val, void* user);
+MGF_API mgf_status mgf_bvh_query(mgf_bvh* b, const mgf_aabb* arg, mgf_bvh_hit_fn cb, void* user); /* bvh.rs:283 */
+/* Bulk query: n AABBs; hits of query q are out_vals[out_offsets[q] .. out_offsets[q+1]) in DFS order. */
+MGF_API mgf_status mgf_bvh_query_many(mgf_bvh* b, const mgf_aabb* args, int64_t n, uint64_t* out_offsets /* n+1 */,
+                                      uint64_t* out_vals, int64_t cap, int64_t* total);
+
+/* ---- World: RigidBodyVec + Solver + broadphase + terrain, resident in HBM for the whole tick.
+ * Replaces mgf_demo/world.rs: World::add_body :178-184 and World::step :227-294, built on
+ * RigidBodyVec (physics.rs:141-315), ContactPruner/Manifold (manifold.rs), ContactConstraint and
+ * Solver (solver.rs).  Constraint insertion order: body i ascending; for each i the terrain
+ * contacts in mesh-BVH DFS order, then partners j < i ascending (DESIGN.md "constraint order"). ---- */
+MGF_API mgf_status mgf_world_new(mgf_ctx* ctx, const mgf_params* params, mgf_world** out);
+MGF_API void mgf_world_free(mgf_world* w);
+MGF_API mgf_status mgf_world_set_terrain(mgf_world* w, const mgf_mesh* mesh);         /* copies; World.terrain */
+/* World::add_body / RigidBodyVec::add_body (physics.rs:200-218), bulk; MGF_ERR_SINGULAR as the unwrap. */
+MGF_API mgf_status mgf_world_add_bodies(mgf_world* w, const mgf_component* comps, int64_t n, const float* mass,
+                                        const float* restitution, const float* friction, const mgf_vec3* world_force,
+                                        uint64_t* first_id);
+MGF_API int64_t mgf_world_len(const mgf_world* w);
+/* One tick (world.rs:227-294): complete_motion, integrate, broadphase, narrowphase,
+ * ContactConstraint::new for every contact, Solver::solve(iters). */
+MGF_API mgf_status mgf_world_step(mgf_world* w, float dt, int32_t iters, mgf_step_stats* stats);
+/* Same tick split at the solver boundary (for parity tests of the constraint list). */
+MGF_API mgf_status mgf_world_build_constraints(mgf_world* w, float dt, mgf_step_stats* stats);
+MGF_API mgf_status mgf_world_solve(mgf_world* w, int32_t iters, mgf_step_stats* stats);   /* Solver::solve solver.rs:72 */
+/* RigidBodyVec::{complete_motion, integrate} alone (physics.rs:262, 222). */
+MGF_API mgf_status mgf_world_complete_motion(mgf_world* w);
+MGF_API mgf_status mgf_world_integrate(mgf_world* w, float dt);
+/* ConstrainedSet::get / set (physics.rs:272-315). */
+MGF_API mgf_status mgf_world_get(mgf_world* w, const mgf_body_ref* r, mgf_velocity* vel, mgf_rigid_body_info* info);
+MGF_API mgf_status mgf_world_set(mgf_world* w, const mgf_body_ref* r, const mgf_velocity* vel);
+/* Bulk state access; any pointer may be NULL.  delta = collider[i].1 (Moving displacement). */
+MGF_API mgf_status mgf_world_read_state(mgf_world* w, mgf_vec3* x, mgf_quat* q, mgf_vec3* v, mgf_vec3* omega,
+                                        mgf_vec3* delta, int64_t cap);
+MGF_API mgf_status mgf_world_write_state(mgf_world* w, const mgf_vec3* x, const mgf_quat* q, const mgf_vec3* v,
+                                         const mgf_vec3* omega, const mgf_vec3* delta, int64_t n);
+MGF_API mgf_status mgf_world_read_colliders(mgf_world* w, mgf_moving_component* out, int64_t cap); /* colliders() :256 */
+/* The Solver's constraint list of the last tick, in insertion order. */
+MGF_API mgf_status mgf_world_read_constraints(mgf_world* w, mgf_constraint* out, int64_t cap, int64_t* count);
+/* Solver::add_constraint in bulk + solve on the resident RigidBodyVec (solver.rs:66-78):
+ * replaces the tick's constraint list with `cons` (insertion order = array order). */
+MGF_API mgf_status mgf_world_set_constraints(mgf_world* w, const mgf_constraint* cons, int64_t n);
+/* Option: 1 = time every solver kernel with HIP events (bench roofline leg); default 0. */
+MGF_API mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_t value);
+/* Raw device pointers of resident state for zero-copy exchange (multi-GPU halo): name in
+ * {"x","q","solver_rec","delta"}; pointer valid until the next add_bodies. */
+MGF_API mgf_status mgf_world_device_ptr(mgf_world* w, const char* name, void** ptr, int64_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGF_HIP_H */

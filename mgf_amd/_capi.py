@@ -1,0 +1,573 @@
+"""ctypes binding of include/mgf_hip.h.  Names follow the reference (mgf) API they replace."""
+import ctypes as C
+import os
+import weakref
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libmgf_hip.so")
+
+
+class MgfError(RuntimeError):
+    """A non-OK mgf_status; `.status` holds the code (the reference panics in these cases)."""
+
+    def __init__(self, status, msg):
+        super().__init__(f"mgf status {status} ({_STATUS_NAMES.get(status, '?')}): {msg}")
+        self.status = status
+
+
+_STATUS_NAMES = {0: "OK", 1: "EMPTY", 2: "NOT_OCCUPIED", 3: "NOT_LEAF", 4: "STATIC_REF", 5: "SINGULAR", 6: "INVALID",
+                 7: "CAPACITY", 8: "HIP", 9: "OOM"}
+OK, ERR_EMPTY, ERR_NOT_OCCUPIED, ERR_NOT_LEAF, ERR_STATIC_REF, ERR_SINGULAR, ERR_INVALID, ERR_CAPACITY, ERR_HIP, ERR_OOM = range(10)
+SPHERE, CAPSULE, TRIANGLE, RECTANGLE, PLANE = 0, 1, 2, 3, 4
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+    def tup(self):
+        return (self.x, self.y, self.z)
+
+
+class Quat(C.Structure):
+    _fields_ = [("s", C.c_float), ("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class Aabb(C.Structure):
+    _fields_ = [("c", Vec3), ("r", Vec3)]
+
+
+class Component(C.Structure):
+    _fields_ = [("tag", C.c_int32), ("p", Vec3), ("d", Vec3), ("r", C.c_float)]
+
+
+class MovingComponent(C.Structure):
+    _fields_ = [("shape", Component), ("delta", Vec3)]
+
+
+class Shape(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("v", C.c_float * 12)]
+
+
+class Contact(C.Structure):
+    _fields_ = [("a", Vec3), ("b", Vec3), ("n", Vec3), ("t", C.c_float)]
+
+
+class LocalContact(C.Structure):
+    _fields_ = [("local_a", Vec3), ("local_b", Vec3), ("glob", Contact)]
+
+
+class BodyRef(C.Structure):
+    _fields_ = [("tag", C.c_int32), ("index", C.c_uint32), ("center", Vec3), ("friction", C.c_float)]
+
+
+class Velocity(C.Structure):
+    _fields_ = [("linear", Vec3), ("angular", Vec3)]
+
+
+class RigidBodyInfo(C.Structure):
+    _fields_ = [("x", Vec3), ("restitution", C.c_float), ("friction", C.c_float), ("inv_mass", C.c_float),
+                ("inv_moment", C.c_float * 9)]
+
+
+class Params(C.Structure):
+    _fields_ = [("baumgarte", C.c_float), ("penetration_slop", C.c_float), ("persistent_threshold_sq", C.c_float),
+                ("collision_epsilon", C.c_float), ("fat_margin", C.c_float)]
+
+
+class StepStats(C.Structure):
+    _fields_ = [("n_bodies", C.c_uint64), ("n_constraints", C.c_uint64), ("n_terrain_constraints", C.c_uint64),
+                ("n_pair_candidates", C.c_uint64), ("n_terrain_candidates", C.c_uint64), ("n_refits", C.c_uint64),
+                ("n_levels", C.c_uint32), ("iters", C.c_uint32),
+                ("ms_integrate", C.c_float), ("ms_broadphase", C.c_float), ("ms_narrowphase", C.c_float),
+                ("ms_setup", C.c_float), ("ms_solve", C.c_float), ("ms_total", C.c_float),
+                ("solver_kernel_launches", C.c_uint64), ("ms_solver_kernels", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+COMPONENT_DTYPE = np.dtype([("tag", "<i4"), ("p", "<f4", 3), ("d", "<f4", 3), ("r", "<f4")])
+MOVING_DTYPE = np.dtype([("tag", "<i4"), ("p", "<f4", 3), ("d", "<f4", 3), ("r", "<f4"), ("delta", "<f4", 3)])
+CONSTRAINT_DTYPE = np.dtype([("a", "<i4"), ("b", "<i4"), ("n_contacts", "<i4"),
+                             ("normal", "<f4", 3), ("t0", "<f4", 3), ("t1", "<f4", 3), ("ra", "<f4", 3), ("rb", "<f4", 3),
+                             ("bias", "<f4"), ("normal_mass", "<f4"), ("tangent_mass0", "<f4"), ("tangent_mass1", "<f4"),
+                             ("normal_impulse", "<f4"), ("friction", "<f4")])
+assert COMPONENT_DTYPE.itemsize == C.sizeof(Component) == 32
+assert MOVING_DTYPE.itemsize == C.sizeof(MovingComponent) == 44
+assert CONSTRAINT_DTYPE.itemsize == 96
+
+# every symbol include/mgf_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "mgf_ctx_create", "mgf_ctx_destroy", "mgf_last_error", "mgf_default_params", "mgf_version",
+    "mgf_contacts", "mgf_contacts_batch", "mgf_local_contacts_pair", "mgf_ray_capsule", "mgf_inertia_tensor",
+    "mgf_mesh_new", "mgf_mesh_free", "mgf_mesh_push_vert", "mgf_mesh_push_face", "mgf_mesh_set_pos", "mgf_mesh_build",
+    "mgf_local_contacts_mesh",
+    "mgf_bvh_new", "mgf_bvh_with_capacity", "mgf_bvh_free", "mgf_bvh_empty", "mgf_bvh_clear", "mgf_bvh_insert",
+    "mgf_bvh_remove", "mgf_bvh_root", "mgf_bvh_get_leaf", "mgf_bvh_bounds", "mgf_bvh_query", "mgf_bvh_query_many",
+    "mgf_world_new", "mgf_world_free", "mgf_world_set_terrain", "mgf_world_add_bodies", "mgf_world_len",
+    "mgf_world_step", "mgf_world_build_constraints", "mgf_world_solve", "mgf_world_complete_motion",
+    "mgf_world_integrate", "mgf_world_get", "mgf_world_set", "mgf_world_read_state", "mgf_world_write_state",
+    "mgf_world_read_colliders", "mgf_world_read_constraints", "mgf_world_set_constraints", "mgf_world_set_option",
+    "mgf_world_device_ptr",
+]
+
+_lib = None
+HIT_FN = C.CFUNCTYPE(None, C.POINTER(C.c_uint64), C.c_void_p)
+
+
+def load_library():
+    """dlopen mgf_amd/libmgf_hip.so.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise MgfError(ERR_HIP, f"{path} is missing: build it with `python -m mgf_amd.build` (hipcc, gfx950). "
+                                "mgf_amd has no CPU fallback.")
+    L = C.CDLL(path)
+    P, vp, i32, i64, u64, f32 = C.POINTER, C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float
+    sig = {
+        "mgf_ctx_create": (i32, [C.c_int, P(vp)]),
+        "mgf_ctx_destroy": (None, [vp]),
+        "mgf_last_error": (C.c_char_p, []),
+        "mgf_default_params": (Params, []),
+        "mgf_version": (C.c_char_p, []),
+        "mgf_contacts": (i32, [vp, P(Shape), P(Vec3), P(Shape), P(Vec3), P(Contact), i32, P(i32)]),
+        "mgf_contacts_batch": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp]),
+        "mgf_local_contacts_pair": (i32, [vp, P(MovingComponent), P(MovingComponent), P(LocalContact), i32, P(i32)]),
+        "mgf_ray_capsule": (i32, [vp, P(Vec3), P(Vec3), P(Shape), P(Vec3), P(f32), P(i32)]),
+        "mgf_inertia_tensor": (i32, [P(Component), f32, P(f32)]),
+        "mgf_mesh_new": (i32, [vp, P(vp)]),
+        "mgf_mesh_free": (None, [vp]),
+        "mgf_mesh_push_vert": (i32, [vp, Vec3, P(u64)]),
+        "mgf_mesh_push_face": (i32, [vp, u64, u64, u64, P(u64)]),
+        "mgf_mesh_set_pos": (i32, [vp, Vec3]),
+        "mgf_mesh_build": (i32, [vp, vp, i64, vp, i64]),
+        "mgf_mesh_bvh_view": (vp, [vp]),
+        "mgf_local_contacts_mesh": (i32, [vp, P(MovingComponent), vp, P(LocalContact), i32, P(i32)]),
+        "mgf_bvh_new": (i32, [vp, P(vp)]),
+        "mgf_bvh_with_capacity": (i32, [vp, u64, P(vp)]),
+        "mgf_bvh_free": (None, [vp]),
+        "mgf_bvh_empty": (i32, [vp]),
+        "mgf_bvh_clear": (i32, [vp]),
+        "mgf_bvh_insert": (i32, [vp, P(Aabb), u64, P(u64)]),
+        "mgf_bvh_remove": (i32, [vp, u64]),
+        "mgf_bvh_root": (i32, [vp, P(u64)]),
+        "mgf_bvh_get_leaf": (i32, [vp, u64, P(u64)]),
+        "mgf_bvh_bounds": (i32, [vp, u64, P(Aabb)]),
+        "mgf_bvh_query": (i32, [vp, P(Aabb), HIT_FN, vp]),
+        "mgf_bvh_query_many": (i32, [vp, vp, i64, vp, vp, i64, P(i64)]),
+        "mgf_bvh_dump": (i64, [vp, vp, vp, i64]),
+        "mgf_world_new": (i32, [vp, P(Params), P(vp)]),
+        "mgf_world_free": (None, [vp]),
+        "mgf_world_set_terrain": (i32, [vp, vp]),
+        "mgf_world_add_bodies": (i32, [vp, vp, i64, vp, vp, vp, vp, P(u64)]),
+        "mgf_world_len": (i64, [vp]),
+        "mgf_world_step": (i32, [vp, f32, i32, P(StepStats)]),
+        "mgf_world_build_constraints": (i32, [vp, f32, P(StepStats)]),
+        "mgf_world_solve": (i32, [vp, i32, P(StepStats)]),
+        "mgf_world_complete_motion": (i32, [vp]),
+        "mgf_world_integrate": (i32, [vp, f32]),
+        "mgf_world_get": (i32, [vp, P(BodyRef), P(Velocity), P(RigidBodyInfo)]),
+        "mgf_world_set": (i32, [vp, P(BodyRef), P(Velocity)]),
+        "mgf_world_read_state": (i32, [vp, vp, vp, vp, vp, vp, i64]),
+        "mgf_world_write_state": (i32, [vp, vp, vp, vp, vp, vp, i64]),
+        "mgf_world_read_colliders": (i32, [vp, vp, i64]),
+        "mgf_world_read_constraints": (i32, [vp, vp, i64, P(i64)]),
+        "mgf_world_set_constraints": (i32, [vp, vp, i64]),
+        "mgf_world_set_option": (i32, [vp, C.c_char_p, i64]),
+        "mgf_world_device_ptr": (i32, [vp, C.c_char_p, P(vp), P(i64)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _check(status):
+    if status != 0:
+        raise MgfError(status, load_library().mgf_last_error().decode(errors="replace"))
+
+
+def _v3(v):
+    return Vec3(float(v[0]), float(v[1]), float(v[2]))
+
+
+def default_params():
+    return load_library().mgf_default_params()
+
+
+def inertia_tensor(tag, p, d, r, mass):
+    """Inertia::tensor (physics.rs:26-93): column-major 3x3 as a flat list of 9."""
+    out = (C.c_float * 9)()
+    _check(load_library().mgf_inertia_tensor(C.byref(Component(tag, _v3(p), _v3(d), float(r))), float(mass), out))
+    return [out[i] for i in range(9)]
+
+
+class Context:
+    """One per GPU (device + HIP stream).  Raises MgfError(HIP) when no GPU is present."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        self._children = weakref.WeakSet()
+        _check(load_library().mgf_ctx_create(int(device), C.byref(self._h)))
+
+    def _adopt(self, obj):
+        self._children.add(obj)
+
+    def close(self):
+        """Destroy the context; handles created from it are released first (they must not outlive it)."""
+        if getattr(self, "_h", None):
+            for child in list(self._children):
+                child.__del__()
+            load_library().mgf_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _shape(d):
+    s = Shape()
+    k = d["kind"]
+    if k == "sphere":
+        s.kind, vals = SPHERE, list(d["c"]) + [d["r"]]
+    elif k == "capsule":
+        s.kind, vals = CAPSULE, list(d["a"]) + list(d["d"]) + [d["r"]]
+    elif k == "triangle":
+        s.kind, vals = TRIANGLE, list(d["a"]) + list(d["b"]) + list(d["c"])
+    elif k == "plane":
+        s.kind, vals = PLANE, list(d["n"]) + [d["d"]]
+    elif k == "rectangle":
+        s.kind, vals = RECTANGLE, list(d["c"]) + list(d["u0"]) + list(d["u1"]) + list(d["e"])
+    else:
+        raise ValueError(k)
+    for i, x in enumerate(vals):
+        s.v[i] = float(x)
+    return s
+
+
+def _contact_dict(c):
+    return dict(a=c.a.tup(), b=c.b.tup(), n=c.n.tup(), t=c.t)
+
+
+def contacts(ctx, a, vel_a, b, vel_b, cap=4):
+    """Contacts::contacts (collision.rs:471-482) on the GPU for shape dicts a, b."""
+    out = (Contact * cap)()
+    n = C.c_int32()
+    va = C.byref(_v3(vel_a)) if vel_a is not None else None
+    vb = C.byref(_v3(vel_b)) if vel_b is not None else None
+    _check(load_library().mgf_contacts(ctx._h, C.byref(_shape(a)), va, C.byref(_shape(b)), vb, out, cap, C.byref(n)))
+    return [_contact_dict(out[i]) for i in range(n.value)]
+
+
+def contacts_batch(ctx, problems):
+    """problems: list of (a, vel_a, b, vel_b).  Returns a list of contact lists."""
+    n = len(problems)
+    A = (Shape * n)(*[_shape(p[0]) for p in problems])
+    B = (Shape * n)(*[_shape(p[2]) for p in problems])
+    va = np.zeros((n, 3), np.float32)
+    vb = np.zeros((n, 3), np.float32)
+    hv = np.zeros(n, np.uint8)
+    for i, p in enumerate(problems):
+        if p[1] is not None:
+            va[i] = p[1]
+            hv[i] |= 1
+        if p[3] is not None:
+            vb[i] = p[3]
+            hv[i] |= 2
+    out = (Contact * (2 * n))()
+    counts = np.zeros(n, np.int32)
+    _check(load_library().mgf_contacts_batch(ctx._h, n, A, va.ctypes.data, B, vb.ctypes.data, hv.ctypes.data, out,
+                                             counts.ctypes.data))
+    return [[_contact_dict(out[2 * i + k]) for k in range(counts[i])] for i in range(n)]
+
+
+def _moving(tag, p, d, r, delta):
+    return MovingComponent(Component(int(tag), _v3(p), _v3(d), float(r)), _v3(delta))
+
+
+def _local_dict(lc):
+    return dict(local_a=lc.local_a.tup(), local_b=lc.local_b.tup(), a=lc.glob.a.tup(), b=lc.glob.b.tup(),
+                n=lc.glob.n.tup(), t=lc.glob.t)
+
+
+def local_contacts_pair(ctx, a, b, cap=4):
+    """LocalContacts for two Moving<Component>s given as (tag, p, d, r, delta) tuples (compound.rs:192-207)."""
+    out = (LocalContact * cap)()
+    n = C.c_int32()
+    _check(load_library().mgf_local_contacts_pair(ctx._h, C.byref(_moving(*a)), C.byref(_moving(*b)), out, cap, C.byref(n)))
+    return [_local_dict(out[i]) for i in range(n.value)]
+
+
+def local_contacts_mesh(ctx, body, mesh, cap=32):
+    out = (LocalContact * cap)()
+    n = C.c_int32()
+    _check(load_library().mgf_local_contacts_mesh(ctx._h, C.byref(_moving(*body)), mesh._h, out, cap, C.byref(n)))
+    return [_local_dict(out[i]) for i in range(n.value)]
+
+
+def ray_capsule(ctx, p, d, cap_a, cap_d, cap_r):
+    """Intersects<Capsule> for Ray (collision.rs:275-359) -> (point, t) or None."""
+    ip = Vec3()
+    t = C.c_float()
+    hit = C.c_int32()
+    s = _shape(dict(kind="capsule", a=cap_a, d=cap_d, r=cap_r))
+    _check(load_library().mgf_ray_capsule(ctx._h, C.byref(_v3(p)), C.byref(_v3(d)), C.byref(s), C.byref(ip), C.byref(t), C.byref(hit)))
+    return (ip.tup(), t.value) if hit.value else None
+
+
+class Mesh:
+    """mgf::Mesh (mesh.rs:32-73)."""
+
+    def __init__(self, ctx):
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        _check(load_library().mgf_mesh_new(ctx._h, C.byref(self._h)))
+        ctx._adopt(self)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load_library().mgf_mesh_free(self._h)
+            self._h = None
+
+    def push_vert(self, p):
+        i = C.c_uint64()
+        _check(load_library().mgf_mesh_push_vert(self._h, _v3(p), C.byref(i)))
+        return i.value
+
+    def push_face(self, a, b, c):
+        i = C.c_uint64()
+        _check(load_library().mgf_mesh_push_face(self._h, a, b, c, C.byref(i)))
+        return i.value
+
+    def set_pos(self, p):
+        _check(load_library().mgf_mesh_set_pos(self._h, _v3(p)))
+
+    def build(self, verts, faces):
+        verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
+        faces = np.ascontiguousarray(faces, np.uint32).reshape(-1, 3)
+        _check(load_library().mgf_mesh_build(self._h, verts.ctypes.data, len(verts), faces.ctypes.data, len(faces)))
+
+    def bvh_dump(self):
+        view = load_library().mgf_mesh_bvh_view(self._h)
+        return _bvh_dump(view)
+
+
+def _bvh_dump(handle):
+    L = load_library()
+    n = L.mgf_bvh_dump(handle, None, None, 0)
+    nodes = np.zeros((max(n, 1), 6), np.int64)
+    boxes = np.zeros((max(n, 1), 6), np.float32)
+    L.mgf_bvh_dump(handle, nodes.ctypes.data, boxes.ctypes.data, n)
+    return nodes[:n], boxes[:n]
+
+
+class Bvh:
+    """mgf::BVH<AABB, usize> (bvh.rs:30-310)."""
+
+    def __init__(self, ctx, capacity=None):
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        if capacity is None:
+            _check(load_library().mgf_bvh_new(ctx._h, C.byref(self._h)))
+        else:
+            _check(load_library().mgf_bvh_with_capacity(ctx._h, capacity, C.byref(self._h)))
+        ctx._adopt(self)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load_library().mgf_bvh_free(self._h)
+            self._h = None
+
+    def empty(self):
+        return bool(load_library().mgf_bvh_empty(self._h))
+
+    def clear(self):
+        _check(load_library().mgf_bvh_clear(self._h))
+
+    def insert(self, c, r, val):
+        i = C.c_uint64()
+        _check(load_library().mgf_bvh_insert(self._h, C.byref(Aabb(_v3(c), _v3(r))), val, C.byref(i)))
+        return i.value
+
+    def remove(self, node):
+        _check(load_library().mgf_bvh_remove(self._h, node))
+
+    def root(self):
+        i = C.c_uint64()
+        _check(load_library().mgf_bvh_root(self._h, C.byref(i)))
+        return i.value
+
+    def get_leaf(self, node):
+        v = C.c_uint64()
+        _check(load_library().mgf_bvh_get_leaf(self._h, node, C.byref(v)))
+        return v.value
+
+    def bounds(self, node):
+        a = Aabb()
+        _check(load_library().mgf_bvh_bounds(self._h, node, C.byref(a)))
+        return a.c.tup(), a.r.tup()
+
+    def query(self, c, r):
+        hits = []
+        cb = HIT_FN(lambda pv, _u: hits.append(pv[0]))
+        _check(load_library().mgf_bvh_query(self._h, C.byref(Aabb(_v3(c), _v3(r))), cb, None))
+        return hits
+
+    def query_many(self, boxes):
+        boxes = np.ascontiguousarray(boxes, np.float32).reshape(-1, 6)
+        n = len(boxes)
+        off = np.zeros(n + 1, np.uint64)
+        total = C.c_int64()
+        cap = 1 << 16
+        while True:
+            vals = np.zeros(cap, np.uint64)
+            st = load_library().mgf_bvh_query_many(self._h, boxes.ctypes.data, n, off.ctypes.data, vals.ctypes.data, cap, C.byref(total))
+            if st == ERR_CAPACITY and total.value > cap:
+                cap = total.value
+                continue
+            _check(st)
+            break
+        return off.astype(np.int64), vals[:total.value].astype(np.int64)
+
+    def dump(self):
+        return _bvh_dump(self._h)
+
+
+class World:
+    """RigidBodyVec + Solver + terrain + broadphase resident on one GPU; `step` is
+    mgf_demo/world.rs::World::step."""
+
+    def __init__(self, ctx, params=None):
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        self.stats = StepStats()
+        p = C.byref(params) if params is not None else None
+        _check(load_library().mgf_world_new(ctx._h, p, C.byref(self._h)))
+        ctx._adopt(self)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load_library().mgf_world_free(self._h)
+            self._h = None
+
+    @classmethod
+    def from_scene(cls, ctx, scene, params=None):
+        w = cls(ctx, params)
+        t = scene["terrain"]
+        if t is not None:
+            m = Mesh(ctx)
+            m.build(t["verts"], t["faces"])
+            m.set_pos(t["pos"])
+            w.set_terrain(m)
+        w.add_bodies(scene["comps"], scene["mass"], scene["restitution"], scene["friction"], scene["force"])
+        if scene.get("v0") is not None:
+            w.write_state(v=scene["v0"])
+        return w
+
+    def set_terrain(self, mesh):
+        _check(load_library().mgf_world_set_terrain(self._h, mesh._h if mesh is not None else None))
+
+    def add_bodies(self, comps, mass, restitution, friction, world_force):
+        comps = np.ascontiguousarray(comps, dtype=COMPONENT_DTYPE)
+        n = len(comps)
+        mass = np.ascontiguousarray(np.broadcast_to(np.asarray(mass, np.float32), (n,)))
+        rest = np.ascontiguousarray(np.broadcast_to(np.asarray(restitution, np.float32), (n,)))
+        fric = np.ascontiguousarray(np.broadcast_to(np.asarray(friction, np.float32), (n,)))
+        force = np.ascontiguousarray(np.broadcast_to(np.asarray(world_force, np.float32), (n, 3)))
+        first = C.c_uint64()
+        _check(load_library().mgf_world_add_bodies(self._h, comps.ctypes.data, n, mass.ctypes.data, rest.ctypes.data,
+                                                   fric.ctypes.data, force.ctypes.data, C.byref(first)))
+        return first.value
+
+    def __len__(self):
+        return load_library().mgf_world_len(self._h)
+
+    def step(self, dt, iters):
+        _check(load_library().mgf_world_step(self._h, float(dt), int(iters), C.byref(self.stats)))
+        return self.stats
+
+    def build_constraints(self, dt):
+        _check(load_library().mgf_world_build_constraints(self._h, float(dt), C.byref(self.stats)))
+        return self.stats
+
+    def solve(self, iters):
+        _check(load_library().mgf_world_solve(self._h, int(iters), C.byref(self.stats)))
+        return self.stats
+
+    def complete_motion(self):
+        _check(load_library().mgf_world_complete_motion(self._h))
+
+    def integrate(self, dt):
+        _check(load_library().mgf_world_integrate(self._h, float(dt)))
+
+    def get(self, index=None, static=None):
+        """ConstrainedSet::get: index for Dynamic(i), static=(center, friction) for Static."""
+        ref = BodyRef(0, index, Vec3(), 0.0) if static is None else BodyRef(1, 0, _v3(static[0]), float(static[1]))
+        vel, info = Velocity(), RigidBodyInfo()
+        _check(load_library().mgf_world_get(self._h, C.byref(ref), C.byref(vel), C.byref(info)))
+        return vel, info
+
+    def set(self, index, linear, angular):
+        ref = BodyRef(0, index, Vec3(), 0.0)
+        vel = Velocity(_v3(linear), _v3(angular))
+        _check(load_library().mgf_world_set(self._h, C.byref(ref), C.byref(vel)))
+
+    def state(self):
+        n = len(self)
+        x = np.zeros((n, 3), np.float32)
+        q = np.zeros((n, 4), np.float32)
+        v = np.zeros((n, 3), np.float32)
+        w = np.zeros((n, 3), np.float32)
+        d = np.zeros((n, 3), np.float32)
+        _check(load_library().mgf_world_read_state(self._h, x.ctypes.data, q.ctypes.data, v.ctypes.data, w.ctypes.data,
+                                                   d.ctypes.data, n))
+        return dict(x=x, q=q, v=v, omega=w, delta=d)
+
+    def write_state(self, x=None, q=None, v=None, omega=None, delta=None):
+        keep = []
+
+        def p(a, k):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, np.float32).reshape(-1, k)
+            assert len(a) == len(self)
+            keep.append(a)
+            return a.ctypes.data
+        _check(load_library().mgf_world_write_state(self._h, p(x, 3), p(q, 4), p(v, 3), p(omega, 3), p(delta, 3), len(self)))
+
+    def colliders(self):
+        out = np.zeros(len(self), MOVING_DTYPE)
+        _check(load_library().mgf_world_read_colliders(self._h, out.ctypes.data, len(out)))
+        return out
+
+    def constraints(self):
+        n = C.c_int64()
+        _check(load_library().mgf_world_read_constraints(self._h, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), CONSTRAINT_DTYPE)
+        _check(load_library().mgf_world_read_constraints(self._h, out.ctypes.data, len(out), C.byref(n)))
+        return out[:n.value]
+
+    def set_constraints(self, cons):
+        cons = np.ascontiguousarray(cons, CONSTRAINT_DTYPE)
+        _check(load_library().mgf_world_set_constraints(self._h, cons.ctypes.data, len(cons)))
+
+    def set_option(self, key, value):
+        _check(load_library().mgf_world_set_option(self._h, key.encode(), int(value)))
+
+    def device_ptr(self, name):
+        p = C.c_void_p()
+        nb = C.c_int64()
+        _check(load_library().mgf_world_device_ptr(self._h, name.encode(), C.byref(p), C.byref(nb)))
+        return p.value, nb.value

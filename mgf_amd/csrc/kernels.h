@@ -1,0 +1,858 @@
+// Hand-written HIP kernels of the mgf per-tick hot path for gfx950 (wave64).
+//
+//   k_integrate        RigidBodyVec::complete_motion + integrate (physics.rs:222-269), swept AABB
+//                      (bounds.rs:60-68), fat-AABB refit test (world.rs:234-238)
+//   k_morton / k_lbvh_build / k_lbvh_refit
+//                      per-tick linear BVH over the fat AABBs (replaces the sequentially mutated
+//                      AVL tree of bvh.rs for the world broadphase; the hit SET is identical
+//                      because acceptance is the reference's own predicate)
+//   k_candidates<FILL> BVH::query (bvh.rs:283-310) for every body at once: mesh-BVH DFS in the
+//                      reference's order + world LBVH; two passes (count, fill) -> CSR
+//   k_narrow_pairs<A,B> / k_narrow_terrain<A>
+//                      one kernel per shape-pair type over the candidate lists
+//   k_count_contacts / k_setup_pairs / k_setup_terrain
+//                      Manifold::from + ContactConstraint::new (manifold.rs:120-148, solver.rs:101-191)
+//   k_adj_* / k_chain / k_frontier0
+//                      order-preserving dependency DAG of the constraint list
+//   k_solve<FIRST>     ContactConstraint::solve (solver.rs:203-252) for one DAG level
+//
+// All f32 arithmetic follows the reference's operation order; the TU is built with
+// -ffp-contract=off.
+#pragma once
+#include "dev_geom.h"
+#include "host_bvh.h"
+
+namespace mgf {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float4 ld4(const float4* p) { return *p; }
+__device__ __forceinline__ V3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
+__device__ __forceinline__ float4 mk4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+// Resident rigid-body state (RigidBodyVec, physics.rs:141-155), SoA of 16-byte words so every
+// streaming access is a coalesced dwordx4 per lane.
+struct Bodies {
+  float4* x;      // x.xyz, -
+  float4* q;      // s, v.xyz
+  float4* srec;   // 4 words/body, the record the solver gathers:
+                  //   [0] v.xyz, w.x   [1] w.y, w.z, inv_mass, I00   [2] I01 I02 I10 I11   [3] I12 I20 I21 I22
+                  //   (I = world inv_moment, column-major Icr)
+  float4* sp0;    // force.xyz, restitution
+  float4* sp1;    // torque.xyz, friction
+  float4* ctor;   // constructor: kind bits, r, half_h, -
+  float4* imb;    // 3 words/body: inv_moment_body columns
+  float4* delta;  // collider.1 (= v*dt), friction
+  float4* einfo;  // x + delta (RigidBodyInfo.x, physics.rs:282), restitution
+  float4* col0;   // collider shape: p.xyz, r
+  float4* col1;   //                 d.xyz, kind bits
+  float4* tb_c;   // tight swept AABB centre / half extents
+  float4* tb_r;
+  float4* fb_c;   // fat AABB (persistent; world.rs:181,237)
+  float4* fb_r;
+};
+
+struct SceneBounds { int lo[3]; int hi[3]; uint32_t n_refits; uint32_t pad; };  // ordered-int encoded floats
+
+__device__ __forceinline__ int f_ord(float f) { int i = __builtin_bit_cast(int, f); return i >= 0 ? i : (i ^ 0x7FFFFFFF); }
+__host__ __device__ __forceinline__ float ord_f(int i) { int j = i >= 0 ? i : (i ^ 0x7FFFFFFF); return __builtin_bit_cast(float, j); }
+
+__device__ __forceinline__ M3 load_imb(const float4* imb, uint32_t i) {
+  float4 a = imb[3 * i], b = imb[3 * i + 1], c = imb[3 * i + 2];
+  return m3_cols(xyz(a), xyz(b), xyz(c));
+}
+
+// ------------------------------------------------------------------------------------------
+// complete_motion + integrate, one pass.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, float dt, float fat_margin, int do_complete,
+                                                      int do_integrate, SceneBounds* sb) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  bool live = i < n;
+  V3 fc = mk3(0, 0, 0);
+  bool refit = false;
+  if (live) {
+    float4 xw = B.x[i];
+    float4 dl = B.delta[i];
+    V3 x = xyz(xw);
+    if (do_complete) x = x + xyz(dl);  // physics.rs:262-269
+    if (do_integrate) {
+      float4 qw = B.q[i];
+      float4 s0 = B.srec[4 * i], s1 = B.srec[4 * i + 1];
+      float4 p0 = B.sp0[i], p1 = B.sp1[i], ct = B.ctor[i];
+      V3 v = mk3(s0.x, s0.y, s0.z), w = mk3(s0.w, s1.x, s1.y);
+      float inv_mass = s1.z;
+      Quat q = mkq(qw.x, mk3(qw.y, qw.z, qw.w));
+      // physics.rs:226-227
+      q = normalize(q + mkq(0.0f, w * dt) * 0.5f * q);
+      // physics.rs:231-232
+      M3 R = m3_from_quat(q);
+      M3 I = R * load_imb(B.imb, i) * transpose(R);
+      // physics.rs:236, 240
+      v = v + xyz(p0) * inv_mass * dt;
+      w = w + I * xyz(p1) * dt;
+      // physics.rs:244-250
+      int kind = (int)f2u(ct.x);
+      Comp col = construct(kind, ct.y, ct.z, x, q);
+      V3 d = v * dt;
+      B.q[i] = make_float4(q.s, q.v.x, q.v.y, q.v.z);
+      B.srec[4 * i] = make_float4(v.x, v.y, v.z, w.x);
+      B.srec[4 * i + 1] = make_float4(w.y, w.z, inv_mass, I.c[0].x);
+      B.srec[4 * i + 2] = make_float4(I.c[0].y, I.c[0].z, I.c[1].x, I.c[1].y);
+      B.srec[4 * i + 3] = make_float4(I.c[1].z, I.c[2].x, I.c[2].y, I.c[2].z);
+      B.delta[i] = mk4(d, p1.w);
+      B.einfo[i] = mk4(x + d, p0.w);
+      B.col0[i] = mk4(col.p, col.r);
+      B.col1[i] = mk4(col.d, u2f((uint32_t)col.kind));
+      Box tb = swept_bounds(col, d);
+      B.tb_c[i] = mk4(tb.c, 0.0f);
+      B.tb_r[i] = mk4(tb.r, 0.0f);
+      Box fb; fb.c = xyz(B.fb_c[i]); fb.r = xyz(B.fb_r[i]);
+      if (!box_contains(fb, tb)) {  // world.rs:235-238
+        fb.c = tb.c;
+        fb.r = tb.r + mk3(fat_margin, fat_margin, fat_margin);
+        B.fb_c[i] = mk4(fb.c, 0.0f);
+        B.fb_r[i] = mk4(fb.r, 0.0f);
+        refit = true;
+      }
+      fc = fb.c;
+    } else if (do_complete) {
+      B.einfo[i] = mk4(x + xyz(dl), B.einfo[i].w);
+    }
+    if (do_complete) B.x[i] = mk4(x, 0.0f);
+  }
+  if (!do_integrate || sb == nullptr) return;
+  // scene bounds of the fat-box centres (for Morton quantisation) + refit count: wave reduce, one atomic per wave
+  int lo[3], hi[3];
+  for (int k = 0; k < 3; ++k) {
+    int o = live ? f_ord(at(fc, k)) : 0x7FFFFFFF;
+    int oh = live ? f_ord(at(fc, k)) : (int)0x80000000;
+    for (int off = 32; off > 0; off >>= 1) {
+      o = min(o, __shfl_xor(o, off));
+      oh = max(oh, __shfl_xor(oh, off));
+    }
+    lo[k] = o; hi[k] = oh;
+  }
+  unsigned long long m = __ballot(refit);
+  if ((threadIdx.x & 63) == 0) {
+    for (int k = 0; k < 3; ++k) { atomicMin(&sb->lo[k], lo[k]); atomicMax(&sb->hi[k], hi[k]); }
+    uint32_t c = (uint32_t)__popcll(m);
+    if (c) atomicAdd(&sb->n_refits, c);
+  }
+}
+
+// RigidBodyInfo.x after a state write (physics.rs:282).
+__global__ __launch_bounds__(kBlock) void k_refresh_einfo(Bodies B, uint32_t n) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) B.einfo[i] = mk4(xyz(B.x[i]) + xyz(B.delta[i]), B.einfo[i].w);
+}
+__global__ void k_reset_step(SceneBounds* sb, uint32_t* tail, uint32_t* done, uint32_t* err) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    for (int k = 0; k < 3; ++k) { sb->lo[k] = 0x7FFFFFFF; sb->hi[k] = (int)0x80000000; }
+    sb->n_refits = 0; sb->pad = 0;
+    *tail = 0; *done = 0; *err = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Linear BVH over the fat AABBs.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t expand10(uint32_t v) {
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+__global__ __launch_bounds__(kBlock) void k_morton(const float4* fb_c, uint32_t n, const SceneBounds* sb, uint32_t* keys, uint32_t* vals) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  V3 c = xyz(fb_c[i]);
+  uint32_t code = 0;
+  for (int k = 0; k < 3; ++k) {
+    float lo = ord_f(sb->lo[k]), hi = ord_f(sb->hi[k]);
+    float ext = hi - lo;
+    float t = ext > 0.0f ? (at(c, k) - lo) / ext : 0.0f;
+    int qv = (int)(t * 1023.0f);
+    qv = qv < 0 ? 0 : (qv > 1023 ? 1023 : qv);
+    code |= expand10((uint32_t)qv) << (2 - k);
+  }
+  keys[i] = code;
+  vals[i] = i;
+}
+
+// Fat BVH2 node, 64 B: both children's boxes live in the parent so one fetch serves both tests.
+struct LNode {
+  float4 a;  // lo(L).xyz, child L   (bit31 set = leaf at sorted position)
+  float4 b;  // hi(L).xyz, child R
+  float4 c;  // lo(R).xyz, parent link (node << 1 | side), kNone for the root
+  float4 d;  // hi(R).xyz, -
+};
+struct Lbvh {
+  LNode* nodes;        // n-1 internal nodes, node 0 = root
+  float4* leaf_c;      // sorted order: fat c.xyz, body index
+  float4* leaf_r;      //               fat r.xyz, -
+  uint32_t* leaf_link; // parent link of each sorted leaf
+  uint32_t* visit;     // arrival counters for the bottom-up refit
+  const uint32_t* skeys;
+  const uint32_t* sidx;
+  uint32_t n;
+  uint32_t* err;       // set to 2 if a traversal stack overflows
+};
+
+__device__ __forceinline__ int lbvh_delta(const uint32_t* keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  uint32_t a = keys[i], b = keys[j];
+  if (a == b) return 32 + __clz((uint32_t)i ^ (uint32_t)j);
+  return __clz(a ^ b);
+}
+
+// Karras 2012: one thread per internal node.
+__global__ __launch_bounds__(kBlock) void k_lbvh_build(Lbvh T) {
+  int i = blockIdx.x * kBlock + threadIdx.x;
+  int n = (int)T.n;
+  if (i >= n - 1) return;
+  const uint32_t* K = T.skeys;
+  int d = (lbvh_delta(K, n, i, i + 1) - lbvh_delta(K, n, i, i - 1)) >= 0 ? 1 : -1;
+  int dmin = lbvh_delta(K, n, i, i - d);
+  int lmax = 2;
+  while (lbvh_delta(K, n, i, i + lmax * d) > dmin) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (lbvh_delta(K, n, i, i + (l + t) * d) > dmin) l += t;
+  int j = i + l * d;
+  int dnode = lbvh_delta(K, n, i, j);
+  int s = 0;
+  for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+    if (lbvh_delta(K, n, i, i + (s + t) * d) > dnode) s += t;
+    if (t == 1) break;
+  }
+  int gamma = i + s * d + min(d, 0);
+  int lo = min(i, j), hi = max(i, j);
+  uint32_t L = (lo == gamma) ? (0x80000000u | (uint32_t)gamma) : (uint32_t)gamma;
+  uint32_t R = (hi == gamma + 1) ? (0x80000000u | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
+  T.nodes[i].a.w = u2f(L);
+  T.nodes[i].b.w = u2f(R);
+  if (i == 0) T.nodes[0].c.w = u2f(kNone);
+  uint32_t linkL = ((uint32_t)i << 1), linkR = ((uint32_t)i << 1) | 1u;
+  if (L & 0x80000000u) T.leaf_link[gamma] = linkL; else T.nodes[gamma].c.w = u2f(linkL);
+  if (R & 0x80000000u) T.leaf_link[gamma + 1] = linkR; else T.nodes[gamma + 1].c.w = u2f(linkR);
+  T.visit[i] = 0;
+}
+
+__device__ __forceinline__ void lnode_store_child_box(LNode* nd, int side, V3 lo, V3 hi) {
+  float* p = reinterpret_cast<float*>(nd);
+  int o = side ? 8 : 0;
+  p[o + 0] = lo.x; p[o + 1] = lo.y; p[o + 2] = lo.z;
+  p[o + 4] = hi.x; p[o + 5] = hi.y; p[o + 6] = hi.z;
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return u2f(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Leaves in sorted order; bottom-up union with one arrival counter per internal node.
+__global__ __launch_bounds__(kBlock) void k_lbvh_refit(Lbvh T, const float4* fb_c, const float4* fb_r) {
+  uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= T.n) return;
+  uint32_t body = T.sidx[k];
+  V3 c = xyz(fb_c[body]), r = xyz(fb_r[body]);
+  T.leaf_c[k] = mk4(c, u2f(body));
+  T.leaf_r[k] = mk4(r, 0.0f);
+  if (T.n < 2) return;
+  V3 lo = c - r, hi = c + r;
+  uint32_t link = T.leaf_link[k];
+  while (link != kNone) {
+    uint32_t node = link >> 1;
+    int side = (int)(link & 1u);
+    LNode* nd = &T.nodes[node];
+    lnode_store_child_box(nd, side, lo, hi);
+    __threadfence();  // release my half before announcing arrival
+    uint32_t old = atomicAdd(&T.visit[node], 1u);
+    if (old == 0) return;  // sibling subtree not finished: it will carry on
+    __threadfence();  // acquire the sibling's half
+    const float* p = reinterpret_cast<const float*>(nd);
+    int o = side ? 0 : 8;  // the other side
+    V3 olo = mk3(ld_agent(p + o), ld_agent(p + o + 1), ld_agent(p + o + 2));
+    V3 ohi = mk3(ld_agent(p + o + 4), ld_agent(p + o + 5), ld_agent(p + o + 6));
+    lo = mk3(fminf(lo.x, olo.x), fminf(lo.y, olo.y), fminf(lo.z, olo.z));
+    hi = mk3(fmaxf(hi.x, ohi.x), fmaxf(hi.y, ohi.y), fmaxf(hi.z, ohi.z));
+    link = f2u(ld_agent(p + 11));  // c.w
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Candidate generation: for body i, terrain faces (mesh BVH, reference DFS order) and partner
+// bodies j < i whose fat AABB overlaps i's tight swept AABB (world.rs:240-290).
+// ------------------------------------------------------------------------------------------
+struct TerrainDev {
+  const DevNode* nodes;   // flattened reference-faithful mesh BVH (host_bvh.h)
+  const float4* verts;    // mesh.verts
+  const uint4* faces;     // mesh.faces (a, b, c, -)
+  uint32_t root;
+  uint32_t n_nodes;       // 0 = no terrain
+  float x[3];             // mesh.x
+  uint32_t* err;          // set to 1 if a traversal stack overflows
+};
+
+constexpr int kStack = 64;
+
+// bvh.rs:283-310 with the reference's order: push lchild, push rchild, pop rchild first.
+template <class F>
+__device__ __forceinline__ void terrain_traverse(const TerrainDev& M, const Box& q, F&& emit) {
+  if (M.n_nodes == 0) return;
+  uint32_t stack[kStack];
+  int sp = 0;
+  stack[sp++] = M.root;
+  while (sp > 0) {
+    uint32_t top = stack[--sp];
+    const float4* raw = reinterpret_cast<const float4*>(&M.nodes[top]);
+    float4 n0 = raw[0], n1 = raw[1];
+    Box nb; nb.c = xyz(n0); nb.r = xyz(n1);
+    if (box_overlaps(q, nb)) {
+      uint32_t w0 = f2u(n0.w), w1 = f2u(n1.w);
+      if (w0 & 0x80000000u) emit(w0 & 0x7FFFFFFFu);
+      else if (sp + 2 <= kStack) { stack[sp++] = w0; stack[sp++] = w1; }
+      else if (M.err) *M.err = 1u;
+    }
+  }
+}
+
+template <class F>
+__device__ __forceinline__ void lbvh_traverse(const Lbvh& T, uint32_t i, const Box& q, float pad_abs, F&& emit) {
+  if (T.n < 2) return;  // a single body has no partner
+  // Inner nodes hold min/max unions: test them against a query padded well past f32 rounding so the
+  // exact (centre, half-extent) acceptance test below is never pre-empted.
+  float pad = pad_abs + 1e-5f * (fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z);
+  V3 qlo = q.c - q.r - mk3(pad, pad, pad), qhi = q.c + q.r + mk3(pad, pad, pad);
+  uint32_t stack[kStack];
+  int sp = 0;
+  stack[sp++] = 0;
+  while (sp > 0) {
+    uint32_t node = stack[--sp];
+    const LNode* nd = &T.nodes[node];
+    float4 a = nd->a, b = nd->b, c = nd->c, d = nd->d;
+    uint32_t ch[2] = {f2u(a.w), f2u(b.w)};
+    bool ov[2];
+    ov[0] = qlo.x <= b.x && a.x <= qhi.x && qlo.y <= b.y && a.y <= qhi.y && qlo.z <= b.z && a.z <= qhi.z;
+    ov[1] = qlo.x <= d.x && c.x <= qhi.x && qlo.y <= d.y && c.y <= qhi.y && qlo.z <= d.z && c.z <= qhi.z;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (!ov[s]) continue;
+      if (ch[s] & 0x80000000u) {
+        uint32_t k = ch[s] & 0x7FFFFFFFu;
+        float4 lc = T.leaf_c[k];
+        uint32_t j = f2u(lc.w);
+        if (j < i) {  // world.rs:266
+          Box fb; fb.c = xyz(lc); fb.r = xyz(T.leaf_r[k]);
+          if (box_overlaps(q, fb)) emit(j);  // the reference's own acceptance test (bvh.rs:297)
+        }
+      } else if (sp < kStack) {
+        stack[sp++] = ch[s];
+      } else if (T.err) {
+        *T.err = 2u;
+      }
+    }
+  }
+}
+
+// FILL = false: count hits per body.  FILL = true: write them (CSR), partners sorted ascending.
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void k_candidates(Bodies B, uint32_t n, Lbvh T, TerrainDev M, float pad,
+                                                       uint32_t* t_cnt, uint32_t* p_cnt, const uint32_t* t_off,
+                                                       const uint32_t* p_off, uint32_t* t_cand, uint32_t* t_owner,
+                                                       uint32_t* p_cand, uint32_t* p_owner) {
+  uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n) return;
+  uint32_t i = T.n >= 1 ? T.sidx[k] : k;  // walk bodies in Morton order: neighbouring lanes share tree paths
+  Box q; q.c = xyz(B.tb_c[i]); q.r = xyz(B.tb_r[i]);
+  // terrain: Mesh::contacts queries bounds - mesh.x (mesh.rs:121)
+  Box qm = q; qm.c = q.c + -mk3(M.x[0], M.x[1], M.x[2]);
+  uint32_t nt = 0, np = 0;
+  uint32_t tb = FILL ? t_off[i] : 0, pb = FILL ? p_off[i] : 0;
+  terrain_traverse(M, qm, [&](uint32_t face) {
+    if (FILL) { t_cand[tb + nt] = face; t_owner[tb + nt] = i; }
+    ++nt;
+  });
+  if (i != 0) {  // world.rs:256
+    lbvh_traverse(T, i, q, pad, [&](uint32_t j) {
+      if (FILL) { p_cand[pb + np] = j; p_owner[pb + np] = i; }
+      ++np;
+    });
+  }
+  if (!FILL) { t_cnt[i] = nt; p_cnt[i] = np; return; }
+  // canonical partner order: ascending j (insertion sort, segments are ~10 long)
+  for (uint32_t a = 1; a < np; ++a) {
+    uint32_t v = p_cand[pb + a];
+    uint32_t b = a;
+    while (b > 0 && p_cand[pb + b - 1] > v) { p_cand[pb + b] = p_cand[pb + b - 1]; --b; }
+    p_cand[pb + b] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Narrowphase, one kernel per shape-pair type.  Output per candidate: contact count and the
+// LocalContact reduced to what Manifold/ContactConstraint::new consume (local_a, local_b, n).
+// ------------------------------------------------------------------------------------------
+struct NContact { float4 la, lb, n; };  // la.xyz + t, lb.xyz, n.xyz
+
+__device__ __forceinline__ Comp load_comp(const Bodies& B, uint32_t i) {
+  float4 c0 = B.col0[i], c1 = B.col1[i];
+  Comp k; k.p = xyz(c0); k.r = c0.w; k.d = xyz(c1); k.kind = (int)f2u(c1.w);
+  return k;
+}
+
+// work = nullptr: dense over [0, m); else the m candidate ids of this pair type.
+template <int KA, int KB>
+__global__ __launch_bounds__(kBlock) void k_narrow_pairs(Bodies B, const uint32_t* work, uint32_t m, const uint32_t* p_owner,
+                                                         const uint32_t* p_cand, uint32_t* p_nc, NContact* p_out) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= m) return;
+  uint32_t p = work ? work[t] : t;
+  uint32_t i = p_owner[p], j = p_cand[p];
+  Comp A = load_comp(B, i), Bc = load_comp(B, j);
+  A.kind = KA; Bc.kind = KB;  // compile-time dispatch: the list holds only this pair type
+  V3 vA = xyz(B.delta[i]), vB = xyz(B.delta[j]);
+  LocalContact lc;
+  bool hit = comp_pair_local(A, vA, Bc, vB, &lc);
+  p_nc[p] = hit ? 1u : 0u;
+  if (hit) {
+    // ContactPruner::push on an empty pruner keeps the contact (manifold.rs:73-79);
+    // Manifold::from(pruner): normal = (0 + n) / 1 (manifold.rs:135-140)
+    V3 nrm = (mk3(0.0f, 0.0f, 0.0f) + lc.g.n) / 1.0f;
+    NContact o; o.la = mk4(lc.la, lc.g.t); o.lb = mk4(lc.lb, 0.0f); o.n = mk4(nrm, 0.0f);
+    p_out[p] = o;
+  }
+}
+
+template <int KA>
+__global__ __launch_bounds__(kBlock) void k_narrow_terrain(Bodies B, TerrainDev M, const uint32_t* work, uint32_t m,
+                                                           const uint32_t* t_owner, const uint32_t* t_cand, uint32_t* t_nc,
+                                                           NContact* t_out /* 2 per candidate */) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= m) return;
+  uint32_t p = work ? work[t] : t;
+  uint32_t i = t_owner[p], f = t_cand[p];
+  Comp A = load_comp(B, i);
+  A.kind = KA;
+  V3 vA = xyz(B.delta[i]);
+  uint4 fi = M.faces[f];
+  V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
+  Triangle tri = mkt(xyz(M.verts[fi.x]) + mx, xyz(M.verts[fi.y]) + mx, xyz(M.verts[fi.z]) + mx);  // mesh.rs:122-126
+  LocalContact lc[2];
+  int nc = comp_tri_local(A, vA, tri, mx, lc);
+  t_nc[p] = (uint32_t)nc;
+  for (int k = 0; k < nc; ++k) {
+    NContact o; o.la = mk4(lc[k].la, lc[k].g.t); o.lb = mk4(lc[k].lb, 0.0f); o.n = mk4(lc[k].g.n, 0.0f);  // Manifold::from(lc) manifold.rs:120-128
+    t_out[2 * p + k] = o;
+  }
+}
+
+// Bin candidate ids by pair type (only launched for scenes that mix spheres and capsules).
+__global__ __launch_bounds__(kBlock) void k_bin_pairs(Bodies B, uint32_t m, const uint32_t* p_owner, const uint32_t* p_cand,
+                                                      uint32_t* lists /* 4 x m */, uint32_t* counts /* 4 */) {
+  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  int type = -1;
+  if (p < m) type = (int)(f2u(B.col1[p_owner[p]].w) * 2u + f2u(B.col1[p_cand[p]].w));
+  for (int ty = 0; ty < 4; ++ty) {  // wave-aggregated append: one atomic per wave per type
+    unsigned long long mask = __ballot(type == ty);
+    if (mask == 0) continue;
+    uint32_t base = 0;
+    int lane = threadIdx.x & 63;
+    int leader = __ffsll((long long)mask) - 1;
+    if (lane == leader) base = atomicAdd(&counts[ty], (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (type == ty) lists[(size_t)ty * m + base + __popcll(mask & ((1ull << lane) - 1ull))] = p;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_bin_terrain(Bodies B, uint32_t m, const uint32_t* t_owner, uint32_t* lists /* 2 x m */,
+                                                        uint32_t* counts /* 2 */) {
+  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  int type = -1;
+  if (p < m) type = (int)f2u(B.col1[t_owner[p]].w);
+  for (int ty = 0; ty < 2; ++ty) {
+    unsigned long long mask = __ballot(type == ty);
+    if (mask == 0) continue;
+    uint32_t base = 0;
+    int lane = threadIdx.x & 63;
+    int leader = __ffsll((long long)mask) - 1;
+    if (lane == leader) base = atomicAdd(&counts[ty], (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (type == ty) lists[(size_t)ty * m + base + __popcll(mask & ((1ull << lane) - 1ull))] = p;
+  }
+}
+
+// Per body: number of constraints it inserts (terrain contacts first, then partners) and the
+// running offset of each candidate inside the body's block.
+__global__ __launch_bounds__(kBlock) void k_count_contacts(uint32_t n, const uint32_t* t_off, const uint32_t* p_off,
+                                                           const uint32_t* t_nc, const uint32_t* p_nc, uint32_t* t_pre,
+                                                           uint32_t* p_pre, uint32_t* cnt, uint32_t* tcnt) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  uint32_t run = 0;
+  for (uint32_t p = t_off[i]; p < t_off[i + 1]; ++p) { t_pre[p] = run; run += t_nc[p]; }
+  tcnt[i] = run;
+  for (uint32_t p = p_off[i]; p < p_off[i + 1]; ++p) { p_pre[p] = run; run += p_nc[p]; }
+  cnt[i] = run;
+}
+
+// ------------------------------------------------------------------------------------------
+// ContactConstraint (solver.rs:82-93, 256-262), single contact.  96-byte record.
+// ------------------------------------------------------------------------------------------
+struct CRec {
+  uint32_t a, b;       // body indices; b = kNone for RigidBodyRef::Static
+  float n[3], t0[3], t1[3], ra[3], rb[3];
+  float bias, nmass, tmass0, tmass1, nimp;
+  float friction;      // dead state in the reference (solver.rs:223-226), kept for read-back
+  float pad;
+};
+static_assert(sizeof(CRec) == 96, "CRec must be 96 bytes");
+
+struct BodyDyn { V3 v, w; float im; M3 I; };
+__device__ __forceinline__ BodyDyn load_dyn(const float4* srec, uint32_t i) {
+  float4 s0 = srec[4 * i], s1 = srec[4 * i + 1], s2 = srec[4 * i + 2], s3 = srec[4 * i + 3];
+  BodyDyn d;
+  d.v = mk3(s0.x, s0.y, s0.z); d.w = mk3(s0.w, s1.x, s1.y); d.im = s1.z;
+  d.I = m3_cols(mk3(s1.w, s2.x, s2.y), mk3(s2.z, s2.w, s3.x), mk3(s3.y, s3.z, s3.w));
+  return d;
+}
+__device__ __forceinline__ BodyDyn static_dyn() {  // physics.rs:289-302
+  BodyDyn d; d.v = mk3(0, 0, 0); d.w = mk3(0, 0, 0); d.im = 0.0f;
+  d.I = m3_cols(mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0));
+  return d;
+}
+__device__ __forceinline__ void st3(float* p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+__device__ __forceinline__ V3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
+// ContactConstraint::new solver.rs:101-191 for one contact.
+__device__ __forceinline__ CRec make_constraint(uint32_t ia, uint32_t ib, const BodyDyn& A, V3 xa, float rest_a, float fric_a,
+                                                const BodyDyn& Bd, V3 xb, float rest_b, float fric_b, V3 normal, V3 ra, V3 rb,
+                                                float dt, float baumgarte, float slop) {
+  CRec c;
+  c.a = ia; c.b = ib;
+  float restitution = fmax_rs(rest_a, rest_b);
+  c.friction = __builtin_sqrtf(fric_a * fric_b);
+  V3 t0, t1;
+  compute_basis(normal, &t0, &t1);  // manifold.rs:125,144
+  V3 ca = ra + xa, cb = rb + xb;
+  V3 ra_cn = cross(ra, normal), rb_cn = cross(rb, normal);
+  float pen = dot(cb - ca, normal);
+  V3 dv = Bd.v + cross(Bd.w, rb) - A.v - cross(A.w, ra);
+  float rel_v = dot(dv, normal);
+  float bias = -baumgarte / dt * (pen > 0.0f ? 0.0f : pen + slop) + (rel_v < -1.0f ? -restitution * rel_v : 0.0f);
+  c.nmass = 1.0f / (A.im + dot(ra_cn, A.I * ra_cn) + Bd.im + dot(rb_cn, Bd.I * rb_cn));
+  V3 ra_ct = cross(ra, t0), rb_ct = cross(rb, t0);
+  c.tmass0 = 1.0f / (A.im + dot(ra_ct, A.I * ra_ct) + Bd.im + dot(rb_ct, Bd.I * rb_ct));
+  ra_ct = cross(ra, t1); rb_ct = cross(rb, t1);
+  c.tmass1 = 1.0f / (A.im + dot(ra_ct, A.I * ra_ct) + Bd.im + dot(rb_ct, Bd.I * rb_ct));
+  c.bias = bias;
+  c.nimp = 0.0f;
+  c.pad = 0.0f;
+  st3(c.n, normal); st3(c.t0, t0); st3(c.t1, t1); st3(c.ra, ra); st3(c.rb, rb);
+  return c;
+}
+
+__device__ __forceinline__ void store_crec(CRec* dst, const CRec& c) {
+  const float4* s = reinterpret_cast<const float4*>(&c);
+  float4* d = reinterpret_cast<float4*>(dst);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d[k] = s[k];
+}
+__device__ __forceinline__ CRec load_crec(const CRec* src) {
+  CRec c;
+  const float4* s = reinterpret_cast<const float4*>(src);
+  float4* d = reinterpret_cast<float4*>(&c);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d[k] = s[k];
+  return c;
+}
+
+__global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, uint32_t m, const uint32_t* p_owner, const uint32_t* p_cand,
+                                                        const uint32_t* p_nc, const uint32_t* p_pre, const NContact* p_in,
+                                                        const uint32_t* base, float dt, float baumgarte, float slop,
+                                                        CRec* cons) {
+  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= m || p_nc[p] == 0) return;
+  uint32_t i = p_owner[p], j = p_cand[p];
+  uint32_t c = base[i] + p_pre[p];
+  NContact k = p_in[p];
+  BodyDyn A = load_dyn(B.srec, i), Bd = load_dyn(B.srec, j);
+  float4 ea = B.einfo[i], eb = B.einfo[j];
+  CRec r = make_constraint(i, j, A, xyz(ea), ea.w, B.delta[i].w, Bd, xyz(eb), eb.w, B.delta[j].w, xyz(k.n), xyz(k.la), xyz(k.lb),
+                           dt, baumgarte, slop);
+  store_crec(&cons[c], r);
+}
+
+__global__ __launch_bounds__(kBlock) void k_setup_terrain(Bodies B, TerrainDev M, uint32_t m, const uint32_t* t_owner,
+                                                          const uint32_t* t_nc, const uint32_t* t_pre, const NContact* t_in,
+                                                          const uint32_t* base, float dt, float baumgarte, float slop, CRec* cons) {
+  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= m) return;
+  uint32_t nc = t_nc[p];
+  if (nc == 0) return;
+  uint32_t i = t_owner[p];
+  BodyDyn A = load_dyn(B.srec, i), S = static_dyn();
+  float4 ea = B.einfo[i];
+  V3 center = mk3(M.x[0], M.x[1], M.x[2]);  // Static{ center: terrain.center(), friction: 0.0 } world.rs:247
+  for (uint32_t k = 0; k < nc; ++k) {
+    NContact in = t_in[2 * p + k];
+    CRec r = make_constraint(i, kNone, A, xyz(ea), ea.w, B.delta[i].w, S, center, 0.0f, 0.0f, xyz(in.n), xyz(in.la), xyz(in.lb), dt,
+                             baumgarte, slop);
+    store_crec(&cons[base[i] + t_pre[p] + k], r);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Dependency DAG of the insertion-ordered constraint list.  A constraint may run once the
+// previous constraint touching each of its bodies has run; running all ready constraints
+// together ("a level") is exactly the sequential Gauss-Seidel result (solver.rs:72-78).
+// Per body: the list of constraints touching it, sorted by insertion index; consecutive entries
+// are linked (succ_a / succ_b by the body's role in the earlier one).
+// ------------------------------------------------------------------------------------------
+// entry = (constraint id << 1) | role, role 0: the body is `a`, role 1: the body is `b`.
+__global__ __launch_bounds__(kBlock) void k_adj_fill(const CRec* cons, uint32_t C, const uint32_t* adj_off, uint32_t* adj_fill,
+                                                     uint32_t* adj_list) {
+  uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= C) return;
+  uint32_t a = cons[c].a, b = cons[c].b;
+  adj_list[adj_off[a] + atomicAdd(&adj_fill[a], 1u)] = (c << 1);
+  if (b != kNone) adj_list[adj_off[b] + atomicAdd(&adj_fill[b], 1u)] = (c << 1) | 1u;
+}
+__global__ __launch_bounds__(kBlock) void k_adj_count(const CRec* cons, uint32_t C, uint32_t* deg) {
+  uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= C) return;
+  atomicAdd(&deg[cons[c].a], 1u);
+  uint32_t b = cons[c].b;
+  if (b != kNone) atomicAdd(&deg[b], 1u);
+}
+
+__global__ __launch_bounds__(kBlock) void k_chain(uint32_t n, const uint32_t* adj_off, uint32_t* adj_list, uint32_t* succ_a,
+                                                  uint32_t* succ_b, uint32_t* indeg) {
+  uint32_t x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= n) return;
+  uint32_t lo = adj_off[x], hi = adj_off[x + 1];
+  for (uint32_t a = lo + 1; a < hi; ++a) {  // ascending constraint id = insertion order
+    uint32_t v = adj_list[a];
+    uint32_t b = a;
+    while (b > lo && adj_list[b - 1] > v) { adj_list[b] = adj_list[b - 1]; --b; }
+    adj_list[b] = v;
+  }
+  for (uint32_t a = lo; a + 1 < hi; ++a) {
+    uint32_t u = adj_list[a], w = adj_list[a + 1];
+    if (u & 1u) succ_b[u >> 1] = w >> 1; else succ_a[u >> 1] = w >> 1;
+    atomicAdd(&indeg[w >> 1], 1u);
+  }
+}
+
+struct Frontier {
+  uint32_t* order;     // constraint ids in level order
+  uint32_t* lvl_off;   // lvl_off[r] .. lvl_off[r+1] = level r
+  uint32_t* tail;      // append cursor into order
+  uint32_t* done;      // finished-block counter
+};
+
+__device__ __forceinline__ void publish_level(const Frontier& F, uint32_t slot) {
+  // Last block to finish records where the next level ends.
+  __shared__ uint32_t s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    uint32_t d = atomicAdd(F.done, 1u);
+    s_last = (d == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x == 0) {
+    __threadfence();
+    F.lvl_off[slot] = __hip_atomic_load(F.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *F.done = 0;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_frontier0(uint32_t C, const uint32_t* indeg, Frontier F) {
+  for (uint32_t c = blockIdx.x * kBlock + threadIdx.x; c < C; c += gridDim.x * kBlock)
+    if (indeg[c] == 0) F.order[atomicAdd(F.tail, 1u)] = c;
+  publish_level(F, 1);
+}
+
+// ContactConstraint::solve solver.rs:203-252 (single contact), incl. the reference's quirks:
+// both friction rows use the dv from before the first row (:217-232); the friction impulse is
+// applied unclamped (:226-231).
+__device__ __forceinline__ void solve_one(CRec& c, BodyDyn& A, BodyDyn& Bd) {
+  V3 n = ld3(c.n), ra = ld3(c.ra), rb = ld3(c.rb);
+  V3 va = A.v, oa = A.w, vb = Bd.v, ob = Bd.w;
+  V3 dv = vb + cross(ob, rb) - va - cross(oa, ra);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    V3 t = k == 0 ? ld3(c.t0) : ld3(c.t1);
+    float tm = k == 0 ? c.tmass0 : c.tmass1;
+    float lambda = -dot(dv, t) * tm;
+    V3 impulse = t * lambda;
+    va = va - impulse * A.im;
+    oa = oa - A.I * cross(ra, impulse);
+    vb = vb + impulse * Bd.im;
+    ob = ob + Bd.I * cross(rb, impulse);
+  }
+  V3 dv2 = vb + cross(ob, rb) - va - cross(oa, ra);
+  float vn = dot(dv2, n);
+  float lambda = c.nmass * (-vn + c.bias);
+  float prev = c.nimp;
+  c.nimp = fmax_rs(prev + lambda, 0.0f);
+  lambda = c.nimp - prev;
+  V3 impulse = n * lambda;
+  va = va - impulse * A.im;
+  oa = oa - A.I * cross(ra, impulse);
+  vb = vb + impulse * Bd.im;
+  ob = ob + Bd.I * cross(rb, impulse);
+  A.v = va; A.w = oa; Bd.v = vb; Bd.w = ob;
+}
+__device__ __forceinline__ void store_vel(float4* srec, uint32_t i, const BodyDyn& d) {  // ConstrainedSet::set physics.rs:306-314
+  srec[4 * i] = make_float4(d.v.x, d.v.y, d.v.z, d.w.x);
+  float2* p = reinterpret_cast<float2*>(&srec[4 * i + 1]);
+  *p = make_float2(d.w.y, d.w.z);
+}
+
+// One DAG level.  FIRST = iteration 0: constraints come from the insertion-ordered list through
+// `order`, are copied to level order for the later iterations, and release their successors.
+template <bool FIRST>
+__global__ __launch_bounds__(kBlock) void k_solve(float4* srec, const CRec* cons_nat, CRec* cons_lvl, Frontier F, uint32_t level,
+                                                  const uint32_t* succ_a, const uint32_t* succ_b, uint32_t* indeg) {
+  uint32_t lo = F.lvl_off[level], hi = F.lvl_off[level + 1];
+  for (uint32_t p = lo + blockIdx.x * kBlock + threadIdx.x; p < hi; p += gridDim.x * kBlock) {
+    uint32_t cid = FIRST ? F.order[p] : p;
+    CRec c = load_crec(FIRST ? &cons_nat[cid] : &cons_lvl[p]);
+    BodyDyn A = load_dyn(srec, c.a);
+    BodyDyn Bd = (c.b == kNone) ? static_dyn() : load_dyn(srec, c.b);
+    solve_one(c, A, Bd);
+    store_vel(srec, c.a, A);
+    if (c.b != kNone) store_vel(srec, c.b, Bd);
+    if (FIRST) {
+      store_crec(&cons_lvl[p], c);
+      uint32_t s = succ_a[cid];
+      if (s != kNone && atomicSub(&indeg[s], 1u) == 1u) F.order[atomicAdd(F.tail, 1u)] = s;
+      s = succ_b[cid];
+      if (s != kNone && atomicSub(&indeg[s], 1u) == 1u) F.order[atomicAdd(F.tail, 1u)] = s;
+    } else {
+      cons_lvl[p].nimp = c.nimp;
+    }
+  }
+  if (FIRST) publish_level(F, level + 2);
+}
+
+// Copy normal impulses back to insertion order (read-back / debugging only).
+__global__ __launch_bounds__(kBlock) void k_unpermute_nimp(uint32_t C, const uint32_t* order, const CRec* cons_lvl, CRec* cons_nat) {
+  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p < C) cons_nat[order[p]].nimp = cons_lvl[p].nimp;
+}
+
+// ------------------------------------------------------------------------------------------
+// Single-shot entry points (golden-vector parity through the C-ABI): one lane per problem.
+// ------------------------------------------------------------------------------------------
+struct ShapeIn { int kind; float v[12]; };
+struct ContactOut { float a[3], b[3], n[3], t; };
+__device__ __forceinline__ ContactOut to_out(const Contact& c) {
+  ContactOut o; st3(o.a, c.a); st3(o.b, c.b); st3(o.n, c.n); o.t = c.t; return o;
+}
+
+// Contacts::contacts for (a [moving]) vs (b [moving]); mirrors the reference's trait resolution.
+__device__ inline int contacts_dispatch(const ShapeIn& a, bool ma, V3 va, const ShapeIn& b, bool mb, V3 vb, Contact out[2]) {
+  auto S = [](const ShapeIn& s) { return mks(mk3(s.v[0], s.v[1], s.v[2]), s.v[3]); };
+  auto Cp = [](const ShapeIn& s) { return mkcap(mk3(s.v[0], s.v[1], s.v[2]), mk3(s.v[3], s.v[4], s.v[5]), s.v[6]); };
+  auto Tr = [](const ShapeIn& s) { return mkt(mk3(s.v[0], s.v[1], s.v[2]), mk3(s.v[3], s.v[4], s.v[5]), mk3(s.v[6], s.v[7], s.v[8])); };
+  auto Pl = [](const ShapeIn& s) { Plane p; p.n = mk3(s.v[0], s.v[1], s.v[2]); p.d = s.v[3]; return p; };
+  const int ka = a.kind, kb = b.kind;
+  if (!ma && mb) {  // static receiver, moving argument
+    if (kb == MGF_SPHERE) {
+      if (ka == MGF_SPHERE) return sphere_msphere(S(a), S(b), vb, out) ? 1 : 0;
+      if (ka == MGF_CAPSULE) return capsule_msphere(Cp(a), S(b), vb, out) ? 1 : 0;
+      if (ka == MGF_TRIANGLE) return tri_msphere(Tr(a), S(b), vb, out) ? 1 : 0;
+      if (ka == MGF_PLANE) return plane_msphere(Pl(a), S(b), vb, out) ? 1 : 0;
+    } else if (kb == MGF_CAPSULE) {
+      if (ka == MGF_SPHERE) return sphere_mcapsule(S(a), Cp(b), vb, out) ? 1 : 0;
+      if (ka == MGF_CAPSULE) return capsule_mcapsule(Cp(a), Cp(b), vb, out) ? 1 : 0;
+      if (ka == MGF_TRIANGLE) return tri_mcapsule(Tr(a), Cp(b), vb, out);
+      if (ka == MGF_PLANE) return plane_mcapsule(Pl(a), Cp(b), vb, out) ? 1 : 0;
+    }
+    return -1;
+  }
+  if (ma && !mb) {  // moving receiver, static argument
+    if (kb == MGF_TRIANGLE || kb == MGF_PLANE) {  // commute_contacts! :607-608, :661-664
+      int n = contacts_dispatch(b, false, mk3(0, 0, 0), a, true, va, out);
+      for (int k = 0; k < n; ++k) out[k] = neg(out[k]);
+      return n;
+    }
+    // collision.rs:1368-1382: rhs sweeps at -self.vel, result shifted by self.vel * t
+    int n = contacts_dispatch(a, false, mk3(0, 0, 0), b, true, -va, out);
+    for (int k = 0; k < n; ++k) { V3 d = va * out[k].t; out[k] = mkc(out[k].a + d, out[k].b + d, out[k].n, out[k].t); }
+    return n;
+  }
+  if (ma && mb) {  // collision.rs:1387-1401
+    int n = contacts_dispatch(a, false, mk3(0, 0, 0), b, true, vb - va, out);
+    for (int k = 0; k < n; ++k) out[k] = mkc(out[k].a + va * out[k].t, out[k].b + va * out[k].t, out[k].n, out[k].t);
+    return n;
+  }
+  return -1;
+}
+
+__global__ void k_contacts_batch(int64_t n, const ShapeIn* a, const float* va, const ShapeIn* b, const float* vb,
+                                 const uint8_t* has_vel, ContactOut* out, int32_t* counts) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  Contact c[2];
+  bool ma = has_vel[t] & 1, mb = has_vel[t] & 2;
+  int m = contacts_dispatch(a[t], ma, ld3(va + 3 * t), b[t], mb, ld3(vb + 3 * t), c);
+  counts[t] = m;
+  for (int k = 0; k < m && k < 2; ++k) out[2 * t + k] = to_out(c[k]);
+}
+
+struct MovingIn { int tag; float p[3], d[3], r; float delta[3]; };
+struct LocalOut { float la[3], lb[3]; ContactOut g; };
+__device__ __forceinline__ Comp to_comp(const MovingIn& m) {
+  Comp k; k.kind = m.tag; k.p = ld3(m.p); k.d = ld3(m.d); k.r = m.r; return k;
+}
+__global__ void k_local_pair(MovingIn a, MovingIn b, LocalOut* out, int32_t* count) {
+  LocalContact lc;
+  bool hit = comp_pair_local(to_comp(a), ld3(a.delta), to_comp(b), ld3(b.delta), &lc);
+  *count = hit ? 1 : 0;
+  if (hit) { st3(out->la, lc.la); st3(out->lb, lc.lb); out->g = to_out(lc.g); }
+}
+// Moving<Component>.local_contacts(&Mesh): mesh-BVH DFS order, up to 2 contacts per face.
+__global__ void k_local_mesh(MovingIn a, TerrainDev M, LocalOut* out, int32_t cap, int32_t* count) {
+  Comp A = to_comp(a);
+  V3 vA = ld3(a.delta);
+  V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
+  Box q = swept_bounds(A, vA);
+  q.c = q.c + -mx;
+  int n = 0;
+  terrain_traverse(M, q, [&](uint32_t f) {
+    uint4 fi = M.faces[f];
+    Triangle tri = mkt(xyz(M.verts[fi.x]) + mx, xyz(M.verts[fi.y]) + mx, xyz(M.verts[fi.z]) + mx);
+    LocalContact lc[2];
+    int m = comp_tri_local(A, vA, tri, mx, lc);
+    for (int k = 0; k < m; ++k) {
+      if (n < cap) { st3(out[n].la, lc[k].la); st3(out[n].lb, lc[k].lb); out[n].g = to_out(lc[k].g); }
+      ++n;
+    }
+  });
+  *count = n;
+}
+__global__ void k_ray_capsule(V3 p, V3 d, Capsule cap, float* out4, int32_t* hit) {
+  V3 ip; float t;
+  bool h = ray_capsule(p, d, cap, &ip, &t);
+  *hit = h ? 1 : 0;
+  if (h) { out4[0] = ip.x; out4[1] = ip.y; out4[2] = ip.z; out4[3] = t; }
+}
+// BVH::query for many AABBs against a flattened host tree (reference DFS order).
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void k_bvh_query(TerrainDev M, const float* boxes /* 6 per query */, int64_t n, uint32_t* cnt,
+                                                      const uint32_t* off, uint32_t* vals) {
+  int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n) return;
+  Box q; q.c = ld3(boxes + 6 * t); q.r = ld3(boxes + 6 * t + 3);
+  uint32_t m = 0, base = FILL ? off[t] : 0;
+  terrain_traverse(M, q, [&](uint32_t v) { if (FILL) vals[base + m] = v; ++m; });
+  if (!FILL) cnt[t] = m;
+}
+
+}  // namespace mgf

@@ -1,0 +1,1105 @@
+// C-ABI of the MI355X-native mgf hot path (include/mgf_hip.h): host orchestration of the
+// hand-written kernels in kernels.h.  No CPU compute fallback exists: every compute entry point
+// needs a HIP device and returns MGF_ERR_HIP without one.
+#include <stdarg.h>
+
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+#include "common.h"
+#include "kernels.h"
+
+using namespace mgf;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+namespace mgf {
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace mgf
+extern "C" const char* mgf_last_error(void) { return g_err; }
+extern "C" const char* mgf_version(void) { return "mgf-hip 0.1 (gfx950)"; }
+extern "C" mgf_params mgf_default_params(void) {
+  mgf_params p;
+  p.baumgarte = 0.2f;               // solver.rs:278
+  p.penetration_slop = 0.05f;       // solver.rs:277
+  p.persistent_threshold_sq = 0.5f; // manifold.rs:38
+  p.collision_epsilon = kCollisionEps;
+  p.fat_margin = 0.25f;             // world.rs:181
+  return p;
+}
+
+static inline unsigned nblk(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+static mgf_status fail(mgf_status s, const char* msg) { set_error("%s", msg); return s; }
+#define LAUNCH_CHECK() MGF_HIP_TRY(hipGetLastError())
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+extern "C" mgf_status mgf_ctx_create(int device, mgf_ctx** out) {
+  if (!out) return fail(MGF_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) {
+    set_error("no HIP device available (%s); mgf-hip has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return MGF_ERR_HIP;
+  }
+  if (device < 0 || device >= count) return fail(MGF_ERR_INVALID, "device index out of range");
+  MGF_HIP_TRY(hipSetDevice(device));
+  std::unique_ptr<mgf_ctx> c(new mgf_ctx());
+  c->device = device;
+  MGF_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->pinned_bytes = 1 << 16;
+  MGF_HIP_TRY(hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault));
+  hipDeviceProp_t prop;
+  MGF_HIP_TRY(hipGetDeviceProperties(&prop, device));
+  c->num_cus = prop.multiProcessorCount;
+  *out = c.release();
+  return MGF_OK;
+}
+extern "C" void mgf_ctx_destroy(mgf_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+  if (ctx->prim_tmp) (void)hipFree(ctx->prim_tmp);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  delete ctx;
+}
+
+static mgf_status ctx_bind(mgf_ctx* ctx) {
+  if (!ctx) return fail(MGF_ERR_INVALID, "ctx is NULL");
+  MGF_HIP_TRY(hipSetDevice(ctx->device));
+  (void)hipGetLastError();  // drop any stale sticky error from unrelated earlier calls
+  return MGF_OK;
+}
+template <class T>
+static mgf_status h2d(mgf_ctx* ctx, T* dst, const T* src, size_t n) {
+  if (n == 0) return MGF_OK;
+  MGF_HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  MGF_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MGF_OK;
+}
+template <class T>
+static mgf_status d2h(mgf_ctx* ctx, T* dst, const T* src, size_t n) {
+  if (n == 0) return MGF_OK;
+  MGF_HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+  MGF_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MGF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host tree + device mirror (shared by mgf_bvh and mgf_mesh)
+// ---------------------------------------------------------------------------------------------
+struct TreeMirror {
+  HostBvh tree;
+  DBuf<DevNode> d_nodes;
+  uint64_t uploaded_version = ~0ull;
+  mgf_status sync(mgf_ctx* ctx) {
+    if (uploaded_version == tree.version()) return MGF_OK;
+    std::vector<DevNode> flat;
+    tree.flatten(&flat);
+    MGF_TRY(d_nodes.ensure(std::max<size_t>(flat.size(), 1), ctx->stream));
+    MGF_TRY(h2d(ctx, d_nodes.p, flat.data(), flat.size()));
+    uploaded_version = tree.version();
+    return MGF_OK;
+  }
+  TerrainDev dev(const float4* verts, const uint4* faces, V3 x, uint32_t* err) const {
+    TerrainDev t;
+    t.nodes = d_nodes.p; t.verts = verts; t.faces = faces;
+    t.root = (uint32_t)tree.root();
+    t.n_nodes = tree.empty() ? 0u : (uint32_t)tree.slots();
+    t.x[0] = x.x; t.x[1] = x.y; t.x[2] = x.z;
+    t.err = err;
+    return t;
+  }
+};
+
+struct mgf_bvh {
+  mgf_ctx* ctx;
+  TreeMirror m;
+};
+struct mgf_mesh {
+  mgf_ctx* ctx;
+  V3 x = mk3(0, 0, 0);
+  std::vector<V3> verts;
+  std::vector<uint32_t> faces;  // 3 per face
+  TreeMirror m;                 // BVH<AABB, usize> over faces (mesh.rs:36)
+  DBuf<float4> d_verts;
+  DBuf<uint4> d_faces;
+  uint64_t geom_version = 0, uploaded_geom = ~0ull;
+  mgf_status sync() {
+    MGF_TRY(m.sync(ctx));
+    if (uploaded_geom != geom_version) {
+      std::vector<float4> hv(verts.size());
+      for (size_t i = 0; i < verts.size(); ++i) hv[i] = make_float4(verts[i].x, verts[i].y, verts[i].z, 0.0f);
+      std::vector<uint4> hf(faces.size() / 3);
+      for (size_t i = 0; i < hf.size(); ++i) hf[i] = make_uint4(faces[3 * i], faces[3 * i + 1], faces[3 * i + 2], 0);
+      MGF_TRY(d_verts.ensure(std::max<size_t>(hv.size(), 1), ctx->stream));
+      MGF_TRY(d_faces.ensure(std::max<size_t>(hf.size(), 1), ctx->stream));
+      MGF_TRY(h2d(ctx, d_verts.p, hv.data(), hv.size()));
+      MGF_TRY(h2d(ctx, d_faces.p, hf.data(), hf.size()));
+      uploaded_geom = geom_version;
+    }
+    return MGF_OK;
+  }
+  TerrainDev dev(uint32_t* err) const { return m.dev(d_verts.p, d_faces.p, x, err); }
+};
+
+static inline Box to_box(const mgf_aabb& a) { Box b; b.c = mk3(a.c.x, a.c.y, a.c.z); b.r = mk3(a.r.x, a.r.y, a.r.z); return b; }
+static inline mgf_aabb from_box(const Box& b) { mgf_aabb a; a.c = {b.c.x, b.c.y, b.c.z}; a.r = {b.r.x, b.r.y, b.r.z}; return a; }
+
+// ---- mgf_bvh ---------------------------------------------------------------------------------
+extern "C" mgf_status mgf_bvh_new(mgf_ctx* ctx, mgf_bvh** out) {
+  if (!ctx || !out) return fail(MGF_ERR_INVALID, "NULL argument");
+  *out = new mgf_bvh{ctx, {}};
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_bvh_with_capacity(mgf_ctx* ctx, uint64_t cap, mgf_bvh** out) {
+  MGF_TRY(mgf_bvh_new(ctx, out));
+  (*out)->m.tree.reserve(cap);
+  return MGF_OK;
+}
+extern "C" void mgf_bvh_free(mgf_bvh* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->ctx->device);
+  delete b;
+}
+extern "C" int32_t mgf_bvh_empty(const mgf_bvh* b) { return (!b || b->m.tree.empty()) ? 1 : 0; }
+extern "C" mgf_status mgf_bvh_clear(mgf_bvh* b) {
+  if (!b) return fail(MGF_ERR_INVALID, "bvh is NULL");
+  b->m.tree.clear();
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_bvh_insert(mgf_bvh* b, const mgf_aabb* key, uint64_t val, uint64_t* id) {
+  if (!b || !key) return fail(MGF_ERR_INVALID, "NULL argument");
+  if (val > 0x7FFFFFFFull) return fail(MGF_ERR_INVALID, "leaf values are limited to 31 bits on the device");
+  uint64_t r = b->m.tree.insert(to_box(*key), val);
+  if (id) *id = r;
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_bvh_remove(mgf_bvh* b, uint64_t id) {
+  if (!b) return fail(MGF_ERR_INVALID, "bvh is NULL");
+  if (!b->m.tree.used(id)) return fail(MGF_ERR_NOT_OCCUPIED, "index is not occupied");
+  b->m.tree.remove(id);
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_bvh_root(const mgf_bvh* b, uint64_t* id) {
+  if (!b || !id) return fail(MGF_ERR_INVALID, "NULL argument");
+  if (b->m.tree.empty()) return fail(MGF_ERR_EMPTY, "BVH is empty, there is no root node");
+  *id = b->m.tree.root();
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_bvh_get_leaf(const mgf_bvh* b, uint64_t id, uint64_t* val) {
+  if (!b || !val) return fail(MGF_ERR_INVALID, "NULL argument");
+  if (!b->m.tree.used(id)) return fail(MGF_ERR_NOT_OCCUPIED, "index is not occupied");
+  if (!b->m.tree.node(id).leaf) return fail(MGF_ERR_NOT_LEAF, "node is not a leaf");
+  *val = b->m.tree.node(id).value;
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_bvh_bounds(const mgf_bvh* b, uint64_t id, mgf_aabb* out) {
+  if (!b || !out) return fail(MGF_ERR_INVALID, "NULL argument");
+  if (!b->m.tree.used(id)) return fail(MGF_ERR_NOT_OCCUPIED, "index is not occupied");
+  *out = from_box(b->m.tree.node(id).box);
+  return MGF_OK;
+}
+// Debug/introspection used by the structural parity tests: per slot
+// {used, height, parent, is_leaf, value|child1, child2}; returns slot count.
+extern "C" MGF_API int64_t mgf_bvh_dump(const mgf_bvh* b, int64_t* out6, mgf_aabb* boxes, int64_t cap) {
+  if (!b) return -1;
+  int64_t n = (int64_t)b->m.tree.slots();
+  for (int64_t i = 0; i < n && i < cap; ++i) {
+    int64_t* o = out6 + 6 * i;
+    if (!b->m.tree.used((uint64_t)i)) { o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0; continue; }
+    const HostBvh::Node& nd = b->m.tree.node((uint64_t)i);
+    o[0] = 1; o[1] = nd.height; o[2] = (int64_t)nd.parent; o[3] = nd.leaf ? 1 : 0;
+    o[4] = nd.leaf ? (int64_t)nd.value : (int64_t)nd.kid[0];
+    o[5] = nd.leaf ? 0 : (int64_t)nd.kid[1];
+    if (boxes) boxes[i] = from_box(nd.box);
+  }
+  return n;
+}
+
+static mgf_status tree_query_many(mgf_ctx* ctx, TreeMirror& m, const mgf_aabb* args, int64_t n, std::vector<uint32_t>* off,
+                                  std::vector<uint32_t>* vals) {
+  MGF_TRY(ctx_bind(ctx));
+  off->assign((size_t)n + 1, 0);
+  vals->clear();
+  if (n == 0 || m.tree.empty()) return MGF_OK;
+  MGF_TRY(m.sync(ctx));
+  DBuf<float> d_boxes;
+  DBuf<uint32_t> d_cnt, d_off, d_vals, d_err;
+  MGF_TRY(d_boxes.ensure((size_t)n * 6, ctx->stream));
+  MGF_TRY(d_cnt.ensure((size_t)n + 1, ctx->stream));
+  MGF_TRY(d_off.ensure((size_t)n + 1, ctx->stream));
+  MGF_TRY(d_err.ensure(1, ctx->stream));
+  MGF_HIP_TRY(hipMemsetAsync(d_err.p, 0, 4, ctx->stream));
+  MGF_TRY(h2d(ctx, d_boxes.p, reinterpret_cast<const float*>(args), (size_t)n * 6));
+  TerrainDev T = m.dev(nullptr, nullptr, mk3(0, 0, 0), d_err.p);
+  k_bvh_query<false><<<nblk(n), kBlock, 0, ctx->stream>>>(T, d_boxes.p, n, d_cnt.p, nullptr, nullptr);
+  LAUNCH_CHECK();
+  MGF_TRY(prim_exclusive_scan_u32(ctx, d_cnt.p, d_off.p, (size_t)n + 1));
+  MGF_TRY(d2h(ctx, off->data(), d_off.p, (size_t)n + 1));
+  uint32_t total = (*off)[n];
+  vals->resize(total);
+  if (total) {
+    MGF_TRY(d_vals.ensure(total, ctx->stream));
+    k_bvh_query<true><<<nblk(n), kBlock, 0, ctx->stream>>>(T, d_boxes.p, n, nullptr, d_off.p, d_vals.p);
+    LAUNCH_CHECK();
+    MGF_TRY(d2h(ctx, vals->data(), d_vals.p, total));
+  }
+  uint32_t err = 0;
+  MGF_TRY(d2h(ctx, &err, d_err.p, 1));
+  if (err) return fail(MGF_ERR_CAPACITY, "BVH traversal stack overflow (tree deeper than 64)");
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_bvh_query(mgf_bvh* b, const mgf_aabb* arg, mgf_bvh_hit_fn cb, void* user) {
+  if (!b || !arg || !cb) return fail(MGF_ERR_INVALID, "NULL argument");
+  std::vector<uint32_t> off, vals;
+  MGF_TRY(tree_query_many(b->ctx, b->m, arg, 1, &off, &vals));
+  for (uint32_t v : vals) { uint64_t v64 = v; cb(&v64, user); }
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_bvh_query_many(mgf_bvh* b, const mgf_aabb* args, int64_t n, uint64_t* out_offsets, uint64_t* out_vals,
+                                         int64_t cap, int64_t* total) {
+  if (!b || (!args && n) || !out_offsets) return fail(MGF_ERR_INVALID, "NULL argument");
+  std::vector<uint32_t> off, vals;
+  MGF_TRY(tree_query_many(b->ctx, b->m, args, n, &off, &vals));
+  for (int64_t i = 0; i <= n; ++i) out_offsets[i] = off[(size_t)i];
+  if (total) *total = (int64_t)vals.size();
+  if ((int64_t)vals.size() > cap) return fail(MGF_ERR_CAPACITY, "out_vals too small");
+  for (size_t i = 0; i < vals.size(); ++i) out_vals[i] = vals[i];
+  return MGF_OK;
+}
+
+// ---- mgf_mesh --------------------------------------------------------------------------------
+extern "C" mgf_status mgf_mesh_new(mgf_ctx* ctx, mgf_mesh** out) {
+  if (!ctx || !out) return fail(MGF_ERR_INVALID, "NULL argument");
+  mgf_mesh* m = new mgf_mesh();
+  m->ctx = ctx;
+  *out = m;
+  return MGF_OK;
+}
+extern "C" void mgf_mesh_free(mgf_mesh* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->ctx->device);
+  delete m;
+}
+extern "C" mgf_status mgf_mesh_push_vert(mgf_mesh* m, mgf_vec3 p, uint64_t* id) {
+  if (!m) return fail(MGF_ERR_INVALID, "mesh is NULL");
+  if (id) *id = m->verts.size();
+  m->verts.push_back(mk3(p.x, p.y, p.z));
+  ++m->geom_version;
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_mesh_push_face(mgf_mesh* m, uint64_t a, uint64_t b, uint64_t c, uint64_t* id) {
+  if (!m) return fail(MGF_ERR_INVALID, "mesh is NULL");
+  size_t nv = m->verts.size();
+  if (a >= nv || b >= nv || c >= nv) return fail(MGF_ERR_INVALID, "vertex index out of bounds");
+  uint64_t index = m->faces.size() / 3;
+  Triangle tri = mkt(m->verts[a], m->verts[b], m->verts[c]);
+  m->faces.push_back((uint32_t)a); m->faces.push_back((uint32_t)b); m->faces.push_back((uint32_t)c);
+  m->m.tree.insert(tri_bounds(tri), index);  // mesh.rs:71
+  ++m->geom_version;
+  if (id) *id = index;
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_mesh_set_pos(mgf_mesh* m, mgf_vec3 p) {
+  if (!m) return fail(MGF_ERR_INVALID, "mesh is NULL");
+  V3 disp = mk3(p.x, p.y, p.z) - m->x;  // geom.rs:459-462 with center() = x (mesh.rs:89)
+  m->x = m->x + disp;                   // AddAssign mesh.rs:76-80
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_mesh_build(mgf_mesh* m, const mgf_vec3* verts, int64_t nverts, const uint32_t* faces, int64_t nfaces) {
+  if (!m || (!verts && nverts) || (!faces && nfaces)) return fail(MGF_ERR_INVALID, "NULL argument");
+  for (int64_t i = 0; i < nverts; ++i) MGF_TRY(mgf_mesh_push_vert(m, verts[i], nullptr));
+  for (int64_t i = 0; i < nfaces; ++i) MGF_TRY(mgf_mesh_push_face(m, faces[3 * i], faces[3 * i + 1], faces[3 * i + 2], nullptr));
+  return MGF_OK;
+}
+extern "C" MGF_API mgf_bvh* mgf_mesh_bvh_view(mgf_mesh* m) {  // debug: not owned by the caller
+  static thread_local mgf_bvh view;
+  view.ctx = m->ctx;
+  view.m.tree = m->m.tree;
+  return &view;
+}
+
+// ---------------------------------------------------------------------------------------------
+// single-shot narrowphase
+// ---------------------------------------------------------------------------------------------
+static_assert(sizeof(ShapeIn) == sizeof(mgf_shape), "shape layout");
+static_assert(sizeof(ContactOut) == sizeof(mgf_contact), "contact layout");
+static_assert(sizeof(LocalOut) == sizeof(mgf_local_contact), "local contact layout");
+static_assert(sizeof(MovingIn) == sizeof(mgf_moving_component), "moving component layout");
+static_assert(sizeof(CRec) == 96, "constraint record layout");
+
+extern "C" mgf_status mgf_contacts_batch(mgf_ctx* ctx, int64_t n, const mgf_shape* a, const mgf_vec3* vel_a, const mgf_shape* b,
+                                         const mgf_vec3* vel_b, const uint8_t* has_vel, mgf_contact* out, int32_t* counts) {
+  MGF_TRY(ctx_bind(ctx));
+  if (n < 0 || (n && (!a || !b || !has_vel || !out || !counts))) return fail(MGF_ERR_INVALID, "NULL argument");
+  if (n == 0) return MGF_OK;
+  for (int64_t i = 0; i < n; ++i)
+    if (a[i].kind == MGF_RECTANGLE || b[i].kind == MGF_RECTANGLE || a[i].kind < 0 || a[i].kind > 4 || b[i].kind < 0 || b[i].kind > 4)
+      return fail(MGF_ERR_INVALID, "shape kind not on the hot path");
+  DBuf<ShapeIn> da, db;
+  DBuf<float> dva, dvb;
+  DBuf<uint8_t> dh;
+  DBuf<ContactOut> dout;
+  DBuf<int32_t> dc;
+  size_t N = (size_t)n;
+  MGF_TRY(da.ensure(N, ctx->stream)); MGF_TRY(db.ensure(N, ctx->stream));
+  MGF_TRY(dva.ensure(3 * N, ctx->stream)); MGF_TRY(dvb.ensure(3 * N, ctx->stream));
+  MGF_TRY(dh.ensure(N, ctx->stream)); MGF_TRY(dout.ensure(2 * N, ctx->stream)); MGF_TRY(dc.ensure(N, ctx->stream));
+  std::vector<float> zeros(3 * N, 0.0f);
+  MGF_TRY(h2d(ctx, da.p, reinterpret_cast<const ShapeIn*>(a), N));
+  MGF_TRY(h2d(ctx, db.p, reinterpret_cast<const ShapeIn*>(b), N));
+  MGF_TRY(h2d(ctx, dva.p, vel_a ? reinterpret_cast<const float*>(vel_a) : zeros.data(), 3 * N));
+  MGF_TRY(h2d(ctx, dvb.p, vel_b ? reinterpret_cast<const float*>(vel_b) : zeros.data(), 3 * N));
+  MGF_TRY(h2d(ctx, dh.p, has_vel, N));
+  k_contacts_batch<<<(unsigned)((N + 63) / 64), 64, 0, ctx->stream>>>(n, da.p, dva.p, db.p, dvb.p, dh.p, dout.p, dc.p);
+  LAUNCH_CHECK();
+  MGF_TRY(d2h(ctx, reinterpret_cast<ContactOut*>(out), dout.p, 2 * N));
+  MGF_TRY(d2h(ctx, counts, dc.p, N));
+  for (int64_t i = 0; i < n; ++i)
+    if (counts[i] < 0) return fail(MGF_ERR_INVALID, "unsupported shape pair");
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_contacts(mgf_ctx* ctx, const mgf_shape* a, const mgf_vec3* vel_a, const mgf_shape* b, const mgf_vec3* vel_b,
+                                   mgf_contact* out, int32_t cap, int32_t* count) {
+  if (!a || !b || !count) return fail(MGF_ERR_INVALID, "NULL argument");
+  uint8_t hv = (vel_a ? 1 : 0) | (vel_b ? 2 : 0);
+  mgf_contact tmp[2];
+  int32_t n = 0;
+  mgf_vec3 z = {0, 0, 0};
+  MGF_TRY(mgf_contacts_batch(ctx, 1, a, vel_a ? vel_a : &z, b, vel_b ? vel_b : &z, &hv, tmp, &n));
+  *count = n;
+  for (int k = 0; k < n && k < cap; ++k) out[k] = tmp[k];
+  if (n > cap) return fail(MGF_ERR_CAPACITY, "contact buffer too small");
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_local_contacts_pair(mgf_ctx* ctx, const mgf_moving_component* a, const mgf_moving_component* b,
+                                              mgf_local_contact* out, int32_t cap, int32_t* count) {
+  MGF_TRY(ctx_bind(ctx));
+  if (!a || !b || !count) return fail(MGF_ERR_INVALID, "NULL argument");
+  DBuf<LocalOut> dout;
+  DBuf<int32_t> dc;
+  MGF_TRY(dout.ensure(1, ctx->stream)); MGF_TRY(dc.ensure(1, ctx->stream));
+  MovingIn ma, mb;
+  memcpy(&ma, a, sizeof(ma)); memcpy(&mb, b, sizeof(mb));
+  k_local_pair<<<1, 1, 0, ctx->stream>>>(ma, mb, dout.p, dc.p);
+  LAUNCH_CHECK();
+  int32_t n = 0;
+  MGF_TRY(d2h(ctx, &n, dc.p, 1));
+  *count = n;
+  if (n > cap) return fail(MGF_ERR_CAPACITY, "contact buffer too small");
+  if (n) MGF_TRY(d2h(ctx, reinterpret_cast<LocalOut*>(out), dout.p, 1));
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_local_contacts_mesh(mgf_ctx* ctx, const mgf_moving_component* body, const mgf_mesh* mesh_c,
+                                              mgf_local_contact* out, int32_t cap, int32_t* count) {
+  MGF_TRY(ctx_bind(ctx));
+  if (!body || !mesh_c || !count) return fail(MGF_ERR_INVALID, "NULL argument");
+  mgf_mesh* mesh = const_cast<mgf_mesh*>(mesh_c);
+  *count = 0;
+  if (mesh->m.tree.empty()) return MGF_OK;
+  MGF_TRY(mesh->sync());
+  const int32_t dcap = 64;
+  DBuf<LocalOut> dout;
+  DBuf<int32_t> dc;
+  DBuf<uint32_t> derr;
+  MGF_TRY(dout.ensure(dcap, ctx->stream)); MGF_TRY(dc.ensure(1, ctx->stream)); MGF_TRY(derr.ensure(1, ctx->stream));
+  MGF_HIP_TRY(hipMemsetAsync(derr.p, 0, 4, ctx->stream));
+  MovingIn ma;
+  memcpy(&ma, body, sizeof(ma));
+  k_local_mesh<<<1, 1, 0, ctx->stream>>>(ma, mesh->dev(derr.p), dout.p, dcap, dc.p);
+  LAUNCH_CHECK();
+  int32_t n = 0;
+  MGF_TRY(d2h(ctx, &n, dc.p, 1));
+  *count = n;
+  if (n > cap || n > dcap) return fail(MGF_ERR_CAPACITY, "contact buffer too small");
+  if (n) MGF_TRY(d2h(ctx, reinterpret_cast<LocalOut*>(out), dout.p, (size_t)n));
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_ray_capsule(mgf_ctx* ctx, const mgf_vec3* p, const mgf_vec3* d, const mgf_shape* cap, mgf_vec3* ip, float* t,
+                                      int32_t* hit) {
+  MGF_TRY(ctx_bind(ctx));
+  if (!p || !d || !cap || !hit || cap->kind != MGF_CAPSULE) return fail(MGF_ERR_INVALID, "bad argument");
+  DBuf<float> dout;
+  DBuf<int32_t> dh;
+  MGF_TRY(dout.ensure(4, ctx->stream)); MGF_TRY(dh.ensure(1, ctx->stream));
+  Capsule c = mkcap(mk3(cap->v[0], cap->v[1], cap->v[2]), mk3(cap->v[3], cap->v[4], cap->v[5]), cap->v[6]);
+  k_ray_capsule<<<1, 1, 0, ctx->stream>>>(mk3(p->x, p->y, p->z), mk3(d->x, d->y, d->z), c, dout.p, dh.p);
+  LAUNCH_CHECK();
+  float o[4];
+  MGF_TRY(d2h(ctx, hit, dh.p, 1));
+  if (*hit) {
+    MGF_TRY(d2h(ctx, o, dout.p, 4));
+    if (ip) { ip->x = o[0]; ip->y = o[1]; ip->z = o[2]; }
+    if (t) *t = o[3];
+  }
+  return MGF_OK;
+}
+
+// Inertia::tensor physics.rs:30-93 (setup-time, host)
+static M3 tensor_of(const Comp& k, float m) {
+  V3 disp;
+  M3 i;
+  if (k.kind == KIND_SPHERE) {
+    float s = 0.4f * m * k.r * k.r;
+    i = m3_diag(s, s, s);
+    disp = k.p;
+  } else {
+    float h = mag(k.d), r = k.r;
+    float mh = m * 2.0f * r / (4.0f * r + 3.0f * h);
+    float mc = m * h / (4.0f / 3.0f * r + h);
+    float ic_x = 1.0f / 12.0f * mc * (3.0f * r * r + h * h);
+    float ic_y = 0.5f * mc * r * r;
+    float is_x = mh * (3.0f * r + 2.0f * h) / 4.0f * h;
+    float is_y = 4.0f / 5.0f * mh * r * r;
+    float i_x = ic_x + is_x, i_y = ic_y + is_y, i_z = ic_x + is_x;
+    M3 rot = m3_from_quat(quat_from_arc(mk3(0.0f, 1.0f, 0.0f) * h, k.d));
+    i = rot * m3_diag(i_x, i_y, i_z) * transpose(rot);
+    disp = comp_center(k);
+  }
+  M3 outer = m3_cols(disp * disp.x, disp * disp.y, disp * disp.z);
+  return i + m * (m3_diag(1.0f, 1.0f, 1.0f) * dot(disp, disp) - outer);
+}
+static inline Comp comp_of(const mgf_component& c) {
+  Comp k; k.kind = c.tag; k.p = mk3(c.p.x, c.p.y, c.p.z); k.d = mk3(c.d.x, c.d.y, c.d.z); k.r = c.r;
+  return k;
+}
+extern "C" mgf_status mgf_inertia_tensor(const mgf_component* c, float mass, float out9[9]) {
+  if (!c || !out9 || (c->tag != MGF_SPHERE && c->tag != MGF_CAPSULE)) return fail(MGF_ERR_INVALID, "bad component");
+  M3 t = tensor_of(comp_of(*c), mass);
+  for (int k = 0; k < 3; ++k) { out9[3 * k] = t.c[k].x; out9[3 * k + 1] = t.c[k].y; out9[3 * k + 2] = t.c[k].z; }
+  return MGF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// World
+// ---------------------------------------------------------------------------------------------
+struct mgf_world {
+  mgf_ctx* ctx = nullptr;
+  mgf_params params;
+  uint32_t n = 0;
+  bool has_sphere = false, has_capsule = false;
+  // RigidBodyVec
+  DBuf<float4> x, q, srec, sp0, sp1, ctor, imb, delta, einfo, col0, col1, tb_c, tb_r, fb_c, fb_r;
+  // terrain (copy of the caller's Mesh)
+  std::unique_ptr<mgf_mesh> terrain;
+  // broadphase
+  DBuf<uint32_t> mkeys, mvals, skeys, sidx, leaf_link, visit;
+  DBuf<LNode> lnodes;
+  DBuf<float4> leaf_c, leaf_r;
+  DBuf<uint32_t> t_cnt, p_cnt, t_off, p_off, t_cand, t_owner, p_cand, p_owner;
+  // narrowphase
+  DBuf<uint32_t> t_nc, p_nc, t_pre, p_pre, cnt, tcnt, base, tbase, work_lists, work_counts;
+  DBuf<NContact> t_out, p_out;
+  // solver
+  DBuf<CRec> cons_nat, cons_lvl;
+  DBuf<uint32_t> deg, adj_off, adj_fill, adj_list, succ_a, succ_b, indeg, order, lvl_off;
+  DBuf<uint32_t> scalars;  // [0] tail, [1] done, [2] err
+  DBuf<SceneBounds> sb;
+  uint32_t Mt = 0, Mp = 0, C = 0, Ct = 0, depth = 0, last_depth = 0, lvl_cap = 0;
+  std::vector<uint32_t> h_lvl;  // level offsets of the current constraint list
+  bool constraints_ready = false, nimp_synced = true, solved_once = false;
+  float last_dt = 0.0f;
+  int64_t opt_time_solver_kernels = 0;
+  hipEvent_t ev[8] = {};
+  std::vector<hipEvent_t> kev;  // per-launch events (option)
+  mgf_step_stats stats;
+
+  Bodies bodies() {
+    Bodies B;
+    B.x = x.p; B.q = q.p; B.srec = srec.p; B.sp0 = sp0.p; B.sp1 = sp1.p; B.ctor = ctor.p; B.imb = imb.p; B.delta = delta.p;
+    B.einfo = einfo.p; B.col0 = col0.p; B.col1 = col1.p; B.tb_c = tb_c.p; B.tb_r = tb_r.p; B.fb_c = fb_c.p; B.fb_r = fb_r.p;
+    return B;
+  }
+  uint32_t* d_tail() { return scalars.p; }
+  uint32_t* d_done() { return scalars.p + 1; }
+  uint32_t* d_err() { return scalars.p + 2; }
+  Frontier frontier() { Frontier F; F.order = order.p; F.lvl_off = lvl_off.p; F.tail = d_tail(); F.done = d_done(); return F; }
+};
+
+extern "C" mgf_status mgf_world_new(mgf_ctx* ctx, const mgf_params* params, mgf_world** out) {
+  MGF_TRY(ctx_bind(ctx));
+  if (!out) return fail(MGF_ERR_INVALID, "out is NULL");
+  std::unique_ptr<mgf_world> w(new mgf_world());
+  w->ctx = ctx;
+  w->params = params ? *params : mgf_default_params();
+  memset(&w->stats, 0, sizeof(w->stats));
+  MGF_TRY(w->scalars.ensure(4, ctx->stream));
+  MGF_TRY(w->sb.ensure(1, ctx->stream));
+  MGF_HIP_TRY(hipMemsetAsync(w->scalars.p, 0, 16, ctx->stream));
+  for (auto& e : w->ev) MGF_HIP_TRY(hipEventCreate(&e));
+  *out = w.release();
+  return MGF_OK;
+}
+extern "C" void mgf_world_free(mgf_world* w) {
+  if (!w) return;
+  (void)hipSetDevice(w->ctx->device);
+  (void)hipStreamSynchronize(w->ctx->stream);
+  for (auto& e : w->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : w->kev) (void)hipEventDestroy(e);
+  delete w;
+}
+extern "C" int64_t mgf_world_len(const mgf_world* w) { return w ? (int64_t)w->n : 0; }
+
+extern "C" mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_t value) {
+  if (!w || !key) return fail(MGF_ERR_INVALID, "NULL argument");
+  if (!strcmp(key, "time_solver_kernels")) { w->opt_time_solver_kernels = value; return MGF_OK; }
+  return fail(MGF_ERR_INVALID, "unknown option");
+}
+
+extern "C" mgf_status mgf_world_set_terrain(mgf_world* w, const mgf_mesh* mesh) {
+  if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
+  MGF_TRY(ctx_bind(w->ctx));
+  if (!mesh) { w->terrain.reset(); return MGF_OK; }
+  std::unique_ptr<mgf_mesh> t(new mgf_mesh());
+  t->ctx = w->ctx;
+  t->x = mesh->x;
+  t->verts = mesh->verts;
+  t->faces = mesh->faces;
+  t->m.tree = mesh->m.tree;
+  t->geom_version = 1;
+  MGF_TRY(t->sync());
+  w->terrain = std::move(t);
+  return MGF_OK;
+}
+
+template <class T>
+static mgf_status append(mgf_ctx* ctx, DBuf<T>& buf, size_t old_n, const std::vector<T>& add) {
+  MGF_TRY(buf.ensure(old_n + add.size(), ctx->stream, true, old_n));
+  return h2d(ctx, buf.p + old_n, add.data(), add.size());
+}
+
+// RigidBodyVec::add_body physics.rs:200-218 + World::add_body world.rs:178-184 (initial fat AABB).
+extern "C" mgf_status mgf_world_add_bodies(mgf_world* w, const mgf_component* comps, int64_t n, const float* mass, const float* restitution,
+                                           const float* friction, const mgf_vec3* world_force, uint64_t* first_id) {
+  if (!w || (n && (!comps || !mass || !restitution || !friction || !world_force))) return fail(MGF_ERR_INVALID, "NULL argument");
+  MGF_TRY(ctx_bind(w->ctx));
+  if (first_id) *first_id = w->n;
+  if (n <= 0) return MGF_OK;
+  if ((uint64_t)w->n + (uint64_t)n > 0x7FFFFFF0ull) return fail(MGF_ERR_INVALID, "too many bodies");
+  size_t N = (size_t)n;
+  std::vector<float4> hx(N), hq(N), hs(4 * N), h0(N), h1(N), hc(N), hi(3 * N), hd(N), he(N), c0(N), c1(N), tc(N), tr(N), fc(N), fr(N);
+  bool hs_ = w->has_sphere, hc_ = w->has_capsule;
+  for (size_t i = 0; i < N; ++i) {
+    const mgf_component& mc = comps[i];
+    if (mc.tag != MGF_SPHERE && mc.tag != MGF_CAPSULE) return fail(MGF_ERR_INVALID, "component tag must be sphere or capsule");
+    if (!(mc.r > 0.0f)) return fail(MGF_ERR_INVALID, "radius must be > 0 (geom.rs:300,328)");
+    Comp k = comp_of(mc);
+    if (k.kind == KIND_SPHERE) k.d = mk3(0, 0, 0);
+    // Component::deconstruct compound.rs:42-52
+    V3 px; Quat pq; float half_h = 0.0f;
+    if (k.kind == KIND_SPHERE) { px = k.p; pq = mkq(1.0f, mk3(0, 0, 0)); hs_ = true; }
+    else {
+      float h = mag(k.d);
+      pq = quat_from_arc(mk3(0.0f, 1.0f, 0.0f) * h, k.d);
+      px = k.p + k.d * 0.5f;
+      half_h = h * 0.5f;
+      hc_ = true;
+    }
+    Comp local = k; local.p = k.p + -px;  // collider - x.to_vec()
+    M3 inv;
+    if (!invert(tensor_of(local, mass[i]), &inv)) return fail(MGF_ERR_SINGULAR, "inertia tensor is not invertible (physics.rs:212)");
+    float inv_mass = 1.0f / mass[i];
+    V3 force = mk3(world_force[i].x, world_force[i].y, world_force[i].z) * mass[i];
+    hx[i] = make_float4(px.x, px.y, px.z, 0.0f);
+    hq[i] = make_float4(pq.s, pq.v.x, pq.v.y, pq.v.z);
+    hs[4 * i] = make_float4(0, 0, 0, 0);
+    hs[4 * i + 1] = make_float4(0, 0, inv_mass, inv.c[0].x);
+    hs[4 * i + 2] = make_float4(inv.c[0].y, inv.c[0].z, inv.c[1].x, inv.c[1].y);
+    hs[4 * i + 3] = make_float4(inv.c[1].z, inv.c[2].x, inv.c[2].y, inv.c[2].z);
+    h0[i] = make_float4(force.x, force.y, force.z, restitution[i]);
+    h1[i] = make_float4(0, 0, 0, friction[i]);
+    uint32_t kind_bits = (uint32_t)k.kind;
+    float kf; memcpy(&kf, &kind_bits, 4);
+    hc[i] = make_float4(kf, k.r, half_h, 0.0f);
+    for (int c = 0; c < 3; ++c) hi[3 * i + c] = make_float4(inv.c[c].x, inv.c[c].y, inv.c[c].z, 0.0f);
+    hd[i] = make_float4(0, 0, 0, friction[i]);
+    he[i] = make_float4(px.x, px.y, px.z, restitution[i]);
+    c0[i] = make_float4(k.p.x, k.p.y, k.p.z, k.r);
+    c1[i] = make_float4(k.d.x, k.d.y, k.d.z, kf);
+    Box tb = swept_bounds(k, mk3(0, 0, 0));
+    tc[i] = make_float4(tb.c.x, tb.c.y, tb.c.z, 0); tr[i] = make_float4(tb.r.x, tb.r.y, tb.r.z, 0);
+    V3 fm = mk3(w->params.fat_margin, w->params.fat_margin, w->params.fat_margin);
+    V3 frr = tb.r + fm;
+    fc[i] = tc[i]; fr[i] = make_float4(frr.x, frr.y, frr.z, 0);
+  }
+  mgf_ctx* ctx = w->ctx;
+  size_t o = w->n;
+  MGF_TRY(append(ctx, w->x, o, hx)); MGF_TRY(append(ctx, w->q, o, hq)); MGF_TRY(append(ctx, w->srec, 4 * o, hs));
+  MGF_TRY(append(ctx, w->sp0, o, h0)); MGF_TRY(append(ctx, w->sp1, o, h1)); MGF_TRY(append(ctx, w->ctor, o, hc));
+  MGF_TRY(append(ctx, w->imb, 3 * o, hi)); MGF_TRY(append(ctx, w->delta, o, hd)); MGF_TRY(append(ctx, w->einfo, o, he));
+  MGF_TRY(append(ctx, w->col0, o, c0)); MGF_TRY(append(ctx, w->col1, o, c1)); MGF_TRY(append(ctx, w->tb_c, o, tc));
+  MGF_TRY(append(ctx, w->tb_r, o, tr)); MGF_TRY(append(ctx, w->fb_c, o, fc)); MGF_TRY(append(ctx, w->fb_r, o, fr));
+  w->n += (uint32_t)n;
+  w->has_sphere = hs_; w->has_capsule = hc_;
+  w->constraints_ready = false;
+  return MGF_OK;
+}
+
+// ---- state access ----------------------------------------------------------------------------
+extern "C" mgf_status mgf_world_read_state(mgf_world* w, mgf_vec3* x, mgf_quat* q, mgf_vec3* v, mgf_vec3* omega, mgf_vec3* delta, int64_t cap) {
+  if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
+  MGF_TRY(ctx_bind(w->ctx));
+  size_t n = w->n;
+  if ((int64_t)n > cap) return fail(MGF_ERR_CAPACITY, "state buffers too small");
+  std::vector<float4> t(4 * n);
+  if (x) { MGF_TRY(d2h(w->ctx, t.data(), w->x.p, n)); for (size_t i = 0; i < n; ++i) x[i] = {t[i].x, t[i].y, t[i].z}; }
+  if (q) { MGF_TRY(d2h(w->ctx, t.data(), w->q.p, n)); for (size_t i = 0; i < n; ++i) q[i] = {t[i].x, t[i].y, t[i].z, t[i].w}; }
+  if (delta) { MGF_TRY(d2h(w->ctx, t.data(), w->delta.p, n)); for (size_t i = 0; i < n; ++i) delta[i] = {t[i].x, t[i].y, t[i].z}; }
+  if (v || omega) {
+    MGF_TRY(d2h(w->ctx, t.data(), w->srec.p, 4 * n));
+    for (size_t i = 0; i < n; ++i) {
+      if (v) v[i] = {t[4 * i].x, t[4 * i].y, t[4 * i].z};
+      if (omega) omega[i] = {t[4 * i].w, t[4 * i + 1].x, t[4 * i + 1].y};
+    }
+  }
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_world_write_state(mgf_world* w, const mgf_vec3* x, const mgf_quat* q, const mgf_vec3* v, const mgf_vec3* omega,
+                                            const mgf_vec3* delta, int64_t n_in) {
+  if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
+  MGF_TRY(ctx_bind(w->ctx));
+  size_t n = w->n;
+  if ((size_t)n_in != n) return fail(MGF_ERR_INVALID, "n must equal the number of bodies");
+  std::vector<float4> t(4 * n);
+  if (x) { for (size_t i = 0; i < n; ++i) t[i] = make_float4(x[i].x, x[i].y, x[i].z, 0); MGF_TRY(h2d(w->ctx, w->x.p, t.data(), n)); }
+  if (q) { for (size_t i = 0; i < n; ++i) t[i] = make_float4(q[i].s, q[i].x, q[i].y, q[i].z); MGF_TRY(h2d(w->ctx, w->q.p, t.data(), n)); }
+  if (delta) {
+    MGF_TRY(d2h(w->ctx, t.data(), w->delta.p, n));
+    for (size_t i = 0; i < n; ++i) t[i] = make_float4(delta[i].x, delta[i].y, delta[i].z, t[i].w);
+    MGF_TRY(h2d(w->ctx, w->delta.p, t.data(), n));
+  }
+  if (v || omega) {
+    MGF_TRY(d2h(w->ctx, t.data(), w->srec.p, 4 * n));
+    for (size_t i = 0; i < n; ++i) {
+      if (v) { t[4 * i].x = v[i].x; t[4 * i].y = v[i].y; t[4 * i].z = v[i].z; }
+      if (omega) { t[4 * i].w = omega[i].x; t[4 * i + 1].x = omega[i].y; t[4 * i + 1].y = omega[i].z; }
+    }
+    MGF_TRY(h2d(w->ctx, w->srec.p, t.data(), 4 * n));
+  }
+  if (n) { k_refresh_einfo<<<nblk(n), kBlock, 0, w->ctx->stream>>>(w->bodies(), (uint32_t)n); LAUNCH_CHECK(); }
+  MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_world_read_colliders(mgf_world* w, mgf_moving_component* out, int64_t cap) {
+  if (!w || !out) return fail(MGF_ERR_INVALID, "NULL argument");
+  MGF_TRY(ctx_bind(w->ctx));
+  size_t n = w->n;
+  if ((int64_t)n > cap) return fail(MGF_ERR_CAPACITY, "buffer too small");
+  std::vector<float4> a(n), b(n), d(n);
+  MGF_TRY(d2h(w->ctx, a.data(), w->col0.p, n)); MGF_TRY(d2h(w->ctx, b.data(), w->col1.p, n)); MGF_TRY(d2h(w->ctx, d.data(), w->delta.p, n));
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t kind; memcpy(&kind, &b[i].w, 4);
+    out[i].shape.tag = (int32_t)kind;
+    out[i].shape.p = {a[i].x, a[i].y, a[i].z};
+    out[i].shape.d = {b[i].x, b[i].y, b[i].z};
+    out[i].shape.r = a[i].w;
+    out[i].delta = {d[i].x, d[i].y, d[i].z};
+  }
+  return MGF_OK;
+}
+// ConstrainedSet::get physics.rs:273-304
+extern "C" mgf_status mgf_world_get(mgf_world* w, const mgf_body_ref* r, mgf_velocity* vel, mgf_rigid_body_info* info) {
+  if (!w || !r) return fail(MGF_ERR_INVALID, "NULL argument");
+  MGF_TRY(ctx_bind(w->ctx));
+  if (r->tag == 1) {
+    if (vel) { vel->linear = {0, 0, 0}; vel->angular = {0, 0, 0}; }
+    if (info) { info->x = r->center; info->restitution = 0.0f; info->friction = r->friction; info->inv_mass = 0.0f; for (float& f : info->inv_moment) f = 0.0f; }
+    return MGF_OK;
+  }
+  if (r->index >= w->n) return fail(MGF_ERR_INVALID, "index out of bounds");
+  float4 s[4], e, d;
+  MGF_TRY(d2h(w->ctx, s, w->srec.p + 4 * (size_t)r->index, 4));
+  MGF_TRY(d2h(w->ctx, &e, w->einfo.p + r->index, 1));
+  MGF_TRY(d2h(w->ctx, &d, w->delta.p + r->index, 1));
+  if (vel) { vel->linear = {s[0].x, s[0].y, s[0].z}; vel->angular = {s[0].w, s[1].x, s[1].y}; }
+  if (info) {
+    info->x = {e.x, e.y, e.z}; info->restitution = e.w; info->friction = d.w; info->inv_mass = s[1].z;
+    float im[9] = {s[1].w, s[2].x, s[2].y, s[2].z, s[2].w, s[3].x, s[3].y, s[3].z, s[3].w};
+    memcpy(info->inv_moment, im, sizeof(im));
+  }
+  return MGF_OK;
+}
+// ConstrainedSet::set physics.rs:306-314
+extern "C" mgf_status mgf_world_set(mgf_world* w, const mgf_body_ref* r, const mgf_velocity* vel) {
+  if (!w || !r || !vel) return fail(MGF_ERR_INVALID, "NULL argument");
+  MGF_TRY(ctx_bind(w->ctx));
+  if (r->tag == 1) return MGF_OK;
+  if (r->index >= w->n) return fail(MGF_ERR_INVALID, "index out of bounds");
+  float4 s[2];
+  MGF_TRY(d2h(w->ctx, s, w->srec.p + 4 * (size_t)r->index, 2));
+  s[0] = make_float4(vel->linear.x, vel->linear.y, vel->linear.z, vel->angular.x);
+  s[1].x = vel->angular.y; s[1].y = vel->angular.z;
+  return h2d(w->ctx, w->srec.p + 4 * (size_t)r->index, s, 2);
+}
+extern "C" mgf_status mgf_world_device_ptr(mgf_world* w, const char* name, void** ptr, int64_t* bytes) {
+  if (!w || !name || !ptr) return fail(MGF_ERR_INVALID, "NULL argument");
+  struct { const char* n; void* p; size_t per; } tab[] = {
+      {"x", w->x.p, 16}, {"q", w->q.p, 16}, {"solver_rec", w->srec.p, 64}, {"delta", w->delta.p, 16}};
+  for (auto& t : tab)
+    if (!strcmp(name, t.n)) { *ptr = t.p; if (bytes) *bytes = (int64_t)(t.per * w->n); return MGF_OK; }
+  return fail(MGF_ERR_INVALID, "unknown array name");
+}
+
+// ---- the tick ----------------------------------------------------------------------------------
+static mgf_status world_integrate(mgf_world* w, float dt, bool complete, bool integrate, bool with_bounds) {
+  mgf_ctx* ctx = w->ctx;
+  if (w->n == 0) return MGF_OK;
+  k_integrate<<<nblk(w->n), kBlock, 0, ctx->stream>>>(w->bodies(), w->n, dt, w->params.fat_margin, complete ? 1 : 0, integrate ? 1 : 0,
+                                                      with_bounds ? w->sb.p : nullptr);
+  LAUNCH_CHECK();
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_world_complete_motion(mgf_world* w) {
+  if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
+  MGF_TRY(ctx_bind(w->ctx));
+  MGF_TRY(world_integrate(w, 0.0f, true, false, false));
+  MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_world_integrate(mgf_world* w, float dt) {
+  if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
+  MGF_TRY(ctx_bind(w->ctx));
+  MGF_TRY(world_integrate(w, dt, false, true, false));
+  MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
+  return MGF_OK;
+}
+
+static mgf_status launch_pairs(mgf_world* w, int ka, int kb, const uint32_t* work, uint32_t m) {
+  if (m == 0) return MGF_OK;
+  hipStream_t s = w->ctx->stream;
+  Bodies B = w->bodies();
+  unsigned g = nblk(m);
+  if (ka == 0 && kb == 0) k_narrow_pairs<0, 0><<<g, kBlock, 0, s>>>(B, work, m, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_out.p);
+  else if (ka == 0 && kb == 1) k_narrow_pairs<0, 1><<<g, kBlock, 0, s>>>(B, work, m, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_out.p);
+  else if (ka == 1 && kb == 0) k_narrow_pairs<1, 0><<<g, kBlock, 0, s>>>(B, work, m, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_out.p);
+  else k_narrow_pairs<1, 1><<<g, kBlock, 0, s>>>(B, work, m, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_out.p);
+  LAUNCH_CHECK();
+  return MGF_OK;
+}
+static mgf_status launch_terrain(mgf_world* w, int ka, const TerrainDev& M, const uint32_t* work, uint32_t m) {
+  if (m == 0) return MGF_OK;
+  hipStream_t s = w->ctx->stream;
+  Bodies B = w->bodies();
+  unsigned g = nblk(m);
+  if (ka == 0) k_narrow_terrain<0><<<g, kBlock, 0, s>>>(B, M, work, m, w->t_owner.p, w->t_cand.p, w->t_nc.p, w->t_out.p);
+  else k_narrow_terrain<1><<<g, kBlock, 0, s>>>(B, M, work, m, w->t_owner.p, w->t_cand.p, w->t_nc.p, w->t_out.p);
+  LAUNCH_CHECK();
+  return MGF_OK;
+}
+
+// Dependency DAG + first frontier for the insertion-ordered list cons_nat[0..C).
+static mgf_status build_dag(mgf_world* w) {
+  mgf_ctx* ctx = w->ctx;
+  hipStream_t s = ctx->stream;
+  uint32_t n = w->n, C = w->C;
+  w->depth = 0;
+  w->h_lvl.clear();
+  w->nimp_synced = true;
+  w->solved_once = false;
+  MGF_HIP_TRY(hipMemsetAsync(w->scalars.p, 0, 8, s));  // tail, done
+  if (C == 0) { w->constraints_ready = true; return MGF_OK; }
+  MGF_TRY(w->deg.ensure(n + 1, s)); MGF_TRY(w->adj_off.ensure(n + 1, s)); MGF_TRY(w->adj_fill.ensure(n + 1, s));
+  MGF_TRY(w->adj_list.ensure(2 * (size_t)C, s));
+  MGF_TRY(w->succ_a.ensure(C, s)); MGF_TRY(w->succ_b.ensure(C, s)); MGF_TRY(w->indeg.ensure(C, s)); MGF_TRY(w->order.ensure(C, s));
+  MGF_TRY(w->cons_lvl.ensure(C, s));
+  if (w->lvl_cap == 0) { w->lvl_cap = 4096; MGF_TRY(w->lvl_off.ensure(w->lvl_cap + 4, s)); }
+  MGF_HIP_TRY(hipMemsetAsync(w->deg.p, 0, (n + 1) * 4, s));
+  MGF_HIP_TRY(hipMemsetAsync(w->adj_fill.p, 0, (n + 1) * 4, s));
+  MGF_HIP_TRY(hipMemsetAsync(w->succ_a.p, 0xFF, (size_t)C * 4, s));
+  MGF_HIP_TRY(hipMemsetAsync(w->succ_b.p, 0xFF, (size_t)C * 4, s));
+  MGF_HIP_TRY(hipMemsetAsync(w->indeg.p, 0, (size_t)C * 4, s));
+  MGF_HIP_TRY(hipMemsetAsync(w->lvl_off.p, 0, (w->lvl_cap + 4) * 4, s));
+  k_adj_count<<<nblk(C), kBlock, 0, s>>>(w->cons_nat.p, C, w->deg.p);
+  LAUNCH_CHECK();
+  MGF_TRY(prim_exclusive_scan_u32(ctx, w->deg.p, w->adj_off.p, (size_t)n + 1));
+  k_adj_fill<<<nblk(C), kBlock, 0, s>>>(w->cons_nat.p, C, w->adj_off.p, w->adj_fill.p, w->adj_list.p);
+  LAUNCH_CHECK();
+  k_chain<<<nblk(n), kBlock, 0, s>>>(n, w->adj_off.p, w->adj_list.p, w->succ_a.p, w->succ_b.p, w->indeg.p);
+  LAUNCH_CHECK();
+  unsigned g0 = std::min<unsigned>(nblk(C), 1024u);
+  k_frontier0<<<g0, kBlock, 0, s>>>(C, w->indeg.p, w->frontier());
+  LAUNCH_CHECK();
+  w->constraints_ready = true;
+  return MGF_OK;
+}
+
+extern "C" mgf_status mgf_world_build_constraints(mgf_world* w, float dt, mgf_step_stats* stats) {
+  if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
+  MGF_TRY(ctx_bind(w->ctx));
+  mgf_ctx* ctx = w->ctx;
+  hipStream_t s = ctx->stream;
+  const uint32_t n = w->n;
+  memset(&w->stats, 0, sizeof(w->stats));
+  w->stats.n_bodies = n;
+  w->last_dt = dt;
+  w->constraints_ready = false;
+  w->C = w->Ct = w->Mt = w->Mp = 0;
+  MGF_HIP_TRY(hipEventRecord(w->ev[0], s));
+  k_reset_step<<<1, 64, 0, s>>>(w->sb.p, w->d_tail(), w->d_done(), w->d_err());
+  LAUNCH_CHECK();
+  if (n == 0) { w->constraints_ready = true; if (stats) *stats = w->stats; MGF_HIP_TRY(hipStreamSynchronize(s)); return MGF_OK; }
+  Bodies B = w->bodies();
+  // 1. complete_motion + integrate (world.rs:230-231)
+  MGF_TRY(world_integrate(w, dt, true, true, true));
+  // 2. linear BVH over the fat AABBs
+  MGF_TRY(w->mkeys.ensure(n, s)); MGF_TRY(w->mvals.ensure(n, s)); MGF_TRY(w->skeys.ensure(n, s)); MGF_TRY(w->sidx.ensure(n, s));
+  MGF_TRY(w->leaf_link.ensure(n, s)); MGF_TRY(w->visit.ensure(n, s)); MGF_TRY(w->lnodes.ensure(n, s));
+  MGF_TRY(w->leaf_c.ensure(n, s)); MGF_TRY(w->leaf_r.ensure(n, s));
+  k_morton<<<nblk(n), kBlock, 0, s>>>(w->fb_c.p, n, w->sb.p, w->mkeys.p, w->mvals.p);
+  LAUNCH_CHECK();
+  MGF_TRY(prim_sort_pairs_u32(ctx, w->mkeys.p, w->skeys.p, w->mvals.p, w->sidx.p, n, 30));
+  Lbvh T;
+  T.nodes = w->lnodes.p; T.leaf_c = w->leaf_c.p; T.leaf_r = w->leaf_r.p; T.leaf_link = w->leaf_link.p; T.visit = w->visit.p;
+  T.skeys = w->skeys.p; T.sidx = w->sidx.p; T.n = n; T.err = w->d_err();
+  if (n >= 2) { k_lbvh_build<<<nblk(n - 1), kBlock, 0, s>>>(T); LAUNCH_CHECK(); }
+  k_lbvh_refit<<<nblk(n), kBlock, 0, s>>>(T, w->fb_c.p, w->fb_r.p);
+  LAUNCH_CHECK();
+  MGF_HIP_TRY(hipEventRecord(w->ev[1], s));
+  // 3. candidates: count, scan, fill
+  TerrainDev M;
+  if (w->terrain && !w->terrain->m.tree.empty()) M = w->terrain->dev(w->d_err());
+  else { memset(&M, 0, sizeof(M)); }
+  MGF_TRY(w->t_cnt.ensure(n + 1, s)); MGF_TRY(w->p_cnt.ensure(n + 1, s)); MGF_TRY(w->t_off.ensure(n + 1, s)); MGF_TRY(w->p_off.ensure(n + 1, s));
+  k_candidates<false><<<nblk(n), kBlock, 0, s>>>(B, n, T, M, 1e-3f, w->t_cnt.p, w->p_cnt.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  LAUNCH_CHECK();
+  MGF_TRY(prim_exclusive_scan_u32(ctx, w->t_cnt.p, w->t_off.p, (size_t)n + 1));
+  MGF_TRY(prim_exclusive_scan_u32(ctx, w->p_cnt.p, w->p_off.p, (size_t)n + 1));
+  uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
+  MGF_HIP_TRY(hipMemcpyAsync(pin, w->t_off.p + n, 4, hipMemcpyDeviceToHost, s));
+  MGF_HIP_TRY(hipMemcpyAsync(pin + 1, w->p_off.p + n, 4, hipMemcpyDeviceToHost, s));
+  MGF_HIP_TRY(hipMemcpyAsync(pin + 2, w->sb.p, sizeof(SceneBounds), hipMemcpyDeviceToHost, s));
+  MGF_HIP_TRY(hipMemcpyAsync(pin + 16, w->d_err(), 4, hipMemcpyDeviceToHost, s));
+  MGF_HIP_TRY(hipStreamSynchronize(s));
+  uint32_t Mt = pin[0], Mp = pin[1];
+  w->stats.n_refits = reinterpret_cast<SceneBounds*>(pin + 2)->n_refits;
+  if (pin[16]) return fail(MGF_ERR_CAPACITY, "BVH traversal stack overflow");
+  w->Mt = Mt; w->Mp = Mp;
+  w->stats.n_terrain_candidates = Mt; w->stats.n_pair_candidates = Mp;
+  MGF_TRY(w->t_cand.ensure(std::max(Mt, 1u), s)); MGF_TRY(w->t_owner.ensure(std::max(Mt, 1u), s));
+  MGF_TRY(w->p_cand.ensure(std::max(Mp, 1u), s)); MGF_TRY(w->p_owner.ensure(std::max(Mp, 1u), s));
+  MGF_TRY(w->t_nc.ensure(std::max(Mt, 1u), s)); MGF_TRY(w->p_nc.ensure(std::max(Mp, 1u), s));
+  MGF_TRY(w->t_pre.ensure(std::max(Mt, 1u), s)); MGF_TRY(w->p_pre.ensure(std::max(Mp, 1u), s));
+  MGF_TRY(w->t_out.ensure(std::max(2 * (size_t)Mt, (size_t)1), s)); MGF_TRY(w->p_out.ensure(std::max(Mp, 1u), s));
+  if (Mt + Mp > 0) {
+    k_candidates<true><<<nblk(n), kBlock, 0, s>>>(B, n, T, M, 1e-3f, nullptr, nullptr, w->t_off.p, w->p_off.p, w->t_cand.p, w->t_owner.p,
+                                                  w->p_cand.p, w->p_owner.p);
+    LAUNCH_CHECK();
+  }
+  MGF_HIP_TRY(hipEventRecord(w->ev[2], s));
+  // 4. narrowphase, one kernel per shape-pair type
+  bool mixed = w->has_sphere && w->has_capsule;
+  if (!mixed) {
+    int k = w->has_capsule ? 1 : 0;
+    MGF_TRY(launch_pairs(w, k, k, nullptr, Mp));
+    MGF_TRY(launch_terrain(w, k, M, nullptr, Mt));
+  } else {
+    size_t mm = std::max(Mt, Mp);
+    MGF_TRY(w->work_lists.ensure(4 * std::max<size_t>(mm, 1), s));
+    MGF_TRY(w->work_counts.ensure(8, s));
+    MGF_HIP_TRY(hipMemsetAsync(w->work_counts.p, 0, 32, s));
+    uint32_t hc[8] = {0};
+    if (Mp) { k_bin_pairs<<<nblk(Mp), kBlock, 0, s>>>(B, Mp, w->p_owner.p, w->p_cand.p, w->work_lists.p, w->work_counts.p); LAUNCH_CHECK(); }
+    MGF_TRY(d2h(ctx, hc, w->work_counts.p, 4));
+    for (int ty = 0; ty < 4; ++ty) MGF_TRY(launch_pairs(w, ty >> 1, ty & 1, w->work_lists.p + (size_t)ty * Mp, hc[ty]));
+    MGF_HIP_TRY(hipStreamSynchronize(s));  // lists are reused for the terrain bins
+    if (Mt) { k_bin_terrain<<<nblk(Mt), kBlock, 0, s>>>(B, Mt, w->t_owner.p, w->work_lists.p, w->work_counts.p + 4); LAUNCH_CHECK(); }
+    MGF_TRY(d2h(ctx, hc + 4, w->work_counts.p + 4, 2));
+    for (int ty = 0; ty < 2; ++ty) MGF_TRY(launch_terrain(w, ty, M, w->work_lists.p + (size_t)ty * Mt, hc[4 + ty]));
+  }
+  MGF_HIP_TRY(hipEventRecord(w->ev[3], s));
+  // 5. constraint numbering in insertion order + ContactConstraint::new
+  MGF_TRY(w->cnt.ensure(n + 1, s)); MGF_TRY(w->tcnt.ensure(n + 1, s)); MGF_TRY(w->base.ensure(n + 1, s)); MGF_TRY(w->tbase.ensure(n + 1, s));
+  k_count_contacts<<<nblk(n), kBlock, 0, s>>>(n, w->t_off.p, w->p_off.p, w->t_nc.p, w->p_nc.p, w->t_pre.p, w->p_pre.p, w->cnt.p, w->tcnt.p);
+  LAUNCH_CHECK();
+  MGF_TRY(prim_exclusive_scan_u32(ctx, w->cnt.p, w->base.p, (size_t)n + 1));
+  MGF_TRY(prim_exclusive_scan_u32(ctx, w->tcnt.p, w->tbase.p, (size_t)n + 1));
+  MGF_HIP_TRY(hipMemcpyAsync(pin, w->base.p + n, 4, hipMemcpyDeviceToHost, s));
+  MGF_HIP_TRY(hipMemcpyAsync(pin + 1, w->tbase.p + n, 4, hipMemcpyDeviceToHost, s));
+  MGF_HIP_TRY(hipStreamSynchronize(s));
+  uint32_t C = pin[0];
+  w->C = C; w->Ct = pin[1];
+  w->stats.n_constraints = C; w->stats.n_terrain_constraints = w->Ct;
+  if (C >= 0x7FFFFFF0u) return fail(MGF_ERR_CAPACITY, "too many constraints");
+  MGF_TRY(w->cons_nat.ensure(std::max(C, 1u), s));
+  if (Mt) {
+    k_setup_terrain<<<nblk(Mt), kBlock, 0, s>>>(B, M, Mt, w->t_owner.p, w->t_nc.p, w->t_pre.p, w->t_out.p, w->base.p, dt, w->params.baumgarte,
+                                                w->params.penetration_slop, w->cons_nat.p);
+    LAUNCH_CHECK();
+  }
+  if (Mp) {
+    k_setup_pairs<<<nblk(Mp), kBlock, 0, s>>>(B, Mp, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_pre.p, w->p_out.p, w->base.p, dt,
+                                              w->params.baumgarte, w->params.penetration_slop, w->cons_nat.p);
+    LAUNCH_CHECK();
+  }
+  MGF_TRY(build_dag(w));
+  MGF_HIP_TRY(hipEventRecord(w->ev[4], s));
+  MGF_HIP_TRY(hipStreamSynchronize(s));
+  float ms;
+  MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[0], w->ev[1])); w->stats.ms_integrate = ms;
+  MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[1], w->ev[2])); w->stats.ms_broadphase = ms;
+  MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[2], w->ev[3])); w->stats.ms_narrowphase = ms;
+  MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[3], w->ev[4])); w->stats.ms_setup = ms;
+  if (stats) *stats = w->stats;
+  return MGF_OK;
+}
+
+// Solver::solve solver.rs:72-78, level-scheduled.
+extern "C" mgf_status mgf_world_solve(mgf_world* w, int32_t iters, mgf_step_stats* stats) {
+  if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
+  if (iters < 0) return fail(MGF_ERR_INVALID, "iters must be >= 0");
+  MGF_TRY(ctx_bind(w->ctx));
+  if (!w->constraints_ready) return fail(MGF_ERR_INVALID, "no constraint list: call mgf_world_build_constraints or mgf_world_set_constraints first");
+  mgf_ctx* ctx = w->ctx;
+  hipStream_t s = ctx->stream;
+  w->stats.iters = (uint32_t)iters;
+  w->stats.solver_kernel_launches = 0;
+  w->stats.ms_solver_kernels = 0.0f;
+  const uint32_t C = w->C;
+  MGF_HIP_TRY(hipEventRecord(w->ev[5], s));
+  const bool timed = w->opt_time_solver_kernels != 0;
+  size_t kev_used = 0;
+  auto tick = [&](void) -> mgf_status {  // event before/after a solver kernel (option)
+    if (!timed) return MGF_OK;
+    if (kev_used == w->kev.size()) { hipEvent_t e; MGF_HIP_TRY(hipEventCreate(&e)); w->kev.push_back(e); }
+    MGF_HIP_TRY(hipEventRecord(w->kev[kev_used++], s));
+    return MGF_OK;
+  };
+  if (C > 0 && iters > 0) {
+    Frontier F = w->frontier();
+    int it_begin = 0;
+    if (!w->solved_once) {
+      // iteration 0 discovers the levels while it solves them
+      uint32_t r = 0;
+      unsigned g0 = std::min<unsigned>(std::max<unsigned>(nblk(C) / 2, 1u), 1024u);
+      uint32_t batch = std::max<uint32_t>(w->last_depth + 4, 8u);
+      uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
+      for (;;) {
+        if (r + batch + 2 > w->lvl_cap) return fail(MGF_ERR_CAPACITY, "constraint DAG deeper than 4096 levels");
+        for (uint32_t k = 0; k < batch; ++k) {
+          MGF_TRY(tick());
+          k_solve<true><<<g0, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->cons_lvl.p, F, r + k, w->succ_a.p, w->succ_b.p, w->indeg.p);
+          LAUNCH_CHECK();
+          MGF_TRY(tick());
+          w->stats.solver_kernel_launches++;
+        }
+        r += batch;
+        MGF_HIP_TRY(hipMemcpyAsync(pin, w->d_tail(), 4, hipMemcpyDeviceToHost, s));
+        MGF_HIP_TRY(hipStreamSynchronize(s));
+        if (pin[0] >= C) break;
+        batch = 8;
+      }
+      w->h_lvl.resize(r + 2);
+      MGF_TRY(d2h(ctx, w->h_lvl.data(), w->lvl_off.p, r + 2));
+      uint32_t depth = 0;
+      while (depth < r && w->h_lvl[depth + 1] > w->h_lvl[depth]) ++depth;
+      if (w->h_lvl[depth] != C) return fail(MGF_ERR_HIP, "internal error: level schedule does not cover the constraint list");
+      w->depth = depth;
+      w->last_depth = depth;
+      w->solved_once = true;
+      w->nimp_synced = false;
+      it_begin = 1;
+    }
+    for (int it = it_begin; it < iters; ++it) {
+      for (uint32_t l = 0; l < w->depth; ++l) {
+        uint32_t sz = w->h_lvl[l + 1] - w->h_lvl[l];
+        MGF_TRY(tick());
+        k_solve<false><<<nblk(sz), kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->cons_lvl.p, F, l, nullptr, nullptr, nullptr);
+        LAUNCH_CHECK();
+        MGF_TRY(tick());
+        w->stats.solver_kernel_launches++;
+      }
+      w->nimp_synced = false;
+    }
+  }
+  MGF_HIP_TRY(hipEventRecord(w->ev[6], s));
+  MGF_HIP_TRY(hipStreamSynchronize(s));
+  float ms;
+  MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[5], w->ev[6]));
+  w->stats.ms_solve = ms;
+  w->stats.n_levels = w->depth;
+  if (timed) {
+    float total = 0.0f;
+    for (size_t k = 0; k + 1 < kev_used; k += 2) { MGF_HIP_TRY(hipEventElapsedTime(&ms, w->kev[k], w->kev[k + 1])); total += ms; }
+    w->stats.ms_solver_kernels = total;
+  }
+  if (stats) *stats = w->stats;
+  return MGF_OK;
+}
+
+extern "C" mgf_status mgf_world_step(mgf_world* w, float dt, int32_t iters, mgf_step_stats* stats) {
+  MGF_TRY(mgf_world_build_constraints(w, dt, nullptr));
+  MGF_TRY(mgf_world_solve(w, iters, nullptr));
+  float ms;
+  MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[0], w->ev[6]));
+  w->stats.ms_total = ms;
+  if (stats) *stats = w->stats;
+  return MGF_OK;
+}
+
+static void crec_to_public(const CRec& c, mgf_constraint* o) {
+  o->a = (int32_t)c.a;
+  o->b = c.b == kNone ? -1 : (int32_t)c.b;
+  o->n_contacts = 1;
+  o->normal = {c.n[0], c.n[1], c.n[2]}; o->t0 = {c.t0[0], c.t0[1], c.t0[2]}; o->t1 = {c.t1[0], c.t1[1], c.t1[2]};
+  o->ra = {c.ra[0], c.ra[1], c.ra[2]}; o->rb = {c.rb[0], c.rb[1], c.rb[2]};
+  o->bias = c.bias; o->normal_mass = c.nmass; o->tangent_mass0 = c.tmass0; o->tangent_mass1 = c.tmass1;
+  o->normal_impulse = c.nimp; o->friction = c.friction;
+}
+extern "C" mgf_status mgf_world_read_constraints(mgf_world* w, mgf_constraint* out, int64_t cap, int64_t* count) {
+  if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
+  MGF_TRY(ctx_bind(w->ctx));
+  if (count) *count = w->C;
+  if (!out) return MGF_OK;
+  if ((int64_t)w->C > cap) return fail(MGF_ERR_CAPACITY, "constraint buffer too small");
+  if (w->C == 0) return MGF_OK;
+  if (!w->nimp_synced) {
+    k_unpermute_nimp<<<nblk(w->C), kBlock, 0, w->ctx->stream>>>(w->C, w->order.p, w->cons_lvl.p, w->cons_nat.p);
+    LAUNCH_CHECK();
+    w->nimp_synced = true;
+  }
+  std::vector<CRec> h(w->C);
+  MGF_TRY(d2h(w->ctx, h.data(), w->cons_nat.p, w->C));
+  for (uint32_t i = 0; i < w->C; ++i) crec_to_public(h[i], &out[i]);
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_world_set_constraints(mgf_world* w, const mgf_constraint* cons, int64_t n) {
+  if (!w || (n && !cons)) return fail(MGF_ERR_INVALID, "NULL argument");
+  MGF_TRY(ctx_bind(w->ctx));
+  if (n < 0 || n >= 0x7FFFFFF0ll) return fail(MGF_ERR_INVALID, "bad constraint count");
+  std::vector<CRec> h((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    const mgf_constraint& c = cons[i];
+    if (c.n_contacts != 1) return fail(MGF_ERR_INVALID, "only single-contact manifolds are supported on this path");
+    if (c.a < 0 || (uint32_t)c.a >= w->n) return fail(MGF_ERR_STATIC_REF, "obj_a must be a Dynamic body in range");
+    if (c.b >= 0 && (uint32_t)c.b >= w->n) return fail(MGF_ERR_INVALID, "obj_b out of range");
+    if (c.a == c.b) return fail(MGF_ERR_INVALID, "a constraint needs two different bodies");
+    CRec r;
+    memset(&r, 0, sizeof(r));
+    r.a = (uint32_t)c.a; r.b = c.b < 0 ? kNone : (uint32_t)c.b;
+    const float* src[5] = {&c.normal.x, &c.t0.x, &c.t1.x, &c.ra.x, &c.rb.x};
+    float* dst[5] = {r.n, r.t0, r.t1, r.ra, r.rb};
+    for (int k = 0; k < 5; ++k) memcpy(dst[k], src[k], 12);
+    r.bias = c.bias; r.nmass = c.normal_mass; r.tmass0 = c.tangent_mass0; r.tmass1 = c.tangent_mass1; r.nimp = c.normal_impulse;
+    r.friction = c.friction;
+    h[(size_t)i] = r;
+  }
+  w->C = (uint32_t)n; w->Ct = 0;
+  MGF_TRY(w->cons_nat.ensure(std::max<size_t>((size_t)n, 1), w->ctx->stream));
+  MGF_TRY(h2d(w->ctx, w->cons_nat.p, h.data(), (size_t)n));
+  memset(&w->stats, 0, sizeof(w->stats));
+  w->stats.n_bodies = w->n; w->stats.n_constraints = w->C;
+  MGF_TRY(build_dag(w));
+  MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
+  return MGF_OK;
+}

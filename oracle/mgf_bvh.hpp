@@ -190,16 +190,19 @@ struct BVH {
   template <class F>
   void query(const AABB& arg_bounds, F&& cb) const {
     if (empty()) return;
-    std::vector<size_t> stack;
-    stack.reserve(64);
-    stack.push_back(root);
-    while (!stack.empty()) {
-      size_t top = stack.back();
-      stack.pop_back();
+    // SmallVec<[usize; 64]> bvh.rs:294 — inline 64, heap spill beyond.
+    size_t inl[64];
+    std::vector<size_t> spill;
+    size_t sp = 0;
+    auto push = [&](size_t v) { if (sp < 64) inl[sp] = v; else spill.push_back(v); ++sp; };
+    auto pop = [&]() -> size_t { --sp; if (sp < 64) return inl[sp]; size_t v = spill.back(); spill.pop_back(); return v; };
+    push(root);
+    while (sp > 0) {
+      size_t top = pop();
       const Node& n = pool[top];
       if (aabb_overlaps(arg_bounds, n.bounds)) {
         if (n.is_leaf) cb(n.leaf);
-        else { stack.push_back(n.child1); stack.push_back(n.child2); }
+        else { push(n.child1); push(n.child2); }
       }
     }
   }
