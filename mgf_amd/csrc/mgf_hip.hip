@@ -982,7 +982,7 @@ extern "C" mgf_status mgf_world_solve(mgf_world* w, int32_t iters, mgf_step_stat
       // iteration 0 discovers the levels while it solves them
       uint32_t r = 0;
       unsigned g0 = std::min<unsigned>(std::max<unsigned>(nblk(C) / 2, 1u), 1024u);
-      uint32_t batch = std::max<uint32_t>(w->last_depth + 4, 8u);
+      uint32_t batch = std::max<uint32_t>(w->last_depth + 2, 8u);
       uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
       for (;;) {
         if (r + batch + 2 > w->lvl_cap) return fail(MGF_ERR_CAPACITY, "constraint DAG deeper than 4096 levels");
@@ -994,10 +994,11 @@ extern "C" mgf_status mgf_world_solve(mgf_world* w, int32_t iters, mgf_step_stat
           w->stats.solver_kernel_launches++;
         }
         r += batch;
-        MGF_HIP_TRY(hipMemcpyAsync(pin, w->d_tail(), 4, hipMemcpyDeviceToHost, s));
+        // level r = [lvl_off[r], lvl_off[r+1]) was queued by the last launch; empty means every level ran
+        MGF_HIP_TRY(hipMemcpyAsync(pin, w->lvl_off.p + r, 8, hipMemcpyDeviceToHost, s));
         MGF_HIP_TRY(hipStreamSynchronize(s));
-        if (pin[0] >= C) break;
-        batch = 8;
+        if (pin[0] == pin[1]) break;
+        batch = 4;
       }
       w->h_lvl.resize(r + 2);
       MGF_TRY(d2h(ctx, w->h_lvl.data(), w->lvl_off.p, r + 2));

@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 --kernel-trace database (rocpd sqlite) per kernel.
+
+    python tools/rocprof_summary.py gpurun_out/prof_x/bench_results.db [steps] > profiles/rNN_kernel_stats.txt
+"""
+import json
+import sqlite3
+import sys
+
+
+def summarise(path):
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start), "
+                      "max(vgpr_count), max(sgpr_count), max(scratch_size), max(lds_size) from kernels group by name "
+                      "order by 3 desc").fetchall()
+    return [dict(name=r[0], calls=r[1], total_us=r[2] / 1e3, avg_us=r[3] / 1e3, min_us=r[4] / 1e3, max_us=r[5] / 1e3,
+                 vgpr=r[6], sgpr=r[7], scratch=r[8], lds=r[9]) for r in rows]
+
+
+def main():
+    path = sys.argv[1]
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    rows = summarise(path)
+    tot = sum(r["total_us"] for r in rows)
+    print(f"# rocprofv3 --kernel-trace summary of {path}")
+    print(f"# total kernel time {tot / 1e3:.3f} ms" + (f" over {steps} ticks = {tot / 1e3 / steps:.3f} ms/tick" if steps else ""))
+    print(f"{'kernel':70s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>9s} {'min_us':>8s} {'max_us':>9s} {'%':>6s} {'vgpr':>5s} {'scratch':>7s}")
+    for r in rows:
+        print(f"{r['name'][:70]:70s} {r['calls']:7d} {r['total_us'] / 1e3:10.3f} {r['avg_us']:9.2f} {r['min_us']:8.2f} "
+              f"{r['max_us']:9.2f} {100 * r['total_us'] / tot:6.1f} {r['vgpr'] or 0:5d} {r['scratch'] or 0:7d}")
+    if "--json" in sys.argv:
+        print(json.dumps(rows))
+
+
+if __name__ == "__main__":
+    main()
