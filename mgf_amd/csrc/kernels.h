@@ -2,8 +2,9 @@
 //
 //   k_integrate        RigidBodyVec::complete_motion + integrate (physics.rs:222-269), swept AABB
 //                      (bounds.rs:60-68), fat-AABB refit test (world.rs:234-238)
-//   k_morton / k_lbvh_build / k_lbvh_refit
-//                      per-tick linear BVH over the fat AABBs (replaces the sequentially mutated
+//   k_scene_bounds / k_morton / k_lbvh_low / k_lbvh_top
+//                      per-tick linear BVH over the fat AABBs: Morton sort + implicit complete tree
+//                      built by reductions, top 10 levels staged in LDS (replaces the sequentially mutated
 //                      AVL tree of bvh.rs for the world broadphase; the hit SET is identical
 //                      because acceptance is the reference's own predicate)
 //   k_candidates<FILL> BVH::query (bvh.rs:283-310) for every body at once: mesh-BVH DFS in the
@@ -14,11 +15,14 @@
 //                      Manifold::from + ContactConstraint::new (manifold.rs:120-148, solver.rs:101-191)
 //   k_adj_* / k_chain / k_frontier0
 //                      order-preserving dependency DAG of the constraint list
-//   k_solve<FIRST>     ContactConstraint::solve (solver.rs:203-252) for one DAG level
+//   k_solve            ContactConstraint::solve (solver.rs:203-252) for one frontier of the unrolled
+//                      (iterations x constraints) dependency graph
 //
 // All f32 arithmetic follows the reference's operation order; the TU is built with
 // -ffp-contract=off.
 #pragma once
+#include <stddef.h>
+
 #include "dev_geom.h"
 #include "host_bvh.h"
 
@@ -72,7 +76,6 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
                                                       int do_integrate, SceneBounds* sb) {
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   bool live = i < n;
-  V3 fc = mk3(0, 0, 0);
   bool refit = false;
   if (live) {
     float4 xw = B.x[i];
@@ -118,29 +121,38 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
         B.fb_r[i] = mk4(fb.r, 0.0f);
         refit = true;
       }
-      fc = fb.c;
     } else if (do_complete) {
       B.einfo[i] = mk4(x + xyz(dl), B.einfo[i].w);
     }
     if (do_complete) B.x[i] = mk4(x, 0.0f);
   }
   if (!do_integrate || sb == nullptr) return;
-  // scene bounds of the fat-box centres (for Morton quantisation) + refit count: wave reduce, one atomic per wave
-  int lo[3], hi[3];
-  for (int k = 0; k < 3; ++k) {
-    int o = live ? f_ord(at(fc, k)) : 0x7FFFFFFF;
-    int oh = live ? f_ord(at(fc, k)) : (int)0x80000000;
-    for (int off = 32; off > 0; off >>= 1) {
-      o = min(o, __shfl_xor(o, off));
-      oh = max(oh, __shfl_xor(oh, off));
-    }
-    lo[k] = o; hi[k] = oh;
+  // refit count: one atomic per block
+  int nref = __syncthreads_count(refit ? 1 : 0);
+  if (threadIdx.x == 0 && nref) atomicAdd(&sb->n_refits, (uint32_t)nref);
+}
+
+// Scene bounds of the fat-box centres (Morton quantisation): grid-stride, block reduce in LDS,
+// one atomic per block and axis.
+__global__ __launch_bounds__(kBlock) void k_scene_bounds(const float4* fb_c, uint32_t n, SceneBounds* sb) {
+  int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    float4 c = fb_c[i];
+    int o[3] = {f_ord(c.x), f_ord(c.y), f_ord(c.z)};
+    for (int k = 0; k < 3; ++k) { lo[k] = min(lo[k], o[k]); hi[k] = max(hi[k], o[k]); }
   }
-  unsigned long long m = __ballot(refit);
-  if ((threadIdx.x & 63) == 0) {
-    for (int k = 0; k < 3; ++k) { atomicMin(&sb->lo[k], lo[k]); atomicMax(&sb->hi[k], hi[k]); }
-    uint32_t c = (uint32_t)__popcll(m);
-    if (c) atomicAdd(&sb->n_refits, c);
+  __shared__ int s_lo[3][kBlock / 64], s_hi[3][kBlock / 64];
+  for (int k = 0; k < 3; ++k) {
+    int a = lo[k], b = hi[k];
+    for (int off = 32; off > 0; off >>= 1) { a = min(a, __shfl_xor(a, off)); b = max(b, __shfl_xor(b, off)); }
+    if ((threadIdx.x & 63) == 0) { s_lo[k][threadIdx.x >> 6] = a; s_hi[k][threadIdx.x >> 6] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    int k = threadIdx.x, a = s_lo[k][0], b = s_hi[k][0];
+    for (int w = 1; w < kBlock / 64; ++w) { a = min(a, s_lo[k][w]); b = max(b, s_hi[k][w]); }
+    atomicMin(&sb->lo[k], a);
+    atomicMax(&sb->hi[k], b);
   }
 }
 
@@ -149,11 +161,11 @@ __global__ __launch_bounds__(kBlock) void k_refresh_einfo(Bodies B, uint32_t n) 
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i < n) B.einfo[i] = mk4(xyz(B.x[i]) + xyz(B.delta[i]), B.einfo[i].w);
 }
-__global__ void k_reset_step(SceneBounds* sb, uint32_t* tail, uint32_t* done, uint32_t* err) {
+__global__ void k_reset_step(SceneBounds* sb, uint32_t* err) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     for (int k = 0; k < 3; ++k) { sb->lo[k] = 0x7FFFFFFF; sb->hi[k] = (int)0x80000000; }
     sb->n_refits = 0; sb->pad = 0;
-    *tail = 0; *done = 0; *err = 0;
+    *err = 0;
   }
 }
 
@@ -184,102 +196,71 @@ __global__ __launch_bounds__(kBlock) void k_morton(const float4* fb_c, uint32_t 
   vals[i] = i;
 }
 
-// Fat BVH2 node, 64 B: both children's boxes live in the parent so one fetch serves both tests.
-struct LNode {
-  float4 a;  // lo(L).xyz, child L   (bit31 set = leaf at sorted position)
-  float4 b;  // hi(L).xyz, child R
-  float4 c;  // lo(R).xyz, parent link (node << 1 | side), kNone for the root
-  float4 d;  // hi(R).xyz, -
-};
+// Linear BVH as an implicit complete binary tree over the Morton-sorted leaves (1-based heap:
+// node k has children 2k and 2k+1, leaves are positions [npad, 2*npad)).  Built by plain
+// reductions (no atomics, no fences), traversed without a stack, top levels staged in LDS.
+struct HNode { float4 lo, hi; };  // min.xyz / max.xyz of the subtree's fat boxes
 struct Lbvh {
-  LNode* nodes;        // n-1 internal nodes, node 0 = root
+  HNode* nodes;        // internal nodes [1, npad); nodes[0] unused
   float4* leaf_c;      // sorted order: fat c.xyz, body index
   float4* leaf_r;      //               fat r.xyz, -
-  uint32_t* leaf_link; // parent link of each sorted leaf
-  uint32_t* visit;     // arrival counters for the bottom-up refit
-  const uint32_t* skeys;
   const uint32_t* sidx;
-  uint32_t n;
-  uint32_t* err;       // set to 2 if a traversal stack overflows
+  uint32_t n;          // live leaves
+  uint32_t npad;       // leaves padded to a power of two (>= 2)
+  uint32_t* err;
 };
+constexpr int kLdsNodes = 1024;  // heap nodes [1, 1024) = 10 levels, 32 KB
 
-__device__ __forceinline__ int lbvh_delta(const uint32_t* keys, int n, int i, int j) {
-  if (j < 0 || j >= n) return -1;
-  uint32_t a = keys[i], b = keys[j];
-  if (a == b) return 32 + __clz((uint32_t)i ^ (uint32_t)j);
-  return __clz(a ^ b);
-}
-
-// Karras 2012: one thread per internal node.
-__global__ __launch_bounds__(kBlock) void k_lbvh_build(Lbvh T) {
-  int i = blockIdx.x * kBlock + threadIdx.x;
-  int n = (int)T.n;
-  if (i >= n - 1) return;
-  const uint32_t* K = T.skeys;
-  int d = (lbvh_delta(K, n, i, i + 1) - lbvh_delta(K, n, i, i - 1)) >= 0 ? 1 : -1;
-  int dmin = lbvh_delta(K, n, i, i - d);
-  int lmax = 2;
-  while (lbvh_delta(K, n, i, i + lmax * d) > dmin) lmax <<= 1;
-  int l = 0;
-  for (int t = lmax >> 1; t >= 1; t >>= 1)
-    if (lbvh_delta(K, n, i, i + (l + t) * d) > dmin) l += t;
-  int j = i + l * d;
-  int dnode = lbvh_delta(K, n, i, j);
-  int s = 0;
-  for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
-    if (lbvh_delta(K, n, i, i + (s + t) * d) > dnode) s += t;
-    if (t == 1) break;
+// One block per 256 consecutive leaves: leaf records + the 8 levels above them.
+__global__ __launch_bounds__(kBlock) void k_lbvh_low(Lbvh T, const float4* fb_c, const float4* fb_r) {
+  __shared__ float s_lo[3][kBlock], s_hi[3][kBlock];
+  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  V3 lo = mk3(kInf, kInf, kInf), hi = mk3(-kInf, -kInf, -kInf);
+  if (p < T.n) {
+    uint32_t body = T.sidx[p];
+    V3 c = xyz(fb_c[body]), r = xyz(fb_r[body]);
+    T.leaf_c[p] = mk4(c, u2f(body));
+    T.leaf_r[p] = mk4(r, 0.0f);
+    lo = c - r; hi = c + r;
   }
-  int gamma = i + s * d + min(d, 0);
-  int lo = min(i, j), hi = max(i, j);
-  uint32_t L = (lo == gamma) ? (0x80000000u | (uint32_t)gamma) : (uint32_t)gamma;
-  uint32_t R = (hi == gamma + 1) ? (0x80000000u | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
-  T.nodes[i].a.w = u2f(L);
-  T.nodes[i].b.w = u2f(R);
-  if (i == 0) T.nodes[0].c.w = u2f(kNone);
-  uint32_t linkL = ((uint32_t)i << 1), linkR = ((uint32_t)i << 1) | 1u;
-  if (L & 0x80000000u) T.leaf_link[gamma] = linkL; else T.nodes[gamma].c.w = u2f(linkL);
-  if (R & 0x80000000u) T.leaf_link[gamma + 1] = linkR; else T.nodes[gamma + 1].c.w = u2f(linkR);
-  T.visit[i] = 0;
+  int t = threadIdx.x;
+  s_lo[0][t] = lo.x; s_lo[1][t] = lo.y; s_lo[2][t] = lo.z;
+  s_hi[0][t] = hi.x; s_hi[1][t] = hi.y; s_hi[2][t] = hi.z;
+  __syncthreads();
+  // level widths 128, 64, ..., 1; the node of width-w entry e is heap index (npad + block_base) / (256 / w) + e
+  uint32_t first = T.npad + blockIdx.x * kBlock;
+  for (int w = kBlock / 2; w >= 1; w >>= 1) {
+    first >>= 1;
+    float l[3], h[3];
+    if (t < w) {
+      for (int k = 0; k < 3; ++k) { l[k] = fminf(s_lo[k][2 * t], s_lo[k][2 * t + 1]); h[k] = fmaxf(s_hi[k][2 * t], s_hi[k][2 * t + 1]); }
+    }
+    __syncthreads();
+    if (t < w) {
+      for (int k = 0; k < 3; ++k) { s_lo[k][t] = l[k]; s_hi[k][t] = h[k]; }
+      if (first + t >= 1 && first + t < T.npad) {
+        HNode nd; nd.lo = make_float4(l[0], l[1], l[2], 0.0f); nd.hi = make_float4(h[0], h[1], h[2], 0.0f);
+        T.nodes[first + t] = nd;
+      }
+    }
+    __syncthreads();
+    if (first <= 1) break;  // reached the root inside this block (npad <= 256)
+  }
 }
-
-__device__ __forceinline__ void lnode_store_child_box(LNode* nd, int side, V3 lo, V3 hi) {
-  float* p = reinterpret_cast<float*>(nd);
-  int o = side ? 8 : 0;
-  p[o + 0] = lo.x; p[o + 1] = lo.y; p[o + 2] = lo.z;
-  p[o + 4] = hi.x; p[o + 5] = hi.y; p[o + 6] = hi.z;
-}
-__device__ __forceinline__ float ld_agent(const float* p) {
-  return u2f(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-
-// Leaves in sorted order; bottom-up union with one arrival counter per internal node.
-__global__ __launch_bounds__(kBlock) void k_lbvh_refit(Lbvh T, const float4* fb_c, const float4* fb_r) {
-  uint32_t k = blockIdx.x * kBlock + threadIdx.x;
-  if (k >= T.n) return;
-  uint32_t body = T.sidx[k];
-  V3 c = xyz(fb_c[body]), r = xyz(fb_r[body]);
-  T.leaf_c[k] = mk4(c, u2f(body));
-  T.leaf_r[k] = mk4(r, 0.0f);
-  if (T.n < 2) return;
-  V3 lo = c - r, hi = c + r;
-  uint32_t link = T.leaf_link[k];
-  while (link != kNone) {
-    uint32_t node = link >> 1;
-    int side = (int)(link & 1u);
-    LNode* nd = &T.nodes[node];
-    lnode_store_child_box(nd, side, lo, hi);
-    __threadfence();  // release my half before announcing arrival
-    uint32_t old = atomicAdd(&T.visit[node], 1u);
-    if (old == 0) return;  // sibling subtree not finished: it will carry on
-    __threadfence();  // acquire the sibling's half
-    const float* p = reinterpret_cast<const float*>(nd);
-    int o = side ? 0 : 8;  // the other side
-    V3 olo = mk3(ld_agent(p + o), ld_agent(p + o + 1), ld_agent(p + o + 2));
-    V3 ohi = mk3(ld_agent(p + o + 4), ld_agent(p + o + 5), ld_agent(p + o + 6));
-    lo = mk3(fminf(lo.x, olo.x), fminf(lo.y, olo.y), fminf(lo.z, olo.z));
-    hi = mk3(fmaxf(hi.x, ohi.x), fmaxf(hi.y, ohi.y), fmaxf(hi.z, ohi.z));
-    link = f2u(ld_agent(p + 11));  // c.w
+// Single block: the levels above the per-block roots (heap indices < npad / 256).
+__global__ __launch_bounds__(1024) void k_lbvh_top(Lbvh T) {
+  uint32_t m = T.npad / kBlock;  // number of per-block roots, heap indices [m, 2m)
+  for (uint32_t w = m / 2; w >= 1; w >>= 1) {  // nodes [w, 2w)
+    for (uint32_t e = threadIdx.x; e < w; e += blockDim.x) {
+      uint32_t k = w + e;
+      HNode a = T.nodes[2 * k], b = T.nodes[2 * k + 1];
+      HNode nd;
+      nd.lo = make_float4(fminf(a.lo.x, b.lo.x), fminf(a.lo.y, b.lo.y), fminf(a.lo.z, b.lo.z), 0.0f);
+      nd.hi = make_float4(fmaxf(a.hi.x, b.hi.x), fmaxf(a.hi.y, b.hi.y), fmaxf(a.hi.z, b.hi.z), 0.0f);
+      T.nodes[k] = nd;
+    }
+    __syncthreads();
+    if (w == 1) break;
   }
 }
 
@@ -320,41 +301,38 @@ __device__ __forceinline__ void terrain_traverse(const TerrainDev& M, const Box&
   }
 }
 
+// Stackless DFS over the implicit tree.  `top` = LDS copy of nodes [0, kLdsNodes).
 template <class F>
-__device__ __forceinline__ void lbvh_traverse(const Lbvh& T, uint32_t i, const Box& q, float pad_abs, F&& emit) {
+__device__ __forceinline__ void lbvh_traverse(const Lbvh& T, const HNode* top, uint32_t i, const Box& q, float pad_abs, F&& emit) {
   if (T.n < 2) return;  // a single body has no partner
   // Inner nodes hold min/max unions: test them against a query padded well past f32 rounding so the
-  // exact (centre, half-extent) acceptance test below is never pre-empted.
+  // exact (centre, half-extent) acceptance test at the leaves is never pre-empted.
   float pad = pad_abs + 1e-5f * (fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z);
   V3 qlo = q.c - q.r - mk3(pad, pad, pad), qhi = q.c + q.r + mk3(pad, pad, pad);
-  uint32_t stack[kStack];
-  int sp = 0;
-  stack[sp++] = 0;
-  while (sp > 0) {
-    uint32_t node = stack[--sp];
-    const LNode* nd = &T.nodes[node];
-    float4 a = nd->a, b = nd->b, c = nd->c, d = nd->d;
-    uint32_t ch[2] = {f2u(a.w), f2u(b.w)};
-    bool ov[2];
-    ov[0] = qlo.x <= b.x && a.x <= qhi.x && qlo.y <= b.y && a.y <= qhi.y && qlo.z <= b.z && a.z <= qhi.z;
-    ov[1] = qlo.x <= d.x && c.x <= qhi.x && qlo.y <= d.y && c.y <= qhi.y && qlo.z <= d.z && c.z <= qhi.z;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      if (!ov[s]) continue;
-      if (ch[s] & 0x80000000u) {
-        uint32_t k = ch[s] & 0x7FFFFFFFu;
-        float4 lc = T.leaf_c[k];
+  const uint32_t npad = T.npad;
+  uint32_t k = 1;
+  for (;;) {
+    bool descend = false;
+    if (k < npad) {
+      float4 lo, hi;
+      if (k < (uint32_t)kLdsNodes) { lo = top[k].lo; hi = top[k].hi; }
+      else { lo = T.nodes[k].lo; hi = T.nodes[k].hi; }
+      descend = qlo.x <= hi.x && lo.x <= qhi.x && qlo.y <= hi.y && lo.y <= qhi.y && qlo.z <= hi.z && lo.z <= qhi.z;
+    } else {
+      uint32_t p = k - npad;
+      if (p < T.n) {
+        float4 lc = T.leaf_c[p];
         uint32_t j = f2u(lc.w);
         if (j < i) {  // world.rs:266
-          Box fb; fb.c = xyz(lc); fb.r = xyz(T.leaf_r[k]);
+          Box fb; fb.c = xyz(lc); fb.r = xyz(T.leaf_r[p]);
           if (box_overlaps(q, fb)) emit(j);  // the reference's own acceptance test (bvh.rs:297)
         }
-      } else if (sp < kStack) {
-        stack[sp++] = ch[s];
-      } else if (T.err) {
-        *T.err = 2u;
       }
     }
+    if (descend) { k = 2 * k; continue; }
+    k = k + 1;
+    k >>= __builtin_ctz(k);  // climb past finished right subtrees, step to the next sibling
+    if (k == 1) break;
   }
 }
 
@@ -364,6 +342,12 @@ __global__ __launch_bounds__(kBlock) void k_candidates(Bodies B, uint32_t n, Lbv
                                                        uint32_t* t_cnt, uint32_t* p_cnt, const uint32_t* t_off,
                                                        const uint32_t* p_off, uint32_t* t_cand, uint32_t* t_owner,
                                                        uint32_t* p_cand, uint32_t* p_owner) {
+  __shared__ HNode s_top[kLdsNodes];
+  {
+    uint32_t lim = T.n >= 2 ? min((uint32_t)kLdsNodes, T.npad) : 0u;
+    for (uint32_t e = threadIdx.x; e < lim; e += kBlock) s_top[e] = T.nodes[e];
+    __syncthreads();
+  }
   uint32_t k = blockIdx.x * kBlock + threadIdx.x;
   if (k >= n) return;
   uint32_t i = T.n >= 1 ? T.sidx[k] : k;  // walk bodies in Morton order: neighbouring lanes share tree paths
@@ -377,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void k_candidates(Bodies B, uint32_t n, Lbv
     ++nt;
   });
   if (i != 0) {  // world.rs:256
-    lbvh_traverse(T, i, q, pad, [&](uint32_t j) {
+    lbvh_traverse(T, s_top, i, q, pad, [&](uint32_t j) {
       if (FILL) { p_cand[pb + np] = j; p_owner[pb + np] = i; }
       ++np;
     });
@@ -504,11 +488,17 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(uint32_t n, const uin
 struct CRec {
   uint32_t a, b;       // body indices; b = kNone for RigidBodyRef::Static
   float n[3], t0[3], t1[3], ra[3], rb[3];
-  float bias, nmass, tmass0, tmass1, nimp;
+  float bias, nmass, tmass0, tmass1;
+  uint32_t succ_a;     // next constraint on body a / b in insertion order (successor word, see k_chain)
+  float nimp;          // ContactState::normal_impulse            (word 22: 8-byte aligned with round)
+  uint32_t round;      // solver iterations already applied in the current Solver::solve call
+  uint32_t succ_b;
+  uint32_t indeg;      // predecessors still pending for the next round (atomics)
+  uint32_t indeg0;     // predecessors inside one iteration (in-degree of round 0)
   float friction;      // dead state in the reference (solver.rs:223-226), kept for read-back
-  float pad;
+  uint32_t pad[4];
 };
-static_assert(sizeof(CRec) == 96, "CRec must be 96 bytes");
+static_assert(sizeof(CRec) == 128, "CRec is one 128-byte line");
 
 struct BodyDyn { V3 v, w; float im; M3 I; };
 __device__ __forceinline__ BodyDyn load_dyn(const float4* srec, uint32_t i) {
@@ -549,7 +539,8 @@ __device__ __forceinline__ CRec make_constraint(uint32_t ia, uint32_t ib, const 
   c.tmass1 = 1.0f / (A.im + dot(ra_ct, A.I * ra_ct) + Bd.im + dot(rb_ct, Bd.I * rb_ct));
   c.bias = bias;
   c.nimp = 0.0f;
-  c.pad = 0.0f;
+  c.round = 0; c.succ_a = kNone; c.succ_b = kNone; c.indeg = 0; c.indeg0 = 0;
+  c.pad[0] = c.pad[1] = c.pad[2] = c.pad[3] = 0;
   st3(c.n, normal); st3(c.t0, t0); st3(c.t1, t1); st3(c.ra, ra); st3(c.rb, rb);
   return c;
 }
@@ -558,16 +549,18 @@ __device__ __forceinline__ void store_crec(CRec* dst, const CRec& c) {
   const float4* s = reinterpret_cast<const float4*>(&c);
   float4* d = reinterpret_cast<float4*>(dst);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) d[k] = s[k];
+  for (int k = 0; k < 8; ++k) d[k] = s[k];
 }
+// words 0..27: everything ContactConstraint::solve needs plus round and the successor words
 __device__ __forceinline__ CRec load_crec(const CRec* src) {
   CRec c;
   const float4* s = reinterpret_cast<const float4*>(src);
   float4* d = reinterpret_cast<float4*>(&c);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) d[k] = s[k];
+  for (int k = 0; k < 7; ++k) d[k] = s[k];
   return c;
 }
+static_assert(offsetof(CRec, nimp) == 88 && offsetof(CRec, round) == 92 && offsetof(CRec, succ_b) == 96, "CRec layout");
 
 __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, uint32_t m, const uint32_t* p_owner, const uint32_t* p_cand,
                                                         const uint32_t* p_nc, const uint32_t* p_pre, const NContact* p_in,
@@ -628,52 +621,68 @@ __global__ __launch_bounds__(kBlock) void k_adj_count(const CRec* cons, uint32_t
   if (b != kNone) atomicAdd(&deg[b], 1u);
 }
 
-__global__ __launch_bounds__(kBlock) void k_chain(uint32_t n, const uint32_t* adj_off, uint32_t* adj_list, uint32_t* succ_a,
-                                                  uint32_t* succ_b, uint32_t* indeg) {
+// Successor word: bits 0..29 constraint id, bit 30 = successor has two dynamic bodies (its
+// per-round in-degree is 2, else 1), bit 31 = the link wraps to the next solver iteration.
+constexpr uint32_t kSuccId = 0x3FFFFFFFu, kSuccTwo = 0x40000000u, kSuccWrap = 0x80000000u;
+
+__global__ __launch_bounds__(kBlock) void k_chain(uint32_t n, CRec* cons, const uint32_t* adj_off, uint32_t* adj_list) {
   uint32_t x = blockIdx.x * kBlock + threadIdx.x;
   if (x >= n) return;
   uint32_t lo = adj_off[x], hi = adj_off[x + 1];
+  if (lo == hi) return;
   for (uint32_t a = lo + 1; a < hi; ++a) {  // ascending constraint id = insertion order
     uint32_t v = adj_list[a];
     uint32_t b = a;
     while (b > lo && adj_list[b - 1] > v) { adj_list[b] = adj_list[b - 1]; --b; }
     adj_list[b] = v;
   }
-  for (uint32_t a = lo; a + 1 < hi; ++a) {
-    uint32_t u = adj_list[a], w = adj_list[a + 1];
-    if (u & 1u) succ_b[u >> 1] = w >> 1; else succ_a[u >> 1] = w >> 1;
-    atomicAdd(&indeg[w >> 1], 1u);
+  for (uint32_t a = lo; a < hi; ++a) {
+    bool last = (a + 1 == hi);
+    uint32_t u = adj_list[a], w = adj_list[last ? lo : a + 1];
+    uint32_t wid = w >> 1;
+    uint32_t word = wid | (cons[wid].b != kNone ? kSuccTwo : 0u) | (last ? kSuccWrap : 0u);
+    if (u & 1u) cons[u >> 1].succ_b = word; else cons[u >> 1].succ_a = word;
+    if (!last) atomicAdd(&cons[wid].indeg0, 1u);  // predecessors inside one iteration
   }
 }
 
+// The solver walks the dependency graph of the WHOLE Solver::solve call (iters x constraints,
+// solver.rs:72-78) as one frontier process: a constraint's round k may run once the previous
+// constraint on each of its bodies has run (its round k, or round k-1 across the wrap).  Every
+// launch solves the current frontier and appends the constraints it released.  This is exactly the
+// sequential Gauss-Seidel result; rounds of different constraints overlap, so the number of
+// launches is the depth of the unrolled graph (about half of iters x per-iteration depth).
 struct Frontier {
-  uint32_t* order;     // constraint ids in level order
-  uint32_t* lvl_off;   // lvl_off[r] .. lvl_off[r+1] = level r
-  uint32_t* tail;      // append cursor into order
-  uint32_t* done;      // finished-block counter
+  uint32_t* order;     // frontier lists, appended launch after launch (capacity iters * C)
+  uint32_t* lvl_off;   // lvl_off[r] = start of launch r's list
+  uint32_t* cnt;       // 3 rotating list-size counters: launch r reads cnt[r%3], appends under cnt[(r+1)%3],
+                       // clears cnt[(r+2)%3] (nobody touches it during launch r) - no fences, no last-block logic
 };
 
-__device__ __forceinline__ void publish_level(const Frontier& F, uint32_t slot) {
-  // Last block to finish records where the next level ends.
-  __shared__ uint32_t s_last;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    uint32_t d = atomicAdd(F.done, 1u);
-    s_last = (d == gridDim.x - 1) ? 1u : 0u;
+// Start of a Solver::solve call: reset round / in-degree of every record; launch 0's list =
+// constraints without predecessors in iteration 0.  Block-aggregated append.
+__global__ __launch_bounds__(kBlock) void k_frontier0(uint32_t C, CRec* cons, Frontier F) {
+  __shared__ uint32_t s_n, s_base;
+  for (uint32_t c0 = blockIdx.x * kBlock; c0 < C; c0 += gridDim.x * kBlock) {
+    uint32_t c = c0 + threadIdx.x;
+    bool ready = false;
+    if (c < C) {
+      uint32_t d0 = cons[c].indeg0;
+      ready = d0 == 0;
+      cons[c].round = 0;
+      cons[c].indeg = ready ? (cons[c].b != kNone ? 2u : 1u) : d0;  // ready ones are armed for their later rounds
+    }
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    uint32_t slot = 0;
+    if (ready) slot = atomicAdd(&s_n, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) s_base = atomicAdd(&F.cnt[0], s_n);
+    __syncthreads();
+    if (ready) F.order[s_base + slot] = c;
+    __syncthreads();
   }
-  __syncthreads();
-  if (s_last && threadIdx.x == 0) {
-    __threadfence();
-    F.lvl_off[slot] = __hip_atomic_load(F.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *F.done = 0;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_frontier0(uint32_t C, const uint32_t* indeg, Frontier F) {
-  for (uint32_t c = blockIdx.x * kBlock + threadIdx.x; c < C; c += gridDim.x * kBlock)
-    if (indeg[c] == 0) F.order[atomicAdd(F.tail, 1u)] = c;
-  publish_level(F, 1);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { F.lvl_off[0] = 0; F.cnt[1] = 0; F.cnt[2] = 0; }
 }
 
 // ContactConstraint::solve solver.rs:203-252 (single contact), incl. the reference's quirks:
@@ -713,37 +722,48 @@ __device__ __forceinline__ void store_vel(float4* srec, uint32_t i, const BodyDy
   *p = make_float2(d.w.y, d.w.z);
 }
 
-// One DAG level.  FIRST = iteration 0: constraints come from the insertion-ordered list through
-// `order`, are copied to level order for the later iterations, and release their successors.
-template <bool FIRST>
-__global__ __launch_bounds__(kBlock) void k_solve(float4* srec, const CRec* cons_nat, CRec* cons_lvl, Frontier F, uint32_t level,
-                                                  const uint32_t* succ_a, const uint32_t* succ_b, uint32_t* indeg) {
-  uint32_t lo = F.lvl_off[level], hi = F.lvl_off[level + 1];
-  for (uint32_t p = lo + blockIdx.x * kBlock + threadIdx.x; p < hi; p += gridDim.x * kBlock) {
-    uint32_t cid = FIRST ? F.order[p] : p;
-    CRec c = load_crec(FIRST ? &cons_nat[cid] : &cons_lvl[p]);
-    BodyDyn A = load_dyn(srec, c.a);
-    BodyDyn Bd = (c.b == kNone) ? static_dyn() : load_dyn(srec, c.b);
-    solve_one(c, A, Bd);
-    store_vel(srec, c.a, A);
-    if (c.b != kNone) store_vel(srec, c.b, Bd);
-    if (FIRST) {
-      store_crec(&cons_lvl[p], c);
-      uint32_t s = succ_a[cid];
-      if (s != kNone && atomicSub(&indeg[s], 1u) == 1u) F.order[atomicAdd(F.tail, 1u)] = s;
-      s = succ_b[cid];
-      if (s != kNone && atomicSub(&indeg[s], 1u) == 1u) F.order[atomicAdd(F.tail, 1u)] = s;
-    } else {
-      cons_lvl[p].nimp = c.nimp;
+// One launch of the frontier process.
+__global__ __launch_bounds__(kBlock) void k_solve(float4* srec, CRec* cons, Frontier F, uint32_t launch, uint32_t iters) {
+  __shared__ uint32_t s_q[2 * kBlock];
+  __shared__ uint32_t s_n, s_base;
+  const uint32_t lo = F.lvl_off[launch];
+  const uint32_t hi = lo + F.cnt[launch % 3];
+  uint32_t* next_cnt = F.cnt + (launch + 1) % 3;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { F.lvl_off[launch + 1] = hi; F.cnt[(launch + 2) % 3] = 0; }
+  for (uint32_t p0 = lo + blockIdx.x * kBlock; p0 < hi; p0 += gridDim.x * kBlock) {
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    uint32_t p = p0 + threadIdx.x;
+    if (p < hi) {
+      uint32_t cid = F.order[p];
+      CRec c = load_crec(&cons[cid]);
+      BodyDyn A = load_dyn(srec, c.a);
+      BodyDyn Bd = (c.b == kNone) ? static_dyn() : load_dyn(srec, c.b);
+      solve_one(c, A, Bd);
+      store_vel(srec, c.a, A);
+      if (c.b != kNone) store_vel(srec, c.b, Bd);
+      uint32_t k = c.round;
+      *reinterpret_cast<float2*>(&cons[cid].nimp) = make_float2(c.nimp, u2f(k + 1));  // nimp, round
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        if (side == 1 && c.b == kNone) break;
+        uint32_t w = side == 0 ? c.succ_a : c.succ_b;
+        uint32_t ks = k + (w >> 31);  // the successor's round this release belongs to
+        if (ks >= iters) continue;
+        uint32_t sid = w & kSuccId;
+        if (atomicSub(&cons[sid].indeg, 1u) == 1u) {
+          cons[sid].indeg = (w & kSuccTwo) ? 2u : 1u;  // re-arm for its next round (nobody decrements before it runs)
+          s_q[atomicAdd(&s_n, 1u)] = sid;
+        }
+      }
     }
+    __syncthreads();
+    uint32_t m = s_n;
+    if (threadIdx.x == 0 && m) s_base = atomicAdd(next_cnt, m);
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < m; e += kBlock) F.order[hi + s_base + e] = s_q[e];
+    __syncthreads();
   }
-  if (FIRST) publish_level(F, level + 2);
-}
-
-// Copy normal impulses back to insertion order (read-back / debugging only).
-__global__ __launch_bounds__(kBlock) void k_unpermute_nimp(uint32_t C, const uint32_t* order, const CRec* cons_lvl, CRec* cons_nat) {
-  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-  if (p < C) cons_nat[order[p]].nimp = cons_lvl[p].nimp;
 }
 
 // ------------------------------------------------------------------------------------------

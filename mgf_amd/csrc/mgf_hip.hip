@@ -337,7 +337,7 @@ static_assert(sizeof(ShapeIn) == sizeof(mgf_shape), "shape layout");
 static_assert(sizeof(ContactOut) == sizeof(mgf_contact), "contact layout");
 static_assert(sizeof(LocalOut) == sizeof(mgf_local_contact), "local contact layout");
 static_assert(sizeof(MovingIn) == sizeof(mgf_moving_component), "moving component layout");
-static_assert(sizeof(CRec) == 96, "constraint record layout");
+static_assert(sizeof(CRec) == 128, "constraint record layout");
 
 extern "C" mgf_status mgf_contacts_batch(mgf_ctx* ctx, int64_t n, const mgf_shape* a, const mgf_vec3* vel_a, const mgf_shape* b,
                                          const mgf_vec3* vel_b, const uint8_t* has_vel, mgf_contact* out, int32_t* counts) {
@@ -494,21 +494,21 @@ struct mgf_world {
   // terrain (copy of the caller's Mesh)
   std::unique_ptr<mgf_mesh> terrain;
   // broadphase
-  DBuf<uint32_t> mkeys, mvals, skeys, sidx, leaf_link, visit;
-  DBuf<LNode> lnodes;
+  DBuf<uint32_t> mkeys, mvals, skeys, sidx;
+  DBuf<HNode> lnodes;
   DBuf<float4> leaf_c, leaf_r;
   DBuf<uint32_t> t_cnt, p_cnt, t_off, p_off, t_cand, t_owner, p_cand, p_owner;
   // narrowphase
   DBuf<uint32_t> t_nc, p_nc, t_pre, p_pre, cnt, tcnt, base, tbase, work_lists, work_counts;
   DBuf<NContact> t_out, p_out;
   // solver
-  DBuf<CRec> cons_nat, cons_lvl;
-  DBuf<uint32_t> deg, adj_off, adj_fill, adj_list, succ_a, succ_b, indeg, order, lvl_off;
-  DBuf<uint32_t> scalars;  // [0] tail, [1] done, [2] err
+  DBuf<CRec> cons_nat;
+  DBuf<uint32_t> deg, adj_off, adj_fill, adj_list, order, lvl_off;
+  DBuf<uint32_t> scalars;  // [0..2] rotating level counters, [3] err
   DBuf<SceneBounds> sb;
-  uint32_t Mt = 0, Mp = 0, C = 0, Ct = 0, depth = 0, last_depth = 0, lvl_cap = 0;
-  std::vector<uint32_t> h_lvl;  // level offsets of the current constraint list
-  bool constraints_ready = false, nimp_synced = true, solved_once = false;
+  uint32_t Mt = 0, Mp = 0, C = 0, Ct = 0, depth = 0, last_launches = 0, lvl_cap = 0;
+  size_t order_cap_iters = 0;
+  bool constraints_ready = false;
   float last_dt = 0.0f;
   int64_t opt_time_solver_kernels = 0;
   hipEvent_t ev[8] = {};
@@ -521,10 +521,9 @@ struct mgf_world {
     B.einfo = einfo.p; B.col0 = col0.p; B.col1 = col1.p; B.tb_c = tb_c.p; B.tb_r = tb_r.p; B.fb_c = fb_c.p; B.fb_r = fb_r.p;
     return B;
   }
-  uint32_t* d_tail() { return scalars.p; }
-  uint32_t* d_done() { return scalars.p + 1; }
-  uint32_t* d_err() { return scalars.p + 2; }
-  Frontier frontier() { Frontier F; F.order = order.p; F.lvl_off = lvl_off.p; F.tail = d_tail(); F.done = d_done(); return F; }
+  uint32_t* d_cnt() { return scalars.p; }
+  uint32_t* d_err() { return scalars.p + 3; }
+  Frontier frontier() { Frontier F; F.order = order.p; F.lvl_off = lvl_off.p; F.cnt = d_cnt(); return F; }
 };
 
 extern "C" mgf_status mgf_world_new(mgf_ctx* ctx, const mgf_params* params, mgf_world** out) {
@@ -798,37 +797,25 @@ static mgf_status launch_terrain(mgf_world* w, int ka, const TerrainDev& M, cons
   return MGF_OK;
 }
 
-// Dependency DAG + first frontier for the insertion-ordered list cons_nat[0..C).
+// Dependency links of the insertion-ordered list cons_nat[0..C): per-body adjacency (sorted),
+// circular successor words, in-degrees of iteration 0.
 static mgf_status build_dag(mgf_world* w) {
   mgf_ctx* ctx = w->ctx;
   hipStream_t s = ctx->stream;
   uint32_t n = w->n, C = w->C;
   w->depth = 0;
-  w->h_lvl.clear();
-  w->nimp_synced = true;
-  w->solved_once = false;
-  MGF_HIP_TRY(hipMemsetAsync(w->scalars.p, 0, 8, s));  // tail, done
   if (C == 0) { w->constraints_ready = true; return MGF_OK; }
+  if (C >= kSuccId) return fail(MGF_ERR_CAPACITY, "too many constraints");
   MGF_TRY(w->deg.ensure(n + 1, s)); MGF_TRY(w->adj_off.ensure(n + 1, s)); MGF_TRY(w->adj_fill.ensure(n + 1, s));
   MGF_TRY(w->adj_list.ensure(2 * (size_t)C, s));
-  MGF_TRY(w->succ_a.ensure(C, s)); MGF_TRY(w->succ_b.ensure(C, s)); MGF_TRY(w->indeg.ensure(C, s)); MGF_TRY(w->order.ensure(C, s));
-  MGF_TRY(w->cons_lvl.ensure(C, s));
-  if (w->lvl_cap == 0) { w->lvl_cap = 4096; MGF_TRY(w->lvl_off.ensure(w->lvl_cap + 4, s)); }
   MGF_HIP_TRY(hipMemsetAsync(w->deg.p, 0, (n + 1) * 4, s));
   MGF_HIP_TRY(hipMemsetAsync(w->adj_fill.p, 0, (n + 1) * 4, s));
-  MGF_HIP_TRY(hipMemsetAsync(w->succ_a.p, 0xFF, (size_t)C * 4, s));
-  MGF_HIP_TRY(hipMemsetAsync(w->succ_b.p, 0xFF, (size_t)C * 4, s));
-  MGF_HIP_TRY(hipMemsetAsync(w->indeg.p, 0, (size_t)C * 4, s));
-  MGF_HIP_TRY(hipMemsetAsync(w->lvl_off.p, 0, (w->lvl_cap + 4) * 4, s));
   k_adj_count<<<nblk(C), kBlock, 0, s>>>(w->cons_nat.p, C, w->deg.p);
   LAUNCH_CHECK();
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->deg.p, w->adj_off.p, (size_t)n + 1));
   k_adj_fill<<<nblk(C), kBlock, 0, s>>>(w->cons_nat.p, C, w->adj_off.p, w->adj_fill.p, w->adj_list.p);
   LAUNCH_CHECK();
-  k_chain<<<nblk(n), kBlock, 0, s>>>(n, w->adj_off.p, w->adj_list.p, w->succ_a.p, w->succ_b.p, w->indeg.p);
-  LAUNCH_CHECK();
-  unsigned g0 = std::min<unsigned>(nblk(C), 1024u);
-  k_frontier0<<<g0, kBlock, 0, s>>>(C, w->indeg.p, w->frontier());
+  k_chain<<<nblk(n), kBlock, 0, s>>>(n, w->cons_nat.p, w->adj_off.p, w->adj_list.p);
   LAUNCH_CHECK();
   w->constraints_ready = true;
   return MGF_OK;
@@ -846,25 +833,27 @@ extern "C" mgf_status mgf_world_build_constraints(mgf_world* w, float dt, mgf_st
   w->constraints_ready = false;
   w->C = w->Ct = w->Mt = w->Mp = 0;
   MGF_HIP_TRY(hipEventRecord(w->ev[0], s));
-  k_reset_step<<<1, 64, 0, s>>>(w->sb.p, w->d_tail(), w->d_done(), w->d_err());
+  k_reset_step<<<1, 64, 0, s>>>(w->sb.p, w->d_err());
   LAUNCH_CHECK();
   if (n == 0) { w->constraints_ready = true; if (stats) *stats = w->stats; MGF_HIP_TRY(hipStreamSynchronize(s)); return MGF_OK; }
   Bodies B = w->bodies();
   // 1. complete_motion + integrate (world.rs:230-231)
   MGF_TRY(world_integrate(w, dt, true, true, true));
   // 2. linear BVH over the fat AABBs
+  uint32_t npad = 256;
+  while (npad < n) npad <<= 1;
   MGF_TRY(w->mkeys.ensure(n, s)); MGF_TRY(w->mvals.ensure(n, s)); MGF_TRY(w->skeys.ensure(n, s)); MGF_TRY(w->sidx.ensure(n, s));
-  MGF_TRY(w->leaf_link.ensure(n, s)); MGF_TRY(w->visit.ensure(n, s)); MGF_TRY(w->lnodes.ensure(n, s));
-  MGF_TRY(w->leaf_c.ensure(n, s)); MGF_TRY(w->leaf_r.ensure(n, s));
+  MGF_TRY(w->lnodes.ensure(npad, s)); MGF_TRY(w->leaf_c.ensure(n, s)); MGF_TRY(w->leaf_r.ensure(n, s));
+  k_scene_bounds<<<std::min<unsigned>(nblk(n), 256u), kBlock, 0, s>>>(w->fb_c.p, n, w->sb.p);
+  LAUNCH_CHECK();
   k_morton<<<nblk(n), kBlock, 0, s>>>(w->fb_c.p, n, w->sb.p, w->mkeys.p, w->mvals.p);
   LAUNCH_CHECK();
   MGF_TRY(prim_sort_pairs_u32(ctx, w->mkeys.p, w->skeys.p, w->mvals.p, w->sidx.p, n, 30));
   Lbvh T;
-  T.nodes = w->lnodes.p; T.leaf_c = w->leaf_c.p; T.leaf_r = w->leaf_r.p; T.leaf_link = w->leaf_link.p; T.visit = w->visit.p;
-  T.skeys = w->skeys.p; T.sidx = w->sidx.p; T.n = n; T.err = w->d_err();
-  if (n >= 2) { k_lbvh_build<<<nblk(n - 1), kBlock, 0, s>>>(T); LAUNCH_CHECK(); }
-  k_lbvh_refit<<<nblk(n), kBlock, 0, s>>>(T, w->fb_c.p, w->fb_r.p);
+  T.nodes = w->lnodes.p; T.leaf_c = w->leaf_c.p; T.leaf_r = w->leaf_r.p; T.sidx = w->sidx.p; T.n = n; T.npad = npad; T.err = w->d_err();
+  k_lbvh_low<<<npad / kBlock, kBlock, 0, s>>>(T, w->fb_c.p, w->fb_r.p);
   LAUNCH_CHECK();
+  if (npad > (uint32_t)kBlock) { k_lbvh_top<<<1, 1024, 0, s>>>(T); LAUNCH_CHECK(); }
   MGF_HIP_TRY(hipEventRecord(w->ev[1], s));
   // 3. candidates: count, scan, fill
   TerrainDev M;
@@ -976,52 +965,45 @@ extern "C" mgf_status mgf_world_solve(mgf_world* w, int32_t iters, mgf_step_stat
     return MGF_OK;
   };
   if (C > 0 && iters > 0) {
+    // frontier lists hold every (constraint, round) once: iters * C entries
+    MGF_TRY(w->order.ensure((size_t)iters * C, s));
+    if (w->lvl_cap == 0) { w->lvl_cap = 1u << 16; MGF_TRY(w->lvl_off.ensure(w->lvl_cap + 4, s)); }
     Frontier F = w->frontier();
-    int it_begin = 0;
-    if (!w->solved_once) {
-      // iteration 0 discovers the levels while it solves them
-      uint32_t r = 0;
-      unsigned g0 = std::min<unsigned>(std::max<unsigned>(nblk(C) / 2, 1u), 1024u);
-      uint32_t batch = std::max<uint32_t>(w->last_depth + 2, 8u);
-      uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
-      for (;;) {
-        if (r + batch + 2 > w->lvl_cap) return fail(MGF_ERR_CAPACITY, "constraint DAG deeper than 4096 levels");
-        for (uint32_t k = 0; k < batch; ++k) {
-          MGF_TRY(tick());
-          k_solve<true><<<g0, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->cons_lvl.p, F, r + k, w->succ_a.p, w->succ_b.p, w->indeg.p);
-          LAUNCH_CHECK();
-          MGF_TRY(tick());
-          w->stats.solver_kernel_launches++;
-        }
-        r += batch;
-        // level r = [lvl_off[r], lvl_off[r+1]) was queued by the last launch; empty means every level ran
-        MGF_HIP_TRY(hipMemcpyAsync(pin, w->lvl_off.p + r, 8, hipMemcpyDeviceToHost, s));
-        MGF_HIP_TRY(hipStreamSynchronize(s));
-        if (pin[0] == pin[1]) break;
-        batch = 4;
-      }
-      w->h_lvl.resize(r + 2);
-      MGF_TRY(d2h(ctx, w->h_lvl.data(), w->lvl_off.p, r + 2));
-      uint32_t depth = 0;
-      while (depth < r && w->h_lvl[depth + 1] > w->h_lvl[depth]) ++depth;
-      if (w->h_lvl[depth] != C) return fail(MGF_ERR_HIP, "internal error: level schedule does not cover the constraint list");
-      w->depth = depth;
-      w->last_depth = depth;
-      w->solved_once = true;
-      w->nimp_synced = false;
-      it_begin = 1;
-    }
-    for (int it = it_begin; it < iters; ++it) {
-      for (uint32_t l = 0; l < w->depth; ++l) {
-        uint32_t sz = w->h_lvl[l + 1] - w->h_lvl[l];
+    MGF_HIP_TRY(hipMemsetAsync(w->scalars.p, 0, 12, s));
+    k_frontier0<<<std::min<unsigned>(nblk(C), 1024u), kBlock, 0, s>>>(C, w->cons_nat.p, F);
+    LAUNCH_CHECK();
+    uint32_t r = 0;
+    // grid: frontiers hold roughly C / (per-iteration depth) constraints; grid-stride covers the rest
+    unsigned g0 = std::min<unsigned>(std::max<unsigned>(nblk(C) / 4, 1u), 2048u);
+    uint32_t batch = std::max<uint32_t>(w->last_launches + 2, 8u);
+    uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
+    for (;;) {
+      if (r + batch + 2 > w->lvl_cap) return fail(MGF_ERR_CAPACITY, "constraint dependency graph deeper than 65536 launches");
+      for (uint32_t k = 0; k < batch; ++k) {
         MGF_TRY(tick());
-        k_solve<false><<<nblk(sz), kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->cons_lvl.p, F, l, nullptr, nullptr, nullptr);
+        k_solve<<<g0, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, F, r + k, (uint32_t)iters);
         LAUNCH_CHECK();
         MGF_TRY(tick());
         w->stats.solver_kernel_launches++;
       }
-      w->nimp_synced = false;
+      r += batch;
+      // launch r's list was filled by the last launch under counter r % 3; empty means everything ran
+      MGF_HIP_TRY(hipMemcpyAsync(pin, w->d_cnt() + (r % 3), 4, hipMemcpyDeviceToHost, s));
+      MGF_HIP_TRY(hipMemcpyAsync(pin + 1, w->lvl_off.p + r, 4, hipMemcpyDeviceToHost, s));
+      MGF_HIP_TRY(hipStreamSynchronize(s));
+      if (pin[0] == 0) {
+        if ((uint64_t)pin[1] != (uint64_t)iters * C) return fail(MGF_ERR_HIP, "internal error: solver schedule does not cover iters x constraints");
+        break;
+      }
+      batch = 4;
     }
+    // number of non-empty launches (for stats and for sizing the next tick's batch)
+    std::vector<uint32_t> h(r + 1);
+    MGF_TRY(d2h(ctx, h.data(), w->lvl_off.p, r + 1));
+    uint32_t used = 0;
+    while (used < r && h[used] < (uint64_t)iters * C) ++used;
+    w->depth = used;
+    w->last_launches = used;
   }
   MGF_HIP_TRY(hipEventRecord(w->ev[6], s));
   MGF_HIP_TRY(hipStreamSynchronize(s));
@@ -1064,11 +1046,6 @@ extern "C" mgf_status mgf_world_read_constraints(mgf_world* w, mgf_constraint* o
   if (!out) return MGF_OK;
   if ((int64_t)w->C > cap) return fail(MGF_ERR_CAPACITY, "constraint buffer too small");
   if (w->C == 0) return MGF_OK;
-  if (!w->nimp_synced) {
-    k_unpermute_nimp<<<nblk(w->C), kBlock, 0, w->ctx->stream>>>(w->C, w->order.p, w->cons_lvl.p, w->cons_nat.p);
-    LAUNCH_CHECK();
-    w->nimp_synced = true;
-  }
   std::vector<CRec> h(w->C);
   MGF_TRY(d2h(w->ctx, h.data(), w->cons_nat.p, w->C));
   for (uint32_t i = 0; i < w->C; ++i) crec_to_public(h[i], &out[i]);
@@ -1093,6 +1070,7 @@ extern "C" mgf_status mgf_world_set_constraints(mgf_world* w, const mgf_constrai
     for (int k = 0; k < 5; ++k) memcpy(dst[k], src[k], 12);
     r.bias = c.bias; r.nmass = c.normal_mass; r.tmass0 = c.tangent_mass0; r.tmass1 = c.tangent_mass1; r.nimp = c.normal_impulse;
     r.friction = c.friction;
+    r.succ_a = kNone; r.succ_b = kNone;
     h[(size_t)i] = r;
   }
   w->C = (uint32_t)n; w->Ct = 0;

@@ -160,20 +160,21 @@ struct World {
     stats.t_solve = std::chrono::duration<double>(t3 - t2).count();
   }
 
-  // Depth of the order-preserving dependency DAG of the current constraint list
-  // (level(c) = 1 + max level of the previous constraint touching either body).
-  // Analysis only; not a reference function.
-  uint32_t constraint_depth() const {
+  // Depth of the order-preserving dependency graph of `iters` solver iterations over the current
+  // constraint list (level = 1 + max level of the previous constraint touching either body, carried
+  // across iterations).  iters = 1 gives the per-iteration depth.  Analysis only; not a reference function.
+  uint32_t constraint_depth(uint32_t iters = 1) const {
     std::vector<uint32_t> last(bodies.len(), 0);
     uint32_t depth = 0;
-    for (const ContactConstraint& c : solver.constraints) {
-      uint32_t la = c.obj_a.is_static ? 0 : last[c.obj_a.index];
-      uint32_t lb = c.obj_b.is_static ? 0 : last[c.obj_b.index];
-      uint32_t l = 1 + std::max(la, lb);
-      if (!c.obj_a.is_static) last[c.obj_a.index] = l;
-      if (!c.obj_b.is_static) last[c.obj_b.index] = l;
-      depth = std::max(depth, l);
-    }
+    for (uint32_t it = 0; it < iters; ++it)
+      for (const ContactConstraint& c : solver.constraints) {
+        uint32_t la = c.obj_a.is_static ? 0 : last[c.obj_a.index];
+        uint32_t lb = c.obj_b.is_static ? 0 : last[c.obj_b.index];
+        uint32_t l = 1 + std::max(la, lb);
+        if (!c.obj_a.is_static) last[c.obj_a.index] = l;
+        if (!c.obj_b.is_static) last[c.obj_b.index] = l;
+        depth = std::max(depth, l);
+      }
     return depth;
   }
 };

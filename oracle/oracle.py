@@ -147,7 +147,7 @@ def lib():
         L.mgfo_world_step.argtypes = [C.c_void_p, C.c_float, C.c_int64, P(Stats)]
         L.mgfo_world_build_constraints.argtypes = [C.c_void_p, C.c_float, P(Stats)]
         L.mgfo_world_solve.argtypes = [C.c_void_p, C.c_int64]
-        L.mgfo_world_constraint_depth.argtypes = [C.c_void_p]
+        L.mgfo_world_constraint_depth.argtypes = [C.c_void_p, C.c_uint32]
         L.mgfo_world_constraint_depth.restype = C.c_uint32
         L.mgfo_world_get_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.mgfo_world_get_constraints.restype = C.c_int64
@@ -304,8 +304,8 @@ class World:
     def solve(self, iters):
         lib().mgfo_world_solve(self.h, iters)
 
-    def constraint_depth(self):
-        return lib().mgfo_world_constraint_depth(self.h)
+    def constraint_depth(self, iters=1):
+        return lib().mgfo_world_constraint_depth(self.h, iters)
 
     def constraints(self):
         n = lib().mgfo_world_get_constraints(self.h, None, 0)

@@ -249,7 +249,7 @@ void mgfo_world_build_constraints(void* wp, float dt, o_stats* st) {
   }
 }
 void mgfo_world_solve(void* wp, int64_t iters) { World* w = (World*)wp; w->solver.solve(w->bodies, (size_t)iters); }
-uint32_t mgfo_world_constraint_depth(void* wp) { return ((World*)wp)->constraint_depth(); }
+uint32_t mgfo_world_constraint_depth(void* wp, uint32_t iters) { return ((World*)wp)->constraint_depth(iters); }
 int64_t mgfo_world_get_constraints(void* wp, o_constraint* out, int64_t cap) {
   World* w = (World*)wp;
   int64_t n = (int64_t)w->solver.constraints.size();

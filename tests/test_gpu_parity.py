@@ -131,7 +131,7 @@ def test_world_step_parity_teacher_forced(ctx, scene_name):
             gw.solve(iters)
             _compare_state(gw, ow, f"{scene_name} step {step}")
             compare_constraints(gw.constraints(), ow.constraints(), check_impulse=True)
-            assert gw.stats.n_levels == ow.constraint_depth()
+            assert gw.stats.n_levels == ow.constraint_depth(iters)  # launches = depth of the unrolled graph
         else:
             ow.step(dt, iters)
     assert total_constraints > 0
