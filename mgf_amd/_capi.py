@@ -331,10 +331,12 @@ class Mesh:
     """mgf::Mesh (mesh.rs:32-73)."""
 
     def __init__(self, ctx):
+        """ctx=None builds a host-only mesh (no device queries)."""
         self._ctx = ctx
         self._h = C.c_void_p()
-        _check(load_library().mgf_mesh_new(ctx._h, C.byref(self._h)))
-        ctx._adopt(self)
+        _check(load_library().mgf_mesh_new(ctx._h if ctx is not None else None, C.byref(self._h)))
+        if ctx is not None:
+            ctx._adopt(self)
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -379,11 +381,13 @@ class Bvh:
     def __init__(self, ctx, capacity=None):
         self._ctx = ctx
         self._h = C.c_void_p()
+        h = ctx._h if ctx is not None else None  # ctx=None: host-only tree (no device queries)
         if capacity is None:
-            _check(load_library().mgf_bvh_new(ctx._h, C.byref(self._h)))
+            _check(load_library().mgf_bvh_new(h, C.byref(self._h)))
         else:
-            _check(load_library().mgf_bvh_with_capacity(ctx._h, capacity, C.byref(self._h)))
-        ctx._adopt(self)
+            _check(load_library().mgf_bvh_with_capacity(h, capacity, C.byref(self._h)))
+        if ctx is not None:
+            ctx._adopt(self)
 
     def __del__(self):
         if getattr(self, "_h", None):

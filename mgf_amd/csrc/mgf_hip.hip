@@ -75,7 +75,7 @@ extern "C" void mgf_ctx_destroy(mgf_ctx* ctx) {
 }
 
 static mgf_status ctx_bind(mgf_ctx* ctx) {
-  if (!ctx) return fail(MGF_ERR_INVALID, "ctx is NULL");
+  if (!ctx) return fail(MGF_ERR_HIP, "no device context: this entry point computes on the GPU (mgf-hip has no CPU fallback)");
   MGF_HIP_TRY(hipSetDevice(ctx->device));
   (void)hipGetLastError();  // drop any stale sticky error from unrelated earlier calls
   return MGF_OK;
@@ -157,8 +157,8 @@ static inline Box to_box(const mgf_aabb& a) { Box b; b.c = mk3(a.c.x, a.c.y, a.c
 static inline mgf_aabb from_box(const Box& b) { mgf_aabb a; a.c = {b.c.x, b.c.y, b.c.z}; a.r = {b.r.x, b.r.y, b.r.z}; return a; }
 
 // ---- mgf_bvh ---------------------------------------------------------------------------------
-extern "C" mgf_status mgf_bvh_new(mgf_ctx* ctx, mgf_bvh** out) {
-  if (!ctx || !out) return fail(MGF_ERR_INVALID, "NULL argument");
+extern "C" mgf_status mgf_bvh_new(mgf_ctx* ctx, mgf_bvh** out) {  // ctx may be NULL: host-only tree (insert/remove/inspect; queries need a device)
+  if (!out) return fail(MGF_ERR_INVALID, "NULL argument");
   *out = new mgf_bvh{ctx, {}};
   return MGF_OK;
 }
@@ -169,7 +169,7 @@ extern "C" mgf_status mgf_bvh_with_capacity(mgf_ctx* ctx, uint64_t cap, mgf_bvh*
 }
 extern "C" void mgf_bvh_free(mgf_bvh* b) {
   if (!b) return;
-  (void)hipSetDevice(b->ctx->device);
+  if (b->ctx) (void)hipSetDevice(b->ctx->device);
   delete b;
 }
 extern "C" int32_t mgf_bvh_empty(const mgf_bvh* b) { return (!b || b->m.tree.empty()) ? 1 : 0; }
@@ -280,8 +280,8 @@ extern "C" mgf_status mgf_bvh_query_many(mgf_bvh* b, const mgf_aabb* args, int64
 }
 
 // ---- mgf_mesh --------------------------------------------------------------------------------
-extern "C" mgf_status mgf_mesh_new(mgf_ctx* ctx, mgf_mesh** out) {
-  if (!ctx || !out) return fail(MGF_ERR_INVALID, "NULL argument");
+extern "C" mgf_status mgf_mesh_new(mgf_ctx* ctx, mgf_mesh** out) {  // ctx may be NULL: host-only mesh
+  if (!out) return fail(MGF_ERR_INVALID, "NULL argument");
   mgf_mesh* m = new mgf_mesh();
   m->ctx = ctx;
   *out = m;
@@ -289,7 +289,7 @@ extern "C" mgf_status mgf_mesh_new(mgf_ctx* ctx, mgf_mesh** out) {
 }
 extern "C" void mgf_mesh_free(mgf_mesh* m) {
   if (!m) return;
-  (void)hipSetDevice(m->ctx->device);
+  if (m->ctx) (void)hipSetDevice(m->ctx->device);
   delete m;
 }
 extern "C" mgf_status mgf_mesh_push_vert(mgf_mesh* m, mgf_vec3 p, uint64_t* id) {

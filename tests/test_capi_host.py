@@ -1,0 +1,149 @@
+"""CPU-side checks of the drop-in boundary and of the product's host logic (no GPU compute):
+the library loads and exports every symbol include/mgf_hip.h declares; compute entry points fail
+loudly without a device; the host-side BVH (insert / remove / balance / free-list reuse) is
+structurally identical to the oracle's restatement of bvh.rs + pool.rs."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import mgf_amd
+from mgf_amd import _capi, scenes
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mgf_hip.h")).read()
+    return sorted(set(re.findall(r"MGF_API\s+[\w\s\*]+?\b(mgf_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = mgf_amd.load_library()
+    declared = _declared_symbols()
+    assert len(declared) >= 45
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(_capi.SYMBOLS) == declared, "Python binding and header disagree"
+
+
+def test_pod_layouts_match_header():
+    assert C.sizeof(_capi.Component) == 32 and C.sizeof(_capi.MovingComponent) == 44
+    assert C.sizeof(_capi.Contact) == 40 and C.sizeof(_capi.LocalContact) == 64
+    assert C.sizeof(_capi.Shape) == 52 and C.sizeof(_capi.BodyRef) == 24
+    assert C.sizeof(_capi.Velocity) == 24 and C.sizeof(_capi.RigidBodyInfo) == 60
+    assert C.sizeof(_capi.Params) == 20
+    p = mgf_amd.default_params()
+    assert (p.baumgarte, p.penetration_slop, p.persistent_threshold_sq, p.fat_margin) == (
+        pytest.approx(0.2), pytest.approx(0.05), 0.5, 0.25)
+
+
+def _no_gpu():
+    try:
+        import torch
+        return not torch.cuda.is_available()
+    except Exception:
+        return True
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="needs a machine without a GPU")
+def test_no_cpu_fallback():
+    with pytest.raises(mgf_amd.MgfError) as e:
+        mgf_amd.Context(0)
+    assert e.value.status == _capi.ERR_HIP
+    # a host-only tree exists, but querying it needs the device
+    b = mgf_amd.Bvh(None)
+    b.insert([0, 0, 0], [1, 1, 1], 7)
+    with pytest.raises(mgf_amd.MgfError) as e:
+        b.query([0, 0, 0], [1, 1, 1])
+    assert e.value.status == _capi.ERR_HIP
+
+
+def _compare_trees(hb, ob):
+    gn, gb = hb.dump()
+    on, obx = ob.dump()
+    assert gn.shape == on.shape
+    assert np.array_equal(gn, on), "node topology / heights / ids differ"
+    used = gn[:, 0] == 1
+    assert np.array_equal(gb[used].view(np.uint32), obx[used].view(np.uint32)), "node bounds differ"
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_host_bvh_matches_reference_restatement(seed):
+    """Random insert/remove traffic (the World::step refit pattern, world.rs:235-238) on both trees."""
+    rng = np.random.default_rng(seed)
+    hb, ob = mgf_amd.Bvh(None), O.Bvh()
+    live = {}
+    for step in range(600):
+        if live and rng.random() < 0.4:
+            val = int(rng.choice(list(live)))
+            hid, oid = live.pop(val)
+            assert hid == oid
+            hb.remove(hid)
+            assert ob.remove(oid) == 0
+        else:
+            val = step
+            c = rng.uniform(-20, 20, 3).astype(np.float32)
+            r = rng.uniform(0.2, 2.0, 3).astype(np.float32)
+            hid, oid = hb.insert(c, r, val), ob.insert(c, r, val)
+            assert hid == oid  # LIFO slot reuse (pool.rs:81-113)
+            live[val] = (hid, oid)
+        if step % 50 == 0 and live:
+            assert hb.root() == ob.root()
+            _compare_trees(hb, ob)
+    _compare_trees(hb, ob)
+    # panics map to statuses
+    with pytest.raises(mgf_amd.MgfError) as e:
+        hb.remove(10 ** 6)
+    assert e.value.status == _capi.ERR_NOT_OCCUPIED
+    for hid, _ in list(live.values()):
+        hb.remove(hid)
+    assert hb.empty()
+    with pytest.raises(mgf_amd.MgfError) as e:
+        hb.root()
+    assert e.value.status == _capi.ERR_EMPTY
+
+
+def test_mesh_bvh_matches_reference_restatement():
+    rng = np.random.default_rng(5)
+    verts = rng.uniform(-10, 10, (300, 3)).astype(np.float32)
+    faces = rng.integers(0, 300, (500, 3)).astype(np.uint32)
+    m = mgf_amd.Mesh(None)
+    m.build(verts, faces)
+    m.set_pos([1.0, -2.0, 3.0])
+    ow = O.World()
+    ow.set_terrain(verts, faces, [1.0, -2.0, 3.0])
+    gn, gb = m.bvh_dump()
+    on, obx = ow.terrain_bvh().dump()
+    assert np.array_equal(gn, on)
+    assert np.array_equal(gb.view(np.uint32), obx.view(np.uint32))
+    with pytest.raises(mgf_amd.MgfError):
+        m.push_face(0, 1, 10 ** 6)  # out-of-bounds vertex (Vec index panic in mesh.rs:65-67)
+
+
+@pytest.mark.parametrize("comp", [(0, [0.3, -1.0, 2.0], [0, 0, 0], 0.7), (1, [0.1, 0.2, 0.3], [0.5, -1.0, 0.25], 0.4),
+                                  (1, [0, 0, 0], [0, 2.0, 0], 1.0), (1, [1, 1, 1], [0, -1.5, 0], 0.5)])
+def test_inertia_tensor_matches_oracle(comp):
+    tag, p, d, r = comp
+    got = mgf_amd.inertia_tensor(tag, p, d, r, 2.5)
+    out = (C.c_float * 9)()
+    O.lib().mgfo_tensor(C.byref(O.component(tag, p, d, r)), 2.5, out)
+    assert np.array_equal(np.asarray(got, np.float32).view(np.uint32), np.asarray(list(out), np.float32).view(np.uint32))
+
+
+def test_scenes_are_deterministic():
+    z = scenes.splitmix64(0x6D6766, 3)
+    assert z.dtype == np.uint64 and len(set(z.tolist())) == 3
+    assert np.array_equal(z, scenes.splitmix64(0x6D6766, 3))
+    s1, s2 = scenes.sphere_pile(6, 5, 4), scenes.sphere_pile(6, 5, 4)
+    assert np.array_equal(s1["comps"]["p"], s2["comps"]["p"]) and np.array_equal(s1["v0"], s2["v0"])
+    assert len(s1["comps"]) == 120
+    b = scenes.balls_demo(8)
+    assert len(b["comps"]) == 512 and b["terrain"]["faces"].shape == (10, 3)
+    # balls.rs:74-92 with num = 8: first body at (-5, 20, -5), pitch 1.25
+    assert tuple(b["comps"]["p"][0]) == (-5.0, 20.0, -5.0) and tuple(b["comps"]["p"][1]) == (-5.0, 20.0, -3.75)
+    full = scenes.balls_demo(11, extra_ball=True, iters=20)
+    assert len(full["comps"]) == 1332 and tuple(full["comps"]["p"][-1]) == (0.0, 130.0, 0.0)

@@ -198,3 +198,16 @@ def test_standalone_solver_on_user_constraints(ctx):
     gw.solve(iters)
     ow.solve(iters)
     _compare_state(gw, ow, "set_constraints round trip")
+
+
+def _closed_form_names():
+    from tests.test_oracle_solver import CASES
+    return sorted(CASES)
+
+
+@pytest.mark.parametrize("name", _closed_form_names())
+def test_closed_form_cases_hip(ctx, name):
+    """The hand-derived solver cases of tests/test_oracle_solver.py, on the HIP path."""
+    import mgf_amd
+    from tests.test_oracle_solver import CASES
+    CASES[name](lambda scene: mgf_amd.World.from_scene(ctx, scene))
