@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo = host-staged exchange, for validating the multi-rank flow on one GPU")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-launch HIP events on the solver kernel")
     args = ap.parse_args()
 
@@ -47,20 +49,25 @@ def main():
 
     import torch
     dist = None
+    dev_index = int(os.environ.get("MGF_BENCH_DEVICE", local_rank))
     if world_size > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world_size,
-                                device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world_size)
 
     import mgf_amd
     from mgf_amd import scenes
     from mgf_amd.tiles import TiledWorld
 
     nx, ny, nz = args.tile
-    ctx = mgf_amd.Context(local_rank)
-    tw = TiledWorld(ctx, rank, world_size, nx, ny, nz, iters=args.iters, dist=dist, device=local_rank)
+    ctx = mgf_amd.Context(dev_index)
+    tw = TiledWorld(ctx, rank, world_size, nx, ny, nz, iters=args.iters, dist=dist, device=dev_index,
+                    host_staging=(args.backend == "gloo"))
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
     dt = tw.dt
 
     def barrier():
@@ -88,10 +95,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        u = torch.tensor([units, cons], dtype=torch.float64, device="cuda")
+        u = torch.tensor([units, cons], dtype=torch.float64, device=red_dev)
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
         units_all, cons_all = float(u[0].item()), float(u[1].item())
     else:

@@ -203,6 +203,24 @@ MGF_API mgf_status mgf_world_read_constraints(mgf_world* w, mgf_constraint* out,
 /* Solver::add_constraint in bulk + solve on the resident RigidBodyVec (solver.rs:66-78):
  * replaces the tick's constraint list with `cons` (insertion order = array order). */
 MGF_API mgf_status mgf_world_set_constraints(mgf_world* w, const mgf_constraint* cons, int64_t n);
+/* ---- spatial tiling across the GPUs of a node (one process per GPU) -----------
+ * A tick on a tile is begin_tick -> [select_boundary, export_bodies -> neighbour -> import_ghosts]
+ * -> collide -> iters x { solve(1) -> [export_velocities -> neighbour -> import_ghost_velocities] }.
+ * Ghost bodies are local copies of a neighbour tile's boundary bodies; they collide with owned
+ * bodies only (their terrain contacts and ghost-ghost pairs belong to their owner).  All buffers
+ * below are DEVICE pointers owned by the caller (e.g. the exchange buffers handed to RCCL).
+ * Ghost record: 36 floats  x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction;
+ * velocity record: 8 floats v3 w3 0 0. */
+MGF_API mgf_status mgf_world_begin_tick(mgf_world* w, float dt);     /* complete_motion + integrate (world.rs:230-231) */
+MGF_API mgf_status mgf_world_collide(mgf_world* w, float dt, mgf_step_stats* stats); /* world.rs:233-291 */
+/* Owned bodies whose fat AABB reaches below x_left / above x_right, ascending ids. */
+MGF_API mgf_status mgf_world_select_boundary(mgf_world* w, float x_left, float x_right, uint32_t* ids_left,
+                                             uint32_t* ids_right, int64_t cap, int64_t* n_left, int64_t* n_right);
+MGF_API mgf_status mgf_world_export_bodies(mgf_world* w, const uint32_t* ids, int64_t n, float* dst);
+MGF_API mgf_status mgf_world_import_ghosts(mgf_world* w, const float* src, int64_t n_ghost);
+MGF_API mgf_status mgf_world_export_velocities(mgf_world* w, const uint32_t* ids, int64_t n, float* dst);
+MGF_API mgf_status mgf_world_import_ghost_velocities(mgf_world* w, const float* src, int64_t n_ghost);
+MGF_API int64_t mgf_world_ghost_len(const mgf_world* w);
 /* Option: 1 = time every solver kernel with HIP events (bench roofline leg); default 0. */
 MGF_API mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_t value);
 /* Raw device pointers of resident state for zero-copy exchange (multi-GPU halo): name in

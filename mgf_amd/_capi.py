@@ -114,6 +114,8 @@ SYMBOLS = [
     "mgf_world_integrate", "mgf_world_get", "mgf_world_set", "mgf_world_read_state", "mgf_world_write_state",
     "mgf_world_read_colliders", "mgf_world_read_constraints", "mgf_world_set_constraints", "mgf_world_set_option",
     "mgf_world_device_ptr",
+    "mgf_world_begin_tick", "mgf_world_collide", "mgf_world_select_boundary", "mgf_world_export_bodies",
+    "mgf_world_import_ghosts", "mgf_world_export_velocities", "mgf_world_import_ghost_velocities", "mgf_world_ghost_len",
 ]
 
 _lib = None
@@ -182,6 +184,14 @@ def load_library():
         "mgf_world_set_constraints": (i32, [vp, vp, i64]),
         "mgf_world_set_option": (i32, [vp, C.c_char_p, i64]),
         "mgf_world_device_ptr": (i32, [vp, C.c_char_p, P(vp), P(i64)]),
+        "mgf_world_begin_tick": (i32, [vp, f32]),
+        "mgf_world_collide": (i32, [vp, f32, P(StepStats)]),
+        "mgf_world_select_boundary": (i32, [vp, f32, f32, vp, vp, i64, P(i64), P(i64)]),
+        "mgf_world_export_bodies": (i32, [vp, vp, i64, vp]),
+        "mgf_world_import_ghosts": (i32, [vp, vp, i64]),
+        "mgf_world_export_velocities": (i32, [vp, vp, i64, vp]),
+        "mgf_world_import_ghost_velocities": (i32, [vp, vp, i64]),
+        "mgf_world_ghost_len": (i64, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -566,6 +576,35 @@ class World:
     def set_constraints(self, cons):
         cons = np.ascontiguousarray(cons, CONSTRAINT_DTYPE)
         _check(load_library().mgf_world_set_constraints(self._h, cons.ctypes.data, len(cons)))
+
+    # ---- tiling (device pointers of the caller) ----
+    def begin_tick(self, dt):
+        _check(load_library().mgf_world_begin_tick(self._h, float(dt)))
+
+    def collide(self, dt):
+        _check(load_library().mgf_world_collide(self._h, float(dt), C.byref(self.stats)))
+        return self.stats
+
+    def select_boundary(self, x_left, x_right, ids_left_ptr, ids_right_ptr, cap):
+        nl, nr = C.c_int64(), C.c_int64()
+        _check(load_library().mgf_world_select_boundary(self._h, float(x_left), float(x_right), ids_left_ptr, ids_right_ptr,
+                                                        int(cap), C.byref(nl), C.byref(nr)))
+        return nl.value, nr.value
+
+    def export_bodies(self, ids_ptr, n, dst_ptr):
+        _check(load_library().mgf_world_export_bodies(self._h, ids_ptr, int(n), dst_ptr))
+
+    def import_ghosts(self, src_ptr, n):
+        _check(load_library().mgf_world_import_ghosts(self._h, src_ptr, int(n)))
+
+    def export_velocities(self, ids_ptr, n, dst_ptr):
+        _check(load_library().mgf_world_export_velocities(self._h, ids_ptr, int(n), dst_ptr))
+
+    def import_ghost_velocities(self, src_ptr, n):
+        _check(load_library().mgf_world_import_ghost_velocities(self._h, src_ptr, int(n)))
+
+    def ghost_len(self):
+        return load_library().mgf_world_ghost_len(self._h)
 
     def set_option(self, key, value):
         _check(load_library().mgf_world_set_option(self._h, key.encode(), int(value)))

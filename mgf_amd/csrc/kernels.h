@@ -337,8 +337,10 @@ __device__ __forceinline__ void lbvh_traverse(const Lbvh& T, const HNode* top, u
 }
 
 // FILL = false: count hits per body.  FILL = true: write them (CSR), partners sorted ascending.
+// Bodies [n_owned, n) are ghosts (copies of a neighbouring tile's bodies): they query the tree like
+// any body, but their terrain contacts and ghost-ghost pairs belong to their owner tile.
 template <bool FILL>
-__global__ __launch_bounds__(kBlock) void k_candidates(Bodies B, uint32_t n, Lbvh T, TerrainDev M, float pad,
+__global__ __launch_bounds__(kBlock) void k_candidates(Bodies B, uint32_t n, uint32_t n_owned, Lbvh T, TerrainDev M, float pad,
                                                        uint32_t* t_cnt, uint32_t* p_cnt, const uint32_t* t_off,
                                                        const uint32_t* p_off, uint32_t* t_cand, uint32_t* t_owner,
                                                        uint32_t* p_cand, uint32_t* p_owner) {
@@ -356,12 +358,15 @@ __global__ __launch_bounds__(kBlock) void k_candidates(Bodies B, uint32_t n, Lbv
   Box qm = q; qm.c = q.c + -mk3(M.x[0], M.x[1], M.x[2]);
   uint32_t nt = 0, np = 0;
   uint32_t tb = FILL ? t_off[i] : 0, pb = FILL ? p_off[i] : 0;
-  terrain_traverse(M, qm, [&](uint32_t face) {
-    if (FILL) { t_cand[tb + nt] = face; t_owner[tb + nt] = i; }
-    ++nt;
-  });
+  if (i < n_owned) {
+    terrain_traverse(M, qm, [&](uint32_t face) {
+      if (FILL) { t_cand[tb + nt] = face; t_owner[tb + nt] = i; }
+      ++nt;
+    });
+  }
   if (i != 0) {  // world.rs:256
     lbvh_traverse(T, s_top, i, q, pad, [&](uint32_t j) {
+      if (j >= n_owned) return;  // ghost-ghost: the owners' business
       if (FILL) { p_cand[pb + np] = j; p_owner[pb + np] = i; }
       ++np;
     });
@@ -764,6 +769,91 @@ __global__ __launch_bounds__(kBlock) void k_solve(float4* srec, CRec* cons, Fron
     for (uint32_t e = threadIdx.x; e < m; e += kBlock) F.order[hi + s_base + e] = s_q[e];
     __syncthreads();
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// Spatial tiling (one process per GPU): boundary selection, ghost export / import.
+// Ghost record, 36 floats: x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction.
+// ------------------------------------------------------------------------------------------
+constexpr int kGhostFloats = 36;
+
+// flags[i] bit0: owned body i's fat box reaches below x_left; bit1: above x_right.
+__global__ __launch_bounds__(kBlock) void k_boundary_flags(Bodies B, uint32_t n_owned, float x_left, float x_right, uint32_t* fl,
+                                                           uint32_t* fr) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i > n_owned) return;
+  uint32_t l = 0, r = 0;
+  if (i < n_owned) {
+    float c = B.fb_c[i].x, h = B.fb_r[i].x;
+    l = (c - h < x_left) ? 1u : 0u;
+    r = (c + h > x_right) ? 1u : 0u;
+  }
+  fl[i] = l; fr[i] = r;  // slot n_owned = 0 so the exclusive scan yields the total there
+}
+__global__ __launch_bounds__(kBlock) void k_boundary_scatter(uint32_t n_owned, const uint32_t* fl, const uint32_t* sl, const uint32_t* fr,
+                                                             const uint32_t* sr, uint32_t* ids_l, uint32_t* ids_r) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_owned) return;
+  if (fl[i]) ids_l[sl[i]] = i;
+  if (fr[i]) ids_r[sr[i]] = i;
+}
+__global__ __launch_bounds__(kBlock) void k_export_bodies(Bodies B, const uint32_t* ids, uint32_t m, float* out) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= m) return;
+  uint32_t i = ids[t];
+  float* o = out + (size_t)t * kGhostFloats;
+  float4 x = B.x[i], q = B.q[i], s0 = B.srec[4 * i], s1 = B.srec[4 * i + 1], s2 = B.srec[4 * i + 2], s3 = B.srec[4 * i + 3];
+  float4 d = B.delta[i], e = B.einfo[i], c0 = B.col0[i], c1 = B.col1[i];
+  o[0] = x.x; o[1] = x.y; o[2] = x.z;
+  o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
+  o[7] = s0.x; o[8] = s0.y; o[9] = s0.z;
+  o[10] = s0.w; o[11] = s1.x; o[12] = s1.y;
+  o[13] = d.x; o[14] = d.y; o[15] = d.z;
+  o[16] = c1.w; o[17] = c0.x; o[18] = c0.y; o[19] = c0.z; o[20] = c1.x; o[21] = c1.y; o[22] = c1.z; o[23] = c0.w;
+  o[24] = s1.z;
+  o[25] = s1.w; o[26] = s2.x; o[27] = s2.y; o[28] = s2.z; o[29] = s2.w; o[30] = s3.x; o[31] = s3.y; o[32] = s3.z; o[33] = s3.w;
+  o[34] = e.w; o[35] = d.w;
+}
+__global__ __launch_bounds__(kBlock) void k_import_ghosts(Bodies B, uint32_t n_owned, uint32_t m, const float* in, float fat_margin) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= m) return;
+  uint32_t i = n_owned + t;
+  const float* o = in + (size_t)t * kGhostFloats;
+  V3 x = mk3(o[0], o[1], o[2]), d = mk3(o[13], o[14], o[15]);
+  B.x[i] = mk4(x, 0.0f);
+  B.q[i] = make_float4(o[3], o[4], o[5], o[6]);
+  B.srec[4 * i] = make_float4(o[7], o[8], o[9], o[10]);
+  B.srec[4 * i + 1] = make_float4(o[11], o[12], o[24], o[25]);
+  B.srec[4 * i + 2] = make_float4(o[26], o[27], o[28], o[29]);
+  B.srec[4 * i + 3] = make_float4(o[30], o[31], o[32], o[33]);
+  B.delta[i] = mk4(d, o[35]);
+  B.einfo[i] = mk4(x + d, o[34]);  // RigidBodyInfo.x = x + delta (physics.rs:282)
+  Comp k; k.kind = (int)f2u(o[16]); k.p = mk3(o[17], o[18], o[19]); k.d = mk3(o[20], o[21], o[22]); k.r = o[23];
+  B.col0[i] = mk4(k.p, k.r);
+  B.col1[i] = mk4(k.d, o[16]);
+  Box tb = swept_bounds(k, d);
+  B.tb_c[i] = mk4(tb.c, 0.0f); B.tb_r[i] = mk4(tb.r, 0.0f);
+  B.fb_c[i] = mk4(tb.c, 0.0f); B.fb_r[i] = mk4(tb.r + mk3(fat_margin, fat_margin, fat_margin), 0.0f);
+  B.sp0[i] = make_float4(0, 0, 0, o[34]); B.sp1[i] = make_float4(0, 0, 0, o[35]);
+  B.ctor[i] = make_float4(o[16], k.r, 0.0f, 0.0f);
+  B.imb[3 * i] = make_float4(0, 0, 0, 0); B.imb[3 * i + 1] = make_float4(0, 0, 0, 0); B.imb[3 * i + 2] = make_float4(0, 0, 0, 0);
+}
+// velocity record: 8 floats (v3, w3, 0, 0)
+__global__ __launch_bounds__(kBlock) void k_export_vel(const float4* srec, const uint32_t* ids, uint32_t m, float4* out) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= m) return;
+  uint32_t i = ids[t];
+  float4 s0 = srec[4 * i], s1 = srec[4 * i + 1];
+  out[2 * t] = s0;
+  out[2 * t + 1] = make_float4(s1.x, s1.y, 0.0f, 0.0f);
+}
+__global__ __launch_bounds__(kBlock) void k_import_ghost_vel(float4* srec, uint32_t n_owned, uint32_t m, const float4* in) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= m) return;
+  uint32_t i = n_owned + t;
+  srec[4 * i] = in[2 * t];
+  float2* p = reinterpret_cast<float2*>(&srec[4 * i + 1]);
+  *p = make_float2(in[2 * t + 1].x, in[2 * t + 1].y);
 }
 
 // ------------------------------------------------------------------------------------------

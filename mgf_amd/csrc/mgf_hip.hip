@@ -487,8 +487,10 @@ extern "C" mgf_status mgf_inertia_tensor(const mgf_component* c, float mass, flo
 struct mgf_world {
   mgf_ctx* ctx = nullptr;
   mgf_params params;
-  uint32_t n = 0;
+  uint32_t n = 0;        // local bodies = owned + ghosts of the current tick
+  uint32_t n_owned = 0;  // bodies of this world's RigidBodyVec (added through add_bodies)
   bool has_sphere = false, has_capsule = false;
+  DBuf<uint32_t> bflag_l, bflag_r, bscan_l, bscan_r;  // boundary selection scratch
   // RigidBodyVec
   DBuf<float4> x, q, srec, sp0, sp1, ctor, imb, delta, einfo, col0, col1, tb_c, tb_r, fb_c, fb_r;
   // terrain (copy of the caller's Mesh)
@@ -548,7 +550,7 @@ extern "C" void mgf_world_free(mgf_world* w) {
   for (auto& e : w->kev) (void)hipEventDestroy(e);
   delete w;
 }
-extern "C" int64_t mgf_world_len(const mgf_world* w) { return w ? (int64_t)w->n : 0; }
+extern "C" int64_t mgf_world_len(const mgf_world* w) { return w ? (int64_t)w->n_owned : 0; }
 
 extern "C" mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_t value) {
   if (!w || !key) return fail(MGF_ERR_INVALID, "NULL argument");
@@ -583,9 +585,10 @@ extern "C" mgf_status mgf_world_add_bodies(mgf_world* w, const mgf_component* co
                                            const float* friction, const mgf_vec3* world_force, uint64_t* first_id) {
   if (!w || (n && (!comps || !mass || !restitution || !friction || !world_force))) return fail(MGF_ERR_INVALID, "NULL argument");
   MGF_TRY(ctx_bind(w->ctx));
-  if (first_id) *first_id = w->n;
+  w->n = w->n_owned;  // ghosts of a previous tick are dropped
+  if (first_id) *first_id = w->n_owned;
   if (n <= 0) return MGF_OK;
-  if ((uint64_t)w->n + (uint64_t)n > 0x7FFFFFF0ull) return fail(MGF_ERR_INVALID, "too many bodies");
+  if ((uint64_t)w->n_owned + (uint64_t)n > 0x7FFFFFF0ull) return fail(MGF_ERR_INVALID, "too many bodies");
   size_t N = (size_t)n;
   std::vector<float4> hx(N), hq(N), hs(4 * N), h0(N), h1(N), hc(N), hi(3 * N), hd(N), he(N), c0(N), c1(N), tc(N), tr(N), fc(N), fr(N);
   bool hs_ = w->has_sphere, hc_ = w->has_capsule;
@@ -633,13 +636,14 @@ extern "C" mgf_status mgf_world_add_bodies(mgf_world* w, const mgf_component* co
     fc[i] = tc[i]; fr[i] = make_float4(frr.x, frr.y, frr.z, 0);
   }
   mgf_ctx* ctx = w->ctx;
-  size_t o = w->n;
+  size_t o = w->n_owned;
   MGF_TRY(append(ctx, w->x, o, hx)); MGF_TRY(append(ctx, w->q, o, hq)); MGF_TRY(append(ctx, w->srec, 4 * o, hs));
   MGF_TRY(append(ctx, w->sp0, o, h0)); MGF_TRY(append(ctx, w->sp1, o, h1)); MGF_TRY(append(ctx, w->ctor, o, hc));
   MGF_TRY(append(ctx, w->imb, 3 * o, hi)); MGF_TRY(append(ctx, w->delta, o, hd)); MGF_TRY(append(ctx, w->einfo, o, he));
   MGF_TRY(append(ctx, w->col0, o, c0)); MGF_TRY(append(ctx, w->col1, o, c1)); MGF_TRY(append(ctx, w->tb_c, o, tc));
   MGF_TRY(append(ctx, w->tb_r, o, tr)); MGF_TRY(append(ctx, w->fb_c, o, fc)); MGF_TRY(append(ctx, w->fb_r, o, fr));
-  w->n += (uint32_t)n;
+  w->n_owned += (uint32_t)n;
+  w->n = w->n_owned;
   w->has_sphere = hs_; w->has_capsule = hc_;
   w->constraints_ready = false;
   return MGF_OK;
@@ -649,7 +653,7 @@ extern "C" mgf_status mgf_world_add_bodies(mgf_world* w, const mgf_component* co
 extern "C" mgf_status mgf_world_read_state(mgf_world* w, mgf_vec3* x, mgf_quat* q, mgf_vec3* v, mgf_vec3* omega, mgf_vec3* delta, int64_t cap) {
   if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
   MGF_TRY(ctx_bind(w->ctx));
-  size_t n = w->n;
+  size_t n = w->n_owned;
   if ((int64_t)n > cap) return fail(MGF_ERR_CAPACITY, "state buffers too small");
   std::vector<float4> t(4 * n);
   if (x) { MGF_TRY(d2h(w->ctx, t.data(), w->x.p, n)); for (size_t i = 0; i < n; ++i) x[i] = {t[i].x, t[i].y, t[i].z}; }
@@ -668,7 +672,7 @@ extern "C" mgf_status mgf_world_write_state(mgf_world* w, const mgf_vec3* x, con
                                             const mgf_vec3* delta, int64_t n_in) {
   if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
   MGF_TRY(ctx_bind(w->ctx));
-  size_t n = w->n;
+  size_t n = w->n_owned;
   if ((size_t)n_in != n) return fail(MGF_ERR_INVALID, "n must equal the number of bodies");
   std::vector<float4> t(4 * n);
   if (x) { for (size_t i = 0; i < n; ++i) t[i] = make_float4(x[i].x, x[i].y, x[i].z, 0); MGF_TRY(h2d(w->ctx, w->x.p, t.data(), n)); }
@@ -693,7 +697,7 @@ extern "C" mgf_status mgf_world_write_state(mgf_world* w, const mgf_vec3* x, con
 extern "C" mgf_status mgf_world_read_colliders(mgf_world* w, mgf_moving_component* out, int64_t cap) {
   if (!w || !out) return fail(MGF_ERR_INVALID, "NULL argument");
   MGF_TRY(ctx_bind(w->ctx));
-  size_t n = w->n;
+  size_t n = w->n_owned;
   if ((int64_t)n > cap) return fail(MGF_ERR_CAPACITY, "buffer too small");
   std::vector<float4> a(n), b(n), d(n);
   MGF_TRY(d2h(w->ctx, a.data(), w->col0.p, n)); MGF_TRY(d2h(w->ctx, b.data(), w->col1.p, n)); MGF_TRY(d2h(w->ctx, d.data(), w->delta.p, n));
@@ -716,7 +720,7 @@ extern "C" mgf_status mgf_world_get(mgf_world* w, const mgf_body_ref* r, mgf_vel
     if (info) { info->x = r->center; info->restitution = 0.0f; info->friction = r->friction; info->inv_mass = 0.0f; for (float& f : info->inv_moment) f = 0.0f; }
     return MGF_OK;
   }
-  if (r->index >= w->n) return fail(MGF_ERR_INVALID, "index out of bounds");
+  if (r->index >= w->n_owned) return fail(MGF_ERR_INVALID, "index out of bounds");
   float4 s[4], e, d;
   MGF_TRY(d2h(w->ctx, s, w->srec.p + 4 * (size_t)r->index, 4));
   MGF_TRY(d2h(w->ctx, &e, w->einfo.p + r->index, 1));
@@ -734,7 +738,7 @@ extern "C" mgf_status mgf_world_set(mgf_world* w, const mgf_body_ref* r, const m
   if (!w || !r || !vel) return fail(MGF_ERR_INVALID, "NULL argument");
   MGF_TRY(ctx_bind(w->ctx));
   if (r->tag == 1) return MGF_OK;
-  if (r->index >= w->n) return fail(MGF_ERR_INVALID, "index out of bounds");
+  if (r->index >= w->n_owned) return fail(MGF_ERR_INVALID, "index out of bounds");
   float4 s[2];
   MGF_TRY(d2h(w->ctx, s, w->srec.p + 4 * (size_t)r->index, 2));
   s[0] = make_float4(vel->linear.x, vel->linear.y, vel->linear.z, vel->angular.x);
@@ -746,15 +750,15 @@ extern "C" mgf_status mgf_world_device_ptr(mgf_world* w, const char* name, void*
   struct { const char* n; void* p; size_t per; } tab[] = {
       {"x", w->x.p, 16}, {"q", w->q.p, 16}, {"solver_rec", w->srec.p, 64}, {"delta", w->delta.p, 16}};
   for (auto& t : tab)
-    if (!strcmp(name, t.n)) { *ptr = t.p; if (bytes) *bytes = (int64_t)(t.per * w->n); return MGF_OK; }
+    if (!strcmp(name, t.n)) { *ptr = t.p; if (bytes) *bytes = (int64_t)(t.per * w->n_owned); return MGF_OK; }
   return fail(MGF_ERR_INVALID, "unknown array name");
 }
 
 // ---- the tick ----------------------------------------------------------------------------------
 static mgf_status world_integrate(mgf_world* w, float dt, bool complete, bool integrate, bool with_bounds) {
   mgf_ctx* ctx = w->ctx;
-  if (w->n == 0) return MGF_OK;
-  k_integrate<<<nblk(w->n), kBlock, 0, ctx->stream>>>(w->bodies(), w->n, dt, w->params.fat_margin, complete ? 1 : 0, integrate ? 1 : 0,
+  if (w->n_owned == 0) return MGF_OK;
+  k_integrate<<<nblk(w->n_owned), kBlock, 0, ctx->stream>>>(w->bodies(), w->n_owned, dt, w->params.fat_margin, complete ? 1 : 0, integrate ? 1 : 0,
                                                       with_bounds ? w->sb.p : nullptr);
   LAUNCH_CHECK();
   return MGF_OK;
@@ -821,24 +825,41 @@ static mgf_status build_dag(mgf_world* w) {
   return MGF_OK;
 }
 
-extern "C" mgf_status mgf_world_build_constraints(mgf_world* w, float dt, mgf_step_stats* stats) {
+// First half of the tick: drop last tick's ghosts, complete_motion + integrate the owned bodies
+// (world.rs:230-231).  After this call a tiled driver may import ghost bodies.
+static mgf_status world_begin(mgf_world* w, float dt) {
   if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
   MGF_TRY(ctx_bind(w->ctx));
-  mgf_ctx* ctx = w->ctx;
-  hipStream_t s = ctx->stream;
-  const uint32_t n = w->n;
+  hipStream_t s = w->ctx->stream;
   memset(&w->stats, 0, sizeof(w->stats));
-  w->stats.n_bodies = n;
+  w->n = w->n_owned;
+  w->stats.n_bodies = w->n_owned;
   w->last_dt = dt;
   w->constraints_ready = false;
   w->C = w->Ct = w->Mt = w->Mp = 0;
   MGF_HIP_TRY(hipEventRecord(w->ev[0], s));
   k_reset_step<<<1, 64, 0, s>>>(w->sb.p, w->d_err());
   LAUNCH_CHECK();
+  MGF_TRY(world_integrate(w, dt, true, true, true));
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_world_begin_tick(mgf_world* w, float dt) {
+  MGF_TRY(world_begin(w, dt));
+  MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
+  return MGF_OK;
+}
+
+// Second half: broadphase, narrowphase, ContactConstraint::new over owned + ghost bodies.
+extern "C" mgf_status mgf_world_collide(mgf_world* w, float dt, mgf_step_stats* stats) {
+  if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
+  MGF_TRY(ctx_bind(w->ctx));
+  mgf_ctx* ctx = w->ctx;
+  hipStream_t s = ctx->stream;
+  const uint32_t n = w->n;
+  w->constraints_ready = false;
+  w->C = w->Ct = w->Mt = w->Mp = 0;
   if (n == 0) { w->constraints_ready = true; if (stats) *stats = w->stats; MGF_HIP_TRY(hipStreamSynchronize(s)); return MGF_OK; }
   Bodies B = w->bodies();
-  // 1. complete_motion + integrate (world.rs:230-231)
-  MGF_TRY(world_integrate(w, dt, true, true, true));
   // 2. linear BVH over the fat AABBs
   uint32_t npad = 256;
   while (npad < n) npad <<= 1;
@@ -860,7 +881,7 @@ extern "C" mgf_status mgf_world_build_constraints(mgf_world* w, float dt, mgf_st
   if (w->terrain && !w->terrain->m.tree.empty()) M = w->terrain->dev(w->d_err());
   else { memset(&M, 0, sizeof(M)); }
   MGF_TRY(w->t_cnt.ensure(n + 1, s)); MGF_TRY(w->p_cnt.ensure(n + 1, s)); MGF_TRY(w->t_off.ensure(n + 1, s)); MGF_TRY(w->p_off.ensure(n + 1, s));
-  k_candidates<false><<<nblk(n), kBlock, 0, s>>>(B, n, T, M, 1e-3f, w->t_cnt.p, w->p_cnt.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  k_candidates<false><<<nblk(n), kBlock, 0, s>>>(B, n, w->n_owned, T, M, 1e-3f, w->t_cnt.p, w->p_cnt.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
   LAUNCH_CHECK();
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->t_cnt.p, w->t_off.p, (size_t)n + 1));
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->p_cnt.p, w->p_off.p, (size_t)n + 1));
@@ -881,7 +902,7 @@ extern "C" mgf_status mgf_world_build_constraints(mgf_world* w, float dt, mgf_st
   MGF_TRY(w->t_pre.ensure(std::max(Mt, 1u), s)); MGF_TRY(w->p_pre.ensure(std::max(Mp, 1u), s));
   MGF_TRY(w->t_out.ensure(std::max(2 * (size_t)Mt, (size_t)1), s)); MGF_TRY(w->p_out.ensure(std::max(Mp, 1u), s));
   if (Mt + Mp > 0) {
-    k_candidates<true><<<nblk(n), kBlock, 0, s>>>(B, n, T, M, 1e-3f, nullptr, nullptr, w->t_off.p, w->p_off.p, w->t_cand.p, w->t_owner.p,
+    k_candidates<true><<<nblk(n), kBlock, 0, s>>>(B, n, w->n_owned, T, M, 1e-3f, nullptr, nullptr, w->t_off.p, w->p_off.p, w->t_cand.p, w->t_owner.p,
                                                   w->p_cand.p, w->p_owner.p);
     LAUNCH_CHECK();
   }
@@ -942,6 +963,88 @@ extern "C" mgf_status mgf_world_build_constraints(mgf_world* w, float dt, mgf_st
   if (stats) *stats = w->stats;
   return MGF_OK;
 }
+
+extern "C" mgf_status mgf_world_build_constraints(mgf_world* w, float dt, mgf_step_stats* stats) {
+  MGF_TRY(world_begin(w, dt));
+  return mgf_world_collide(w, dt, stats);
+}
+
+// ---- tiling support: boundary selection, ghost export / import (device buffers of the caller) ----
+extern "C" mgf_status mgf_world_select_boundary(mgf_world* w, float x_left, float x_right, uint32_t* ids_left, uint32_t* ids_right,
+                                                int64_t cap, int64_t* n_left, int64_t* n_right) {
+  if (!w || !n_left || !n_right) return fail(MGF_ERR_INVALID, "NULL argument");
+  MGF_TRY(ctx_bind(w->ctx));
+  mgf_ctx* ctx = w->ctx;
+  hipStream_t s = ctx->stream;
+  uint32_t n = w->n_owned;
+  *n_left = *n_right = 0;
+  if (n == 0) return MGF_OK;
+  MGF_TRY(w->bflag_l.ensure(n + 1, s)); MGF_TRY(w->bflag_r.ensure(n + 1, s)); MGF_TRY(w->bscan_l.ensure(n + 1, s)); MGF_TRY(w->bscan_r.ensure(n + 1, s));
+  k_boundary_flags<<<nblk(n + 1), kBlock, 0, s>>>(w->bodies(), n, x_left, x_right, w->bflag_l.p, w->bflag_r.p);
+  LAUNCH_CHECK();
+  MGF_TRY(prim_exclusive_scan_u32(ctx, w->bflag_l.p, w->bscan_l.p, (size_t)n + 1));
+  MGF_TRY(prim_exclusive_scan_u32(ctx, w->bflag_r.p, w->bscan_r.p, (size_t)n + 1));
+  uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
+  MGF_HIP_TRY(hipMemcpyAsync(pin, w->bscan_l.p + n, 4, hipMemcpyDeviceToHost, s));
+  MGF_HIP_TRY(hipMemcpyAsync(pin + 1, w->bscan_r.p + n, 4, hipMemcpyDeviceToHost, s));
+  MGF_HIP_TRY(hipStreamSynchronize(s));
+  *n_left = pin[0]; *n_right = pin[1];
+  if ((int64_t)pin[0] > cap || (int64_t)pin[1] > cap) return fail(MGF_ERR_CAPACITY, "boundary id buffers too small");
+  if (!ids_left || !ids_right) return fail(MGF_ERR_INVALID, "NULL id buffer");
+  k_boundary_scatter<<<nblk(n), kBlock, 0, s>>>(n, w->bflag_l.p, w->bscan_l.p, w->bflag_r.p, w->bscan_r.p, ids_left, ids_right);
+  LAUNCH_CHECK();
+  MGF_HIP_TRY(hipStreamSynchronize(s));
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_world_export_bodies(mgf_world* w, const uint32_t* ids, int64_t n, float* dst) {
+  if (!w || (n && (!ids || !dst))) return fail(MGF_ERR_INVALID, "NULL argument");
+  MGF_TRY(ctx_bind(w->ctx));
+  if (n > 0) { k_export_bodies<<<nblk(n), kBlock, 0, w->ctx->stream>>>(w->bodies(), ids, (uint32_t)n, dst); LAUNCH_CHECK(); }
+  MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
+  return MGF_OK;
+}
+template <class T>
+static mgf_status grow_keep(mgf_world* w, DBuf<T>& b, size_t per, size_t need) {
+  return b.ensure(per * need, w->ctx->stream, true, per * (size_t)w->n_owned);
+}
+extern "C" mgf_status mgf_world_import_ghosts(mgf_world* w, const float* src, int64_t n_ghost) {
+  if (!w || (n_ghost && !src) || n_ghost < 0) return fail(MGF_ERR_INVALID, "bad argument");
+  MGF_TRY(ctx_bind(w->ctx));
+  size_t need = (size_t)w->n_owned + (size_t)n_ghost;
+  if (need > 0x7FFFFFF0ull) return fail(MGF_ERR_INVALID, "too many bodies");
+  MGF_TRY(grow_keep(w, w->x, 1, need)); MGF_TRY(grow_keep(w, w->q, 1, need)); MGF_TRY(grow_keep(w, w->srec, 4, need));
+  MGF_TRY(grow_keep(w, w->sp0, 1, need)); MGF_TRY(grow_keep(w, w->sp1, 1, need)); MGF_TRY(grow_keep(w, w->ctor, 1, need));
+  MGF_TRY(grow_keep(w, w->imb, 3, need)); MGF_TRY(grow_keep(w, w->delta, 1, need)); MGF_TRY(grow_keep(w, w->einfo, 1, need));
+  MGF_TRY(grow_keep(w, w->col0, 1, need)); MGF_TRY(grow_keep(w, w->col1, 1, need)); MGF_TRY(grow_keep(w, w->tb_c, 1, need));
+  MGF_TRY(grow_keep(w, w->tb_r, 1, need)); MGF_TRY(grow_keep(w, w->fb_c, 1, need)); MGF_TRY(grow_keep(w, w->fb_r, 1, need));
+  if (n_ghost > 0) {
+    k_import_ghosts<<<nblk(n_ghost), kBlock, 0, w->ctx->stream>>>(w->bodies(), w->n_owned, (uint32_t)n_ghost, src, w->params.fat_margin);
+    LAUNCH_CHECK();
+  }
+  w->n = (uint32_t)need;
+  w->constraints_ready = false;
+  MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_world_export_velocities(mgf_world* w, const uint32_t* ids, int64_t n, float* dst) {
+  if (!w || (n && (!ids || !dst))) return fail(MGF_ERR_INVALID, "NULL argument");
+  MGF_TRY(ctx_bind(w->ctx));
+  if (n > 0) { k_export_vel<<<nblk(n), kBlock, 0, w->ctx->stream>>>(w->srec.p, ids, (uint32_t)n, reinterpret_cast<float4*>(dst)); LAUNCH_CHECK(); }
+  MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_world_import_ghost_velocities(mgf_world* w, const float* src, int64_t n_ghost) {
+  if (!w || (n_ghost && !src)) return fail(MGF_ERR_INVALID, "NULL argument");
+  MGF_TRY(ctx_bind(w->ctx));
+  if ((uint64_t)n_ghost != (uint64_t)(w->n - w->n_owned)) return fail(MGF_ERR_INVALID, "ghost count mismatch");
+  if (n_ghost > 0) {
+    k_import_ghost_vel<<<nblk(n_ghost), kBlock, 0, w->ctx->stream>>>(w->srec.p, w->n_owned, (uint32_t)n_ghost, reinterpret_cast<const float4*>(src));
+    LAUNCH_CHECK();
+  }
+  MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
+  return MGF_OK;
+}
+extern "C" int64_t mgf_world_ghost_len(const mgf_world* w) { return w ? (int64_t)(w->n - w->n_owned) : 0; }
 
 // Solver::solve solver.rs:72-78, level-scheduled.
 extern "C" mgf_status mgf_world_solve(mgf_world* w, int32_t iters, mgf_step_stats* stats) {

@@ -48,10 +48,11 @@ _BOX_FACES = np.array([(0, 1, 3), (1, 2, 3), (0, 5, 1), (0, 4, 5), (0, 3, 7), (0
                        (2, 6, 3), (3, 6, 7), (1, 5, 2), (2, 5, 6)], dtype=np.uint32)
 
 
-def box_terrain(half, height, pos):
+def box_terrain(half, height, pos, half_z=None):
     h, H = np.float32(half), np.float32(height)
-    verts = np.array([(-h, 0, -h), (-h, 0, h), (h, 0, h), (h, 0, -h),
-                      (-h, H, -h), (-h, H, h), (h, H, h), (h, H, -h)], dtype=np.float32)
+    g = h if half_z is None else np.float32(half_z)
+    verts = np.array([(-h, 0, -g), (-h, 0, g), (h, 0, g), (h, 0, -g),
+                      (-h, H, -g), (-h, H, g), (h, H, g), (h, H, -g)], dtype=np.float32)
     return dict(verts=verts, faces=_BOX_FACES.copy(), pos=np.asarray(pos, np.float32))
 
 
@@ -108,6 +109,30 @@ def sphere_pile(nx, ny, nz, seed=SEED, iters=10, shuffle=True, x_offset=0.0):
     half = max(nx, nz) / 2.0 + 1.0
     terrain = box_terrain(half, ny + 2.0, (x_offset, 0.0, 0.0))
     return _scene(f"sphere_pile_{nx}x{ny}x{nz}", _spheres(c, 0.5), terrain, v0=v0, iters=iters)
+
+
+def sphere_pile_tile(nx, ny, nz, rank, world_size, seed=SEED, iters=10):
+    """x-slab tile `rank` of a (world_size*nx) x ny x nz pile in ONE open box (BASELINE config 4 family;
+    world_size == 1 is sphere_pile).  Tile r owns lattice columns [r*nx, (r+1)*nx); its bodies, jitter and
+    velocities come from per-tile SplitMix64 streams so every rank can build its own tile independently."""
+    if world_size == 1:
+        sc = sphere_pile(nx, ny, nz, seed=seed, iters=iters)
+        sc["x_range"] = (-np.inf, np.inf)
+        return sc
+    n = nx * ny * nz
+    gx = world_size * nx
+    i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    base = np.stack([i.ravel() + rank * nx - (gx - 1) / 2.0, j.ravel() + 0.5, k.ravel() - (nz - 1) / 2.0], axis=1).astype(np.float32)
+    st = 16 * (rank + 1)
+    jit = np.stack([uniform(seed, n, -0.05, 0.05, stream=st + s) for s in (1, 2, 3)], axis=1)
+    v0 = np.stack([uniform(seed, n, -1.0, 1.0, stream=st + s) for s in (4, 5, 6)], axis=1)
+    c = (base + jit).astype(np.float32)
+    perm = seeded_permutation(seed, n, stream=st + 7)
+    c, v0 = c[perm], v0[perm]
+    terrain = box_terrain(gx / 2.0 + 1.0, ny + 2.0, (0.0, 0.0, 0.0), half_z=nz / 2.0 + 1.0)
+    sc = _scene(f"sphere_pile_tile{rank}of{world_size}_{nx}x{ny}x{nz}", _spheres(c, 0.5), terrain, v0=v0, iters=iters)
+    sc["x_range"] = (rank * nx - gx / 2.0, (rank + 1) * nx - gx / 2.0)
+    return sc
 
 
 def config(idx):

@@ -87,6 +87,11 @@ struct World {
   ContactConstraintParams params;
   Solver solver;  // last step's solver (kept for inspection)
   StepStats stats;
+  // Spatial tiling (not in the reference, which is single-process): bodies [n_owned, len) are ghosts,
+  // local copies of a neighbouring tile's boundary bodies.  They collide with owned bodies only;
+  // their terrain contacts and ghost-ghost pairs belong to their owner tile.  Mirrors the HIP path's
+  // mgf_world_import_ghosts & co. so the tiled algorithm has an exact CPU counterpart.
+  size_t n_owned = 0;
 
   // world.rs:178-184
   bool add_body(const Component& col, float mass, float rest, float fric, V3 world_force, size_t* id_out) {
@@ -95,34 +100,105 @@ struct World {
     AABB b = bounds(bodies.collider[id]);
     size_t bvh_id = bvh.insert(b + fat_margin, id);
     bvh_ids.push_back(bvh_id);
+    n_owned = bodies.len();
     if (id_out) *id_out = id;
     return true;
   }
 
-  // world.rs:227-294 up to (not including) solver.solve
-  void build_constraints(float dt) {
+  void drop_ghosts() {
+    RigidBodyVec& b = bodies;
+    for (size_t i = n_owned; i < bvh_ids.size(); ++i) bvh.remove(bvh_ids[i]);
+    bvh_ids.resize(n_owned);
+    b.x.resize(n_owned); b.q.resize(n_owned); b.v.resize(n_owned); b.omega.resize(n_owned); b.force.resize(n_owned);
+    b.torque.resize(n_owned); b.restitution.resize(n_owned); b.friction.resize(n_owned); b.inv_mass.resize(n_owned);
+    b.inv_moment_body.resize(n_owned, m3_zero()); b.inv_moment.resize(n_owned, m3_zero());
+    b.constructor.resize(n_owned); b.collider.resize(n_owned);
+  }
+  // record: x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction (36 floats)
+  void add_ghost(const float* o) {
+    RigidBodyVec& b = bodies;
+    Component k;
+    uint32_t tag;
+    std::memcpy(&tag, &o[16], 4);
+    if (tag == 0u) k = component(Sphere{v3(o[17], o[18], o[19]), o[23]});
+    else k = component(Capsule{v3(o[17], o[18], o[19]), v3(o[20], o[21], o[22]), o[23]});
+    V3 delta = v3(o[13], o[14], o[15]);
+    b.x.push_back(v3(o[0], o[1], o[2]));
+    b.q.push_back(Quat{o[3], v3(o[4], o[5], o[6])});
+    b.v.push_back(v3(o[7], o[8], o[9]));
+    b.omega.push_back(v3(o[10], o[11], o[12]));
+    b.force.push_back(v3(0, 0, 0)); b.torque.push_back(v3(0, 0, 0));
+    b.restitution.push_back(o[34]); b.friction.push_back(o[35]); b.inv_mass.push_back(o[24]);
+    M3 I = m3_new(o[25], o[26], o[27], o[28], o[29], o[30], o[31], o[32], o[33]);
+    b.inv_moment_body.push_back(m3_zero()); b.inv_moment.push_back(I);
+    b.constructor.push_back(ComponentConstructor{k.kind, o[23], 0.0f});
+    b.collider.push_back(sweep(k, delta));
+    size_t id = b.len() - 1;
+    bvh_ids.push_back(bvh.insert(bounds(b.collider[id]) + fat_margin, id));
+  }
+  void export_body(size_t i, float* o) const {
+    const RigidBodyVec& b = bodies;
+    const Moving<Component>& c = b.collider[i];
+    o[0] = b.x[i].x; o[1] = b.x[i].y; o[2] = b.x[i].z;
+    o[3] = b.q[i].s; o[4] = b.q[i].v.x; o[5] = b.q[i].v.y; o[6] = b.q[i].v.z;
+    o[7] = b.v[i].x; o[8] = b.v[i].y; o[9] = b.v[i].z;
+    o[10] = b.omega[i].x; o[11] = b.omega[i].y; o[12] = b.omega[i].z;
+    o[13] = c.vel.x; o[14] = c.vel.y; o[15] = c.vel.z;
+    uint32_t tag = (uint32_t)c.shape.kind;
+    std::memcpy(&o[16], &tag, 4);
+    if (c.shape.kind == COMP_SPHERE) { o[17] = c.shape.s.c.x; o[18] = c.shape.s.c.y; o[19] = c.shape.s.c.z; o[20] = o[21] = o[22] = 0.0f; o[23] = c.shape.s.r; }
+    else { o[17] = c.shape.c.a.x; o[18] = c.shape.c.a.y; o[19] = c.shape.c.a.z; o[20] = c.shape.c.d.x; o[21] = c.shape.c.d.y; o[22] = c.shape.c.d.z; o[23] = c.shape.c.r; }
+    o[24] = b.inv_mass[i];
+    for (int k = 0; k < 3; ++k) { o[25 + 3 * k] = b.inv_moment[i].c[k].x; o[26 + 3 * k] = b.inv_moment[i].c[k].y; o[27 + 3 * k] = b.inv_moment[i].c[k].z; }
+    o[34] = b.restitution[i]; o[35] = b.friction[i];
+  }
+  // owned bodies whose fat box reaches below x_left / above x_right (ascending ids)
+  void select_boundary(float x_left, float x_right, std::vector<uint32_t>* left, std::vector<uint32_t>* right) const {
+    left->clear(); right->clear();
+    for (size_t i = 0; i < n_owned; ++i) {
+      const AABB& fb = bvh[bvh_ids[i]];
+      if (fb.c.x - fb.r.x < x_left) left->push_back((uint32_t)i);
+      if (fb.c.x + fb.r.x > x_right) right->push_back((uint32_t)i);
+    }
+  }
+
+  // world.rs:228-231
+  void begin_tick(float dt) {
     using clk = std::chrono::steady_clock;
+    drop_ghosts();
     solver = Solver();
     stats = StepStats();
     auto t0 = clk::now();
     bodies.complete_motion();
     bodies.integrate(dt);
+    stats.t_integrate = std::chrono::duration<double>(clk::now() - t0).count();
+  }
+  // world.rs:227-294 up to (not including) solver.solve
+  void build_constraints(float dt) {
+    begin_tick(dt);
+    collide(dt);
+  }
+  // world.rs:233-291
+  void collide(float dt) {
+    using clk = std::chrono::steady_clock;
     auto t1 = clk::now();
     std::vector<size_t> hits;
     const size_t n = bodies.len();
     for (size_t i = 0; i < n; ++i) {
       const Moving<Component> collider = bodies.collider[i];
       AABB b = bounds(collider);
-      if (!aabb_contains(bvh[bvh_ids[i]], b)) {
-        bvh.remove(bvh_ids[i]);
-        bvh_ids[i] = bvh.insert(b + fat_margin, i);
-        stats.n_refits++;
+      if (i < n_owned) {
+        if (!aabb_contains(bvh[bvh_ids[i]], b)) {
+          bvh.remove(bvh_ids[i]);
+          bvh_ids[i] = bvh.insert(b + fat_margin, i);
+          stats.n_refits++;
+        }
+        local_contacts(collider, terrain, [&](const LocalContact& lc) {
+          solver.add_constraint(ContactConstraint::make(bodies, dynamic_ref(i), static_ref(terrain.center(), 0.0f),
+                                                        manifold_from(lc), dt, params));
+          stats.n_terrain_constraints++;
+        });
       }
-      local_contacts(collider, terrain, [&](const LocalContact& lc) {
-        solver.add_constraint(ContactConstraint::make(bodies, dynamic_ref(i), static_ref(terrain.center(), 0.0f),
-                                                      manifold_from(lc), dt, params));
-        stats.n_terrain_constraints++;
-      });
       if (i == 0) continue;
       auto on_hit = [&](size_t j) {
         ContactPruner pruner;
@@ -133,13 +209,13 @@ struct World {
       };
       if (order_mode == ORDER_DEMO) {
         bvh.query(b, [&](size_t j) {
-          if (j >= i) return;
+          if (j >= i || j >= n_owned) return;
           stats.n_pair_candidates++;
           on_hit(j);
         });
       } else {
         hits.clear();
-        bvh.query(b, [&](size_t j) { if (j < i) hits.push_back(j); });
+        bvh.query(b, [&](size_t j) { if (j < i && j < n_owned) hits.push_back(j); });
         std::sort(hits.begin(), hits.end());
         stats.n_pair_candidates += hits.size();
         for (size_t j : hits) on_hit(j);
@@ -147,7 +223,6 @@ struct World {
     }
     auto t2 = clk::now();
     stats.n_constraints = solver.len();
-    stats.t_integrate = std::chrono::duration<double>(t1 - t0).count();
     stats.t_collide = std::chrono::duration<double>(t2 - t1).count();
   }
 

@@ -147,6 +147,13 @@ def lib():
         L.mgfo_world_step.argtypes = [C.c_void_p, C.c_float, C.c_int64, P(Stats)]
         L.mgfo_world_build_constraints.argtypes = [C.c_void_p, C.c_float, P(Stats)]
         L.mgfo_world_solve.argtypes = [C.c_void_p, C.c_int64]
+        L.mgfo_world_begin_tick.argtypes = [C.c_void_p, C.c_float]
+        L.mgfo_world_collide.argtypes = [C.c_void_p, C.c_float, P(Stats)]
+        L.mgfo_world_select_boundary.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, P(C.c_int64), P(C.c_int64)]
+        L.mgfo_world_export_bodies.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.mgfo_world_import_ghosts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.mgfo_world_export_velocities.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.mgfo_world_import_ghost_velocities.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.mgfo_world_constraint_depth.argtypes = [C.c_void_p, C.c_uint32]
         L.mgfo_world_constraint_depth.restype = C.c_uint32
         L.mgfo_world_get_constraints.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -303,6 +310,42 @@ class World:
 
     def solve(self, iters):
         lib().mgfo_world_solve(self.h, iters)
+
+    # ---- tiling counterpart (numpy buffers) ----
+    def begin_tick(self, dt):
+        lib().mgfo_world_begin_tick(self.h, dt)
+
+    def collide(self, dt):
+        lib().mgfo_world_collide(self.h, dt, C.byref(self.stats))
+        return self.stats
+
+    def select_boundary(self, x_left, x_right):
+        n = len(self)
+        l = np.zeros(max(n, 1), np.uint32)
+        r = np.zeros(max(n, 1), np.uint32)
+        nl, nr = C.c_int64(), C.c_int64()
+        lib().mgfo_world_select_boundary(self.h, x_left, x_right, l.ctypes.data, r.ctypes.data, n, C.byref(nl), C.byref(nr))
+        return l[:nl.value].copy(), r[:nr.value].copy()
+
+    def export_bodies(self, ids):
+        ids = np.ascontiguousarray(ids, np.uint32)
+        out = np.zeros((len(ids), 36), np.float32)
+        lib().mgfo_world_export_bodies(self.h, ids.ctypes.data, len(ids), out.ctypes.data)
+        return out
+
+    def import_ghosts(self, recs):
+        recs = np.ascontiguousarray(recs, np.float32).reshape(-1, 36)
+        lib().mgfo_world_import_ghosts(self.h, recs.ctypes.data, len(recs))
+
+    def export_velocities(self, ids):
+        ids = np.ascontiguousarray(ids, np.uint32)
+        out = np.zeros((len(ids), 8), np.float32)
+        lib().mgfo_world_export_velocities(self.h, ids.ctypes.data, len(ids), out.ctypes.data)
+        return out
+
+    def import_ghost_velocities(self, vel):
+        vel = np.ascontiguousarray(vel, np.float32).reshape(-1, 8)
+        lib().mgfo_world_import_ghost_velocities(self.h, vel.ctypes.data, len(vel))
 
     def constraint_depth(self, iters=1):
         return lib().mgfo_world_constraint_depth(self.h, iters)

@@ -229,7 +229,7 @@ int64_t mgfo_world_add_bodies(void* wp, const o_component* comps, int64_t n, con
   }
   return (int64_t)w->bodies.len();
 }
-int64_t mgfo_world_len(void* wp) { return (int64_t)((World*)wp)->bodies.len(); }
+int64_t mgfo_world_len(void* wp) { return (int64_t)((World*)wp)->n_owned; }
 void mgfo_world_step(void* wp, float dt, int64_t iters, o_stats* st) {
   World* w = (World*)wp;
   w->step(dt, (size_t)iters);
@@ -246,6 +246,48 @@ void mgfo_world_build_constraints(void* wp, float dt, o_stats* st) {
   if (st) {
     const StepStats& s = w->stats;
     *st = o_stats{s.n_constraints, s.n_terrain_constraints, s.n_pair_candidates, s.n_refits, s.t_integrate, s.t_collide, s.t_solve};
+  }
+}
+// ---- tiling counterpart of mgf_world_{begin_tick,collide,select_boundary,export_*,import_*} ----
+void mgfo_world_begin_tick(void* wp, float dt) { ((World*)wp)->begin_tick(dt); }
+void mgfo_world_collide(void* wp, float dt, o_stats* st) {
+  World* w = (World*)wp;
+  w->collide(dt);
+  if (st) {
+    const StepStats& s = w->stats;
+    *st = o_stats{s.n_constraints, s.n_terrain_constraints, s.n_pair_candidates, s.n_refits, s.t_integrate, s.t_collide, s.t_solve};
+  }
+}
+int64_t mgfo_world_owned_len(void* wp) { return (int64_t)((World*)wp)->n_owned; }
+void mgfo_world_select_boundary(void* wp, float x_left, float x_right, uint32_t* ids_l, uint32_t* ids_r, int64_t cap, int64_t* nl, int64_t* nr) {
+  std::vector<uint32_t> l, r;
+  ((World*)wp)->select_boundary(x_left, x_right, &l, &r);
+  *nl = (int64_t)l.size(); *nr = (int64_t)r.size();
+  for (size_t i = 0; i < l.size() && (int64_t)i < cap; ++i) ids_l[i] = l[i];
+  for (size_t i = 0; i < r.size() && (int64_t)i < cap; ++i) ids_r[i] = r[i];
+}
+void mgfo_world_export_bodies(void* wp, const uint32_t* ids, int64_t n, float* out) {
+  for (int64_t i = 0; i < n; ++i) ((World*)wp)->export_body(ids[i], out + 36 * i);
+}
+void mgfo_world_import_ghosts(void* wp, const float* in, int64_t n) {
+  World* w = (World*)wp;
+  w->drop_ghosts();
+  for (int64_t i = 0; i < n; ++i) w->add_ghost(in + 36 * i);
+}
+void mgfo_world_export_velocities(void* wp, const uint32_t* ids, int64_t n, float* out) {
+  World* w = (World*)wp;
+  for (int64_t i = 0; i < n; ++i) {
+    const V3 v = w->bodies.v[ids[i]], o = w->bodies.omega[ids[i]];
+    float* p = out + 8 * i;
+    p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = o.x; p[4] = o.y; p[5] = o.z; p[6] = p[7] = 0.0f;
+  }
+}
+void mgfo_world_import_ghost_velocities(void* wp, const float* in, int64_t n) {
+  World* w = (World*)wp;
+  for (int64_t i = 0; i < n; ++i) {
+    const float* p = in + 8 * i;
+    w->bodies.v[w->n_owned + i] = v3(p[0], p[1], p[2]);
+    w->bodies.omega[w->n_owned + i] = v3(p[3], p[4], p[5]);
   }
 }
 void mgfo_world_solve(void* wp, int64_t iters) { World* w = (World*)wp; w->solver.solve(w->bodies, (size_t)iters); }
@@ -279,7 +321,7 @@ int64_t mgfo_world_get_constraints(void* wp, o_constraint* out, int64_t cap) {
 void mgfo_world_get_state(void* wp, o_vec3* x, o_quat* q, o_vec3* v, o_vec3* omega, o_vec3* delta) {
   World* w = (World*)wp;
   const RigidBodyVec& b = w->bodies;
-  for (size_t i = 0; i < b.len(); ++i) {
+  for (size_t i = 0; i < w->n_owned; ++i) {
     if (x) x[i] = O(b.x[i]);
     if (q) q[i] = o_quat{b.q[i].s, b.q[i].v.x, b.q[i].v.y, b.q[i].v.z};
     if (v) v[i] = O(b.v[i]);
@@ -290,7 +332,7 @@ void mgfo_world_get_state(void* wp, o_vec3* x, o_quat* q, o_vec3* v, o_vec3* ome
 void mgfo_world_set_state(void* wp, const o_vec3* x, const o_quat* q, const o_vec3* v, const o_vec3* omega, const o_vec3* delta) {
   World* w = (World*)wp;
   RigidBodyVec& b = w->bodies;
-  for (size_t i = 0; i < b.len(); ++i) {
+  for (size_t i = 0; i < w->n_owned; ++i) {
     if (x) b.x[i] = V(x[i]);
     if (q) b.q[i] = Quat{q[i].s, v3(q[i].x, q[i].y, q[i].z)};
     if (v) b.v[i] = V(v[i]);

@@ -1,0 +1,96 @@
+"""Multi-tile (multi-GPU) host logic on CPU: the tile driver of mgf_amd/tiles.py with the oracle
+engine, in one process and across two gloo ranks."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from mgf_amd import scenes
+from mgf_amd.tiles import Tile, step_tiles_inprocess
+from tests.oracle_engine import OracleEngine
+from tests.util import oracle_world, rel_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_tiles(nx, ny, nz, P, engine=OracleEngine):
+    tiles = []
+    for r in range(P):
+        sc = scenes.sphere_pile_tile(nx, ny, nz, r, P)
+        tiles.append(Tile(engine(sc), sc["x_range"], r, P, sc["dt"], sc["iters"]))
+    return tiles
+
+
+def test_single_tile_equals_plain_world():
+    sc = scenes.sphere_pile_tile(6, 5, 6, 0, 1)
+    tile = Tile(OracleEngine(sc), sc["x_range"], 0, 1, sc["dt"], sc["iters"])
+    ow = oracle_world(sc)
+    for _ in range(5):
+        step_tiles_inprocess([tile])
+        ow.step(float(sc["dt"]), sc["iters"])
+    a, b = tile.e.state(), ow.state()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_two_tiles_inprocess_ghost_protocol():
+    tiles = make_tiles(6, 5, 6, 2)
+    n_owned = [len(t.e.w) for t in tiles]
+    for tick in range(8):
+        stats = step_tiles_inprocess(tiles)
+        assert all(len(t.e.w) == n for t, n in zip(tiles, n_owned))  # ghosts are not owned bodies
+        assert all(s["n_constraints"] > 0 for s in stats)
+    # each tile exported the bodies of its inner face and nothing else
+    xl = tiles[0].e.state()["x"][tiles[0].e.ids[1], 0]
+    assert len(xl) > 0 and xl.min() > tiles[0].x_hi - 2.5 and len(tiles[0].e.ids[0]) == 0
+    xr = tiles[1].e.state()["x"][tiles[1].e.ids[0], 0]
+    assert len(xr) > 0 and xr.max() < tiles[1].x_lo + 2.5 and len(tiles[1].e.ids[1]) == 0
+    for t in tiles:
+        s = t.e.state()
+        assert np.isfinite(s["x"]).all() and np.isfinite(s["v"]).all()
+
+
+def test_tiled_result_tracks_the_undivided_world():
+    """Block-Jacobi coupling across the slab face is a different iteration than one global Gauss-Seidel;
+    the deviation is measured and bounded, not hidden."""
+    P, nx, ny, nz = 2, 5, 4, 5
+    tiles = make_tiles(nx, ny, nz, P)
+    # the same bodies in one world: concatenate the tiles' scenes
+    scs = [scenes.sphere_pile_tile(nx, ny, nz, r, P) for r in range(P)]
+    merged = dict(scs[0])
+    for key in ("comps", "mass", "restitution", "friction", "force", "v0"):
+        merged[key] = np.concatenate([s[key] for s in scs])
+    ow = oracle_world(merged)
+    for _ in range(10):
+        step_tiles_inprocess(tiles)
+        ow.step(float(merged["dt"]), merged["iters"])
+    whole = ow.state()
+    tiled_v = np.concatenate([t.e.state()["v"] for t in tiles])
+    tiled_x = np.concatenate([t.e.state()["x"] for t in tiles])
+    dv, dx = rel_err(tiled_v, whole["v"]), rel_err(tiled_x, whole["x"])
+    print(f"tiled-vs-undivided deviation after 10 ticks: v {dv:.3e}, x {dx:.3e}")
+    assert dx < 0.05 and dv < 1.0
+
+
+@pytest.mark.timeout(300)
+def test_two_gloo_ranks_match_inprocess_tiles(tmp_path):
+    """world_size 2 over gloo (real point-to-point transport) == the in-process two-tile run, bit for bit."""
+    nx, ny, nz, ticks = 5, 4, 5, 6
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "tests", "tile_worker.py"), str(tmp_path), str(nx), str(ny), str(nz), str(ticks)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    tiles = make_tiles(nx, ny, nz, 2)
+    ncons = [[], []]
+    for _ in range(ticks):
+        for k, s in enumerate(step_tiles_inprocess(tiles)):
+            ncons[k].append(s["n_constraints"])
+    for rank in range(2):
+        got = np.load(tmp_path / f"rank{rank}.npz")
+        want = tiles[rank].e.state()
+        assert got["ncons"].tolist() == ncons[rank]
+        for k in want:
+            assert np.array_equal(got[k], want[k]), f"rank {rank} {k}"
