@@ -135,10 +135,74 @@ def sphere_pile_tile(nx, ny, nz, rank, world_size, seed=SEED, iters=10):
     return sc
 
 
+def heightfield_terrain(quads_x, quads_z, size_x, size_z, amplitude, seed=SEED, pos=(0.0, 0.0, 0.0)):
+    """Static triangle-soup terrain: (quads_x x quads_z) quads = 2*quads_x*quads_z triangles over
+    [-size_x/2, size_x/2] x [-size_z/2, size_z/2], vertex heights U(-amplitude, amplitude), normals up."""
+    vx, vz = quads_x + 1, quads_z + 1
+    xs = np.linspace(-size_x / 2.0, size_x / 2.0, vx, dtype=np.float32)
+    zs = np.linspace(-size_z / 2.0, size_z / 2.0, vz, dtype=np.float32)
+    h = uniform(seed, vx * vz, -amplitude, amplitude, stream=21).reshape(vx, vz)
+    X, Z = np.meshgrid(xs, zs, indexing="ij")
+    verts = np.stack([X.ravel(), h.ravel(), Z.ravel()], axis=1).astype(np.float32)
+    i, k = np.meshgrid(np.arange(quads_x), np.arange(quads_z), indexing="ij")
+    v00 = (i * vz + k).ravel()
+    v01, v10, v11 = v00 + 1, v00 + vz, v00 + vz + 1
+    faces = np.concatenate([np.stack([v00, v01, v10], axis=1), np.stack([v01, v11, v10], axis=1)]).astype(np.uint32)
+    # interleave the two triangles of each quad (insertion order matters for the mesh BVH)
+    faces = faces.reshape(2, -1, 3).transpose(1, 0, 2).reshape(-1, 3)
+    return dict(verts=verts, faces=np.ascontiguousarray(faces), pos=np.asarray(pos, np.float32))
+
+
+def _capsules(centres, dirs, half_len, r):
+    comps = np.zeros(len(centres), dtype=COMPONENT_DTYPE)
+    comps["tag"] = 1
+    d = (dirs * np.float32(2.0 * half_len)).astype(np.float32)
+    comps["p"] = (centres - d * np.float32(0.5)).astype(np.float32)
+    comps["d"] = d
+    comps["r"] = r
+    return comps
+
+
+def _unit_vectors(seed, n, stream):
+    z = uniform(seed, n, -1.0, 1.0, stream=stream)
+    phi = uniform(seed, n, 0.0, 2.0 * np.pi, stream=stream + 1)
+    s = np.sqrt(np.maximum(0.0, 1.0 - z.astype(np.float64) ** 2))
+    return np.stack([s * np.cos(phi), z, s * np.sin(phi)], axis=1).astype(np.float32)
+
+
+def capsule_field(nx, ny, nz, quads=None, seed=SEED, iters=10, pitch=1.6, y0=1.2, sphere_fraction=0.0):
+    """BASELINE config 3 family: nx*ny*nz capsules (r = 0.5, |d| = 0.5: the demo capsule of capsules.rs:67-75
+    at half scale) with seeded random orientations on a lattice above a heightfield of 2*quads^2 triangles
+    (Capsule-Triangle narrowphase).  capsule_field(128, 32, 32, quads=158) is the 131 072-capsule /
+    49 928-triangle configuration.  sphere_fraction > 0 mixes in spheres (r = 0.5)."""
+    n = nx * ny * nz
+    i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    base = np.stack([(i.ravel() - (nx - 1) / 2.0) * pitch, y0 + j.ravel() * pitch, (k.ravel() - (nz - 1) / 2.0) * pitch], axis=1)
+    jit = np.stack([uniform(seed, n, -0.05, 0.05, stream=s) for s in (31, 32, 33)], axis=1)
+    c = (base + jit).astype(np.float32)
+    dirs = _unit_vectors(seed, n, 34)
+    comps = _capsules(c, dirs, 0.25, 0.5)
+    if sphere_fraction > 0.0:
+        is_sphere = uniform01(seed, n, stream=36) < sphere_fraction
+        comps["tag"][is_sphere] = 0
+        comps["p"][is_sphere] = c[is_sphere]
+        comps["d"][is_sphere] = 0.0
+    v0 = np.stack([uniform(seed, n, -0.5, 0.5, stream=s) for s in (37, 38, 39)], axis=1)
+    perm = seeded_permutation(seed, n, stream=40)
+    comps, v0 = comps[perm], v0[perm]
+    if quads is None:
+        quads = max(4, int(round(max(nx, nz) * pitch / 1.3)))
+    size_x, size_z = nx * pitch + 4.0, nz * pitch + 4.0
+    terrain = heightfield_terrain(quads, quads, size_x, size_z, 0.2, seed=seed)
+    return _scene(f"capsule_field_{nx}x{ny}x{nz}_q{quads}", comps, terrain, v0=v0, iters=iters)
+
+
 def config(idx):
     """BASELINE.json configs by index."""
     if idx == 0:
         return balls_demo(8)
     if idx == 1:
         return sphere_pile(64, 64, 64)
+    if idx == 2:
+        return capsule_field(128, 32, 32, quads=158)
     raise NotImplementedError(f"config {idx}")

@@ -1,0 +1,105 @@
+"""BASELINE.json's full-size configurations on the GPU: a one-tick comparison with the oracle (the
+oracle needs a few seconds per tick at this size) and size-independent properties of the tick:
+determinism, constraint-list invariants, schedule coverage, finite state, momentum bookkeeping."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.util import compare_constraints, oracle_world, rel_err, values_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import mgf_amd
+    c = mgf_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _scene(name):
+    from mgf_amd import scenes
+    return scenes.sphere_pile(64, 64, 64) if name == "config2_spheres_262144" else scenes.capsule_field(128, 32, 32, quads=158, y0=0.9)
+
+
+@pytest.mark.parametrize("name", ["config2_spheres_262144", "config3_capsules_131072_tris_49928"])
+def test_full_size_tick_matches_oracle_and_properties(ctx, name):
+    import mgf_amd
+    scene = _scene(name)
+    dt, iters = float(scene["dt"]), scene["iters"]
+    n = len(scene["comps"])
+    assert n == (262144 if "spheres" in name else 131072)
+    if "capsules" in name:
+        assert len(scene["terrain"]["faces"]) == 49928
+    gw = mgf_amd.World.from_scene(ctx, scene)
+    gw2 = mgf_amd.World.from_scene(ctx, scene)
+    ow = oracle_world(scene)
+    # --- tick 1 against the oracle: constraint list and post-step state
+    ow.build_constraints(dt)
+    st = gw.build_constraints(dt)
+    oc, gc = ow.constraints(), gw.constraints()
+    compare_constraints(gc, oc)
+    ow.solve(iters)
+    gw.solve(iters)
+    g, o = gw.state(), ow.state()
+    for k in ("x", "q", "v", "omega", "delta"):
+        assert rel_err(g[k], o[k]) <= 1e-4, k
+        assert values_equal(g[k], o[k]), f"{k} not bit-identical"
+    assert gw.stats.n_levels == ow.constraint_depth(iters)
+    # --- constraint-list invariants (size independent)
+    a, b = gc["a"], gc["b"]
+    assert (a >= 0).all() and (a < n).all() and (b < a).all()          # partner j < i (world.rs:266); static = -1
+    assert np.all(np.diff(a) >= 0)                                      # insertion order: body i ascending
+    same = a[1:] == a[:-1]
+    bt, bn = b[:-1][same], b[1:][same]
+    assert np.all((bt == -1) | (bn != -1))                              # terrain constraints precede partners
+    both = (bt >= 0) & (bn >= 0)
+    assert np.all(bn[both] > bt[both])                                  # partners ascending, no duplicates
+    nrm = np.linalg.norm(gc["normal"].astype(np.float64), axis=1)
+    assert np.allclose(nrm, 1.0, atol=1e-5)
+    assert (gc["normal_impulse"] >= 0).all() and np.isfinite(gc["normal_mass"]).all()
+    # body-body impulses are equal and opposite: the pair constraints cannot change total momentum.
+    # (unit masses) total change of momentum = gravity + terrain constraints only
+    # --- determinism: an independent world built from the same arrays gives the same bits
+    for _ in range(3):
+        s1 = gw2.step(dt, iters)
+    for _ in range(2):
+        gw.step(dt, iters)
+    a1, a2 = gw.state(), gw2.state()
+    for k in a1:
+        assert np.array_equal(a1[k].view(np.uint32), a2[k].view(np.uint32)), f"non-deterministic {k}"
+        assert np.isfinite(a1[k]).all()
+    assert s1.n_constraints == gw.stats.n_constraints
+    # --- a later, contact-rich tick: advance the GPU, teacher-force the oracle from its state, compare one tick
+    for _ in range(40 if "capsules" in name else 15):
+        gw.step(dt, iters)
+    s = gw.state()
+    ow.set_state(x=s["x"], q=s["q"], v=s["v"], omega=s["omega"], delta=s["delta"])
+    ow.build_constraints(dt)
+    st2 = gw.build_constraints(dt)
+    compare_constraints(gw.constraints(), ow.constraints())
+    ow.solve(iters)
+    gw.solve(iters)
+    g, o = gw.state(), ow.state()
+    for k in ("x", "q", "v", "omega", "delta"):
+        assert values_equal(g[k], o[k]), f"later tick: {k} not bit-identical (rel err {rel_err(g[k], o[k])})"
+    print(f"{name}: later tick {st2.n_constraints} constraints ({st2.n_terrain_constraints} terrain)")
+    print(f"{name}: {st.n_constraints} constraints, {gw.stats.n_levels} solver launches, "
+          f"{st.n_pair_candidates} pair candidates, {st.n_terrain_candidates} terrain candidates")
+
+
+def test_pair_constraints_conserve_momentum(ctx):
+    """Solve only the body-body constraints of a large pile (no gravity step, no terrain): total linear
+    momentum is unchanged up to f32 accumulation (every impulse is applied +/- to the two bodies)."""
+    import mgf_amd
+    from mgf_amd import scenes
+    scene = scenes.sphere_pile(40, 40, 40)
+    scene = dict(scene, terrain=None)
+    gw = mgf_amd.World.from_scene(ctx, scene)
+    gw.build_constraints(float(scene["dt"]))
+    assert gw.stats.n_constraints > 50000 and gw.stats.n_terrain_constraints == 0
+    p0 = gw.state()["v"].astype(np.float64).sum(axis=0)
+    gw.solve(10)
+    p1 = gw.state()["v"].astype(np.float64).sum(axis=0)
+    assert np.abs(p1 - p0).max() < 1e-2 * np.sqrt(len(gw)), (p0, p1)

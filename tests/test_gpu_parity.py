@@ -100,19 +100,24 @@ def _compare_state(gw, ow, what, exact=True):
             assert values_equal(g[k], o[k]), f"{what}: {k} not bit-identical (rel err {e})"
 
 
-@pytest.mark.parametrize("scene_name", ["balls8", "pile12", "pile16_noshuffle"])
+@pytest.mark.parametrize("scene_name", ["balls8", "pile12", "pile16_noshuffle", "capsules", "mixed"])
 def test_world_step_parity_teacher_forced(ctx, scene_name):
     """Per-step parity from identical snapshots: constraint list, then post-step state."""
     import mgf_amd
     from mgf_amd import scenes
     scene = {"balls8": lambda: scenes.balls_demo(8), "pile12": lambda: scenes.sphere_pile(12, 12, 12),
-             "pile16_noshuffle": lambda: scenes.sphere_pile(16, 8, 16, shuffle=False)}[scene_name]()
+             "pile16_noshuffle": lambda: scenes.sphere_pile(16, 8, 16, shuffle=False),
+             "capsules": lambda: scenes.capsule_field(8, 3, 8),                       # Capsule-Capsule, Capsule-Triangle
+             "mixed": lambda: scenes.capsule_field(8, 3, 8, sphere_fraction=0.5),     # all four pair types + binning
+             }[scene_name]()
     dt, iters = float(scene["dt"]), scene["iters"]
     ow = oracle_world(scene)
     gw = mgf_amd.World.from_scene(ctx, scene)
     _compare_state(gw, ow, "initial")
     # let the oracle run the scene forward; at chosen steps teacher-force the GPU from the oracle snapshot
     checkpoints = {0, 1, 2, 5, 20, 60, 140, 141, 142, 170, 200} if scene_name == "balls8" else {0, 1, 2, 3, 10, 25, 40}
+    if scene_name in ("capsules", "mixed"):
+        checkpoints = {0, 10, 20, 30, 31, 45, 60, 75, 90, 120}
     last = max(checkpoints)
     total_constraints = 0
     for step in range(last + 1):
