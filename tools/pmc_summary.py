@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as
+MI355X_MICROARCH.md prescribes).  Counter unit: KiB.  On gfx950 FETCH_SIZE reads exactly 1/2 of a wide
+coalesced read stream (guide §HBM); both the raw and the x2-corrected read side are reported.
+
+    python tools/pmc_summary.py gpurun_out/pmc_fetch/pmc_counter_collection.csv gpurun_out/pmc_write/pmc_counter_collection.csv
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def load(path, counter):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            name = row["Kernel_Name"].split("(")[0]
+            tot[name] += float(row["Counter_Value"])
+            cnt[name] += 1
+    return tot, cnt
+
+
+def main():
+    fetch, fc = load(sys.argv[1], "FETCH_SIZE")
+    write, wc = load(sys.argv[2], "WRITE_SIZE")
+    rows = []
+    for k in fetch:
+        n = fc[k]
+        f = fetch[k] * 1024.0 / n
+        w = write.get(k, 0.0) * 1024.0 / max(wc.get(k, 1), 1)
+        rows.append(dict(kernel=k, launches=n, fetch_bytes_per_launch_raw=f, write_bytes_per_launch=w,
+                         hbm_bytes_per_launch_raw=f + w, hbm_bytes_per_launch_fetch_x2=2 * f + w))
+    rows.sort(key=lambda r: -r["hbm_bytes_per_launch_raw"] * r["launches"])
+    print(f"{'kernel':60s} {'launches':>8s} {'fetch/launch':>14s} {'write/launch':>14s} {'total raw':>14s} {'total fetchx2':>14s}")
+    for r in rows[:25]:
+        print(f"{r['kernel'][:60]:60s} {r['launches']:8d} {r['fetch_bytes_per_launch_raw']:14.0f} {r['write_bytes_per_launch']:14.0f} "
+              f"{r['hbm_bytes_per_launch_raw']:14.0f} {r['hbm_bytes_per_launch_fetch_x2']:14.0f}")
+    if len(sys.argv) > 3:
+        json.dump(rows, open(sys.argv[3], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
