@@ -2,9 +2,9 @@
 //
 //   k_integrate        RigidBodyVec::complete_motion + integrate (physics.rs:222-269), swept AABB
 //                      (bounds.rs:60-68), fat-AABB refit test (world.rs:234-238)
-//   k_scene_bounds / k_morton / k_lbvh_low / k_lbvh_top
-//                      per-tick linear BVH over the fat AABBs: Morton sort + implicit complete tree
-//                      built by reductions, top 10 levels staged in LDS (replaces the sequentially mutated
+//   k_scene_bounds / k_morton / k_lbvh_leaves / k_lbvh_low / k_lbvh_top
+//                      per-tick linear BVH over the fat AABBs: Morton sort + implicit complete 4-ary tree
+//                      over Morton cells, built by reductions, top 5 levels staged in LDS (replaces the sequentially mutated
 //                      AVL tree of bvh.rs for the world broadphase; the hit SET is identical
 //                      because acceptance is the reference's own predicate)
 //   k_candidates<FILL> BVH::query (bvh.rs:283-310) for every body at once: mesh-BVH DFS in the
@@ -165,7 +165,7 @@ __global__ void k_reset_step(SceneBounds* sb, uint32_t* err) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     for (int k = 0; k < 3; ++k) { sb->lo[k] = 0x7FFFFFFF; sb->hi[k] = (int)0x80000000; }
     sb->n_refits = 0; sb->pad = 0;
-    *err = 0;
+    err[0] = 0; err[1] = 0;  // traversal stack overflow, candidate row overflow
   }
 }
 
@@ -196,71 +196,122 @@ __global__ __launch_bounds__(kBlock) void k_morton(const float4* fb_c, uint32_t 
   vals[i] = i;
 }
 
-// Linear BVH as an implicit complete binary tree over the Morton-sorted leaves (1-based heap:
-// node k has children 2k and 2k+1, leaves are positions [npad, 2*npad)).  Built by plain
-// reductions (no atomics, no fences), traversed without a stack, top levels staged in LDS.
-struct HNode { float4 lo, hi; };  // min.xyz / max.xyz of the subtree's fat boxes
+// Linear BVH as an implicit complete 4-ary tree over MORTON CELLS.  A leaf is the cell of one 2L-bit
+// Morton prefix (an axis-aligned region of the scene) and owns the contiguous range of sorted bodies
+// whose key has that prefix; internal nodes are shorter prefixes, so every node is a spatial region
+// by construction and its box (union of the contained fat boxes) stays compact however the bodies
+// move.  An internal node stores the boxes of its four children (128 bytes: one fetch decides four
+// subtrees); last-level nodes also carry their children's body ranges in the .w words.  Level l
+// holds 4^l nodes at heap offset (4^l - 1) / 3; node k's children are 4k+1 .. 4k+4.  Built by plain
+// reductions (no atomics, no fences); traversed with a register-only bitmask trail; top levels in LDS.
+struct QNode { float4 lo[4], hi[4]; };     // child c: min = lo[c].xyz, max = hi[c].xyz; last level: lo.w = first body, hi.w = end
+struct LeafRec { float4 c, r; };           // fat box centre | body index, half extents (sorted order)
 struct Lbvh {
-  HNode* nodes;        // internal nodes [1, npad); nodes[0] unused
-  float4* leaf_c;      // sorted order: fat c.xyz, body index
-  float4* leaf_r;      //               fat r.xyz, -
+  QNode* nodes;        // (4^levels - 1) / 3 internal nodes
+  LeafRec* leaves;     // n records in Morton order
   const uint32_t* sidx;
-  uint32_t n;          // live leaves
-  uint32_t npad;       // leaves padded to a power of two (>= 2)
+  const uint32_t* skeys;
+  uint32_t* cell_lo;   // 4^levels cells: first body / end of each cell's range
+  uint32_t* cell_hi;
+  uint32_t n;          // live bodies
+  uint32_t levels;     // internal levels L >= 4; 4^L leaf cells
   uint32_t* err;
+  unsigned long long* dbg;  // optional: [0] node fetches, [1] leaf records tested, [2] max fetches of one query
 };
-constexpr int kLdsNodes = 1024;  // heap nodes [1, 1024) = 10 levels, 32 KB
+constexpr int kLdsQNodes = 341;  // levels 0..4 (1 + 4 + 16 + 64 + 256 nodes), 43 KB
+constexpr int kMortonBits = 30;
+__host__ __device__ __forceinline__ uint32_t qlevel_offset(uint32_t l) { return ((1u << (2 * l)) - 1u) / 3u; }
 
-// One block per 256 consecutive leaves: leaf records + the 8 levels above them.
-__global__ __launch_bounds__(kBlock) void k_lbvh_low(Lbvh T, const float4* fb_c, const float4* fb_r) {
-  __shared__ float s_lo[3][kBlock], s_hi[3][kBlock];
+__device__ __forceinline__ void box_min_max(V3& lo, V3& hi, V3 l, V3 h) {
+  lo = mk3(fminf(lo.x, l.x), fminf(lo.y, l.y), fminf(lo.z, l.z));
+  hi = mk3(fmaxf(hi.x, h.x), fmaxf(hi.y, h.y), fmaxf(hi.z, h.z));
+}
+
+// Sorted bodies -> leaf records + cell ranges (cell_lo/cell_hi pre-set to 0: empty cells have lo == hi).
+__global__ __launch_bounds__(kBlock) void k_lbvh_leaves(Lbvh T, const float4* fb_c, const float4* fb_r) {
   uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= T.n) return;
+  uint32_t body = T.sidx[p];
+  LeafRec lr; lr.c = mk4(xyz(fb_c[body]), u2f(body)); lr.r = mk4(xyz(fb_r[body]), 0.0f);
+  T.leaves[p] = lr;
+  const int shift = kMortonBits - 2 * (int)T.levels;
+  uint32_t cell = T.skeys[p] >> shift;
+  if (p == 0 || (T.skeys[p - 1] >> shift) != cell) T.cell_lo[cell] = p;
+  if (p + 1 == T.n || (T.skeys[p + 1] >> shift) != cell) T.cell_hi[cell] = p + 1;
+}
+
+// One block per 256 consecutive cells: the 4 internal levels above them.
+// Block b owns the subtree rooted at level L-4, index b; its union box goes to sub_lo/sub_hi[b].
+__global__ __launch_bounds__(kBlock) void k_lbvh_low(Lbvh T, float4* sub_lo, float4* sub_hi) {
+  __shared__ float s_lo[3][kBlock], s_hi[3][kBlock];
+  __shared__ uint32_t s_rng[2][kBlock];
+  const int t = threadIdx.x;
+  uint32_t g = blockIdx.x * kBlock + t;
   V3 lo = mk3(kInf, kInf, kInf), hi = mk3(-kInf, -kInf, -kInf);
-  if (p < T.n) {
-    uint32_t body = T.sidx[p];
-    V3 c = xyz(fb_c[body]), r = xyz(fb_r[body]);
-    T.leaf_c[p] = mk4(c, u2f(body));
-    T.leaf_r[p] = mk4(r, 0.0f);
-    lo = c - r; hi = c + r;
+  uint32_t b0 = T.cell_lo[g], b1 = T.cell_hi[g];
+  for (uint32_t p = b0; p < b1; ++p) {
+    LeafRec lr = T.leaves[p];
+    box_min_max(lo, hi, xyz(lr.c) - xyz(lr.r), xyz(lr.c) + xyz(lr.r));
   }
-  int t = threadIdx.x;
   s_lo[0][t] = lo.x; s_lo[1][t] = lo.y; s_lo[2][t] = lo.z;
   s_hi[0][t] = hi.x; s_hi[1][t] = hi.y; s_hi[2][t] = hi.z;
+  s_rng[0][t] = b0; s_rng[1][t] = b1;
   __syncthreads();
-  // level widths 128, 64, ..., 1; the node of width-w entry e is heap index (npad + block_base) / (256 / w) + e
-  uint32_t first = T.npad + blockIdx.x * kBlock;
-  for (int w = kBlock / 2; w >= 1; w >>= 1) {
-    first >>= 1;
-    float l[3], h[3];
+  // widths 64, 16, 4, 1 at levels L-1 .. L-4
+  uint32_t lvl = T.levels;
+  uint32_t first = blockIdx.x * kBlock;  // index of this block's first entry within the level below
+  for (int w = kBlock / 4; w >= 1; w >>= 2) {
+    lvl -= 1;
+    first >>= 2;
+    QNode nd;
+    V3 ulo = mk3(kInf, kInf, kInf), uhi = mk3(-kInf, -kInf, -kInf);
     if (t < w) {
-      for (int k = 0; k < 3; ++k) { l[k] = fminf(s_lo[k][2 * t], s_lo[k][2 * t + 1]); h[k] = fmaxf(s_hi[k][2 * t], s_hi[k][2 * t + 1]); }
-    }
-    __syncthreads();
-    if (t < w) {
-      for (int k = 0; k < 3; ++k) { s_lo[k][t] = l[k]; s_hi[k][t] = h[k]; }
-      if (first + t >= 1 && first + t < T.npad) {
-        HNode nd; nd.lo = make_float4(l[0], l[1], l[2], 0.0f); nd.hi = make_float4(h[0], h[1], h[2], 0.0f);
-        T.nodes[first + t] = nd;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        V3 l = mk3(s_lo[0][4 * t + c], s_lo[1][4 * t + c], s_lo[2][4 * t + c]);
+        V3 h = mk3(s_hi[0][4 * t + c], s_hi[1][4 * t + c], s_hi[2][4 * t + c]);
+        bool leaf_level = (w == kBlock / 4);
+        nd.lo[c] = mk4(l, leaf_level ? u2f(s_rng[0][4 * t + c]) : 0.0f);
+        nd.hi[c] = mk4(h, leaf_level ? u2f(s_rng[1][4 * t + c]) : 0.0f);
+        box_min_max(ulo, uhi, l, h);
       }
+      T.nodes[qlevel_offset(lvl) + first + t] = nd;
     }
     __syncthreads();
-    if (first <= 1) break;  // reached the root inside this block (npad <= 256)
+    if (t < w) {
+      s_lo[0][t] = ulo.x; s_lo[1][t] = ulo.y; s_lo[2][t] = ulo.z;
+      s_hi[0][t] = uhi.x; s_hi[1][t] = uhi.y; s_hi[2][t] = uhi.z;
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    sub_lo[blockIdx.x] = make_float4(s_lo[0][0], s_lo[1][0], s_lo[2][0], 0.0f);
+    sub_hi[blockIdx.x] = make_float4(s_hi[0][0], s_hi[1][0], s_hi[2][0], 0.0f);
   }
 }
-// Single block: the levels above the per-block roots (heap indices < npad / 256).
-__global__ __launch_bounds__(1024) void k_lbvh_top(Lbvh T) {
-  uint32_t m = T.npad / kBlock;  // number of per-block roots, heap indices [m, 2m)
-  for (uint32_t w = m / 2; w >= 1; w >>= 1) {  // nodes [w, 2w)
+// Single block: levels L-5 .. 0 above the per-block subtree roots (4^(L-4) of them), ping-ponging the
+// per-node union boxes between two scratch arrays.
+__global__ __launch_bounds__(1024) void k_lbvh_top(Lbvh T, float4* a_lo, float4* a_hi, float4* b_lo, float4* b_hi) {
+  uint32_t m = 1u << (2 * (T.levels - 4));  // entries in a_lo/a_hi
+  for (int lvl = (int)T.levels - 5; lvl >= 0; --lvl) {
+    uint32_t w = m >> 2;
     for (uint32_t e = threadIdx.x; e < w; e += blockDim.x) {
-      uint32_t k = w + e;
-      HNode a = T.nodes[2 * k], b = T.nodes[2 * k + 1];
-      HNode nd;
-      nd.lo = make_float4(fminf(a.lo.x, b.lo.x), fminf(a.lo.y, b.lo.y), fminf(a.lo.z, b.lo.z), 0.0f);
-      nd.hi = make_float4(fmaxf(a.hi.x, b.hi.x), fmaxf(a.hi.y, b.hi.y), fmaxf(a.hi.z, b.hi.z), 0.0f);
-      T.nodes[k] = nd;
+      QNode nd;
+      V3 ulo = mk3(kInf, kInf, kInf), uhi = mk3(-kInf, -kInf, -kInf);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float4 l = a_lo[4 * e + c], h = a_hi[4 * e + c];
+        nd.lo[c] = l; nd.hi[c] = h;
+        box_min_max(ulo, uhi, xyz(l), xyz(h));
+      }
+      T.nodes[qlevel_offset((uint32_t)lvl) + e] = nd;
+      b_lo[e] = mk4(ulo, 0.0f); b_hi[e] = mk4(uhi, 0.0f);
     }
     __syncthreads();
-    if (w == 1) break;
+    float4* t;
+    t = a_lo; a_lo = b_lo; b_lo = t;
+    t = a_hi; a_hi = b_hi; b_hi = t;
+    m = w;
   }
 }
 
@@ -278,7 +329,7 @@ struct TerrainDev {
   uint32_t* err;          // set to 1 if a traversal stack overflows
 };
 
-constexpr int kStack = 64;
+constexpr int kStack = 32;  // reference-built trees are AVL-balanced: depth <= 1.44 log2(faces)
 
 // bvh.rs:283-310 with the reference's order: push lchild, push rchild, pop rchild first.
 template <class F>
@@ -301,40 +352,83 @@ __device__ __forceinline__ void terrain_traverse(const TerrainDev& M, const Box&
   }
 }
 
-// Stackless DFS over the implicit tree.  `top` = LDS copy of nodes [0, kLdsNodes).
+// Depth-first traversal of the implicit 4-ary tree with a bitmask trail (4 pending-child bits per level)
+// instead of a stack.  `top` = LDS copy of nodes [0, kLdsQNodes).
 template <class F>
-__device__ __forceinline__ void lbvh_traverse(const Lbvh& T, const HNode* top, uint32_t i, const Box& q, float pad_abs, F&& emit) {
+__device__ __forceinline__ void lbvh_traverse(const Lbvh& T, const QNode* top, uint32_t i, const Box& q, float pad_abs, F&& emit) {
   if (T.n < 2) return;  // a single body has no partner
   // Inner nodes hold min/max unions: test them against a query padded well past f32 rounding so the
   // exact (centre, half-extent) acceptance test at the leaves is never pre-empted.
   float pad = pad_abs + 1e-5f * (fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z);
   V3 qlo = q.c - q.r - mk3(pad, pad, pad), qhi = q.c + q.r + mk3(pad, pad, pad);
-  const uint32_t npad = T.npad;
-  uint32_t k = 1;
+  const int last = (int)T.levels - 1;
+  uint64_t trail = 0;
+  uint32_t k = 0;
+  int lvl = 0;
+  bool fresh = true;
+  uint32_t dbg_nodes = 0, dbg_leaves = 0;
   for (;;) {
-    bool descend = false;
-    if (k < npad) {
-      float4 lo, hi;
-      if (k < (uint32_t)kLdsNodes) { lo = top[k].lo; hi = top[k].hi; }
-      else { lo = T.nodes[k].lo; hi = T.nodes[k].hi; }
-      descend = qlo.x <= hi.x && lo.x <= qhi.x && qlo.y <= hi.y && lo.y <= qhi.y && qlo.z <= hi.z && lo.z <= qhi.z;
-    } else {
-      uint32_t p = k - npad;
-      if (p < T.n) {
-        float4 lc = T.leaf_c[p];
-        uint32_t j = f2u(lc.w);
-        if (j < i) {  // world.rs:266
-          Box fb; fb.c = xyz(lc); fb.r = xyz(T.leaf_r[p]);
-          if (box_overlaps(q, fb)) emit(j);  // the reference's own acceptance test (bvh.rs:297)
-        }
+    uint32_t m;
+    if (fresh) {
+      ++dbg_nodes;
+      const QNode* nd = (k < (uint32_t)kLdsQNodes) ? &top[k] : &T.nodes[k];
+      m = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float4 lo = nd->lo[c], hi = nd->hi[c];
+        bool ov = qlo.x <= hi.x && lo.x <= qhi.x && qlo.y <= hi.y && lo.y <= qhi.y && qlo.z <= hi.z && lo.z <= qhi.z;
+        m |= ov ? (1u << c) : 0u;
       }
+    } else {
+      m = (uint32_t)(trail >> (4 * lvl)) & 15u;
     }
-    if (descend) { k = 2 * k; continue; }
-    k = k + 1;
-    k >>= __builtin_ctz(k);  // climb past finished right subtrees, step to the next sibling
-    if (k == 1) break;
+    if (m) {
+      int c = __builtin_ctz(m);
+      m &= m - 1;
+      trail = (trail & ~(15ull << (4 * lvl))) | ((uint64_t)m << (4 * lvl));
+      if (lvl == last) {
+        // child c is a Morton cell: its body range rides in the node's .w words
+        const QNode* nd = (k < (uint32_t)kLdsQNodes) ? &top[k] : &T.nodes[k];
+        uint32_t p0 = f2u(nd->lo[c].w), p1 = f2u(nd->hi[c].w);
+        dbg_leaves += p1 - p0;
+        for (uint32_t pb = p0; pb < p1; pb += 4) {
+          LeafRec lr[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lr[e] = T.leaves[min(pb + e, p1 - 1)];  // independent loads in flight together
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            uint32_t j = f2u(lr[e].c.w);
+            if (pb + e < p1 && j < i) {  // world.rs:266
+              Box fb; fb.c = xyz(lr[e].c); fb.r = xyz(lr[e].r);
+              if (box_overlaps(q, fb)) emit(j);  // the reference's own acceptance test (bvh.rs:297)
+            }
+          }
+        }
+        fresh = false;
+        continue;
+      }
+      k = 4 * k + 1 + (uint32_t)c;
+      ++lvl;
+      fresh = true;
+      continue;
+    }
+    if (lvl == 0) break;
+    k = (k - 1) >> 2;
+    --lvl;
+    fresh = false;
+  }
+  if (T.dbg) {
+    atomicAdd(&T.dbg[0], (unsigned long long)dbg_nodes);
+    atomicAdd(&T.dbg[1], (unsigned long long)dbg_leaves);
+    atomicMax(&T.dbg[2], (unsigned long long)dbg_nodes);
   }
 }
+
+// XCD-aware query mapping: workgroup b is observed to run on XCD b % 8, each with a private 4 MB L2.
+// Give XCD x the x-th contiguous eighth of the Morton-ordered queries, so the part of the tree it
+// walks (a spatial eighth of the scene) stays resident in its own L2.  Launch xcd_grid(n) blocks.
+__host__ __device__ __forceinline__ uint32_t xcd_blocks_per(uint32_t n) { return ((n + kBlock - 1) / kBlock + 7) / 8; }
+__device__ __forceinline__ uint32_t xcd_logical_block() { return (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3); }
 
 // FILL = false: count hits per body.  FILL = true: write them (CSR), partners sorted ascending.
 // Bodies [n_owned, n) are ghosts (copies of a neighbouring tile's bodies): they query the tree like
@@ -344,13 +438,16 @@ __global__ __launch_bounds__(kBlock) void k_candidates(Bodies B, uint32_t n, uin
                                                        uint32_t* t_cnt, uint32_t* p_cnt, const uint32_t* t_off,
                                                        const uint32_t* p_off, uint32_t* t_cand, uint32_t* t_owner,
                                                        uint32_t* p_cand, uint32_t* p_owner) {
-  __shared__ HNode s_top[kLdsNodes];
+  __shared__ QNode s_top[kLdsQNodes];
   {
-    uint32_t lim = T.n >= 2 ? min((uint32_t)kLdsNodes, T.npad) : 0u;
-    for (uint32_t e = threadIdx.x; e < lim; e += kBlock) s_top[e] = T.nodes[e];
+    uint32_t total = qlevel_offset(T.levels);
+    uint32_t lim = T.n >= 2 ? min((uint32_t)kLdsQNodes, total) : 0u;
+    const float4* src = reinterpret_cast<const float4*>(T.nodes);
+    float4* dst = reinterpret_cast<float4*>(s_top);
+    for (uint32_t e = threadIdx.x; e < lim * 8u; e += kBlock) dst[e] = src[e];
     __syncthreads();
   }
-  uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+  uint32_t k = xcd_logical_block() * kBlock + threadIdx.x;
   if (k >= n) return;
   uint32_t i = T.n >= 1 ? T.sidx[k] : k;  // walk bodies in Morton order: neighbouring lanes share tree paths
   Box q; q.c = xyz(B.tb_c[i]); q.r = xyz(B.tb_r[i]);
@@ -379,6 +476,149 @@ __global__ __launch_bounds__(kBlock) void k_candidates(Bodies B, uint32_t n, uin
     while (b > 0 && p_cand[pb + b - 1] > v) { p_cand[pb + b] = p_cand[pb + b - 1]; --b; }
     p_cand[pb + b] = v;
   }
+}
+
+// Single-pass candidate generation into fixed-capacity global rows (the common case); bodies with more
+// hits than a row holds raise `overflow` and the host re-runs the exact two-pass path (k_candidates).
+constexpr int kRowCap = 32;   // partner row
+constexpr int kRowCapT = 16;  // terrain row
+
+// Terrain faces per body, reference DFS order (mesh.rs:121, bvh.rs:283-310).  One lane per body.
+__global__ __launch_bounds__(kBlock) void k_terrain_rows(Bodies B, uint32_t n_owned, TerrainDev M, uint32_t* rows_t, uint32_t* t_cnt,
+                                                         uint32_t* overflow) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_owned) return;
+  Box q; q.c = xyz(B.tb_c[i]) + -mk3(M.x[0], M.x[1], M.x[2]); q.r = xyz(B.tb_r[i]);
+  uint32_t* row = rows_t + (size_t)i * kRowCapT;
+  uint32_t nt = 0;
+  terrain_traverse(M, q, [&](uint32_t face) {
+    if (nt < (uint32_t)kRowCapT) row[nt] = face;
+    ++nt;
+  });
+  t_cnt[i] = nt;
+  if (nt > (uint32_t)kRowCapT) *overflow = 1u;
+}
+
+// Partner bodies per body: cooperative traversal, 8 lanes per query.  A 4-ary node is eight 16-byte
+// words (lo[0..3], hi[0..3]); lane s of the group loads word s, so a node costs ONE cache-line lookup
+// per query instead of eight per lane (the per-lane form is bound by L1 tag lookups once neighbouring
+// queries stop walking in lock-step).  Lanes 0-3 test child s against the query (hi comes from lane
+// s+4 by shuffle), a ballot yields the 4-bit child mask, and the traversal state (node, level, trail)
+// is replicated in the group's lanes so its control flow stays uniform.  Leaf cells: lane pairs load
+// one 32-byte record each (4 records per step).
+constexpr int kCoopLanes = 8;
+constexpr int kCoopBlock = 512;                 // 64 queries per block
+constexpr int kCoopLdsNodes = 85;               // levels 0..3 staged in LDS (10.9 KB)
+__device__ __forceinline__ uint32_t xcd_logical_block_coop() { return (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3); }
+
+__global__ __launch_bounds__(kCoopBlock) void k_pair_rows(Bodies B, uint32_t n, uint32_t n_owned, Lbvh T, float pad_abs, uint32_t* rows_p,
+                                                          uint32_t* p_cnt, uint32_t* overflow) {
+  __shared__ float4 s_top[kCoopLdsNodes * 8];
+  {
+    uint32_t total = qlevel_offset(T.levels);
+    uint32_t lim = T.n >= 2 ? min((uint32_t)kCoopLdsNodes, total) : 0u;
+    const float4* src = reinterpret_cast<const float4*>(T.nodes);
+    for (uint32_t e = threadIdx.x; e < lim * 8u; e += kCoopBlock) s_top[e] = src[e];
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7;
+  const int gbase = lane & ~7;
+  uint32_t kq = xcd_logical_block_coop() * (kCoopBlock / kCoopLanes) + (threadIdx.x >> 3);
+  if (kq >= n) return;  // whole group leaves together
+  uint32_t i = T.sidx[kq];  // Morton order: neighbouring groups walk neighbouring subtrees
+  uint32_t np = 0;
+  if (i != 0 && T.n >= 2) {  // world.rs:256
+    Box q; q.c = xyz(B.tb_c[i]); q.r = xyz(B.tb_r[i]);
+    float pad = pad_abs + 1e-5f * (fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z);
+    V3 qlo = q.c - q.r - mk3(pad, pad, pad), qhi = q.c + q.r + mk3(pad, pad, pad);
+    uint32_t* row = rows_p + (size_t)i * kRowCap;
+    const float4* gnodes = reinterpret_cast<const float4*>(T.nodes);
+    const float4* gleaves = reinterpret_cast<const float4*>(T.leaves);
+    const int last = (int)T.levels - 1;
+    uint64_t trail = 0;
+    uint32_t k = 0;
+    int lvl = 0;
+    bool fresh = true;
+    float4 v = make_float4(0, 0, 0, 0);  // this lane's word of the current node
+    for (;;) {
+      uint32_t m;
+      if (fresh) {
+        v = (k < (uint32_t)kCoopLdsNodes) ? s_top[k * 8 + sub] : gnodes[(size_t)k * 8 + sub];
+        // lanes 0-3: lo[sub]; their hi[sub] sits in lane sub + 4
+        float hx = __shfl(v.x, gbase + (sub & 3) + 4), hy = __shfl(v.y, gbase + (sub & 3) + 4), hz = __shfl(v.z, gbase + (sub & 3) + 4);
+        bool ov = sub < 4 && qlo.x <= hx && v.x <= qhi.x && qlo.y <= hy && v.y <= qhi.y && qlo.z <= hz && v.z <= qhi.z;
+        unsigned long long bal = __ballot(ov);
+        m = (uint32_t)(bal >> gbase) & 15u;
+      } else {
+        m = (uint32_t)(trail >> (4 * lvl)) & 15u;
+      }
+      if (m) {
+        int c = __builtin_ctz(m);
+        m &= m - 1;
+        trail = (trail & ~(15ull << (4 * lvl))) | ((uint64_t)m << (4 * lvl));
+        if (lvl == last) {
+          // child c is a Morton cell; its body range rides in the .w words of lo[c] / hi[c]
+          uint32_t p0 = f2u(__shfl(v.w, gbase + c)), p1 = f2u(__shfl(v.w, gbase + c + 4));
+          for (uint32_t pb = p0; pb < p1; pb += 4) {
+            uint32_t rec = min(pb + (uint32_t)(sub >> 1), p1 - 1);
+            float4 w = gleaves[(size_t)rec * 2 + (sub & 1)];  // even lane: centre | body, odd lane: half extents
+            float rx = __shfl(w.x, lane | 1), ry = __shfl(w.y, lane | 1), rz = __shfl(w.z, lane | 1);
+            uint32_t j = f2u(w.w);
+            bool hit = false;
+            if (!(sub & 1) && pb + (uint32_t)(sub >> 1) < p1 && j < i && j < n_owned) {  // world.rs:266; ghost-ghost skipped
+              Box fb; fb.c = xyz(w); fb.r = mk3(rx, ry, rz);
+              hit = box_overlaps(q, fb);  // the reference's own acceptance test (bvh.rs:297)
+            }
+            unsigned long long hb = __ballot(hit);
+            uint32_t gm = (uint32_t)(hb >> gbase) & 255u;
+            if (hit) {
+              uint32_t slot = np + __popc(gm & ((1u << sub) - 1u));
+              if (slot < (uint32_t)kRowCap) row[slot] = j;
+            }
+            np += __popc(gm);
+          }
+          fresh = false;
+          continue;
+        }
+        k = 4 * k + 1 + (uint32_t)c;
+        ++lvl;
+        fresh = true;
+        continue;
+      }
+      if (lvl == 0) break;
+      k = (k - 1) >> 2;
+      --lvl;
+      fresh = false;
+    }
+  }
+  if (sub == 0) {
+    p_cnt[i] = np;
+    if (np > (uint32_t)kRowCap) *overflow = 1u;
+  }
+}
+
+// rows -> CSR (terrain and partner candidate lists with their owners); partners sorted ascending in LDS
+// (canonical insertion order).
+__global__ __launch_bounds__(kBlock) void k_rows_to_csr(uint32_t n, const uint32_t* rows_t, const uint32_t* rows_p, const uint32_t* t_off,
+                                                        const uint32_t* p_off, uint32_t* t_cand, uint32_t* t_owner, uint32_t* p_cand,
+                                                        uint32_t* p_owner) {
+  __shared__ uint32_t s_row[kRowCap][kBlock];
+  const int tid = threadIdx.x;
+  uint32_t i = blockIdx.x * kBlock + tid;
+  if (i >= n) return;
+  uint32_t tb = t_off[i], nt = t_off[i + 1] - tb, pb = p_off[i], np = p_off[i + 1] - pb;
+  if (nt > (uint32_t)kRowCapT || np > (uint32_t)kRowCap) return;  // overflowed body: the host takes the two-pass path
+  const uint32_t* rt = rows_t + (size_t)i * kRowCapT;
+  const uint32_t* rp = rows_p + (size_t)i * kRowCap;
+  for (uint32_t a = 0; a < nt; ++a) { t_cand[tb + a] = rt[a]; t_owner[tb + a] = i; }
+  for (uint32_t a = 0; a < np; ++a) {
+    uint32_t v = rp[a];
+    uint32_t b = a;
+    while (b > 0 && s_row[b - 1][tid] > v) { s_row[b][tid] = s_row[b - 1][tid]; --b; }
+    s_row[b][tid] = v;
+  }
+  for (uint32_t a = 0; a < np; ++a) { p_cand[pb + a] = s_row[a][tid]; p_owner[pb + a] = i; }
 }
 
 // ------------------------------------------------------------------------------------------

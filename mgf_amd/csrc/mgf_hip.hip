@@ -497,9 +497,15 @@ struct mgf_world {
   std::unique_ptr<mgf_mesh> terrain;
   // broadphase
   DBuf<uint32_t> mkeys, mvals, skeys, sidx;
-  DBuf<HNode> lnodes;
-  DBuf<float4> leaf_c, leaf_r;
-  DBuf<uint32_t> t_cnt, p_cnt, t_off, p_off, t_cand, t_owner, p_cand, p_owner;
+  DBuf<QNode> lnodes;
+  DBuf<LeafRec> leaves;
+  DBuf<float4> sub_lo, sub_hi, sub2_lo, sub2_hi;
+  DBuf<uint32_t> cell_lo, cell_hi;
+  DBuf<uint32_t> t_cnt, p_cnt, t_off, p_off, t_cand, t_owner, p_cand, p_owner, rows, rows_t;
+  int64_t opt_debug_bvh = 0;
+  DBuf<unsigned long long> dbg;
+  int64_t opt_two_pass = 0;  // 1 = always use the exact two-pass candidate path (tests the overflow fallback)
+  uint64_t n_row_overflows = 0;
   // narrowphase
   DBuf<uint32_t> t_nc, p_nc, t_pre, p_pre, cnt, tcnt, base, tbase, work_lists, work_counts;
   DBuf<NContact> t_out, p_out;
@@ -535,9 +541,9 @@ extern "C" mgf_status mgf_world_new(mgf_ctx* ctx, const mgf_params* params, mgf_
   w->ctx = ctx;
   w->params = params ? *params : mgf_default_params();
   memset(&w->stats, 0, sizeof(w->stats));
-  MGF_TRY(w->scalars.ensure(4, ctx->stream));
+  MGF_TRY(w->scalars.ensure(8, ctx->stream));
   MGF_TRY(w->sb.ensure(1, ctx->stream));
-  MGF_HIP_TRY(hipMemsetAsync(w->scalars.p, 0, 16, ctx->stream));
+  MGF_HIP_TRY(hipMemsetAsync(w->scalars.p, 0, 32, ctx->stream));
   for (auto& e : w->ev) MGF_HIP_TRY(hipEventCreate(&e));
   *out = w.release();
   return MGF_OK;
@@ -555,6 +561,8 @@ extern "C" int64_t mgf_world_len(const mgf_world* w) { return w ? (int64_t)w->n_
 extern "C" mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_t value) {
   if (!w || !key) return fail(MGF_ERR_INVALID, "NULL argument");
   if (!strcmp(key, "time_solver_kernels")) { w->opt_time_solver_kernels = value; return MGF_OK; }
+  if (!strcmp(key, "two_pass_candidates")) { w->opt_two_pass = value; return MGF_OK; }
+  if (!strcmp(key, "debug_bvh")) { w->opt_debug_bvh = value; return MGF_OK; }
   return fail(MGF_ERR_INVALID, "unknown option");
 }
 
@@ -861,39 +869,73 @@ extern "C" mgf_status mgf_world_collide(mgf_world* w, float dt, mgf_step_stats* 
   if (n == 0) { w->constraints_ready = true; if (stats) *stats = w->stats; MGF_HIP_TRY(hipStreamSynchronize(s)); return MGF_OK; }
   Bodies B = w->bodies();
   // 2. linear BVH over the fat AABBs
-  uint32_t npad = 256;
-  while (npad < n) npad <<= 1;
+  uint32_t levels = 4;  // 4^levels Morton cells, about one body per cell
+  while (((uint64_t)1 << (2 * levels)) < n && levels < (uint32_t)kMortonBits / 2) ++levels;
+  const uint32_t cells = 1u << (2 * levels), nblocks = cells / kBlock;
   MGF_TRY(w->mkeys.ensure(n, s)); MGF_TRY(w->mvals.ensure(n, s)); MGF_TRY(w->skeys.ensure(n, s)); MGF_TRY(w->sidx.ensure(n, s));
-  MGF_TRY(w->lnodes.ensure(npad, s)); MGF_TRY(w->leaf_c.ensure(n, s)); MGF_TRY(w->leaf_r.ensure(n, s));
+  MGF_TRY(w->lnodes.ensure(qlevel_offset(levels), s)); MGF_TRY(w->leaves.ensure(n, s));
+  MGF_TRY(w->cell_lo.ensure(cells, s)); MGF_TRY(w->cell_hi.ensure(cells, s));
+  MGF_TRY(w->sub_lo.ensure(nblocks, s)); MGF_TRY(w->sub_hi.ensure(nblocks, s));
+  MGF_TRY(w->sub2_lo.ensure(nblocks / 4 + 1, s)); MGF_TRY(w->sub2_hi.ensure(nblocks / 4 + 1, s));
+  MGF_HIP_TRY(hipMemsetAsync(w->cell_lo.p, 0, (size_t)cells * 4, s));
+  MGF_HIP_TRY(hipMemsetAsync(w->cell_hi.p, 0, (size_t)cells * 4, s));
   k_scene_bounds<<<std::min<unsigned>(nblk(n), 256u), kBlock, 0, s>>>(w->fb_c.p, n, w->sb.p);
   LAUNCH_CHECK();
   k_morton<<<nblk(n), kBlock, 0, s>>>(w->fb_c.p, n, w->sb.p, w->mkeys.p, w->mvals.p);
   LAUNCH_CHECK();
-  MGF_TRY(prim_sort_pairs_u32(ctx, w->mkeys.p, w->skeys.p, w->mvals.p, w->sidx.p, n, 30));
+  MGF_TRY(prim_sort_pairs_u32(ctx, w->mkeys.p, w->skeys.p, w->mvals.p, w->sidx.p, n, kMortonBits));
   Lbvh T;
-  T.nodes = w->lnodes.p; T.leaf_c = w->leaf_c.p; T.leaf_r = w->leaf_r.p; T.sidx = w->sidx.p; T.n = n; T.npad = npad; T.err = w->d_err();
-  k_lbvh_low<<<npad / kBlock, kBlock, 0, s>>>(T, w->fb_c.p, w->fb_r.p);
+  T.nodes = w->lnodes.p; T.leaves = w->leaves.p; T.sidx = w->sidx.p; T.skeys = w->skeys.p; T.cell_lo = w->cell_lo.p; T.cell_hi = w->cell_hi.p;
+  T.n = n; T.levels = levels; T.err = w->d_err();
+  T.dbg = nullptr;
+  if (w->opt_debug_bvh) {
+    MGF_TRY(w->dbg.ensure(4, s));
+    MGF_HIP_TRY(hipMemsetAsync(w->dbg.p, 0, 32, s));
+    T.dbg = w->dbg.p;
+  }
+  k_lbvh_leaves<<<nblk(n), kBlock, 0, s>>>(T, w->fb_c.p, w->fb_r.p);
   LAUNCH_CHECK();
-  if (npad > (uint32_t)kBlock) { k_lbvh_top<<<1, 1024, 0, s>>>(T); LAUNCH_CHECK(); }
+  k_lbvh_low<<<nblocks, kBlock, 0, s>>>(T, w->sub_lo.p, w->sub_hi.p);
+  LAUNCH_CHECK();
+  if (levels > 4) { k_lbvh_top<<<1, 1024, 0, s>>>(T, w->sub_lo.p, w->sub_hi.p, w->sub2_lo.p, w->sub2_hi.p); LAUNCH_CHECK(); }
   MGF_HIP_TRY(hipEventRecord(w->ev[1], s));
   // 3. candidates: count, scan, fill
   TerrainDev M;
   if (w->terrain && !w->terrain->m.tree.empty()) M = w->terrain->dev(w->d_err());
   else { memset(&M, 0, sizeof(M)); }
   MGF_TRY(w->t_cnt.ensure(n + 1, s)); MGF_TRY(w->p_cnt.ensure(n + 1, s)); MGF_TRY(w->t_off.ensure(n + 1, s)); MGF_TRY(w->p_off.ensure(n + 1, s));
-  k_candidates<false><<<nblk(n), kBlock, 0, s>>>(B, n, w->n_owned, T, M, 1e-3f, w->t_cnt.p, w->p_cnt.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-  LAUNCH_CHECK();
+  uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
+  bool two_pass = w->opt_two_pass != 0;
+  if (!two_pass) {
+    // fast path: one traversal, hits written to fixed-capacity rows
+    MGF_TRY(w->rows.ensure((size_t)n * kRowCap, s));
+    MGF_TRY(w->rows_t.ensure((size_t)n * kRowCapT, s));
+    MGF_HIP_TRY(hipMemsetAsync(w->t_cnt.p, 0, (size_t)(n + 1) * 4, s));  // ghosts have no terrain row
+    if (M.n_nodes && w->n_owned) {
+      k_terrain_rows<<<nblk(w->n_owned), kBlock, 0, s>>>(B, w->n_owned, M, w->rows_t.p, w->t_cnt.p, w->d_err() + 1);
+      LAUNCH_CHECK();
+    }
+    {
+      const uint32_t per_block = kCoopBlock / kCoopLanes;
+      const uint32_t grid = 8 * (((n + per_block - 1) / per_block + 7) / 8);
+      k_pair_rows<<<grid, kCoopBlock, 0, s>>>(B, n, w->n_owned, T, 1e-3f, w->rows.p, w->p_cnt.p, w->d_err() + 1);
+      LAUNCH_CHECK();
+    }
+  } else {
+    k_candidates<false><<<8 * xcd_blocks_per(n), kBlock, 0, s>>>(B, n, w->n_owned, T, M, 1e-3f, w->t_cnt.p, w->p_cnt.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    LAUNCH_CHECK();
+  }
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->t_cnt.p, w->t_off.p, (size_t)n + 1));
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->p_cnt.p, w->p_off.p, (size_t)n + 1));
-  uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
   MGF_HIP_TRY(hipMemcpyAsync(pin, w->t_off.p + n, 4, hipMemcpyDeviceToHost, s));
   MGF_HIP_TRY(hipMemcpyAsync(pin + 1, w->p_off.p + n, 4, hipMemcpyDeviceToHost, s));
   MGF_HIP_TRY(hipMemcpyAsync(pin + 2, w->sb.p, sizeof(SceneBounds), hipMemcpyDeviceToHost, s));
-  MGF_HIP_TRY(hipMemcpyAsync(pin + 16, w->d_err(), 4, hipMemcpyDeviceToHost, s));
+  MGF_HIP_TRY(hipMemcpyAsync(pin + 16, w->d_err(), 8, hipMemcpyDeviceToHost, s));
   MGF_HIP_TRY(hipStreamSynchronize(s));
   uint32_t Mt = pin[0], Mp = pin[1];
   w->stats.n_refits = reinterpret_cast<SceneBounds*>(pin + 2)->n_refits;
   if (pin[16]) return fail(MGF_ERR_CAPACITY, "BVH traversal stack overflow");
+  if (!two_pass && pin[17]) { two_pass = true; w->n_row_overflows++; }  // some body has more than kRowCap hits: exact path
   w->Mt = Mt; w->Mp = Mp;
   w->stats.n_terrain_candidates = Mt; w->stats.n_pair_candidates = Mp;
   MGF_TRY(w->t_cand.ensure(std::max(Mt, 1u), s)); MGF_TRY(w->t_owner.ensure(std::max(Mt, 1u), s));
@@ -902,8 +944,12 @@ extern "C" mgf_status mgf_world_collide(mgf_world* w, float dt, mgf_step_stats* 
   MGF_TRY(w->t_pre.ensure(std::max(Mt, 1u), s)); MGF_TRY(w->p_pre.ensure(std::max(Mp, 1u), s));
   MGF_TRY(w->t_out.ensure(std::max(2 * (size_t)Mt, (size_t)1), s)); MGF_TRY(w->p_out.ensure(std::max(Mp, 1u), s));
   if (Mt + Mp > 0) {
-    k_candidates<true><<<nblk(n), kBlock, 0, s>>>(B, n, w->n_owned, T, M, 1e-3f, nullptr, nullptr, w->t_off.p, w->p_off.p, w->t_cand.p, w->t_owner.p,
-                                                  w->p_cand.p, w->p_owner.p);
+    if (two_pass) {
+      k_candidates<true><<<8 * xcd_blocks_per(n), kBlock, 0, s>>>(B, n, w->n_owned, T, M, 1e-3f, nullptr, nullptr, w->t_off.p, w->p_off.p, w->t_cand.p, w->t_owner.p,
+                                                    w->p_cand.p, w->p_owner.p);
+    } else {
+      k_rows_to_csr<<<nblk(n), kBlock, 0, s>>>(n, w->rows_t.p, w->rows.p, w->t_off.p, w->p_off.p, w->t_cand.p, w->t_owner.p, w->p_cand.p, w->p_owner.p);
+    }
     LAUNCH_CHECK();
   }
   MGF_HIP_TRY(hipEventRecord(w->ev[2], s));
@@ -955,6 +1001,12 @@ extern "C" mgf_status mgf_world_collide(mgf_world* w, float dt, mgf_step_stats* 
   MGF_TRY(build_dag(w));
   MGF_HIP_TRY(hipEventRecord(w->ev[4], s));
   MGF_HIP_TRY(hipStreamSynchronize(s));
+  if (w->opt_debug_bvh) {
+    unsigned long long h[3];
+    MGF_TRY(d2h(ctx, h, w->dbg.p, 3));
+    fprintf(stderr, "[mgf debug_bvh] n=%u levels=%u node fetches/query=%.1f leaf records/query=%.1f max fetches=%llu\n", n, levels,
+            (double)h[0] / n, (double)h[1] / n, h[2]);
+  }
   float ms;
   MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[0], w->ev[1])); w->stats.ms_integrate = ms;
   MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[1], w->ev[2])); w->stats.ms_broadphase = ms;

@@ -242,3 +242,50 @@ def test_tiled_worlds_match_oracle_tiles(ctx):
         g, o = gt[r].e.state(), ot[r].e.state()
         for k in ("x", "q", "v", "omega", "delta"):
             assert values_equal(g[k], o[k]), f"tile {r} {k}: rel err {rel_err(g[k], o[k])}"
+
+
+def _crowded_scene():
+    """One big sphere (last index) touched by 80 small ones: more than the 32-entry candidate row."""
+    from mgf_amd import scenes
+    rng = np.random.default_rng(11)
+    d = rng.normal(size=(80, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:, 1] = np.abs(d[:, 1])
+    centres = np.concatenate([(d * 3.45 + [0, 4.0, 0]).astype(np.float32), np.array([[0, 4.0, 0]], np.float32)])
+    comps = np.zeros(len(centres), scenes.COMPONENT_DTYPE)
+    comps["p"] = centres
+    comps["r"] = 0.5
+    comps["r"][-1] = 3.0
+    sc = scenes._scene("crowded", comps, scenes.box_terrain(12.0, 12.0, (0, 0, 0)), v0=rng.uniform(-0.2, 0.2, (len(comps), 3)))
+    return sc
+
+
+@pytest.mark.parametrize("force_two_pass", [0, 1])
+def test_candidate_row_overflow_falls_back_exactly(ctx, force_two_pass):
+    import mgf_amd
+    scene = _crowded_scene()
+    dt, iters = float(scene["dt"]), scene["iters"]
+    ow = oracle_world(scene)
+    gw = mgf_amd.World.from_scene(ctx, scene)
+    gw.set_option("two_pass_candidates", force_two_pass)
+    for step in range(6):
+        so = ow.step(dt, iters)
+        sg = gw.step(dt, iters)
+        assert sg.n_constraints == so.n_constraints and sg.n_pair_candidates == so.n_pair_candidates
+        compare_constraints(gw.constraints(), ow.constraints(), check_impulse=True)
+    assert so.n_pair_candidates >= 60  # the big sphere alone has > 32 partners
+    _compare_state(gw, ow, "crowded scene")
+
+
+def test_two_pass_and_row_paths_agree(ctx):
+    import mgf_amd
+    from mgf_amd import scenes
+    scene = scenes.capsule_field(8, 3, 8, sphere_fraction=0.5)
+    a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
+    b.set_option("two_pass_candidates", 1)
+    for _ in range(40):
+        sa, sb = a.step(float(scene["dt"]), 10), b.step(float(scene["dt"]), 10)
+        assert (sa.n_constraints, sa.n_pair_candidates, sa.n_terrain_candidates) == (sb.n_constraints, sb.n_pair_candidates, sb.n_terrain_candidates)
+    s1, s2 = a.state(), b.state()
+    for k in s1:
+        assert bits_equal(s1[k], s2[k]), k
