@@ -118,7 +118,7 @@ def main():
         if kms > 0:
             achieved = ku * SOLVE_BYTES_PER_UNIT / (kms * 1e-3) / 1e9
             incl_gaps = units * SOLVE_BYTES_PER_UNIT / (phase["ms_solve"] * 1e-3) / 1e9 if phase["ms_solve"] > 0 else None
-            roofline = {"bound": "hbm", "kernel": "k_solve (ContactConstraint::solve, one DAG level per launch)",
+            roofline = {"bound": "hbm", "kernel": "k_solve_flow (ContactConstraint::solve for all iterations of a tick, one persistent dataflow launch)",
                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5),
                         "traffic": _pmc_traffic(),
@@ -162,7 +162,7 @@ def main():
 
 def _pmc_traffic():
     """HBM bytes per k_solve launch from committed rocprofv3 PMC passes (profiles/), or None."""
-    p = os.path.join(ROOT, "profiles", "pmc_k_solve.json")
+    p = os.path.join(ROOT, "profiles", "pmc_k_solve_flow.json")
     if os.path.exists(p):
         try:
             return json.load(open(p)).get("hbm_bytes_per_launch")

@@ -17,6 +17,7 @@
 //                      order-preserving dependency DAG of the constraint list
 //   k_solve            ContactConstraint::solve (solver.rs:203-252) for one frontier of the unrolled
 //                      (iterations x constraints) dependency graph
+//   k_solve_flow       the same graph walked by one persistent dataflow launch (write-through hand-offs)
 //
 // All f32 arithmetic follows the reference's operation order; the TU is built with
 // -ffp-contract=off.
@@ -741,7 +742,8 @@ struct CRec {
   uint32_t indeg;      // predecessors still pending for the next round (atomics)
   uint32_t indeg0;     // predecessors inside one iteration (in-degree of round 0)
   float friction;      // dead state in the reference (solver.rs:223-226), kept for read-back
-  uint32_t pad[4];
+  uint32_t ta, da;     // position of this constraint in body a's insertion-ordered list, and the list's length
+  uint32_t tb, db;     // same for body b (unused for Static)
 };
 static_assert(sizeof(CRec) == 128, "CRec is one 128-byte line");
 
@@ -785,7 +787,7 @@ __device__ __forceinline__ CRec make_constraint(uint32_t ia, uint32_t ib, const 
   c.bias = bias;
   c.nimp = 0.0f;
   c.round = 0; c.succ_a = kNone; c.succ_b = kNone; c.indeg = 0; c.indeg0 = 0;
-  c.pad[0] = c.pad[1] = c.pad[2] = c.pad[3] = 0;
+  c.ta = c.da = c.tb = c.db = 0;
   st3(c.n, normal); st3(c.t0, t0); st3(c.t1, t1); st3(c.ra, ra); st3(c.rb, rb);
   return c;
 }
@@ -796,13 +798,13 @@ __device__ __forceinline__ void store_crec(CRec* dst, const CRec& c) {
 #pragma unroll
   for (int k = 0; k < 8; ++k) d[k] = s[k];
 }
-// words 0..27: everything ContactConstraint::solve needs plus round and the successor words
+// the whole 128-byte line
 __device__ __forceinline__ CRec load_crec(const CRec* src) {
   CRec c;
   const float4* s = reinterpret_cast<const float4*>(src);
   float4* d = reinterpret_cast<float4*>(&c);
 #pragma unroll
-  for (int k = 0; k < 7; ++k) d[k] = s[k];
+  for (int k = 0; k < 8; ++k) d[k] = s[k];
   return c;
 }
 static_assert(offsetof(CRec, nimp) == 88 && offsetof(CRec, round) == 92 && offsetof(CRec, succ_b) == 96, "CRec layout");
@@ -886,7 +888,8 @@ __global__ __launch_bounds__(kBlock) void k_chain(uint32_t n, CRec* cons, const 
     uint32_t u = adj_list[a], w = adj_list[last ? lo : a + 1];
     uint32_t wid = w >> 1;
     uint32_t word = wid | (cons[wid].b != kNone ? kSuccTwo : 0u) | (last ? kSuccWrap : 0u);
-    if (u & 1u) cons[u >> 1].succ_b = word; else cons[u >> 1].succ_a = word;
+    if (u & 1u) { cons[u >> 1].succ_b = word; cons[u >> 1].tb = a - lo; cons[u >> 1].db = hi - lo; }
+    else { cons[u >> 1].succ_a = word; cons[u >> 1].ta = a - lo; cons[u >> 1].da = hi - lo; }
     if (!last) atomicAdd(&cons[wid].indeg0, 1u);  // predecessors inside one iteration
   }
 }
@@ -1008,6 +1011,288 @@ __global__ __launch_bounds__(kBlock) void k_solve(float4* srec, CRec* cons, Fron
     __syncthreads();
     for (uint32_t e = threadIdx.x; e < m; e += kBlock) F.order[hi + s_base + e] = s_q[e];
     __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Dataflow solver: the same dependency graph as k_solve, walked by ONE persistent launch.
+//
+// Every constraint c has a fixed owner lane (c mod L, L = lanes of the resident grid); a lane runs its
+// nodes in (iteration, constraint) order - a topological order of the unrolled graph, so the globally
+// smallest pending node is always runnable and the process cannot deadlock while every lane is resident.
+// Readiness is an arrival counter: a finished node adds 1 (2 if the successor has a single dynamic
+// body) to each successor's counter, and node (c, k) may run once arr[c] >= 2 (k + 1).  No queues, no
+// kernel boundaries: a hand-off costs one write-through store + one device-scope atomic on the
+// producer and one polled load on the consumer (MI355X guide, Guideline 16 recipe R1):
+//   * body velocities are exchanged with sc1 (write-through / L1-bypassing) 16-byte buffer accesses,
+//   * the producer drains its stores (s_waitcnt vmcnt(0)) before the relaxed agent-scope atomic,
+//   * the consumer polls with relaxed agent-scope loads, then issues its sc1 loads.
+// Constraint records are private to their owner lane (plain accesses).  Spins are bounded: a lane that
+// waits too long raises `abort` and every lane leaves (the host reports MGF_ERR_HIP).
+// ------------------------------------------------------------------------------------------
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+constexpr int kSc1 = 16;  // aux bits of the raw buffer builtins on gfx950: sc1
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(p, 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ BodyDyn load_dyn_sc1(__amdgpu_buffer_rsrc_t r, uint32_t i) {
+  v4f_t s0 = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(i * 64u), 0, kSc1);
+  v4f_t s1 = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(i * 64u + 16u), 0, kSc1);
+  v4f_t s2 = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(i * 64u + 32u), 0, kSc1);
+  v4f_t s3 = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(i * 64u + 48u), 0, kSc1);
+  BodyDyn d;
+  d.v = mk3(s0.x, s0.y, s0.z); d.w = mk3(s0.w, s1.x, s1.y); d.im = s1.z;
+  d.I = m3_cols(mk3(s1.w, s2.x, s2.y), mk3(s2.z, s2.w, s3.x), mk3(s3.y, s3.z, s3.w));
+  return d;
+}
+__device__ __forceinline__ void store_vel_sc1(__amdgpu_buffer_rsrc_t r, uint32_t i, const BodyDyn& d) {
+  v4f_t a = {d.v.x, d.v.y, d.v.z, d.w.x};
+  v2f_t b = {d.w.y, d.w.z};
+  __builtin_amdgcn_raw_buffer_store_b128(a, r, (int)(i * 64u), 0, kSc1);
+  __builtin_amdgcn_raw_buffer_store_b64(b, r, (int)(i * 64u + 16u), 0, kSc1);
+}
+
+// arr[c] = 2 - (weighted predecessors inside iteration 0): node (c, 0) is ready at arr >= 2.
+__global__ __launch_bounds__(kBlock) void k_flow_init(uint32_t C, const CRec* cons, uint32_t* arr, uint32_t* abort_flag) {
+  uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  if (c == 0) *abort_flag = 0;
+  if (c >= C) return;
+  uint32_t d0 = cons[c].indeg0;
+  arr[c] = 2u - d0 * (cons[c].b != kNone ? 1u : 2u);
+}
+
+__global__ __launch_bounds__(kBlock) void k_solve_flow(float4* srec, CRec* cons, uint32_t* arr, uint32_t C, uint32_t iters,
+                                                       uint32_t* abort_flag, uint32_t spin_limit, int sleep_mode) {
+  const uint32_t L = gridDim.x * kBlock;
+  const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
+  __amdgpu_buffer_rsrc_t rs = make_rsrc(srec);
+  uint32_t c = gl, round = 0;
+  bool done = (c >= C) || iters == 0;
+  bool have_rec = false;
+  CRec rec;
+  uint32_t spins = 0;
+  for (;;) {
+    if (!__any(!done)) break;
+    bool progressed = false;
+    if (!done) {
+      // the record is private to this lane: fetch it while the node is still waiting for its predecessors
+      if (!have_rec) { rec = load_crec(&cons[c]); have_rec = true; }
+      uint32_t a = __hip_atomic_load(&arr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a >= 2u * (round + 1u)) {
+        asm volatile("" ::: "memory");  // nothing below may be hoisted above the poll
+        BodyDyn A = load_dyn_sc1(rs, rec.a);
+        BodyDyn Bd = (rec.b == kNone) ? static_dyn() : load_dyn_sc1(rs, rec.b);
+        solve_one(rec, A, Bd);
+        store_vel_sc1(rs, rec.a, A);
+        if (rec.b != kNone) store_vel_sc1(rs, rec.b, Bd);
+        cons[c].nimp = rec.nimp;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // velocities are out before the successors hear of it
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+          if (side == 1 && rec.b == kNone) break;
+          uint32_t w = side == 0 ? rec.succ_a : rec.succ_b;
+          if (round + (w >> 31) >= iters) continue;
+          __hip_atomic_fetch_add(&arr[w & kSuccId], (w & kSuccTwo) ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        progressed = true;
+        have_rec = false;
+        c += L;
+        if (c >= C) { c = gl; ++round; if (round >= iters) done = true; }
+      }
+    }
+    if (__any(progressed)) { spins = 0; continue; }
+    if (sleep_mode == 1) __builtin_amdgcn_s_sleep(1);
+    else if (sleep_mode == 2) __builtin_amdgcn_s_sleep(4);
+    else if (sleep_mode == 3) __builtin_amdgcn_s_sleep(16);
+    if ((++spins & 255u) == 0u) {
+      bool give_up = spins > spin_limit;
+      if (give_up) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (give_up || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Dataflow solver, self-validating hand-off (solver mode 2).  Body x's constraints run in list order
+// every iteration, so the node at list position t of iteration k needs body x after exactly k*d + t
+// earlier solves (d = length of x's list).  Velocities live in a side array of two 16-byte halves per
+// body, (v, tag) and (w, tag), tag = number of solves applied so far.  A producer just stores the two
+// halves (write-through, no drain, no atomic); a consumer polls the halves of its two bodies until
+// all tags equal the versions it needs - the poll that succeeds already delivered the data.
+// A hand-off is one store propagation + one polled load.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_flow2_init(uint32_t n, const float4* srec, float4* svel, uint32_t* abort_flag) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i == 0) *abort_flag = 0;
+  if (i >= n) return;
+  float4 s0 = srec[4 * i], s1 = srec[4 * i + 1];
+  svel[2 * i] = make_float4(s0.x, s0.y, s0.z, u2f(0u));
+  svel[2 * i + 1] = make_float4(s0.w, s1.x, s1.y, u2f(0u));
+}
+__global__ __launch_bounds__(kBlock) void k_flow2_finish(uint32_t n, const float4* svel, float4* srec) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float4 h0 = svel[2 * i], h1 = svel[2 * i + 1];
+  srec[4 * i] = make_float4(h0.x, h0.y, h0.z, h1.x);
+  float2* p = reinterpret_cast<float2*>(&srec[4 * i + 1]);
+  *p = make_float2(h1.y, h1.z);
+}
+struct BodyInv { float im; M3 I; };
+__device__ __forceinline__ BodyInv load_inv(const float4* srec, uint32_t i) {
+  float4 s1 = srec[4 * i + 1], s2 = srec[4 * i + 2], s3 = srec[4 * i + 3];
+  BodyInv d; d.im = s1.z;
+  d.I = m3_cols(mk3(s1.w, s2.x, s2.y), mk3(s2.z, s2.w, s3.x), mk3(s3.y, s3.z, s3.w));
+  return d;
+}
+
+__global__ __launch_bounds__(kBlock) void k_solve_flow2(const float4* srec, float4* svel, CRec* cons, uint32_t C, uint32_t iters,
+                                                        uint32_t* abort_flag, uint32_t spin_limit, int sleep_mode) {
+  const uint32_t L = gridDim.x * kBlock;
+  const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
+  __amdgpu_buffer_rsrc_t rv = make_rsrc(svel);
+  uint32_t c = gl, round = 0;
+  bool done = (c >= C) || iters == 0;
+  bool have_rec = false;
+  CRec rec;
+  BodyInv ia, ib;
+  uint32_t va = 0, vb = 0;
+  uint32_t spins = 0;
+  for (;;) {
+    if (!__any(!done)) break;
+    bool progressed = false;
+    if (!done) {
+      if (!have_rec) {  // private record + immutable inverse mass / inertia: fetched while the node waits
+        rec = load_crec(&cons[c]);
+        ia = load_inv(srec, rec.a);
+        if (rec.b != kNone) ib = load_inv(srec, rec.b);
+        else { ib.im = 0.0f; ib.I = m3_cols(mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)); }
+        va = round * rec.da + rec.ta;
+        vb = round * rec.db + rec.tb;
+        have_rec = true;
+      }
+      const bool dyn_b = rec.b != kNone;
+      v4f_t a0 = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(rec.a * 32u), 0, kSc1);
+      v4f_t a1 = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(rec.a * 32u + 16u), 0, kSc1);
+      v4f_t b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+      if (dyn_b) {
+        b0 = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(rec.b * 32u), 0, kSc1);
+        b1 = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(rec.b * 32u + 16u), 0, kSc1);
+      }
+      bool ready = f2u(a0.w) == va && f2u(a1.w) == va && (!dyn_b || (f2u(b0.w) == vb && f2u(b1.w) == vb));
+      if (ready) {
+        BodyDyn A, Bd;
+        A.v = mk3(a0.x, a0.y, a0.z); A.w = mk3(a1.x, a1.y, a1.z); A.im = ia.im; A.I = ia.I;
+        Bd.v = mk3(b0.x, b0.y, b0.z); Bd.w = mk3(b1.x, b1.y, b1.z); Bd.im = ib.im; Bd.I = ib.I;
+        solve_one(rec, A, Bd);
+        v4f_t o0 = {A.v.x, A.v.y, A.v.z, u2f(va + 1u)}, o1 = {A.w.x, A.w.y, A.w.z, u2f(va + 1u)};
+        __builtin_amdgcn_raw_buffer_store_b128(o0, rv, (int)(rec.a * 32u), 0, kSc1);
+        __builtin_amdgcn_raw_buffer_store_b128(o1, rv, (int)(rec.a * 32u + 16u), 0, kSc1);
+        if (dyn_b) {
+          v4f_t p0 = {Bd.v.x, Bd.v.y, Bd.v.z, u2f(vb + 1u)}, p1 = {Bd.w.x, Bd.w.y, Bd.w.z, u2f(vb + 1u)};
+          __builtin_amdgcn_raw_buffer_store_b128(p0, rv, (int)(rec.b * 32u), 0, kSc1);
+          __builtin_amdgcn_raw_buffer_store_b128(p1, rv, (int)(rec.b * 32u + 16u), 0, kSc1);
+        }
+        cons[c].nimp = rec.nimp;
+        progressed = true;
+        have_rec = false;
+        c += L;
+        if (c >= C) { c = gl; ++round; if (round >= iters) done = true; }
+      }
+    }
+    if (__any(progressed)) { spins = 0; continue; }
+    if (sleep_mode == 1) __builtin_amdgcn_s_sleep(1);
+    else if (sleep_mode == 2) __builtin_amdgcn_s_sleep(4);
+    else if (sleep_mode == 3) __builtin_amdgcn_s_sleep(16);
+    if ((++spins & 255u) == 0u) {
+      bool give_up = spins > spin_limit;
+      if (give_up) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (give_up || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Dataflow solver, solver mode 3 = mode 1's light readiness poll (4-byte arrival counter) + mode 2's
+// version-tagged velocity halves.  The producer issues its tagged write-through stores and the arrival
+// atomics back to back - no store drain: if the arrival overtakes the data, the consumer sees a wrong
+// tag and simply re-loads.  A hand-off is: store/atomic propagation, one 4-byte poll, one 64-byte load.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_solve_flow3(const float4* srec, float4* svel, CRec* cons, uint32_t* arr, uint32_t C,
+                                                        uint32_t iters, uint32_t* abort_flag, uint32_t spin_limit, int sleep_mode) {
+  const uint32_t L = gridDim.x * kBlock;
+  const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
+  __amdgpu_buffer_rsrc_t rv = make_rsrc(svel);
+  uint32_t c = gl, round = 0;
+  bool done = (c >= C) || iters == 0;
+  bool have_rec = false;
+  CRec rec;
+  BodyInv ia, ib;
+  uint32_t va = 0, vb = 0;
+  uint32_t spins = 0;
+  for (;;) {
+    if (!__any(!done)) break;
+    bool progressed = false;
+    if (!done) {
+      if (!have_rec) {  // private record + immutable inverse mass / inertia: fetched while the node waits
+        rec = load_crec(&cons[c]);
+        ia = load_inv(srec, rec.a);
+        if (rec.b != kNone) ib = load_inv(srec, rec.b);
+        else { ib.im = 0.0f; ib.I = m3_cols(mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)); }
+        va = round * rec.da + rec.ta;
+        vb = round * rec.db + rec.tb;
+        have_rec = true;
+      }
+      uint32_t arrived = __hip_atomic_load(&arr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (arrived >= 2u * (round + 1u)) {
+        asm volatile("" ::: "memory");
+        const bool dyn_b = rec.b != kNone;
+        v4f_t a0 = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(rec.a * 32u), 0, kSc1);
+        v4f_t a1 = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(rec.a * 32u + 16u), 0, kSc1);
+        v4f_t b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+        if (dyn_b) {
+          b0 = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(rec.b * 32u), 0, kSc1);
+          b1 = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(rec.b * 32u + 16u), 0, kSc1);
+        }
+        bool fresh = f2u(a0.w) == va && f2u(a1.w) == va && (!dyn_b || (f2u(b0.w) == vb && f2u(b1.w) == vb));
+        if (fresh) {  // otherwise the arrival overtook the data: poll again
+          BodyDyn A, Bd;
+          A.v = mk3(a0.x, a0.y, a0.z); A.w = mk3(a1.x, a1.y, a1.z); A.im = ia.im; A.I = ia.I;
+          Bd.v = mk3(b0.x, b0.y, b0.z); Bd.w = mk3(b1.x, b1.y, b1.z); Bd.im = ib.im; Bd.I = ib.I;
+          solve_one(rec, A, Bd);
+          v4f_t o0 = {A.v.x, A.v.y, A.v.z, u2f(va + 1u)}, o1 = {A.w.x, A.w.y, A.w.z, u2f(va + 1u)};
+          __builtin_amdgcn_raw_buffer_store_b128(o0, rv, (int)(rec.a * 32u), 0, kSc1);
+          __builtin_amdgcn_raw_buffer_store_b128(o1, rv, (int)(rec.a * 32u + 16u), 0, kSc1);
+          if (dyn_b) {
+            v4f_t p0 = {Bd.v.x, Bd.v.y, Bd.v.z, u2f(vb + 1u)}, p1 = {Bd.w.x, Bd.w.y, Bd.w.z, u2f(vb + 1u)};
+            __builtin_amdgcn_raw_buffer_store_b128(p0, rv, (int)(rec.b * 32u), 0, kSc1);
+            __builtin_amdgcn_raw_buffer_store_b128(p1, rv, (int)(rec.b * 32u + 16u), 0, kSc1);
+          }
+#pragma unroll
+          for (int side = 0; side < 2; ++side) {
+            if (side == 1 && !dyn_b) break;
+            uint32_t w = side == 0 ? rec.succ_a : rec.succ_b;
+            if (round + (w >> 31) >= iters) continue;
+            __hip_atomic_fetch_add(&arr[w & kSuccId], (w & kSuccTwo) ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          cons[c].nimp = rec.nimp;
+          progressed = true;
+          have_rec = false;
+          c += L;
+          if (c >= C) { c = gl; ++round; if (round >= iters) done = true; }
+        }
+      }
+    }
+    if (__any(progressed)) { spins = 0; continue; }
+    if (sleep_mode == 1) __builtin_amdgcn_s_sleep(1);
+    else if (sleep_mode == 2) __builtin_amdgcn_s_sleep(4);
+    else if (sleep_mode == 3) __builtin_amdgcn_s_sleep(16);
+    if ((++spins & 255u) == 0u) {
+      bool give_up = spins > spin_limit;
+      if (give_up) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (give_up || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
   }
 }
 

@@ -502,6 +502,15 @@ struct mgf_world {
   DBuf<float4> sub_lo, sub_hi, sub2_lo, sub2_hi;
   DBuf<uint32_t> cell_lo, cell_hi;
   DBuf<uint32_t> t_cnt, p_cnt, t_off, p_off, t_cand, t_owner, p_cand, p_owner, rows, rows_t;
+  // 1 (default) = one persistent dataflow launch per Solver::solve (k_solve_flow);
+  // 0 = one launch per frontier of the dependency graph (k_solve); 2, 3 = dataflow variants with
+  // version-tagged velocity words (k_solve_flow2 / k_solve_flow3), kept for comparison
+  int64_t opt_solver_mode = 1;
+  DBuf<uint32_t> flow_arr;
+  DBuf<float4> svel;
+  int flow2_grid = 0;
+  int flow_grid = 0;
+  int64_t opt_flow_blocks_per_cu = 0, opt_flow_sleep = 2;
   int64_t opt_debug_bvh = 0;
   DBuf<unsigned long long> dbg;
   int64_t opt_two_pass = 0;  // 1 = always use the exact two-pass candidate path (tests the overflow fallback)
@@ -563,6 +572,9 @@ extern "C" mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_
   if (!strcmp(key, "time_solver_kernels")) { w->opt_time_solver_kernels = value; return MGF_OK; }
   if (!strcmp(key, "two_pass_candidates")) { w->opt_two_pass = value; return MGF_OK; }
   if (!strcmp(key, "debug_bvh")) { w->opt_debug_bvh = value; return MGF_OK; }
+  if (!strcmp(key, "solver_mode")) { w->opt_solver_mode = value; return MGF_OK; }
+  if (!strcmp(key, "flow_blocks_per_cu")) { w->opt_flow_blocks_per_cu = value; w->flow_grid = 0; w->flow2_grid = 0; return MGF_OK; }
+  if (!strcmp(key, "flow_sleep")) { w->opt_flow_sleep = value; return MGF_OK; }
   return fail(MGF_ERR_INVALID, "unknown option");
 }
 
@@ -1119,7 +1131,83 @@ extern "C" mgf_status mgf_world_solve(mgf_world* w, int32_t iters, mgf_step_stat
     MGF_HIP_TRY(hipEventRecord(w->kev[kev_used++], s));
     return MGF_OK;
   };
-  if (C > 0 && iters > 0) {
+  if (C > 0 && iters > 0 && w->opt_solver_mode == 3) {
+    if (w->flow2_grid == 0) {
+      int per_cu = 0;
+      MGF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_solve_flow3, kBlock, 0));
+      int want = w->opt_flow_blocks_per_cu > 0 ? (int)w->opt_flow_blocks_per_cu : 4;
+      per_cu = std::max(1, std::min(per_cu - 1, want));
+      w->flow2_grid = per_cu * ctx->num_cus;
+    }
+    unsigned g = std::min<unsigned>((unsigned)w->flow2_grid, nblk(C));
+    MGF_TRY(w->svel.ensure(2 * (size_t)w->n, s));
+    MGF_TRY(w->flow_arr.ensure(C, s));
+    k_flow2_init<<<nblk(w->n), kBlock, 0, s>>>(w->n, w->srec.p, w->svel.p, w->d_err() + 2);
+    LAUNCH_CHECK();
+    k_flow_init<<<nblk(C), kBlock, 0, s>>>(C, w->cons_nat.p, w->flow_arr.p, w->d_err() + 2);
+    LAUNCH_CHECK();
+    MGF_TRY(tick());
+    k_solve_flow3<<<g, kBlock, 0, s>>>(w->srec.p, w->svel.p, w->cons_nat.p, w->flow_arr.p, C, (uint32_t)iters, w->d_err() + 2, 4u << 20,
+                                      (int)w->opt_flow_sleep);
+    LAUNCH_CHECK();
+    MGF_TRY(tick());
+    k_flow2_finish<<<nblk(w->n), kBlock, 0, s>>>(w->n, w->svel.p, w->srec.p);
+    LAUNCH_CHECK();
+    w->stats.solver_kernel_launches = 1;
+    uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
+    MGF_HIP_TRY(hipMemcpyAsync(pin, w->d_err() + 2, 4, hipMemcpyDeviceToHost, s));
+    MGF_HIP_TRY(hipStreamSynchronize(s));
+    if (pin[0]) return fail(MGF_ERR_HIP, "dataflow solver gave up waiting (grid not fully resident?)");
+    w->depth = 1;
+  } else if (C > 0 && iters > 0 && w->opt_solver_mode == 2) {
+    if (w->flow2_grid == 0) {
+      int per_cu = 0;
+      MGF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_solve_flow2, kBlock, 0));
+      int want = w->opt_flow_blocks_per_cu > 0 ? (int)w->opt_flow_blocks_per_cu : 4;
+      per_cu = std::max(1, std::min(per_cu - 1, want));
+      w->flow2_grid = per_cu * ctx->num_cus;
+    }
+    unsigned g = std::min<unsigned>((unsigned)w->flow2_grid, nblk(C));
+    MGF_TRY(w->svel.ensure(2 * (size_t)w->n, s));
+    k_flow2_init<<<nblk(w->n), kBlock, 0, s>>>(w->n, w->srec.p, w->svel.p, w->d_err() + 2);
+    LAUNCH_CHECK();
+    MGF_TRY(tick());
+    k_solve_flow2<<<g, kBlock, 0, s>>>(w->srec.p, w->svel.p, w->cons_nat.p, C, (uint32_t)iters, w->d_err() + 2, 4u << 20, (int)w->opt_flow_sleep);
+    LAUNCH_CHECK();
+    MGF_TRY(tick());
+    k_flow2_finish<<<nblk(w->n), kBlock, 0, s>>>(w->n, w->svel.p, w->srec.p);
+    LAUNCH_CHECK();
+    w->stats.solver_kernel_launches = 1;
+    uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
+    MGF_HIP_TRY(hipMemcpyAsync(pin, w->d_err() + 2, 4, hipMemcpyDeviceToHost, s));
+    MGF_HIP_TRY(hipStreamSynchronize(s));
+    if (pin[0]) return fail(MGF_ERR_HIP, "dataflow solver gave up waiting (grid not fully resident?)");
+    w->depth = 1;
+  } else if (C > 0 && iters > 0 && w->opt_solver_mode == 1) {
+    // persistent dataflow launch: every lane must be resident, so the grid is sized from the occupancy
+    // query with one block per CU of margin (the API over-reports by one for some kernels on ROCm 7.2)
+    if (w->flow_grid == 0) {
+      int per_cu = 0;
+      MGF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_solve_flow, kBlock, 0));
+      int want = w->opt_flow_blocks_per_cu > 0 ? (int)w->opt_flow_blocks_per_cu : 4;
+      per_cu = std::max(1, std::min(per_cu - 1, want));
+      w->flow_grid = per_cu * ctx->num_cus;
+    }
+    unsigned g = std::min<unsigned>((unsigned)w->flow_grid, nblk(C));
+    MGF_TRY(w->flow_arr.ensure(C, s));
+    k_flow_init<<<nblk(C), kBlock, 0, s>>>(C, w->cons_nat.p, w->flow_arr.p, w->d_err() + 2);
+    LAUNCH_CHECK();
+    MGF_TRY(tick());
+    k_solve_flow<<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C, (uint32_t)iters, w->d_err() + 2, 4u << 20, (int)w->opt_flow_sleep);
+    LAUNCH_CHECK();
+    MGF_TRY(tick());
+    w->stats.solver_kernel_launches = 1;
+    uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
+    MGF_HIP_TRY(hipMemcpyAsync(pin, w->d_err() + 2, 4, hipMemcpyDeviceToHost, s));
+    MGF_HIP_TRY(hipStreamSynchronize(s));
+    if (pin[0]) return fail(MGF_ERR_HIP, "dataflow solver gave up waiting (grid not fully resident?)");
+    w->depth = 1;
+  } else if (C > 0 && iters > 0) {
     // frontier lists hold every (constraint, round) once: iters * C entries
     MGF_TRY(w->order.ensure((size_t)iters * C, s));
     if (w->lvl_cap == 0) { w->lvl_cap = 1u << 16; MGF_TRY(w->lvl_off.ensure(w->lvl_cap + 4, s)); }
@@ -1226,6 +1314,7 @@ extern "C" mgf_status mgf_world_set_constraints(mgf_world* w, const mgf_constrai
     r.bias = c.bias; r.nmass = c.normal_mass; r.tmass0 = c.tangent_mass0; r.tmass1 = c.tangent_mass1; r.nimp = c.normal_impulse;
     r.friction = c.friction;
     r.succ_a = kNone; r.succ_b = kNone;
+    r.ta = r.da = r.tb = r.db = 0;
     h[(size_t)i] = r;
   }
   w->C = (uint32_t)n; w->Ct = 0;

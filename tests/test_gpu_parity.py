@@ -113,6 +113,7 @@ def test_world_step_parity_teacher_forced(ctx, scene_name):
     dt, iters = float(scene["dt"]), scene["iters"]
     ow = oracle_world(scene)
     gw = mgf_amd.World.from_scene(ctx, scene)
+    gw.set_option("solver_mode", 0)  # launch-per-frontier path: n_levels is then the depth of the unrolled graph
     _compare_state(gw, ow, "initial")
     # let the oracle run the scene forward; at chosen steps teacher-force the GPU from the oracle snapshot
     checkpoints = {0, 1, 2, 5, 20, 60, 140, 141, 142, 170, 200} if scene_name == "balls8" else {0, 1, 2, 3, 10, 25, 40}
@@ -289,3 +290,25 @@ def test_two_pass_and_row_paths_agree(ctx):
     s1, s2 = a.state(), b.state()
     for k in s1:
         assert bits_equal(s1[k], s2[k]), k
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("scene_name", ["pile12", "mixed", "balls8"])
+def test_dataflow_solver_matches_oracle(ctx, scene_name, mode):
+    """solver_mode=1 (one persistent dataflow launch) must give the sequential Gauss-Seidel result too."""
+    import mgf_amd
+    from mgf_amd import scenes
+    scene = {"pile12": lambda: scenes.sphere_pile(12, 12, 12), "mixed": lambda: scenes.capsule_field(8, 3, 8, sphere_fraction=0.5),
+             "balls8": lambda: scenes.balls_demo(8)}[scene_name]()
+    dt, iters = float(scene["dt"]), scene["iters"]
+    ow = oracle_world(scene)
+    gw = mgf_amd.World.from_scene(ctx, scene)
+    gw.set_option("solver_mode", mode)
+    n_ticks = 160 if scene_name == "balls8" else 60
+    for step in range(n_ticks):
+        so = ow.step(dt, iters)
+        sg = gw.step(dt, iters)
+        assert sg.n_constraints == so.n_constraints, f"step {step}"
+        if step % 20 == 0 or step == n_ticks - 1:
+            compare_constraints(gw.constraints(), ow.constraints(), check_impulse=True)
+            _compare_state(gw, ow, f"dataflow {scene_name} step {step}")
