@@ -507,11 +507,13 @@ struct mgf_world {
   // version-tagged velocity words (k_solve_flow2 / k_solve_flow3), kept for comparison
   int64_t opt_solver_mode = 1;
   DBuf<uint32_t> flow_arr;
+  DBuf<uint64_t> flow_trace;
   DBuf<float4> svel;
   int flow2_grid = 0;
   int flow_grid = 0;
   int64_t opt_flow_blocks_per_cu = 0, opt_flow_sleep = 2;
-  int64_t opt_debug_bvh = 0;
+  int flowk_grid = 0;
+  int64_t opt_debug_bvh = 0, opt_flow_trace = 0;
   DBuf<unsigned long long> dbg;
   int64_t opt_two_pass = 0;  // 1 = always use the exact two-pass candidate path (tests the overflow fallback)
   uint64_t n_row_overflows = 0;
@@ -571,9 +573,10 @@ extern "C" mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_
   if (!w || !key) return fail(MGF_ERR_INVALID, "NULL argument");
   if (!strcmp(key, "time_solver_kernels")) { w->opt_time_solver_kernels = value; return MGF_OK; }
   if (!strcmp(key, "two_pass_candidates")) { w->opt_two_pass = value; return MGF_OK; }
+  if (!strcmp(key, "flow_trace")) { w->opt_flow_trace = value; return MGF_OK; }
   if (!strcmp(key, "debug_bvh")) { w->opt_debug_bvh = value; return MGF_OK; }
   if (!strcmp(key, "solver_mode")) { w->opt_solver_mode = value; return MGF_OK; }
-  if (!strcmp(key, "flow_blocks_per_cu")) { w->opt_flow_blocks_per_cu = value; w->flow_grid = 0; w->flow2_grid = 0; return MGF_OK; }
+  if (!strcmp(key, "flow_blocks_per_cu")) { w->opt_flow_blocks_per_cu = value; w->flow_grid = 0; w->flow2_grid = 0; w->flowk_grid = 0; return MGF_OK; }
   if (!strcmp(key, "flow_sleep")) { w->opt_flow_sleep = value; return MGF_OK; }
   return fail(MGF_ERR_INVALID, "unknown option");
 }
@@ -1110,6 +1113,17 @@ extern "C" mgf_status mgf_world_import_ghost_velocities(mgf_world* w, const floa
 }
 extern "C" int64_t mgf_world_ghost_len(const mgf_world* w) { return w ? (int64_t)(w->n - w->n_owned) : 0; }
 
+// development aid: per-node (ready seen, released) timestamps of a dataflow launch -> /tmp/mgf_flow_trace.bin
+static mgf_status dump_flow_trace(mgf_world* w, uint32_t C, int32_t iters) {
+  std::vector<uint64_t> h(2 * (size_t)iters * C);
+  MGF_TRY(d2h(w->ctx, h.data(), w->flow_trace.p, h.size()));
+  if (FILE* f = fopen("/tmp/mgf_flow_trace.bin", "wb")) {
+    uint64_t hdr[2] = {C, (uint64_t)iters};
+    fwrite(hdr, 8, 2, f); fwrite(h.data(), 8, h.size(), f); fclose(f);
+  }
+  return MGF_OK;
+}
+
 // Solver::solve solver.rs:72-78, level-scheduled.
 extern "C" mgf_status mgf_world_solve(mgf_world* w, int32_t iters, mgf_step_stats* stats) {
   if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
@@ -1183,12 +1197,42 @@ extern "C" mgf_status mgf_world_solve(mgf_world* w, int32_t iters, mgf_step_stat
     MGF_HIP_TRY(hipStreamSynchronize(s));
     if (pin[0]) return fail(MGF_ERR_HIP, "dataflow solver gave up waiting (grid not fully resident?)");
     w->depth = 1;
+  } else if (C > 0 && iters > 0 && w->opt_solver_mode == 4) {
+    if (w->flowk_grid == 0) {
+      int per_cu = 0;
+      MGF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_solve_flowk<4, false>, kBlock, 0));
+      int want = w->opt_flow_blocks_per_cu > 0 ? (int)w->opt_flow_blocks_per_cu : 4;
+      per_cu = std::max(1, std::min(per_cu - 1, want));
+      w->flowk_grid = per_cu * ctx->num_cus;
+    }
+    unsigned g = std::min<unsigned>((unsigned)w->flowk_grid, nblk(C));
+    MGF_TRY(w->flow_arr.ensure(C, s));
+    k_flow_init<<<nblk(C), kBlock, 0, s>>>(C, w->cons_nat.p, w->flow_arr.p, w->d_err() + 2);
+    LAUNCH_CHECK();
+    MGF_TRY(tick());
+    if (w->opt_flow_trace) {
+      MGF_TRY(w->flow_trace.ensure(2 * (size_t)iters * C, s));
+      k_solve_flowk<4, true><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C, (uint32_t)iters, w->d_err() + 2, 4u << 20,
+                                                 (int)w->opt_flow_sleep, w->flow_trace.p);
+      MGF_TRY(dump_flow_trace(w, C, iters));
+    } else {
+      k_solve_flowk<4, false><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C, (uint32_t)iters, w->d_err() + 2, 4u << 20,
+                                                  (int)w->opt_flow_sleep, nullptr);
+    }
+    LAUNCH_CHECK();
+    MGF_TRY(tick());
+    w->stats.solver_kernel_launches = 1;
+    uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
+    MGF_HIP_TRY(hipMemcpyAsync(pin, w->d_err() + 2, 4, hipMemcpyDeviceToHost, s));
+    MGF_HIP_TRY(hipStreamSynchronize(s));
+    if (pin[0]) return fail(MGF_ERR_HIP, "dataflow solver gave up waiting (grid not fully resident?)");
+    w->depth = 1;
   } else if (C > 0 && iters > 0 && w->opt_solver_mode == 1) {
     // persistent dataflow launch: every lane must be resident, so the grid is sized from the occupancy
     // query with one block per CU of margin (the API over-reports by one for some kernels on ROCm 7.2)
     if (w->flow_grid == 0) {
       int per_cu = 0;
-      MGF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_solve_flow, kBlock, 0));
+      MGF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_solve_flow<false>, kBlock, 0));
       int want = w->opt_flow_blocks_per_cu > 0 ? (int)w->opt_flow_blocks_per_cu : 4;
       per_cu = std::max(1, std::min(per_cu - 1, want));
       w->flow_grid = per_cu * ctx->num_cus;
@@ -1198,7 +1242,15 @@ extern "C" mgf_status mgf_world_solve(mgf_world* w, int32_t iters, mgf_step_stat
     k_flow_init<<<nblk(C), kBlock, 0, s>>>(C, w->cons_nat.p, w->flow_arr.p, w->d_err() + 2);
     LAUNCH_CHECK();
     MGF_TRY(tick());
-    k_solve_flow<<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C, (uint32_t)iters, w->d_err() + 2, 4u << 20, (int)w->opt_flow_sleep);
+    if (w->opt_flow_trace) {  // development aid: per-node (ready seen, released) timestamps -> /tmp/mgf_flow_trace.bin
+      MGF_TRY(w->flow_trace.ensure(2 * (size_t)iters * C, s));
+      k_solve_flow<true><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C, (uint32_t)iters, w->d_err() + 2, 4u << 20,
+                                             (int)w->opt_flow_sleep, w->flow_trace.p);
+      MGF_TRY(dump_flow_trace(w, C, iters));
+    } else {
+      k_solve_flow<false><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C, (uint32_t)iters, w->d_err() + 2, 4u << 20,
+                                              (int)w->opt_flow_sleep, nullptr);
+    }
     LAUNCH_CHECK();
     MGF_TRY(tick());
     w->stats.solver_kernel_launches = 1;

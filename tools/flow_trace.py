@@ -1,0 +1,63 @@
+"""Critical-path breakdown of the dataflow solver from per-node timestamps (development aid)."""
+import sys
+sys.path.insert(0, '/root/repo')
+import numpy as np, mgf_amd
+from mgf_amd import scenes
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+mode = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+ctx = mgf_amd.Context(0)
+sc = scenes.sphere_pile(n, n, n)
+w = mgf_amd.World.from_scene(ctx, sc)
+w.set_option('solver_mode', mode)
+for s in range(ticks): w.step(float(sc['dt']), 10)
+w.set_option('flow_trace', 1)
+w.step(float(sc['dt']), 10)
+w.set_option('flow_trace', 0)
+cons = w.constraints()
+raw = np.fromfile('/tmp/mgf_flow_trace.bin', dtype=np.uint64)
+C, iters = int(raw[0]), int(raw[1])
+tr = raw[2:].reshape(iters, C, 2).astype(np.int64)
+t0 = tr[:, :, 0].min()
+seen = (tr[:, :, 0] - t0) * 0.01   # us (100 MHz)
+done = (tr[:, :, 1] - t0) * 0.01
+print(f"C={C} iters={iters} span={done.max():.1f} us; node service (seen->released) mean {np.mean(done-seen):.2f} us p50 {np.median(done-seen):.2f} p90 {np.percentile(done-seen,90):.2f}")
+A = cons['a'].astype(np.int64); B = cons['b'].astype(np.int64)
+# predecessors in the unrolled graph
+nb = int(max(A.max(), B.max())) + 1
+lists = [[] for _ in range(nb)]
+for c in range(C):
+    lists[A[c]].append(c)
+    if B[c] >= 0: lists[B[c]].append(c)
+preds = [[] for _ in range(C)]   # (pred constraint, wrap)
+for l in lists:
+    for k, c in enumerate(l):
+        if k > 0: preds[c].append((l[k-1], 0))
+        else: preds[c].append((l[-1], 1))
+# hand-off latency: seen(node) - max(done(pred))
+lat = []
+crit_pred = {}
+for r in range(iters):
+    for c in range(C):
+        best = -1.0; bp = None
+        for (p, wrap) in preds[c]:
+            rr = r - wrap
+            if rr < 0: continue
+            if done[rr, p] > best: best = done[rr, p]; bp = (rr, p)
+        if bp is not None:
+            lat.append(seen[r, c] - best); crit_pred[(r, c)] = bp
+lat = np.array(lat)
+print(f"hand-off (last pred released -> seen) mean {lat.mean():.2f} us p10 {np.percentile(lat,10):.2f} p50 {np.median(lat):.2f} p90 {np.percentile(lat,90):.2f} p99 {np.percentile(lat,99):.2f}")
+# walk the critical path back from the last finished node
+r, c = np.unravel_index(np.argmax(done), done.shape)
+hops = 0; svc = 0.0; ho = 0.0
+path = []
+while (r, c) in crit_pred:
+    pr, pc = crit_pred[(r, c)]
+    svc += done[r, c] - seen[r, c]; ho += seen[r, c] - done[pr, pc]; hops += 1
+    path.append((seen[r, c] - done[pr, pc], done[r, c] - seen[r, c]))
+    r, c = pr, pc
+print(f"critical path: {hops} hops, service {svc:.1f} us ({svc/hops:.2f}/hop), hand-off {ho:.1f} us ({ho/hops:.2f}/hop), first node seen at {seen[r,c]:.1f} us")
+h = np.array(path)
+print("hand-off on the critical path: p10 %.2f p50 %.2f p90 %.2f max %.2f" % tuple(np.percentile(h[:,0],[10,50,90,100])))
+print("service  on the critical path: p10 %.2f p50 %.2f p90 %.2f max %.2f" % tuple(np.percentile(h[:,1],[10,50,90,100])))
