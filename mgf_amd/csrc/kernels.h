@@ -425,6 +425,39 @@ __device__ __forceinline__ void lbvh_traverse(const Lbvh& T, const QNode* top, u
   }
 }
 
+// Sizes of the tick's variable-length lists, kept on the device so that the host can enqueue the whole
+// tick without reading them back: buffers and grids are sized from host-side capacities (last tick's
+// sizes plus slack), kernels take the real sizes from here.  If a capacity turns out too small the
+// effective sizes become 0 (every later kernel of the tick is a no-op), `fail` says why, and the host
+// grows the buffers and re-runs the collide phase.
+struct StepCounts {
+  uint32_t Mt, Mp, C, Ct;                      // effective: terrain / pair candidates, constraints, terrain constraints
+  uint32_t fail;                               // kFail* bits
+  uint32_t need_Mt, need_Mp, need_C, need_Ct;  // actual sizes (valid up to the first failing stage)
+  uint32_t bins[6];                            // candidates per shape-pair type (scenes mixing spheres and capsules)
+  uint32_t pad;
+};
+constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u;
+
+__global__ void k_caps_candidates(const uint32_t* mt, const uint32_t* mp, uint32_t cap_t, uint32_t cap_p, const uint32_t* row_overflow,
+                                  StepCounts* sc) {
+  StepCounts r;
+  r.need_Mt = *mt; r.need_Mp = *mp; r.need_C = 0; r.need_Ct = 0;
+  r.fail = 0;
+  if (r.need_Mt > cap_t || r.need_Mp > cap_p) r.fail |= kFailCandCap;
+  if (row_overflow && *row_overflow) r.fail |= kFailRowOverflow;
+  r.Mt = r.fail ? 0u : r.need_Mt; r.Mp = r.fail ? 0u : r.need_Mp; r.C = 0; r.Ct = 0;
+  for (int k = 0; k < 6; ++k) r.bins[k] = 0;
+  r.pad = 0;
+  *sc = r;
+}
+__global__ void k_caps_constraints(const uint32_t* c, const uint32_t* ct, uint32_t cap_c, StepCounts* sc) {
+  if (sc->fail) return;
+  sc->need_C = *c; sc->need_Ct = *ct;
+  if (*c > cap_c) { sc->fail |= kFailConsCap; sc->Mt = 0; sc->Mp = 0; sc->C = 0; sc->Ct = 0; return; }
+  sc->C = *c; sc->Ct = *ct;
+}
+
 // XCD-aware query mapping: workgroup b is observed to run on XCD b % 8, each with a private 4 MB L2.
 // Give XCD x the x-th contiguous eighth of the Morton-ordered queries, so the part of the tree it
 // walks (a spatial eighth of the scene) stays resident in its own L2.  Launch xcd_grid(n) blocks.
@@ -438,8 +471,9 @@ template <bool FILL>
 __global__ __launch_bounds__(kBlock) void k_candidates(Bodies B, uint32_t n, uint32_t n_owned, Lbvh T, TerrainDev M, float pad,
                                                        uint32_t* t_cnt, uint32_t* p_cnt, const uint32_t* t_off,
                                                        const uint32_t* p_off, uint32_t* t_cand, uint32_t* t_owner,
-                                                       uint32_t* p_cand, uint32_t* p_owner) {
+                                                       uint32_t* p_cand, uint32_t* p_owner, const StepCounts* sc) {
   __shared__ QNode s_top[kLdsQNodes];
+  if (FILL && sc->fail) return;
   {
     uint32_t total = qlevel_offset(T.levels);
     uint32_t lim = T.n >= 2 ? min((uint32_t)kLdsQNodes, total) : 0u;
@@ -601,13 +635,13 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_rows(Bodies B, uint32_t n, 
 
 // rows -> CSR (terrain and partner candidate lists with their owners); partners sorted ascending in LDS
 // (canonical insertion order).
-__global__ __launch_bounds__(kBlock) void k_rows_to_csr(uint32_t n, const uint32_t* rows_t, const uint32_t* rows_p, const uint32_t* t_off,
-                                                        const uint32_t* p_off, uint32_t* t_cand, uint32_t* t_owner, uint32_t* p_cand,
-                                                        uint32_t* p_owner) {
+__global__ __launch_bounds__(kBlock) void k_rows_to_csr(const StepCounts* sc, uint32_t n, const uint32_t* rows_t, const uint32_t* rows_p,
+                                                        const uint32_t* t_off, const uint32_t* p_off, uint32_t* t_cand, uint32_t* t_owner,
+                                                        uint32_t* p_cand, uint32_t* p_owner) {
   __shared__ uint32_t s_row[kRowCap][kBlock];
   const int tid = threadIdx.x;
   uint32_t i = blockIdx.x * kBlock + tid;
-  if (i >= n) return;
+  if (i >= n || sc->fail) return;
   uint32_t tb = t_off[i], nt = t_off[i + 1] - tb, pb = p_off[i], np = p_off[i + 1] - pb;
   if (nt > (uint32_t)kRowCapT || np > (uint32_t)kRowCap) return;  // overflowed body: the host takes the two-pass path
   const uint32_t* rt = rows_t + (size_t)i * kRowCapT;
@@ -636,10 +670,10 @@ __device__ __forceinline__ Comp load_comp(const Bodies& B, uint32_t i) {
 
 // work = nullptr: dense over [0, m); else the m candidate ids of this pair type.
 template <int KA, int KB>
-__global__ __launch_bounds__(kBlock) void k_narrow_pairs(Bodies B, const uint32_t* work, uint32_t m, const uint32_t* p_owner,
+__global__ __launch_bounds__(kBlock) void k_narrow_pairs(Bodies B, const uint32_t* work, const uint32_t* m_ptr, const uint32_t* p_owner,
                                                          const uint32_t* p_cand, uint32_t* p_nc, NContact* p_out) {
   uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= m) return;
+  if (t >= *m_ptr) return;
   uint32_t p = work ? work[t] : t;
   uint32_t i = p_owner[p], j = p_cand[p];
   Comp A = load_comp(B, i), Bc = load_comp(B, j);
@@ -658,11 +692,11 @@ __global__ __launch_bounds__(kBlock) void k_narrow_pairs(Bodies B, const uint32_
 }
 
 template <int KA>
-__global__ __launch_bounds__(kBlock) void k_narrow_terrain(Bodies B, TerrainDev M, const uint32_t* work, uint32_t m,
+__global__ __launch_bounds__(kBlock) void k_narrow_terrain(Bodies B, TerrainDev M, const uint32_t* work, const uint32_t* m_ptr,
                                                            const uint32_t* t_owner, const uint32_t* t_cand, uint32_t* t_nc,
                                                            NContact* t_out /* 2 per candidate */) {
   uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= m) return;
+  if (t >= *m_ptr) return;
   uint32_t p = work ? work[t] : t;
   uint32_t i = t_owner[p], f = t_cand[p];
   Comp A = load_comp(B, i);
@@ -681,9 +715,10 @@ __global__ __launch_bounds__(kBlock) void k_narrow_terrain(Bodies B, TerrainDev 
 }
 
 // Bin candidate ids by pair type (only launched for scenes that mix spheres and capsules).
-__global__ __launch_bounds__(kBlock) void k_bin_pairs(Bodies B, uint32_t m, const uint32_t* p_owner, const uint32_t* p_cand,
-                                                      uint32_t* lists /* 4 x m */, uint32_t* counts /* 4 */) {
+__global__ __launch_bounds__(kBlock) void k_bin_pairs(Bodies B, const uint32_t* m_ptr, uint32_t stride, const uint32_t* p_owner,
+                                                      const uint32_t* p_cand, uint32_t* lists /* 4 x stride */, uint32_t* counts /* 4 */) {
   uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t m = *m_ptr;
   int type = -1;
   if (p < m) type = (int)(f2u(B.col1[p_owner[p]].w) * 2u + f2u(B.col1[p_cand[p]].w));
   for (int ty = 0; ty < 4; ++ty) {  // wave-aggregated append: one atomic per wave per type
@@ -694,12 +729,13 @@ __global__ __launch_bounds__(kBlock) void k_bin_pairs(Bodies B, uint32_t m, cons
     int leader = __ffsll((long long)mask) - 1;
     if (lane == leader) base = atomicAdd(&counts[ty], (uint32_t)__popcll(mask));
     base = __shfl(base, leader);
-    if (type == ty) lists[(size_t)ty * m + base + __popcll(mask & ((1ull << lane) - 1ull))] = p;
+    if (type == ty) lists[(size_t)ty * stride + base + __popcll(mask & ((1ull << lane) - 1ull))] = p;
   }
 }
-__global__ __launch_bounds__(kBlock) void k_bin_terrain(Bodies B, uint32_t m, const uint32_t* t_owner, uint32_t* lists /* 2 x m */,
-                                                        uint32_t* counts /* 2 */) {
+__global__ __launch_bounds__(kBlock) void k_bin_terrain(Bodies B, const uint32_t* m_ptr, uint32_t stride, const uint32_t* t_owner,
+                                                        uint32_t* lists /* 2 x stride */, uint32_t* counts /* 2 */) {
   uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t m = *m_ptr;
   int type = -1;
   if (p < m) type = (int)f2u(B.col1[t_owner[p]].w);
   for (int ty = 0; ty < 2; ++ty) {
@@ -710,17 +746,18 @@ __global__ __launch_bounds__(kBlock) void k_bin_terrain(Bodies B, uint32_t m, co
     int leader = __ffsll((long long)mask) - 1;
     if (lane == leader) base = atomicAdd(&counts[ty], (uint32_t)__popcll(mask));
     base = __shfl(base, leader);
-    if (type == ty) lists[(size_t)ty * m + base + __popcll(mask & ((1ull << lane) - 1ull))] = p;
+    if (type == ty) lists[(size_t)ty * stride + base + __popcll(mask & ((1ull << lane) - 1ull))] = p;
   }
 }
 
 // Per body: number of constraints it inserts (terrain contacts first, then partners) and the
 // running offset of each candidate inside the body's block.
-__global__ __launch_bounds__(kBlock) void k_count_contacts(uint32_t n, const uint32_t* t_off, const uint32_t* p_off,
+__global__ __launch_bounds__(kBlock) void k_count_contacts(const StepCounts* sc, uint32_t n, const uint32_t* t_off, const uint32_t* p_off,
                                                            const uint32_t* t_nc, const uint32_t* p_nc, uint32_t* t_pre,
                                                            uint32_t* p_pre, uint32_t* cnt, uint32_t* tcnt) {
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
+  if (sc->fail) { cnt[i] = 0; tcnt[i] = 0; return; }
   uint32_t run = 0;
   for (uint32_t p = t_off[i]; p < t_off[i + 1]; ++p) { t_pre[p] = run; run += t_nc[p]; }
   tcnt[i] = run;
@@ -809,12 +846,12 @@ __device__ __forceinline__ CRec load_crec(const CRec* src) {
 }
 static_assert(offsetof(CRec, nimp) == 88 && offsetof(CRec, round) == 92 && offsetof(CRec, succ_b) == 96, "CRec layout");
 
-__global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, uint32_t m, const uint32_t* p_owner, const uint32_t* p_cand,
+__global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCounts* sc, const uint32_t* p_owner, const uint32_t* p_cand,
                                                         const uint32_t* p_nc, const uint32_t* p_pre, const NContact* p_in,
                                                         const uint32_t* base, float dt, float baumgarte, float slop,
                                                         CRec* cons) {
   uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-  if (p >= m || p_nc[p] == 0) return;
+  if (p >= sc->Mp || p_nc[p] == 0) return;
   uint32_t i = p_owner[p], j = p_cand[p];
   uint32_t c = base[i] + p_pre[p];
   NContact k = p_in[p];
@@ -825,11 +862,11 @@ __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, uint32_t m, co
   store_crec(&cons[c], r);
 }
 
-__global__ __launch_bounds__(kBlock) void k_setup_terrain(Bodies B, TerrainDev M, uint32_t m, const uint32_t* t_owner,
+__global__ __launch_bounds__(kBlock) void k_setup_terrain(Bodies B, TerrainDev M, const StepCounts* sc, const uint32_t* t_owner,
                                                           const uint32_t* t_nc, const uint32_t* t_pre, const NContact* t_in,
                                                           const uint32_t* base, float dt, float baumgarte, float slop, CRec* cons) {
   uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-  if (p >= m) return;
+  if (p >= sc->Mt) return;
   uint32_t nc = t_nc[p];
   if (nc == 0) return;
   uint32_t i = t_owner[p];
@@ -852,17 +889,17 @@ __global__ __launch_bounds__(kBlock) void k_setup_terrain(Bodies B, TerrainDev M
 // are linked (succ_a / succ_b by the body's role in the earlier one).
 // ------------------------------------------------------------------------------------------
 // entry = (constraint id << 1) | role, role 0: the body is `a`, role 1: the body is `b`.
-__global__ __launch_bounds__(kBlock) void k_adj_fill(const CRec* cons, uint32_t C, const uint32_t* adj_off, uint32_t* adj_fill,
+__global__ __launch_bounds__(kBlock) void k_adj_fill(const CRec* cons, const uint32_t* C_ptr, const uint32_t* adj_off, uint32_t* adj_fill,
                                                      uint32_t* adj_list) {
   uint32_t c = blockIdx.x * kBlock + threadIdx.x;
-  if (c >= C) return;
+  if (c >= *C_ptr) return;
   uint32_t a = cons[c].a, b = cons[c].b;
   adj_list[adj_off[a] + atomicAdd(&adj_fill[a], 1u)] = (c << 1);
   if (b != kNone) adj_list[adj_off[b] + atomicAdd(&adj_fill[b], 1u)] = (c << 1) | 1u;
 }
-__global__ __launch_bounds__(kBlock) void k_adj_count(const CRec* cons, uint32_t C, uint32_t* deg) {
+__global__ __launch_bounds__(kBlock) void k_adj_count(const CRec* cons, const uint32_t* C_ptr, uint32_t* deg) {
   uint32_t c = blockIdx.x * kBlock + threadIdx.x;
-  if (c >= C) return;
+  if (c >= *C_ptr) return;
   atomicAdd(&deg[cons[c].a], 1u);
   uint32_t b = cons[c].b;
   if (b != kNone) atomicAdd(&deg[b], 1u);
@@ -1055,17 +1092,18 @@ __device__ __forceinline__ void store_vel_sc1(__amdgpu_buffer_rsrc_t r, uint32_t
 }
 
 // arr[c] = 2 - (weighted predecessors inside iteration 0): node (c, 0) is ready at arr >= 2.
-__global__ __launch_bounds__(kBlock) void k_flow_init(uint32_t C, const CRec* cons, uint32_t* arr, uint32_t* abort_flag) {
+__global__ __launch_bounds__(kBlock) void k_flow_init(const uint32_t* C_ptr, const CRec* cons, uint32_t* arr, uint32_t* abort_flag) {
   uint32_t c = blockIdx.x * kBlock + threadIdx.x;
   if (c == 0) *abort_flag = 0;
-  if (c >= C) return;
+  if (c >= *C_ptr) return;
   uint32_t d0 = cons[c].indeg0;
   arr[c] = 2u - d0 * (cons[c].b != kNone ? 1u : 2u);
 }
 
 template <bool TRACE>
-__global__ __launch_bounds__(kBlock) void k_solve_flow(float4* srec, CRec* cons, uint32_t* arr, uint32_t C, uint32_t iters,
+__global__ __launch_bounds__(kBlock) void k_solve_flow(float4* srec, CRec* cons, uint32_t* arr, const uint32_t* C_ptr, uint32_t iters,
                                                        uint32_t* abort_flag, uint32_t spin_limit, int sleep_mode, uint64_t* trace) {
+  const uint32_t C = *C_ptr;
   const uint32_t L = gridDim.x * kBlock;
   const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
   __amdgpu_buffer_rsrc_t rs = make_rsrc(srec);
@@ -1127,8 +1165,9 @@ __global__ __launch_bounds__(kBlock) void k_solve_flow(float4* srec, CRec* cons,
 // Still deadlock-free: the globally smallest pending node is the head of its slot.
 // ------------------------------------------------------------------------------------------
 template <int KS, bool TRACE>
-__global__ __launch_bounds__(kBlock) void k_solve_flowk(float4* srec, CRec* cons, uint32_t* arr, uint32_t C, uint32_t iters,
+__global__ __launch_bounds__(kBlock) void k_solve_flowk(float4* srec, CRec* cons, uint32_t* arr, const uint32_t* C_ptr, uint32_t iters,
                                                         uint32_t* abort_flag, uint32_t spin_limit, int sleep_mode, uint64_t* trace) {
+  const uint32_t C = *C_ptr;
   const uint32_t L = gridDim.x * kBlock;
   const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
   __amdgpu_buffer_rsrc_t rs = make_rsrc(srec);
@@ -1183,188 +1222,6 @@ __global__ __launch_bounds__(kBlock) void k_solve_flowk(float4* srec, CRec* cons
         if (pick == j) { sc[j] = cn; sr[j] = round; sa[j] = ia; sb[j] = ib; }
     }
     if (__any(pick >= 0)) { spins = 0; continue; }
-    if (sleep_mode == 1) __builtin_amdgcn_s_sleep(1);
-    else if (sleep_mode == 2) __builtin_amdgcn_s_sleep(4);
-    else if (sleep_mode == 3) __builtin_amdgcn_s_sleep(16);
-    if ((++spins & 255u) == 0u) {
-      bool give_up = spins > spin_limit;
-      if (give_up) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (give_up || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Dataflow solver, self-validating hand-off (solver mode 2).  Body x's constraints run in list order
-// every iteration, so the node at list position t of iteration k needs body x after exactly k*d + t
-// earlier solves (d = length of x's list).  Velocities live in a side array of two 16-byte halves per
-// body, (v, tag) and (w, tag), tag = number of solves applied so far.  A producer just stores the two
-// halves (write-through, no drain, no atomic); a consumer polls the halves of its two bodies until
-// all tags equal the versions it needs - the poll that succeeds already delivered the data.
-// A hand-off is one store propagation + one polled load.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_flow2_init(uint32_t n, const float4* srec, float4* svel, uint32_t* abort_flag) {
-  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i == 0) *abort_flag = 0;
-  if (i >= n) return;
-  float4 s0 = srec[4 * i], s1 = srec[4 * i + 1];
-  svel[2 * i] = make_float4(s0.x, s0.y, s0.z, u2f(0u));
-  svel[2 * i + 1] = make_float4(s0.w, s1.x, s1.y, u2f(0u));
-}
-__global__ __launch_bounds__(kBlock) void k_flow2_finish(uint32_t n, const float4* svel, float4* srec) {
-  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  float4 h0 = svel[2 * i], h1 = svel[2 * i + 1];
-  srec[4 * i] = make_float4(h0.x, h0.y, h0.z, h1.x);
-  float2* p = reinterpret_cast<float2*>(&srec[4 * i + 1]);
-  *p = make_float2(h1.y, h1.z);
-}
-struct BodyInv { float im; M3 I; };
-__device__ __forceinline__ BodyInv load_inv(const float4* srec, uint32_t i) {
-  float4 s1 = srec[4 * i + 1], s2 = srec[4 * i + 2], s3 = srec[4 * i + 3];
-  BodyInv d; d.im = s1.z;
-  d.I = m3_cols(mk3(s1.w, s2.x, s2.y), mk3(s2.z, s2.w, s3.x), mk3(s3.y, s3.z, s3.w));
-  return d;
-}
-
-__global__ __launch_bounds__(kBlock) void k_solve_flow2(const float4* srec, float4* svel, CRec* cons, uint32_t C, uint32_t iters,
-                                                        uint32_t* abort_flag, uint32_t spin_limit, int sleep_mode) {
-  const uint32_t L = gridDim.x * kBlock;
-  const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
-  __amdgpu_buffer_rsrc_t rv = make_rsrc(svel);
-  uint32_t c = gl, round = 0;
-  bool done = (c >= C) || iters == 0;
-  bool have_rec = false;
-  CRec rec;
-  BodyInv ia, ib;
-  uint32_t va = 0, vb = 0;
-  uint32_t spins = 0;
-  for (;;) {
-    if (!__any(!done)) break;
-    bool progressed = false;
-    if (!done) {
-      if (!have_rec) {  // private record + immutable inverse mass / inertia: fetched while the node waits
-        rec = load_crec(&cons[c]);
-        ia = load_inv(srec, rec.a);
-        if (rec.b != kNone) ib = load_inv(srec, rec.b);
-        else { ib.im = 0.0f; ib.I = m3_cols(mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)); }
-        va = round * rec.da + rec.ta;
-        vb = round * rec.db + rec.tb;
-        have_rec = true;
-      }
-      const bool dyn_b = rec.b != kNone;
-      v4f_t a0 = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(rec.a * 32u), 0, kSc1);
-      v4f_t a1 = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(rec.a * 32u + 16u), 0, kSc1);
-      v4f_t b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
-      if (dyn_b) {
-        b0 = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(rec.b * 32u), 0, kSc1);
-        b1 = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(rec.b * 32u + 16u), 0, kSc1);
-      }
-      bool ready = f2u(a0.w) == va && f2u(a1.w) == va && (!dyn_b || (f2u(b0.w) == vb && f2u(b1.w) == vb));
-      if (ready) {
-        BodyDyn A, Bd;
-        A.v = mk3(a0.x, a0.y, a0.z); A.w = mk3(a1.x, a1.y, a1.z); A.im = ia.im; A.I = ia.I;
-        Bd.v = mk3(b0.x, b0.y, b0.z); Bd.w = mk3(b1.x, b1.y, b1.z); Bd.im = ib.im; Bd.I = ib.I;
-        solve_one(rec, A, Bd);
-        v4f_t o0 = {A.v.x, A.v.y, A.v.z, u2f(va + 1u)}, o1 = {A.w.x, A.w.y, A.w.z, u2f(va + 1u)};
-        __builtin_amdgcn_raw_buffer_store_b128(o0, rv, (int)(rec.a * 32u), 0, kSc1);
-        __builtin_amdgcn_raw_buffer_store_b128(o1, rv, (int)(rec.a * 32u + 16u), 0, kSc1);
-        if (dyn_b) {
-          v4f_t p0 = {Bd.v.x, Bd.v.y, Bd.v.z, u2f(vb + 1u)}, p1 = {Bd.w.x, Bd.w.y, Bd.w.z, u2f(vb + 1u)};
-          __builtin_amdgcn_raw_buffer_store_b128(p0, rv, (int)(rec.b * 32u), 0, kSc1);
-          __builtin_amdgcn_raw_buffer_store_b128(p1, rv, (int)(rec.b * 32u + 16u), 0, kSc1);
-        }
-        cons[c].nimp = rec.nimp;
-        progressed = true;
-        have_rec = false;
-        c += L;
-        if (c >= C) { c = gl; ++round; if (round >= iters) done = true; }
-      }
-    }
-    if (__any(progressed)) { spins = 0; continue; }
-    if (sleep_mode == 1) __builtin_amdgcn_s_sleep(1);
-    else if (sleep_mode == 2) __builtin_amdgcn_s_sleep(4);
-    else if (sleep_mode == 3) __builtin_amdgcn_s_sleep(16);
-    if ((++spins & 255u) == 0u) {
-      bool give_up = spins > spin_limit;
-      if (give_up) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (give_up || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Dataflow solver, solver mode 3 = mode 1's light readiness poll (4-byte arrival counter) + mode 2's
-// version-tagged velocity halves.  The producer issues its tagged write-through stores and the arrival
-// atomics back to back - no store drain: if the arrival overtakes the data, the consumer sees a wrong
-// tag and simply re-loads.  A hand-off is: store/atomic propagation, one 4-byte poll, one 64-byte load.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_solve_flow3(const float4* srec, float4* svel, CRec* cons, uint32_t* arr, uint32_t C,
-                                                        uint32_t iters, uint32_t* abort_flag, uint32_t spin_limit, int sleep_mode) {
-  const uint32_t L = gridDim.x * kBlock;
-  const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
-  __amdgpu_buffer_rsrc_t rv = make_rsrc(svel);
-  uint32_t c = gl, round = 0;
-  bool done = (c >= C) || iters == 0;
-  bool have_rec = false;
-  CRec rec;
-  BodyInv ia, ib;
-  uint32_t va = 0, vb = 0;
-  uint32_t spins = 0;
-  for (;;) {
-    if (!__any(!done)) break;
-    bool progressed = false;
-    if (!done) {
-      if (!have_rec) {  // private record + immutable inverse mass / inertia: fetched while the node waits
-        rec = load_crec(&cons[c]);
-        ia = load_inv(srec, rec.a);
-        if (rec.b != kNone) ib = load_inv(srec, rec.b);
-        else { ib.im = 0.0f; ib.I = m3_cols(mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)); }
-        va = round * rec.da + rec.ta;
-        vb = round * rec.db + rec.tb;
-        have_rec = true;
-      }
-      uint32_t arrived = __hip_atomic_load(&arr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (arrived >= 2u * (round + 1u)) {
-        asm volatile("" ::: "memory");
-        const bool dyn_b = rec.b != kNone;
-        v4f_t a0 = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(rec.a * 32u), 0, kSc1);
-        v4f_t a1 = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(rec.a * 32u + 16u), 0, kSc1);
-        v4f_t b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
-        if (dyn_b) {
-          b0 = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(rec.b * 32u), 0, kSc1);
-          b1 = __builtin_amdgcn_raw_buffer_load_b128(rv, (int)(rec.b * 32u + 16u), 0, kSc1);
-        }
-        bool fresh = f2u(a0.w) == va && f2u(a1.w) == va && (!dyn_b || (f2u(b0.w) == vb && f2u(b1.w) == vb));
-        if (fresh) {  // otherwise the arrival overtook the data: poll again
-          BodyDyn A, Bd;
-          A.v = mk3(a0.x, a0.y, a0.z); A.w = mk3(a1.x, a1.y, a1.z); A.im = ia.im; A.I = ia.I;
-          Bd.v = mk3(b0.x, b0.y, b0.z); Bd.w = mk3(b1.x, b1.y, b1.z); Bd.im = ib.im; Bd.I = ib.I;
-          solve_one(rec, A, Bd);
-          v4f_t o0 = {A.v.x, A.v.y, A.v.z, u2f(va + 1u)}, o1 = {A.w.x, A.w.y, A.w.z, u2f(va + 1u)};
-          __builtin_amdgcn_raw_buffer_store_b128(o0, rv, (int)(rec.a * 32u), 0, kSc1);
-          __builtin_amdgcn_raw_buffer_store_b128(o1, rv, (int)(rec.a * 32u + 16u), 0, kSc1);
-          if (dyn_b) {
-            v4f_t p0 = {Bd.v.x, Bd.v.y, Bd.v.z, u2f(vb + 1u)}, p1 = {Bd.w.x, Bd.w.y, Bd.w.z, u2f(vb + 1u)};
-            __builtin_amdgcn_raw_buffer_store_b128(p0, rv, (int)(rec.b * 32u), 0, kSc1);
-            __builtin_amdgcn_raw_buffer_store_b128(p1, rv, (int)(rec.b * 32u + 16u), 0, kSc1);
-          }
-#pragma unroll
-          for (int side = 0; side < 2; ++side) {
-            if (side == 1 && !dyn_b) break;
-            uint32_t w = side == 0 ? rec.succ_a : rec.succ_b;
-            if (round + (w >> 31) >= iters) continue;
-            __hip_atomic_fetch_add(&arr[w & kSuccId], (w & kSuccTwo) ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          cons[c].nimp = rec.nimp;
-          progressed = true;
-          have_rec = false;
-          c += L;
-          if (c >= C) { c = gl; ++round; if (round >= iters) done = true; }
-        }
-      }
-    }
-    if (__any(progressed)) { spins = 0; continue; }
     if (sleep_mode == 1) __builtin_amdgcn_s_sleep(1);
     else if (sleep_mode == 2) __builtin_amdgcn_s_sleep(4);
     else if (sleep_mode == 3) __builtin_amdgcn_s_sleep(16);

@@ -503,14 +503,17 @@ struct mgf_world {
   DBuf<uint32_t> cell_lo, cell_hi;
   DBuf<uint32_t> t_cnt, p_cnt, t_off, p_off, t_cand, t_owner, p_cand, p_owner, rows, rows_t;
   // 1 (default) = one persistent dataflow launch per Solver::solve (k_solve_flow);
-  // 0 = one launch per frontier of the dependency graph (k_solve); 2, 3 = dataflow variants with
-  // version-tagged velocity words (k_solve_flow2 / k_solve_flow3), kept for comparison
+  // 0 = one launch per frontier of the dependency graph (k_solve, the independent cross-check);
+  // 4 = dataflow launch with out-of-order slots per lane (k_solve_flowk)
   int64_t opt_solver_mode = 1;
   DBuf<uint32_t> flow_arr;
   DBuf<uint64_t> flow_trace;
-  DBuf<float4> svel;
-  int flow2_grid = 0;
   int flow_grid = 0;
+  // device-resident list sizes + speculative capacities (see StepCounts)
+  DBuf<StepCounts> sc;
+  uint32_t cap_t = 0, cap_p = 0, cap_c = 0;
+  uint64_t n_cap_retries = 0;
+  bool tick_two_pass = false;
   int64_t opt_flow_blocks_per_cu = 0, opt_flow_sleep = 2;
   int flowk_grid = 0;
   int64_t opt_debug_bvh = 0, opt_flow_trace = 0;
@@ -554,6 +557,8 @@ extern "C" mgf_status mgf_world_new(mgf_ctx* ctx, const mgf_params* params, mgf_
   memset(&w->stats, 0, sizeof(w->stats));
   MGF_TRY(w->scalars.ensure(8, ctx->stream));
   MGF_TRY(w->sb.ensure(1, ctx->stream));
+  MGF_TRY(w->sc.ensure(1, ctx->stream));
+  MGF_HIP_TRY(hipMemsetAsync(w->sc.p, 0, sizeof(StepCounts), ctx->stream));
   MGF_HIP_TRY(hipMemsetAsync(w->scalars.p, 0, 32, ctx->stream));
   for (auto& e : w->ev) MGF_HIP_TRY(hipEventCreate(&e));
   *out = w.release();
@@ -576,8 +581,13 @@ extern "C" mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_
   if (!strcmp(key, "flow_trace")) { w->opt_flow_trace = value; return MGF_OK; }
   if (!strcmp(key, "debug_bvh")) { w->opt_debug_bvh = value; return MGF_OK; }
   if (!strcmp(key, "solver_mode")) { w->opt_solver_mode = value; return MGF_OK; }
-  if (!strcmp(key, "flow_blocks_per_cu")) { w->opt_flow_blocks_per_cu = value; w->flow_grid = 0; w->flow2_grid = 0; w->flowk_grid = 0; return MGF_OK; }
+  if (!strcmp(key, "flow_blocks_per_cu")) { w->opt_flow_blocks_per_cu = value; w->flow_grid = 0; w->flowk_grid = 0; return MGF_OK; }
   if (!strcmp(key, "flow_sleep")) { w->opt_flow_sleep = value; return MGF_OK; }
+  if (!strcmp(key, "list_capacity")) {  // tests: force the speculative list capacities (the next tick must re-run its collide phase)
+    if (value < 1 || value > 0x7FFFFFF0ll) return fail(MGF_ERR_INVALID, "list_capacity out of range");
+    w->cap_t = w->cap_p = w->cap_c = (uint32_t)value;
+    return MGF_OK;
+  }
   return fail(MGF_ERR_INVALID, "unknown option");
 }
 
@@ -801,50 +811,50 @@ extern "C" mgf_status mgf_world_integrate(mgf_world* w, float dt) {
   return MGF_OK;
 }
 
-static mgf_status launch_pairs(mgf_world* w, int ka, int kb, const uint32_t* work, uint32_t m) {
-  if (m == 0) return MGF_OK;
+static mgf_status launch_pairs(mgf_world* w, int ka, int kb, const uint32_t* work, const uint32_t* m_ptr, uint32_t cap) {
+  if (cap == 0) return MGF_OK;
   hipStream_t s = w->ctx->stream;
   Bodies B = w->bodies();
-  unsigned g = nblk(m);
-  if (ka == 0 && kb == 0) k_narrow_pairs<0, 0><<<g, kBlock, 0, s>>>(B, work, m, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_out.p);
-  else if (ka == 0 && kb == 1) k_narrow_pairs<0, 1><<<g, kBlock, 0, s>>>(B, work, m, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_out.p);
-  else if (ka == 1 && kb == 0) k_narrow_pairs<1, 0><<<g, kBlock, 0, s>>>(B, work, m, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_out.p);
-  else k_narrow_pairs<1, 1><<<g, kBlock, 0, s>>>(B, work, m, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_out.p);
+  unsigned g = nblk(cap);
+  if (ka == 0 && kb == 0) k_narrow_pairs<0, 0><<<g, kBlock, 0, s>>>(B, work, m_ptr, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_out.p);
+  else if (ka == 0 && kb == 1) k_narrow_pairs<0, 1><<<g, kBlock, 0, s>>>(B, work, m_ptr, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_out.p);
+  else if (ka == 1 && kb == 0) k_narrow_pairs<1, 0><<<g, kBlock, 0, s>>>(B, work, m_ptr, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_out.p);
+  else k_narrow_pairs<1, 1><<<g, kBlock, 0, s>>>(B, work, m_ptr, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_out.p);
   LAUNCH_CHECK();
   return MGF_OK;
 }
-static mgf_status launch_terrain(mgf_world* w, int ka, const TerrainDev& M, const uint32_t* work, uint32_t m) {
-  if (m == 0) return MGF_OK;
+static mgf_status launch_terrain(mgf_world* w, int ka, const TerrainDev& M, const uint32_t* work, const uint32_t* m_ptr, uint32_t cap) {
+  if (cap == 0) return MGF_OK;
   hipStream_t s = w->ctx->stream;
   Bodies B = w->bodies();
-  unsigned g = nblk(m);
-  if (ka == 0) k_narrow_terrain<0><<<g, kBlock, 0, s>>>(B, M, work, m, w->t_owner.p, w->t_cand.p, w->t_nc.p, w->t_out.p);
-  else k_narrow_terrain<1><<<g, kBlock, 0, s>>>(B, M, work, m, w->t_owner.p, w->t_cand.p, w->t_nc.p, w->t_out.p);
+  unsigned g = nblk(cap);
+  if (ka == 0) k_narrow_terrain<0><<<g, kBlock, 0, s>>>(B, M, work, m_ptr, w->t_owner.p, w->t_cand.p, w->t_nc.p, w->t_out.p);
+  else k_narrow_terrain<1><<<g, kBlock, 0, s>>>(B, M, work, m_ptr, w->t_owner.p, w->t_cand.p, w->t_nc.p, w->t_out.p);
   LAUNCH_CHECK();
   return MGF_OK;
 }
 
 // Dependency links of the insertion-ordered list cons_nat[0..C): per-body adjacency (sorted),
-// circular successor words, in-degrees of iteration 0.
-static mgf_status build_dag(mgf_world* w) {
+// circular successor words, in-degrees of iteration 0.  C is read on the device (sc->C); grids and
+// buffers are sized by `cap_c`.
+static mgf_status build_dag(mgf_world* w, uint32_t cap_c) {
   mgf_ctx* ctx = w->ctx;
   hipStream_t s = ctx->stream;
-  uint32_t n = w->n, C = w->C;
+  uint32_t n = w->n;
   w->depth = 0;
-  if (C == 0) { w->constraints_ready = true; return MGF_OK; }
-  if (C >= kSuccId) return fail(MGF_ERR_CAPACITY, "too many constraints");
+  if (cap_c == 0) return MGF_OK;
+  if (cap_c >= kSuccId) return fail(MGF_ERR_CAPACITY, "too many constraints");
   MGF_TRY(w->deg.ensure(n + 1, s)); MGF_TRY(w->adj_off.ensure(n + 1, s)); MGF_TRY(w->adj_fill.ensure(n + 1, s));
-  MGF_TRY(w->adj_list.ensure(2 * (size_t)C, s));
+  MGF_TRY(w->adj_list.ensure(2 * (size_t)cap_c, s));
   MGF_HIP_TRY(hipMemsetAsync(w->deg.p, 0, (n + 1) * 4, s));
   MGF_HIP_TRY(hipMemsetAsync(w->adj_fill.p, 0, (n + 1) * 4, s));
-  k_adj_count<<<nblk(C), kBlock, 0, s>>>(w->cons_nat.p, C, w->deg.p);
+  k_adj_count<<<nblk(cap_c), kBlock, 0, s>>>(w->cons_nat.p, &w->sc.p->C, w->deg.p);
   LAUNCH_CHECK();
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->deg.p, w->adj_off.p, (size_t)n + 1));
-  k_adj_fill<<<nblk(C), kBlock, 0, s>>>(w->cons_nat.p, C, w->adj_off.p, w->adj_fill.p, w->adj_list.p);
+  k_adj_fill<<<nblk(cap_c), kBlock, 0, s>>>(w->cons_nat.p, &w->sc.p->C, w->adj_off.p, w->adj_fill.p, w->adj_list.p);
   LAUNCH_CHECK();
   k_chain<<<nblk(n), kBlock, 0, s>>>(n, w->cons_nat.p, w->adj_off.p, w->adj_list.p);
   LAUNCH_CHECK();
-  w->constraints_ready = true;
   return MGF_OK;
 }
 
@@ -859,6 +869,7 @@ static mgf_status world_begin(mgf_world* w, float dt) {
   w->stats.n_bodies = w->n_owned;
   w->last_dt = dt;
   w->constraints_ready = false;
+  w->tick_two_pass = false;
   w->C = w->Ct = w->Mt = w->Mp = 0;
   MGF_HIP_TRY(hipEventRecord(w->ev[0], s));
   k_reset_step<<<1, 64, 0, s>>>(w->sb.p, w->d_err());
@@ -872,17 +883,20 @@ extern "C" mgf_status mgf_world_begin_tick(mgf_world* w, float dt) {
   return MGF_OK;
 }
 
-// Second half: broadphase, narrowphase, ContactConstraint::new over owned + ghost bodies.
-extern "C" mgf_status mgf_world_collide(mgf_world* w, float dt, mgf_step_stats* stats) {
-  if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
-  MGF_TRY(ctx_bind(w->ctx));
+// Second half: broadphase, narrowphase, ContactConstraint::new over owned + ghost bodies.  Enqueue only:
+// nothing is read back, list sizes stay on the device (StepCounts), buffers and grids use the
+// capacities cap_t / cap_p / cap_c.
+static mgf_status collide_enqueue(mgf_world* w, float dt) {
   mgf_ctx* ctx = w->ctx;
   hipStream_t s = ctx->stream;
   const uint32_t n = w->n;
-  w->constraints_ready = false;
-  w->C = w->Ct = w->Mt = w->Mp = 0;
-  if (n == 0) { w->constraints_ready = true; if (stats) *stats = w->stats; MGF_HIP_TRY(hipStreamSynchronize(s)); return MGF_OK; }
+  StepCounts* sc = w->sc.p;
+  if (n == 0) { MGF_HIP_TRY(hipMemsetAsync(sc, 0, sizeof(StepCounts), s)); return MGF_OK; }
   Bodies B = w->bodies();
+  // first tick: room for a few candidates per body; later ticks: last tick's sizes plus slack (collide_finish)
+  if (w->cap_p == 0) { w->cap_p = std::max(4 * n, 1024u); w->cap_t = std::max(2 * n, 1024u); w->cap_c = std::max(4 * n, 1024u); }
+  const uint32_t cap_t = w->cap_t, cap_p = w->cap_p, cap_c = w->cap_c;
+  MGF_HIP_TRY(hipMemsetAsync(w->d_err() + 1, 0, 4, s));  // row-overflow flag (re-armed for a re-run inside the tick)
   // 2. linear BVH over the fat AABBs
   uint32_t levels = 4;  // 4^levels Morton cells, about one body per cell
   while (((uint64_t)1 << (2 * levels)) < n && levels < (uint32_t)kMortonBits / 2) ++levels;
@@ -914,13 +928,17 @@ extern "C" mgf_status mgf_world_collide(mgf_world* w, float dt, mgf_step_stats* 
   LAUNCH_CHECK();
   if (levels > 4) { k_lbvh_top<<<1, 1024, 0, s>>>(T, w->sub_lo.p, w->sub_hi.p, w->sub2_lo.p, w->sub2_hi.p); LAUNCH_CHECK(); }
   MGF_HIP_TRY(hipEventRecord(w->ev[1], s));
-  // 3. candidates: count, scan, fill
+  // 3. candidates
   TerrainDev M;
   if (w->terrain && !w->terrain->m.tree.empty()) M = w->terrain->dev(w->d_err());
   else { memset(&M, 0, sizeof(M)); }
   MGF_TRY(w->t_cnt.ensure(n + 1, s)); MGF_TRY(w->p_cnt.ensure(n + 1, s)); MGF_TRY(w->t_off.ensure(n + 1, s)); MGF_TRY(w->p_off.ensure(n + 1, s));
-  uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
-  bool two_pass = w->opt_two_pass != 0;
+  MGF_TRY(w->t_cand.ensure(cap_t, s)); MGF_TRY(w->t_owner.ensure(cap_t, s));
+  MGF_TRY(w->p_cand.ensure(cap_p, s)); MGF_TRY(w->p_owner.ensure(cap_p, s));
+  MGF_TRY(w->t_nc.ensure(cap_t, s)); MGF_TRY(w->p_nc.ensure(cap_p, s));
+  MGF_TRY(w->t_pre.ensure(cap_t, s)); MGF_TRY(w->p_pre.ensure(cap_p, s));
+  MGF_TRY(w->t_out.ensure(2 * (size_t)cap_t, s)); MGF_TRY(w->p_out.ensure(cap_p, s));
+  const bool two_pass = w->opt_two_pass != 0 || w->tick_two_pass;
   if (!two_pass) {
     // fast path: one traversal, hits written to fixed-capacity rows
     MGF_TRY(w->rows.ensure((size_t)n * kRowCap, s));
@@ -937,98 +955,126 @@ extern "C" mgf_status mgf_world_collide(mgf_world* w, float dt, mgf_step_stats* 
       LAUNCH_CHECK();
     }
   } else {
-    k_candidates<false><<<8 * xcd_blocks_per(n), kBlock, 0, s>>>(B, n, w->n_owned, T, M, 1e-3f, w->t_cnt.p, w->p_cnt.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    k_candidates<false><<<8 * xcd_blocks_per(n), kBlock, 0, s>>>(B, n, w->n_owned, T, M, 1e-3f, w->t_cnt.p, w->p_cnt.p, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     LAUNCH_CHECK();
   }
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->t_cnt.p, w->t_off.p, (size_t)n + 1));
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->p_cnt.p, w->p_off.p, (size_t)n + 1));
-  MGF_HIP_TRY(hipMemcpyAsync(pin, w->t_off.p + n, 4, hipMemcpyDeviceToHost, s));
-  MGF_HIP_TRY(hipMemcpyAsync(pin + 1, w->p_off.p + n, 4, hipMemcpyDeviceToHost, s));
-  MGF_HIP_TRY(hipMemcpyAsync(pin + 2, w->sb.p, sizeof(SceneBounds), hipMemcpyDeviceToHost, s));
-  MGF_HIP_TRY(hipMemcpyAsync(pin + 16, w->d_err(), 8, hipMemcpyDeviceToHost, s));
-  MGF_HIP_TRY(hipStreamSynchronize(s));
-  uint32_t Mt = pin[0], Mp = pin[1];
-  w->stats.n_refits = reinterpret_cast<SceneBounds*>(pin + 2)->n_refits;
-  if (pin[16]) return fail(MGF_ERR_CAPACITY, "BVH traversal stack overflow");
-  if (!two_pass && pin[17]) { two_pass = true; w->n_row_overflows++; }  // some body has more than kRowCap hits: exact path
-  w->Mt = Mt; w->Mp = Mp;
-  w->stats.n_terrain_candidates = Mt; w->stats.n_pair_candidates = Mp;
-  MGF_TRY(w->t_cand.ensure(std::max(Mt, 1u), s)); MGF_TRY(w->t_owner.ensure(std::max(Mt, 1u), s));
-  MGF_TRY(w->p_cand.ensure(std::max(Mp, 1u), s)); MGF_TRY(w->p_owner.ensure(std::max(Mp, 1u), s));
-  MGF_TRY(w->t_nc.ensure(std::max(Mt, 1u), s)); MGF_TRY(w->p_nc.ensure(std::max(Mp, 1u), s));
-  MGF_TRY(w->t_pre.ensure(std::max(Mt, 1u), s)); MGF_TRY(w->p_pre.ensure(std::max(Mp, 1u), s));
-  MGF_TRY(w->t_out.ensure(std::max(2 * (size_t)Mt, (size_t)1), s)); MGF_TRY(w->p_out.ensure(std::max(Mp, 1u), s));
-  if (Mt + Mp > 0) {
-    if (two_pass) {
-      k_candidates<true><<<8 * xcd_blocks_per(n), kBlock, 0, s>>>(B, n, w->n_owned, T, M, 1e-3f, nullptr, nullptr, w->t_off.p, w->p_off.p, w->t_cand.p, w->t_owner.p,
-                                                    w->p_cand.p, w->p_owner.p);
-    } else {
-      k_rows_to_csr<<<nblk(n), kBlock, 0, s>>>(n, w->rows_t.p, w->rows.p, w->t_off.p, w->p_off.p, w->t_cand.p, w->t_owner.p, w->p_cand.p, w->p_owner.p);
-    }
-    LAUNCH_CHECK();
+  k_caps_candidates<<<1, 1, 0, s>>>(w->t_off.p + n, w->p_off.p + n, cap_t, cap_p, two_pass ? nullptr : w->d_err() + 1, sc);
+  LAUNCH_CHECK();
+  if (two_pass) {
+    k_candidates<true><<<8 * xcd_blocks_per(n), kBlock, 0, s>>>(B, n, w->n_owned, T, M, 1e-3f, nullptr, nullptr, w->t_off.p, w->p_off.p, w->t_cand.p, w->t_owner.p,
+                                                  w->p_cand.p, w->p_owner.p, sc);
+  } else {
+    k_rows_to_csr<<<nblk(n), kBlock, 0, s>>>(sc, n, w->rows_t.p, w->rows.p, w->t_off.p, w->p_off.p, w->t_cand.p, w->t_owner.p, w->p_cand.p, w->p_owner.p);
   }
+  LAUNCH_CHECK();
   MGF_HIP_TRY(hipEventRecord(w->ev[2], s));
   // 4. narrowphase, one kernel per shape-pair type
   bool mixed = w->has_sphere && w->has_capsule;
   if (!mixed) {
     int k = w->has_capsule ? 1 : 0;
-    MGF_TRY(launch_pairs(w, k, k, nullptr, Mp));
-    MGF_TRY(launch_terrain(w, k, M, nullptr, Mt));
+    MGF_TRY(launch_pairs(w, k, k, nullptr, &sc->Mp, cap_p));
+    if (M.n_nodes) MGF_TRY(launch_terrain(w, k, M, nullptr, &sc->Mt, cap_t));
   } else {
-    size_t mm = std::max(Mt, Mp);
-    MGF_TRY(w->work_lists.ensure(4 * std::max<size_t>(mm, 1), s));
-    MGF_TRY(w->work_counts.ensure(8, s));
-    MGF_HIP_TRY(hipMemsetAsync(w->work_counts.p, 0, 32, s));
-    uint32_t hc[8] = {0};
-    if (Mp) { k_bin_pairs<<<nblk(Mp), kBlock, 0, s>>>(B, Mp, w->p_owner.p, w->p_cand.p, w->work_lists.p, w->work_counts.p); LAUNCH_CHECK(); }
-    MGF_TRY(d2h(ctx, hc, w->work_counts.p, 4));
-    for (int ty = 0; ty < 4; ++ty) MGF_TRY(launch_pairs(w, ty >> 1, ty & 1, w->work_lists.p + (size_t)ty * Mp, hc[ty]));
-    MGF_HIP_TRY(hipStreamSynchronize(s));  // lists are reused for the terrain bins
-    if (Mt) { k_bin_terrain<<<nblk(Mt), kBlock, 0, s>>>(B, Mt, w->t_owner.p, w->work_lists.p, w->work_counts.p + 4); LAUNCH_CHECK(); }
-    MGF_TRY(d2h(ctx, hc + 4, w->work_counts.p + 4, 2));
-    for (int ty = 0; ty < 2; ++ty) MGF_TRY(launch_terrain(w, ty, M, w->work_lists.p + (size_t)ty * Mt, hc[4 + ty]));
+    MGF_TRY(w->work_lists.ensure(4 * (size_t)cap_p + 2 * (size_t)cap_t, s));
+    uint32_t* lists_p = w->work_lists.p;
+    uint32_t* lists_t = w->work_lists.p + 4 * (size_t)cap_p;
+    k_bin_pairs<<<nblk(cap_p), kBlock, 0, s>>>(B, &sc->Mp, cap_p, w->p_owner.p, w->p_cand.p, lists_p, sc->bins);
+    LAUNCH_CHECK();
+    for (int ty = 0; ty < 4; ++ty) MGF_TRY(launch_pairs(w, ty >> 1, ty & 1, lists_p + (size_t)ty * cap_p, &sc->bins[ty], cap_p));
+    if (M.n_nodes) {
+      k_bin_terrain<<<nblk(cap_t), kBlock, 0, s>>>(B, &sc->Mt, cap_t, w->t_owner.p, lists_t, sc->bins + 4);
+      LAUNCH_CHECK();
+      for (int ty = 0; ty < 2; ++ty) MGF_TRY(launch_terrain(w, ty, M, lists_t + (size_t)ty * cap_t, &sc->bins[4 + ty], cap_t));
+    }
   }
   MGF_HIP_TRY(hipEventRecord(w->ev[3], s));
   // 5. constraint numbering in insertion order + ContactConstraint::new
   MGF_TRY(w->cnt.ensure(n + 1, s)); MGF_TRY(w->tcnt.ensure(n + 1, s)); MGF_TRY(w->base.ensure(n + 1, s)); MGF_TRY(w->tbase.ensure(n + 1, s));
-  k_count_contacts<<<nblk(n), kBlock, 0, s>>>(n, w->t_off.p, w->p_off.p, w->t_nc.p, w->p_nc.p, w->t_pre.p, w->p_pre.p, w->cnt.p, w->tcnt.p);
+  k_count_contacts<<<nblk(n), kBlock, 0, s>>>(sc, n, w->t_off.p, w->p_off.p, w->t_nc.p, w->p_nc.p, w->t_pre.p, w->p_pre.p, w->cnt.p, w->tcnt.p);
   LAUNCH_CHECK();
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->cnt.p, w->base.p, (size_t)n + 1));
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->tcnt.p, w->tbase.p, (size_t)n + 1));
-  MGF_HIP_TRY(hipMemcpyAsync(pin, w->base.p + n, 4, hipMemcpyDeviceToHost, s));
-  MGF_HIP_TRY(hipMemcpyAsync(pin + 1, w->tbase.p + n, 4, hipMemcpyDeviceToHost, s));
-  MGF_HIP_TRY(hipStreamSynchronize(s));
-  uint32_t C = pin[0];
-  w->C = C; w->Ct = pin[1];
-  w->stats.n_constraints = C; w->stats.n_terrain_constraints = w->Ct;
-  if (C >= 0x7FFFFFF0u) return fail(MGF_ERR_CAPACITY, "too many constraints");
-  MGF_TRY(w->cons_nat.ensure(std::max(C, 1u), s));
-  if (Mt) {
-    k_setup_terrain<<<nblk(Mt), kBlock, 0, s>>>(B, M, Mt, w->t_owner.p, w->t_nc.p, w->t_pre.p, w->t_out.p, w->base.p, dt, w->params.baumgarte,
-                                                w->params.penetration_slop, w->cons_nat.p);
+  k_caps_constraints<<<1, 1, 0, s>>>(w->base.p + n, w->tbase.p + n, cap_c, sc);
+  LAUNCH_CHECK();
+  MGF_TRY(w->cons_nat.ensure(cap_c, s));
+  if (M.n_nodes) {
+    k_setup_terrain<<<nblk(cap_t), kBlock, 0, s>>>(B, M, sc, w->t_owner.p, w->t_nc.p, w->t_pre.p, w->t_out.p, w->base.p, dt, w->params.baumgarte,
+                                                   w->params.penetration_slop, w->cons_nat.p);
     LAUNCH_CHECK();
   }
-  if (Mp) {
-    k_setup_pairs<<<nblk(Mp), kBlock, 0, s>>>(B, Mp, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_pre.p, w->p_out.p, w->base.p, dt,
-                                              w->params.baumgarte, w->params.penetration_slop, w->cons_nat.p);
-    LAUNCH_CHECK();
-  }
-  MGF_TRY(build_dag(w));
+  k_setup_pairs<<<nblk(cap_p), kBlock, 0, s>>>(B, sc, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_pre.p, w->p_out.p, w->base.p, dt,
+                                               w->params.baumgarte, w->params.penetration_slop, w->cons_nat.p);
+  LAUNCH_CHECK();
+  MGF_TRY(build_dag(w, cap_c));
   MGF_HIP_TRY(hipEventRecord(w->ev[4], s));
+  return MGF_OK;
+}
+
+// Read the tick's sizes and flags back (the stream must have been synchronised by the caller's copy):
+// MGF_OK + *retry=false when the collide phase is complete; *retry=true after growing a capacity or
+// switching to the exact two-pass candidate path (the caller re-enqueues the phase).
+static mgf_status collide_finish(mgf_world* w, bool* retry) {
+  mgf_ctx* ctx = w->ctx;
+  hipStream_t s = ctx->stream;
+  *retry = false;
+  if (w->n == 0) { w->constraints_ready = true; return MGF_OK; }
+  uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
+  MGF_HIP_TRY(hipMemcpyAsync(pin, w->sc.p, sizeof(StepCounts), hipMemcpyDeviceToHost, s));
+  MGF_HIP_TRY(hipMemcpyAsync(pin + 32, w->sb.p, sizeof(SceneBounds), hipMemcpyDeviceToHost, s));
+  MGF_HIP_TRY(hipMemcpyAsync(pin + 64, w->d_err(), 12, hipMemcpyDeviceToHost, s));
   MGF_HIP_TRY(hipStreamSynchronize(s));
+  StepCounts h = *reinterpret_cast<StepCounts*>(pin);
+  w->stats.n_refits = reinterpret_cast<SceneBounds*>(pin + 32)->n_refits;
+  if (pin[64]) return fail(MGF_ERR_CAPACITY, "BVH traversal stack overflow");
+  auto grown = [](uint32_t need) { return (uint32_t)std::min<uint64_t>((uint64_t)need + need / 2 + 1024, 0x7FFFFFF0ull); };
+  if (h.fail & kFailRowOverflow) { w->tick_two_pass = true; w->n_row_overflows++; *retry = true; }
+  if (h.fail & kFailCandCap) {
+    if (h.need_Mt > w->cap_t) w->cap_t = grown(h.need_Mt);
+    if (h.need_Mp > w->cap_p) w->cap_p = grown(h.need_Mp);
+    *retry = true;
+  }
+  if (h.fail & kFailConsCap) {
+    if (h.need_C >= 0x7FFFFFF0u) return fail(MGF_ERR_CAPACITY, "too many constraints");
+    w->cap_c = grown(h.need_C);
+    *retry = true;
+  }
+  if (*retry) { w->n_cap_retries++; return MGF_OK; }
+  // keep headroom for the next tick (contact counts drift slowly): grow ahead of need, without a re-run
+  if ((uint64_t)h.need_Mt * 5 > (uint64_t)w->cap_t * 4) w->cap_t = grown(h.need_Mt);
+  if ((uint64_t)h.need_Mp * 5 > (uint64_t)w->cap_p * 4) w->cap_p = grown(h.need_Mp);
+  if ((uint64_t)h.need_C * 5 > (uint64_t)w->cap_c * 4) w->cap_c = grown(h.need_C);
+  w->Mt = h.Mt; w->Mp = h.Mp; w->C = h.C; w->Ct = h.Ct;
+  w->stats.n_terrain_candidates = h.Mt; w->stats.n_pair_candidates = h.Mp;
+  w->stats.n_constraints = h.C; w->stats.n_terrain_constraints = h.Ct;
+  w->constraints_ready = true;
   if (w->opt_debug_bvh) {
-    unsigned long long h[3];
-    MGF_TRY(d2h(ctx, h, w->dbg.p, 3));
-    fprintf(stderr, "[mgf debug_bvh] n=%u levels=%u node fetches/query=%.1f leaf records/query=%.1f max fetches=%llu\n", n, levels,
-            (double)h[0] / n, (double)h[1] / n, h[2]);
+    unsigned long long hd[3];
+    MGF_TRY(d2h(ctx, hd, w->dbg.p, 3));
+    fprintf(stderr, "[mgf debug_bvh] n=%u node fetches/query=%.1f leaf records/query=%.1f max fetches=%llu\n", w->n, (double)hd[0] / w->n,
+            (double)hd[1] / w->n, hd[2]);
   }
   float ms;
   MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[0], w->ev[1])); w->stats.ms_integrate = ms;
   MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[1], w->ev[2])); w->stats.ms_broadphase = ms;
   MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[2], w->ev[3])); w->stats.ms_narrowphase = ms;
   MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[3], w->ev[4])); w->stats.ms_setup = ms;
-  if (stats) *stats = w->stats;
   return MGF_OK;
+}
+
+extern "C" mgf_status mgf_world_collide(mgf_world* w, float dt, mgf_step_stats* stats) {
+  if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
+  MGF_TRY(ctx_bind(w->ctx));
+  w->constraints_ready = false;
+  w->C = w->Ct = w->Mt = w->Mp = 0;
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    bool retry = false;
+    MGF_TRY(collide_enqueue(w, dt));
+    MGF_TRY(collide_finish(w, &retry));
+    if (!retry) { if (stats) *stats = w->stats; return MGF_OK; }
+  }
+  return fail(MGF_ERR_HIP, "internal error: collide phase did not settle its buffer capacities");
 }
 
 extern "C" mgf_status mgf_world_build_constraints(mgf_world* w, float dt, mgf_step_stats* stats) {
@@ -1036,7 +1082,6 @@ extern "C" mgf_status mgf_world_build_constraints(mgf_world* w, float dt, mgf_st
   return mgf_world_collide(w, dt, stats);
 }
 
-// ---- tiling support: boundary selection, ghost export / import (device buffers of the caller) ----
 extern "C" mgf_status mgf_world_select_boundary(mgf_world* w, float x_left, float x_right, uint32_t* ids_left, uint32_t* ids_right,
                                                 int64_t cap, int64_t* n_left, int64_t* n_right) {
   if (!w || !n_left || !n_right) return fail(MGF_ERR_INVALID, "NULL argument");
@@ -1124,19 +1169,57 @@ static mgf_status dump_flow_trace(mgf_world* w, uint32_t C, int32_t iters) {
   return MGF_OK;
 }
 
-// Solver::solve solver.rs:72-78, level-scheduled.
-extern "C" mgf_status mgf_world_solve(mgf_world* w, int32_t iters, mgf_step_stats* stats) {
-  if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
-  if (iters < 0) return fail(MGF_ERR_INVALID, "iters must be >= 0");
-  MGF_TRY(ctx_bind(w->ctx));
-  if (!w->constraints_ready) return fail(MGF_ERR_INVALID, "no constraint list: call mgf_world_build_constraints or mgf_world_set_constraints first");
+// Persistent dataflow launch (modes 1 and 4), enqueue only.  Every lane must be resident, so the grid is sized
+// from the occupancy query with one block per CU of margin (the API over-reports by one for some
+// kernels on ROCm 7.2).  C is read on the device; `cap_c` bounds the grid.
+static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c) {
   mgf_ctx* ctx = w->ctx;
   hipStream_t s = ctx->stream;
-  w->stats.iters = (uint32_t)iters;
-  w->stats.solver_kernel_launches = 0;
-  w->stats.ms_solver_kernels = 0.0f;
+  const bool kslots = w->opt_solver_mode == 4;
+  int& grid = kslots ? w->flowk_grid : w->flow_grid;
+  if (grid == 0) {
+    int per_cu = 0;
+    if (kslots) MGF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_solve_flowk<4, false>, kBlock, 0));
+    else MGF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_solve_flow<false>, kBlock, 0));
+    int want = w->opt_flow_blocks_per_cu > 0 ? (int)w->opt_flow_blocks_per_cu : 4;
+    per_cu = std::max(1, std::min(per_cu - 1, want));
+    grid = per_cu * ctx->num_cus;
+  }
+  const uint32_t* C_ptr = &w->sc.p->C;
+  uint32_t* abort_flag = w->d_err() + 2;
+  unsigned g = std::min<unsigned>((unsigned)grid, std::max(1u, nblk(cap_c)));
+  MGF_TRY(w->flow_arr.ensure(std::max(cap_c, 1u), s));
+  k_flow_init<<<std::max(1u, nblk(cap_c)), kBlock, 0, s>>>(C_ptr, w->cons_nat.p, w->flow_arr.p, abort_flag);
+  LAUNCH_CHECK();
+  const bool timed = w->opt_time_solver_kernels != 0;
+  if (timed) {
+    while (w->kev.size() < 2) { hipEvent_t e; MGF_HIP_TRY(hipEventCreate(&e)); w->kev.push_back(e); }
+    MGF_HIP_TRY(hipEventRecord(w->kev[0], s));
+  }
+  uint64_t* trace = nullptr;
+  if (w->opt_flow_trace) {  // development aid (needs the host-side C: only after a synchronous collide)
+    MGF_TRY(w->flow_trace.ensure(2 * (size_t)iters * std::max(w->C, 1u), s));
+    trace = w->flow_trace.p;
+  }
+  const uint32_t spin_limit = 4u << 20;
+  const int sleep = (int)w->opt_flow_sleep;
+  if (kslots) {
+    if (trace) k_solve_flowk<4, true><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, trace);
+    else k_solve_flowk<4, false><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, nullptr);
+  } else {
+    if (trace) k_solve_flow<true><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, trace);
+    else k_solve_flow<false><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, nullptr);
+  }
+  LAUNCH_CHECK();
+  if (timed) MGF_HIP_TRY(hipEventRecord(w->kev[1], s));
+  return MGF_OK;
+}
+
+// One launch per frontier of the unrolled dependency graph (mode 0): host loop with read-backs.
+static mgf_status solve_frontier(mgf_world* w, int32_t iters) {
+  mgf_ctx* ctx = w->ctx;
+  hipStream_t s = ctx->stream;
   const uint32_t C = w->C;
-  MGF_HIP_TRY(hipEventRecord(w->ev[5], s));
   const bool timed = w->opt_time_solver_kernels != 0;
   size_t kev_used = 0;
   auto tick = [&](void) -> mgf_status {  // event before/after a solver kernel (option)
@@ -1145,179 +1228,133 @@ extern "C" mgf_status mgf_world_solve(mgf_world* w, int32_t iters, mgf_step_stat
     MGF_HIP_TRY(hipEventRecord(w->kev[kev_used++], s));
     return MGF_OK;
   };
-  if (C > 0 && iters > 0 && w->opt_solver_mode == 3) {
-    if (w->flow2_grid == 0) {
-      int per_cu = 0;
-      MGF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_solve_flow3, kBlock, 0));
-      int want = w->opt_flow_blocks_per_cu > 0 ? (int)w->opt_flow_blocks_per_cu : 4;
-      per_cu = std::max(1, std::min(per_cu - 1, want));
-      w->flow2_grid = per_cu * ctx->num_cus;
+  // frontier lists hold every (constraint, round) once: iters * C entries
+  MGF_TRY(w->order.ensure((size_t)iters * C, s));
+  if (w->lvl_cap == 0) { w->lvl_cap = 1u << 16; MGF_TRY(w->lvl_off.ensure(w->lvl_cap + 4, s)); }
+  Frontier F = w->frontier();
+  MGF_HIP_TRY(hipMemsetAsync(w->scalars.p, 0, 12, s));
+  k_frontier0<<<std::min<unsigned>(nblk(C), 1024u), kBlock, 0, s>>>(C, w->cons_nat.p, F);
+  LAUNCH_CHECK();
+  uint32_t r = 0;
+  // grid: frontiers hold roughly C / (per-iteration depth) constraints; grid-stride covers the rest
+  unsigned g0 = std::min<unsigned>(std::max<unsigned>(nblk(C) / 4, 1u), 2048u);
+  uint32_t batch = std::max<uint32_t>(w->last_launches + 2, 8u);
+  uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
+  for (;;) {
+    if (r + batch + 2 > w->lvl_cap) return fail(MGF_ERR_CAPACITY, "constraint dependency graph deeper than 65536 launches");
+    for (uint32_t k = 0; k < batch; ++k) {
+      MGF_TRY(tick());
+      k_solve<<<g0, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, F, r + k, (uint32_t)iters);
+      LAUNCH_CHECK();
+      MGF_TRY(tick());
+      w->stats.solver_kernel_launches++;
     }
-    unsigned g = std::min<unsigned>((unsigned)w->flow2_grid, nblk(C));
-    MGF_TRY(w->svel.ensure(2 * (size_t)w->n, s));
-    MGF_TRY(w->flow_arr.ensure(C, s));
-    k_flow2_init<<<nblk(w->n), kBlock, 0, s>>>(w->n, w->srec.p, w->svel.p, w->d_err() + 2);
-    LAUNCH_CHECK();
-    k_flow_init<<<nblk(C), kBlock, 0, s>>>(C, w->cons_nat.p, w->flow_arr.p, w->d_err() + 2);
-    LAUNCH_CHECK();
-    MGF_TRY(tick());
-    k_solve_flow3<<<g, kBlock, 0, s>>>(w->srec.p, w->svel.p, w->cons_nat.p, w->flow_arr.p, C, (uint32_t)iters, w->d_err() + 2, 4u << 20,
-                                      (int)w->opt_flow_sleep);
-    LAUNCH_CHECK();
-    MGF_TRY(tick());
-    k_flow2_finish<<<nblk(w->n), kBlock, 0, s>>>(w->n, w->svel.p, w->srec.p);
-    LAUNCH_CHECK();
-    w->stats.solver_kernel_launches = 1;
-    uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
-    MGF_HIP_TRY(hipMemcpyAsync(pin, w->d_err() + 2, 4, hipMemcpyDeviceToHost, s));
+    r += batch;
+    // launch r's list was filled by the last launch under counter r % 3; empty means everything ran
+    MGF_HIP_TRY(hipMemcpyAsync(pin, w->d_cnt() + (r % 3), 4, hipMemcpyDeviceToHost, s));
+    MGF_HIP_TRY(hipMemcpyAsync(pin + 1, w->lvl_off.p + r, 4, hipMemcpyDeviceToHost, s));
     MGF_HIP_TRY(hipStreamSynchronize(s));
-    if (pin[0]) return fail(MGF_ERR_HIP, "dataflow solver gave up waiting (grid not fully resident?)");
-    w->depth = 1;
-  } else if (C > 0 && iters > 0 && w->opt_solver_mode == 2) {
-    if (w->flow2_grid == 0) {
-      int per_cu = 0;
-      MGF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_solve_flow2, kBlock, 0));
-      int want = w->opt_flow_blocks_per_cu > 0 ? (int)w->opt_flow_blocks_per_cu : 4;
-      per_cu = std::max(1, std::min(per_cu - 1, want));
-      w->flow2_grid = per_cu * ctx->num_cus;
+    if (pin[0] == 0) {
+      if ((uint64_t)pin[1] != (uint64_t)iters * C) return fail(MGF_ERR_HIP, "internal error: solver schedule does not cover iters x constraints");
+      break;
     }
-    unsigned g = std::min<unsigned>((unsigned)w->flow2_grid, nblk(C));
-    MGF_TRY(w->svel.ensure(2 * (size_t)w->n, s));
-    k_flow2_init<<<nblk(w->n), kBlock, 0, s>>>(w->n, w->srec.p, w->svel.p, w->d_err() + 2);
-    LAUNCH_CHECK();
-    MGF_TRY(tick());
-    k_solve_flow2<<<g, kBlock, 0, s>>>(w->srec.p, w->svel.p, w->cons_nat.p, C, (uint32_t)iters, w->d_err() + 2, 4u << 20, (int)w->opt_flow_sleep);
-    LAUNCH_CHECK();
-    MGF_TRY(tick());
-    k_flow2_finish<<<nblk(w->n), kBlock, 0, s>>>(w->n, w->svel.p, w->srec.p);
-    LAUNCH_CHECK();
-    w->stats.solver_kernel_launches = 1;
-    uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
-    MGF_HIP_TRY(hipMemcpyAsync(pin, w->d_err() + 2, 4, hipMemcpyDeviceToHost, s));
-    MGF_HIP_TRY(hipStreamSynchronize(s));
-    if (pin[0]) return fail(MGF_ERR_HIP, "dataflow solver gave up waiting (grid not fully resident?)");
-    w->depth = 1;
-  } else if (C > 0 && iters > 0 && w->opt_solver_mode == 4) {
-    if (w->flowk_grid == 0) {
-      int per_cu = 0;
-      MGF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_solve_flowk<4, false>, kBlock, 0));
-      int want = w->opt_flow_blocks_per_cu > 0 ? (int)w->opt_flow_blocks_per_cu : 4;
-      per_cu = std::max(1, std::min(per_cu - 1, want));
-      w->flowk_grid = per_cu * ctx->num_cus;
-    }
-    unsigned g = std::min<unsigned>((unsigned)w->flowk_grid, nblk(C));
-    MGF_TRY(w->flow_arr.ensure(C, s));
-    k_flow_init<<<nblk(C), kBlock, 0, s>>>(C, w->cons_nat.p, w->flow_arr.p, w->d_err() + 2);
-    LAUNCH_CHECK();
-    MGF_TRY(tick());
-    if (w->opt_flow_trace) {
-      MGF_TRY(w->flow_trace.ensure(2 * (size_t)iters * C, s));
-      k_solve_flowk<4, true><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C, (uint32_t)iters, w->d_err() + 2, 4u << 20,
-                                                 (int)w->opt_flow_sleep, w->flow_trace.p);
-      MGF_TRY(dump_flow_trace(w, C, iters));
-    } else {
-      k_solve_flowk<4, false><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C, (uint32_t)iters, w->d_err() + 2, 4u << 20,
-                                                  (int)w->opt_flow_sleep, nullptr);
-    }
-    LAUNCH_CHECK();
-    MGF_TRY(tick());
-    w->stats.solver_kernel_launches = 1;
-    uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
-    MGF_HIP_TRY(hipMemcpyAsync(pin, w->d_err() + 2, 4, hipMemcpyDeviceToHost, s));
-    MGF_HIP_TRY(hipStreamSynchronize(s));
-    if (pin[0]) return fail(MGF_ERR_HIP, "dataflow solver gave up waiting (grid not fully resident?)");
-    w->depth = 1;
-  } else if (C > 0 && iters > 0 && w->opt_solver_mode == 1) {
-    // persistent dataflow launch: every lane must be resident, so the grid is sized from the occupancy
-    // query with one block per CU of margin (the API over-reports by one for some kernels on ROCm 7.2)
-    if (w->flow_grid == 0) {
-      int per_cu = 0;
-      MGF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_solve_flow<false>, kBlock, 0));
-      int want = w->opt_flow_blocks_per_cu > 0 ? (int)w->opt_flow_blocks_per_cu : 4;
-      per_cu = std::max(1, std::min(per_cu - 1, want));
-      w->flow_grid = per_cu * ctx->num_cus;
-    }
-    unsigned g = std::min<unsigned>((unsigned)w->flow_grid, nblk(C));
-    MGF_TRY(w->flow_arr.ensure(C, s));
-    k_flow_init<<<nblk(C), kBlock, 0, s>>>(C, w->cons_nat.p, w->flow_arr.p, w->d_err() + 2);
-    LAUNCH_CHECK();
-    MGF_TRY(tick());
-    if (w->opt_flow_trace) {  // development aid: per-node (ready seen, released) timestamps -> /tmp/mgf_flow_trace.bin
-      MGF_TRY(w->flow_trace.ensure(2 * (size_t)iters * C, s));
-      k_solve_flow<true><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C, (uint32_t)iters, w->d_err() + 2, 4u << 20,
-                                             (int)w->opt_flow_sleep, w->flow_trace.p);
-      MGF_TRY(dump_flow_trace(w, C, iters));
-    } else {
-      k_solve_flow<false><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C, (uint32_t)iters, w->d_err() + 2, 4u << 20,
-                                              (int)w->opt_flow_sleep, nullptr);
-    }
-    LAUNCH_CHECK();
-    MGF_TRY(tick());
-    w->stats.solver_kernel_launches = 1;
-    uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
-    MGF_HIP_TRY(hipMemcpyAsync(pin, w->d_err() + 2, 4, hipMemcpyDeviceToHost, s));
-    MGF_HIP_TRY(hipStreamSynchronize(s));
-    if (pin[0]) return fail(MGF_ERR_HIP, "dataflow solver gave up waiting (grid not fully resident?)");
-    w->depth = 1;
-  } else if (C > 0 && iters > 0) {
-    // frontier lists hold every (constraint, round) once: iters * C entries
-    MGF_TRY(w->order.ensure((size_t)iters * C, s));
-    if (w->lvl_cap == 0) { w->lvl_cap = 1u << 16; MGF_TRY(w->lvl_off.ensure(w->lvl_cap + 4, s)); }
-    Frontier F = w->frontier();
-    MGF_HIP_TRY(hipMemsetAsync(w->scalars.p, 0, 12, s));
-    k_frontier0<<<std::min<unsigned>(nblk(C), 1024u), kBlock, 0, s>>>(C, w->cons_nat.p, F);
-    LAUNCH_CHECK();
-    uint32_t r = 0;
-    // grid: frontiers hold roughly C / (per-iteration depth) constraints; grid-stride covers the rest
-    unsigned g0 = std::min<unsigned>(std::max<unsigned>(nblk(C) / 4, 1u), 2048u);
-    uint32_t batch = std::max<uint32_t>(w->last_launches + 2, 8u);
-    uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
-    for (;;) {
-      if (r + batch + 2 > w->lvl_cap) return fail(MGF_ERR_CAPACITY, "constraint dependency graph deeper than 65536 launches");
-      for (uint32_t k = 0; k < batch; ++k) {
-        MGF_TRY(tick());
-        k_solve<<<g0, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, F, r + k, (uint32_t)iters);
-        LAUNCH_CHECK();
-        MGF_TRY(tick());
-        w->stats.solver_kernel_launches++;
-      }
-      r += batch;
-      // launch r's list was filled by the last launch under counter r % 3; empty means everything ran
-      MGF_HIP_TRY(hipMemcpyAsync(pin, w->d_cnt() + (r % 3), 4, hipMemcpyDeviceToHost, s));
-      MGF_HIP_TRY(hipMemcpyAsync(pin + 1, w->lvl_off.p + r, 4, hipMemcpyDeviceToHost, s));
-      MGF_HIP_TRY(hipStreamSynchronize(s));
-      if (pin[0] == 0) {
-        if ((uint64_t)pin[1] != (uint64_t)iters * C) return fail(MGF_ERR_HIP, "internal error: solver schedule does not cover iters x constraints");
-        break;
-      }
-      batch = 4;
-    }
-    // number of non-empty launches (for stats and for sizing the next tick's batch)
-    std::vector<uint32_t> h(r + 1);
-    MGF_TRY(d2h(ctx, h.data(), w->lvl_off.p, r + 1));
-    uint32_t used = 0;
-    while (used < r && h[used] < (uint64_t)iters * C) ++used;
-    w->depth = used;
-    w->last_launches = used;
+    batch = 4;
   }
-  MGF_HIP_TRY(hipEventRecord(w->ev[6], s));
+  // number of non-empty launches (for stats and for sizing the next tick's batch)
+  std::vector<uint32_t> h(r + 1);
+  MGF_TRY(d2h(ctx, h.data(), w->lvl_off.p, r + 1));
+  uint32_t used = 0;
+  while (used < r && h[used] < (uint64_t)iters * C) ++used;
+  w->depth = used;
+  w->last_launches = used;
+  if (timed) {
+    float total = 0.0f, ms;
+    for (size_t k = 0; k + 1 < kev_used; k += 2) { MGF_HIP_TRY(hipEventElapsedTime(&ms, w->kev[k], w->kev[k + 1])); total += ms; }
+    w->stats.ms_solver_kernels = total;
+  }
+  return MGF_OK;
+}
+
+// After a dataflow launch has been synchronised: abort flag, timings.
+static mgf_status solve_flow_finish(mgf_world* w) {
+  uint32_t* pin = static_cast<uint32_t*>(w->ctx->pinned);
+  MGF_HIP_TRY(hipMemcpyAsync(pin + 80, w->d_err() + 2, 4, hipMemcpyDeviceToHost, w->ctx->stream));
+  MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
+  if (pin[80]) return fail(MGF_ERR_HIP, "dataflow solver gave up waiting (grid not fully resident?)");
+  w->stats.solver_kernel_launches = 1;
+  w->depth = 1;
+  if (w->opt_time_solver_kernels) {
+    float ms;
+    MGF_HIP_TRY(hipEventElapsedTime(&ms, w->kev[0], w->kev[1]));
+    w->stats.ms_solver_kernels = ms;
+  }
+  return MGF_OK;
+}
+
+// Solver::solve solver.rs:72-78 (exact sequential order, see kernels.h).
+extern "C" mgf_status mgf_world_solve(mgf_world* w, int32_t iters, mgf_step_stats* stats) {
+  if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
+  if (iters < 0) return fail(MGF_ERR_INVALID, "iters must be >= 0");
+  MGF_TRY(ctx_bind(w->ctx));
+  if (!w->constraints_ready) return fail(MGF_ERR_INVALID, "no constraint list: call mgf_world_build_constraints or mgf_world_set_constraints first");
+  hipStream_t s = w->ctx->stream;
+  w->stats.iters = (uint32_t)iters;
+  w->stats.solver_kernel_launches = 0;
+  w->stats.ms_solver_kernels = 0.0f;
+  w->depth = 0;
+  MGF_HIP_TRY(hipEventRecord(w->ev[5], s));
+  if (w->C > 0 && iters > 0) {
+    if (w->opt_solver_mode == 0) {
+      MGF_TRY(solve_frontier(w, iters));
+    } else {
+      MGF_TRY(solve_flow_enqueue(w, iters, w->C));
+      if (w->opt_flow_trace) MGF_TRY(dump_flow_trace(w, w->C, iters));
+      MGF_HIP_TRY(hipEventRecord(w->ev[6], s));
+      MGF_TRY(solve_flow_finish(w));
+    }
+  }
+  if (w->opt_solver_mode == 0 || !(w->C > 0 && iters > 0)) MGF_HIP_TRY(hipEventRecord(w->ev[6], s));
   MGF_HIP_TRY(hipStreamSynchronize(s));
   float ms;
   MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[5], w->ev[6]));
   w->stats.ms_solve = ms;
   w->stats.n_levels = w->depth;
-  if (timed) {
-    float total = 0.0f;
-    for (size_t k = 0; k + 1 < kev_used; k += 2) { MGF_HIP_TRY(hipEventElapsedTime(&ms, w->kev[k], w->kev[k + 1])); total += ms; }
-    w->stats.ms_solver_kernels = total;
-  }
   if (stats) *stats = w->stats;
   return MGF_OK;
 }
 
+// World::step world.rs:227-294.  With a dataflow solver the whole tick is enqueued without a read-back
+// and synchronised once at the end; a capacity miss re-runs the collide phase (the solver was a no-op).
 extern "C" mgf_status mgf_world_step(mgf_world* w, float dt, int32_t iters, mgf_step_stats* stats) {
-  MGF_TRY(mgf_world_build_constraints(w, dt, nullptr));
-  MGF_TRY(mgf_world_solve(w, iters, nullptr));
+  if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
+  if (iters < 0) return fail(MGF_ERR_INVALID, "iters must be >= 0");
+  if (w->opt_solver_mode == 0 || w->opt_flow_trace || w->opt_debug_bvh) {
+    MGF_TRY(mgf_world_build_constraints(w, dt, nullptr));
+    MGF_TRY(mgf_world_solve(w, iters, nullptr));
+  } else {
+    MGF_TRY(world_begin(w, dt));
+    hipStream_t s = w->ctx->stream;
+    bool done = false;
+    for (int attempt = 0; attempt < 8 && !done; ++attempt) {
+      bool retry = false;
+      MGF_TRY(collide_enqueue(w, dt));
+      MGF_HIP_TRY(hipEventRecord(w->ev[5], s));
+      if (w->n > 0 && iters > 0) MGF_TRY(solve_flow_enqueue(w, iters, w->cap_c));
+      MGF_HIP_TRY(hipEventRecord(w->ev[6], s));
+      MGF_TRY(collide_finish(w, &retry));
+      done = !retry;
+    }
+    if (!done) return fail(MGF_ERR_HIP, "internal error: collide phase did not settle its buffer capacities");
+    w->stats.iters = (uint32_t)iters;
+    w->stats.solver_kernel_launches = 0;
+    w->stats.ms_solver_kernels = 0.0f;
+    w->depth = 0;
+    if (w->C > 0 && iters > 0) MGF_TRY(solve_flow_finish(w));
+    float ms;
+    MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[5], w->ev[6]));
+    w->stats.ms_solve = ms;
+    w->stats.n_levels = w->depth;
+  }
   float ms;
   MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[0], w->ev[6]));
   w->stats.ms_total = ms;
@@ -1374,7 +1411,12 @@ extern "C" mgf_status mgf_world_set_constraints(mgf_world* w, const mgf_constrai
   MGF_TRY(h2d(w->ctx, w->cons_nat.p, h.data(), (size_t)n));
   memset(&w->stats, 0, sizeof(w->stats));
   w->stats.n_bodies = w->n; w->stats.n_constraints = w->C;
-  MGF_TRY(build_dag(w));
+  StepCounts hc;
+  memset(&hc, 0, sizeof(hc));
+  hc.C = hc.need_C = w->C;
+  MGF_TRY(h2d(w->ctx, w->sc.p, &hc, 1));
+  MGF_TRY(build_dag(w, w->C));
+  w->constraints_ready = true;
   MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
   return MGF_OK;
 }
