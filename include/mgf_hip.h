@@ -111,6 +111,9 @@ typedef struct mgf_world mgf_world;
 /* ---- context ---------------------------------------------------------------------- */
 MGF_API mgf_status mgf_ctx_create(int device, mgf_ctx** out);
 MGF_API void mgf_ctx_destroy(mgf_ctx* ctx);
+/* Enqueue all work of this context on a caller-owned hipStream_t (e.g. the stream the caller's RCCL
+ * transfers are ordered on) instead of the context's own stream.  The caller keeps ownership. */
+MGF_API mgf_status mgf_ctx_set_stream(mgf_ctx* ctx, void* hip_stream);
 MGF_API const char* mgf_last_error(void);        /* thread-local message for the last non-OK status */
 MGF_API mgf_params mgf_default_params(void);     /* DefaultContactConstraintParams / DefaultPruningParams */
 MGF_API const char* mgf_version(void);
@@ -221,7 +224,16 @@ MGF_API mgf_status mgf_world_import_ghosts(mgf_world* w, const float* src, int64
 MGF_API mgf_status mgf_world_export_velocities(mgf_world* w, const uint32_t* ids, int64_t n, float* dst);
 MGF_API mgf_status mgf_world_import_ghost_velocities(mgf_world* w, const float* src, int64_t n_ghost);
 MGF_API int64_t mgf_world_ghost_len(const mgf_world* w);
-/* Option: 1 = time every solver kernel with HIP events (bench roofline leg); default 0. */
+/* Stream-ordered variant of the loop above, for a driver that issues its RCCL transfers on the context's
+ * stream (mgf_ctx_set_stream): with option "stream_ordered" = 1 begin_tick / select_boundary's scatter /
+ * export_* / import_* only enqueue; mgf_world_solve_enqueue is Solver::solve without the read-back, and
+ * mgf_world_finish synchronises once and reports the outcome (status, timings) of everything enqueued. */
+MGF_API mgf_status mgf_world_solve_enqueue(mgf_world* w, int32_t iters);
+MGF_API mgf_status mgf_world_finish(mgf_world* w, mgf_step_stats* stats);
+/* Options (development and test knobs; defaults in brackets): "time_solver_kernels" [0] HIP events around the
+ * solver kernels; "solver_mode" [1] 1 = persistent dataflow launch, 0 = one launch per dependency frontier,
+ * 4 = dataflow with out-of-order slots; "two_pass_candidates" [0]; "stream_ordered" [0]; "list_capacity";
+ * "flow_blocks_per_cu"; "flow_sleep"; "flow_trace"; "debug_bvh". */
 MGF_API mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_t value);
 /* Raw device pointers of resident state for zero-copy exchange (multi-GPU halo): name in
  * {"x","q","solver_rec","delta"}; pointer valid until the next add_bodies. */

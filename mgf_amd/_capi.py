@@ -103,7 +103,7 @@ assert CONSTRAINT_DTYPE.itemsize == 96
 
 # every symbol include/mgf_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "mgf_ctx_create", "mgf_ctx_destroy", "mgf_last_error", "mgf_default_params", "mgf_version",
+    "mgf_ctx_create", "mgf_ctx_destroy", "mgf_ctx_set_stream", "mgf_last_error", "mgf_default_params", "mgf_version",
     "mgf_contacts", "mgf_contacts_batch", "mgf_local_contacts_pair", "mgf_ray_capsule", "mgf_inertia_tensor",
     "mgf_mesh_new", "mgf_mesh_free", "mgf_mesh_push_vert", "mgf_mesh_push_face", "mgf_mesh_set_pos", "mgf_mesh_build",
     "mgf_local_contacts_mesh",
@@ -116,6 +116,7 @@ SYMBOLS = [
     "mgf_world_device_ptr",
     "mgf_world_begin_tick", "mgf_world_collide", "mgf_world_select_boundary", "mgf_world_export_bodies",
     "mgf_world_import_ghosts", "mgf_world_export_velocities", "mgf_world_import_ghost_velocities", "mgf_world_ghost_len",
+    "mgf_world_solve_enqueue", "mgf_world_finish",
 ]
 
 _lib = None
@@ -136,6 +137,7 @@ def load_library():
     sig = {
         "mgf_ctx_create": (i32, [C.c_int, P(vp)]),
         "mgf_ctx_destroy": (None, [vp]),
+        "mgf_ctx_set_stream": (i32, [vp, vp]),
         "mgf_last_error": (C.c_char_p, []),
         "mgf_default_params": (Params, []),
         "mgf_version": (C.c_char_p, []),
@@ -192,6 +194,8 @@ def load_library():
         "mgf_world_export_velocities": (i32, [vp, vp, i64, vp]),
         "mgf_world_import_ghost_velocities": (i32, [vp, vp, i64]),
         "mgf_world_ghost_len": (i64, [vp]),
+        "mgf_world_solve_enqueue": (i32, [vp, i32]),
+        "mgf_world_finish": (i32, [vp, P(StepStats)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -231,6 +235,10 @@ class Context:
 
     def _adopt(self, obj):
         self._children.add(obj)
+
+    def set_stream(self, hip_stream):
+        """Enqueue this context's work on a caller-owned hipStream_t (an int handle, e.g. torch's cuda_stream)."""
+        _check(load_library().mgf_ctx_set_stream(self._h, C.c_void_p(int(hip_stream))))
 
     def close(self):
         """Destroy the context; handles created from it are released first (they must not outlive it)."""
@@ -605,6 +613,13 @@ class World:
 
     def ghost_len(self):
         return load_library().mgf_world_ghost_len(self._h)
+
+    def solve_enqueue(self, iters):
+        _check(load_library().mgf_world_solve_enqueue(self._h, int(iters)))
+
+    def finish(self):
+        _check(load_library().mgf_world_finish(self._h, C.byref(self.stats)))
+        return self.stats
 
     def set_option(self, key, value):
         _check(load_library().mgf_world_set_option(self._h, key.encode(), int(value)))

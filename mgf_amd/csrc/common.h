@@ -35,6 +35,7 @@ void set_error(const char* fmt, ...);  // thread-local message behind mgf_last_e
 struct mgf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool own_stream = true;    // false after mgf_ctx_set_stream: the caller's stream
   void* prim_tmp = nullptr;  // rocPRIM temporary storage
   size_t prim_tmp_bytes = 0;
   void* pinned = nullptr;    // small pinned staging area for read-backs

@@ -65,10 +65,21 @@ extern "C" mgf_status mgf_ctx_create(int device, mgf_ctx** out) {
   *out = c.release();
   return MGF_OK;
 }
+extern "C" mgf_status mgf_ctx_set_stream(mgf_ctx* ctx, void* stream) {
+  if (!ctx) return fail(MGF_ERR_INVALID, "ctx is NULL");
+  MGF_HIP_TRY(hipSetDevice(ctx->device));
+  MGF_HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  ctx->stream = static_cast<hipStream_t>(stream);
+  ctx->own_stream = false;
+  return MGF_OK;
+}
 extern "C" void mgf_ctx_destroy(mgf_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  ctx->stream = nullptr;
   if (ctx->prim_tmp) (void)hipFree(ctx->prim_tmp);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   delete ctx;
@@ -517,6 +528,8 @@ struct mgf_world {
   int64_t opt_flow_blocks_per_cu = 0, opt_flow_sleep = 2;
   int flowk_grid = 0;
   int64_t opt_debug_bvh = 0, opt_flow_trace = 0;
+  int64_t opt_stream_ordered = 0;  // 1: the tiling calls (begin_tick, export_*, import_*) do not synchronise the ctx stream
+  bool solve_pending = false;      // a dataflow launch was enqueued by mgf_world_solve_enqueue and not yet checked
   DBuf<unsigned long long> dbg;
   int64_t opt_two_pass = 0;  // 1 = always use the exact two-pass candidate path (tests the overflow fallback)
   uint64_t n_row_overflows = 0;
@@ -535,6 +548,7 @@ struct mgf_world {
   int64_t opt_time_solver_kernels = 0;
   hipEvent_t ev[8] = {};
   std::vector<hipEvent_t> kev;  // per-launch events (option)
+  size_t kev_used = 0;
   mgf_step_stats stats;
 
   Bodies bodies() {
@@ -583,6 +597,7 @@ extern "C" mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_
   if (!strcmp(key, "solver_mode")) { w->opt_solver_mode = value; return MGF_OK; }
   if (!strcmp(key, "flow_blocks_per_cu")) { w->opt_flow_blocks_per_cu = value; w->flow_grid = 0; w->flowk_grid = 0; return MGF_OK; }
   if (!strcmp(key, "flow_sleep")) { w->opt_flow_sleep = value; return MGF_OK; }
+  if (!strcmp(key, "stream_ordered")) { w->opt_stream_ordered = value; return MGF_OK; }
   if (!strcmp(key, "list_capacity")) {  // tests: force the speculative list capacities (the next tick must re-run its collide phase)
     if (value < 1 || value > 0x7FFFFFF0ll) return fail(MGF_ERR_INVALID, "list_capacity out of range");
     w->cap_t = w->cap_p = w->cap_c = (uint32_t)value;
@@ -787,6 +802,14 @@ extern "C" mgf_status mgf_world_device_ptr(mgf_world* w, const char* name, void*
   return fail(MGF_ERR_INVALID, "unknown array name");
 }
 
+// The tiling entry points are synchronous by default (the caller may touch its buffers as soon as the call
+// returns); with option stream_ordered = 1 they only enqueue on the ctx stream - for a caller that issues its
+// own work (copies, RCCL) on that same stream (mgf_ctx_set_stream).
+static mgf_status sync_unless_ordered(mgf_world* w) {
+  if (!w->opt_stream_ordered) MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
+  return MGF_OK;
+}
+
 // ---- the tick ----------------------------------------------------------------------------------
 static mgf_status world_integrate(mgf_world* w, float dt, bool complete, bool integrate, bool with_bounds) {
   mgf_ctx* ctx = w->ctx;
@@ -879,8 +902,7 @@ static mgf_status world_begin(mgf_world* w, float dt) {
 }
 extern "C" mgf_status mgf_world_begin_tick(mgf_world* w, float dt) {
   MGF_TRY(world_begin(w, dt));
-  MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
-  return MGF_OK;
+  return sync_unless_ordered(w);
 }
 
 // Second half: broadphase, narrowphase, ContactConstraint::new over owned + ghost bodies.  Enqueue only:
@@ -1105,15 +1127,13 @@ extern "C" mgf_status mgf_world_select_boundary(mgf_world* w, float x_left, floa
   if (!ids_left || !ids_right) return fail(MGF_ERR_INVALID, "NULL id buffer");
   k_boundary_scatter<<<nblk(n), kBlock, 0, s>>>(n, w->bflag_l.p, w->bscan_l.p, w->bflag_r.p, w->bscan_r.p, ids_left, ids_right);
   LAUNCH_CHECK();
-  MGF_HIP_TRY(hipStreamSynchronize(s));
-  return MGF_OK;
+  return sync_unless_ordered(w);
 }
 extern "C" mgf_status mgf_world_export_bodies(mgf_world* w, const uint32_t* ids, int64_t n, float* dst) {
   if (!w || (n && (!ids || !dst))) return fail(MGF_ERR_INVALID, "NULL argument");
   MGF_TRY(ctx_bind(w->ctx));
   if (n > 0) { k_export_bodies<<<nblk(n), kBlock, 0, w->ctx->stream>>>(w->bodies(), ids, (uint32_t)n, dst); LAUNCH_CHECK(); }
-  MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
-  return MGF_OK;
+  return sync_unless_ordered(w);
 }
 template <class T>
 static mgf_status grow_keep(mgf_world* w, DBuf<T>& b, size_t per, size_t need) {
@@ -1135,15 +1155,13 @@ extern "C" mgf_status mgf_world_import_ghosts(mgf_world* w, const float* src, in
   }
   w->n = (uint32_t)need;
   w->constraints_ready = false;
-  MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
-  return MGF_OK;
+  return sync_unless_ordered(w);
 }
 extern "C" mgf_status mgf_world_export_velocities(mgf_world* w, const uint32_t* ids, int64_t n, float* dst) {
   if (!w || (n && (!ids || !dst))) return fail(MGF_ERR_INVALID, "NULL argument");
   MGF_TRY(ctx_bind(w->ctx));
   if (n > 0) { k_export_vel<<<nblk(n), kBlock, 0, w->ctx->stream>>>(w->srec.p, ids, (uint32_t)n, reinterpret_cast<float4*>(dst)); LAUNCH_CHECK(); }
-  MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
-  return MGF_OK;
+  return sync_unless_ordered(w);
 }
 extern "C" mgf_status mgf_world_import_ghost_velocities(mgf_world* w, const float* src, int64_t n_ghost) {
   if (!w || (n_ghost && !src)) return fail(MGF_ERR_INVALID, "NULL argument");
@@ -1153,8 +1171,7 @@ extern "C" mgf_status mgf_world_import_ghost_velocities(mgf_world* w, const floa
     k_import_ghost_vel<<<nblk(n_ghost), kBlock, 0, w->ctx->stream>>>(w->srec.p, w->n_owned, (uint32_t)n_ghost, reinterpret_cast<const float4*>(src));
     LAUNCH_CHECK();
   }
-  MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
-  return MGF_OK;
+  return sync_unless_ordered(w);
 }
 extern "C" int64_t mgf_world_ghost_len(const mgf_world* w) { return w ? (int64_t)(w->n - w->n_owned) : 0; }
 
@@ -1192,9 +1209,10 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
   k_flow_init<<<std::max(1u, nblk(cap_c)), kBlock, 0, s>>>(C_ptr, w->cons_nat.p, w->flow_arr.p, abort_flag);
   LAUNCH_CHECK();
   const bool timed = w->opt_time_solver_kernels != 0;
+  if (!w->solve_pending) w->kev_used = 0;  // a tiled tick enqueues several launches before it reads the events
   if (timed) {
-    while (w->kev.size() < 2) { hipEvent_t e; MGF_HIP_TRY(hipEventCreate(&e)); w->kev.push_back(e); }
-    MGF_HIP_TRY(hipEventRecord(w->kev[0], s));
+    while (w->kev.size() < w->kev_used + 2) { hipEvent_t e; MGF_HIP_TRY(hipEventCreate(&e)); w->kev.push_back(e); }
+    MGF_HIP_TRY(hipEventRecord(w->kev[w->kev_used], s));
   }
   uint64_t* trace = nullptr;
   if (w->opt_flow_trace) {  // development aid (needs the host-side C: only after a synchronous collide)
@@ -1211,7 +1229,7 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
     else k_solve_flow<false><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, nullptr);
   }
   LAUNCH_CHECK();
-  if (timed) MGF_HIP_TRY(hipEventRecord(w->kev[1], s));
+  if (timed) { MGF_HIP_TRY(hipEventRecord(w->kev[w->kev_used + 1], s)); w->kev_used += 2; }
   return MGF_OK;
 }
 
@@ -1284,9 +1302,9 @@ static mgf_status solve_flow_finish(mgf_world* w) {
   w->stats.solver_kernel_launches = 1;
   w->depth = 1;
   if (w->opt_time_solver_kernels) {
-    float ms;
-    MGF_HIP_TRY(hipEventElapsedTime(&ms, w->kev[0], w->kev[1]));
-    w->stats.ms_solver_kernels = ms;
+    float ms, total = 0.0f;
+    for (size_t k = 0; k + 1 < w->kev_used; k += 2) { MGF_HIP_TRY(hipEventElapsedTime(&ms, w->kev[k], w->kev[k + 1])); total += ms; }
+    w->stats.ms_solver_kernels = total;
   }
   return MGF_OK;
 }
@@ -1319,6 +1337,53 @@ extern "C" mgf_status mgf_world_solve(mgf_world* w, int32_t iters, mgf_step_stat
   MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[5], w->ev[6]));
   w->stats.ms_solve = ms;
   w->stats.n_levels = w->depth;
+  if (stats) *stats = w->stats;
+  return MGF_OK;
+}
+
+// Solver::solve without the read-back: the launch is enqueued on the ctx stream and its outcome is checked by
+// the next mgf_world_finish (a tiled driver interleaves single iterations with ghost velocity exchanges
+// on the same stream).  Solver mode 0 has a host loop and runs synchronously here.
+extern "C" mgf_status mgf_world_solve_enqueue(mgf_world* w, int32_t iters) {
+  if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
+  if (iters < 0) return fail(MGF_ERR_INVALID, "iters must be >= 0");
+  if (w->opt_solver_mode == 0 || w->opt_flow_trace) return mgf_world_solve(w, iters, nullptr);
+  MGF_TRY(ctx_bind(w->ctx));
+  if (!w->constraints_ready) return fail(MGF_ERR_INVALID, "no constraint list: call mgf_world_build_constraints or mgf_world_set_constraints first");
+  if (!w->solve_pending) {
+    MGF_HIP_TRY(hipEventRecord(w->ev[5], w->ctx->stream));
+    w->stats.iters = 0;
+    w->stats.solver_kernel_launches = 0;
+    w->stats.ms_solver_kernels = 0.0f;
+  }
+  if (w->C > 0 && iters > 0) {
+    MGF_TRY(solve_flow_enqueue(w, iters, w->C));
+    w->stats.solver_kernel_launches++;
+  }
+  w->stats.iters += (uint32_t)iters;
+  w->solve_pending = true;
+  return MGF_OK;
+}
+// Synchronise the ctx stream and report what the enqueued work did (solver abort flag, timings).
+extern "C" mgf_status mgf_world_finish(mgf_world* w, mgf_step_stats* stats) {
+  if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
+  MGF_TRY(ctx_bind(w->ctx));
+  hipStream_t s = w->ctx->stream;
+  if (w->solve_pending) {
+    w->solve_pending = false;
+    MGF_HIP_TRY(hipEventRecord(w->ev[6], s));
+    uint32_t launches = w->stats.solver_kernel_launches;
+    if (launches) MGF_TRY(solve_flow_finish(w)); else MGF_HIP_TRY(hipStreamSynchronize(s));
+    w->stats.solver_kernel_launches = launches;
+    float ms;
+    MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[5], w->ev[6]));
+    w->stats.ms_solve = ms;
+    w->stats.n_levels = launches;
+    MGF_HIP_TRY(hipEventElapsedTime(&ms, w->ev[0], w->ev[6]));
+    w->stats.ms_total = ms;
+  } else {
+    MGF_HIP_TRY(hipStreamSynchronize(s));
+  }
   if (stats) *stats = w->stats;
   return MGF_OK;
 }

@@ -7,6 +7,7 @@ data path).  The tick on every tile:
     <-> neighbours                  body records (36 floats each)
     import_ghosts, collide          broadphase / narrowphase / ContactConstraint::new on owned + ghost
     iters x { solve(1); <-> neighbours: velocities of the exported bodies (8 floats each) }
+    finish                          the one place the host waits for the solver (status, timings)
 
 Semantics (what the oracle's tile mode reproduces exactly): Gauss-Seidel inside a tile, ghost
 velocities refreshed from their owner after every solver iteration (block-Jacobi across tiles);
@@ -27,63 +28,77 @@ VEL_FLOATS = 8
 
 
 class HipEngine:
-    """One tile on one GPU.  Exchange buffers are torch CUDA tensors; the C-ABI gets raw pointers."""
+    """One tile on one GPU.  Exchange buffers are torch CUDA tensors; the C-ABI gets raw pointers.
+
+    Everything - the C-ABI's kernels, torch's copies, and the RCCL transfers torch.distributed orders against
+    the current stream - is issued on ONE torch stream (mgf_ctx_set_stream + option stream_ordered), so a tick
+    needs no host synchronisation between its exchange steps: the host only waits where it needs a number
+    (boundary counts, the collide phase's list sizes) and once at the end (finish)."""
 
     def __init__(self, ctx, scene, device):
         import torch
         from ._capi import World
         self.torch = torch
         self.device = torch.device("cuda", device)
+        # one stream per context: tiles that share a context (in-process emulation) share its stream
+        if getattr(ctx, "torch_stream", None) is None:
+            ctx.torch_stream = torch.cuda.Stream(device=self.device)
+            ctx.set_stream(ctx.torch_stream.cuda_stream)
+        self.stream = ctx.torch_stream
         self.world = World.from_scene(ctx, scene)
-        n = len(self.world)
-        self.ids = [torch.zeros(max(n, 1), dtype=torch.int32, device=self.device) for _ in range(2)]
-        self.counts = [0, 0]
+        self.world.set_option("stream_ordered", 1)
+        n = max(len(self.world), 1)
+        self.n_cap = n
+        with torch.cuda.stream(self.stream):
+            self.ids = torch.zeros(2 * n, dtype=torch.int32, device=self.device)  # [0:n] left face, [n:2n] right face
+        self.counts = (0, 0)
+
+    def stream_ctx(self):
+        return self.torch.cuda.stream(self.stream)
+
+    def alloc(self, rows, width):
+        return self.torch.empty((rows, width), dtype=self.torch.float32, device=self.device)
 
     def begin_tick(self, dt):
         self.world.begin_tick(dt)
 
     def select_boundary(self, x_left, x_right):
-        n = len(self.world)
-        self.counts = list(self.world.select_boundary(x_left, x_right, self.ids[0].data_ptr(), self.ids[1].data_ptr(), max(n, 1)))
-        return tuple(self.counts)
+        p = self.ids.data_ptr()
+        self.counts = tuple(self.world.select_boundary(x_left, x_right, p, p + 4 * self.n_cap, self.n_cap))
+        return self.counts
 
-    def export_bodies(self, side):
-        m = self.counts[side]
-        out = self.torch.empty((m, GHOST_FLOATS), dtype=self.torch.float32, device=self.device)
-        self.world.export_bodies(self.ids[side].data_ptr(), m, out.data_ptr())
+    def _export(self, fn, width):
+        ml, mr = self.counts
+        out = self.alloc(ml + mr, width)
+        p = self.ids.data_ptr()
+        if ml:
+            fn(p, ml, out.data_ptr())
+        if mr:
+            fn(p + 4 * self.n_cap, mr, out.data_ptr() + 4 * width * ml)
         return out
 
-    def _sync_torch(self):
-        # torch (cat, RCCL recv) runs on torch's stream, the C-ABI on its own: make the buffers final first
-        self.torch.cuda.current_stream(self.device).synchronize()
+    def export_bodies(self):
+        return self._export(self.world.export_bodies, GHOST_FLOATS)
 
     def import_ghosts(self, recs):
-        recs = recs.contiguous()
-        self._sync_torch()
+        self._keep = recs  # the kernel reads it asynchronously (same stream: safe against reuse, keep it anyway)
         self.world.import_ghosts(recs.data_ptr(), recs.shape[0])
 
     def collide(self, dt):
         return self.world.collide(dt).as_dict()
 
-    def solve(self, iters):
-        return self.world.solve(iters).as_dict()
+    def solve_iteration(self):
+        self.world.solve_enqueue(1)
 
-    def export_velocities(self, side):
-        m = self.counts[side]
-        out = self.torch.empty((m, VEL_FLOATS), dtype=self.torch.float32, device=self.device)
-        self.world.export_velocities(self.ids[side].data_ptr(), m, out.data_ptr())
-        return out
+    def export_velocities(self):
+        return self._export(self.world.export_velocities, VEL_FLOATS)
 
     def import_ghost_velocities(self, vel):
-        vel = vel.contiguous()
-        self._sync_torch()
+        self._keep_v = vel
         self.world.import_ghost_velocities(vel.data_ptr(), vel.shape[0])
 
-    def empty(self, width):
-        return self.torch.empty((0, width), dtype=self.torch.float32, device=self.device)
-
-    def cat(self, parts):
-        return self.torch.cat(parts, dim=0)
+    def finish(self):
+        return self.world.finish().as_dict()
 
     def state(self):
         return self.world.state()
@@ -92,61 +107,61 @@ class HipEngine:
 class DistTransport:
     """Neighbour exchange over torch.distributed point-to-point ops (RCCL on GPUs, gloo on CPU)."""
 
-    def __init__(self, dist, rank, world_size, torch_device, host_staging=False):
+    def __init__(self, dist, rank, world_size, host_staging=False):
         import torch
         self.dist, self.rank, self.world_size = dist, rank, world_size
         self.torch = torch
-        self.out_dev = torch_device
         # host_staging: move payloads through CPU tensors (gloo has no CUDA point-to-point); used to
         # validate the multi-rank flow on a single GPU.  RCCL exchanges device buffers directly.
-        self.dev = torch.device("cpu") if host_staging else torch_device
+        self.host_staging = host_staging
+        self.left = rank - 1 if rank > 0 else None
+        self.right = rank + 1 if rank + 1 < world_size else None
 
-    def exchange(self, send_left, send_right, width, recv_counts=None):
-        """Send row blocks to the left/right neighbour, receive theirs.  Returns (from_left, from_right).
-        recv_counts = (n_from_left, n_from_right) when already known (velocity refresh: one row per ghost),
-        which saves the count round-trip."""
+    def _batch(self, ops):
+        if ops:
+            for r in self.dist.batch_isend_irecv(ops):
+                r.wait()  # RCCL: orders the current stream after the transfer, does not block the host
+
+    def exchange(self, send, split, width, alloc, recv_counts=None):
+        """`send` holds split[0] rows for the left neighbour followed by split[1] rows for the right one.
+        Returns the rows received: the left neighbour's first.  recv_counts = (n_from_left, n_from_right)
+        when already known (velocity refresh: one row per ghost), which saves the count round-trip."""
         torch, dist = self.torch, self.dist
-        send_left, send_right = send_left.to(self.dev), send_right.to(self.dev)
-        left = self.rank - 1 if self.rank > 0 else None
-        right = self.rank + 1 if self.rank + 1 < self.world_size else None
+        ml, mr = split
+        if self.host_staging:
+            out_alloc, alloc = alloc, (lambda rows, w: torch.empty((rows, w), dtype=torch.float32))
+            send = send.cpu()
         if recv_counts is None:
-            # 1. row counts
-            cnt_send = torch.tensor([send_left.shape[0], send_right.shape[0]], dtype=torch.int64, device=self.dev)
-            cnt_recv = torch.zeros(2, dtype=torch.int64, device=self.dev)
+            dev = send.device
+            cnt_send = torch.tensor([ml, mr], dtype=torch.int64, device=dev)
+            cnt_recv = torch.zeros(2, dtype=torch.int64, device=dev)
             ops = []
-            if left is not None:
-                ops += [dist.P2POp(dist.isend, cnt_send[0:1], left), dist.P2POp(dist.irecv, cnt_recv[0:1], left)]
-            if right is not None:
-                ops += [dist.P2POp(dist.isend, cnt_send[1:2], right), dist.P2POp(dist.irecv, cnt_recv[1:2], right)]
-            if ops:
-                for r in dist.batch_isend_irecv(ops):
-                    r.wait()
+            if self.left is not None:
+                ops += [dist.P2POp(dist.isend, cnt_send[0:1], self.left), dist.P2POp(dist.irecv, cnt_recv[0:1], self.left)]
+            if self.right is not None:
+                ops += [dist.P2POp(dist.isend, cnt_send[1:2], self.right), dist.P2POp(dist.irecv, cnt_recv[1:2], self.right)]
+            self._batch(ops)
             nl, nr = (int(v) for v in cnt_recv.tolist())
         else:
             nl, nr = recv_counts
-        # 2. payloads
-        from_left = torch.empty((nl, width), dtype=torch.float32, device=self.dev)
-        from_right = torch.empty((nr, width), dtype=torch.float32, device=self.dev)
+        recv = alloc(nl + nr, width)
         ops = []
-        if left is not None:
-            if send_left.shape[0]:
-                ops.append(dist.P2POp(dist.isend, send_left.contiguous(), left))
+        if self.left is not None:
+            if ml:
+                ops.append(dist.P2POp(dist.isend, send[:ml], self.left))
             if nl:
-                ops.append(dist.P2POp(dist.irecv, from_left, left))
-        if right is not None:
-            if send_right.shape[0]:
-                ops.append(dist.P2POp(dist.isend, send_right.contiguous(), right))
+                ops.append(dist.P2POp(dist.irecv, recv[:nl], self.left))
+        if self.right is not None:
+            if mr:
+                ops.append(dist.P2POp(dist.isend, send[ml:], self.right))
             if nr:
-                ops.append(dist.P2POp(dist.irecv, from_right, right))
-        if ops:
-            for r in dist.batch_isend_irecv(ops):
-                r.wait()
-        return from_left.to(self.out_dev), from_right.to(self.out_dev)
-
-
-class NullTransport:
-    def exchange(self, send_left, send_right, width, recv_counts=None):
-        return send_left[:0], send_right[:0]
+                ops.append(dist.P2POp(dist.irecv, recv[nl:], self.right))
+        self._batch(ops)
+        if self.host_staging:
+            dev_recv = out_alloc(nl + nr, width)
+            dev_recv.copy_(recv)
+            recv = dev_recv
+        return recv, (nl, nr)
 
 
 class Tile:
@@ -159,63 +174,80 @@ class Tile:
         self.has_left, self.has_right = rank > 0, rank + 1 < world_size
 
     def phase_begin(self):
+        """-> (rows for [left | right], (n_left, n_right))"""
         e = self.e
         e.begin_tick(self.dt)
         x_left = self.x_lo + self.halo if self.has_left else -np.inf
         x_right = self.x_hi - self.halo if self.has_right else np.inf
-        e.select_boundary(np.float32(max(x_left, -3.0e38)), np.float32(min(x_right, 3.0e38)))
-        return (e.export_bodies(0) if self.has_left else e.empty(GHOST_FLOATS),
-                e.export_bodies(1) if self.has_right else e.empty(GHOST_FLOATS))
+        split = e.select_boundary(np.float32(max(x_left, -3.0e38)), np.float32(min(x_right, 3.0e38)))
+        return e.export_bodies(), split
 
-    def phase_collide(self, from_left, from_right):
-        self.e.import_ghosts(self.e.cat([from_left, from_right]))
+    def phase_collide(self, ghosts):
+        self.e.import_ghosts(ghosts)
         return self.e.collide(self.dt)
 
     def phase_solve_one(self):
-        st = self.e.solve(1)
-        return st, (self.e.export_velocities(0) if self.has_left else self.e.empty(VEL_FLOATS),
-                    self.e.export_velocities(1) if self.has_right else self.e.empty(VEL_FLOATS))
+        self.e.solve_iteration()
+        return self.e.export_velocities()
 
-    def phase_refresh(self, from_left, from_right):
-        self.e.import_ghost_velocities(self.e.cat([from_left, from_right]))
+    def phase_refresh(self, vel):
+        self.e.import_ghost_velocities(vel)
+
+    def phase_end(self):
+        return self.e.finish()
 
 
 def step_tile(tile, transport):
     """One tick of one tile with a real transport (one process per tile)."""
-    sl, sr = tile.phase_begin()
-    fl, fr = transport.exchange(sl, sr, GHOST_FLOATS)
-    ghosts = (fl.shape[0], fr.shape[0])
-    stats = tile.phase_collide(fl, fr)
-    launches, ms_solve, ms_kern = 0, 0.0, 0.0
-    for it in range(tile.iters):
-        st, (vl, vr) = tile.phase_solve_one()
-        launches += st["solver_kernel_launches"]
-        ms_solve += st["ms_solve"]
-        ms_kern += st.get("ms_solver_kernels", 0.0)
-        if it + 1 < tile.iters and tile.world_size > 1:
-            fl, fr = transport.exchange(vl, vr, VEL_FLOATS, recv_counts=ghosts)
-            tile.phase_refresh(fl, fr)
-    stats = dict(stats)
-    stats.update(solver_kernel_launches=launches, ms_solve=ms_solve, ms_solver_kernels=ms_kern, n_levels=launches)
+    e = tile.e
+    with e.stream_ctx():
+        send, split = tile.phase_begin()
+        ghosts, counts = transport.exchange(send, split, GHOST_FLOATS, e.alloc)
+        stats = dict(tile.phase_collide(ghosts))
+        for it in range(tile.iters):
+            vel = tile.phase_solve_one()
+            if it + 1 < tile.iters and tile.world_size > 1:
+                got, _ = transport.exchange(vel, split, VEL_FLOATS, e.alloc, recv_counts=counts)
+                tile.phase_refresh(got)
+        fin = tile.phase_end()
+    for k in ("solver_kernel_launches", "ms_solve", "ms_solver_kernels", "n_levels", "ms_total", "iters"):
+        if k in fin:
+            stats[k] = fin[k]
     return stats
+
+
+def _gather_rows(tiles, sends, splits, r, cat, empty, width):
+    """What tile r receives: the right-face rows of tile r-1, then the left-face rows of tile r+1."""
+    parts = []
+    if r > 0:
+        parts.append(sends[r - 1][splits[r - 1][0]:])
+    if r + 1 < len(tiles):
+        parts.append(sends[r + 1][:splits[r + 1][0]])
+    return cat(parts) if parts else empty(0, width)
 
 
 def step_tiles_inprocess(tiles):
     """All tiles of a scene in ONE process (tests / emulation): same phases, exchange by hand."""
+    import torch
+    with tiles[0].e.stream_ctx():
+        return _step_tiles_inprocess(tiles, torch)
+
+
+def _step_tiles_inprocess(tiles, torch):
     P = len(tiles)
-    sends = [t.phase_begin() for t in tiles]
+    begun = [t.phase_begin() for t in tiles]
+    sends, splits = [b[0] for b in begun], [b[1] for b in begun]
+    cat = lambda parts: torch.cat(parts, dim=0)  # noqa: E731
     stats = []
     for r, t in enumerate(tiles):
-        fl = sends[r - 1][1] if r > 0 else t.e.empty(GHOST_FLOATS)
-        fr = sends[r + 1][0] if r + 1 < P else t.e.empty(GHOST_FLOATS)
-        stats.append(t.phase_collide(fl, fr))
+        stats.append(dict(t.phase_collide(_gather_rows(tiles, sends, splits, r, cat, t.e.alloc, GHOST_FLOATS))))
     for it in range(tiles[0].iters):
-        vels = [t.phase_solve_one()[1] for t in tiles]
+        vels = [t.phase_solve_one() for t in tiles]
         if it + 1 < tiles[0].iters and P > 1:
             for r, t in enumerate(tiles):
-                fl = vels[r - 1][1] if r > 0 else t.e.empty(VEL_FLOATS)
-                fr = vels[r + 1][0] if r + 1 < P else t.e.empty(VEL_FLOATS)
-                t.phase_refresh(fl, fr)
+                t.phase_refresh(_gather_rows(tiles, vels, splits, r, cat, t.e.alloc, VEL_FLOATS))
+    for r, t in enumerate(tiles):
+        stats[r].update(t.phase_end())
     return stats
 
 
@@ -237,7 +269,7 @@ class TiledWorld:
             eng = HipEngine(ctx, self.scene, device)
             self.world = eng.world
             self.tile = Tile(eng, self.scene["x_range"], rank, world_size, self.dt, iters, halo=halo)
-            self.transport = DistTransport(dist, rank, world_size, torch.device("cuda", device), host_staging=host_staging)
+            self.transport = DistTransport(dist, rank, world_size, host_staging=host_staging)
 
     def step(self):
         if self.tile is None:

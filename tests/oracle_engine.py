@@ -1,5 +1,7 @@
 """CPU engine for mgf_amd.tiles (tests only): the oracle's tile mode behind the same interface as
 mgf_amd.tiles.HipEngine, with torch CPU tensors as exchange buffers."""
+import contextlib
+
 import numpy as np
 import torch
 
@@ -12,6 +14,12 @@ class OracleEngine:
         self.w = oracle_world(scene, O.ORDER_CANONICAL)
         self.ids = [np.zeros(0, np.uint32), np.zeros(0, np.uint32)]
 
+    def stream_ctx(self):
+        return contextlib.nullcontext()
+
+    def alloc(self, rows, width):
+        return torch.empty((rows, width), dtype=torch.float32)
+
     def begin_tick(self, dt):
         self.w.begin_tick(dt)
 
@@ -20,32 +28,28 @@ class OracleEngine:
         self.ids = [l, r]
         return len(l), len(r)
 
-    def export_bodies(self, side):
-        return torch.from_numpy(self.w.export_bodies(self.ids[side]))
+    def export_bodies(self):
+        return torch.from_numpy(np.concatenate([self.w.export_bodies(self.ids[0]).reshape(-1, 36), self.w.export_bodies(self.ids[1]).reshape(-1, 36)]))
 
     def import_ghosts(self, recs):
-        self.w.import_ghosts(recs.numpy())
+        self.w.import_ghosts(np.ascontiguousarray(recs.numpy()))
 
     def collide(self, dt):
         st = self.w.collide(dt)
         return dict(n_constraints=st.n_constraints, n_terrain_constraints=st.n_terrain_constraints,
                     n_pair_candidates=st.n_pair_candidates, n_refits=st.n_refits)
 
-    def solve(self, iters):
-        self.w.solve(iters)
-        return dict(solver_kernel_launches=0, ms_solve=0.0, ms_solver_kernels=0.0)
+    def solve_iteration(self):
+        self.w.solve(1)
 
-    def export_velocities(self, side):
-        return torch.from_numpy(self.w.export_velocities(self.ids[side]))
+    def export_velocities(self):
+        return torch.from_numpy(np.concatenate([self.w.export_velocities(self.ids[0]).reshape(-1, 8), self.w.export_velocities(self.ids[1]).reshape(-1, 8)]))
 
     def import_ghost_velocities(self, vel):
-        self.w.import_ghost_velocities(vel.numpy())
+        self.w.import_ghost_velocities(np.ascontiguousarray(vel.numpy()))
 
-    def empty(self, width):
-        return torch.empty((0, width), dtype=torch.float32)
-
-    def cat(self, parts):
-        return torch.cat(parts, dim=0)
+    def finish(self):
+        return dict(solver_kernel_launches=0, ms_solve=0.0, ms_solver_kernels=0.0)
 
     def state(self):
         return self.w.state()

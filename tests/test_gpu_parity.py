@@ -237,7 +237,7 @@ def test_tiled_worlds_match_oracle_tiles(ctx):
         so = step_tiles_inprocess(ot)
         for r in range(P):
             assert sg[r]["n_constraints"] == so[r]["n_constraints"], f"tick {tick} tile {r}"
-            assert gt[r].e.counts == [len(ot[r].e.ids[0]), len(ot[r].e.ids[1])]
+            assert tuple(gt[r].e.counts) == (len(ot[r].e.ids[0]), len(ot[r].e.ids[1]))
     assert gt[0].e.counts[1] > 0 and gt[1].e.counts[0] > 0
     for r in range(P):
         g, o = gt[r].e.state(), ot[r].e.state()

@@ -21,7 +21,7 @@ def main():
     rank, ws = dist.get_rank(), dist.get_world_size()
     scene = scenes.sphere_pile_tile(nx, ny, nz, rank, ws)
     tile = Tile(OracleEngine(scene), scene["x_range"], rank, ws, scene["dt"], scene["iters"])
-    tr = DistTransport(dist, rank, ws, torch.device("cpu"))
+    tr = DistTransport(dist, rank, ws)
     ncons = []
     for _ in range(ticks):
         ncons.append(step_tile(tile, tr)["n_constraints"])
