@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--refresh-every", type=int, default=None, help="solver iterations between ghost velocity refreshes (multi-GPU; default: mgf_amd.tiles.DEFAULT_REFRESH_EVERY)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo = host-staged exchange, for validating the multi-rank flow on one GPU")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-launch HIP events on the solver kernel")
@@ -61,12 +62,13 @@ def main():
 
     import mgf_amd
     from mgf_amd import scenes
-    from mgf_amd.tiles import TiledWorld
+    from mgf_amd.tiles import DEFAULT_REFRESH_EVERY, TiledWorld
+    refresh_every = args.refresh_every or DEFAULT_REFRESH_EVERY
 
     nx, ny, nz = args.tile
     ctx = mgf_amd.Context(dev_index)
     tw = TiledWorld(ctx, rank, world_size, nx, ny, nz, iters=args.iters, dist=dist, device=dev_index,
-                    host_staging=(args.backend == "gloo"))
+                    host_staging=(args.backend == "gloo"), refresh_every=refresh_every)
     red_dev = "cuda" if args.backend == "nccl" else "cpu"
     dt = tw.dt
 
@@ -146,7 +148,7 @@ def main():
                                    + ("" if world_size == 1 else f"; {world_size} x-slab tiles side by side, ghost halo over RCCL"),
                        "bodies_per_gpu": nx * ny * nz, "bodies_total": nx * ny * nz * world_size, "iters": args.iters,
                        "dt": dt, "constraint_order": "canonical (i asc; terrain DFS; partners j<i asc)",
-                       "parallelism": "1 GPU" if world_size == 1 else f"{world_size} spatial x-slabs, neighbour halo exchange"},
+                       "parallelism": "1 GPU" if world_size == 1 else f"{world_size} spatial x-slabs, neighbour halo exchange (ghost bodies once per tick, ghost velocities every {refresh_every} solver iterations)"},
             "physics_steps_per_sec": args.steps / elapsed,
             "constraints_per_step": cons_all / args.steps,
             "solver_levels_mean": float(np.mean(levels)), "solver_launches_per_step": launches / args.steps,

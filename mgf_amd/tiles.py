@@ -6,14 +6,17 @@ data path).  The tick on every tile:
     select_boundary / export        owned bodies whose fat AABB reaches into the halo of a slab face
     <-> neighbours                  body records (36 floats each)
     import_ghosts, collide          broadphase / narrowphase / ContactConstraint::new on owned + ghost
-    iters x { solve(1); <-> neighbours: velocities of the exported bodies (8 floats each) }
+    iters/R x { solve(R); <-> neighbours: velocities of the exported bodies (8 floats each) }
     finish                          the one place the host waits for the solver (status, timings)
 
 Semantics (what the oracle's tile mode reproduces exactly): Gauss-Seidel inside a tile, ghost
-velocities refreshed from their owner after every solver iteration (block-Jacobi across tiles);
+velocities refreshed from their owner after every R solver iterations (block-Jacobi across tiles);
 a constraint between bodies of two tiles exists on both tiles, each tile keeping the result for the
 body it owns.  Ownership is by initial slab; a body drifting past the halo raises (migration is
 future work).
+
+Process set-up note: `import torch` must happen before the first mgf_amd.Context (torch ships its own
+libamdhip64 with the same soname as /opt/rocm's; the first one loaded serves the whole process).
 
 The driver is transport- and engine-agnostic: `HipEngine` drives mgf_amd.World through the C-ABI
 with torch CUDA tensors as exchange buffers (RCCL via torch.distributed); tests run the same driver
@@ -25,6 +28,12 @@ from . import scenes
 
 GHOST_FLOATS = 36
 VEL_FLOATS = 8
+# Solver iterations between two ghost velocity refreshes (1 = refresh after every iteration).  Measured on a
+# two-tile 6x6x6 pile after 60 ticks (tests/test_tiles_cpu.py::test_seam_quality_vs_refresh_interval): mean
+# resting penetration of the sphere pairs straddling the slab face 0.043 (R=1), 0.046 (R=2), 0.055 (R=10)
+# against 0.044 for pairs inside a tile - R=2 halves the exchanges and solver launches and keeps the seam at
+# the interior's level.
+DEFAULT_REFRESH_EVERY = 2
 
 
 class HipEngine:
@@ -87,8 +96,8 @@ class HipEngine:
     def collide(self, dt):
         return self.world.collide(dt).as_dict()
 
-    def solve_iteration(self):
-        self.world.solve_enqueue(1)
+    def solve_iterations(self, k):
+        self.world.solve_enqueue(k)
 
     def export_velocities(self):
         return self._export(self.world.export_velocities, VEL_FLOATS)
@@ -167,11 +176,20 @@ class DistTransport:
 class Tile:
     """One tile's tick, split into phases so several tiles can also be stepped in one process."""
 
-    def __init__(self, engine, x_range, rank, world_size, dt, iters, halo=1.0):
+    def __init__(self, engine, x_range, rank, world_size, dt, iters, halo=1.0, refresh_every=DEFAULT_REFRESH_EVERY):
         self.e, self.rank, self.world_size = engine, rank, world_size
         self.x_lo, self.x_hi = x_range
         self.dt, self.iters, self.halo = float(dt), int(iters), float(halo)
         self.has_left, self.has_right = rank > 0, rank + 1 < world_size
+        self.refresh_every = max(1, int(refresh_every))
+
+    def chunks(self):
+        """Solver iterations between two ghost velocity refreshes: [R, R, ..., rest]."""
+        left, out = self.iters, []
+        while left > 0:
+            out.append(min(self.refresh_every, left))
+            left -= out[-1]
+        return out
 
     def phase_begin(self):
         """-> (rows for [left | right], (n_left, n_right))"""
@@ -186,8 +204,8 @@ class Tile:
         self.e.import_ghosts(ghosts)
         return self.e.collide(self.dt)
 
-    def phase_solve_one(self):
-        self.e.solve_iteration()
+    def phase_solve(self, k):
+        self.e.solve_iterations(k)
         return self.e.export_velocities()
 
     def phase_refresh(self, vel):
@@ -204,9 +222,10 @@ def step_tile(tile, transport):
         send, split = tile.phase_begin()
         ghosts, counts = transport.exchange(send, split, GHOST_FLOATS, e.alloc)
         stats = dict(tile.phase_collide(ghosts))
-        for it in range(tile.iters):
-            vel = tile.phase_solve_one()
-            if it + 1 < tile.iters and tile.world_size > 1:
+        chunks = tile.chunks()
+        for ci, k in enumerate(chunks):
+            vel = tile.phase_solve(k)
+            if ci + 1 < len(chunks) and tile.world_size > 1:
                 got, _ = transport.exchange(vel, split, VEL_FLOATS, e.alloc, recv_counts=counts)
                 tile.phase_refresh(got)
         fin = tile.phase_end()
@@ -241,9 +260,10 @@ def _step_tiles_inprocess(tiles, torch):
     stats = []
     for r, t in enumerate(tiles):
         stats.append(dict(t.phase_collide(_gather_rows(tiles, sends, splits, r, cat, t.e.alloc, GHOST_FLOATS))))
-    for it in range(tiles[0].iters):
-        vels = [t.phase_solve_one() for t in tiles]
-        if it + 1 < tiles[0].iters and P > 1:
+    chunks = tiles[0].chunks()
+    for ci, k in enumerate(chunks):
+        vels = [t.phase_solve(k) for t in tiles]
+        if ci + 1 < len(chunks) and P > 1:
             for r, t in enumerate(tiles):
                 t.phase_refresh(_gather_rows(tiles, vels, splits, r, cat, t.e.alloc, VEL_FLOATS))
     for r, t in enumerate(tiles):
@@ -255,7 +275,7 @@ class TiledWorld:
     """bench.py's view: this rank's tile of the BASELINE sphere-pile workload."""
 
     def __init__(self, ctx, rank, world_size, nx, ny, nz, iters=10, dist=None, device=0, seed=scenes.SEED, halo=1.0,
-                 host_staging=False):
+                 host_staging=False, refresh_every=DEFAULT_REFRESH_EVERY):
         self.rank, self.world_size, self.dist = rank, world_size, dist
         self.iters = iters
         self.scene = scenes.sphere_pile_tile(nx, ny, nz, rank, world_size, seed=seed, iters=iters)
@@ -268,7 +288,7 @@ class TiledWorld:
             import torch
             eng = HipEngine(ctx, self.scene, device)
             self.world = eng.world
-            self.tile = Tile(eng, self.scene["x_range"], rank, world_size, self.dt, iters, halo=halo)
+            self.tile = Tile(eng, self.scene["x_range"], rank, world_size, self.dt, iters, halo=halo, refresh_every=refresh_every)
             self.transport = DistTransport(dist, rank, world_size, host_staging=host_staging)
 
     def step(self):

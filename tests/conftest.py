@@ -2,6 +2,8 @@ import os
 import sys
 
 import pytest
+import torch  # noqa: F401  - before libmgf_hip.so: torch bundles its own libamdhip64 (same soname as /opt/rocm's);
+#                  whichever is loaded first serves both, and torch only finds the GPU through its own copy
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

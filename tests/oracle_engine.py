@@ -39,8 +39,8 @@ class OracleEngine:
         return dict(n_constraints=st.n_constraints, n_terrain_constraints=st.n_terrain_constraints,
                     n_pair_candidates=st.n_pair_candidates, n_refits=st.n_refits)
 
-    def solve_iteration(self):
-        self.w.solve(1)
+    def solve_iterations(self, k):
+        self.w.solve(k)
 
     def export_velocities(self):
         return torch.from_numpy(np.concatenate([self.w.export_velocities(self.ids[0]).reshape(-1, 8), self.w.export_velocities(self.ids[1]).reshape(-1, 8)]))

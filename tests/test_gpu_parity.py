@@ -219,9 +219,10 @@ def test_closed_form_cases_hip(ctx, name):
     CASES[name](lambda scene: mgf_amd.World.from_scene(ctx, scene))
 
 
-def test_tiled_worlds_match_oracle_tiles(ctx):
-    """Two x-slab tiles (ghost export/import kernels, ghost filtering in the broadphase, per-iteration
-    velocity refresh) on the GPU vs the oracle's tile mode: bit-identical per tile."""
+@pytest.mark.parametrize("refresh_every", [1, 2, 3, 10])
+def test_tiled_worlds_match_oracle_tiles(ctx, refresh_every):
+    """Two x-slab tiles (ghost export/import kernels, ghost filtering in the broadphase, ghost velocity
+    refresh every R solver iterations) on the GPU vs the oracle's tile mode: bit-identical per tile."""
     import mgf_amd
     from mgf_amd import scenes
     from mgf_amd.tiles import HipEngine, Tile, step_tiles_inprocess
@@ -230,8 +231,8 @@ def test_tiled_worlds_match_oracle_tiles(ctx):
     gt, ot = [], []
     for r in range(P):
         sc = scenes.sphere_pile_tile(nx, ny, nz, r, P)
-        gt.append(Tile(HipEngine(ctx, sc, 0), sc["x_range"], r, P, sc["dt"], sc["iters"]))
-        ot.append(Tile(OracleEngine(sc), sc["x_range"], r, P, sc["dt"], sc["iters"]))
+        gt.append(Tile(HipEngine(ctx, sc, 0), sc["x_range"], r, P, sc["dt"], sc["iters"], refresh_every=refresh_every))
+        ot.append(Tile(OracleEngine(sc), sc["x_range"], r, P, sc["dt"], sc["iters"], refresh_every=refresh_every))
     for tick in range(12):
         sg = step_tiles_inprocess(gt)
         so = step_tiles_inprocess(ot)

@@ -15,11 +15,11 @@ from tests.util import oracle_world, rel_err
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def make_tiles(nx, ny, nz, P, engine=OracleEngine):
+def make_tiles(nx, ny, nz, P, engine=OracleEngine, **kw):
     tiles = []
     for r in range(P):
         sc = scenes.sphere_pile_tile(nx, ny, nz, r, P)
-        tiles.append(Tile(engine(sc), sc["x_range"], r, P, sc["dt"], sc["iters"]))
+        tiles.append(Tile(engine(sc), sc["x_range"], r, P, sc["dt"], sc["iters"], **kw))
     return tiles
 
 
@@ -72,6 +72,41 @@ def test_tiled_result_tracks_the_undivided_world():
     dv, dx = rel_err(tiled_v, whole["v"]), rel_err(tiled_x, whole["x"])
     print(f"tiled-vs-undivided deviation after 10 ticks: v {dv:.3e}, x {dx:.3e}")
     assert dx < 0.05 and dv < 1.0
+
+
+def test_refresh_interval_chunks():
+    sc = scenes.sphere_pile_tile(2, 2, 2, 0, 1)
+    mk = lambda it, R: Tile(OracleEngine(sc), sc["x_range"], 0, 2, sc["dt"], it, refresh_every=R).chunks()  # noqa: E731
+    assert mk(10, 1) == [1] * 10 and mk(10, 2) == [2] * 5 and mk(10, 3) == [3, 3, 3, 1] and mk(10, 10) == [10] and mk(10, 99) == [10]
+    assert mk(0, 2) == []
+
+
+def _seam_penetration(tiles, radius=0.5):
+    """mean overlap depth of touching sphere pairs: (pairs across the slab face, pairs inside a tile)"""
+    from scipy.spatial import cKDTree
+    x = np.concatenate([t.e.state()["x"] for t in tiles]).astype(np.float64)
+    owner = np.concatenate([np.full(len(t.e.state()["x"]), r) for r, t in enumerate(tiles)])
+    pairs = cKDTree(x).query_pairs(2 * radius, output_type="ndarray")
+    pen = 2 * radius - np.linalg.norm(x[pairs[:, 0]] - x[pairs[:, 1]], axis=1)
+    cross = owner[pairs[:, 0]] != owner[pairs[:, 1]]
+    return float(pen[cross].mean()), float(pen[~cross].mean()), int(cross.sum())
+
+
+def test_seam_quality_vs_refresh_interval():
+    """What the ghost refresh interval costs physically: resting penetration of the sphere pairs that straddle
+    the slab face, against pairs inside a tile (both near the solver's 0.05 slop).  The default interval must
+    keep the seam at the interior's level; the numbers are printed for DESIGN.md §7."""
+    from mgf_amd.tiles import DEFAULT_REFRESH_EVERY
+    rows = {}
+    for R in sorted({1, DEFAULT_REFRESH_EVERY, 10}):
+        tiles = make_tiles(6, 6, 6, 2, refresh_every=R)
+        for _ in range(60):
+            step_tiles_inprocess(tiles)
+        rows[R] = _seam_penetration(tiles)
+        print(f"refresh every {R:2d} iterations: seam penetration {rows[R][0]:.4f} ({rows[R][2]} pairs), interior {rows[R][1]:.4f}")
+    seam, interior, n = rows[DEFAULT_REFRESH_EVERY]
+    assert n >= 10 and seam < 1.25 * interior
+    assert rows[1][0] < 1.25 * rows[1][1]
 
 
 @pytest.mark.timeout(300)
