@@ -772,15 +772,21 @@ struct CRec {
   uint32_t a, b;       // body indices; b = kNone for RigidBodyRef::Static
   float n[3], t0[3], t1[3], ra[3], rb[3];
   float bias, nmass, tmass0, tmass1;
-  uint32_t succ_a;     // next constraint on body a / b in insertion order (successor word, see k_chain)
+  uint32_t pad0;
   float nimp;          // ContactState::normal_impulse            (word 22: 8-byte aligned with round)
-  uint32_t round;      // solver iterations already applied in the current Solver::solve call
-  uint32_t succ_b;
-  uint32_t indeg;      // predecessors still pending for the next round (atomics)
-  uint32_t indeg0;     // predecessors inside one iteration (in-degree of round 0)
+  uint32_t round;      // solver iterations already applied in the current Solver::solve call (launch-per-frontier mode)
+  uint32_t pad1;
+  uint32_t indeg;      // predecessors still pending for the next round (atomics; launch-per-frontier mode)
+  uint32_t pad2;
   float friction;      // dead state in the reference (solver.rs:223-226), kept for read-back
-  uint32_t ta, da;     // position of this constraint in body a's insertion-ordered list, and the list's length
-  uint32_t tb, db;     // same for body b (unused for Static)
+  uint32_t pad3[4];
+};
+// Dependency links live outside the records, in compact arrays (ConsLinks): building them touches 4-16 bytes per
+// constraint instead of a 128-byte line.
+struct ConsLinks {
+  uint2* ab;           // (a, b) of every constraint
+  uint2* succ;         // successor words on body a / body b (see k_chain)
+  uint8_t* pred;       // pred[2c + role] = 1 if the constraint has a predecessor on that body inside one iteration
 };
 static_assert(sizeof(CRec) == 128, "CRec is one 128-byte line");
 
@@ -823,8 +829,8 @@ __device__ __forceinline__ CRec make_constraint(uint32_t ia, uint32_t ib, const 
   c.tmass1 = 1.0f / (A.im + dot(ra_ct, A.I * ra_ct) + Bd.im + dot(rb_ct, Bd.I * rb_ct));
   c.bias = bias;
   c.nimp = 0.0f;
-  c.round = 0; c.succ_a = kNone; c.succ_b = kNone; c.indeg = 0; c.indeg0 = 0;
-  c.ta = c.da = c.tb = c.db = 0;
+  c.round = 0; c.indeg = 0; c.pad0 = c.pad1 = c.pad2 = 0;
+  c.pad3[0] = c.pad3[1] = c.pad3[2] = c.pad3[3] = 0;
   st3(c.n, normal); st3(c.t0, t0); st3(c.t1, t1); st3(c.ra, ra); st3(c.rb, rb);
   return c;
 }
@@ -844,12 +850,12 @@ __device__ __forceinline__ CRec load_crec(const CRec* src) {
   for (int k = 0; k < 8; ++k) d[k] = s[k];
   return c;
 }
-static_assert(offsetof(CRec, nimp) == 88 && offsetof(CRec, round) == 92 && offsetof(CRec, succ_b) == 96, "CRec layout");
+static_assert(offsetof(CRec, nimp) == 88 && offsetof(CRec, round) == 92 && offsetof(CRec, indeg) == 100, "CRec layout");
 
 __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCounts* sc, const uint32_t* p_owner, const uint32_t* p_cand,
                                                         const uint32_t* p_nc, const uint32_t* p_pre, const NContact* p_in,
                                                         const uint32_t* base, float dt, float baumgarte, float slop,
-                                                        CRec* cons) {
+                                                        CRec* cons, uint2* ab, uint32_t* deg) {
   uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= sc->Mp || p_nc[p] == 0) return;
   uint32_t i = p_owner[p], j = p_cand[p];
@@ -860,11 +866,15 @@ __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCoun
   CRec r = make_constraint(i, j, A, xyz(ea), ea.w, B.delta[i].w, Bd, xyz(eb), eb.w, B.delta[j].w, xyz(k.n), xyz(k.la), xyz(k.lb),
                            dt, baumgarte, slop);
   store_crec(&cons[c], r);
+  ab[c] = make_uint2(i, j);
+  atomicAdd(&deg[i], 1u);
+  atomicAdd(&deg[j], 1u);
 }
 
 __global__ __launch_bounds__(kBlock) void k_setup_terrain(Bodies B, TerrainDev M, const StepCounts* sc, const uint32_t* t_owner,
                                                           const uint32_t* t_nc, const uint32_t* t_pre, const NContact* t_in,
-                                                          const uint32_t* base, float dt, float baumgarte, float slop, CRec* cons) {
+                                                          const uint32_t* base, float dt, float baumgarte, float slop, CRec* cons,
+                                                          uint2* ab, uint32_t* deg) {
   uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= sc->Mt) return;
   uint32_t nc = t_nc[p];
@@ -878,7 +888,9 @@ __global__ __launch_bounds__(kBlock) void k_setup_terrain(Bodies B, TerrainDev M
     CRec r = make_constraint(i, kNone, A, xyz(ea), ea.w, B.delta[i].w, S, center, 0.0f, 0.0f, xyz(in.n), xyz(in.la), xyz(in.lb), dt,
                              baumgarte, slop);
     store_crec(&cons[base[i] + t_pre[p] + k], r);
+    ab[base[i] + t_pre[p] + k] = make_uint2(i, kNone);
   }
+  atomicAdd(&deg[i], nc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -889,19 +901,22 @@ __global__ __launch_bounds__(kBlock) void k_setup_terrain(Bodies B, TerrainDev M
 // are linked (succ_a / succ_b by the body's role in the earlier one).
 // ------------------------------------------------------------------------------------------
 // entry = (constraint id << 1) | role, role 0: the body is `a`, role 1: the body is `b`.
-__global__ __launch_bounds__(kBlock) void k_adj_fill(const CRec* cons, const uint32_t* C_ptr, const uint32_t* adj_off, uint32_t* adj_fill,
+__global__ __launch_bounds__(kBlock) void k_adj_fill(const uint2* ab, const uint32_t* C_ptr, const uint32_t* adj_off, uint32_t* adj_fill,
                                                      uint32_t* adj_list) {
   uint32_t c = blockIdx.x * kBlock + threadIdx.x;
   if (c >= *C_ptr) return;
-  uint32_t a = cons[c].a, b = cons[c].b;
-  adj_list[adj_off[a] + atomicAdd(&adj_fill[a], 1u)] = (c << 1);
-  if (b != kNone) adj_list[adj_off[b] + atomicAdd(&adj_fill[b], 1u)] = (c << 1) | 1u;
+  uint2 e = ab[c];
+  adj_list[adj_off[e.x] + atomicAdd(&adj_fill[e.x], 1u)] = (c << 1);
+  if (e.y != kNone) adj_list[adj_off[e.y] + atomicAdd(&adj_fill[e.y], 1u)] = (c << 1) | 1u;
 }
-__global__ __launch_bounds__(kBlock) void k_adj_count(const CRec* cons, const uint32_t* C_ptr, uint32_t* deg) {
+// (a, b) and per-body degrees of a caller-supplied constraint list (mgf_world_set_constraints); the tick's own
+// list gets them from the setup kernels.
+__global__ __launch_bounds__(kBlock) void k_links_from_records(const CRec* cons, uint32_t C, uint2* ab, uint32_t* deg) {
   uint32_t c = blockIdx.x * kBlock + threadIdx.x;
-  if (c >= *C_ptr) return;
-  atomicAdd(&deg[cons[c].a], 1u);
-  uint32_t b = cons[c].b;
+  if (c >= C) return;
+  uint32_t a = cons[c].a, b = cons[c].b;
+  ab[c] = make_uint2(a, b);
+  atomicAdd(&deg[a], 1u);
   if (b != kNone) atomicAdd(&deg[b], 1u);
 }
 
@@ -909,7 +924,7 @@ __global__ __launch_bounds__(kBlock) void k_adj_count(const CRec* cons, const ui
 // per-round in-degree is 2, else 1), bit 31 = the link wraps to the next solver iteration.
 constexpr uint32_t kSuccId = 0x3FFFFFFFu, kSuccTwo = 0x40000000u, kSuccWrap = 0x80000000u;
 
-__global__ __launch_bounds__(kBlock) void k_chain(uint32_t n, CRec* cons, const uint32_t* adj_off, uint32_t* adj_list) {
+__global__ __launch_bounds__(kBlock) void k_chain(uint32_t n, ConsLinks K, const uint32_t* adj_off, uint32_t* adj_list) {
   uint32_t x = blockIdx.x * kBlock + threadIdx.x;
   if (x >= n) return;
   uint32_t lo = adj_off[x], hi = adj_off[x + 1];
@@ -920,15 +935,18 @@ __global__ __launch_bounds__(kBlock) void k_chain(uint32_t n, CRec* cons, const 
     while (b > lo && adj_list[b - 1] > v) { adj_list[b] = adj_list[b - 1]; --b; }
     adj_list[b] = v;
   }
+  uint32_t* succ = reinterpret_cast<uint32_t*>(K.succ);
   for (uint32_t a = lo; a < hi; ++a) {
     bool last = (a + 1 == hi);
     uint32_t u = adj_list[a], w = adj_list[last ? lo : a + 1];
     uint32_t wid = w >> 1;
-    uint32_t word = wid | (cons[wid].b != kNone ? kSuccTwo : 0u) | (last ? kSuccWrap : 0u);
-    if (u & 1u) { cons[u >> 1].succ_b = word; cons[u >> 1].tb = a - lo; cons[u >> 1].db = hi - lo; }
-    else { cons[u >> 1].succ_a = word; cons[u >> 1].ta = a - lo; cons[u >> 1].da = hi - lo; }
-    if (!last) atomicAdd(&cons[wid].indeg0, 1u);  // predecessors inside one iteration
+    uint32_t word = wid | (K.ab[wid].y != kNone ? kSuccTwo : 0u) | (last ? kSuccWrap : 0u);
+    succ[2 * (u >> 1) + (u & 1u)] = word;
+    K.pred[2 * (u >> 1) + (u & 1u)] = a > lo ? 1 : 0;  // predecessor on this body inside one iteration
   }
+}
+__device__ __forceinline__ uint32_t links_indeg0(const ConsLinks& K, uint32_t c) {
+  return (uint32_t)K.pred[2 * c] + (K.ab[c].y != kNone ? (uint32_t)K.pred[2 * c + 1] : 0u);
 }
 
 // The solver walks the dependency graph of the WHOLE Solver::solve call (iters x constraints,
@@ -946,13 +964,13 @@ struct Frontier {
 
 // Start of a Solver::solve call: reset round / in-degree of every record; launch 0's list =
 // constraints without predecessors in iteration 0.  Block-aggregated append.
-__global__ __launch_bounds__(kBlock) void k_frontier0(uint32_t C, CRec* cons, Frontier F) {
+__global__ __launch_bounds__(kBlock) void k_frontier0(uint32_t C, CRec* cons, ConsLinks K, Frontier F) {
   __shared__ uint32_t s_n, s_base;
   for (uint32_t c0 = blockIdx.x * kBlock; c0 < C; c0 += gridDim.x * kBlock) {
     uint32_t c = c0 + threadIdx.x;
     bool ready = false;
     if (c < C) {
-      uint32_t d0 = cons[c].indeg0;
+      uint32_t d0 = links_indeg0(K, c);
       ready = d0 == 0;
       cons[c].round = 0;
       cons[c].indeg = ready ? (cons[c].b != kNone ? 2u : 1u) : d0;  // ready ones are armed for their later rounds
@@ -1008,7 +1026,7 @@ __device__ __forceinline__ void store_vel(float4* srec, uint32_t i, const BodyDy
 }
 
 // One launch of the frontier process.
-__global__ __launch_bounds__(kBlock) void k_solve(float4* srec, CRec* cons, Frontier F, uint32_t launch, uint32_t iters) {
+__global__ __launch_bounds__(kBlock) void k_solve(float4* srec, CRec* cons, ConsLinks K, Frontier F, uint32_t launch, uint32_t iters) {
   __shared__ uint32_t s_q[2 * kBlock];
   __shared__ uint32_t s_n, s_base;
   const uint32_t lo = F.lvl_off[launch];
@@ -1029,10 +1047,11 @@ __global__ __launch_bounds__(kBlock) void k_solve(float4* srec, CRec* cons, Fron
       if (c.b != kNone) store_vel(srec, c.b, Bd);
       uint32_t k = c.round;
       *reinterpret_cast<float2*>(&cons[cid].nimp) = make_float2(c.nimp, u2f(k + 1));  // nimp, round
+      const uint2 sw = K.succ[cid];
 #pragma unroll
       for (int side = 0; side < 2; ++side) {
         if (side == 1 && c.b == kNone) break;
-        uint32_t w = side == 0 ? c.succ_a : c.succ_b;
+        uint32_t w = side == 0 ? sw.x : sw.y;
         uint32_t ks = k + (w >> 31);  // the successor's round this release belongs to
         if (ks >= iters) continue;
         uint32_t sid = w & kSuccId;
@@ -1092,16 +1111,16 @@ __device__ __forceinline__ void store_vel_sc1(__amdgpu_buffer_rsrc_t r, uint32_t
 }
 
 // arr[c] = 2 - (weighted predecessors inside iteration 0): node (c, 0) is ready at arr >= 2.
-__global__ __launch_bounds__(kBlock) void k_flow_init(const uint32_t* C_ptr, const CRec* cons, uint32_t* arr, uint32_t* abort_flag) {
+__global__ __launch_bounds__(kBlock) void k_flow_init(const uint32_t* C_ptr, ConsLinks K, uint32_t* arr, uint32_t* abort_flag) {
   uint32_t c = blockIdx.x * kBlock + threadIdx.x;
   if (c == 0) *abort_flag = 0;
   if (c >= *C_ptr) return;
-  uint32_t d0 = cons[c].indeg0;
-  arr[c] = 2u - d0 * (cons[c].b != kNone ? 1u : 2u);
+  uint32_t d0 = links_indeg0(K, c);
+  arr[c] = 2u - d0 * (K.ab[c].y != kNone ? 1u : 2u);
 }
 
 template <bool TRACE>
-__global__ __launch_bounds__(kBlock) void k_solve_flow(float4* srec, CRec* cons, uint32_t* arr, const uint32_t* C_ptr, uint32_t iters,
+__global__ __launch_bounds__(kBlock) void k_solve_flow(float4* srec, CRec* cons, ConsLinks K, uint32_t* arr, const uint32_t* C_ptr, uint32_t iters,
                                                        uint32_t* abort_flag, uint32_t spin_limit, int sleep_mode, uint64_t* trace) {
   const uint32_t C = *C_ptr;
   const uint32_t L = gridDim.x * kBlock;
@@ -1111,13 +1130,14 @@ __global__ __launch_bounds__(kBlock) void k_solve_flow(float4* srec, CRec* cons,
   bool done = (c >= C) || iters == 0;
   bool have_rec = false;
   CRec rec;
+  uint2 sw = make_uint2(0u, 0u);
   uint32_t spins = 0;
   for (;;) {
     if (!__any(!done)) break;
     bool progressed = false;
     if (!done) {
       // the record is private to this lane: fetch it while the node is still waiting for its predecessors
-      if (!have_rec) { rec = load_crec(&cons[c]); have_rec = true; }
+      if (!have_rec) { rec = load_crec(&cons[c]); sw = K.succ[c]; have_rec = true; }
       uint32_t a = __hip_atomic_load(&arr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (a >= 2u * (round + 1u)) {
         asm volatile("" ::: "memory");  // nothing below may be hoisted above the poll
@@ -1132,7 +1152,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_flow(float4* srec, CRec* cons,
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
           if (side == 1 && rec.b == kNone) break;
-          uint32_t w = side == 0 ? rec.succ_a : rec.succ_b;
+          uint32_t w = side == 0 ? sw.x : sw.y;
           if (round + (w >> 31) >= iters) continue;
           __hip_atomic_fetch_add(&arr[w & kSuccId], (w & kSuccTwo) ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1165,7 +1185,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_flow(float4* srec, CRec* cons,
 // Still deadlock-free: the globally smallest pending node is the head of its slot.
 // ------------------------------------------------------------------------------------------
 template <int KS, bool TRACE>
-__global__ __launch_bounds__(kBlock) void k_solve_flowk(float4* srec, CRec* cons, uint32_t* arr, const uint32_t* C_ptr, uint32_t iters,
+__global__ __launch_bounds__(kBlock) void k_solve_flowk(float4* srec, CRec* cons, ConsLinks K, uint32_t* arr, const uint32_t* C_ptr, uint32_t iters,
                                                         uint32_t* abort_flag, uint32_t spin_limit, int sleep_mode, uint64_t* trace) {
   const uint32_t C = *C_ptr;
   const uint32_t L = gridDim.x * kBlock;
@@ -1175,7 +1195,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_flowk(float4* srec, CRec* cons
 #pragma unroll
   for (int j = 0; j < KS; ++j) {
     sc[j] = gl + (uint32_t)j * L; sr[j] = iters; sa[j] = 0; sb[j] = kNone;
-    if (sc[j] < C && iters > 0) { sr[j] = 0; uint2 ab = *reinterpret_cast<const uint2*>(&cons[sc[j]]); sa[j] = ab.x; sb[j] = ab.y; }
+    if (sc[j] < C && iters > 0) { sr[j] = 0; uint2 ab = K.ab[sc[j]]; sa[j] = ab.x; sb[j] = ab.y; }
   }
   uint32_t spins = 0;
   for (;;) {
@@ -1198,6 +1218,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_flowk(float4* srec, CRec* cons
         if (pick == j) { c = sc[j]; round = sr[j]; ia = sa[j]; ib = sb[j]; }
       if (TRACE) trace[2 * ((size_t)round * C + c)] = wall_clock64();
       CRec rec = load_crec(&cons[c]);  // private to this lane; in flight together with the body records
+      const uint2 sw = K.succ[c];
       BodyDyn A = load_dyn_sc1(rs, ia);
       BodyDyn Bd = (ib == kNone) ? static_dyn() : load_dyn_sc1(rs, ib);
       solve_one(rec, A, Bd);
@@ -1208,7 +1229,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_flowk(float4* srec, CRec* cons
 #pragma unroll
       for (int side = 0; side < 2; ++side) {
         if (side == 1 && ib == kNone) break;
-        uint32_t w = side == 0 ? rec.succ_a : rec.succ_b;
+        uint32_t w = side == 0 ? sw.x : sw.y;
         if (round + (w >> 31) >= iters) continue;
         __hip_atomic_fetch_add(&arr[w & kSuccId], (w & kSuccTwo) ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -1216,7 +1237,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_flowk(float4* srec, CRec* cons
       // next node of this slot
       uint32_t cn = c + (uint32_t)KS * L;
       if (cn >= C) { cn = gl + (uint32_t)pick * L; ++round; }
-      if (cn != c && round < iters) { uint2 ab = *reinterpret_cast<const uint2*>(&cons[cn]); ia = ab.x; ib = ab.y; }
+      if (cn != c && round < iters) { uint2 ab = K.ab[cn]; ia = ab.x; ib = ab.y; }
 #pragma unroll
       for (int j = 0; j < KS; ++j)
         if (pick == j) { sc[j] = cn; sr[j] = round; sa[j] = ia; sb[j] = ib; }

@@ -538,6 +538,8 @@ struct mgf_world {
   DBuf<NContact> t_out, p_out;
   // solver
   DBuf<CRec> cons_nat;
+  DBuf<uint2> c_ab, c_succ;  // compact dependency links (ConsLinks)
+  DBuf<uint8_t> c_pred;
   DBuf<uint32_t> deg, adj_off, adj_fill, adj_list, order, lvl_off;
   DBuf<uint32_t> scalars;  // [0..2] rotating level counters, [3] err
   DBuf<SceneBounds> sb;
@@ -559,6 +561,7 @@ struct mgf_world {
   }
   uint32_t* d_cnt() { return scalars.p; }
   uint32_t* d_err() { return scalars.p + 3; }
+  ConsLinks links() { ConsLinks K; K.ab = c_ab.p; K.succ = c_succ.p; K.pred = c_pred.p; return K; }
   Frontier frontier() { Frontier F; F.order = order.p; F.lvl_off = lvl_off.p; F.cnt = d_cnt(); return F; }
 };
 
@@ -857,9 +860,19 @@ static mgf_status launch_terrain(mgf_world* w, int ka, const TerrainDev& M, cons
   return MGF_OK;
 }
 
-// Dependency links of the insertion-ordered list cons_nat[0..C): per-body adjacency (sorted),
-// circular successor words, in-degrees of iteration 0.  C is read on the device (sc->C); grids and
-// buffers are sized by `cap_c`.
+// Dependency links of the insertion-ordered list cons_nat[0..C) (ConsLinks).
+static mgf_status links_ensure(mgf_world* w, uint32_t cap_c) {
+  hipStream_t s = w->ctx->stream;
+  uint32_t n = w->n;
+  MGF_TRY(w->c_ab.ensure(std::max(cap_c, 1u), s)); MGF_TRY(w->c_succ.ensure(std::max(cap_c, 1u), s)); MGF_TRY(w->c_pred.ensure(2 * (size_t)std::max(cap_c, 1u), s));
+  MGF_TRY(w->deg.ensure(n + 1, s)); MGF_TRY(w->adj_off.ensure(n + 1, s)); MGF_TRY(w->adj_fill.ensure(n + 1, s));
+  MGF_TRY(w->adj_list.ensure(2 * (size_t)std::max(cap_c, 1u), s));
+  MGF_HIP_TRY(hipMemsetAsync(w->deg.p, 0, (n + 1) * 4, s));
+  MGF_HIP_TRY(hipMemsetAsync(w->adj_fill.p, 0, (n + 1) * 4, s));
+  return MGF_OK;
+}
+// c_ab and deg are filled (by the setup kernels, or k_links_from_records): sorted per-body adjacency, successor
+// words, predecessor flags.  C is read on the device (sc->C); grids and buffers are sized by `cap_c`.
 static mgf_status build_dag(mgf_world* w, uint32_t cap_c) {
   mgf_ctx* ctx = w->ctx;
   hipStream_t s = ctx->stream;
@@ -867,16 +880,10 @@ static mgf_status build_dag(mgf_world* w, uint32_t cap_c) {
   w->depth = 0;
   if (cap_c == 0) return MGF_OK;
   if (cap_c >= kSuccId) return fail(MGF_ERR_CAPACITY, "too many constraints");
-  MGF_TRY(w->deg.ensure(n + 1, s)); MGF_TRY(w->adj_off.ensure(n + 1, s)); MGF_TRY(w->adj_fill.ensure(n + 1, s));
-  MGF_TRY(w->adj_list.ensure(2 * (size_t)cap_c, s));
-  MGF_HIP_TRY(hipMemsetAsync(w->deg.p, 0, (n + 1) * 4, s));
-  MGF_HIP_TRY(hipMemsetAsync(w->adj_fill.p, 0, (n + 1) * 4, s));
-  k_adj_count<<<nblk(cap_c), kBlock, 0, s>>>(w->cons_nat.p, &w->sc.p->C, w->deg.p);
-  LAUNCH_CHECK();
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->deg.p, w->adj_off.p, (size_t)n + 1));
-  k_adj_fill<<<nblk(cap_c), kBlock, 0, s>>>(w->cons_nat.p, &w->sc.p->C, w->adj_off.p, w->adj_fill.p, w->adj_list.p);
+  k_adj_fill<<<nblk(cap_c), kBlock, 0, s>>>(w->c_ab.p, &w->sc.p->C, w->adj_off.p, w->adj_fill.p, w->adj_list.p);
   LAUNCH_CHECK();
-  k_chain<<<nblk(n), kBlock, 0, s>>>(n, w->cons_nat.p, w->adj_off.p, w->adj_list.p);
+  k_chain<<<nblk(n), kBlock, 0, s>>>(n, w->links(), w->adj_off.p, w->adj_list.p);
   LAUNCH_CHECK();
   return MGF_OK;
 }
@@ -1021,13 +1028,14 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   k_caps_constraints<<<1, 1, 0, s>>>(w->base.p + n, w->tbase.p + n, cap_c, sc);
   LAUNCH_CHECK();
   MGF_TRY(w->cons_nat.ensure(cap_c, s));
+  MGF_TRY(links_ensure(w, cap_c));
   if (M.n_nodes) {
     k_setup_terrain<<<nblk(cap_t), kBlock, 0, s>>>(B, M, sc, w->t_owner.p, w->t_nc.p, w->t_pre.p, w->t_out.p, w->base.p, dt, w->params.baumgarte,
-                                                   w->params.penetration_slop, w->cons_nat.p);
+                                                   w->params.penetration_slop, w->cons_nat.p, w->c_ab.p, w->deg.p);
     LAUNCH_CHECK();
   }
   k_setup_pairs<<<nblk(cap_p), kBlock, 0, s>>>(B, sc, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_pre.p, w->p_out.p, w->base.p, dt,
-                                               w->params.baumgarte, w->params.penetration_slop, w->cons_nat.p);
+                                               w->params.baumgarte, w->params.penetration_slop, w->cons_nat.p, w->c_ab.p, w->deg.p);
   LAUNCH_CHECK();
   MGF_TRY(build_dag(w, cap_c));
   MGF_HIP_TRY(hipEventRecord(w->ev[4], s));
@@ -1206,7 +1214,7 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
   uint32_t* abort_flag = w->d_err() + 2;
   unsigned g = std::min<unsigned>((unsigned)grid, std::max(1u, nblk(cap_c)));
   MGF_TRY(w->flow_arr.ensure(std::max(cap_c, 1u), s));
-  k_flow_init<<<std::max(1u, nblk(cap_c)), kBlock, 0, s>>>(C_ptr, w->cons_nat.p, w->flow_arr.p, abort_flag);
+  k_flow_init<<<std::max(1u, nblk(cap_c)), kBlock, 0, s>>>(C_ptr, w->links(), w->flow_arr.p, abort_flag);
   LAUNCH_CHECK();
   const bool timed = w->opt_time_solver_kernels != 0;
   if (!w->solve_pending) w->kev_used = 0;  // a tiled tick enqueues several launches before it reads the events
@@ -1222,11 +1230,11 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
   const uint32_t spin_limit = 4u << 20;
   const int sleep = (int)w->opt_flow_sleep;
   if (kslots) {
-    if (trace) k_solve_flowk<4, true><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, trace);
-    else k_solve_flowk<4, false><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, nullptr);
+    if (trace) k_solve_flowk<4, true><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->links(), w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, trace);
+    else k_solve_flowk<4, false><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->links(), w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, nullptr);
   } else {
-    if (trace) k_solve_flow<true><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, trace);
-    else k_solve_flow<false><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, nullptr);
+    if (trace) k_solve_flow<true><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->links(), w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, trace);
+    else k_solve_flow<false><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->links(), w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, nullptr);
   }
   LAUNCH_CHECK();
   if (timed) { MGF_HIP_TRY(hipEventRecord(w->kev[w->kev_used + 1], s)); w->kev_used += 2; }
@@ -1251,7 +1259,7 @@ static mgf_status solve_frontier(mgf_world* w, int32_t iters) {
   if (w->lvl_cap == 0) { w->lvl_cap = 1u << 16; MGF_TRY(w->lvl_off.ensure(w->lvl_cap + 4, s)); }
   Frontier F = w->frontier();
   MGF_HIP_TRY(hipMemsetAsync(w->scalars.p, 0, 12, s));
-  k_frontier0<<<std::min<unsigned>(nblk(C), 1024u), kBlock, 0, s>>>(C, w->cons_nat.p, F);
+  k_frontier0<<<std::min<unsigned>(nblk(C), 1024u), kBlock, 0, s>>>(C, w->cons_nat.p, w->links(), F);
   LAUNCH_CHECK();
   uint32_t r = 0;
   // grid: frontiers hold roughly C / (per-iteration depth) constraints; grid-stride covers the rest
@@ -1262,7 +1270,7 @@ static mgf_status solve_frontier(mgf_world* w, int32_t iters) {
     if (r + batch + 2 > w->lvl_cap) return fail(MGF_ERR_CAPACITY, "constraint dependency graph deeper than 65536 launches");
     for (uint32_t k = 0; k < batch; ++k) {
       MGF_TRY(tick());
-      k_solve<<<g0, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, F, r + k, (uint32_t)iters);
+      k_solve<<<g0, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->links(), F, r + k, (uint32_t)iters);
       LAUNCH_CHECK();
       MGF_TRY(tick());
       w->stats.solver_kernel_launches++;
@@ -1467,8 +1475,6 @@ extern "C" mgf_status mgf_world_set_constraints(mgf_world* w, const mgf_constrai
     for (int k = 0; k < 5; ++k) memcpy(dst[k], src[k], 12);
     r.bias = c.bias; r.nmass = c.normal_mass; r.tmass0 = c.tangent_mass0; r.tmass1 = c.tangent_mass1; r.nimp = c.normal_impulse;
     r.friction = c.friction;
-    r.succ_a = kNone; r.succ_b = kNone;
-    r.ta = r.da = r.tb = r.db = 0;
     h[(size_t)i] = r;
   }
   w->C = (uint32_t)n; w->Ct = 0;
@@ -1480,6 +1486,11 @@ extern "C" mgf_status mgf_world_set_constraints(mgf_world* w, const mgf_constrai
   memset(&hc, 0, sizeof(hc));
   hc.C = hc.need_C = w->C;
   MGF_TRY(h2d(w->ctx, w->sc.p, &hc, 1));
+  MGF_TRY(links_ensure(w, w->C));
+  if (w->C) {
+    k_links_from_records<<<nblk(w->C), kBlock, 0, w->ctx->stream>>>(w->cons_nat.p, w->C, w->c_ab.p, w->deg.p);
+    LAUNCH_CHECK();
+  }
   MGF_TRY(build_dag(w, w->C));
   w->constraints_ready = true;
   MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
