@@ -60,7 +60,7 @@ struct Bodies {
   float4* fb_r;
 };
 
-struct SceneBounds { int lo[3]; int hi[3]; uint32_t n_refits; uint32_t pad; };  // ordered-int encoded floats
+struct SceneBounds { int lo[3]; int hi[3]; uint32_t n_refits; uint32_t pad; int rmax[3]; uint32_t pad2; };  // ordered-int encoded floats; rmax = largest fat half extent
 
 __device__ __forceinline__ int f_ord(float f) { int i = __builtin_bit_cast(int, f); return i >= 0 ? i : (i ^ 0x7FFFFFFF); }
 __host__ __device__ __forceinline__ float ord_f(int i) { int j = i >= 0 ? i : (i ^ 0x7FFFFFFF); return __builtin_bit_cast(float, j); }
@@ -135,25 +135,28 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
 
 // Scene bounds of the fat-box centres (Morton quantisation): grid-stride, block reduce in LDS,
 // one atomic per block and axis.
-__global__ __launch_bounds__(kBlock) void k_scene_bounds(const float4* fb_c, uint32_t n, SceneBounds* sb) {
+__global__ __launch_bounds__(kBlock) void k_scene_bounds(const float4* fb_c, const float4* fb_r, uint32_t n, SceneBounds* sb) {
   int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  int rm[3] = {0, 0, 0};  // half extents are >= 0: plain int order
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    float4 c = fb_c[i];
+    float4 c = fb_c[i], r = fb_r[i];
     int o[3] = {f_ord(c.x), f_ord(c.y), f_ord(c.z)};
-    for (int k = 0; k < 3; ++k) { lo[k] = min(lo[k], o[k]); hi[k] = max(hi[k], o[k]); }
+    int e[3] = {f_ord(r.x), f_ord(r.y), f_ord(r.z)};
+    for (int k = 0; k < 3; ++k) { lo[k] = min(lo[k], o[k]); hi[k] = max(hi[k], o[k]); rm[k] = max(rm[k], e[k]); }
   }
-  __shared__ int s_lo[3][kBlock / 64], s_hi[3][kBlock / 64];
+  __shared__ int s_lo[3][kBlock / 64], s_hi[3][kBlock / 64], s_rm[3][kBlock / 64];
   for (int k = 0; k < 3; ++k) {
-    int a = lo[k], b = hi[k];
-    for (int off = 32; off > 0; off >>= 1) { a = min(a, __shfl_xor(a, off)); b = max(b, __shfl_xor(b, off)); }
-    if ((threadIdx.x & 63) == 0) { s_lo[k][threadIdx.x >> 6] = a; s_hi[k][threadIdx.x >> 6] = b; }
+    int a = lo[k], b = hi[k], c = rm[k];
+    for (int off = 32; off > 0; off >>= 1) { a = min(a, __shfl_xor(a, off)); b = max(b, __shfl_xor(b, off)); c = max(c, __shfl_xor(c, off)); }
+    if ((threadIdx.x & 63) == 0) { s_lo[k][threadIdx.x >> 6] = a; s_hi[k][threadIdx.x >> 6] = b; s_rm[k][threadIdx.x >> 6] = c; }
   }
   __syncthreads();
   if (threadIdx.x < 3) {
-    int k = threadIdx.x, a = s_lo[k][0], b = s_hi[k][0];
-    for (int w = 1; w < kBlock / 64; ++w) { a = min(a, s_lo[k][w]); b = max(b, s_hi[k][w]); }
+    int k = threadIdx.x, a = s_lo[k][0], b = s_hi[k][0], c = s_rm[k][0];
+    for (int w = 1; w < kBlock / 64; ++w) { a = min(a, s_lo[k][w]); b = max(b, s_hi[k][w]); c = max(c, s_rm[k][w]); }
     atomicMin(&sb->lo[k], a);
     atomicMax(&sb->hi[k], b);
+    atomicMax(&sb->rmax[k], c);
   }
 }
 
@@ -165,7 +168,8 @@ __global__ __launch_bounds__(kBlock) void k_refresh_einfo(Bodies B, uint32_t n) 
 __global__ void k_reset_step(SceneBounds* sb, uint32_t* err) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     for (int k = 0; k < 3; ++k) { sb->lo[k] = 0x7FFFFFFF; sb->hi[k] = (int)0x80000000; }
-    sb->n_refits = 0; sb->pad = 0;
+    sb->n_refits = 0; sb->pad = 0; sb->pad2 = 0;
+    for (int k = 0; k < 3; ++k) sb->rmax[k] = 0;
     err[0] = 0; err[1] = 0;  // traversal stack overflow, candidate row overflow
   }
 }
@@ -180,19 +184,19 @@ __device__ __forceinline__ uint32_t expand10(uint32_t v) {
   v = (v * 0x00000005u) & 0x49249249u;
   return v;
 }
+// 10-bit coordinate of the Morton code: monotone in v (the grid broadphase relies on that)
+__device__ __forceinline__ uint32_t morton_quant(float v, float lo, float hi) {
+  float ext = hi - lo;
+  float t = ext > 0.0f ? (v - lo) / ext : 0.0f;
+  int qv = (int)(t * 1023.0f);
+  return (uint32_t)(qv < 0 ? 0 : (qv > 1023 ? 1023 : qv));
+}
 __global__ __launch_bounds__(kBlock) void k_morton(const float4* fb_c, uint32_t n, const SceneBounds* sb, uint32_t* keys, uint32_t* vals) {
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   V3 c = xyz(fb_c[i]);
   uint32_t code = 0;
-  for (int k = 0; k < 3; ++k) {
-    float lo = ord_f(sb->lo[k]), hi = ord_f(sb->hi[k]);
-    float ext = hi - lo;
-    float t = ext > 0.0f ? (at(c, k) - lo) / ext : 0.0f;
-    int qv = (int)(t * 1023.0f);
-    qv = qv < 0 ? 0 : (qv > 1023 ? 1023 : qv);
-    code |= expand10((uint32_t)qv) << (2 - k);
-  }
+  for (int k = 0; k < 3; ++k) code |= expand10(morton_quant(at(c, k), ord_f(sb->lo[k]), ord_f(sb->hi[k]))) << (2 - k);
   keys[i] = code;
   vals[i] = i;
 }
@@ -437,15 +441,16 @@ struct StepCounts {
   uint32_t bins[6];                            // candidates per shape-pair type (scenes mixing spheres and capsules)
   uint32_t pad;
 };
-constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u;
+constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u, kFailGridWide = 8u;
 
 __global__ void k_caps_candidates(const uint32_t* mt, const uint32_t* mp, uint32_t cap_t, uint32_t cap_p, const uint32_t* row_overflow,
-                                  StepCounts* sc) {
+                                  const uint32_t* grid_wide, StepCounts* sc) {
   StepCounts r;
   r.need_Mt = *mt; r.need_Mp = *mp; r.need_C = 0; r.need_Ct = 0;
   r.fail = 0;
   if (r.need_Mt > cap_t || r.need_Mp > cap_p) r.fail |= kFailCandCap;
   if (row_overflow && *row_overflow) r.fail |= kFailRowOverflow;
+  if (grid_wide && *grid_wide) r.fail |= kFailGridWide;
   r.Mt = r.fail ? 0u : r.need_Mt; r.Mp = r.fail ? 0u : r.need_Mp; r.C = 0; r.Ct = 0;
   for (int k = 0; k < 6; ++k) r.bins[k] = 0;
   r.pad = 0;
@@ -625,6 +630,88 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_rows(Bodies B, uint32_t n, 
       k = (k - 1) >> 2;
       --lvl;
       fresh = false;
+    }
+  }
+  if (sub == 0) {
+    p_cnt[i] = np;
+    if (np > (uint32_t)kRowCap) *overflow = 1u;
+  }
+}
+
+// Partner bodies per body without a tree walk.  The leaf level of the Morton-cell tree IS a uniform grid: cell
+// (cx, cy, cz) is the 2L-bit Morton prefix of its interleaved coordinates, and cell_lo/cell_hi give its bodies.
+// A body j can only be accepted by query i (tight_i overlaps fat_j) if its fat-box centre lies within
+// tight_i grown by the largest fat half extent of the scene (SceneBounds::rmax), so the query enumerates the
+// cells of that region directly: ~50 independent 8-byte look-ups and as many independent leaf records, two
+// dependent memory round trips instead of the ~30 of the top-down walk.  8 lanes share a query, one cell per
+// lane per round.  Scenes whose largest body spans many cells raise `too_wide` and the host switches to the
+// tree walk (k_pair_rows) - the accepted set is the same either way (the reference's predicate on the leaf
+// records).
+constexpr uint32_t kGridMaxCells = 512;
+__global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, uint32_t n_owned, Lbvh T, const SceneBounds* sb, float pad_abs,
+                                                          uint32_t* rows_p, uint32_t* p_cnt, uint32_t* overflow, uint32_t* too_wide) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7;
+  const int gbase = lane & ~7;
+  uint32_t kq = xcd_logical_block_coop() * (kCoopBlock / kCoopLanes) + (threadIdx.x >> 3);
+  if (kq >= n) return;  // whole group leaves together
+  uint32_t i = T.sidx[kq];
+  uint32_t np = 0;
+  if (i != 0 && T.n >= 2) {  // world.rs:256
+    Box q; q.c = xyz(B.tb_c[i]); q.r = xyz(B.tb_r[i]);
+    float pad = pad_abs + 1e-5f * (fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z);
+    const uint32_t P = 2u * T.levels;
+    const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};  // prefix bits per axis (x is the most significant)
+    uint32_t ca[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float lo = ord_f(sb->lo[k]), hi = ord_f(sb->hi[k]), rm = ord_f(sb->rmax[k]);
+      float a = at(q.c, k) - at(q.r, k) - rm - pad, b = at(q.c, k) + at(q.r, k) + rm + pad;
+      uint32_t c0 = morton_quant(a, lo, hi) >> (10u - nb[k]), c1 = morton_quant(b, lo, hi) >> (10u - nb[k]);
+      ca[k] = c0; d[k] = c1 - c0 + 1u;
+    }
+    const uint32_t ncell = d[0] * d[1] * d[2];
+    if (ncell > kGridMaxCells) {
+      if (sub == 0) *too_wide = 1u;
+    } else {
+      uint32_t* row = rows_p + (size_t)i * kRowCap;
+      const int shift = kMortonBits - (int)P;
+      for (uint32_t cb = 0; cb < ncell; cb += kCoopLanes) {
+        uint32_t idx = cb + (uint32_t)sub;
+        uint32_t p0 = 0, p1 = 0;
+        if (idx < ncell) {
+          uint32_t cz = idx % d[2], t = idx / d[2];
+          uint32_t cy = t % d[1], cx = t / d[1];
+          uint32_t code = (expand10((ca[0] + cx) << (10u - nb[0])) << 2) | (expand10((ca[1] + cy) << (10u - nb[1])) << 1) |
+                          expand10((ca[2] + cz) << (10u - nb[2]));
+          uint32_t cell = code >> shift;
+          p0 = T.cell_lo[cell]; p1 = T.cell_hi[cell];
+        }
+        // every lane walks its own cell's bodies; the group stays together for the ballots
+        for (;;) {
+          bool more = p0 < p1;
+          unsigned long long mb = __ballot(more);
+          if (((uint32_t)(mb >> gbase) & 255u) == 0u) break;
+          bool hit = false;
+          uint32_t j = 0;
+          if (more) {
+            LeafRec lr = T.leaves[p0];
+            j = f2u(lr.c.w);
+            if (j < i && j < n_owned) {  // world.rs:266; ghost-ghost skipped
+              Box fb; fb.c = xyz(lr.c); fb.r = xyz(lr.r);
+              hit = box_overlaps(q, fb);  // the reference's own acceptance test (bvh.rs:297)
+            }
+            ++p0;
+          }
+          unsigned long long hb = __ballot(hit);
+          uint32_t gm = (uint32_t)(hb >> gbase) & 255u;
+          if (hit) {
+            uint32_t slot = np + __popc(gm & ((1u << sub) - 1u));
+            if (slot < (uint32_t)kRowCap) row[slot] = j;
+          }
+          np += __popc(gm);
+        }
+      }
     }
   }
   if (sub == 0) {

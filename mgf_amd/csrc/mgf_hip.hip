@@ -525,6 +525,8 @@ struct mgf_world {
   uint32_t cap_t = 0, cap_p = 0, cap_c = 0;
   uint64_t n_cap_retries = 0;
   bool tick_two_pass = false;
+  bool grid_too_wide = false;       // sticky: the largest body spans too many Morton cells for the grid broadphase
+  int64_t opt_broadphase_tree = 0;  // 1 = always walk the tree (k_pair_rows) instead of enumerating grid cells
   int64_t opt_flow_blocks_per_cu = 0, opt_flow_sleep = 2;
   int flowk_grid = 0;
   int64_t opt_debug_bvh = 0, opt_flow_trace = 0;
@@ -595,6 +597,7 @@ extern "C" mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_
   if (!w || !key) return fail(MGF_ERR_INVALID, "NULL argument");
   if (!strcmp(key, "time_solver_kernels")) { w->opt_time_solver_kernels = value; return MGF_OK; }
   if (!strcmp(key, "two_pass_candidates")) { w->opt_two_pass = value; return MGF_OK; }
+  if (!strcmp(key, "broadphase_tree")) { w->opt_broadphase_tree = value; return MGF_OK; }
   if (!strcmp(key, "flow_trace")) { w->opt_flow_trace = value; return MGF_OK; }
   if (!strcmp(key, "debug_bvh")) { w->opt_debug_bvh = value; return MGF_OK; }
   if (!strcmp(key, "solver_mode")) { w->opt_solver_mode = value; return MGF_OK; }
@@ -926,6 +929,7 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   if (w->cap_p == 0) { w->cap_p = std::max(4 * n, 1024u); w->cap_t = std::max(2 * n, 1024u); w->cap_c = std::max(4 * n, 1024u); }
   const uint32_t cap_t = w->cap_t, cap_p = w->cap_p, cap_c = w->cap_c;
   MGF_HIP_TRY(hipMemsetAsync(w->d_err() + 1, 0, 4, s));  // row-overflow flag (re-armed for a re-run inside the tick)
+  MGF_HIP_TRY(hipMemsetAsync(w->d_err() + 3, 0, 4, s));  // grid-too-wide flag
   // 2. linear BVH over the fat AABBs
   uint32_t levels = 4;  // 4^levels Morton cells, about one body per cell
   while (((uint64_t)1 << (2 * levels)) < n && levels < (uint32_t)kMortonBits / 2) ++levels;
@@ -937,7 +941,7 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   MGF_TRY(w->sub2_lo.ensure(nblocks / 4 + 1, s)); MGF_TRY(w->sub2_hi.ensure(nblocks / 4 + 1, s));
   MGF_HIP_TRY(hipMemsetAsync(w->cell_lo.p, 0, (size_t)cells * 4, s));
   MGF_HIP_TRY(hipMemsetAsync(w->cell_hi.p, 0, (size_t)cells * 4, s));
-  k_scene_bounds<<<std::min<unsigned>(nblk(n), 256u), kBlock, 0, s>>>(w->fb_c.p, n, w->sb.p);
+  k_scene_bounds<<<std::min<unsigned>(nblk(n), 256u), kBlock, 0, s>>>(w->fb_c.p, w->fb_r.p, n, w->sb.p);
   LAUNCH_CHECK();
   k_morton<<<nblk(n), kBlock, 0, s>>>(w->fb_c.p, n, w->sb.p, w->mkeys.p, w->mvals.p);
   LAUNCH_CHECK();
@@ -953,9 +957,13 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   }
   k_lbvh_leaves<<<nblk(n), kBlock, 0, s>>>(T, w->fb_c.p, w->fb_r.p);
   LAUNCH_CHECK();
-  k_lbvh_low<<<nblocks, kBlock, 0, s>>>(T, w->sub_lo.p, w->sub_hi.p);
-  LAUNCH_CHECK();
-  if (levels > 4) { k_lbvh_top<<<1, 1024, 0, s>>>(T, w->sub_lo.p, w->sub_hi.p, w->sub2_lo.p, w->sub2_hi.p); LAUNCH_CHECK(); }
+  const bool two_pass = w->opt_two_pass != 0 || w->tick_two_pass;
+  const bool use_grid = !two_pass && !w->opt_broadphase_tree && !w->grid_too_wide;
+  if (!use_grid) {  // inner nodes are only needed by the tree walks
+    k_lbvh_low<<<nblocks, kBlock, 0, s>>>(T, w->sub_lo.p, w->sub_hi.p);
+    LAUNCH_CHECK();
+    if (levels > 4) { k_lbvh_top<<<1, 1024, 0, s>>>(T, w->sub_lo.p, w->sub_hi.p, w->sub2_lo.p, w->sub2_hi.p); LAUNCH_CHECK(); }
+  }
   MGF_HIP_TRY(hipEventRecord(w->ev[1], s));
   // 3. candidates
   TerrainDev M;
@@ -967,9 +975,8 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   MGF_TRY(w->t_nc.ensure(cap_t, s)); MGF_TRY(w->p_nc.ensure(cap_p, s));
   MGF_TRY(w->t_pre.ensure(cap_t, s)); MGF_TRY(w->p_pre.ensure(cap_p, s));
   MGF_TRY(w->t_out.ensure(2 * (size_t)cap_t, s)); MGF_TRY(w->p_out.ensure(cap_p, s));
-  const bool two_pass = w->opt_two_pass != 0 || w->tick_two_pass;
   if (!two_pass) {
-    // fast path: one traversal, hits written to fixed-capacity rows
+    // fast path: one pass, hits written to fixed-capacity rows
     MGF_TRY(w->rows.ensure((size_t)n * kRowCap, s));
     MGF_TRY(w->rows_t.ensure((size_t)n * kRowCapT, s));
     MGF_HIP_TRY(hipMemsetAsync(w->t_cnt.p, 0, (size_t)(n + 1) * 4, s));  // ghosts have no terrain row
@@ -980,7 +987,8 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
     {
       const uint32_t per_block = kCoopBlock / kCoopLanes;
       const uint32_t grid = 8 * (((n + per_block - 1) / per_block + 7) / 8);
-      k_pair_rows<<<grid, kCoopBlock, 0, s>>>(B, n, w->n_owned, T, 1e-3f, w->rows.p, w->p_cnt.p, w->d_err() + 1);
+      if (use_grid) k_pair_grid<<<grid, kCoopBlock, 0, s>>>(B, n, w->n_owned, T, w->sb.p, 1e-3f, w->rows.p, w->p_cnt.p, w->d_err() + 1, w->d_err() + 3);
+      else k_pair_rows<<<grid, kCoopBlock, 0, s>>>(B, n, w->n_owned, T, 1e-3f, w->rows.p, w->p_cnt.p, w->d_err() + 1);
       LAUNCH_CHECK();
     }
   } else {
@@ -989,7 +997,7 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   }
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->t_cnt.p, w->t_off.p, (size_t)n + 1));
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->p_cnt.p, w->p_off.p, (size_t)n + 1));
-  k_caps_candidates<<<1, 1, 0, s>>>(w->t_off.p + n, w->p_off.p + n, cap_t, cap_p, two_pass ? nullptr : w->d_err() + 1, sc);
+  k_caps_candidates<<<1, 1, 0, s>>>(w->t_off.p + n, w->p_off.p + n, cap_t, cap_p, two_pass ? nullptr : w->d_err() + 1, use_grid ? w->d_err() + 3 : nullptr, sc);
   LAUNCH_CHECK();
   if (two_pass) {
     k_candidates<true><<<8 * xcd_blocks_per(n), kBlock, 0, s>>>(B, n, w->n_owned, T, M, 1e-3f, nullptr, nullptr, w->t_off.p, w->p_off.p, w->t_cand.p, w->t_owner.p,
@@ -1059,7 +1067,8 @@ static mgf_status collide_finish(mgf_world* w, bool* retry) {
   w->stats.n_refits = reinterpret_cast<SceneBounds*>(pin + 32)->n_refits;
   if (pin[64]) return fail(MGF_ERR_CAPACITY, "BVH traversal stack overflow");
   auto grown = [](uint32_t need) { return (uint32_t)std::min<uint64_t>((uint64_t)need + need / 2 + 1024, 0x7FFFFFF0ull); };
-  if (h.fail & kFailRowOverflow) { w->tick_two_pass = true; w->n_row_overflows++; *retry = true; }
+  if (h.fail & kFailGridWide) { w->grid_too_wide = true; *retry = true; }
+  else if (h.fail & kFailRowOverflow) { w->tick_two_pass = true; w->n_row_overflows++; *retry = true; }
   if (h.fail & kFailCandCap) {
     if (h.need_Mt > w->cap_t) w->cap_t = grown(h.need_Mt);
     if (h.need_Mp > w->cap_p) w->cap_p = grown(h.need_Mp);

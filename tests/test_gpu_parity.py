@@ -301,6 +301,25 @@ def test_list_capacity_miss_reruns_collide_exactly(ctx, mode):
     compare_constraints(a.constraints(), b.constraints(), check_impulse=True)
 
 
+@pytest.mark.parametrize("scene_name", ["pile16", "capsules", "mixed"])
+def test_grid_and_tree_broadphase_agree(ctx, scene_name):
+    """Default broadphase = direct enumeration of Morton cells (k_pair_grid); option broadphase_tree walks the
+    4-ary tree (k_pair_rows).  Same acceptance predicate, so the same candidates and the same tick."""
+    import mgf_amd
+    from mgf_amd import scenes
+    scene = {"pile16": lambda: scenes.sphere_pile(16, 16, 16), "capsules": lambda: scenes.capsule_field(10, 3, 10),
+             "mixed": lambda: scenes.capsule_field(8, 3, 8, sphere_fraction=0.5)}[scene_name]()
+    a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
+    b.set_option("broadphase_tree", 1)
+    for _ in range(30):
+        sa, sb = a.step(float(scene["dt"]), 10), b.step(float(scene["dt"]), 10)
+        assert (sa.n_constraints, sa.n_pair_candidates, sa.n_terrain_candidates) == (sb.n_constraints, sb.n_pair_candidates, sb.n_terrain_candidates)
+    assert sa.n_pair_candidates > 0
+    s1, s2 = a.state(), b.state()
+    for k in s1:
+        assert bits_equal(s1[k], s2[k]), k
+
+
 def test_two_pass_and_row_paths_agree(ctx):
     import mgf_amd
     from mgf_amd import scenes
