@@ -191,14 +191,30 @@ __device__ __forceinline__ uint32_t morton_quant(float v, float lo, float hi) {
   int qv = (int)(t * 1023.0f);
   return (uint32_t)(qv < 0 ? 0 : (qv > 1023 ? 1023 : qv));
 }
-__global__ __launch_bounds__(kBlock) void k_morton(const float4* fb_c, uint32_t n, const SceneBounds* sb, uint32_t* keys, uint32_t* vals) {
+// Counting sort of the bodies into Morton cells (a cell = one 2L-bit prefix of the 30-bit code): cell of every
+// body + its arrival rank inside the cell.  After a scan of the per-cell counts k_scatter_leaves places body i
+// at cell_lo[cell] + rank.  The order INSIDE a cell is arrival order (it varies from run to run); nothing
+// downstream depends on it - candidate rows are sorted by body index before they are used.
+__global__ __launch_bounds__(kBlock) void k_morton_count(const float4* fb_c, uint32_t n, const SceneBounds* sb, int shift, uint32_t* cell_of,
+                                                         uint32_t* rank, uint32_t* cell_cnt) {
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   V3 c = xyz(fb_c[i]);
   uint32_t code = 0;
   for (int k = 0; k < 3; ++k) code |= expand10(morton_quant(at(c, k), ord_f(sb->lo[k]), ord_f(sb->hi[k]))) << (2 - k);
-  keys[i] = code;
-  vals[i] = i;
+  uint32_t cell = code >> shift;
+  cell_of[i] = cell;
+  rank[i] = atomicAdd(&cell_cnt[cell], 1u);
+}
+
+// Zero several small arrays with one launch (instead of one fill kernel each).
+struct ZeroList { uint32_t* p[6]; uint32_t words[6]; };
+__global__ __launch_bounds__(kBlock) void k_zero_many(ZeroList z) {
+  for (int a = 0; a < 6; ++a) {
+    uint32_t* p = z.p[a];
+    if (!p) continue;
+    for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < z.words[a]; e += gridDim.x * kBlock) p[e] = 0u;
+  }
 }
 
 // Linear BVH as an implicit complete 4-ary tree over MORTON CELLS.  A leaf is the cell of one 2L-bit
@@ -214,10 +230,8 @@ struct LeafRec { float4 c, r; };           // fat box centre | body index, half 
 struct Lbvh {
   QNode* nodes;        // (4^levels - 1) / 3 internal nodes
   LeafRec* leaves;     // n records in Morton order
-  const uint32_t* sidx;
-  const uint32_t* skeys;
-  uint32_t* cell_lo;   // 4^levels cells: first body / end of each cell's range
-  uint32_t* cell_hi;
+  uint32_t* sidx;      // body index of every leaf record
+  uint32_t* cell_lo;   // 4^levels + 1 entries: cell c holds the leaf records [cell_lo[c], cell_lo[c + 1])
   uint32_t n;          // live bodies
   uint32_t levels;     // internal levels L >= 4; 4^L leaf cells
   uint32_t* err;
@@ -232,17 +246,15 @@ __device__ __forceinline__ void box_min_max(V3& lo, V3& hi, V3 l, V3 h) {
   hi = mk3(fmaxf(hi.x, h.x), fmaxf(hi.y, h.y), fmaxf(hi.z, h.z));
 }
 
-// Sorted bodies -> leaf records + cell ranges (cell_lo/cell_hi pre-set to 0: empty cells have lo == hi).
-__global__ __launch_bounds__(kBlock) void k_lbvh_leaves(Lbvh T, const float4* fb_c, const float4* fb_r) {
-  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-  if (p >= T.n) return;
-  uint32_t body = T.sidx[p];
+// Bodies -> leaf records in cell order (counting sort, second half).
+__global__ __launch_bounds__(kBlock) void k_scatter_leaves(Lbvh T, const float4* fb_c, const float4* fb_r, const uint32_t* cell_of,
+                                                           const uint32_t* rank) {
+  uint32_t body = blockIdx.x * kBlock + threadIdx.x;
+  if (body >= T.n) return;
+  uint32_t p = T.cell_lo[cell_of[body]] + rank[body];
   LeafRec lr; lr.c = mk4(xyz(fb_c[body]), u2f(body)); lr.r = mk4(xyz(fb_r[body]), 0.0f);
   T.leaves[p] = lr;
-  const int shift = kMortonBits - 2 * (int)T.levels;
-  uint32_t cell = T.skeys[p] >> shift;
-  if (p == 0 || (T.skeys[p - 1] >> shift) != cell) T.cell_lo[cell] = p;
-  if (p + 1 == T.n || (T.skeys[p + 1] >> shift) != cell) T.cell_hi[cell] = p + 1;
+  T.sidx[p] = body;
 }
 
 // One block per 256 consecutive cells: the 4 internal levels above them.
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void k_lbvh_low(Lbvh T, float4* sub_lo, flo
   const int t = threadIdx.x;
   uint32_t g = blockIdx.x * kBlock + t;
   V3 lo = mk3(kInf, kInf, kInf), hi = mk3(-kInf, -kInf, -kInf);
-  uint32_t b0 = T.cell_lo[g], b1 = T.cell_hi[g];
+  uint32_t b0 = T.cell_lo[g], b1 = T.cell_lo[g + 1];
   for (uint32_t p = b0; p < b1; ++p) {
     LeafRec lr = T.leaves[p];
     box_min_max(lo, hi, xyz(lr.c) - xyz(lr.r), xyz(lr.c) + xyz(lr.r));
@@ -639,7 +651,7 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_rows(Bodies B, uint32_t n, 
 }
 
 // Partner bodies per body without a tree walk.  The leaf level of the Morton-cell tree IS a uniform grid: cell
-// (cx, cy, cz) is the 2L-bit Morton prefix of its interleaved coordinates, and cell_lo/cell_hi give its bodies.
+// (cx, cy, cz) is the 2L-bit Morton prefix of its interleaved coordinates, and cell_lo gives its bodies.
 // A body j can only be accepted by query i (tight_i overlaps fat_j) if its fat-box centre lies within
 // tight_i grown by the largest fat half extent of the scene (SceneBounds::rmax), so the query enumerates the
 // cells of that region directly: ~50 independent 8-byte look-ups and as many independent leaf records, two
@@ -685,7 +697,7 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, 
           uint32_t code = (expand10((ca[0] + cx) << (10u - nb[0])) << 2) | (expand10((ca[1] + cy) << (10u - nb[1])) << 1) |
                           expand10((ca[2] + cz) << (10u - nb[2]));
           uint32_t cell = code >> shift;
-          p0 = T.cell_lo[cell]; p1 = T.cell_hi[cell];
+          p0 = T.cell_lo[cell]; p1 = T.cell_lo[cell + 1];
         }
         // every lane walks its own cell's bodies; the group stays together for the ballots
         for (;;) {

@@ -507,11 +507,11 @@ struct mgf_world {
   // terrain (copy of the caller's Mesh)
   std::unique_ptr<mgf_mesh> terrain;
   // broadphase
-  DBuf<uint32_t> mkeys, mvals, skeys, sidx;
+  DBuf<uint32_t> cell_of, cell_rank, sidx;
   DBuf<QNode> lnodes;
   DBuf<LeafRec> leaves;
   DBuf<float4> sub_lo, sub_hi, sub2_lo, sub2_hi;
-  DBuf<uint32_t> cell_lo, cell_hi;
+  DBuf<uint32_t> cell_lo, cell_cnt;
   DBuf<uint32_t> t_cnt, p_cnt, t_off, p_off, t_cand, t_owner, p_cand, p_owner, rows, rows_t;
   // 1 (default) = one persistent dataflow launch per Solver::solve (k_solve_flow);
   // 0 = one launch per frontier of the dependency graph (k_solve, the independent cross-check);
@@ -864,14 +864,16 @@ static mgf_status launch_terrain(mgf_world* w, int ka, const TerrainDev& M, cons
 }
 
 // Dependency links of the insertion-ordered list cons_nat[0..C) (ConsLinks).
-static mgf_status links_ensure(mgf_world* w, uint32_t cap_c) {
+static mgf_status links_ensure(mgf_world* w, uint32_t cap_c, bool zero = false) {
   hipStream_t s = w->ctx->stream;
   uint32_t n = w->n;
   MGF_TRY(w->c_ab.ensure(std::max(cap_c, 1u), s)); MGF_TRY(w->c_succ.ensure(std::max(cap_c, 1u), s)); MGF_TRY(w->c_pred.ensure(2 * (size_t)std::max(cap_c, 1u), s));
   MGF_TRY(w->deg.ensure(n + 1, s)); MGF_TRY(w->adj_off.ensure(n + 1, s)); MGF_TRY(w->adj_fill.ensure(n + 1, s));
   MGF_TRY(w->adj_list.ensure(2 * (size_t)std::max(cap_c, 1u), s));
-  MGF_HIP_TRY(hipMemsetAsync(w->deg.p, 0, (n + 1) * 4, s));
-  MGF_HIP_TRY(hipMemsetAsync(w->adj_fill.p, 0, (n + 1) * 4, s));
+  if (zero) {
+    MGF_HIP_TRY(hipMemsetAsync(w->deg.p, 0, (n + 1) * 4, s));
+    MGF_HIP_TRY(hipMemsetAsync(w->adj_fill.p, 0, (n + 1) * 4, s));
+  }
   return MGF_OK;
 }
 // c_ab and deg are filled (by the setup kernels, or k_links_from_records): sorted per-body adjacency, successor
@@ -928,26 +930,37 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   // first tick: room for a few candidates per body; later ticks: last tick's sizes plus slack (collide_finish)
   if (w->cap_p == 0) { w->cap_p = std::max(4 * n, 1024u); w->cap_t = std::max(2 * n, 1024u); w->cap_c = std::max(4 * n, 1024u); }
   const uint32_t cap_t = w->cap_t, cap_p = w->cap_p, cap_c = w->cap_c;
-  MGF_HIP_TRY(hipMemsetAsync(w->d_err() + 1, 0, 4, s));  // row-overflow flag (re-armed for a re-run inside the tick)
-  MGF_HIP_TRY(hipMemsetAsync(w->d_err() + 3, 0, 4, s));  // grid-too-wide flag
   // 2. linear BVH over the fat AABBs
   uint32_t levels = 4;  // 4^levels Morton cells, about one body per cell
   while (((uint64_t)1 << (2 * levels)) < n && levels < (uint32_t)kMortonBits / 2) ++levels;
   const uint32_t cells = 1u << (2 * levels), nblocks = cells / kBlock;
-  MGF_TRY(w->mkeys.ensure(n, s)); MGF_TRY(w->mvals.ensure(n, s)); MGF_TRY(w->skeys.ensure(n, s)); MGF_TRY(w->sidx.ensure(n, s));
+  MGF_TRY(w->cell_of.ensure(n, s)); MGF_TRY(w->cell_rank.ensure(n, s)); MGF_TRY(w->sidx.ensure(n, s));
   MGF_TRY(w->lnodes.ensure(qlevel_offset(levels), s)); MGF_TRY(w->leaves.ensure(n, s));
-  MGF_TRY(w->cell_lo.ensure(cells, s)); MGF_TRY(w->cell_hi.ensure(cells, s));
+  MGF_TRY(w->cell_lo.ensure((size_t)cells + 1, s)); MGF_TRY(w->cell_cnt.ensure((size_t)cells + 1, s));
   MGF_TRY(w->sub_lo.ensure(nblocks, s)); MGF_TRY(w->sub_hi.ensure(nblocks, s));
   MGF_TRY(w->sub2_lo.ensure(nblocks / 4 + 1, s)); MGF_TRY(w->sub2_hi.ensure(nblocks / 4 + 1, s));
-  MGF_HIP_TRY(hipMemsetAsync(w->cell_lo.p, 0, (size_t)cells * 4, s));
-  MGF_HIP_TRY(hipMemsetAsync(w->cell_hi.p, 0, (size_t)cells * 4, s));
+  MGF_TRY(w->t_cnt.ensure(n + 1, s)); MGF_TRY(w->p_cnt.ensure(n + 1, s)); MGF_TRY(w->t_off.ensure(n + 1, s)); MGF_TRY(w->p_off.ensure(n + 1, s));
+  MGF_TRY(w->cons_nat.ensure(cap_c, s));
+  MGF_TRY(links_ensure(w, cap_c));
+  {  // one launch clears every per-tick counter array
+    ZeroList z;
+    memset(&z, 0, sizeof(z));
+    z.p[0] = w->cell_cnt.p; z.words[0] = cells + 1;
+    z.p[1] = w->t_cnt.p; z.words[1] = n + 1;  // ghosts have no terrain row
+    z.p[2] = w->deg.p; z.words[2] = n + 1;
+    z.p[3] = w->adj_fill.p; z.words[3] = n + 1;
+    z.p[4] = w->d_err() + 1; z.words[4] = 1;  // row-overflow flag (re-armed for a re-run inside the tick)
+    z.p[5] = w->d_err() + 3; z.words[5] = 1;  // grid-too-wide flag
+    k_zero_many<<<256, kBlock, 0, s>>>(z);
+    LAUNCH_CHECK();
+  }
   k_scene_bounds<<<std::min<unsigned>(nblk(n), 256u), kBlock, 0, s>>>(w->fb_c.p, w->fb_r.p, n, w->sb.p);
   LAUNCH_CHECK();
-  k_morton<<<nblk(n), kBlock, 0, s>>>(w->fb_c.p, n, w->sb.p, w->mkeys.p, w->mvals.p);
+  k_morton_count<<<nblk(n), kBlock, 0, s>>>(w->fb_c.p, n, w->sb.p, kMortonBits - 2 * (int)levels, w->cell_of.p, w->cell_rank.p, w->cell_cnt.p);
   LAUNCH_CHECK();
-  MGF_TRY(prim_sort_pairs_u32(ctx, w->mkeys.p, w->skeys.p, w->mvals.p, w->sidx.p, n, kMortonBits));
+  MGF_TRY(prim_exclusive_scan_u32(ctx, w->cell_cnt.p, w->cell_lo.p, (size_t)cells + 1));
   Lbvh T;
-  T.nodes = w->lnodes.p; T.leaves = w->leaves.p; T.sidx = w->sidx.p; T.skeys = w->skeys.p; T.cell_lo = w->cell_lo.p; T.cell_hi = w->cell_hi.p;
+  T.nodes = w->lnodes.p; T.leaves = w->leaves.p; T.sidx = w->sidx.p; T.cell_lo = w->cell_lo.p;
   T.n = n; T.levels = levels; T.err = w->d_err();
   T.dbg = nullptr;
   if (w->opt_debug_bvh) {
@@ -955,7 +968,7 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
     MGF_HIP_TRY(hipMemsetAsync(w->dbg.p, 0, 32, s));
     T.dbg = w->dbg.p;
   }
-  k_lbvh_leaves<<<nblk(n), kBlock, 0, s>>>(T, w->fb_c.p, w->fb_r.p);
+  k_scatter_leaves<<<nblk(n), kBlock, 0, s>>>(T, w->fb_c.p, w->fb_r.p, w->cell_of.p, w->cell_rank.p);
   LAUNCH_CHECK();
   const bool two_pass = w->opt_two_pass != 0 || w->tick_two_pass;
   const bool use_grid = !two_pass && !w->opt_broadphase_tree && !w->grid_too_wide;
@@ -969,7 +982,6 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   TerrainDev M;
   if (w->terrain && !w->terrain->m.tree.empty()) M = w->terrain->dev(w->d_err());
   else { memset(&M, 0, sizeof(M)); }
-  MGF_TRY(w->t_cnt.ensure(n + 1, s)); MGF_TRY(w->p_cnt.ensure(n + 1, s)); MGF_TRY(w->t_off.ensure(n + 1, s)); MGF_TRY(w->p_off.ensure(n + 1, s));
   MGF_TRY(w->t_cand.ensure(cap_t, s)); MGF_TRY(w->t_owner.ensure(cap_t, s));
   MGF_TRY(w->p_cand.ensure(cap_p, s)); MGF_TRY(w->p_owner.ensure(cap_p, s));
   MGF_TRY(w->t_nc.ensure(cap_t, s)); MGF_TRY(w->p_nc.ensure(cap_p, s));
@@ -979,7 +991,6 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
     // fast path: one pass, hits written to fixed-capacity rows
     MGF_TRY(w->rows.ensure((size_t)n * kRowCap, s));
     MGF_TRY(w->rows_t.ensure((size_t)n * kRowCapT, s));
-    MGF_HIP_TRY(hipMemsetAsync(w->t_cnt.p, 0, (size_t)(n + 1) * 4, s));  // ghosts have no terrain row
     if (M.n_nodes && w->n_owned) {
       k_terrain_rows<<<nblk(w->n_owned), kBlock, 0, s>>>(B, w->n_owned, M, w->rows_t.p, w->t_cnt.p, w->d_err() + 1);
       LAUNCH_CHECK();
@@ -1035,8 +1046,6 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->tcnt.p, w->tbase.p, (size_t)n + 1));
   k_caps_constraints<<<1, 1, 0, s>>>(w->base.p + n, w->tbase.p + n, cap_c, sc);
   LAUNCH_CHECK();
-  MGF_TRY(w->cons_nat.ensure(cap_c, s));
-  MGF_TRY(links_ensure(w, cap_c));
   if (M.n_nodes) {
     k_setup_terrain<<<nblk(cap_t), kBlock, 0, s>>>(B, M, sc, w->t_owner.p, w->t_nc.p, w->t_pre.p, w->t_out.p, w->base.p, dt, w->params.baumgarte,
                                                    w->params.penetration_slop, w->cons_nat.p, w->c_ab.p, w->deg.p);
@@ -1495,7 +1504,7 @@ extern "C" mgf_status mgf_world_set_constraints(mgf_world* w, const mgf_constrai
   memset(&hc, 0, sizeof(hc));
   hc.C = hc.need_C = w->C;
   MGF_TRY(h2d(w->ctx, w->sc.p, &hc, 1));
-  MGF_TRY(links_ensure(w, w->C));
+  MGF_TRY(links_ensure(w, w->C, true));
   if (w->C) {
     k_links_from_records<<<nblk(w->C), kBlock, 0, w->ctx->stream>>>(w->cons_nat.p, w->C, w->c_ab.p, w->deg.p);
     LAUNCH_CHECK();
