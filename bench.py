@@ -36,7 +36,6 @@ def main():
     ap.add_argument("--refresh-every", type=int, default=None, help="solver iterations between ghost velocity refreshes (multi-GPU; default: mgf_amd.tiles.DEFAULT_REFRESH_EVERY)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo = host-staged exchange, for validating the multi-rank flow on one GPU")
-    ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-launch HIP events on the solver kernel")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -77,6 +76,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize() if torch.cuda.is_available() else None
 
+    # HIP events around the dominant kernel (k_solve_flow) on the stream it is launched on, inside the timed region
+    tw.world.set_option("time_solver_kernels", 1)
     for _ in range(args.warmup):
         tw.step()
     barrier()
@@ -86,12 +87,14 @@ def main():
     phase = dict(ms_integrate=0.0, ms_broadphase=0.0, ms_narrowphase=0.0, ms_setup=0.0, ms_solve=0.0)
     launches = 0
     levels = []
+    kms = 0.0
     for _ in range(args.steps):
         st = tw.step()
         units += st["n_constraints"] * args.iters
         cons += st["n_constraints"]
         launches += st["solver_kernel_launches"]
         levels.append(st["n_levels"])
+        kms += st["ms_solver_kernels"]
         for k in phase:
             phase[k] += st[k]
     barrier()
@@ -106,31 +109,19 @@ def main():
     else:
         units_all, cons_all = float(units), float(cons)
 
-    # ---- roofline leg: per-launch HIP events on the dominant kernel (k_solve), rank 0 ----------
+    # ---- roofline of the dominant kernel, rank 0: algorithmic bytes of the timed launches / their HIP-event time
     roofline = None
-    if rank == 0:
-        tw.world.set_option("time_solver_kernels", 1)
-        ku = kms = kl = 0.0
-        for _ in range(args.profile_steps):
-            st = tw.step()
-            ku += st["n_constraints"] * args.iters
-            kms += st["ms_solver_kernels"]
-            kl += st["solver_kernel_launches"]
-        tw.world.set_option("time_solver_kernels", 0)
-        if kms > 0:
-            achieved = ku * SOLVE_BYTES_PER_UNIT / (kms * 1e-3) / 1e9
-            incl_gaps = units * SOLVE_BYTES_PER_UNIT / (phase["ms_solve"] * 1e-3) / 1e9 if phase["ms_solve"] > 0 else None
-            roofline = {"bound": "hbm", "kernel": "k_solve_flow (ContactConstraint::solve for all iterations of a tick, one persistent dataflow launch)",
-                        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5),
-                        "traffic": _pmc_traffic(),
-                        "bytes_per_unit": SOLVE_BYTES_PER_UNIT,
-                        "avg_launch_us": round(kms * 1e3 / kl, 3), "launches_per_step": round(kl / args.profile_steps, 1),
-                        "avg_units_per_launch": round(ku / kl, 1),
-                        "achieved_incl_launch_gaps": None if incl_gaps is None else round(incl_gaps, 2)}
-    elif args.profile_steps:
-        for _ in range(args.profile_steps):
-            tw.step()
+    if rank == 0 and kms > 0 and launches > 0:
+        achieved = units * SOLVE_BYTES_PER_UNIT / (kms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "k_solve_flow (ContactConstraint::solve, persistent dataflow launch: "
+                                              + ("all iterations of a tick" if world_size == 1 else f"{refresh_every} iteration(s) between ghost refreshes") + ")",
+                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": _pmc_traffic(),
+                    "bytes_per_unit": SOLVE_BYTES_PER_UNIT,
+                    "avg_launch_us": round(kms * 1e3 / launches, 3), "launches_per_step": round(launches / args.steps, 2),
+                    "avg_units_per_launch": round(units / launches, 1),
+                    "launches_timed": int(launches)}
 
     # ---- CPU baseline: the oracle (C++ restatement of mgf), 1 core, bounded sample -------------
     cpu = None

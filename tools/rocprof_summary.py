@@ -17,9 +17,16 @@ def summarise(path):
                  vgpr=r[6], sgpr=r[7], scratch=r[8], lds=r[9]) for r in rows]
 
 
+def last_launches(path, pattern, count):
+    """average duration (us) of the last `count` launches of the kernels matching `pattern` (bench.py's timed region)"""
+    db = sqlite3.connect(path)
+    rows = db.execute("select end-start from kernels where name like ? order by start desc limit ?", (f"%{pattern}%", count)).fetchall()
+    return sum(r[0] for r in rows) / 1e3 / max(len(rows), 1), len(rows)
+
+
 def main():
     path = sys.argv[1]
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else None
     rows = summarise(path)
     tot = sum(r["total_us"] for r in rows)
     print(f"# rocprofv3 --kernel-trace summary of {path}")
@@ -28,6 +35,10 @@ def main():
     for r in rows:
         print(f"{r['name'][:70]:70s} {r['calls']:7d} {r['total_us'] / 1e3:10.3f} {r['avg_us']:9.2f} {r['min_us']:8.2f} "
               f"{r['max_us']:9.2f} {100 * r['total_us'] / tot:6.1f} {r['vgpr'] or 0:5d} {r['scratch'] or 0:7d}")
+    if "--timed" in sys.argv:  # --timed <kernel substring> <launches in bench.py's timed region>
+        k = sys.argv.index("--timed")
+        avg, cnt = last_launches(path, sys.argv[k + 1], int(sys.argv[k + 2]))
+        print(f"# {sys.argv[k + 1]}: average of the last {cnt} launches (bench.py's timed region) = {avg:.2f} us")
     if "--json" in sys.argv:
         print(json.dumps(rows))
 
