@@ -116,7 +116,7 @@ SYMBOLS = [
     "mgf_world_device_ptr",
     "mgf_world_begin_tick", "mgf_world_collide", "mgf_world_select_boundary", "mgf_world_export_bodies",
     "mgf_world_import_ghosts", "mgf_world_export_velocities", "mgf_world_import_ghost_velocities", "mgf_world_ghost_len",
-    "mgf_world_solve_enqueue", "mgf_world_finish",
+    "mgf_world_solve_enqueue", "mgf_world_finish", "mgf_world_counter",
 ]
 
 _lib = None
@@ -196,6 +196,7 @@ def load_library():
         "mgf_world_ghost_len": (i64, [vp]),
         "mgf_world_solve_enqueue": (i32, [vp, i32]),
         "mgf_world_finish": (i32, [vp, P(StepStats)]),
+        "mgf_world_counter": (i32, [vp, C.c_char_p, P(i64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -620,6 +621,11 @@ class World:
     def finish(self):
         _check(load_library().mgf_world_finish(self._h, C.byref(self.stats)))
         return self.stats
+
+    def counter(self, name):
+        v = C.c_int64()
+        _check(load_library().mgf_world_counter(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     def set_option(self, key, value):
         _check(load_library().mgf_world_set_option(self._h, key.encode(), int(value)))

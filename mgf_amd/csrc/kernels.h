@@ -248,13 +248,14 @@ __device__ __forceinline__ void box_min_max(V3& lo, V3& hi, V3 l, V3 h) {
 
 // Bodies -> leaf records in cell order (counting sort, second half).
 __global__ __launch_bounds__(kBlock) void k_scatter_leaves(Lbvh T, const float4* fb_c, const float4* fb_r, const uint32_t* cell_of,
-                                                           const uint32_t* rank) {
+                                                           const uint32_t* rank, uint32_t* brank) {
   uint32_t body = blockIdx.x * kBlock + threadIdx.x;
   if (body >= T.n) return;
   uint32_t p = T.cell_lo[cell_of[body]] + rank[body];
   LeafRec lr; lr.c = mk4(xyz(fb_c[body]), u2f(body)); lr.r = mk4(xyz(fb_r[body]), 0.0f);
   T.leaves[p] = lr;
   T.sidx[p] = body;
+  brank[body] = p;  // position in cell order (the block-local solver groups bodies by it)
 }
 
 // One block per 256 consecutive cells: the 4 internal levels above them.
@@ -1090,14 +1091,14 @@ __global__ __launch_bounds__(kBlock) void k_frontier0(uint32_t C, CRec* cons, Co
 // ContactConstraint::solve solver.rs:203-252 (single contact), incl. the reference's quirks:
 // both friction rows use the dv from before the first row (:217-232); the friction impulse is
 // applied unclamped (:226-231).
-__device__ __forceinline__ void solve_one(CRec& c, BodyDyn& A, BodyDyn& Bd) {
-  V3 n = ld3(c.n), ra = ld3(c.ra), rb = ld3(c.rb);
+__device__ __forceinline__ void solve_core(V3 n, V3 t0, V3 t1, V3 ra, V3 rb, float bias, float nmass, float tmass0, float tmass1,
+                                           float& nimp, BodyDyn& A, BodyDyn& Bd) {
   V3 va = A.v, oa = A.w, vb = Bd.v, ob = Bd.w;
   V3 dv = vb + cross(ob, rb) - va - cross(oa, ra);
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    V3 t = k == 0 ? ld3(c.t0) : ld3(c.t1);
-    float tm = k == 0 ? c.tmass0 : c.tmass1;
+    V3 t = k == 0 ? t0 : t1;
+    float tm = k == 0 ? tmass0 : tmass1;
     float lambda = -dot(dv, t) * tm;
     V3 impulse = t * lambda;
     va = va - impulse * A.im;
@@ -1107,16 +1108,19 @@ __device__ __forceinline__ void solve_one(CRec& c, BodyDyn& A, BodyDyn& Bd) {
   }
   V3 dv2 = vb + cross(ob, rb) - va - cross(oa, ra);
   float vn = dot(dv2, n);
-  float lambda = c.nmass * (-vn + c.bias);
-  float prev = c.nimp;
-  c.nimp = fmax_rs(prev + lambda, 0.0f);
-  lambda = c.nimp - prev;
+  float lambda = nmass * (-vn + bias);
+  float prev = nimp;
+  nimp = fmax_rs(prev + lambda, 0.0f);
+  lambda = nimp - prev;
   V3 impulse = n * lambda;
   va = va - impulse * A.im;
   oa = oa - A.I * cross(ra, impulse);
   vb = vb + impulse * Bd.im;
   ob = ob + Bd.I * cross(rb, impulse);
   A.v = va; A.w = oa; Bd.v = vb; Bd.w = ob;
+}
+__device__ __forceinline__ void solve_one(CRec& c, BodyDyn& A, BodyDyn& Bd) {
+  solve_core(ld3(c.n), ld3(c.t0), ld3(c.t1), ld3(c.ra), ld3(c.rb), c.bias, c.nmass, c.tmass0, c.tmass1, c.nimp, A, Bd);
 }
 __device__ __forceinline__ void store_vel(float4* srec, uint32_t i, const BodyDyn& d) {  // ConstrainedSet::set physics.rs:306-314
   srec[4 * i] = make_float4(d.v.x, d.v.y, d.v.z, d.w.x);
@@ -1220,7 +1224,9 @@ __global__ __launch_bounds__(kBlock) void k_flow_init(const uint32_t* C_ptr, Con
 
 template <bool TRACE>
 __global__ __launch_bounds__(kBlock) void k_solve_flow(float4* srec, CRec* cons, ConsLinks K, uint32_t* arr, const uint32_t* C_ptr, uint32_t iters,
-                                                       uint32_t* abort_flag, uint32_t spin_limit, int sleep_mode, uint64_t* trace) {
+                                                       uint32_t* abort_flag, uint32_t spin_limit, int sleep_mode, uint64_t* trace,
+                                                       const uint32_t* run_if) {
+  if (run_if && *run_if == 0u) return;  // stand-by launch behind the block-local solver: runs only if that one declined
   const uint32_t C = *C_ptr;
   const uint32_t L = gridDim.x * kBlock;
   const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
@@ -1349,6 +1355,284 @@ __global__ __launch_bounds__(kBlock) void k_solve_flowk(float4* srec, CRec* cons
       bool give_up = spins > spin_limit;
       if (give_up) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (give_up || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Block-local dataflow solver (solver mode 5).  Same dependency graph and the same arrival-counter protocol as
+// k_solve_flow, but the work is cut into spatial blocks: bodies in cell (Morton) order, `nb` consecutive bodies per
+// block, ONE 512-thread workgroup per block, one block per CU.  A constraint belongs to the block of its body a.
+//   * A body touched only by its own block's constraints is PRIVATE: its 64-byte solver record lives in the
+//     workgroup's LDS for the whole Solver::solve call.  Bodies touched from two blocks stay in global memory and
+//     are exchanged with write-through (sc1) accesses as in k_solve_flow.
+//   * A constraint whose predecessors all belong to its own block has its arrival counter in LDS; the others use
+//     the global counter array.
+//   * Constraint records stay in global memory; ready nodes go through two LDS queues (one for constraints that
+//     live entirely in LDS, one for those that touch global memory) and ANY lane of the serving waves may run
+//     any ready node: a wave takes up to 64 nodes per trip, instead of the few its own lanes would hold if
+//     constraints were pinned to lanes (measured: pinned lanes ran ~10 of 64 lanes per trip, issue-bound).
+// A hand-off inside a block is an LDS write + an LDS atomic; only hand-offs across block faces pay the L2 price.
+// The waves serving the all-LDS queue only touch global memory for the record fetch; a few waves serve the
+// other queue and poll the global counters.  Every ready node is eventually taken, so the scheme is
+// deadlock-free as long as all blocks are resident.
+// ------------------------------------------------------------------------------------------
+constexpr int kF5Threads = 512;
+constexpr uint32_t kF5MaxCons = 3072;                     // constraints per block
+constexpr uint32_t kF5MaxBodies = 1088;                   // bodies per block (LDS: 64 B each)
+constexpr uint32_t kF5SlotBytes = 25;                     // LDS per slot: c, aref, bref, cnt (4 each), succ (8), round (1)
+constexpr uint32_t kRefGlobal = 0x80000000u;              // body ref: bit 31 = global id (sc1 path), else LDS index; kNone = static
+constexpr uint32_t kSuccLocal = 0x20000000u;              // successor word: low bits are a block-local slot
+struct Flow5 {
+  const uint32_t* sidx;    // cell-ordered body ids
+  const uint32_t* brank;   // body -> position in cell order
+  const uint32_t* base;    // body -> first own constraint (n + 1 entries)
+  uint8_t* shared;         // body touched by constraints of two blocks
+  uint8_t* gcnt;           // constraint has a predecessor in another block: global arrival counter
+  uint32_t* lslot;         // constraint -> slot in its block's list
+  uint32_t* wg_n;          // per block: [3g] end of class 0, [3g + 1] end of class 1, [3g + 2] all constraints
+  uint32_t* wg_list;       // per block: kF5MaxCons constraint ids, class 0 first
+  uint32_t* fail;          // set when a block does not fit (the host falls back to k_solve_flow)
+  uint32_t nb, nblocks, n;
+};
+
+__global__ __launch_bounds__(kBlock) void k_flow5_mark(Flow5 F, ConsLinks K, const uint32_t* C_ptr) {
+  uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= *C_ptr) return;
+  uint2 e = K.ab[c];
+  uint32_t ga = F.brank[e.x] / F.nb;
+  if (e.y != kNone && F.brank[e.y] / F.nb != ga) F.shared[e.y] = 1;
+  uint2 sw = K.succ[c];
+  uint32_t s0 = sw.x & kSuccId;
+  if (F.brank[K.ab[s0].x] / F.nb != ga) F.gcnt[s0] = 1;
+  if (e.y != kNone) {
+    uint32_t s1 = sw.y & kSuccId;
+    if (F.brank[K.ab[s1].x] / F.nb != ga) F.gcnt[s1] = 1;
+  }
+}
+
+// One workgroup per block: the block's constraint list in three classes -
+//   0: arrival counter and both bodies in LDS;  1: global arrival counter (a predecessor lives in another block);
+//   2: LDS counter, but a body shared with another block.
+__device__ __forceinline__ int f5_class(const Flow5& F, const ConsLinks& K, uint32_t g, uint32_t c, bool a_shared) {
+  if (F.gcnt[c]) return 1;
+  uint32_t b = K.ab[c].y;
+  bool glob = a_shared || (b != kNone && (F.brank[b] / F.nb != g || F.shared[b]));
+  return glob ? 2 : 0;
+}
+__global__ __launch_bounds__(kF5Threads) void k_flow5_prep(Flow5 F, ConsLinks K) {
+  __shared__ uint32_t s_scan[3][kF5Threads];
+  const uint32_t g = blockIdx.x, t = threadIdx.x;
+  const uint32_t p_lo = g * F.nb, p_hi = min(F.n, p_lo + F.nb);
+  uint32_t nc[3] = {0, 0, 0};
+  for (uint32_t p = p_lo + t; p < p_hi; p += kF5Threads) {
+    uint32_t x = F.sidx[p];
+    bool xs = F.shared[x] != 0;
+    for (uint32_t c = F.base[x]; c < F.base[x + 1]; ++c) {
+      int k = f5_class(F, K, g, c, xs);
+      nc[0] += k == 0; nc[1] += k == 1; nc[2] += k == 2;
+    }
+  }
+  for (int k = 0; k < 3; ++k) s_scan[k][t] = nc[k];
+  __syncthreads();
+  for (int off = 1; off < kF5Threads; off <<= 1) {  // inclusive scans
+    uint32_t a[3];
+    for (int k = 0; k < 3; ++k) a[k] = t >= (uint32_t)off ? s_scan[k][t - off] : 0u;
+    __syncthreads();
+    for (int k = 0; k < 3; ++k) s_scan[k][t] += a[k];
+    __syncthreads();
+  }
+  const uint32_t N0 = s_scan[0][kF5Threads - 1], N1 = s_scan[1][kF5Threads - 1], N2 = s_scan[2][kF5Threads - 1];
+  uint32_t o[3] = {s_scan[0][t] - nc[0], N0 + s_scan[1][t] - nc[1], N0 + N1 + s_scan[2][t] - nc[2]};
+  if (t == 0) { F.wg_n[3 * g] = N0; F.wg_n[3 * g + 1] = N0 + N1; F.wg_n[3 * g + 2] = N0 + N1 + N2; }
+  if (N0 + N1 + N2 > kF5MaxCons) { if (t == 0) *F.fail = 1u; return; }
+  uint32_t* list = F.wg_list + (size_t)g * kF5MaxCons;
+  for (uint32_t p = p_lo + t; p < p_hi; p += kF5Threads) {
+    uint32_t x = F.sidx[p];
+    bool xs = F.shared[x] != 0;
+    for (uint32_t c = F.base[x]; c < F.base[x + 1]; ++c) {
+      int k = f5_class(F, K, g, c, xs);
+      uint32_t slot = o[k]++;
+      list[slot] = c;
+      F.lslot[c] = slot;
+    }
+  }
+}
+
+__device__ __forceinline__ BodyDyn f5_load_body(const float4* s_body, __amdgpu_buffer_rsrc_t rs, uint32_t ref) {
+  if (ref == kNone) return static_dyn();
+  if (ref & kRefGlobal) return load_dyn_sc1(rs, ref & ~kRefGlobal);
+  return load_dyn(s_body, ref);
+}
+__device__ __forceinline__ void f5_store_vel(float4* s_body, __amdgpu_buffer_rsrc_t rs, uint32_t ref, const BodyDyn& d) {
+  if (ref == kNone) return;
+  if (ref & kRefGlobal) { store_vel_sc1(rs, ref & ~kRefGlobal, d); return; }
+  store_vel(s_body, ref, d);
+}
+
+// Per block-local slot, in LDS: constraint id, body refs, arrival counter, successor words, iteration counter.
+struct F5Slots {
+  uint32_t* c;      // constraint id
+  uint32_t* aref;
+  uint32_t* bref;
+  uint32_t* cnt;    // arrivals since the slot last ran (LDS-counter slots): ready at 2
+  uint2* succ;
+  uint8_t* round;   // iterations done; bit 7: queued by its poller (global-counter slots)
+};
+// Ready queues in LDS (one for the fast class, one for the rest): any lane of the serving waves may run any ready
+// node, so a wave takes up to 64 of them per trip instead of the few its own lanes would hold.
+struct F5Queue { uint16_t* ring; uint32_t* head; uint32_t* tail; };
+constexpr uint32_t kF5Ring = 4096;  // > kF5MaxCons: a slot is queued at most once at a time
+__device__ __forceinline__ void f5_push(const F5Queue& q, uint32_t slot) {
+  uint32_t pos = __hip_atomic_fetch_add(q.tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  q.ring[pos & (kF5Ring - 1u)] = (uint16_t)(slot | 0x8000u);
+}
+
+__global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* cons, ConsLinks K, Flow5 F, uint32_t* arr, uint32_t iters,
+                                                            uint32_t* abort_flag, uint32_t spin_limit) {
+  if (*F.fail) return;  // a block did not fit: the stand-by k_solve_flow launch behind this one does the work
+  extern __shared__ float4 s_dyn[];
+  float4* s_body = s_dyn;  // 4 x nb
+  F5Slots S;
+  S.c = reinterpret_cast<uint32_t*>(s_dyn + 4 * (size_t)F.nb);
+  S.aref = S.c + kF5MaxCons; S.bref = S.aref + kF5MaxCons; S.cnt = S.bref + kF5MaxCons;
+  S.succ = reinterpret_cast<uint2*>(S.cnt + kF5MaxCons);
+  uint32_t* s_ctl = reinterpret_cast<uint32_t*>(S.succ + kF5MaxCons);  // [0,1] fast head/tail, [2,3] slow head/tail, [4] nodes left
+  F5Queue qf, qs;
+  qf.head = s_ctl; qf.tail = s_ctl + 1; qs.head = s_ctl + 2; qs.tail = s_ctl + 3;
+  uint32_t* s_left = s_ctl + 4;
+  qf.ring = reinterpret_cast<uint16_t*>(s_ctl + 8);
+  qs.ring = qf.ring + kF5Ring;
+  S.round = reinterpret_cast<uint8_t*>(qs.ring + kF5Ring);
+  const uint32_t g = blockIdx.x, t = threadIdx.x;
+  const uint32_t p_lo = g * F.nb, p_hi = min(F.n, p_lo + F.nb);
+  __amdgpu_buffer_rsrc_t rs = make_rsrc(srec);
+  for (uint32_t p = p_lo + t; p < p_hi; p += kF5Threads) {
+    uint32_t x = F.sidx[p];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_body[4 * (p - p_lo) + k] = srec[4 * (size_t)x + k];
+  }
+  const uint32_t N0 = F.wg_n[3 * g], N01 = F.wg_n[3 * g + 1], N = F.wg_n[3 * g + 2];
+  for (uint32_t e = t; e < 2u * kF5Ring / 2u; e += kF5Threads) reinterpret_cast<uint32_t*>(qf.ring)[e] = 0u;  // both rings
+  if (t < 8) s_ctl[t] = t == 4 ? N * iters : 0u;
+  __syncthreads();
+  const uint32_t* list = F.wg_list + (size_t)g * kF5MaxCons;
+  // slot table: every slot's constants, translated to block-local references where possible
+  for (uint32_t idx = t; idx < N; idx += kF5Threads) {
+    uint32_t c = list[idx];
+    uint2 e = K.ab[c];
+    uint32_t a = e.x, b = e.y;
+    S.c[idx] = c;
+    S.aref[idx] = F.shared[a] ? (a | kRefGlobal) : (F.brank[a] - p_lo);
+    S.bref[idx] = b == kNone ? kNone : ((F.brank[b] / F.nb != g || F.shared[b]) ? (b | kRefGlobal) : (F.brank[b] - p_lo));
+    uint32_t c0 = 2u - links_indeg0(K, c) * (b != kNone ? 1u : 2u);
+    S.cnt[idx] = c0;
+    S.round[idx] = 0;
+    uint2 sw = K.succ[c];
+    uint32_t w[2] = {sw.x, sw.y};
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      if (side == 1 && b == kNone) { w[1] = 0u; break; }
+      uint32_t sid = w[side] & kSuccId;
+      bool local = F.brank[K.ab[sid].x] / F.nb == g && !F.gcnt[sid];
+      if (local) w[side] = (w[side] & (kSuccTwo | kSuccWrap)) | kSuccLocal | F.lslot[sid];
+    }
+    S.succ[idx] = make_uint2(w[0], w[1]);
+    // iteration 0's frontier (slots with a global counter are found by their pollers)
+    if (!(idx >= N0 && idx < N01) && c0 >= 2u && iters > 0) f5_push(idx < N0 ? qf : qs, idx);
+  }
+  __syncthreads();
+  // waves [0, nfast) serve the fast queue, the rest the slow queue; the slow waves also poll the global counters
+  // (a dedicated polling wave was tried: slower, it keeps the CU's memory queue busy)
+  const uint32_t wave = t >> 6, lane = t & 63u, nwaves = kF5Threads / 64u;
+  uint32_t nslow = N > N0 ? (3u * nwaves * (N - N0) + 2u * N - 1u) / (2u * N) : 0u;
+  if (N > N0 && nslow < 1u) nslow = 1u;
+  if (nslow > nwaves - 1u && N0 > 0u) nslow = nwaves - 1u;
+  if (nslow > nwaves) nslow = nwaves;
+  const bool slow_wave = wave >= nwaves - nslow;
+  const F5Queue& q = slow_wave ? qs : qf;
+  const uint32_t poll_lanes = nslow * 64u, poll_id = (wave - (nwaves - nslow)) * 64u + lane;
+  uint32_t spins = 0;
+  for (;;) {
+    if (__hip_atomic_load(s_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
+    if (slow_wave) {  // global counters that reached their iteration's threshold: queue the slot (once)
+      for (uint32_t idx = N0 + poll_id; idx < N01; idx += poll_lanes) {
+        uint32_t r = S.round[idx];
+        if (r < iters) {
+          uint32_t av = __hip_atomic_load(&arr[S.c[idx]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (av >= 2u * (r + 1u)) { S.round[idx] = (uint8_t)(r | 0x80u); f5_push(qs, idx); }
+        }
+      }
+    }
+    // take up to 64 ready nodes
+    uint32_t h = 0, take = 0;
+    if (lane == 0) {
+      h = __hip_atomic_load(q.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      uint32_t tl = __hip_atomic_load(q.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      take = min(tl - h, 64u);
+      if (take) {
+        uint32_t expect = h;
+        if (!__hip_atomic_compare_exchange_strong(q.head, &expect, h + take, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) take = 0;
+      }
+    }
+    h = __shfl(h, 0); take = __shfl(take, 0);
+    if (take) {
+      spins = 0;
+      if (lane < take) {
+        uint16_t* cell = &q.ring[(h + lane) & (kF5Ring - 1u)];
+        uint32_t e;
+        do { e = *reinterpret_cast<volatile uint16_t*>(cell); } while (!(e & 0x8000u));  // the pusher is between its two writes
+        *cell = 0;
+        const uint32_t slot = e & 0x7FFFu;
+        const uint32_t c = S.c[slot];
+        const uint32_t round = S.round[slot] & 0x7Fu;
+        CRec rec = load_crec(&cons[c]);  // only the lane running the constraint touches its record
+        const uint32_t aref = S.aref[slot], bref = S.bref[slot];
+        BodyDyn A = f5_load_body(s_body, rs, aref);
+        BodyDyn Bd = f5_load_body(s_body, rs, bref);
+        solve_one(rec, A, Bd);
+        f5_store_vel(s_body, rs, aref, A);
+        f5_store_vel(s_body, rs, bref, Bd);
+        cons[c].nimp = rec.nimp;
+        const bool gcounter = slot >= N0 && slot < N01;
+        if (!gcounter) S.cnt[slot] = 0u;  // no arrival of the next iteration can come before this node's own releases
+        S.round[slot] = (uint8_t)(round + 1u);
+        // velocities and the impulse are out (LDS, write-through stores) before any successor hears of it
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        uint2 sw = S.succ[slot];
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+          if (side == 1 && bref == kNone) break;
+          uint32_t w = side == 0 ? sw.x : sw.y;
+          if (round + (w >> 31) >= iters) continue;
+          uint32_t add = (w & kSuccTwo) ? 1u : 2u;
+          if (w & kSuccLocal) {
+            uint32_t sl = w & 0xFFFFu;
+            uint32_t old = __hip_atomic_fetch_add(&S.cnt[sl], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old + add >= 2u) f5_push(sl < N0 ? qf : qs, sl);
+          } else {
+            __hip_atomic_fetch_add(&arr[w & kSuccId], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+      if (lane == 0) __hip_atomic_fetch_sub(s_left, take, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      continue;
+    }
+    __builtin_amdgcn_s_sleep(2);
+    if ((++spins & 255u) == 0u) {
+      bool give_up = spins > spin_limit;
+      if (give_up) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (give_up || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
+  }
+  __syncthreads();
+  // private bodies go back to the RigidBodyVec
+  for (uint32_t p = p_lo + t; p < p_hi; p += kF5Threads) {
+    uint32_t x = F.sidx[p];
+    if (!F.shared[x]) {
+      srec[4 * (size_t)x] = s_body[4 * (p - p_lo)];
+      float4 s1 = s_body[4 * (p - p_lo) + 1];
+      *reinterpret_cast<float2*>(&srec[4 * (size_t)x + 1]) = make_float2(s1.x, s1.y);
     }
   }
 }

@@ -519,17 +519,23 @@ struct mgf_world {
   int64_t opt_solver_mode = 1;
   DBuf<uint32_t> flow_arr;
   DBuf<uint64_t> flow_trace;
+  // block-local solver (mode 5)
+  DBuf<uint32_t> brank, f5_shared, f5_gcnt, f5_lslot, f5_wg_n, f5_list;
+  bool flow5_ok = false, flow5_prepped = false;  // the constraint list came from collide (own-block ranges valid) / prep done
+  uint32_t f5_nb = 0, f5_nblocks = 0;
   int flow_grid = 0;
   // device-resident list sizes + speculative capacities (see StepCounts)
   DBuf<StepCounts> sc;
   uint32_t cap_t = 0, cap_p = 0, cap_c = 0;
-  uint64_t n_cap_retries = 0;
+  uint64_t n_cap_retries = 0, n_flow5_fallbacks = 0;
   bool tick_two_pass = false;
   bool grid_too_wide = false;       // sticky: the largest body spans too many Morton cells for the grid broadphase
   int64_t opt_broadphase_tree = 0;  // 1 = always walk the tree (k_pair_rows) instead of enumerating grid cells
   int64_t opt_flow_blocks_per_cu = 0, opt_flow_sleep = 2;
   int flowk_grid = 0;
   int64_t opt_debug_bvh = 0, opt_flow_trace = 0;
+  int64_t opt_flow5_block = 0;     // minimum bodies per block of the block-local solver (tests)
+  bool flow5_attr_set = false;
   int64_t opt_stream_ordered = 0;  // 1: the tiling calls (begin_tick, export_*, import_*) do not synchronise the ctx stream
   bool solve_pending = false;      // a dataflow launch was enqueued by mgf_world_solve_enqueue and not yet checked
   DBuf<unsigned long long> dbg;
@@ -563,6 +569,13 @@ struct mgf_world {
   }
   uint32_t* d_cnt() { return scalars.p; }
   uint32_t* d_err() { return scalars.p + 3; }
+  Flow5 flow5() {
+    Flow5 F;
+    F.sidx = sidx.p; F.brank = brank.p; F.base = base.p; F.shared = reinterpret_cast<uint8_t*>(f5_shared.p);
+    F.gcnt = reinterpret_cast<uint8_t*>(f5_gcnt.p); F.lslot = f5_lslot.p; F.wg_n = f5_wg_n.p; F.wg_list = f5_list.p;
+    F.fail = d_err() + 4; F.nb = f5_nb; F.nblocks = f5_nblocks; F.n = n;
+    return F;
+  }
   ConsLinks links() { ConsLinks K; K.ab = c_ab.p; K.succ = c_succ.p; K.pred = c_pred.p; return K; }
   Frontier frontier() { Frontier F; F.order = order.p; F.lvl_off = lvl_off.p; F.cnt = d_cnt(); return F; }
 };
@@ -603,6 +616,7 @@ extern "C" mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_
   if (!strcmp(key, "solver_mode")) { w->opt_solver_mode = value; return MGF_OK; }
   if (!strcmp(key, "flow_blocks_per_cu")) { w->opt_flow_blocks_per_cu = value; w->flow_grid = 0; w->flowk_grid = 0; return MGF_OK; }
   if (!strcmp(key, "flow_sleep")) { w->opt_flow_sleep = value; return MGF_OK; }
+  if (!strcmp(key, "flow5_block")) { w->opt_flow5_block = value; w->flow5_prepped = false; return MGF_OK; }
   if (!strcmp(key, "stream_ordered")) { w->opt_stream_ordered = value; return MGF_OK; }
   if (!strcmp(key, "list_capacity")) {  // tests: force the speculative list capacities (the next tick must re-run its collide phase)
     if (value < 1 || value > 0x7FFFFFF0ll) return fail(MGF_ERR_INVALID, "list_capacity out of range");
@@ -610,6 +624,16 @@ extern "C" mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_
     return MGF_OK;
   }
   return fail(MGF_ERR_INVALID, "unknown option");
+}
+
+extern "C" mgf_status mgf_world_counter(const mgf_world* w, const char* name, int64_t* out) {
+  if (!w || !name || !out) return fail(MGF_ERR_INVALID, "NULL argument");
+  if (!strcmp(name, "row_overflows")) { *out = (int64_t)w->n_row_overflows; return MGF_OK; }
+  if (!strcmp(name, "capacity_retries")) { *out = (int64_t)w->n_cap_retries; return MGF_OK; }
+  if (!strcmp(name, "flow5_fallbacks")) { *out = (int64_t)w->n_flow5_fallbacks; return MGF_OK; }
+  if (!strcmp(name, "grid_too_wide")) { *out = w->grid_too_wide ? 1 : 0; return MGF_OK; }
+  if (!strcmp(name, "flow5_blocks")) { *out = (int64_t)w->f5_nblocks; return MGF_OK; }
+  return fail(MGF_ERR_INVALID, "unknown counter");
 }
 
 extern "C" mgf_status mgf_world_set_terrain(mgf_world* w, const mgf_mesh* mesh) {
@@ -934,7 +958,8 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   uint32_t levels = 4;  // 4^levels Morton cells, about one body per cell
   while (((uint64_t)1 << (2 * levels)) < n && levels < (uint32_t)kMortonBits / 2) ++levels;
   const uint32_t cells = 1u << (2 * levels), nblocks = cells / kBlock;
-  MGF_TRY(w->cell_of.ensure(n, s)); MGF_TRY(w->cell_rank.ensure(n, s)); MGF_TRY(w->sidx.ensure(n, s));
+  MGF_TRY(w->cell_of.ensure(n, s)); MGF_TRY(w->cell_rank.ensure(n, s)); MGF_TRY(w->sidx.ensure(n, s)); MGF_TRY(w->brank.ensure(n, s));
+  w->flow5_ok = true; w->flow5_prepped = false;
   MGF_TRY(w->lnodes.ensure(qlevel_offset(levels), s)); MGF_TRY(w->leaves.ensure(n, s));
   MGF_TRY(w->cell_lo.ensure((size_t)cells + 1, s)); MGF_TRY(w->cell_cnt.ensure((size_t)cells + 1, s));
   MGF_TRY(w->sub_lo.ensure(nblocks, s)); MGF_TRY(w->sub_hi.ensure(nblocks, s));
@@ -968,7 +993,7 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
     MGF_HIP_TRY(hipMemsetAsync(w->dbg.p, 0, 32, s));
     T.dbg = w->dbg.p;
   }
-  k_scatter_leaves<<<nblk(n), kBlock, 0, s>>>(T, w->fb_c.p, w->fb_r.p, w->cell_of.p, w->cell_rank.p);
+  k_scatter_leaves<<<nblk(n), kBlock, 0, s>>>(T, w->fb_c.p, w->fb_r.p, w->cell_of.p, w->cell_rank.p, w->brank.p);
   LAUNCH_CHECK();
   const bool two_pass = w->opt_two_pass != 0 || w->tick_two_pass;
   const bool use_grid = !two_pass && !w->opt_broadphase_tree && !w->grid_too_wide;
@@ -1219,13 +1244,47 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
   mgf_ctx* ctx = w->ctx;
   hipStream_t s = ctx->stream;
   const bool kslots = w->opt_solver_mode == 4;
+  bool use5 = w->opt_solver_mode == 5 && w->flow5_ok && !w->opt_flow_trace && w->n > 0 && iters <= 100;  // iteration counters are 7-bit in LDS
+  if (use5) {
+    // blocks of nb bodies in cell order, one workgroup each, all resident: at most one per CU
+    const uint32_t need = (w->n + (uint32_t)ctx->num_cus - 1u) / (uint32_t)ctx->num_cus;
+    uint32_t nb = std::max(need, std::min(w->n, 1024u));
+    if (w->opt_flow5_block > 0) nb = std::max(need, (uint32_t)w->opt_flow5_block);  // tests: small blocks on small scenes
+    if (nb > kF5MaxBodies) use5 = false;
+    else { w->f5_nb = nb; w->f5_nblocks = (w->n + nb - 1u) / nb; }
+  }
+  if (use5 && !w->flow5_prepped) {
+    const uint32_t n = w->n;
+    MGF_TRY(w->f5_shared.ensure(n / 4 + 1, s)); MGF_TRY(w->f5_gcnt.ensure(cap_c / 4 + 1, s)); MGF_TRY(w->f5_lslot.ensure(std::max(cap_c, 1u), s));
+    MGF_TRY(w->f5_wg_n.ensure(3 * (size_t)w->f5_nblocks, s)); MGF_TRY(w->f5_list.ensure((size_t)w->f5_nblocks * kF5MaxCons, s));
+    if (!w->flow5_attr_set) {
+      MGF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_flow5), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(64 * (size_t)kF5MaxBodies + (size_t)kF5SlotBytes * kF5MaxCons + 4 * (size_t)kF5Ring + 64)));
+      w->flow5_attr_set = true;
+    }
+    ZeroList z;
+    memset(&z, 0, sizeof(z));
+    z.p[0] = w->f5_shared.p; z.words[0] = n / 4 + 1;
+    z.p[1] = w->f5_gcnt.p; z.words[1] = cap_c / 4 + 1;
+    z.p[2] = w->d_err() + 4; z.words[2] = 1;
+    k_zero_many<<<64, kBlock, 0, s>>>(z);
+    LAUNCH_CHECK();
+    Flow5 F = w->flow5();
+    k_flow5_mark<<<std::max(1u, nblk(cap_c)), kBlock, 0, s>>>(F, w->links(), &w->sc.p->C);
+    LAUNCH_CHECK();
+    k_flow5_prep<<<F.nblocks, kF5Threads, 0, s>>>(F, w->links());
+    LAUNCH_CHECK();
+    w->flow5_prepped = true;
+  }
   int& grid = kslots ? w->flowk_grid : w->flow_grid;
   if (grid == 0) {
     int per_cu = 0;
     if (kslots) MGF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_solve_flowk<4, false>, kBlock, 0));
     else MGF_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_solve_flow<false>, kBlock, 0));
     int want = w->opt_flow_blocks_per_cu > 0 ? (int)w->opt_flow_blocks_per_cu : 4;
-    per_cu = std::max(1, std::min(per_cu - 1, want));
+    if (w->opt_flow_blocks_per_cu < 0) per_cu = (int)-w->opt_flow_blocks_per_cu;  // experiment: exact value, no occupancy margin
+    else per_cu = std::max(1, std::min(per_cu - 1, want));
+    if (getenv("MGF_FLOW_DEBUG")) fprintf(stderr, "[mgf] dataflow grid: %d blocks/CU x %d CUs\n", per_cu, ctx->num_cus);
     grid = per_cu * ctx->num_cus;
   }
   const uint32_t* C_ptr = &w->sc.p->C;
@@ -1247,12 +1306,19 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
   }
   const uint32_t spin_limit = 4u << 20;
   const int sleep = (int)w->opt_flow_sleep;
-  if (kslots) {
+  if (use5) {
+    Flow5 F = w->flow5();
+    const size_t lds = 64 * (size_t)F.nb + (size_t)kF5SlotBytes * kF5MaxCons + 4 * (size_t)kF5Ring + 64;
+    k_solve_flow5<<<F.nblocks, kF5Threads, lds, s>>>(w->srec.p, w->cons_nat.p, w->links(), F, w->flow_arr.p, (uint32_t)iters, abort_flag, spin_limit);
+    LAUNCH_CHECK();
+    // stand-by: the global dataflow kernel runs only if a block did not fit its workgroup (flag raised by k_flow5_prep)
+    k_solve_flow<false><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->links(), w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, nullptr, F.fail);
+  } else if (kslots) {
     if (trace) k_solve_flowk<4, true><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->links(), w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, trace);
     else k_solve_flowk<4, false><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->links(), w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, nullptr);
   } else {
-    if (trace) k_solve_flow<true><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->links(), w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, trace);
-    else k_solve_flow<false><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->links(), w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, nullptr);
+    if (trace) k_solve_flow<true><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->links(), w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, trace, nullptr);
+    else k_solve_flow<false><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->links(), w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, nullptr, nullptr);
   }
   LAUNCH_CHECK();
   if (timed) { MGF_HIP_TRY(hipEventRecord(w->kev[w->kev_used + 1], s)); w->kev_used += 2; }
@@ -1322,9 +1388,10 @@ static mgf_status solve_frontier(mgf_world* w, int32_t iters) {
 // After a dataflow launch has been synchronised: abort flag, timings.
 static mgf_status solve_flow_finish(mgf_world* w) {
   uint32_t* pin = static_cast<uint32_t*>(w->ctx->pinned);
-  MGF_HIP_TRY(hipMemcpyAsync(pin + 80, w->d_err() + 2, 4, hipMemcpyDeviceToHost, w->ctx->stream));
+  MGF_HIP_TRY(hipMemcpyAsync(pin + 80, w->d_err() + 2, 12, hipMemcpyDeviceToHost, w->ctx->stream));  // abort, grid-wide, flow5 fail
   MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
   if (pin[80]) return fail(MGF_ERR_HIP, "dataflow solver gave up waiting (grid not fully resident?)");
+  if (w->opt_solver_mode == 5 && w->flow5_prepped && pin[82]) w->n_flow5_fallbacks++;
   w->stats.solver_kernel_launches = 1;
   w->depth = 1;
   if (w->opt_time_solver_kernels) {
@@ -1504,6 +1571,7 @@ extern "C" mgf_status mgf_world_set_constraints(mgf_world* w, const mgf_constrai
   memset(&hc, 0, sizeof(hc));
   hc.C = hc.need_C = w->C;
   MGF_TRY(h2d(w->ctx, w->sc.p, &hc, 1));
+  w->flow5_ok = false; w->flow5_prepped = false;  // a caller's list has no per-body blocks
   MGF_TRY(links_ensure(w, w->C, true));
   if (w->C) {
     k_links_from_records<<<nblk(w->C), kBlock, 0, w->ctx->stream>>>(w->cons_nat.p, w->C, w->c_ab.p, w->deg.p);

@@ -334,7 +334,7 @@ def test_two_pass_and_row_paths_agree(ctx):
         assert bits_equal(s1[k], s2[k]), k
 
 
-@pytest.mark.parametrize("mode", [1, 4])
+@pytest.mark.parametrize("mode", [1, 4, 5, 105])
 @pytest.mark.parametrize("scene_name", ["pile12", "mixed", "balls8"])
 def test_dataflow_solver_matches_oracle(ctx, scene_name, mode):
     """solver_mode=1 (one persistent dataflow launch) must give the sequential Gauss-Seidel result too."""
@@ -345,7 +345,9 @@ def test_dataflow_solver_matches_oracle(ctx, scene_name, mode):
     dt, iters = float(scene["dt"]), scene["iters"]
     ow = oracle_world(scene)
     gw = mgf_amd.World.from_scene(ctx, scene)
-    gw.set_option("solver_mode", mode)
+    gw.set_option("solver_mode", mode % 100)
+    if mode == 105:  # block-local solver with small blocks: many block faces on a small scene
+        gw.set_option("flow5_block", 96)
     n_ticks = 160 if scene_name == "balls8" else 60
     for step in range(n_ticks):
         so = ow.step(dt, iters)
