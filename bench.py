@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--solver-mode", type=int, default=None, help="override the library's default solver mode (development)")
     ap.add_argument("--refresh-every", type=int, default=None, help="solver iterations between ghost velocity refreshes (multi-GPU; default: mgf_amd.tiles.DEFAULT_REFRESH_EVERY)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo = host-staged exchange, for validating the multi-rank flow on one GPU")
@@ -76,6 +77,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize() if torch.cuda.is_available() else None
 
+    if args.solver_mode is not None:
+        tw.world.set_option("solver_mode", args.solver_mode)
     # HIP events around the dominant kernel (k_solve_flow) on the stream it is launched on, inside the timed region
     tw.world.set_option("time_solver_kernels", 1)
     for _ in range(args.warmup):
@@ -113,8 +116,10 @@ def main():
     roofline = None
     if rank == 0 and kms > 0 and launches > 0:
         achieved = units * SOLVE_BYTES_PER_UNIT / (kms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_solve_flow (ContactConstraint::solve, persistent dataflow launch: "
-                                              + ("all iterations of a tick" if world_size == 1 else f"{refresh_every} iteration(s) between ghost refreshes") + ")",
+        mode = args.solver_mode if args.solver_mode is not None else 5
+        kname = {5: "k_solve_flow5 (ContactConstraint::solve, block-local persistent dataflow launch", 1: "k_solve_flow (ContactConstraint::solve, persistent dataflow launch",
+                 4: "k_solve_flowk (ContactConstraint::solve, persistent dataflow launch", 0: "k_solve (ContactConstraint::solve, one launch per dependency frontier"}[mode]
+        roofline = {"bound": "hbm", "kernel": kname + ": " + ("all iterations of a tick" if world_size == 1 else f"{refresh_every} iteration(s) between ghost refreshes") + ")",
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": _pmc_traffic(),
@@ -155,7 +160,7 @@ def main():
 
 def _pmc_traffic():
     """HBM bytes per k_solve launch from committed rocprofv3 PMC passes (profiles/), or None."""
-    p = os.path.join(ROOT, "profiles", "pmc_k_solve_flow.json")
+    p = os.path.join(ROOT, "profiles", "pmc_k_solve_flow5.json")
     if os.path.exists(p):
         try:
             return json.load(open(p)).get("hbm_bytes_per_launch")

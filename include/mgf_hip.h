@@ -231,7 +231,7 @@ MGF_API int64_t mgf_world_ghost_len(const mgf_world* w);
 MGF_API mgf_status mgf_world_solve_enqueue(mgf_world* w, int32_t iters);
 MGF_API mgf_status mgf_world_finish(mgf_world* w, mgf_step_stats* stats);
 /* Options (development and test knobs; defaults in brackets): "time_solver_kernels" [0] HIP events around the
- * solver kernels; "solver_mode" [1] 1 = persistent dataflow launch, 0 = one launch per dependency frontier,
+ * solver kernels; "solver_mode" [5] 1 = persistent dataflow launch, 0 = one launch per dependency frontier,
  * 4 = dataflow with out-of-order slots, 5 = block-local dataflow (velocities and counters of a spatial block in LDS); "two_pass_candidates" [0]; "stream_ordered" [0]; "list_capacity";
  * "flow_blocks_per_cu"; "flow_sleep"; "flow_trace"; "debug_bvh". */
 MGF_API mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_t value);

@@ -513,10 +513,12 @@ struct mgf_world {
   DBuf<float4> sub_lo, sub_hi, sub2_lo, sub2_hi;
   DBuf<uint32_t> cell_lo, cell_cnt;
   DBuf<uint32_t> t_cnt, p_cnt, t_off, p_off, t_cand, t_owner, p_cand, p_owner, rows, rows_t;
-  // 1 (default) = one persistent dataflow launch per Solver::solve (k_solve_flow);
+  // 5 (default) = block-local dataflow launch (k_solve_flow5: a spatial block's velocities, counters and ready queues in
+  //     LDS), with k_solve_flow as its stand-by when a block does not fit;
+  // 1 = one persistent dataflow launch per Solver::solve, everything through L2 (k_solve_flow);
   // 0 = one launch per frontier of the dependency graph (k_solve, the independent cross-check);
   // 4 = dataflow launch with out-of-order slots per lane (k_solve_flowk)
-  int64_t opt_solver_mode = 1;
+  int64_t opt_solver_mode = 5;
   DBuf<uint32_t> flow_arr;
   DBuf<uint64_t> flow_trace;
   // block-local solver (mode 5)
@@ -633,6 +635,18 @@ extern "C" mgf_status mgf_world_counter(const mgf_world* w, const char* name, in
   if (!strcmp(name, "flow5_fallbacks")) { *out = (int64_t)w->n_flow5_fallbacks; return MGF_OK; }
   if (!strcmp(name, "grid_too_wide")) { *out = w->grid_too_wide ? 1 : 0; return MGF_OK; }
   if (!strcmp(name, "flow5_blocks")) { *out = (int64_t)w->f5_nblocks; return MGF_OK; }
+  if (!strncmp(name, "flow5_class", 11) && (name[11] == '0' || name[11] == '1' || name[11] == '2') && !name[12]) {
+    // constraints of the last prepared tick in class 0 / 1 / 2 (all-LDS / global counter / LDS counter + shared body)
+    *out = 0;
+    if (!w->flow5_prepped || w->f5_nblocks == 0) return MGF_OK;
+    std::vector<uint32_t> h(3 * (size_t)w->f5_nblocks);
+    mgf_world* mw = const_cast<mgf_world*>(w);
+    MGF_TRY(ctx_bind(mw->ctx));
+    MGF_TRY(d2h(mw->ctx, h.data(), mw->f5_wg_n.p, h.size()));
+    int k = name[11] - '0';
+    for (uint32_t g = 0; g < w->f5_nblocks; ++g) *out += (int64_t)(h[3 * g + k] - (k ? h[3 * g + k - 1] : 0u));
+    return MGF_OK;
+  }
   return fail(MGF_ERR_INVALID, "unknown counter");
 }
 

@@ -20,6 +20,6 @@ for spec in specs:
         t0 = time.perf_counter(); st = w.step(float(sc['dt']), 10); el = time.perf_counter() - t0
         if s >= 10: ms.append(st.ms_solve); tot.append(el * 1e3); C = st.n_constraints
     v = w.state()["v"]
-    extra = f" flow5 blocks {w.counter('flow5_blocks')} fallbacks {w.counter('flow5_fallbacks')}" if mode == 5 else ""
+    extra = f" flow5 blocks {w.counter('flow5_blocks')} fallbacks {w.counter('flow5_fallbacks')} classes {w.counter('flow5_class0')}/{w.counter('flow5_class1')}/{w.counter('flow5_class2')}" if mode == 5 else ""
     print(f"n={n} mode {mode} blocks/cu {bpc} sleep {sl} k {k}: solve {np.mean(ms):.3f} ms  tick {np.mean(tot):.3f} ms  C={C} vsum={float(np.abs(v).sum()):.6f}{extra}", flush=True)
     del w
