@@ -103,6 +103,11 @@ typedef struct mgf_step_stats {
   float ms_solver_kernels;         /* sum of their HIP-event durations (0 if not timed) */
 } mgf_step_stats;
 
+/* Particle (geom.rs:802-855): a Ray { p, d } has dt = INFINITY; a Segment { a, b } is p = a, d = b - a, dt = 1. */
+typedef struct { mgf_vec3 p; mgf_vec3 d; float dt; } mgf_particle;
+/* Intersection collision.rs:151-158 */
+typedef struct { mgf_vec3 p; float t; } mgf_intersection;
+
 typedef struct mgf_ctx mgf_ctx;
 typedef struct mgf_mesh mgf_mesh;
 typedef struct mgf_bvh mgf_bvh;
@@ -169,6 +174,16 @@ MGF_API mgf_status mgf_bvh_query(mgf_bvh* b, const mgf_aabb* arg, mgf_bvh_hit_fn
 /* Bulk query: n AABBs; hits of query q are out_vals[out_offsets[q] .. out_offsets[q+1]) in DFS order. */
 MGF_API mgf_status mgf_bvh_query_many(mgf_bvh* b, const mgf_aabb* args, int64_t n, uint64_t* out_offsets /* n+1 */,
                                       uint64_t* out_vals, int64_t cap, int64_t* total);
+/* BVH::raytrace (bvh.rs:345-369): every leaf whose bounds the particle intersects, with that intersection, in the
+ * reference's visiting order; _many is the bulk form (CSR offsets per particle). */
+typedef void (*mgf_bvh_ray_fn)(const uint64_t* value, const mgf_intersection* inter, void* user);
+MGF_API mgf_status mgf_bvh_raytrace(mgf_bvh* b, const mgf_particle* arg, mgf_bvh_ray_fn cb, void* user);
+MGF_API mgf_status mgf_bvh_raytrace_many(mgf_bvh* b, const mgf_particle* args, int64_t n, uint64_t* out_offsets, uint64_t* out_vals,
+                                         mgf_intersection* out_inter, int64_t cap, int64_t* total);
+/* Intersects<Sphere | Capsule | Triangle | Plane> (shapes != NULL) or Intersects<AABB> (boxes != NULL) for n
+ * particle/target pairs (collision.rs:169-373); hit[i] = 1 and out[i] filled, or hit[i] = 0. */
+MGF_API mgf_status mgf_intersections_batch(mgf_ctx* ctx, int64_t n, const mgf_particle* parts, const mgf_shape* shapes,
+                                           const mgf_aabb* boxes, mgf_intersection* out, int32_t* hit);
 
 /* ---- World: RigidBodyVec + Solver + broadphase + terrain, resident in HBM for the whole tick.
  * Replaces mgf_demo/world.rs: World::add_body :178-184 and World::step :227-294, built on

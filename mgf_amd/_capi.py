@@ -109,6 +109,7 @@ SYMBOLS = [
     "mgf_local_contacts_mesh",
     "mgf_bvh_new", "mgf_bvh_with_capacity", "mgf_bvh_free", "mgf_bvh_empty", "mgf_bvh_clear", "mgf_bvh_insert",
     "mgf_bvh_remove", "mgf_bvh_root", "mgf_bvh_get_leaf", "mgf_bvh_bounds", "mgf_bvh_query", "mgf_bvh_query_many",
+    "mgf_bvh_raytrace", "mgf_bvh_raytrace_many", "mgf_intersections_batch",
     "mgf_world_new", "mgf_world_free", "mgf_world_set_terrain", "mgf_world_add_bodies", "mgf_world_len",
     "mgf_world_step", "mgf_world_build_constraints", "mgf_world_solve", "mgf_world_complete_motion",
     "mgf_world_integrate", "mgf_world_get", "mgf_world_set", "mgf_world_read_state", "mgf_world_write_state",
@@ -166,6 +167,9 @@ def load_library():
         "mgf_bvh_bounds": (i32, [vp, u64, P(Aabb)]),
         "mgf_bvh_query": (i32, [vp, P(Aabb), HIT_FN, vp]),
         "mgf_bvh_query_many": (i32, [vp, vp, i64, vp, vp, i64, P(i64)]),
+        "mgf_bvh_raytrace": (i32, [vp, vp, vp, vp]),
+        "mgf_bvh_raytrace_many": (i32, [vp, vp, i64, vp, vp, vp, i64, P(i64)]),
+        "mgf_intersections_batch": (i32, [vp, i64, vp, vp, vp, vp, vp]),
         "mgf_bvh_dump": (i64, [vp, vp, vp, i64]),
         "mgf_world_new": (i32, [vp, P(Params), P(vp)]),
         "mgf_world_free": (None, [vp]),
@@ -336,6 +340,38 @@ def local_contacts_mesh(ctx, body, mesh, cap=32):
     return [_local_dict(out[i]) for i in range(n.value)]
 
 
+PARTICLE_DTYPE = np.dtype([("p", "<f4", 3), ("d", "<f4", 3), ("dt", "<f4")])
+INTERSECTION_DTYPE = np.dtype([("p", "<f4", 3), ("t", "<f4")])
+
+
+def particles(rays=(), segments=()):
+    """Particles (geom.rs:802-855) from rays [(p, d)] and segments [(a, b)]: a Segment is p = a, d = b - a, DT = 1."""
+    out = np.zeros(len(rays) + len(segments), PARTICLE_DTYPE)
+    for i, (p, d) in enumerate(rays):
+        out[i] = (p, d, np.inf)
+    for i, (a, b) in enumerate(segments):
+        a32, b32 = np.asarray(a, np.float32), np.asarray(b, np.float32)
+        out[len(rays) + i] = (a32, b32 - a32, 1.0)
+    return out
+
+
+def intersections(ctx, parts, shapes=None, boxes=None):
+    """Intersects<Shape> (shape dicts) or Intersects<AABB> (rows c3 r3) for each particle -> [(point, t) or None]."""
+    parts = np.ascontiguousarray(parts, PARTICLE_DTYPE)
+    n = len(parts)
+    out = np.zeros(max(n, 1), INTERSECTION_DTYPE)
+    hit = np.zeros(max(n, 1), np.int32)
+    sp = bp = None
+    if shapes is not None:
+        arr = (Shape * max(n, 1))(*[_shape(x) for x in shapes])
+        sp = C.cast(arr, C.c_void_p)
+    else:
+        bx = np.ascontiguousarray(boxes, np.float32).reshape(-1, 6)
+        bp = bx.ctypes.data
+    _check(load_library().mgf_intersections_batch(ctx._h, n, parts.ctypes.data, sp, bp, out.ctypes.data, hit.ctypes.data))
+    return [(tuple(float(v) for v in out[i]["p"]), float(out[i]["t"])) if hit[i] else None for i in range(n)]
+
+
 def ray_capsule(ctx, p, d, cap_a, cap_d, cap_r):
     """Intersects<Capsule> for Ray (collision.rs:275-359) -> (point, t) or None."""
     ip = Vec3()
@@ -463,6 +499,25 @@ class Bvh:
             _check(st)
             break
         return off.astype(np.int64), vals[:total.value].astype(np.int64)
+
+    def raytrace_many(self, parts):
+        """BVH::raytrace for each particle: (offsets, values, intersections with the leaf bounds)."""
+        parts = np.ascontiguousarray(parts, PARTICLE_DTYPE)
+        n = len(parts)
+        off = np.zeros(n + 1, np.uint64)
+        total = C.c_int64()
+        cap = 1 << 16
+        while True:
+            vals = np.zeros(cap, np.uint64)
+            inter = np.zeros(cap, INTERSECTION_DTYPE)
+            st = load_library().mgf_bvh_raytrace_many(self._h, parts.ctypes.data, n, off.ctypes.data, vals.ctypes.data, inter.ctypes.data, cap,
+                                                      C.byref(total))
+            if st == ERR_CAPACITY and total.value > cap:
+                cap = total.value
+                continue
+            _check(st)
+            break
+        return off.astype(np.int64), vals[:total.value].astype(np.int64), inter[:total.value]
 
     def dump(self):
         return _bvh_dump(self._h)

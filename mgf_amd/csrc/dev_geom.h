@@ -131,19 +131,19 @@ __device__ inline bool closest_pts_seg_first(V3 a1, V3 b1, V3 a2, V3 b2, V3* p1)
 }
 
 // ---- rays ---------------------------------------------------------------------------
-__device__ inline bool ray_sphere(V3 p, V3 d, const Sphere& s, V3* ip, float* tout) {  // :249-273
+__device__ inline bool ray_sphere(V3 p, V3 d, const Sphere& s, V3* ip, float* tout, float dt = kInf) {  // :249-273; dt = Particle::DT
   V3 m = p - s.c;
   float a = mag2(d), b = dot(m, d), c = mag2(m) - s.r * s.r;
   if (c > 0.0f && b > 0.0f) return false;
   float discr = b * b - a * c;
   if (discr < 0.0f) return false;
   float t = fmax_rs((-b - __builtin_sqrtf(discr)) / a, 0.0f);
-  if (t > kInf) return false;
+  if (t > dt) return false;
   *ip = p + t * d; *tout = t;
   return true;
 }
 
-__device__ __noinline__ bool ray_capsule(V3 p, V3 d, const Capsule& cap, V3* ip, float* tout) {  // :275-359
+__device__ __noinline__ bool ray_capsule(V3 p, V3 d, const Capsule& cap, V3* ip, float* tout, float dt = kInf) {  // :275-359
   V3 m = p - cap.a;
   float md = dot(m, cap.d), nd = dot(d, cap.d), dd = dot(cap.d, cap.d);
   float nn = mag2(d), mn = dot(m, d);
@@ -159,7 +159,7 @@ __device__ __noinline__ bool ray_capsule(V3 p, V3 d, const Capsule& cap, V3* ip,
     float discr = b * b - nn * c;
     if (discr < 0.0f) return false;
     t = fmax_rs((-b - __builtin_sqrtf(discr)) / nn, 0.0f);
-    if (t > kInf) return false;
+    if (t > dt) return false;
     *ip = p + t * d; *tout = t;
     return true;
   }
@@ -182,8 +182,43 @@ __device__ __noinline__ bool ray_capsule(V3 p, V3 d, const Capsule& cap, V3* ip,
     if (d2 < 0.0f) return false;
     t = fmax_rs((-b2 - __builtin_sqrtf(d2)) / nn, 0.0f);
   }
-  if (t > kInf) return false;
+  if (t > dt) return false;
   *ip = p + t * d; *tout = t;
+  return true;
+}
+
+// Intersects<Plane> :169-184, Intersects<Triangle> :186-200, Intersects<AABB> :202-236
+__device__ inline bool ray_plane(V3 p, V3 d, const Plane& pl, V3* ip, float* tout, float dt = kInf) {
+  float denom = dot(pl.n, d);
+  if (denom == 0.0f) return false;
+  float t = (pl.d - dot(pl.n, p)) / denom;
+  if (t <= 0.0f || t > dt) return false;
+  *ip = p + d * t; *tout = t;
+  return true;
+}
+__device__ inline bool ray_triangle(V3 p, V3 d, const Triangle& tri, V3* ip, float* tout, float dt = kInf) {
+  V3 q; float t;
+  if (ray_plane(p, d, plane_from(tri.a, tri.b, tri.c), &q, &t, dt) && tri_contains(tri, q)) { *ip = q; *tout = t; return true; }
+  return false;
+}
+__device__ inline bool ray_box(V3 p, V3 d, const Box& a, V3* ip, float* tout, float dt = kInf) {
+  float t_min = 0.0f, t_max = kInf;
+#pragma unroll
+  for (int dim = 0; dim < 3; ++dim) {
+    float pd = at(p, dim), dd = at(d, dim), ac = at(a.c, dim), ar = at(a.r, dim);
+    if (fabs_rs(dd) < kCollisionEps) {
+      if (fabs_rs(pd - ac) > ar) return false;
+    } else {
+      float ood = 1.0f / dd;
+      float t1 = (ac - ar - pd) * ood;
+      float t2 = (ac + ar - pd) * ood;
+      if (t1 > t2) { t_min = fmax_rs(t_min, t2); t_max = fmin_rs(t_max, t1); }
+      else { t_min = fmax_rs(t_min, t1); t_max = fmin_rs(t_max, t2); }
+      if (t_min > t_max) return false;
+    }
+  }
+  if (t_min > dt) return false;
+  *ip = p + d * t_min; *tout = t_min;
   return true;
 }
 

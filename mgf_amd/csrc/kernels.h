@@ -1782,6 +1782,60 @@ __global__ void k_contacts_batch(int64_t n, const ShapeIn* a, const float* va, c
   for (int k = 0; k < m && k < 2; ++k) out[2 * t + k] = to_out(c[k]);
 }
 
+// Intersects<Shape> for a particle (Ray: dt = inf; Segment: p = a, d = b - a, dt = 1) collision.rs:169-373
+struct ParticleIn { float p[3], d[3], dt; };
+struct InterOut { float p[3], t; };
+__device__ inline int intersection_dispatch(const ParticleIn& q, const ShapeIn& s, V3* ip, float* t) {
+  V3 p = ld3(q.p), d = ld3(q.d);
+  switch (s.kind) {
+    case MGF_SPHERE: return ray_sphere(p, d, mks(mk3(s.v[0], s.v[1], s.v[2]), s.v[3]), ip, t, q.dt) ? 1 : 0;
+    case MGF_CAPSULE: return ray_capsule(p, d, mkcap(mk3(s.v[0], s.v[1], s.v[2]), mk3(s.v[3], s.v[4], s.v[5]), s.v[6]), ip, t, q.dt) ? 1 : 0;
+    case MGF_TRIANGLE: return ray_triangle(p, d, mkt(mk3(s.v[0], s.v[1], s.v[2]), mk3(s.v[3], s.v[4], s.v[5]), mk3(s.v[6], s.v[7], s.v[8])), ip, t, q.dt) ? 1 : 0;
+    case MGF_PLANE: { Plane pl; pl.n = mk3(s.v[0], s.v[1], s.v[2]); pl.d = s.v[3]; return ray_plane(p, d, pl, ip, t, q.dt) ? 1 : 0; }
+    default: return -1;
+  }
+}
+__global__ void k_intersections_batch(int64_t n, const ParticleIn* parts, const ShapeIn* shapes, const float* boxes /* or */, InterOut* out,
+                                      int32_t* hit) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  V3 ip = mk3(0, 0, 0); float t = 0.0f;
+  int h;
+  if (boxes) { Box b; b.c = ld3(boxes + 6 * i); b.r = ld3(boxes + 6 * i + 3); h = ray_box(ld3(parts[i].p), ld3(parts[i].d), b, &ip, &t, parts[i].dt) ? 1 : 0; }
+  else h = intersection_dispatch(parts[i], shapes[i], &ip, &t);
+  hit[i] = h;
+  if (h == 1) { st3(out[i].p, ip); out[i].t = t; }
+}
+// BVH::raytrace bvh.rs:345-369 over a flattened reference-built tree, reference visiting order.
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void k_bvh_raytrace(TerrainDev M, const ParticleIn* parts, int64_t n, uint32_t* cnt, const uint32_t* off,
+                                                         uint32_t* vals, InterOut* inters) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  V3 p = ld3(parts[i].p), d = ld3(parts[i].d);
+  const float dt = parts[i].dt;
+  uint32_t m = 0, base = FILL ? off[i] : 0;
+  uint32_t stack[kStack];
+  int sp = 0;
+  stack[sp++] = M.root;
+  while (sp > 0) {
+    uint32_t top = stack[--sp];
+    const float4* raw = reinterpret_cast<const float4*>(&M.nodes[top]);
+    float4 n0 = raw[0], n1 = raw[1];
+    Box nb; nb.c = xyz(n0); nb.r = xyz(n1);
+    V3 ip; float t;
+    if (ray_box(p, d, nb, &ip, &t, dt)) {
+      uint32_t w0 = f2u(n0.w), w1 = f2u(n1.w);
+      if (w0 & 0x80000000u) {
+        if (FILL) { vals[base + m] = w0 & 0x7FFFFFFFu; st3(inters[base + m].p, ip); inters[base + m].t = t; }
+        ++m;
+      } else if (sp + 2 <= kStack) { stack[sp++] = w0; stack[sp++] = w1; }
+      else if (M.err) *M.err = 1u;
+    }
+  }
+  if (!FILL) cnt[i] = m;
+}
+
 struct MovingIn { int tag; float p[3], d[3], r; float delta[3]; };
 struct LocalOut { float la[3], lb[3]; ContactOut g; };
 __device__ __forceinline__ Comp to_comp(const MovingIn& m) {

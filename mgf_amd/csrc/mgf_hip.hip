@@ -290,6 +290,88 @@ extern "C" mgf_status mgf_bvh_query_many(mgf_bvh* b, const mgf_aabb* args, int64
   return MGF_OK;
 }
 
+// BVH::raytrace bvh.rs:345-369 for a batch of particles: per particle the leaf values and the intersections
+// with the leaf bounds, in the reference's visiting order (count pass, scan, fill pass).
+static_assert(sizeof(ParticleIn) == sizeof(mgf_particle), "particle layout");
+static_assert(sizeof(InterOut) == sizeof(mgf_intersection), "intersection layout");
+static mgf_status tree_raytrace_many(mgf_ctx* ctx, TreeMirror& m, const mgf_particle* parts, int64_t n, std::vector<uint32_t>* off,
+                                     std::vector<uint32_t>* vals, std::vector<mgf_intersection>* inters) {
+  MGF_TRY(ctx_bind(ctx));
+  off->assign((size_t)n + 1, 0);
+  vals->clear(); inters->clear();
+  if (n == 0 || m.tree.empty()) return MGF_OK;
+  MGF_TRY(m.sync(ctx));
+  DBuf<ParticleIn> d_parts;
+  DBuf<uint32_t> d_cnt, d_off, d_vals, d_err;
+  DBuf<InterOut> d_int;
+  MGF_TRY(d_parts.ensure((size_t)n, ctx->stream));
+  MGF_TRY(d_cnt.ensure((size_t)n + 1, ctx->stream));
+  MGF_TRY(d_off.ensure((size_t)n + 1, ctx->stream));
+  MGF_TRY(d_err.ensure(1, ctx->stream));
+  MGF_HIP_TRY(hipMemsetAsync(d_err.p, 0, 4, ctx->stream));
+  MGF_TRY(h2d(ctx, d_parts.p, reinterpret_cast<const ParticleIn*>(parts), (size_t)n));
+  TerrainDev T = m.dev(nullptr, nullptr, mk3(0, 0, 0), d_err.p);
+  k_bvh_raytrace<false><<<nblk(n), kBlock, 0, ctx->stream>>>(T, d_parts.p, n, d_cnt.p, nullptr, nullptr, nullptr);
+  LAUNCH_CHECK();
+  MGF_TRY(prim_exclusive_scan_u32(ctx, d_cnt.p, d_off.p, (size_t)n + 1));
+  MGF_TRY(d2h(ctx, off->data(), d_off.p, (size_t)n + 1));
+  uint32_t total = (*off)[n];
+  vals->resize(total); inters->resize(total);
+  if (total) {
+    MGF_TRY(d_vals.ensure(total, ctx->stream));
+    MGF_TRY(d_int.ensure(total, ctx->stream));
+    k_bvh_raytrace<true><<<nblk(n), kBlock, 0, ctx->stream>>>(T, d_parts.p, n, nullptr, d_off.p, d_vals.p, d_int.p);
+    LAUNCH_CHECK();
+    MGF_TRY(d2h(ctx, vals->data(), d_vals.p, total));
+    MGF_TRY(d2h(ctx, reinterpret_cast<InterOut*>(inters->data()), d_int.p, total));
+  }
+  uint32_t err = 0;
+  MGF_TRY(d2h(ctx, &err, d_err.p, 1));
+  if (err) return fail(MGF_ERR_CAPACITY, "BVH traversal stack overflow (tree deeper than 64)");
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_bvh_raytrace(mgf_bvh* b, const mgf_particle* arg, mgf_bvh_ray_fn cb, void* user) {
+  if (!b || !arg || !cb) return fail(MGF_ERR_INVALID, "NULL argument");
+  std::vector<uint32_t> off, vals;
+  std::vector<mgf_intersection> inters;
+  MGF_TRY(tree_raytrace_many(b->ctx, b->m, arg, 1, &off, &vals, &inters));
+  for (size_t k = 0; k < vals.size(); ++k) { uint64_t v64 = vals[k]; cb(&v64, &inters[k], user); }
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_bvh_raytrace_many(mgf_bvh* b, const mgf_particle* args, int64_t n, uint64_t* out_offsets, uint64_t* out_vals,
+                                            mgf_intersection* out_inter, int64_t cap, int64_t* total) {
+  if (!b || (!args && n) || !out_offsets) return fail(MGF_ERR_INVALID, "NULL argument");
+  std::vector<uint32_t> off, vals;
+  std::vector<mgf_intersection> inters;
+  MGF_TRY(tree_raytrace_many(b->ctx, b->m, args, n, &off, &vals, &inters));
+  for (int64_t i = 0; i <= n; ++i) out_offsets[i] = off[(size_t)i];
+  if (total) *total = (int64_t)vals.size();
+  if ((int64_t)vals.size() > cap) return fail(MGF_ERR_CAPACITY, "output buffers too small");
+  for (size_t i = 0; i < vals.size(); ++i) { if (out_vals) out_vals[i] = vals[i]; if (out_inter) out_inter[i] = inters[i]; }
+  return MGF_OK;
+}
+// Intersects<Shape> / Intersects<AABB> for a batch of particles (collision.rs:169-373); hit[i] = 1 / 0.
+extern "C" mgf_status mgf_intersections_batch(mgf_ctx* ctx, int64_t n, const mgf_particle* parts, const mgf_shape* shapes, const mgf_aabb* boxes,
+                                              mgf_intersection* out, int32_t* hit) {
+  if (n < 0 || (n && (!parts || (!shapes && !boxes) || (shapes && boxes) || !out || !hit))) return fail(MGF_ERR_INVALID, "bad argument");
+  MGF_TRY(ctx_bind(ctx));
+  if (n == 0) return MGF_OK;
+  if (shapes)
+    for (int64_t i = 0; i < n; ++i)
+      if (shapes[i].kind != MGF_SPHERE && shapes[i].kind != MGF_CAPSULE && shapes[i].kind != MGF_TRIANGLE && shapes[i].kind != MGF_PLANE)
+        return fail(MGF_ERR_INVALID, "intersection: shape must be sphere, capsule, triangle or plane");
+  DBuf<ParticleIn> dp; DBuf<ShapeIn> ds; DBuf<float> db; DBuf<InterOut> dout; DBuf<int32_t> dh;
+  MGF_TRY(dp.ensure((size_t)n, ctx->stream)); MGF_TRY(dout.ensure((size_t)n, ctx->stream)); MGF_TRY(dh.ensure((size_t)n, ctx->stream));
+  MGF_TRY(h2d(ctx, dp.p, reinterpret_cast<const ParticleIn*>(parts), (size_t)n));
+  if (shapes) { MGF_TRY(ds.ensure((size_t)n, ctx->stream)); MGF_TRY(h2d(ctx, ds.p, reinterpret_cast<const ShapeIn*>(shapes), (size_t)n)); }
+  else { MGF_TRY(db.ensure(6 * (size_t)n, ctx->stream)); MGF_TRY(h2d(ctx, db.p, reinterpret_cast<const float*>(boxes), 6 * (size_t)n)); }
+  k_intersections_batch<<<nblk(n), kBlock, 0, ctx->stream>>>(n, dp.p, shapes ? ds.p : nullptr, shapes ? nullptr : db.p, dout.p, dh.p);
+  LAUNCH_CHECK();
+  MGF_TRY(d2h(ctx, reinterpret_cast<InterOut*>(out), dout.p, (size_t)n));
+  MGF_TRY(d2h(ctx, hit, dh.p, (size_t)n));
+  return MGF_OK;
+}
+
 // ---- mgf_mesh --------------------------------------------------------------------------------
 extern "C" mgf_status mgf_mesh_new(mgf_ctx* ctx, mgf_mesh** out) {  // ctx may be NULL: host-only mesh
   if (!out) return fail(MGF_ERR_INVALID, "NULL argument");

@@ -186,6 +186,27 @@ struct BVH {
     }
   }
 
+  // bvh.rs:345-369 raytrace: `hit(bounds, &inter)` is Intersects<AABB> of the caller's particle (collision.rs:202-236);
+  // cb(value, Intersection with the leaf's bounds).  Same stack discipline as query.
+  template <class T, class F>
+  void raytrace(T&& hit, F&& cb) const {
+    if (empty()) return;
+    size_t inl[64];
+    std::vector<size_t> spill;
+    size_t sp = 0;
+    auto push = [&](size_t v) { if (sp < 64) inl[sp] = v; else spill.push_back(v); ++sp; };
+    auto pop = [&]() -> size_t { --sp; if (sp < 64) return inl[sp]; size_t v = spill.back(); spill.pop_back(); return v; };
+    push(root);
+    while (sp > 0) {
+      size_t top = pop();
+      const Node& n = pool[top];
+      decltype(hit(n.bounds)) inter = hit(n.bounds);
+      if (inter.first) {
+        if (n.is_leaf) cb(n.leaf, inter.second);
+        else { push(n.child1); push(n.child2); }
+      }
+    }
+  }
   // bvh.rs:283-310: explicit stack, push lchild then rchild, pop rchild first.
   template <class F>
   void query(const AABB& arg_bounds, F&& cb) const {

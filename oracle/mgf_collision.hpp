@@ -48,7 +48,7 @@ static inline bool contains(const Rectangle& r, V3 p) {
 }
 
 // Ray ∩ Sphere collision.rs:249-273 (Ray::DT = inf so the `t > DT` test never fires)
-static inline bool ray_sphere(const Ray& ray, const Sphere& s, Intersection* out) {
+static inline bool ray_sphere(const Ray& ray, const Sphere& s, Intersection* out, float dt = F32_INF) {  // dt = Particle::DT (Ray inf, Segment 1)
   V3 p = ray.p, d = ray.d;
   V3 m = p - s.c;
   float a = magnitude2(d), b = dot(m, d), c = magnitude2(m) - s.r * s.r;
@@ -56,13 +56,13 @@ static inline bool ray_sphere(const Ray& ray, const Sphere& s, Intersection* out
   float discr = b * b - a * c;
   if (discr < 0.0f) return false;
   float t = fmaxf_rs((-b - std::sqrt(discr)) / a, 0.0f);
-  if (t > F32_INF) return false;
+  if (t > dt) return false;
   *out = Intersection{p + t * d, t};
   return true;
 }
 
 // Ray ∩ Capsule collision.rs:275-359
-static inline bool ray_capsule(const Ray& ray, const Capsule& cap, Intersection* out) {
+static inline bool ray_capsule(const Ray& ray, const Capsule& cap, Intersection* out, float dt = F32_INF) {
   V3 p = ray.p, d = ray.d;
   V3 m = p - cap.a;
   float md = dot(m, cap.d), nd = dot(d, cap.d), dd = dot(cap.d, cap.d);
@@ -82,7 +82,7 @@ static inline bool ray_capsule(const Ray& ray, const Capsule& cap, Intersection*
     float discr = b * b - nn * c;
     if (discr < 0.0f) return false;
     float t = fmaxf_rs((-b - std::sqrt(discr)) / nn, 0.0f);
-    if (t > F32_INF) return false;
+    if (t > dt) return false;
     *out = Intersection{p + t * d, t};
     return true;
   }
@@ -106,8 +106,45 @@ static inline bool ray_capsule(const Ray& ray, const Capsule& cap, Intersection*
     if (discr2 < 0.0f) return false;
     t = fmaxf_rs((-b2 - std::sqrt(discr2)) / nn, 0.0f);
   }
-  if (t > F32_INF) return false;
+  if (t > dt) return false;
   *out = Intersection{p + t * d, t};
+  return true;
+}
+
+// Intersects<Plane> collision.rs:169-184
+static inline bool ray_plane(const Ray& ray, const Plane& pl, Intersection* out, float dt = F32_INF) {
+  float denom = dot(pl.n, ray.d);
+  if (denom == 0.0f) return false;
+  float t = (pl.d - dot(pl.n, ray.p)) / denom;
+  if (t <= 0.0f || t > dt) return false;
+  *out = Intersection{ray.p + ray.d * t, t};
+  return true;
+}
+// Intersects<Poly> collision.rs:186-200 (Triangle, Rectangle)
+template <class Poly>
+static inline bool ray_polygon(const Ray& ray, const Poly& poly, Intersection* out, float dt = F32_INF) {
+  Intersection i;
+  if (ray_plane(ray, to_plane(poly), &i, dt) && contains(poly, i.p)) { *out = i; return true; }
+  return false;
+}
+// Intersects<AABB> collision.rs:202-236
+static inline bool ray_aabb(const Ray& ray, const AABB& a, Intersection* out, float dt = F32_INF) {
+  float t_min = 0.0f, t_max = F32_INF;
+  for (int dim = 0; dim < 3; ++dim) {
+    float pd = idx(ray.p, dim), dd = idx(ray.d, dim), ac = idx(a.c, dim), ar = idx(a.r, dim);
+    if (std::fabs(dd) < COLLISION_EPSILON) {
+      if (std::fabs(pd - ac) > ar) return false;
+    } else {
+      float ood = 1.0f / dd;
+      float t1 = (ac - ar - pd) * ood;
+      float t2 = (ac + ar - pd) * ood;
+      if (t1 > t2) { t_min = fmaxf_rs(t_min, t2); t_max = fminf_rs(t_max, t1); }
+      else { t_min = fmaxf_rs(t_min, t1); t_max = fminf_rs(t_max, t2); }
+      if (t_min > t_max) return false;
+    }
+  }
+  if (t_min > dt) return false;
+  *out = Intersection{ray.p + ray.d * t_min, t_min};
   return true;
 }
 

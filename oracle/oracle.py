@@ -98,6 +98,12 @@ def lib():
         for f in (L.mgfo_ray_capsule, L.mgfo_ray_sphere):
             f.argtypes = [P(Vec3), P(Vec3), P(Shape), P(Vec3), P(C.c_float)]
             f.restype = C.c_int
+        L.mgfo_intersection.argtypes = [P(Vec3), P(Vec3), C.c_float, P(Shape), P(Vec3), P(C.c_float)]
+        L.mgfo_intersection.restype = C.c_int
+        L.mgfo_intersection_aabb.argtypes = [P(Vec3), P(Vec3), C.c_float, P(Aabb), P(Vec3), P(C.c_float)]
+        L.mgfo_intersection_aabb.restype = C.c_int
+        L.mgfo_bvh_raytrace.argtypes = [C.c_void_p, P(Vec3), P(Vec3), C.c_float, P(C.c_uint64), P(Vec3), P(C.c_float), C.c_int64]
+        L.mgfo_bvh_raytrace.restype = C.c_int64
         L.mgfo_tri_closest_point.argtypes = [P(Shape), P(Vec3), P(Vec3)]
         L.mgfo_compute_basis.argtypes = [P(Vec3), P(Vec3)]
         L.mgfo_quat_from_arc.argtypes = [P(Vec3), P(Vec3), P(Quat)]
@@ -217,6 +223,22 @@ def contacts(a, vel_a, b, vel_b, cap=8):
     return [dict(a=out[i].a.tup(), b=out[i].b.tup(), n=out[i].n.tup(), t=out[i].t) for i in range(min(n, cap))]
 
 
+def intersection(p, d, dt, sh):
+    """Intersects<shape> for a Ray (dt = inf) or a Segment (dt = 1, p = a, d = b - a): (point, t) or None."""
+    ip, t = Vec3(), C.c_float()
+    r = lib().mgfo_intersection(C.byref(vec3(p)), C.byref(vec3(d)), C.c_float(dt), C.byref(sh), C.byref(ip), C.byref(t))
+    if r < 0:
+        raise ValueError("unsupported shape")
+    return (ip.tup(), t.value) if r else None
+
+
+def intersection_aabb(p, d, dt, c, r):
+    ip, t = Vec3(), C.c_float()
+    box = Aabb(vec3(c), vec3(r))
+    hit = lib().mgfo_intersection_aabb(C.byref(vec3(p)), C.byref(vec3(d)), C.c_float(dt), C.byref(box), C.byref(ip), C.byref(t))
+    return (ip.tup(), t.value) if hit else None
+
+
 def component(tag, p, d, r):
     return Component(tag, vec3(p), vec3(d), float(r))
 
@@ -257,6 +279,14 @@ class Bvh:
         out = (C.c_uint64 * cap)()
         n = lib().mgfo_bvh_query(self.h, C.byref(self._aabb(c, r)), out, cap)
         return [out[i] for i in range(min(n, cap))]
+
+    def raytrace(self, p, d, dt=float("inf"), cap=4096):
+        """BVH::raytrace: [(value, point, t)] in the reference's visiting order."""
+        vals = (C.c_uint64 * cap)()
+        ips = (Vec3 * cap)()
+        ts = (C.c_float * cap)()
+        n = lib().mgfo_bvh_raytrace(self.h, C.byref(vec3(p)), C.byref(vec3(d)), C.c_float(dt), vals, ips, ts, cap)
+        return [(vals[i], ips[i].tup(), ts[i]) for i in range(min(n, cap))]
 
     def dump(self):
         n = lib().mgfo_bvh_dump(self.h, None, None, 0)

@@ -3,6 +3,7 @@
 // __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by mgf_amd/.
 #include <cstdio>
 #include <cstring>
+#include <utility>
 
 #include "mgf_world.hpp"
 
@@ -131,6 +132,42 @@ int mgfo_ray_sphere(const o_vec3* p, const o_vec3* d, const o_shape* s, o_vec3* 
   if (!ray_sphere(Ray{V(*p), V(*d)}, as_sphere(*s), &i)) return 0;
   *ip = O(i.p); *t = i.t;
   return 1;
+}
+// Intersects<Shape> for a Ray (dt = inf) or Segment (dt = 1; p = a, d = b - a) collision.rs:169-373.
+// kinds: 0 sphere, 1 capsule, 2 triangle, 3 rectangle, 4 plane; returns 1 on hit, 0 on miss, -1 unsupported.
+int mgfo_intersection(const o_vec3* p, const o_vec3* d, float dt, const o_shape* sh, o_vec3* ip, float* t) {
+  Intersection i;
+  Ray r{V(*p), V(*d)};
+  bool hit;
+  switch (sh->kind) {
+    case 0: hit = ray_sphere(r, as_sphere(*sh), &i, dt); break;
+    case 1: hit = ray_capsule(r, as_capsule(*sh), &i, dt); break;
+    case 2: hit = ray_polygon(r, as_tri(*sh), &i, dt); break;
+    case 3: hit = ray_polygon(r, as_rect(*sh), &i, dt); break;
+    case 4: hit = ray_plane(r, as_plane(*sh), &i, dt); break;
+    default: return -1;
+  }
+  if (!hit) return 0;
+  *ip = O(i.p); *t = i.t;
+  return 1;
+}
+int mgfo_intersection_aabb(const o_vec3* p, const o_vec3* d, float dt, const o_aabb* a, o_vec3* ip, float* t) {
+  Intersection i;
+  if (!ray_aabb(Ray{V(*p), V(*d)}, AABB{V(a->c), V(a->r)}, &i, dt)) return 0;
+  *ip = O(i.p); *t = i.t;
+  return 1;
+}
+// BVH::raytrace bvh.rs:345-369: values + intersections with the leaf bounds, in the reference's DFS order
+int64_t mgfo_bvh_raytrace(void* b, const o_vec3* p, const o_vec3* d, float dt, uint64_t* vals, o_vec3* ips, float* ts, int64_t cap) {
+  int64_t n = 0;
+  Ray r{V(*p), V(*d)};
+  ((BVH<size_t>*)b)->raytrace(
+      [&](const AABB& bounds) { Intersection i; bool h = ray_aabb(r, bounds, &i, dt); return std::make_pair(h, i); },
+      [&](size_t v, const Intersection& i) {
+        if (n < cap) { vals[n] = v; ips[n] = O(i.p); ts[n] = i.t; }
+        ++n;
+      });
+  return n;
 }
 void mgfo_tri_closest_point(const o_shape* tri, const o_vec3* to, o_vec3* out) { *out = O(tri_closest_point(as_tri(*tri), V(*to))); }
 void mgfo_compute_basis(const o_vec3* n, o_vec3* out2) { V3 b[2]; compute_basis(V(*n), b); out2[0] = O(b[0]); out2[1] = O(b[1]); }
