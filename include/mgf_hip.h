@@ -112,6 +112,7 @@ typedef struct mgf_ctx mgf_ctx;
 typedef struct mgf_mesh mgf_mesh;
 typedef struct mgf_bvh mgf_bvh;
 typedef struct mgf_world mgf_world;
+typedef struct mgf_compound mgf_compound;
 
 /* ---- context ---------------------------------------------------------------------- */
 MGF_API mgf_status mgf_ctx_create(int device, mgf_ctx** out);
@@ -221,6 +222,20 @@ MGF_API mgf_status mgf_world_read_constraints(mgf_world* w, mgf_constraint* out,
 /* Solver::add_constraint in bulk + solve on the resident RigidBodyVec (solver.rs:66-78):
  * replaces the tick's constraint list with `cons` (insertion order = array order). */
 MGF_API mgf_status mgf_world_set_constraints(mgf_world* w, const mgf_constraint* cons, int64_t n);
+/* ---- Compound (compound.rs:230-352): a static aggregate of spheres and capsules with a pose and an internal BVH ----
+ * mgf_compound_new = Compound::new (components inserted into the BVH in order); set_pose writes the pub fields
+ * disp / rot (rot is assumed normalised, as in the reference); contacts_many = Contacts<RHS> for Compound with
+ * RHS = Moving<Sphere> / Moving<Capsule> for n moving components at once (per rhs: the contacts in the order the
+ * reference's callback receives them, CSR offsets); intersections = Intersects<Compound> for n particles;
+ * bounds = BoundedBy<AABB> (MGF_ERR_EMPTY for an empty compound, bvh.rs:265). */
+MGF_API mgf_status mgf_compound_new(mgf_ctx* ctx, const mgf_component* comps, int64_t n, mgf_compound** out);
+MGF_API void mgf_compound_free(mgf_compound* c);
+MGF_API mgf_status mgf_compound_set_pose(mgf_compound* c, mgf_vec3 disp, mgf_quat rot);
+MGF_API mgf_status mgf_compound_bounds(const mgf_compound* c, mgf_aabb* out);
+MGF_API mgf_status mgf_compound_contacts_many(mgf_compound* c, const mgf_moving_component* rhs, int64_t n, uint64_t* out_offsets,
+                                              mgf_contact* out, int64_t cap, int64_t* total);
+MGF_API mgf_status mgf_compound_intersections(mgf_compound* c, const mgf_particle* parts, int64_t n, mgf_intersection* out,
+                                              int32_t* hit);
 /* ---- spatial tiling across the GPUs of a node (one process per GPU) -----------
  * A tick on a tile is begin_tick -> [select_boundary, export_bodies -> neighbour -> import_ghosts]
  * -> collide -> iters x { solve(1) -> [export_velocities -> neighbour -> import_ghost_velocities] }.

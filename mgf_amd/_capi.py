@@ -110,6 +110,8 @@ SYMBOLS = [
     "mgf_bvh_new", "mgf_bvh_with_capacity", "mgf_bvh_free", "mgf_bvh_empty", "mgf_bvh_clear", "mgf_bvh_insert",
     "mgf_bvh_remove", "mgf_bvh_root", "mgf_bvh_get_leaf", "mgf_bvh_bounds", "mgf_bvh_query", "mgf_bvh_query_many",
     "mgf_bvh_raytrace", "mgf_bvh_raytrace_many", "mgf_intersections_batch",
+    "mgf_compound_new", "mgf_compound_free", "mgf_compound_set_pose", "mgf_compound_bounds", "mgf_compound_contacts_many",
+    "mgf_compound_intersections",
     "mgf_world_new", "mgf_world_free", "mgf_world_set_terrain", "mgf_world_add_bodies", "mgf_world_len",
     "mgf_world_step", "mgf_world_build_constraints", "mgf_world_solve", "mgf_world_complete_motion",
     "mgf_world_integrate", "mgf_world_get", "mgf_world_set", "mgf_world_read_state", "mgf_world_write_state",
@@ -170,6 +172,12 @@ def load_library():
         "mgf_bvh_raytrace": (i32, [vp, vp, vp, vp]),
         "mgf_bvh_raytrace_many": (i32, [vp, vp, i64, vp, vp, vp, i64, P(i64)]),
         "mgf_intersections_batch": (i32, [vp, i64, vp, vp, vp, vp, vp]),
+        "mgf_compound_new": (i32, [vp, vp, i64, P(vp)]),
+        "mgf_compound_free": (None, [vp]),
+        "mgf_compound_set_pose": (i32, [vp, Vec3, Quat]),
+        "mgf_compound_bounds": (i32, [vp, P(Aabb)]),
+        "mgf_compound_contacts_many": (i32, [vp, vp, i64, vp, vp, i64, P(i64)]),
+        "mgf_compound_intersections": (i32, [vp, vp, i64, vp, vp]),
         "mgf_bvh_dump": (i64, [vp, vp, vp, i64]),
         "mgf_world_new": (i32, [vp, P(Params), P(vp)]),
         "mgf_world_free": (None, [vp]),
@@ -380,6 +388,60 @@ def ray_capsule(ctx, p, d, cap_a, cap_d, cap_r):
     s = _shape(dict(kind="capsule", a=cap_a, d=cap_d, r=cap_r))
     _check(load_library().mgf_ray_capsule(ctx._h, C.byref(_v3(p)), C.byref(_v3(d)), C.byref(s), C.byref(ip), C.byref(t), C.byref(hit)))
     return (ip.tup(), t.value) if hit.value else None
+
+
+CONTACT_DTYPE = np.dtype([("a", "<f4", 3), ("b", "<f4", 3), ("n", "<f4", 3), ("t", "<f4")])
+
+
+class Compound:
+    """mgf::Compound (compound.rs:230-352): comps = COMPONENT_DTYPE array (tag, p, d, r)."""
+
+    def __init__(self, ctx, comps):
+        self._h = C.c_void_p()
+        self._ctx = ctx
+        comps = np.ascontiguousarray(comps, COMPONENT_DTYPE)
+        _check(load_library().mgf_compound_new(ctx._h if ctx is not None else None, comps.ctypes.data, len(comps), C.byref(self._h)))
+        if ctx is not None:
+            ctx._adopt(self)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load_library().mgf_compound_free(self._h)
+            self._h = None
+
+    def set_pose(self, disp, rot):
+        """rot = (s, x, y, z), assumed normalised"""
+        _check(load_library().mgf_compound_set_pose(self._h, _v3(disp), Quat(*[float(v) for v in rot])))
+
+    def bounds(self):
+        b = Aabb()
+        _check(load_library().mgf_compound_bounds(self._h, C.byref(b)))
+        return b.c.tup(), b.r.tup()
+
+    def contacts_many(self, moving):
+        """moving = MOVING_DTYPE array of swept spheres / capsules -> (offsets, CONTACT_DTYPE array)"""
+        moving = np.ascontiguousarray(moving, MOVING_DTYPE)
+        n = len(moving)
+        off = np.zeros(n + 1, np.uint64)
+        total = C.c_int64()
+        cap = max(4 * n, 16)
+        while True:
+            out = np.zeros(cap, CONTACT_DTYPE)
+            st = load_library().mgf_compound_contacts_many(self._h, moving.ctypes.data, n, off.ctypes.data, out.ctypes.data, cap, C.byref(total))
+            if st == ERR_CAPACITY and total.value > cap:
+                cap = total.value
+                continue
+            _check(st)
+            break
+        return off.astype(np.int64), out[:total.value]
+
+    def intersections(self, parts):
+        parts = np.ascontiguousarray(parts, PARTICLE_DTYPE)
+        n = len(parts)
+        out = np.zeros(max(n, 1), INTERSECTION_DTYPE)
+        hit = np.zeros(max(n, 1), np.int32)
+        _check(load_library().mgf_compound_intersections(self._h, parts.ctypes.data, n, out.ctypes.data, hit.ctypes.data))
+        return [(tuple(float(v) for v in out[i]["p"]), float(out[i]["t"])) if hit[i] else None for i in range(n)]
 
 
 class Mesh:

@@ -1837,6 +1837,113 @@ __global__ __launch_bounds__(kBlock) void k_bvh_raytrace(TerrainDev M, const Par
 }
 
 struct MovingIn { int tag; float p[3], d[3], r; float delta[3]; };
+// ---- Compound (compound.rs:230-352): components + internal reference-built BVH + pose -------------------
+struct CompIn { int tag; float p[3], d[3], r; };
+struct CompoundDev {
+  TerrainDev tree;       // flattened BVH<AABB, Component>; leaf value = component index
+  const CompIn* comps;
+  float disp[3];
+  float rot[4];          // s, x, y, z
+};
+__device__ __forceinline__ Comp to_comp(const CompIn& m) { Comp k; k.kind = m.tag; k.p = ld3(m.p); k.d = ld3(m.d); k.r = m.r; return k; }
+// Volumetric::rotate for AABB geom.rs:940-985
+HD Box box_rotate(const Box& b, Quat rot) {
+  V3 vx = rotate(rot, mk3(b.r.x, 0.0f, 0.0f)), vy = rotate(rot, mk3(0.0f, b.r.y, 0.0f)), vz = rotate(rot, mk3(0.0f, 0.0f, b.r.z));
+  V3 p[8] = {b.c + (vx + vy + vz), b.c + (vx + vy - vz), b.c + (vx - vy + vz), b.c + (vx - vy - vz),
+             b.c + (-vx + vy + vz), b.c + (-vx + vy - vz), b.c + (-vx - vy + vz), b.c + (-vx - vy - vz)};
+  V3 lo = p[7], hi = p[7];
+#pragma unroll
+  for (int e = 6; e >= 0; --e) {  // p1.min(p2.min(... p8)): nested right to left
+    lo = mk3(fmin_rs(p[e].x, lo.x), fmin_rs(p[e].y, lo.y), fmin_rs(p[e].z, lo.z));
+    hi = mk3(fmax_rs(p[e].x, hi.x), fmax_rs(p[e].y, hi.y), fmax_rs(p[e].z, hi.z));
+  }
+  Box o; o.r = (hi - lo) / 2.0f; o.c = (hi + lo) / 2.0f;
+  return o;
+}
+// Volumetric::rotate for Component (sphere: no-op; capsule: about its centre) geom.rs:999-1015
+__device__ inline Comp comp_rotate(Comp k, Quat r) {
+  if (k.kind == KIND_CAPSULE) { V3 ctr = comp_center(k); k.p = ctr + rotate(r, k.p - ctr); k.d = rotate(r, k.d); }
+  return k;
+}
+// Volumetric::rotate_about geom.rs:932-937 (set_pos moves the centre)
+__device__ inline Comp comp_rotate_about(Comp k, Quat r, V3 p) {
+  V3 ctr = comp_center(k);
+  V3 disp = (p + rotate(r, ctr - p)) - ctr;
+  k.p = k.p + disp;
+  return comp_rotate(k, r);
+}
+__device__ inline ShapeIn comp_shape(const Comp& k) {
+  ShapeIn s; s.kind = k.kind == KIND_SPHERE ? MGF_SPHERE : MGF_CAPSULE;
+  for (int e = 0; e < 12; ++e) s.v[e] = 0.0f;
+  if (k.kind == KIND_SPHERE) { st3(s.v, k.p); s.v[3] = k.r; }
+  else { st3(s.v, k.p); st3(s.v + 3, k.d); s.v[6] = k.r; }
+  return s;
+}
+// Contacts<RHS> for Compound compound.rs:334-352, RHS = Moving<Sphere | Capsule>: one thread per rhs, contacts in BVH
+// query order (count pass / fill pass).
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void k_compound_contacts(CompoundDev D, const MovingIn* rhs, int64_t n, uint32_t* cnt, const uint32_t* off,
+                                                              ContactOut* out) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  Comp R; R.kind = rhs[i].tag; R.p = ld3(rhs[i].p); R.d = ld3(rhs[i].d); R.r = rhs[i].r;
+  V3 vel = ld3(rhs[i].delta), disp = ld3(D.disp);
+  Quat rot = mkq(D.rot[0], mk3(D.rot[1], D.rot[2], D.rot[3]));
+  Quat conj = mkq(rot.s, -rot.v);
+  Box rb = box_rotate(swept_bounds(R, vel), conj);
+  rb.c = rotate(conj, rb.c + -disp) + disp;
+  ShapeIn rs = comp_shape(R);
+  uint32_t m = 0, base = FILL ? off[i] : 0;
+  terrain_traverse(D.tree, rb, [&](uint32_t ci) {
+    Comp shape = comp_rotate_about(to_comp(D.comps[ci]), rot, mk3(0.0f, 0.0f, 0.0f));
+    shape.p = shape.p + disp;
+    Contact c[2];
+    int k = contacts_dispatch(rs, true, vel, comp_shape(shape), false, mk3(0, 0, 0), c);  // Moving<Recv>.contacts(&Arg) :1368-1382
+    for (int e = 0; e < k; ++e) {
+      if (FILL) out[base + m] = to_out(neg(c[e]));
+      ++m;
+    }
+  });
+  if (!FILL) cnt[i] = m;
+}
+// Intersects<Compound> for a particle compound.rs:309-332
+__global__ __launch_bounds__(kBlock) void k_compound_intersections(CompoundDev D, const ParticleIn* parts, int64_t n, InterOut* out, int32_t* hit) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  V3 pp = ld3(parts[i].p), pd = ld3(parts[i].d), disp = ld3(D.disp);
+  const float dt = parts[i].dt;
+  Quat rot = mkq(D.rot[0], mk3(D.rot[1], D.rot[2], D.rot[3]));
+  Quat conj = mkq(rot.s, -rot.v);
+  V3 rp = rotate(conj, pp + -disp) + disp, rd = rotate(conj, pd);
+  bool have = false;
+  V3 best_p = mk3(0, 0, 0); float best_t = 0.0f;
+  uint32_t stack[kStack];
+  int sp = 0;
+  if (D.tree.n_nodes) stack[sp++] = D.tree.root;
+  while (sp > 0) {
+    uint32_t top = stack[--sp];
+    const float4* raw = reinterpret_cast<const float4*>(&D.tree.nodes[top]);
+    float4 n0 = raw[0], n1 = raw[1];
+    Box nb; nb.c = xyz(n0); nb.r = xyz(n1);
+    V3 ip; float t;
+    if (ray_box(rp, rd, nb, &ip, &t, kInf)) {  // the BVH is traced with a Ray (DT = inf), :315-316
+      uint32_t w0 = f2u(n0.w), w1 = f2u(n1.w);
+      if (w0 & 0x80000000u) {
+        if (!(t > dt)) {
+          Comp shape = comp_rotate(to_comp(D.comps[w0 & 0x7FFFFFFFu]), rot);
+          shape.p = shape.p + disp;
+          ParticleIn q = parts[i];
+          V3 sip; float st;
+          if (intersection_dispatch(q, comp_shape(shape), &sip, &st) == 1 && !(have && st > best_t)) { best_p = sip; best_t = st; have = true; }
+        }
+      } else if (sp + 2 <= kStack) { stack[sp++] = w0; stack[sp++] = w1; }
+      else if (D.tree.err) *D.tree.err = 1u;
+    }
+  }
+  hit[i] = have ? 1 : 0;
+  if (have) { st3(out[i].p, best_p); out[i].t = best_t; }
+}
+
 struct LocalOut { float la[3], lb[3]; ContactOut g; };
 __device__ __forceinline__ Comp to_comp(const MovingIn& m) {
   Comp k; k.kind = m.tag; k.p = ld3(m.p); k.d = ld3(m.d); k.r = m.r; return k;

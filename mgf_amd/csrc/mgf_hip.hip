@@ -372,6 +372,136 @@ extern "C" mgf_status mgf_intersections_batch(mgf_ctx* ctx, int64_t n, const mgf
   return MGF_OK;
 }
 
+static inline Comp comp_of(const mgf_component& c) {
+  Comp k; k.kind = c.tag; k.p = mk3(c.p.x, c.p.y, c.p.z); k.d = mk3(c.d.x, c.d.y, c.d.z); k.r = c.r;
+  return k;
+}
+// ---- mgf_compound (compound.rs:230-352) -------------------------------------------------------
+static_assert(sizeof(CompIn) == sizeof(mgf_component), "component layout");
+struct mgf_compound {
+  mgf_ctx* ctx;
+  std::vector<mgf_component> comps;
+  TreeMirror m;            // BVH<AABB, Component>: leaf value = index into comps (the reference stores the Component itself)
+  DBuf<CompIn> d_comps;
+  bool comps_uploaded = false;
+  V3 disp = mk3(0, 0, 0);
+  Quat rot = mkq(1.0f, mk3(0, 0, 0));
+  mgf_status sync() {
+    MGF_TRY(m.sync(ctx));
+    if (!comps_uploaded) {
+      MGF_TRY(d_comps.ensure(std::max<size_t>(comps.size(), 1), ctx->stream));
+      MGF_TRY(h2d(ctx, d_comps.p, reinterpret_cast<const CompIn*>(comps.data()), comps.size()));
+      comps_uploaded = true;
+    }
+    return MGF_OK;
+  }
+  CompoundDev dev(uint32_t* err) const {
+    CompoundDev D;
+    D.tree = m.dev(nullptr, nullptr, mk3(0, 0, 0), err);
+    D.comps = d_comps.p;
+    D.disp[0] = disp.x; D.disp[1] = disp.y; D.disp[2] = disp.z;
+    D.rot[0] = rot.s; D.rot[1] = rot.v.x; D.rot[2] = rot.v.y; D.rot[3] = rot.v.z;
+    return D;
+  }
+};
+// Compound::new compound.rs:244-257: components are inserted into the internal BVH in order
+extern "C" mgf_status mgf_compound_new(mgf_ctx* ctx, const mgf_component* comps, int64_t n, mgf_compound** out) {
+  if (!out || n < 0 || (n && !comps)) return fail(MGF_ERR_INVALID, "bad argument");
+  std::unique_ptr<mgf_compound> c(new mgf_compound());
+  c->ctx = ctx;
+  for (int64_t i = 0; i < n; ++i) {
+    if (comps[i].tag != MGF_SPHERE && comps[i].tag != MGF_CAPSULE) return fail(MGF_ERR_INVALID, "component tag must be sphere or capsule");
+    if (!(comps[i].r >= 0.0f)) return fail(MGF_ERR_INVALID, "radius must be >= 0 (geom.rs:300,328)");
+    c->comps.push_back(comps[i]);
+    c->m.tree.insert(comp_bounds(comp_of(comps[i])), (uint64_t)i);
+  }
+  *out = c.release();
+  return MGF_OK;
+}
+extern "C" void mgf_compound_free(mgf_compound* c) {
+  if (!c) return;
+  if (c->ctx) { (void)hipSetDevice(c->ctx->device); (void)hipStreamSynchronize(c->ctx->stream); }
+  delete c;
+}
+extern "C" mgf_status mgf_compound_set_pose(mgf_compound* c, mgf_vec3 disp, mgf_quat rot) {  // pub fields disp, rot (:234-236)
+  if (!c) return fail(MGF_ERR_INVALID, "compound is NULL");
+  c->disp = mk3(disp.x, disp.y, disp.z);
+  c->rot = mkq(rot.s, mk3(rot.x, rot.y, rot.z));
+  return MGF_OK;
+}
+// contacts of n moving components against the compound (Contacts<RHS> for Compound :334-352, RHS = Moving<Sphere> /
+// Moving<Capsule>); per rhs the contacts in the order the reference's callback sees them (CSR offsets).
+extern "C" mgf_status mgf_compound_contacts_many(mgf_compound* c, const mgf_moving_component* rhs, int64_t n, uint64_t* out_offsets,
+                                                 mgf_contact* out, int64_t cap, int64_t* total) {
+  if (!c || n < 0 || (n && !rhs) || !out_offsets) return fail(MGF_ERR_INVALID, "bad argument");
+  mgf_ctx* ctx = c->ctx;
+  MGF_TRY(ctx_bind(ctx));
+  for (int64_t i = 0; i <= n; ++i) out_offsets[i] = 0;
+  if (total) *total = 0;
+  if (n == 0 || c->comps.empty()) return MGF_OK;
+  for (int64_t i = 0; i < n; ++i)
+    if (rhs[i].shape.tag != MGF_SPHERE && rhs[i].shape.tag != MGF_CAPSULE) return fail(MGF_ERR_INVALID, "rhs must be a moving sphere or capsule");
+  MGF_TRY(c->sync());
+  DBuf<MovingIn> d_rhs; DBuf<uint32_t> d_cnt, d_off, d_err; DBuf<ContactOut> d_out;
+  MGF_TRY(d_rhs.ensure((size_t)n, ctx->stream)); MGF_TRY(d_cnt.ensure((size_t)n + 1, ctx->stream)); MGF_TRY(d_off.ensure((size_t)n + 1, ctx->stream));
+  MGF_TRY(d_err.ensure(1, ctx->stream));
+  MGF_HIP_TRY(hipMemsetAsync(d_err.p, 0, 4, ctx->stream));
+  MGF_TRY(h2d(ctx, d_rhs.p, reinterpret_cast<const MovingIn*>(rhs), (size_t)n));
+  CompoundDev D = c->dev(d_err.p);
+  k_compound_contacts<false><<<nblk(n), kBlock, 0, ctx->stream>>>(D, d_rhs.p, n, d_cnt.p, nullptr, nullptr);
+  LAUNCH_CHECK();
+  MGF_TRY(prim_exclusive_scan_u32(ctx, d_cnt.p, d_off.p, (size_t)n + 1));
+  std::vector<uint32_t> off((size_t)n + 1);
+  MGF_TRY(d2h(ctx, off.data(), d_off.p, (size_t)n + 1));
+  for (int64_t i = 0; i <= n; ++i) out_offsets[i] = off[(size_t)i];
+  uint32_t tot = off[(size_t)n];
+  if (total) *total = tot;
+  if ((int64_t)tot > cap) return fail(MGF_ERR_CAPACITY, "contact buffer too small");
+  if (tot) {
+    if (!out) return fail(MGF_ERR_INVALID, "NULL contact buffer");
+    MGF_TRY(d_out.ensure(tot, ctx->stream));
+    k_compound_contacts<true><<<nblk(n), kBlock, 0, ctx->stream>>>(D, d_rhs.p, n, nullptr, d_off.p, d_out.p);
+    LAUNCH_CHECK();
+    MGF_TRY(d2h(ctx, reinterpret_cast<ContactOut*>(out), d_out.p, tot));
+  }
+  uint32_t err = 0;
+  MGF_TRY(d2h(ctx, &err, d_err.p, 1));
+  if (err) return fail(MGF_ERR_CAPACITY, "BVH traversal stack overflow");
+  return MGF_OK;
+}
+// Intersects<Compound> for n particles (:309-332)
+extern "C" mgf_status mgf_compound_intersections(mgf_compound* c, const mgf_particle* parts, int64_t n, mgf_intersection* out, int32_t* hit) {
+  if (!c || n < 0 || (n && (!parts || !out || !hit))) return fail(MGF_ERR_INVALID, "bad argument");
+  mgf_ctx* ctx = c->ctx;
+  MGF_TRY(ctx_bind(ctx));
+  if (n == 0) return MGF_OK;
+  if (c->comps.empty()) { for (int64_t i = 0; i < n; ++i) hit[i] = 0; return MGF_OK; }
+  MGF_TRY(c->sync());
+  DBuf<ParticleIn> dp; DBuf<InterOut> dout; DBuf<int32_t> dh; DBuf<uint32_t> d_err;
+  MGF_TRY(dp.ensure((size_t)n, ctx->stream)); MGF_TRY(dout.ensure((size_t)n, ctx->stream)); MGF_TRY(dh.ensure((size_t)n, ctx->stream));
+  MGF_TRY(d_err.ensure(1, ctx->stream));
+  MGF_HIP_TRY(hipMemsetAsync(d_err.p, 0, 4, ctx->stream));
+  MGF_TRY(h2d(ctx, dp.p, reinterpret_cast<const ParticleIn*>(parts), (size_t)n));
+  k_compound_intersections<<<nblk(n), kBlock, 0, ctx->stream>>>(c->dev(d_err.p), dp.p, n, dout.p, dh.p);
+  LAUNCH_CHECK();
+  MGF_TRY(d2h(ctx, reinterpret_cast<InterOut*>(out), dout.p, (size_t)n));
+  MGF_TRY(d2h(ctx, hit, dh.p, (size_t)n));
+  uint32_t err = 0;
+  MGF_TRY(d2h(ctx, &err, d_err.p, 1));
+  if (err) return fail(MGF_ERR_CAPACITY, "BVH traversal stack overflow");
+  return MGF_OK;
+}
+// BoundedBy<AABB> for Compound :274-278 (host arithmetic, same functions as the device code)
+extern "C" mgf_status mgf_compound_bounds(const mgf_compound* c, mgf_aabb* out) {
+  if (!c || !out) return fail(MGF_ERR_INVALID, "NULL argument");
+  if (c->m.tree.empty()) return fail(MGF_ERR_EMPTY, "BVH is empty, there is no root node");
+  Box b = c->m.tree.node(c->m.tree.root()).box;
+  b = box_rotate(b, c->rot);
+  b.c = b.c + c->disp;
+  *out = from_box(b);
+  return MGF_OK;
+}
+
 // ---- mgf_mesh --------------------------------------------------------------------------------
 extern "C" mgf_status mgf_mesh_new(mgf_ctx* ctx, mgf_mesh** out) {  // ctx may be NULL: host-only mesh
   if (!out) return fail(MGF_ERR_INVALID, "NULL argument");
@@ -562,10 +692,6 @@ static M3 tensor_of(const Comp& k, float m) {
   }
   M3 outer = m3_cols(disp * disp.x, disp * disp.y, disp * disp.z);
   return i + m * (m3_diag(1.0f, 1.0f, 1.0f) * dot(disp, disp) - outer);
-}
-static inline Comp comp_of(const mgf_component& c) {
-  Comp k; k.kind = c.tag; k.p = mk3(c.p.x, c.p.y, c.p.z); k.d = mk3(c.d.x, c.d.y, c.d.z); k.r = c.r;
-  return k;
 }
 extern "C" mgf_status mgf_inertia_tensor(const mgf_component* c, float mass, float out9[9]) {
   if (!c || !out9 || (c->tag != MGF_SPHERE && c->tag != MGF_CAPSULE)) return fail(MGF_ERR_INVALID, "bad component");

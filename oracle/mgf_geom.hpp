@@ -185,6 +185,11 @@ static inline AABB bounds(const Triangle& t) {  // bounds.rs:137-154
   float d2 = fmaxf_rs(std::fabs(t.a.z - c.z), fmaxf_rs(std::fabs(t.b.z - c.z), std::fabs(t.c.z - c.z)));
   return AABB{c, v3(d0, d1, d2)};
 }
+static inline AABB bounds(const Rectangle& q) {  // bounds.rs:156-168
+  V3 p1 = q.c + q.u[0] * q.e[0], p2 = q.c + q.u[1] * q.e[1];
+  return AABB{q.c, v3(fmaxf_rs(std::fabs(p1.x - q.c.x), std::fabs(p2.x - q.c.x)), fmaxf_rs(std::fabs(p1.y - q.c.y), std::fabs(p2.y - q.c.y)),
+                      fmaxf_rs(std::fabs(p1.z - q.c.z), std::fabs(p2.z - q.c.z)))};
+}
 static inline AABB bounds(const Sphere& s) { return AABB{s.c, v3(s.r, s.r, s.r)}; }  // bounds.rs:170-177
 static inline AABB bounds(const Capsule& c) {  // bounds.rs:179-188
   float r = c.r + magnitude(c.d) * 0.5f;

@@ -104,6 +104,15 @@ def lib():
         L.mgfo_intersection_aabb.restype = C.c_int
         L.mgfo_bvh_raytrace.argtypes = [C.c_void_p, P(Vec3), P(Vec3), C.c_float, P(C.c_uint64), P(Vec3), P(C.c_float), C.c_int64]
         L.mgfo_bvh_raytrace.restype = C.c_int64
+        L.mgfo_compound_new.argtypes = [P(Component), C.c_int64]
+        L.mgfo_compound_new.restype = C.c_void_p
+        L.mgfo_compound_free.argtypes = [C.c_void_p]
+        L.mgfo_compound_set_pose.argtypes = [C.c_void_p, P(Vec3), P(Quat)]
+        L.mgfo_compound_bounds.argtypes = [C.c_void_p, P(Aabb)]
+        L.mgfo_compound_contacts.argtypes = [C.c_void_p, P(Shape), P(Vec3), P(Contact), C.c_int]
+        L.mgfo_compound_contacts.restype = C.c_int
+        L.mgfo_compound_intersection.argtypes = [C.c_void_p, P(Vec3), P(Vec3), C.c_float, P(Vec3), P(C.c_float)]
+        L.mgfo_compound_intersection.restype = C.c_int
         L.mgfo_tri_closest_point.argtypes = [P(Shape), P(Vec3), P(Vec3)]
         L.mgfo_compute_basis.argtypes = [P(Vec3), P(Vec3)]
         L.mgfo_quat_from_arc.argtypes = [P(Vec3), P(Vec3), P(Quat)]
@@ -248,6 +257,42 @@ def local_contacts_pair(ca, da, cb, db, cap=8):
     n = lib().mgfo_local_contacts_pair(C.byref(ca), C.byref(vec3(da)), C.byref(cb), C.byref(vec3(db)), out, cap)
     return [dict(local_a=out[i].local_a.tup(), local_b=out[i].local_b.tup(), a=out[i].glob.a.tup(),
                  b=out[i].glob.b.tup(), n=out[i].glob.n.tup(), t=out[i].glob.t) for i in range(min(n, cap))]
+
+
+class Compound:
+    """mgf::Compound (compound.rs:230-352): components = list of component(tag, p, d, r)."""
+
+    def __init__(self, comps):
+        arr = (Component * len(comps))(*comps)
+        self.h = lib().mgfo_compound_new(arr, len(comps))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().mgfo_compound_free(self.h)
+            self.h = None
+
+    def set_pose(self, disp, rot):
+        """rot = (s, x, y, z)"""
+        q = Quat(*[float(v) for v in rot])
+        lib().mgfo_compound_set_pose(self.h, C.byref(vec3(disp)), C.byref(q))
+
+    def bounds(self):
+        b = Aabb()
+        lib().mgfo_compound_bounds(self.h, C.byref(b))
+        return b.c.tup(), b.r.tup()
+
+    def contacts(self, sh, vel, cap=16):
+        """compound.contacts(&Moving::sweep(shape, vel)) -> contacts in callback order"""
+        out = (Contact * cap)()
+        n = lib().mgfo_compound_contacts(self.h, C.byref(sh), C.byref(vec3(vel)), out, cap)
+        if n < 0:
+            raise ValueError("unsupported shape")
+        return [dict(a=out[i].a.tup(), b=out[i].b.tup(), n=out[i].n.tup(), t=out[i].t) for i in range(min(n, cap))]
+
+    def intersection(self, p, d, dt=float("inf")):
+        ip, t = Vec3(), C.c_float()
+        hit = lib().mgfo_compound_intersection(self.h, C.byref(vec3(p)), C.byref(vec3(d)), C.c_float(dt), C.byref(ip), C.byref(t))
+        return (ip.tup(), t.value) if hit else None
 
 
 class Bvh:

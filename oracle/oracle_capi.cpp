@@ -5,6 +5,7 @@
 #include <cstring>
 #include <utility>
 
+#include "mgf_compound.hpp"
 #include "mgf_world.hpp"
 
 using namespace mgfo;
@@ -168,6 +169,37 @@ int64_t mgfo_bvh_raytrace(void* b, const o_vec3* p, const o_vec3* d, float dt, u
         ++n;
       });
   return n;
+}
+// ---- Compound (compound.rs:230-352) ----
+void* mgfo_compound_new(const o_component* comps, int64_t n) {
+  std::vector<Component> v;
+  for (int64_t i = 0; i < n; ++i) v.push_back(as_component(comps[i]));
+  return new Compound(v);
+}
+void mgfo_compound_free(void* c) { delete (Compound*)c; }
+void mgfo_compound_set_pose(void* c, const o_vec3* disp, const o_quat* rot) {
+  ((Compound*)c)->disp = V(*disp);
+  ((Compound*)c)->rot = Quat{rot->s, v3(rot->x, rot->y, rot->z)};
+}
+void mgfo_compound_bounds(void* c, o_aabb* out) { AABB b = ((Compound*)c)->bounds(); out->c = O(b.c); out->r = O(b.r); }
+// compound.contacts(&Moving(shape, vel)); shape kinds 0 sphere, 1 capsule, 3 rectangle
+int mgfo_compound_contacts(void* cp, const o_shape* sh, const o_vec3* vel, o_contact* out, int cap) {
+  Compound* c = (Compound*)cp;
+  int n = 0;
+  auto cb = [&](const Contact& k) { if (n < cap) out[n] = OC(k); ++n; };
+  switch (sh->kind) {
+    case 0: c->contacts(sweep(as_sphere(*sh), V(*vel)), cb); break;
+    case 1: c->contacts(sweep(as_capsule(*sh), V(*vel)), cb); break;
+    case 3: c->contacts(sweep(as_rect(*sh), V(*vel)), cb); break;
+    default: return -1;
+  }
+  return n;
+}
+int mgfo_compound_intersection(void* cp, const o_vec3* p, const o_vec3* d, float dt, o_vec3* ip, float* t) {
+  Intersection i;
+  if (!((Compound*)cp)->intersection(Ray{V(*p), V(*d)}, dt, &i)) return 0;
+  *ip = O(i.p); *t = i.t;
+  return 1;
 }
 void mgfo_tri_closest_point(const o_shape* tri, const o_vec3* to, o_vec3* out) { *out = O(tri_closest_point(as_tri(*tri), V(*to))); }
 void mgfo_compute_basis(const o_vec3* n, o_vec3* out2) { V3 b[2]; compute_basis(V(*n), b); out2[0] = O(b[0]); out2[1] = O(b[1]); }
