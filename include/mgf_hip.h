@@ -222,6 +222,14 @@ MGF_API mgf_status mgf_world_read_constraints(mgf_world* w, mgf_constraint* out,
 /* Solver::add_constraint in bulk + solve on the resident RigidBodyVec (solver.rs:66-78):
  * replaces the tick's constraint list with `cons` (insertion order = array order). */
 MGF_API mgf_status mgf_world_set_constraints(mgf_world* w, const mgf_constraint* cons, int64_t n);
+/* ---- scene I/O: the serde_json shape of the reference's persistent types (bvh.rs:29-47, pool.rs:25-41, mesh.rs:31-37,
+ * geom.rs:256-260; cgmath vectors as {"x","y","z"}).  *_to_json writes a NUL-terminated string; *len is its length
+ * (MGF_ERR_CAPACITY if cap < *len + 1).  *_from_json rebuilds the identical tree - entry for entry, free list included -
+ * so later inserts reuse the same slots as in the process that wrote the file. */
+MGF_API mgf_status mgf_bvh_to_json(const mgf_bvh* b, char* buf, int64_t cap, int64_t* len);
+MGF_API mgf_status mgf_bvh_from_json(mgf_ctx* ctx, const char* json, int64_t len, mgf_bvh** out);
+MGF_API mgf_status mgf_mesh_to_json(const mgf_mesh* m, char* buf, int64_t cap, int64_t* len);
+MGF_API mgf_status mgf_mesh_from_json(mgf_ctx* ctx, const char* json, int64_t len, mgf_mesh** out);
 /* ---- Compound (compound.rs:230-352): a static aggregate of spheres and capsules with a pose and an internal BVH ----
  * mgf_compound_new = Compound::new (components inserted into the BVH in order); set_pose writes the pub fields
  * disp / rot (rot is assumed normalised, as in the reference); contacts_many = Contacts<RHS> for Compound with

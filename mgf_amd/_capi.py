@@ -112,6 +112,7 @@ SYMBOLS = [
     "mgf_bvh_raytrace", "mgf_bvh_raytrace_many", "mgf_intersections_batch",
     "mgf_compound_new", "mgf_compound_free", "mgf_compound_set_pose", "mgf_compound_bounds", "mgf_compound_contacts_many",
     "mgf_compound_intersections",
+    "mgf_bvh_to_json", "mgf_bvh_from_json", "mgf_mesh_to_json", "mgf_mesh_from_json",
     "mgf_world_new", "mgf_world_free", "mgf_world_set_terrain", "mgf_world_add_bodies", "mgf_world_len",
     "mgf_world_step", "mgf_world_build_constraints", "mgf_world_solve", "mgf_world_complete_motion",
     "mgf_world_integrate", "mgf_world_get", "mgf_world_set", "mgf_world_read_state", "mgf_world_write_state",
@@ -178,6 +179,10 @@ def load_library():
         "mgf_compound_bounds": (i32, [vp, P(Aabb)]),
         "mgf_compound_contacts_many": (i32, [vp, vp, i64, vp, vp, i64, P(i64)]),
         "mgf_compound_intersections": (i32, [vp, vp, i64, vp, vp]),
+        "mgf_bvh_to_json": (i32, [vp, vp, i64, P(i64)]),
+        "mgf_bvh_from_json": (i32, [vp, C.c_char_p, i64, P(vp)]),
+        "mgf_mesh_to_json": (i32, [vp, vp, i64, P(i64)]),
+        "mgf_mesh_from_json": (i32, [vp, C.c_char_p, i64, P(vp)]),
         "mgf_bvh_dump": (i64, [vp, vp, vp, i64]),
         "mgf_world_new": (i32, [vp, P(Params), P(vp)]),
         "mgf_world_free": (None, [vp]),
@@ -390,6 +395,16 @@ def ray_capsule(ctx, p, d, cap_a, cap_d, cap_r):
     return (ip.tup(), t.value) if hit.value else None
 
 
+def _to_json(fn, handle):
+    n = C.c_int64()
+    st = fn(handle, None, 0, C.byref(n))
+    if st not in (OK, ERR_CAPACITY):
+        _check(st)
+    buf = C.create_string_buffer(n.value + 1)
+    _check(fn(handle, buf, n.value + 1, C.byref(n)))
+    return buf.value.decode()
+
+
 CONTACT_DTYPE = np.dtype([("a", "<f4", 3), ("b", "<f4", 3), ("n", "<f4", 3), ("t", "<f4")])
 
 
@@ -460,6 +475,21 @@ class Mesh:
             load_library().mgf_mesh_free(self._h)
             self._h = None
 
+    def to_json(self):
+        """serde_json shape of mgf::Mesh (mesh.rs:31-37)"""
+        return _to_json(load_library().mgf_mesh_to_json, self._h)
+
+    @classmethod
+    def from_json(cls, ctx, text):
+        self = cls.__new__(cls)
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        raw = text.encode()
+        _check(load_library().mgf_mesh_from_json(ctx._h if ctx is not None else None, raw, len(raw), C.byref(self._h)))
+        if ctx is not None:
+            ctx._adopt(self)
+        return self
+
     def push_vert(self, p):
         i = C.c_uint64()
         _check(load_library().mgf_mesh_push_vert(self._h, _v3(p), C.byref(i)))
@@ -510,6 +540,21 @@ class Bvh:
         if getattr(self, "_h", None):
             load_library().mgf_bvh_free(self._h)
             self._h = None
+
+    def to_json(self):
+        """serde_json shape of BVH<AABB, usize> (bvh.rs:29-47 over pool.rs:25-41)"""
+        return _to_json(load_library().mgf_bvh_to_json, self._h)
+
+    @classmethod
+    def from_json(cls, ctx, text):
+        self = cls.__new__(cls)
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        raw = text.encode()
+        _check(load_library().mgf_bvh_from_json(ctx._h if ctx is not None else None, raw, len(raw), C.byref(self._h)))
+        if ctx is not None:
+            ctx._adopt(self)
+        return self
 
     def empty(self):
         return bool(load_library().mgf_bvh_empty(self._h))

@@ -41,6 +41,12 @@ class HostBvh {
   void reserve(uint64_t n) { nodes_.reserve(n); }
   void clear() { nodes_.clear(); live_ = 0; has_free_ = false; root_ = 0; ++version_; }
   uint64_t version() const { return version_; }
+  bool has_free() const { return has_free_; }        // Pool::free_list (pool.rs:38) is Some(free_head())
+  uint64_t free_head() const { return free_head_; }
+  // deserialised state (scene_io.h has validated the links)
+  void restore(std::vector<Node> nodes, uint64_t root, uint64_t live, bool has_free, uint64_t free_head) {
+    nodes_ = std::move(nodes); root_ = root; live_ = live; has_free_ = has_free; free_head_ = free_head; ++version_;
+  }
 
   // BVH::insert bvh.rs:125-217
   uint64_t insert(const Box& b, uint64_t value) {

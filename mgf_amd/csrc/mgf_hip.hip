@@ -9,6 +9,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "scene_io.h"
 
 using namespace mgf;
 
@@ -376,6 +377,77 @@ static inline Comp comp_of(const mgf_component& c) {
   Comp k; k.kind = c.tag; k.p = mk3(c.p.x, c.p.y, c.p.z); k.d = mk3(c.d.x, c.d.y, c.d.z); k.r = c.r;
   return k;
 }
+// ---- scene I/O (serde_json shape of BVH<AABB, usize> and Mesh; scene_io.h) --------------------------------
+static mgf_status emit_json(const std::string& js, char* buf, int64_t cap, int64_t* len) {
+  if (len) *len = (int64_t)js.size();
+  if (!buf || cap < (int64_t)js.size() + 1) return fail(MGF_ERR_CAPACITY, "JSON buffer too small (len reports the size needed, plus one for the terminator)");
+  memcpy(buf, js.data(), js.size());
+  buf[js.size()] = 0;
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_bvh_to_json(const mgf_bvh* b, char* buf, int64_t cap, int64_t* len) {
+  if (!b) return fail(MGF_ERR_INVALID, "NULL argument");
+  std::string js;
+  sio::write_bvh(js, b->m.tree);
+  return emit_json(js, buf, cap, len);
+}
+extern "C" mgf_status mgf_bvh_from_json(mgf_ctx* ctx, const char* json, int64_t len, mgf_bvh** out) {
+  if (!json || len < 0 || !out) return fail(MGF_ERR_INVALID, "bad argument");
+  sio::Parser P{json, json + len, {}};
+  sio::Val v;
+  if (!P.value(&v)) { set_error("JSON: %s at byte %lld", P.err.c_str(), (long long)(P.p - json)); return MGF_ERR_INVALID; }
+  std::unique_ptr<mgf_bvh> b(new mgf_bvh{ctx, {}});
+  std::string err;
+  if (!sio::read_bvh(v, &b->m.tree, &err)) { set_error("%s", err.c_str()); return MGF_ERR_INVALID; }
+  *out = b.release();
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_mesh_to_json(const mgf_mesh* m, char* buf, int64_t cap, int64_t* len) {
+  if (!m) return fail(MGF_ERR_INVALID, "NULL argument");
+  std::string js = "{\"x\":";
+  sio::put_v3(js, m->x);
+  js += ",\"verts\":[";
+  for (size_t i = 0; i < m->verts.size(); ++i) { if (i) js += ','; sio::put_v3(js, m->verts[i]); }
+  js += "],\"faces\":[";
+  for (size_t i = 0; i + 2 < m->faces.size(); i += 3) {
+    if (i) js += ',';
+    js += '['; sio::put_u64(js, m->faces[i]); js += ','; sio::put_u64(js, m->faces[i + 1]); js += ','; sio::put_u64(js, m->faces[i + 2]); js += ']';
+  }
+  js += "],\"bvh\":";
+  sio::write_bvh(js, m->m.tree);
+  js += "}";
+  return emit_json(js, buf, cap, len);
+}
+extern "C" mgf_status mgf_mesh_from_json(mgf_ctx* ctx, const char* json, int64_t len, mgf_mesh** out) {
+  if (!json || len < 0 || !out) return fail(MGF_ERR_INVALID, "bad argument");
+  sio::Parser P{json, json + len, {}};
+  sio::Val v;
+  if (!P.value(&v)) { set_error("JSON: %s at byte %lld", P.err.c_str(), (long long)(P.p - json)); return MGF_ERR_INVALID; }
+  std::unique_ptr<mgf_mesh> m(new mgf_mesh());
+  m->ctx = ctx;
+  const sio::Val* verts = v.get("verts");
+  const sio::Val* faces = v.get("faces");
+  const sio::Val* bvh = v.get("bvh");
+  if (v.kind != sio::Val::Obj || !sio::as_v3(v.get("x"), &m->x) || !verts || verts->kind != sio::Val::Arr || !faces || faces->kind != sio::Val::Arr || !bvh)
+    return fail(MGF_ERR_INVALID, "Mesh: expected {x, verts, faces, bvh}");
+  for (const sio::Val& e : verts->arr) { V3 p; if (!sio::as_v3(&e, &p)) return fail(MGF_ERR_INVALID, "Mesh: bad vertex"); m->verts.push_back(p); }
+  for (const sio::Val& e : faces->arr) {
+    uint64_t id[3];
+    if (e.kind != sio::Val::Arr || e.arr.size() != 3 || !sio::as_u64(&e.arr[0], &id[0]) || !sio::as_u64(&e.arr[1], &id[1]) || !sio::as_u64(&e.arr[2], &id[2]))
+      return fail(MGF_ERR_INVALID, "Mesh: bad face");
+    for (int k = 0; k < 3; ++k) { if (id[k] >= m->verts.size()) return fail(MGF_ERR_INVALID, "Mesh: face index out of range"); m->faces.push_back((uint32_t)id[k]); }
+  }
+  std::string err;
+  if (!sio::read_bvh(*bvh, &m->m.tree, &err)) { set_error("%s", err.c_str()); return MGF_ERR_INVALID; }
+  // every leaf of the face tree must name a face
+  for (uint64_t i = 0; i < m->m.tree.slots(); ++i)
+    if (m->m.tree.used(i) && m->m.tree.node(i).leaf && m->m.tree.node(i).value >= m->faces.size() / 3)
+      return fail(MGF_ERR_INVALID, "Mesh: BVH leaf names a face that does not exist");
+  ++m->geom_version;
+  *out = m.release();
+  return MGF_OK;
+}
+
 // ---- mgf_compound (compound.rs:230-352) -------------------------------------------------------
 static_assert(sizeof(CompIn) == sizeof(mgf_component), "component layout");
 struct mgf_compound {

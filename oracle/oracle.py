@@ -148,6 +148,8 @@ def lib():
         L.mgfo_bvh_get_leaf.restype = C.c_int
         L.mgfo_bvh_query.argtypes = [C.c_void_p, P(Aabb), P(C.c_uint64), C.c_int64]
         L.mgfo_bvh_query.restype = C.c_int64
+        L.mgfo_bvh_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, P(C.c_int64), P(C.c_int64)]
+        L.mgfo_bvh_pool.restype = C.c_int64
         L.mgfo_bvh_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.mgfo_bvh_dump.restype = C.c_int64
         L.mgfo_world_new.argtypes = [C.c_int]
@@ -332,6 +334,28 @@ class Bvh:
         ts = (C.c_float * cap)()
         n = lib().mgfo_bvh_raytrace(self.h, C.byref(vec3(p)), C.byref(vec3(d)), C.c_float(dt), vals, ips, ts, cap)
         return [(vals[i], ips[i].tup(), ts[i]) for i in range(min(n, cap))]
+
+    def serde(self):
+        """The tree as the Python value serde_json would produce for BVH<AABB, usize> (bvh.rs:29-47, pool.rs:25-41)."""
+        nodes, bounds = self.dump()
+        n = len(nodes)
+        state = np.zeros(max(n, 1), np.int32)
+        nxt = np.zeros(max(n, 1), np.int64)
+        fl, ln = C.c_int64(), C.c_int64()
+        lib().mgfo_bvh_pool(self.h, state.ctypes.data, nxt.ctypes.data, n, C.byref(fl), C.byref(ln))
+        entries = []
+        v3d = lambda a: dict(x=float(a[0]), y=float(a[1]), z=float(a[2]))  # noqa: E731
+        for i in range(n):
+            if state[i] == 0:
+                entries.append("FreeListEnd")
+            elif state[i] == 1:
+                entries.append({"FreeListPtr": {"next_free": int(nxt[i])}})
+            else:
+                _, h, parent, leaf, a, b = (int(v) for v in nodes[i])
+                nt = {"Leaf": a} if leaf else {"Parent": [a, b]}
+                entries.append({"Occupied": {"height": h, "parent": parent, "bounds": {"c": v3d(bounds[i][:3]), "r": v3d(bounds[i][3:])}, "node_type": nt}})
+        root = int(lib().mgfo_bvh_root(self.h)) if ln.value else 0
+        return {"root": root, "pool": {"len": int(ln.value), "free_list": None if fl.value < 0 else int(fl.value), "entries": entries}}
 
     def dump(self):
         n = lib().mgfo_bvh_dump(self.h, None, None, 0)

@@ -260,6 +260,16 @@ int64_t mgfo_bvh_query(void* b, const o_aabb* q, uint64_t* out, int64_t cap) {
   return n;
 }
 // dump nodes for structural comparison: per pool slot {occupied, height, parent, is_leaf, leaf/child1, child2}
+// Pool internals (pool.rs:25-41) for the scene I/O tests: per entry 0 FreeListEnd / 1 FreeListPtr / 2 Occupied and next_free;
+// returns free_list (-1 = None) through *free_list and len through *len
+int64_t mgfo_bvh_pool(void* bp, int32_t* state, int64_t* next_free, int64_t cap, int64_t* free_list, int64_t* len) {
+  BVH<size_t>& b = *(BVH<size_t>*)bp;
+  int64_t n = (int64_t)b.pool.entries.size();
+  for (int64_t i = 0; i < n && i < cap; ++i) { state[i] = (int32_t)b.pool.entries[(size_t)i].st; next_free[i] = (int64_t)b.pool.entries[(size_t)i].next_free; }
+  *free_list = b.pool.has_free ? (int64_t)b.pool.free_list : -1;
+  *len = (int64_t)b.pool.len;
+  return n;
+}
 int64_t mgfo_bvh_dump(void* bp, int64_t* out6, o_aabb* bounds_out, int64_t cap) {
   BVH<size_t>& b = *(BVH<size_t>*)bp;
   int64_t n = (int64_t)b.pool.entries.size();
