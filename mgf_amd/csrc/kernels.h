@@ -1386,16 +1386,32 @@ constexpr uint32_t kSuccLocal = 0x20000000u;              // successor word: low
 struct Flow5 {
   const uint32_t* sidx;    // cell-ordered body ids
   const uint32_t* brank;   // body -> position in cell order
-  const uint32_t* base;    // body -> first own constraint (n + 1 entries)
   uint8_t* shared;         // body touched by constraints of two blocks
   uint8_t* gcnt;           // constraint has a predecessor in another block: global arrival counter
-  uint32_t* lslot;         // constraint -> slot in its block's list
-  uint32_t* wg_n;          // per block: [3g] end of class 0, [3g + 1] end of class 1, [3g + 2] all constraints
-  uint32_t* wg_list;       // per block: kF5MaxCons constraint ids, class 0 first
+  uint32_t* lslot;         // constraint -> (class << 12) | index inside its block's class
+  uint32_t* wg_cnt;        // per block and class k (0 all-LDS, 1 global counter, 2 LDS counter + shared body): f5_cnt(F, g, k),
+                           // one 128-byte line per counter (same-line atomics serialise)
+  // per block, kF5MaxCons rows each, final slot order (class 0, then 1, then 2): what k_solve_flow5 copies into LDS
+  uint32_t* t_c;           // constraint id
+  uint32_t* t_aref;        // body refs (LDS index, or id | kRefGlobal, or kNone)
+  uint32_t* t_bref;
+  uint32_t* t_cnt0;        // arrival counter of iteration 0
+  uint2* t_succ;           // successor words, block-local slots where possible
   uint32_t* fail;          // set when a block does not fit (the host falls back to k_solve_flow)
   uint32_t nb, nblocks, n;
 };
-
+__device__ __forceinline__ uint32_t f5_ref(const Flow5& F, uint32_t g, uint32_t body) {
+  if (body == kNone) return kNone;
+  return (F.brank[body] / F.nb != g || F.shared[body]) ? (body | kRefGlobal) : (F.brank[body] - g * F.nb);
+}
+constexpr uint32_t kF5CntStride = 32;  // words
+__device__ __forceinline__ uint32_t* f5_cnt(const Flow5& F, uint32_t g, uint32_t k) { return F.wg_cnt + (size_t)(4u * g + k) * kF5CntStride; }
+// final slot of a constraint inside its block: classes are laid out 0 | 1 | 2
+__device__ __forceinline__ uint32_t f5_slot(const Flow5& F, uint32_t g, uint32_t packed) {
+  uint32_t k = packed >> 12, idx = packed & 0xFFFu;
+  uint32_t base = k == 0 ? 0u : (k == 1 ? *f5_cnt(F, g, 0) : *f5_cnt(F, g, 0) + *f5_cnt(F, g, 1));
+  return base + idx;
+}
 __global__ __launch_bounds__(kBlock) void k_flow5_mark(Flow5 F, ConsLinks K, const uint32_t* C_ptr) {
   uint32_t c = blockIdx.x * kBlock + threadIdx.x;
   if (c >= *C_ptr) return;
@@ -1411,52 +1427,44 @@ __global__ __launch_bounds__(kBlock) void k_flow5_mark(Flow5 F, ConsLinks K, con
   }
 }
 
-// One workgroup per block: the block's constraint list in three classes -
-//   0: arrival counter and both bodies in LDS;  1: global arrival counter (a predecessor lives in another block);
-//   2: LDS counter, but a body shared with another block.
-__device__ __forceinline__ int f5_class(const Flow5& F, const ConsLinks& K, uint32_t g, uint32_t c, bool a_shared) {
-  if (F.gcnt[c]) return 1;
-  uint32_t b = K.ab[c].y;
-  bool glob = a_shared || (b != kNone && (F.brank[b] / F.nb != g || F.shared[b]));
-  return glob ? 2 : 0;
+// Per constraint: class (0: arrival counter and both bodies in LDS; 1: global arrival counter - a predecessor lives in
+// another block; 2: LDS counter, but a body shared with another block) and an index inside that class of its block.
+// The order inside a class is arrival order; any order is valid (every ready node may run).
+__global__ __launch_bounds__(kBlock) void k_flow5_assign(Flow5 F, ConsLinks K, const uint32_t* C_ptr) {
+  uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= *C_ptr) return;
+  uint2 e = K.ab[c];
+  uint32_t g = F.brank[e.x] / F.nb;
+  uint32_t k;
+  if (F.gcnt[c]) k = 1;
+  else k = ((f5_ref(F, g, e.x) & kRefGlobal) || (e.y != kNone && (f5_ref(F, g, e.y) & kRefGlobal))) ? 2u : 0u;
+  uint32_t idx = atomicAdd(f5_cnt(F, g, k), 1u);
+  if (idx >= kF5MaxCons) { *F.fail = 1u; idx = 0; }
+  F.lslot[c] = (k << 12) | idx;
 }
-__global__ __launch_bounds__(kF5Threads) void k_flow5_prep(Flow5 F, ConsLinks K) {
-  __shared__ uint32_t s_scan[3][kF5Threads];
-  const uint32_t g = blockIdx.x, t = threadIdx.x;
-  const uint32_t p_lo = g * F.nb, p_hi = min(F.n, p_lo + F.nb);
-  uint32_t nc[3] = {0, 0, 0};
-  for (uint32_t p = p_lo + t; p < p_hi; p += kF5Threads) {
-    uint32_t x = F.sidx[p];
-    bool xs = F.shared[x] != 0;
-    for (uint32_t c = F.base[x]; c < F.base[x + 1]; ++c) {
-      int k = f5_class(F, K, g, c, xs);
-      nc[0] += k == 0; nc[1] += k == 1; nc[2] += k == 2;
-    }
+// Per constraint: its row of the block's slot table, in final slot order.
+__global__ __launch_bounds__(kBlock) void k_flow5_table(Flow5 F, ConsLinks K, const uint32_t* C_ptr) {
+  uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= *C_ptr) return;
+  uint2 e = K.ab[c];
+  uint32_t g = F.brank[e.x] / F.nb;
+  if (*f5_cnt(F, g, 0) + *f5_cnt(F, g, 1) + *f5_cnt(F, g, 2) > kF5MaxCons) { *F.fail = 1u; return; }
+  uint32_t slot = f5_slot(F, g, F.lslot[c]);
+  size_t row = (size_t)g * kF5MaxCons + slot;
+  F.t_c[row] = c;
+  F.t_aref[row] = f5_ref(F, g, e.x);
+  F.t_bref[row] = f5_ref(F, g, e.y);
+  F.t_cnt0[row] = 2u - links_indeg0(K, c) * (e.y != kNone ? 1u : 2u);
+  uint2 sw = K.succ[c];
+  uint32_t w[2] = {sw.x, sw.y};
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    if (side == 1 && e.y == kNone) { w[1] = 0u; break; }
+    uint32_t sid = w[side] & kSuccId;
+    bool local = F.brank[K.ab[sid].x] / F.nb == g && !F.gcnt[sid];
+    if (local) w[side] = (w[side] & (kSuccTwo | kSuccWrap)) | kSuccLocal | f5_slot(F, g, F.lslot[sid]);
   }
-  for (int k = 0; k < 3; ++k) s_scan[k][t] = nc[k];
-  __syncthreads();
-  for (int off = 1; off < kF5Threads; off <<= 1) {  // inclusive scans
-    uint32_t a[3];
-    for (int k = 0; k < 3; ++k) a[k] = t >= (uint32_t)off ? s_scan[k][t - off] : 0u;
-    __syncthreads();
-    for (int k = 0; k < 3; ++k) s_scan[k][t] += a[k];
-    __syncthreads();
-  }
-  const uint32_t N0 = s_scan[0][kF5Threads - 1], N1 = s_scan[1][kF5Threads - 1], N2 = s_scan[2][kF5Threads - 1];
-  uint32_t o[3] = {s_scan[0][t] - nc[0], N0 + s_scan[1][t] - nc[1], N0 + N1 + s_scan[2][t] - nc[2]};
-  if (t == 0) { F.wg_n[3 * g] = N0; F.wg_n[3 * g + 1] = N0 + N1; F.wg_n[3 * g + 2] = N0 + N1 + N2; }
-  if (N0 + N1 + N2 > kF5MaxCons) { if (t == 0) *F.fail = 1u; return; }
-  uint32_t* list = F.wg_list + (size_t)g * kF5MaxCons;
-  for (uint32_t p = p_lo + t; p < p_hi; p += kF5Threads) {
-    uint32_t x = F.sidx[p];
-    bool xs = F.shared[x] != 0;
-    for (uint32_t c = F.base[x]; c < F.base[x + 1]; ++c) {
-      int k = f5_class(F, K, g, c, xs);
-      uint32_t slot = o[k]++;
-      list[slot] = c;
-      F.lslot[c] = slot;
-    }
-  }
+  F.t_succ[row] = make_uint2(w[0], w[1]);
 }
 
 __device__ __forceinline__ BodyDyn f5_load_body(const float4* s_body, __amdgpu_buffer_rsrc_t rs, uint32_t ref) {
@@ -1512,32 +1520,16 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
 #pragma unroll
     for (int k = 0; k < 4; ++k) s_body[4 * (p - p_lo) + k] = srec[4 * (size_t)x + k];
   }
-  const uint32_t N0 = F.wg_n[3 * g], N01 = F.wg_n[3 * g + 1], N = F.wg_n[3 * g + 2];
+  const uint32_t N0 = *f5_cnt(F, g, 0), N01 = N0 + *f5_cnt(F, g, 1), N = N01 + *f5_cnt(F, g, 2);
   for (uint32_t e = t; e < 2u * kF5Ring / 2u; e += kF5Threads) reinterpret_cast<uint32_t*>(qf.ring)[e] = 0u;  // both rings
   if (t < 8) s_ctl[t] = t == 4 ? N * iters : 0u;
   __syncthreads();
-  const uint32_t* list = F.wg_list + (size_t)g * kF5MaxCons;
-  // slot table: every slot's constants, translated to block-local references where possible
+  // the block's slot table (built once per tick by k_flow5_table): a coalesced copy
   for (uint32_t idx = t; idx < N; idx += kF5Threads) {
-    uint32_t c = list[idx];
-    uint2 e = K.ab[c];
-    uint32_t a = e.x, b = e.y;
-    S.c[idx] = c;
-    S.aref[idx] = F.shared[a] ? (a | kRefGlobal) : (F.brank[a] - p_lo);
-    S.bref[idx] = b == kNone ? kNone : ((F.brank[b] / F.nb != g || F.shared[b]) ? (b | kRefGlobal) : (F.brank[b] - p_lo));
-    uint32_t c0 = 2u - links_indeg0(K, c) * (b != kNone ? 1u : 2u);
-    S.cnt[idx] = c0;
+    size_t row = (size_t)g * kF5MaxCons + idx;
+    uint32_t c0 = F.t_cnt0[row];
+    S.c[idx] = F.t_c[row]; S.aref[idx] = F.t_aref[row]; S.bref[idx] = F.t_bref[row]; S.cnt[idx] = c0; S.succ[idx] = F.t_succ[row];
     S.round[idx] = 0;
-    uint2 sw = K.succ[c];
-    uint32_t w[2] = {sw.x, sw.y};
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      if (side == 1 && b == kNone) { w[1] = 0u; break; }
-      uint32_t sid = w[side] & kSuccId;
-      bool local = F.brank[K.ab[sid].x] / F.nb == g && !F.gcnt[sid];
-      if (local) w[side] = (w[side] & (kSuccTwo | kSuccWrap)) | kSuccLocal | F.lslot[sid];
-    }
-    S.succ[idx] = make_uint2(w[0], w[1]);
     // iteration 0's frontier (slots with a global counter are found by their pollers)
     if (!(idx >= N0 && idx < N01) && c0 >= 2u && iters > 0) f5_push(idx < N0 ? qf : qs, idx);
   }

@@ -802,7 +802,8 @@ struct mgf_world {
   DBuf<uint32_t> flow_arr;
   DBuf<uint64_t> flow_trace;
   // block-local solver (mode 5)
-  DBuf<uint32_t> brank, f5_shared, f5_gcnt, f5_lslot, f5_wg_n, f5_list;
+  DBuf<uint32_t> brank, f5_shared, f5_gcnt, f5_lslot, f5_wg_cnt, f5_tc, f5_taref, f5_tbref, f5_tcnt0;
+  DBuf<uint2> f5_tsucc;
   bool flow5_ok = false, flow5_prepped = false;  // the constraint list came from collide (own-block ranges valid) / prep done
   uint32_t f5_nb = 0, f5_nblocks = 0;
   int flow_grid = 0;
@@ -853,8 +854,9 @@ struct mgf_world {
   uint32_t* d_err() { return scalars.p + 3; }
   Flow5 flow5() {
     Flow5 F;
-    F.sidx = sidx.p; F.brank = brank.p; F.base = base.p; F.shared = reinterpret_cast<uint8_t*>(f5_shared.p);
-    F.gcnt = reinterpret_cast<uint8_t*>(f5_gcnt.p); F.lslot = f5_lslot.p; F.wg_n = f5_wg_n.p; F.wg_list = f5_list.p;
+    F.sidx = sidx.p; F.brank = brank.p; F.shared = reinterpret_cast<uint8_t*>(f5_shared.p);
+    F.gcnt = reinterpret_cast<uint8_t*>(f5_gcnt.p); F.lslot = f5_lslot.p; F.wg_cnt = f5_wg_cnt.p;
+    F.t_c = f5_tc.p; F.t_aref = f5_taref.p; F.t_bref = f5_tbref.p; F.t_cnt0 = f5_tcnt0.p; F.t_succ = f5_tsucc.p;
     F.fail = d_err() + 4; F.nb = f5_nb; F.nblocks = f5_nblocks; F.n = n;
     return F;
   }
@@ -919,12 +921,12 @@ extern "C" mgf_status mgf_world_counter(const mgf_world* w, const char* name, in
     // constraints of the last prepared tick in class 0 / 1 / 2 (all-LDS / global counter / LDS counter + shared body)
     *out = 0;
     if (!w->flow5_prepped || w->f5_nblocks == 0) return MGF_OK;
-    std::vector<uint32_t> h(3 * (size_t)w->f5_nblocks);
+    std::vector<uint32_t> h(4 * (size_t)w->f5_nblocks * kF5CntStride);
     mgf_world* mw = const_cast<mgf_world*>(w);
     MGF_TRY(ctx_bind(mw->ctx));
-    MGF_TRY(d2h(mw->ctx, h.data(), mw->f5_wg_n.p, h.size()));
+    MGF_TRY(d2h(mw->ctx, h.data(), mw->f5_wg_cnt.p, h.size()));
     int k = name[11] - '0';
-    for (uint32_t g = 0; g < w->f5_nblocks; ++g) *out += (int64_t)(h[3 * g + k] - (k ? h[3 * g + k - 1] : 0u));
+    for (uint32_t g = 0; g < w->f5_nblocks; ++g) *out += (int64_t)h[(size_t)(4 * g + k) * kF5CntStride];
     return MGF_OK;
   }
   return fail(MGF_ERR_INVALID, "unknown counter");
@@ -1550,7 +1552,10 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
   if (use5 && !w->flow5_prepped) {
     const uint32_t n = w->n;
     MGF_TRY(w->f5_shared.ensure(n / 4 + 1, s)); MGF_TRY(w->f5_gcnt.ensure(cap_c / 4 + 1, s)); MGF_TRY(w->f5_lslot.ensure(std::max(cap_c, 1u), s));
-    MGF_TRY(w->f5_wg_n.ensure(3 * (size_t)w->f5_nblocks, s)); MGF_TRY(w->f5_list.ensure((size_t)w->f5_nblocks * kF5MaxCons, s));
+    const size_t rows = (size_t)w->f5_nblocks * kF5MaxCons;
+    MGF_TRY(w->f5_wg_cnt.ensure(4 * (size_t)w->f5_nblocks * kF5CntStride, s));
+    MGF_TRY(w->f5_tc.ensure(rows, s)); MGF_TRY(w->f5_taref.ensure(rows, s)); MGF_TRY(w->f5_tbref.ensure(rows, s));
+    MGF_TRY(w->f5_tcnt0.ensure(rows, s)); MGF_TRY(w->f5_tsucc.ensure(rows, s));
     if (!w->flow5_attr_set) {
       MGF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_flow5), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)(64 * (size_t)kF5MaxBodies + (size_t)kF5SlotBytes * kF5MaxCons + 4 * (size_t)kF5Ring + 64)));
@@ -1561,12 +1566,16 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
     z.p[0] = w->f5_shared.p; z.words[0] = n / 4 + 1;
     z.p[1] = w->f5_gcnt.p; z.words[1] = cap_c / 4 + 1;
     z.p[2] = w->d_err() + 4; z.words[2] = 1;
+    z.p[3] = w->f5_wg_cnt.p; z.words[3] = 4 * w->f5_nblocks * kF5CntStride;
     k_zero_many<<<64, kBlock, 0, s>>>(z);
     LAUNCH_CHECK();
     Flow5 F = w->flow5();
-    k_flow5_mark<<<std::max(1u, nblk(cap_c)), kBlock, 0, s>>>(F, w->links(), &w->sc.p->C);
+    const unsigned gc = std::max(1u, nblk(cap_c));
+    k_flow5_mark<<<gc, kBlock, 0, s>>>(F, w->links(), &w->sc.p->C);
     LAUNCH_CHECK();
-    k_flow5_prep<<<F.nblocks, kF5Threads, 0, s>>>(F, w->links());
+    k_flow5_assign<<<gc, kBlock, 0, s>>>(F, w->links(), &w->sc.p->C);
+    LAUNCH_CHECK();
+    k_flow5_table<<<gc, kBlock, 0, s>>>(F, w->links(), &w->sc.p->C);
     LAUNCH_CHECK();
     w->flow5_prepped = true;
   }
