@@ -219,15 +219,15 @@ def test_closed_form_cases_hip(ctx, name):
     CASES[name](lambda scene: mgf_amd.World.from_scene(ctx, scene))
 
 
-@pytest.mark.parametrize("refresh_every", [1, 2, 3, 10])
-def test_tiled_worlds_match_oracle_tiles(ctx, refresh_every):
+@pytest.mark.parametrize("refresh_every,P", [(1, 2), (2, 2), (3, 2), (10, 2), (2, 3), (1, 4)])
+def test_tiled_worlds_match_oracle_tiles(ctx, refresh_every, P):
     """Two x-slab tiles (ghost export/import kernels, ghost filtering in the broadphase, ghost velocity
     refresh every R solver iterations) on the GPU vs the oracle's tile mode: bit-identical per tile."""
     import mgf_amd
     from mgf_amd import scenes
     from mgf_amd.tiles import HipEngine, Tile, step_tiles_inprocess
     from tests.oracle_engine import OracleEngine
-    P, nx, ny, nz = 2, 8, 6, 8
+    nx, ny, nz = (8, 6, 8) if P == 2 else (5, 5, 6)
     gt, ot = [], []
     for r in range(P):
         sc = scenes.sphere_pile_tile(nx, ny, nz, r, P)
@@ -240,6 +240,8 @@ def test_tiled_worlds_match_oracle_tiles(ctx, refresh_every):
             assert sg[r]["n_constraints"] == so[r]["n_constraints"], f"tick {tick} tile {r}"
             assert tuple(gt[r].e.counts) == (len(ot[r].e.ids[0]), len(ot[r].e.ids[1]))
     assert gt[0].e.counts[1] > 0 and gt[1].e.counts[0] > 0
+    if P > 2:
+        assert gt[1].e.counts[0] > 0 and gt[1].e.counts[1] > 0  # an interior tile exports both ways
     for r in range(P):
         g, o = gt[r].e.state(), ot[r].e.state()
         for k in ("x", "q", "v", "omega", "delta"):

@@ -52,6 +52,24 @@ def test_two_tiles_inprocess_ghost_protocol():
         assert np.isfinite(s["x"]).all() and np.isfinite(s["v"]).all()
 
 
+def test_three_tiles_middle_tile_has_two_neighbours():
+    """The middle slab exchanges with both sides: its ghosts come from two tiles and its boundary bodies go two ways."""
+    tiles = make_tiles(4, 4, 4, 3)
+    for tick in range(10):
+        stats = step_tiles_inprocess(tiles)
+        assert all(s["n_constraints"] > 0 for s in stats)
+    mid = tiles[1]
+    assert len(mid.e.ids[0]) > 0 and len(mid.e.ids[1]) > 0
+    assert len(tiles[0].e.ids[0]) == 0 and len(tiles[2].e.ids[1]) == 0
+    x = mid.e.state()["x"][:, 0]
+    assert x[mid.e.ids[0]].max() < mid.x_lo + 2.5 and x[mid.e.ids[1]].min() > mid.x_hi - 2.5
+    # a body near both faces of a narrow slab may be exported both ways; every export is an owned body
+    assert set(mid.e.ids[0]) <= set(range(len(mid.e.w))) and set(mid.e.ids[1]) <= set(range(len(mid.e.w)))
+    for t in tiles:
+        s = t.e.state()
+        assert np.isfinite(s["x"]).all() and np.isfinite(s["v"]).all()
+
+
 def test_tiled_result_tracks_the_undivided_world():
     """Block-Jacobi coupling across the slab face is a different iteration than one global Gauss-Seidel;
     the deviation is measured and bounded, not hidden."""
@@ -110,20 +128,22 @@ def test_seam_quality_vs_refresh_interval():
 
 
 @pytest.mark.timeout(300)
-def test_two_gloo_ranks_match_inprocess_tiles(tmp_path):
-    """world_size 2 over gloo (real point-to-point transport) == the in-process two-tile run, bit for bit."""
+@pytest.mark.parametrize("ws", [2, 3])
+def test_gloo_ranks_match_inprocess_tiles(tmp_path, ws):
+    """world_size 2 and 3 over gloo (real point-to-point transport; with 3 ranks the middle one talks to both sides)
+    == the in-process tile loop, bit for bit."""
     nx, ny, nz, ticks = 5, 4, 5, 6
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "tests", "tile_worker.py"), str(tmp_path), str(nx), str(ny), str(nz), str(ticks)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ws}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29515 + ws), os.path.join(ROOT, "tests", "tile_worker.py"), str(tmp_path), str(nx), str(ny), str(nz), str(ticks)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    tiles = make_tiles(nx, ny, nz, 2)
-    ncons = [[], []]
+    tiles = make_tiles(nx, ny, nz, ws)
+    ncons = [[] for _ in range(ws)]
     for _ in range(ticks):
         for k, s in enumerate(step_tiles_inprocess(tiles)):
             ncons[k].append(s["n_constraints"])
-    for rank in range(2):
+    for rank in range(ws):
         got = np.load(tmp_path / f"rank{rank}.npz")
         want = tiles[rank].e.state()
         assert got["ncons"].tolist() == ncons[rank]
