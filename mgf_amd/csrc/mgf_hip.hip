@@ -1387,7 +1387,7 @@ static mgf_status collide_finish(mgf_world* w, bool* retry) {
   mgf_ctx* ctx = w->ctx;
   hipStream_t s = ctx->stream;
   *retry = false;
-  if (w->n == 0) { w->constraints_ready = true; return MGF_OK; }
+  if (w->n == 0) { MGF_HIP_TRY(hipStreamSynchronize(s)); w->constraints_ready = true; return MGF_OK; }
   uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
   MGF_HIP_TRY(hipMemcpyAsync(pin, w->sc.p, sizeof(StepCounts), hipMemcpyDeviceToHost, s));
   MGF_HIP_TRY(hipMemcpyAsync(pin + 32, w->sb.p, sizeof(SceneBounds), hipMemcpyDeviceToHost, s));
