@@ -454,7 +454,7 @@ struct StepCounts {
   uint32_t bins[6];                            // candidates per shape-pair type (scenes mixing spheres and capsules)
   uint32_t pad;
 };
-constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u, kFailGridWide = 8u;
+constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u, kFailGridWide = 8u, kFailTerrainRow = 16u;
 
 __global__ void k_caps_candidates(const uint32_t* mt, const uint32_t* mp, uint32_t cap_t, uint32_t cap_p, const uint32_t* row_overflow,
                                   const uint32_t* grid_wide, StepCounts* sc) {
@@ -462,7 +462,8 @@ __global__ void k_caps_candidates(const uint32_t* mt, const uint32_t* mp, uint32
   r.need_Mt = *mt; r.need_Mp = *mp; r.need_C = 0; r.need_Ct = 0;
   r.fail = 0;
   if (r.need_Mt > cap_t || r.need_Mp > cap_p) r.fail |= kFailCandCap;
-  if (row_overflow && *row_overflow) r.fail |= kFailRowOverflow;
+  if (row_overflow && (*row_overflow & 1u)) r.fail |= kFailRowOverflow;
+  if (row_overflow && (*row_overflow & 2u)) r.fail |= kFailTerrainRow;
   if (grid_wide && *grid_wide) r.fail |= kFailGridWide;
   r.Mt = r.fail ? 0u : r.need_Mt; r.Mp = r.fail ? 0u : r.need_Mp; r.C = 0; r.Ct = 0;
   for (int k = 0; k < 6; ++k) r.bins[k] = 0;
@@ -534,22 +535,23 @@ __global__ __launch_bounds__(kBlock) void k_candidates(Bodies B, uint32_t n, uin
 // Single-pass candidate generation into fixed-capacity global rows (the common case); bodies with more
 // hits than a row holds raise `overflow` and the host re-runs the exact two-pass path (k_candidates).
 constexpr int kRowCap = 32;   // partner row
-constexpr int kRowCapT = 16;  // terrain row
+constexpr int kRowCapT = 16;  // terrain row: initial capacity; the host doubles it (up to kRowCapTMax) when a body overflows
+constexpr int kRowCapTMax = 128;
 
 // Terrain faces per body, reference DFS order (mesh.rs:121, bvh.rs:283-310).  One lane per body.
-__global__ __launch_bounds__(kBlock) void k_terrain_rows(Bodies B, uint32_t n_owned, TerrainDev M, uint32_t* rows_t, uint32_t* t_cnt,
-                                                         uint32_t* overflow) {
+__global__ __launch_bounds__(kBlock) void k_terrain_rows(Bodies B, uint32_t n_owned, TerrainDev M, uint32_t cap_row, uint32_t* rows_t,
+                                                         uint32_t* t_cnt, uint32_t* overflow) {
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n_owned) return;
   Box q; q.c = xyz(B.tb_c[i]) + -mk3(M.x[0], M.x[1], M.x[2]); q.r = xyz(B.tb_r[i]);
-  uint32_t* row = rows_t + (size_t)i * kRowCapT;
+  uint32_t* row = rows_t + (size_t)i * cap_row;
   uint32_t nt = 0;
   terrain_traverse(M, q, [&](uint32_t face) {
-    if (nt < (uint32_t)kRowCapT) row[nt] = face;
+    if (nt < cap_row) row[nt] = face;
     ++nt;
   });
   t_cnt[i] = nt;
-  if (nt > (uint32_t)kRowCapT) *overflow = 1u;
+  if (nt > cap_row) atomicOr(overflow, 2u);  // bit 1: a terrain row, bit 0: a partner row
 }
 
 // Partner bodies per body: cooperative traversal, 8 lanes per query.  A 4-ary node is eight 16-byte
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_rows(Bodies B, uint32_t n, 
   }
   if (sub == 0) {
     p_cnt[i] = np;
-    if (np > (uint32_t)kRowCap) *overflow = 1u;
+    if (np > (uint32_t)kRowCap) atomicOr(overflow, 1u);
   }
 }
 
@@ -729,13 +731,13 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, 
   }
   if (sub == 0) {
     p_cnt[i] = np;
-    if (np > (uint32_t)kRowCap) *overflow = 1u;
+    if (np > (uint32_t)kRowCap) atomicOr(overflow, 1u);
   }
 }
 
 // rows -> CSR (terrain and partner candidate lists with their owners); partners sorted ascending in LDS
 // (canonical insertion order).
-__global__ __launch_bounds__(kBlock) void k_rows_to_csr(const StepCounts* sc, uint32_t n, const uint32_t* rows_t, const uint32_t* rows_p,
+__global__ __launch_bounds__(kBlock) void k_rows_to_csr(const StepCounts* sc, uint32_t n, uint32_t cap_row_t, const uint32_t* rows_t, const uint32_t* rows_p,
                                                         const uint32_t* t_off, const uint32_t* p_off, uint32_t* t_cand, uint32_t* t_owner,
                                                         uint32_t* p_cand, uint32_t* p_owner) {
   __shared__ uint32_t s_row[kRowCap][kBlock];
@@ -743,8 +745,8 @@ __global__ __launch_bounds__(kBlock) void k_rows_to_csr(const StepCounts* sc, ui
   uint32_t i = blockIdx.x * kBlock + tid;
   if (i >= n || sc->fail) return;
   uint32_t tb = t_off[i], nt = t_off[i + 1] - tb, pb = p_off[i], np = p_off[i + 1] - pb;
-  if (nt > (uint32_t)kRowCapT || np > (uint32_t)kRowCap) return;  // overflowed body: the host takes the two-pass path
-  const uint32_t* rt = rows_t + (size_t)i * kRowCapT;
+  if (nt > cap_row_t || np > (uint32_t)kRowCap) return;  // overflowed body: the host re-runs with wider rows or the two-pass path
+  const uint32_t* rt = rows_t + (size_t)i * cap_row_t;
   const uint32_t* rp = rows_p + (size_t)i * kRowCap;
   for (uint32_t a = 0; a < nt; ++a) { t_cand[tb + a] = rt[a]; t_owner[tb + a] = i; }
   for (uint32_t a = 0; a < np; ++a) {

@@ -812,6 +812,7 @@ struct mgf_world {
   uint32_t cap_t = 0, cap_p = 0, cap_c = 0;
   uint64_t n_cap_retries = 0, n_flow5_fallbacks = 0;
   bool tick_two_pass = false;
+  uint32_t row_cap_t = kRowCapT;    // terrain faces per body in the row path (grows on overflow, sticky)
   bool grid_too_wide = false;       // sticky: the largest body spans too many Morton cells for the grid broadphase
   int64_t opt_broadphase_tree = 0;  // 1 = always walk the tree (k_pair_rows) instead of enumerating grid cells
   int64_t opt_flow_blocks_per_cu = 0, opt_flow_sleep = 2;
@@ -1311,9 +1312,9 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   if (!two_pass) {
     // fast path: one pass, hits written to fixed-capacity rows
     MGF_TRY(w->rows.ensure((size_t)n * kRowCap, s));
-    MGF_TRY(w->rows_t.ensure((size_t)n * kRowCapT, s));
+    MGF_TRY(w->rows_t.ensure((size_t)n * w->row_cap_t, s));
     if (M.n_nodes && w->n_owned) {
-      k_terrain_rows<<<nblk(w->n_owned), kBlock, 0, s>>>(B, w->n_owned, M, w->rows_t.p, w->t_cnt.p, w->d_err() + 1);
+      k_terrain_rows<<<nblk(w->n_owned), kBlock, 0, s>>>(B, w->n_owned, M, w->row_cap_t, w->rows_t.p, w->t_cnt.p, w->d_err() + 1);
       LAUNCH_CHECK();
     }
     {
@@ -1335,7 +1336,7 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
     k_candidates<true><<<8 * xcd_blocks_per(n), kBlock, 0, s>>>(B, n, w->n_owned, T, M, 1e-3f, nullptr, nullptr, w->t_off.p, w->p_off.p, w->t_cand.p, w->t_owner.p,
                                                   w->p_cand.p, w->p_owner.p, sc);
   } else {
-    k_rows_to_csr<<<nblk(n), kBlock, 0, s>>>(sc, n, w->rows_t.p, w->rows.p, w->t_off.p, w->p_off.p, w->t_cand.p, w->t_owner.p, w->p_cand.p, w->p_owner.p);
+    k_rows_to_csr<<<nblk(n), kBlock, 0, s>>>(sc, n, w->row_cap_t, w->rows_t.p, w->rows.p, w->t_off.p, w->p_off.p, w->t_cand.p, w->t_owner.p, w->p_cand.p, w->p_owner.p);
   }
   LAUNCH_CHECK();
   MGF_HIP_TRY(hipEventRecord(w->ev[2], s));
@@ -1398,7 +1399,12 @@ static mgf_status collide_finish(mgf_world* w, bool* retry) {
   if (pin[64]) return fail(MGF_ERR_CAPACITY, "BVH traversal stack overflow");
   auto grown = [](uint32_t need) { return (uint32_t)std::min<uint64_t>((uint64_t)need + need / 2 + 1024, 0x7FFFFFF0ull); };
   if (h.fail & kFailGridWide) { w->grid_too_wide = true; *retry = true; }
-  else if (h.fail & kFailRowOverflow) { w->tick_two_pass = true; w->n_row_overflows++; *retry = true; }
+  else if (h.fail & (kFailRowOverflow | kFailTerrainRow)) {
+    w->n_row_overflows++;
+    *retry = true;
+    if ((h.fail & kFailTerrainRow) && !(h.fail & kFailRowOverflow) && w->row_cap_t < (uint32_t)kRowCapTMax) w->row_cap_t *= 2;  // wider terrain rows from now on
+    else w->tick_two_pass = true;  // exact count / fill path for this tick
+  }
   if (h.fail & kFailCandCap) {
     if (h.need_Mt > w->cap_t) w->cap_t = grown(h.need_Mt);
     if (h.need_Mp > w->cap_p) w->cap_p = grown(h.need_Mp);
