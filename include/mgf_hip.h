@@ -270,11 +270,11 @@ MGF_API mgf_status mgf_world_solve_enqueue(mgf_world* w, int32_t iters);
 MGF_API mgf_status mgf_world_finish(mgf_world* w, mgf_step_stats* stats);
 /* Options (development and test knobs; defaults in brackets): "time_solver_kernels" [0] HIP events around the
  * solver kernels; "solver_mode" [5] 1 = persistent dataflow launch, 0 = one launch per dependency frontier,
- * 4 = dataflow with out-of-order slots, 5 = block-local dataflow (velocities and counters of a spatial block in LDS); "two_pass_candidates" [0]; "stream_ordered" [0]; "list_capacity";
+ * 4 = dataflow with out-of-order slots, 5 = block-local dataflow (velocities and counters of a spatial block in LDS); "two_pass_candidates" [0]; "broadphase_tree" [0]; "terrain_tree" [0]; "stream_ordered" [0]; "list_capacity";
  * "flow_blocks_per_cu"; "flow_sleep"; "flow_trace"; "debug_bvh". */
 MGF_API mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_t value);
 /* Diagnostics: how often a slow path was taken.  name in {"row_overflows", "capacity_retries", "flow5_fallbacks",
- * "grid_too_wide", "flow5_blocks"}. */
+ * "grid_too_wide", "flow5_blocks", "flow5_class0|1|2", "terrain_grid", "terrain_row_capacity"}. */
 MGF_API mgf_status mgf_world_counter(const mgf_world* w, const char* name, int64_t* out);
 /* Raw device pointers of resident state for zero-copy exchange (multi-GPU halo): name in
  * {"x","q","solver_rec","delta"}; pointer valid until the next add_bodies. */

@@ -109,6 +109,26 @@ class HostBvh {
     }
   }
 
+  // Leaves in the order a full BVH::query visits them (bvh.rs:283-310: push lchild, push rchild, pop rchild first).
+  // Any query reports its hits in this order, whatever it prunes - so a hit list can be found by other means and
+  // sorted by rank.  rank_of_value[v] for leaf value v (values must be dense indices), leaf_of_value[v] = node id.
+  void dfs_ranks(size_t n_values, std::vector<uint32_t>* rank_of_value, std::vector<uint32_t>* value_of_rank,
+                 std::vector<uint32_t>* leaf_of_value, std::vector<uint32_t>* parent_of_node) const {
+    rank_of_value->assign(n_values, 0u); value_of_rank->clear(); leaf_of_value->assign(n_values, 0u);
+    parent_of_node->assign(nodes_.size(), 0u);
+    for (size_t i = 0; i < nodes_.size(); ++i) parent_of_node->at(i) = (uint32_t)nodes_[i].parent;
+    if (empty()) return;
+    std::vector<uint64_t> stack{root_};
+    while (!stack.empty()) {
+      uint64_t top = stack.back(); stack.pop_back();
+      const Node& n = nodes_[top];
+      if (n.leaf) {
+        if (n.value < n_values) { (*rank_of_value)[n.value] = (uint32_t)value_of_rank->size(); (*leaf_of_value)[n.value] = (uint32_t)top; }
+        value_of_rank->push_back((uint32_t)n.value);
+      } else { stack.push_back(n.kid[0]); stack.push_back(n.kid[1]); }
+    }
+  }
+
   // Flatten for the device.  Unused slots become empty leaves that nothing points at.
   void flatten(std::vector<DevNode>* out) const {
     out->resize(nodes_.size());

@@ -208,9 +208,9 @@ __global__ __launch_bounds__(kBlock) void k_morton_count(const float4* fb_c, uin
 }
 
 // Zero several small arrays with one launch (instead of one fill kernel each).
-struct ZeroList { uint32_t* p[6]; uint32_t words[6]; };
+struct ZeroList { uint32_t* p[8]; uint32_t words[8]; };
 __global__ __launch_bounds__(kBlock) void k_zero_many(ZeroList z) {
-  for (int a = 0; a < 6; ++a) {
+  for (int a = 0; a < 8; ++a) {
     uint32_t* p = z.p[a];
     if (!p) continue;
     for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < z.words[a]; e += gridDim.x * kBlock) p[e] = 0u;
@@ -454,10 +454,10 @@ struct StepCounts {
   uint32_t bins[6];                            // candidates per shape-pair type (scenes mixing spheres and capsules)
   uint32_t pad;
 };
-constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u, kFailGridWide = 8u, kFailTerrainRow = 16u;
+constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u, kFailGridWide = 8u, kFailTerrainRow = 16u, kFailTerrainWide = 32u;
 
 __global__ void k_caps_candidates(const uint32_t* mt, const uint32_t* mp, uint32_t cap_t, uint32_t cap_p, const uint32_t* row_overflow,
-                                  const uint32_t* grid_wide, StepCounts* sc) {
+                                  const uint32_t* grid_wide, const uint32_t* terrain_wide, StepCounts* sc) {
   StepCounts r;
   r.need_Mt = *mt; r.need_Mp = *mp; r.need_C = 0; r.need_Ct = 0;
   r.fail = 0;
@@ -465,6 +465,7 @@ __global__ void k_caps_candidates(const uint32_t* mt, const uint32_t* mp, uint32
   if (row_overflow && (*row_overflow & 1u)) r.fail |= kFailRowOverflow;
   if (row_overflow && (*row_overflow & 2u)) r.fail |= kFailTerrainRow;
   if (grid_wide && *grid_wide) r.fail |= kFailGridWide;
+  if (terrain_wide && *terrain_wide) r.fail |= kFailTerrainWide;
   r.Mt = r.fail ? 0u : r.need_Mt; r.Mp = r.fail ? 0u : r.need_Mp; r.C = 0; r.Ct = 0;
   for (int k = 0; k < 6; ++k) r.bins[k] = 0;
   r.pad = 0;
@@ -735,9 +736,113 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, 
   }
 }
 
+// Terrain faces per body without walking the reference tree.  A static mesh gets the same Morton-cell grid as the
+// bodies (cells over the face boxes, built once per set_terrain); a query enumerates the cells its box can reach,
+// applies Mesh::contacts' own acceptance test (query overlaps the face's leaf bounds, bvh.rs:297) and - because the
+// reference only reaches a leaf through its ancestors - re-checks the ancestors' boxes for hits that are within
+// rounding distance of not overlapping (an ancestor box is the union of its children up to f32 rounding, so a clear
+// overlap with the leaf implies an overlap with every ancestor).  Hits are stored as DFS RANKS: BVH::query reports
+// leaves in one fixed order whatever it prunes (HostBvh::dfs_ranks), so sorting a body's row by rank restores the
+// reference's callback order.  Meshes whose faces span many cells raise `too_wide`; the host then uses the tree walk.
+struct FaceGrid {
+  Lbvh T;                      // cells over the face boxes: leaves[].c.w = face id
+  const SceneBounds* sb;
+  const uint32_t* rank_of_face;
+  const uint32_t* leaf_of_face;  // node id of the face's leaf in the reference tree
+  const uint32_t* parent;        // per node of the reference tree
+};
+__global__ __launch_bounds__(kCoopBlock) void k_terrain_grid(Bodies B, uint32_t n_owned, const uint32_t* order, TerrainDev M, FaceGrid G,
+                                                             float pad_abs, uint32_t cap_row, uint32_t* rows_t, uint32_t* t_cnt,
+                                                             uint32_t* overflow, uint32_t* too_wide) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7;
+  const int gbase = lane & ~7;
+  uint32_t kq = xcd_logical_block_coop() * (kCoopBlock / kCoopLanes) + (threadIdx.x >> 3);
+  if (kq >= n_owned) return;  // whole group leaves together
+  uint32_t i = order ? order[kq] : kq;
+  if (i >= n_owned) {  // cell order runs over owned + ghost bodies: ghosts have no terrain row
+    return;
+  }
+  Box q; q.c = xyz(B.tb_c[i]) + -mk3(M.x[0], M.x[1], M.x[2]); q.r = xyz(B.tb_r[i]);
+  float mag = fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z;
+  float pad = pad_abs + 1e-5f * mag;
+  const uint32_t P = 2u * G.T.levels;
+  const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};
+  uint32_t ca[3], d[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float lo = ord_f(G.sb->lo[k]), hi = ord_f(G.sb->hi[k]), rm = ord_f(G.sb->rmax[k]);
+    float a = at(q.c, k) - at(q.r, k) - rm - pad, b = at(q.c, k) + at(q.r, k) + rm + pad;
+    uint32_t c0 = morton_quant(a, lo, hi) >> (10u - nb[k]), c1 = morton_quant(b, lo, hi) >> (10u - nb[k]);
+    ca[k] = c0; d[k] = c1 - c0 + 1u;
+  }
+  const uint32_t ncell = d[0] * d[1] * d[2];
+  uint32_t nt = 0;
+  if (ncell > kGridMaxCells) {
+    if (sub == 0) *too_wide = 1u;
+  } else {
+    uint32_t* row = rows_t + (size_t)i * cap_row;
+    const int shift = kMortonBits - (int)P;
+    for (uint32_t cb = 0; cb < ncell; cb += kCoopLanes) {
+      uint32_t idx = cb + (uint32_t)sub;
+      uint32_t p0 = 0, p1 = 0;
+      if (idx < ncell) {
+        uint32_t cz = idx % d[2], t = idx / d[2];
+        uint32_t cy = t % d[1], cx = t / d[1];
+        uint32_t code = (expand10((ca[0] + cx) << (10u - nb[0])) << 2) | (expand10((ca[1] + cy) << (10u - nb[1])) << 1) |
+                        expand10((ca[2] + cz) << (10u - nb[2]));
+        uint32_t cell = code >> shift;
+        p0 = G.T.cell_lo[cell]; p1 = G.T.cell_lo[cell + 1];
+      }
+      for (;;) {
+        bool more = p0 < p1;
+        unsigned long long mb = __ballot(more);
+        if (((uint32_t)(mb >> gbase) & 255u) == 0u) break;
+        bool hit = false;
+        uint32_t rank = 0;
+        if (more) {
+          LeafRec lr = G.T.leaves[p0];
+          uint32_t face = f2u(lr.c.w);
+          Box fb; fb.c = xyz(lr.c); fb.r = xyz(lr.r);
+          if (box_overlaps(q, fb)) {  // the reference's acceptance test at the leaf (bvh.rs:297)
+            hit = true;
+            // by how much?  a clear overlap needs no ancestor check
+            float gap = fmin_rs(fmin_rs(q.r.x + fb.r.x - fabs_rs(q.c.x - fb.c.x), q.r.y + fb.r.y - fabs_rs(q.c.y - fb.c.y)),
+                                q.r.z + fb.r.z - fabs_rs(q.c.z - fb.c.z));
+            float tol = 1e-4f * (mag + fabs_rs(fb.c.x) + fabs_rs(fb.c.y) + fabs_rs(fb.c.z) + fb.r.x + fb.r.y + fb.r.z);
+            if (!(gap > tol)) {
+              uint32_t node = G.leaf_of_face[face];
+              while (node != M.root) {
+                node = G.parent[node];
+                const float4* raw = reinterpret_cast<const float4*>(&M.nodes[node]);
+                Box nbx; nbx.c = xyz(raw[0]); nbx.r = xyz(raw[1]);
+                if (!box_overlaps(q, nbx)) { hit = false; break; }
+              }
+            }
+            rank = G.rank_of_face[face];
+          }
+          ++p0;
+        }
+        unsigned long long hb = __ballot(hit);
+        uint32_t gm = (uint32_t)(hb >> gbase) & 255u;
+        if (hit) {
+          uint32_t slot = nt + __popc(gm & ((1u << sub) - 1u));
+          if (slot < cap_row) row[slot] = rank;
+        }
+        nt += __popc(gm);
+      }
+    }
+  }
+  if (sub == 0) {
+    t_cnt[i] = nt;
+    if (nt > cap_row) atomicOr(overflow, 2u);
+  }
+}
+
 // rows -> CSR (terrain and partner candidate lists with their owners); partners sorted ascending in LDS
 // (canonical insertion order).
-__global__ __launch_bounds__(kBlock) void k_rows_to_csr(const StepCounts* sc, uint32_t n, uint32_t cap_row_t, const uint32_t* rows_t, const uint32_t* rows_p,
+__global__ __launch_bounds__(kBlock) void k_rows_to_csr(const StepCounts* sc, uint32_t n, uint32_t cap_row_t, const uint32_t* face_of_rank,
+                                                        const uint32_t* rows_t, const uint32_t* rows_p,
                                                         const uint32_t* t_off, const uint32_t* p_off, uint32_t* t_cand, uint32_t* t_owner,
                                                         uint32_t* p_cand, uint32_t* p_owner) {
   __shared__ uint32_t s_row[kRowCap][kBlock];
@@ -748,7 +853,17 @@ __global__ __launch_bounds__(kBlock) void k_rows_to_csr(const StepCounts* sc, ui
   if (nt > cap_row_t || np > (uint32_t)kRowCap) return;  // overflowed body: the host re-runs with wider rows or the two-pass path
   const uint32_t* rt = rows_t + (size_t)i * cap_row_t;
   const uint32_t* rp = rows_p + (size_t)i * kRowCap;
-  for (uint32_t a = 0; a < nt; ++a) { t_cand[tb + a] = rt[a]; t_owner[tb + a] = i; }
+  if (face_of_rank) {  // the row holds DFS ranks in discovery order: sort, then name the faces
+    for (uint32_t a = 0; a < nt; ++a) {
+      uint32_t v = rt[a];
+      uint32_t b = a;
+      while (b > 0 && t_cand[tb + b - 1] > v) { t_cand[tb + b] = t_cand[tb + b - 1]; --b; }
+      t_cand[tb + b] = v;
+    }
+    for (uint32_t a = 0; a < nt; ++a) { t_cand[tb + a] = face_of_rank[t_cand[tb + a]]; t_owner[tb + a] = i; }
+  } else {
+    for (uint32_t a = 0; a < nt; ++a) { t_cand[tb + a] = rt[a]; t_owner[tb + a] = i; }
+  }
   for (uint32_t a = 0; a < np; ++a) {
     uint32_t v = rp[a];
     uint32_t b = a;

@@ -163,6 +163,22 @@ struct mgf_mesh {
     return MGF_OK;
   }
   TerrainDev dev(uint32_t* err) const { return m.dev(d_verts.p, d_faces.p, x, err); }
+  // Morton-cell grid over the face boxes + DFS ranks of the faces (k_terrain_grid); built by build_face_grid
+  struct Grid {
+    bool ready = false;
+    uint32_t levels = 0, n_faces = 0;
+    DBuf<float4> fb_c, fb_r;
+    DBuf<uint32_t> cell_of, cell_rank, cell_cnt, cell_lo, sidx, brank, rank_of_face, face_of_rank, leaf_of_face, parent;
+    DBuf<LeafRec> leaves;
+    DBuf<SceneBounds> sb;
+  } grid;
+  FaceGrid face_grid() const {
+    FaceGrid G;
+    G.T.nodes = nullptr; G.T.leaves = grid.leaves.p; G.T.sidx = grid.sidx.p; G.T.cell_lo = grid.cell_lo.p;
+    G.T.n = grid.n_faces; G.T.levels = grid.levels; G.T.err = nullptr; G.T.dbg = nullptr;
+    G.sb = grid.sb.p; G.rank_of_face = grid.rank_of_face.p; G.leaf_of_face = grid.leaf_of_face.p; G.parent = grid.parent.p;
+    return G;
+  }
 };
 
 static inline Box to_box(const mgf_aabb& a) { Box b; b.c = mk3(a.c.x, a.c.y, a.c.z); b.r = mk3(a.r.x, a.r.y, a.r.z); return b; }
@@ -813,7 +829,9 @@ struct mgf_world {
   uint64_t n_cap_retries = 0, n_flow5_fallbacks = 0;
   bool tick_two_pass = false;
   uint32_t row_cap_t = kRowCapT;    // terrain faces per body in the row path (grows on overflow, sticky)
+  bool terrain_grid_off = false;    // sticky: the mesh's faces span too many cells for the face grid (k_terrain_grid)
   bool grid_too_wide = false;       // sticky: the largest body spans too many Morton cells for the grid broadphase
+  int64_t opt_terrain_tree = 0;     // 1 = always walk the mesh BVH (k_terrain_rows) instead of the face grid
   int64_t opt_broadphase_tree = 0;  // 1 = always walk the tree (k_pair_rows) instead of enumerating grid cells
   int64_t opt_flow_blocks_per_cu = 0, opt_flow_sleep = 2;
   int flowk_grid = 0;
@@ -872,11 +890,11 @@ extern "C" mgf_status mgf_world_new(mgf_ctx* ctx, const mgf_params* params, mgf_
   w->ctx = ctx;
   w->params = params ? *params : mgf_default_params();
   memset(&w->stats, 0, sizeof(w->stats));
-  MGF_TRY(w->scalars.ensure(8, ctx->stream));
+  MGF_TRY(w->scalars.ensure(16, ctx->stream));
   MGF_TRY(w->sb.ensure(1, ctx->stream));
   MGF_TRY(w->sc.ensure(1, ctx->stream));
   MGF_HIP_TRY(hipMemsetAsync(w->sc.p, 0, sizeof(StepCounts), ctx->stream));
-  MGF_HIP_TRY(hipMemsetAsync(w->scalars.p, 0, 32, ctx->stream));
+  MGF_HIP_TRY(hipMemsetAsync(w->scalars.p, 0, 64, ctx->stream));
   for (auto& e : w->ev) MGF_HIP_TRY(hipEventCreate(&e));
   *out = w.release();
   return MGF_OK;
@@ -896,6 +914,7 @@ extern "C" mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_
   if (!strcmp(key, "time_solver_kernels")) { w->opt_time_solver_kernels = value; return MGF_OK; }
   if (!strcmp(key, "two_pass_candidates")) { w->opt_two_pass = value; return MGF_OK; }
   if (!strcmp(key, "broadphase_tree")) { w->opt_broadphase_tree = value; return MGF_OK; }
+  if (!strcmp(key, "terrain_tree")) { w->opt_terrain_tree = value; return MGF_OK; }
   if (!strcmp(key, "flow_trace")) { w->opt_flow_trace = value; return MGF_OK; }
   if (!strcmp(key, "debug_bvh")) { w->opt_debug_bvh = value; return MGF_OK; }
   if (!strcmp(key, "solver_mode")) { w->opt_solver_mode = value; return MGF_OK; }
@@ -917,6 +936,8 @@ extern "C" mgf_status mgf_world_counter(const mgf_world* w, const char* name, in
   if (!strcmp(name, "capacity_retries")) { *out = (int64_t)w->n_cap_retries; return MGF_OK; }
   if (!strcmp(name, "flow5_fallbacks")) { *out = (int64_t)w->n_flow5_fallbacks; return MGF_OK; }
   if (!strcmp(name, "grid_too_wide")) { *out = w->grid_too_wide ? 1 : 0; return MGF_OK; }
+  if (!strcmp(name, "terrain_grid")) { *out = (w->terrain && w->terrain->grid.ready && !w->terrain_grid_off && !w->opt_terrain_tree) ? 1 : 0; return MGF_OK; }
+  if (!strcmp(name, "terrain_row_capacity")) { *out = (int64_t)w->row_cap_t; return MGF_OK; }
   if (!strcmp(name, "flow5_blocks")) { *out = (int64_t)w->f5_nblocks; return MGF_OK; }
   if (!strncmp(name, "flow5_class", 11) && (name[11] == '0' || name[11] == '1' || name[11] == '2') && !name[12]) {
     // constraints of the last prepared tick in class 0 / 1 / 2 (all-LDS / global counter / LDS counter + shared body)
@@ -933,6 +954,53 @@ extern "C" mgf_status mgf_world_counter(const mgf_world* w, const char* name, in
   return fail(MGF_ERR_INVALID, "unknown counter");
 }
 
+// The static mesh's face grid: face boxes = the leaf bounds of the reference tree, counting-sorted into Morton cells with
+// the same kernels as the bodies; DFS ranks and parent links from the host tree.
+static mgf_status build_face_grid(mgf_mesh* t) {
+  mgf_ctx* ctx = t->ctx;
+  hipStream_t s = ctx->stream;
+  mgf_mesh::Grid& G = t->grid;
+  G.ready = false;
+  const size_t nf = t->faces.size() / 3;
+  if (nf < 64 || t->m.tree.empty()) return MGF_OK;  // tiny meshes: the tree walk is cheap
+  std::vector<uint32_t> rank_of, face_of, leaf_of, parent;
+  t->m.tree.dfs_ranks(nf, &rank_of, &face_of, &leaf_of, &parent);
+  if (face_of.size() != nf) return MGF_OK;  // a face without a leaf (or two): not a Mesh::push_face tree, keep the walk
+  std::vector<float4> bc(nf), br(nf);
+  for (size_t f = 0; f < nf; ++f) {
+    const Box& b = t->m.tree.node(leaf_of[f]).box;
+    bc[f] = make_float4(b.c.x, b.c.y, b.c.z, 0.0f); br[f] = make_float4(b.r.x, b.r.y, b.r.z, 0.0f);
+  }
+  uint32_t levels = 4;
+  while (((uint64_t)1 << (2 * levels)) < nf && levels < (uint32_t)kMortonBits / 2) ++levels;
+  const uint32_t cells = 1u << (2 * levels);
+  G.levels = levels; G.n_faces = (uint32_t)nf;
+  MGF_TRY(G.fb_c.ensure(nf, s)); MGF_TRY(G.fb_r.ensure(nf, s)); MGF_TRY(G.cell_of.ensure(nf, s)); MGF_TRY(G.cell_rank.ensure(nf, s));
+  MGF_TRY(G.cell_cnt.ensure((size_t)cells + 1, s)); MGF_TRY(G.cell_lo.ensure((size_t)cells + 1, s)); MGF_TRY(G.sidx.ensure(nf, s));
+  MGF_TRY(G.brank.ensure(nf, s)); MGF_TRY(G.leaves.ensure(nf, s)); MGF_TRY(G.sb.ensure(1, s));
+  MGF_TRY(G.rank_of_face.ensure(nf, s)); MGF_TRY(G.face_of_rank.ensure(nf, s)); MGF_TRY(G.leaf_of_face.ensure(nf, s));
+  MGF_TRY(G.parent.ensure(std::max<size_t>(parent.size(), 1), s));
+  MGF_TRY(h2d(ctx, G.fb_c.p, bc.data(), nf)); MGF_TRY(h2d(ctx, G.fb_r.p, br.data(), nf));
+  MGF_TRY(h2d(ctx, G.rank_of_face.p, rank_of.data(), nf)); MGF_TRY(h2d(ctx, G.face_of_rank.p, face_of.data(), nf));
+  MGF_TRY(h2d(ctx, G.leaf_of_face.p, leaf_of.data(), nf)); MGF_TRY(h2d(ctx, G.parent.p, parent.data(), parent.size()));
+  MGF_HIP_TRY(hipMemsetAsync(G.cell_cnt.p, 0, ((size_t)cells + 1) * 4, s));
+  SceneBounds sb0;
+  for (int k = 0; k < 3; ++k) { sb0.lo[k] = 0x7FFFFFFF; sb0.hi[k] = (int)0x80000000; sb0.rmax[k] = 0; }
+  sb0.n_refits = 0; sb0.pad = 0; sb0.pad2 = 0;
+  MGF_TRY(h2d(ctx, G.sb.p, &sb0, 1));
+  k_scene_bounds<<<std::min<unsigned>(nblk(nf), 256u), kBlock, 0, s>>>(G.fb_c.p, G.fb_r.p, (uint32_t)nf, G.sb.p);
+  LAUNCH_CHECK();
+  k_morton_count<<<nblk(nf), kBlock, 0, s>>>(G.fb_c.p, (uint32_t)nf, G.sb.p, kMortonBits - 2 * (int)levels, G.cell_of.p, G.cell_rank.p, G.cell_cnt.p);
+  LAUNCH_CHECK();
+  MGF_TRY(prim_exclusive_scan_u32(ctx, G.cell_cnt.p, G.cell_lo.p, (size_t)cells + 1));
+  FaceGrid FG = t->face_grid();
+  k_scatter_leaves<<<nblk(nf), kBlock, 0, s>>>(FG.T, G.fb_c.p, G.fb_r.p, G.cell_of.p, G.cell_rank.p, G.brank.p);
+  LAUNCH_CHECK();
+  MGF_HIP_TRY(hipStreamSynchronize(s));
+  G.ready = true;
+  return MGF_OK;
+}
+
 extern "C" mgf_status mgf_world_set_terrain(mgf_world* w, const mgf_mesh* mesh) {
   if (!w) return fail(MGF_ERR_INVALID, "world is NULL");
   MGF_TRY(ctx_bind(w->ctx));
@@ -945,7 +1013,9 @@ extern "C" mgf_status mgf_world_set_terrain(mgf_world* w, const mgf_mesh* mesh) 
   t->m.tree = mesh->m.tree;
   t->geom_version = 1;
   MGF_TRY(t->sync());
+  MGF_TRY(build_face_grid(t.get()));
   w->terrain = std::move(t);
+  w->terrain_grid_off = false;
   return MGF_OK;
 }
 
@@ -1273,6 +1343,7 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
     z.p[3] = w->adj_fill.p; z.words[3] = n + 1;
     z.p[4] = w->d_err() + 1; z.words[4] = 1;  // row-overflow flag (re-armed for a re-run inside the tick)
     z.p[5] = w->d_err() + 3; z.words[5] = 1;  // grid-too-wide flag
+    z.p[6] = w->d_err() + 5; z.words[6] = 1;  // terrain-grid-too-wide flag
     k_zero_many<<<256, kBlock, 0, s>>>(z);
     LAUNCH_CHECK();
   }
@@ -1309,12 +1380,20 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   MGF_TRY(w->t_nc.ensure(cap_t, s)); MGF_TRY(w->p_nc.ensure(cap_p, s));
   MGF_TRY(w->t_pre.ensure(cap_t, s)); MGF_TRY(w->p_pre.ensure(cap_p, s));
   MGF_TRY(w->t_out.ensure(2 * (size_t)cap_t, s)); MGF_TRY(w->p_out.ensure(cap_p, s));
+  const bool terrain_grid = !two_pass && M.n_nodes && w->terrain->grid.ready && !w->terrain_grid_off && !w->opt_terrain_tree;
   if (!two_pass) {
     // fast path: one pass, hits written to fixed-capacity rows
     MGF_TRY(w->rows.ensure((size_t)n * kRowCap, s));
     MGF_TRY(w->rows_t.ensure((size_t)n * w->row_cap_t, s));
     if (M.n_nodes && w->n_owned) {
-      k_terrain_rows<<<nblk(w->n_owned), kBlock, 0, s>>>(B, w->n_owned, M, w->row_cap_t, w->rows_t.p, w->t_cnt.p, w->d_err() + 1);
+      if (terrain_grid) {
+        const uint32_t per_block = kCoopBlock / kCoopLanes;
+        const uint32_t tg = 8 * (((w->n_owned + per_block - 1) / per_block + 7) / 8);
+        k_terrain_grid<<<tg, kCoopBlock, 0, s>>>(B, w->n_owned, nullptr, M, w->terrain->face_grid(), 1e-3f, w->row_cap_t, w->rows_t.p, w->t_cnt.p,
+                                                 w->d_err() + 1, w->d_err() + 5);
+      } else {
+        k_terrain_rows<<<nblk(w->n_owned), kBlock, 0, s>>>(B, w->n_owned, M, w->row_cap_t, w->rows_t.p, w->t_cnt.p, w->d_err() + 1);
+      }
       LAUNCH_CHECK();
     }
     {
@@ -1330,13 +1409,14 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   }
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->t_cnt.p, w->t_off.p, (size_t)n + 1));
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->p_cnt.p, w->p_off.p, (size_t)n + 1));
-  k_caps_candidates<<<1, 1, 0, s>>>(w->t_off.p + n, w->p_off.p + n, cap_t, cap_p, two_pass ? nullptr : w->d_err() + 1, use_grid ? w->d_err() + 3 : nullptr, sc);
+  k_caps_candidates<<<1, 1, 0, s>>>(w->t_off.p + n, w->p_off.p + n, cap_t, cap_p, two_pass ? nullptr : w->d_err() + 1, use_grid ? w->d_err() + 3 : nullptr,
+                                    terrain_grid ? w->d_err() + 5 : nullptr, sc);
   LAUNCH_CHECK();
   if (two_pass) {
     k_candidates<true><<<8 * xcd_blocks_per(n), kBlock, 0, s>>>(B, n, w->n_owned, T, M, 1e-3f, nullptr, nullptr, w->t_off.p, w->p_off.p, w->t_cand.p, w->t_owner.p,
                                                   w->p_cand.p, w->p_owner.p, sc);
   } else {
-    k_rows_to_csr<<<nblk(n), kBlock, 0, s>>>(sc, n, w->row_cap_t, w->rows_t.p, w->rows.p, w->t_off.p, w->p_off.p, w->t_cand.p, w->t_owner.p, w->p_cand.p, w->p_owner.p);
+    k_rows_to_csr<<<nblk(n), kBlock, 0, s>>>(sc, n, w->row_cap_t, terrain_grid ? w->terrain->grid.face_of_rank.p : nullptr, w->rows_t.p, w->rows.p, w->t_off.p, w->p_off.p, w->t_cand.p, w->t_owner.p, w->p_cand.p, w->p_owner.p);
   }
   LAUNCH_CHECK();
   MGF_HIP_TRY(hipEventRecord(w->ev[2], s));
@@ -1398,7 +1478,8 @@ static mgf_status collide_finish(mgf_world* w, bool* retry) {
   w->stats.n_refits = reinterpret_cast<SceneBounds*>(pin + 32)->n_refits;
   if (pin[64]) return fail(MGF_ERR_CAPACITY, "BVH traversal stack overflow");
   auto grown = [](uint32_t need) { return (uint32_t)std::min<uint64_t>((uint64_t)need + need / 2 + 1024, 0x7FFFFFF0ull); };
-  if (h.fail & kFailGridWide) { w->grid_too_wide = true; *retry = true; }
+  if (h.fail & kFailTerrainWide) { w->terrain_grid_off = true; *retry = true; }
+  else if (h.fail & kFailGridWide) { w->grid_too_wide = true; *retry = true; }
   else if (h.fail & (kFailRowOverflow | kFailTerrainRow)) {
     w->n_row_overflows++;
     *retry = true;

@@ -322,6 +322,25 @@ def test_grid_and_tree_broadphase_agree(ctx, scene_name):
         assert bits_equal(s1[k], s2[k]), k
 
 
+def test_terrain_face_grid_and_tree_walk_agree(ctx):
+    """Terrain candidates: cell enumeration over the face boxes + DFS-rank sort (k_terrain_grid) vs the reference-order
+    walk of the mesh BVH (k_terrain_rows): same faces in the same order, so the same tick."""
+    import mgf_amd
+    from mgf_amd import scenes
+    scene = scenes.capsule_field(24, 3, 24, quads=40)
+    a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
+    b.set_option("terrain_tree", 1)
+    assert a.counter("terrain_grid") == 1 and b.counter("terrain_grid") == 0
+    for _ in range(60):
+        sa, sb = a.step(float(scene["dt"]), 10), b.step(float(scene["dt"]), 10)
+        assert (sa.n_constraints, sa.n_terrain_constraints, sa.n_terrain_candidates) == (sb.n_constraints, sb.n_terrain_constraints, sb.n_terrain_candidates)
+    assert sa.n_terrain_constraints > 100 and a.counter("terrain_grid") == 1
+    compare_constraints(a.constraints(), b.constraints(), check_impulse=True)
+    s1, s2 = a.state(), b.state()
+    for k in s1:
+        assert bits_equal(s1[k], s2[k]), k
+
+
 def test_two_pass_and_row_paths_agree(ctx):
     import mgf_amd
     from mgf_amd import scenes
