@@ -76,10 +76,8 @@ struct DBuf {
   size_t bytes() const { return cap * sizeof(T); }
 };
 
-// Library primitives (rocPRIM) — prims.hip.  Sort/scan are stock primitives; every
+// Library primitive (rocPRIM) — prims.hip.  The device-wide scan is a stock primitive; every
 // physics kernel is hand-written (kernels.h).
-mgf_status prim_sort_pairs_u32(mgf_ctx* ctx, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
-                               uint32_t* vals_out, size_t n, int end_bit);
 // out[0..n] = exclusive prefix sum of in[0..n-1], out[n] = total (in must have n+1 readable slots; slot n is ignored)
 mgf_status prim_exclusive_scan_u32(mgf_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n_plus_1);
 

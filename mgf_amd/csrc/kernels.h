@@ -2,22 +2,30 @@
 //
 //   k_integrate        RigidBodyVec::complete_motion + integrate (physics.rs:222-269), swept AABB
 //                      (bounds.rs:60-68), fat-AABB refit test (world.rs:234-238)
-//   k_scene_bounds / k_morton / k_lbvh_leaves / k_lbvh_low / k_lbvh_top
-//                      per-tick linear BVH over the fat AABBs: Morton sort + implicit complete 4-ary tree
-//                      over Morton cells, built by reductions, top 5 levels staged in LDS (replaces the sequentially mutated
-//                      AVL tree of bvh.rs for the world broadphase; the hit SET is identical
-//                      because acceptance is the reference's own predicate)
-//   k_candidates<FILL> BVH::query (bvh.rs:283-310) for every body at once: mesh-BVH DFS in the
-//                      reference's order + world LBVH; two passes (count, fill) -> CSR
+//   k_scene_bounds / k_morton_count / k_scatter_leaves
+//                      bodies counting-sorted into Morton cells (cell = 2L-bit prefix of the 30-bit code of the fat-box
+//                      centre); the same kernels build the static grid over a terrain mesh's face boxes
+//   k_pair_grid        BVH::query (bvh.rs:283-310) of the world tree for every body at once by cell enumeration;
+//                      k_lbvh_low / k_lbvh_top + k_pair_rows (implicit 4-ary tree over the cells, cooperative walk)
+//                      when one body spans too many cells; the hit SET is the reference's because acceptance is its own
+//                      predicate on the leaf boxes
+//   k_terrain_grid     Mesh::contacts' BVH::query by cell enumeration over the face boxes, hits stored as DFS ranks;
+//                      k_terrain_rows = the walk of the flattened reference tree in the reference's order
+//   k_candidates<FILL> the exact two-pass (count, fill) tree walk used when a candidate row overflows
+//   k_rows_to_csr      rows -> CSR, partners ascending, terrain faces in DFS order
 //   k_narrow_pairs<A,B> / k_narrow_terrain<A>
 //                      one kernel per shape-pair type over the candidate lists
 //   k_count_contacts / k_setup_pairs / k_setup_terrain
 //                      Manifold::from + ContactConstraint::new (manifold.rs:120-148, solver.rs:101-191)
-//   k_adj_* / k_chain / k_frontier0
-//                      order-preserving dependency DAG of the constraint list
-//   k_solve            ContactConstraint::solve (solver.rs:203-252) for one frontier of the unrolled
-//                      (iterations x constraints) dependency graph
-//   k_solve_flow       the same graph walked by one persistent dataflow launch (write-through hand-offs)
+//   k_adj_fill / k_chain
+//                      order-preserving dependency links of the constraint list (compact arrays, ConsLinks)
+//   k_solve_flow5      ContactConstraint::solve (solver.rs:203-252) for a whole Solver::solve call: block-local persistent
+//                      dataflow launch (a spatial block's velocities, arrival counters and ready queues in LDS)
+//   k_solve_flow       the same graph with every hand-off through L2 (stand-by of k_solve_flow5, solver mode 1)
+//   k_frontier0 / k_solve
+//                      one launch per frontier of the unrolled (iterations x constraints) graph (solver mode 0, cross-check)
+//   k_compound_* / k_bvh_raytrace / k_intersections_batch
+//                      Compound (compound.rs:230-352), BVH::raytrace and Intersects (bvh.rs:345-369, collision.rs:169-373)
 //
 // All f32 arithmetic follows the reference's operation order; the TU is built with
 // -ffp-contract=off.

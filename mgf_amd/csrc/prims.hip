@@ -1,5 +1,5 @@
-// rocPRIM-backed device-wide sort and scan (library primitives, kept in their own TU so the
-// hand-written kernels recompile quickly).
+// rocPRIM-backed device-wide scan (a library primitive, kept in its own TU so the hand-written kernels
+// recompile quickly).
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
@@ -13,16 +13,6 @@ static mgf_status ensure_tmp(mgf_ctx* ctx, size_t bytes) {
   size_t nb = bytes + bytes / 2 + 4096;
   MGF_HIP_TRY(hipMalloc(&ctx->prim_tmp, nb));
   ctx->prim_tmp_bytes = nb;
-  return MGF_OK;
-}
-
-mgf_status prim_sort_pairs_u32(mgf_ctx* ctx, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in,
-                               uint32_t* vals_out, size_t n, int end_bit) {
-  if (n == 0) return MGF_OK;
-  size_t bytes = 0;
-  MGF_HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, ctx->stream));
-  MGF_TRY(ensure_tmp(ctx, bytes));
-  MGF_HIP_TRY(rocprim::radix_sort_pairs(ctx->prim_tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, ctx->stream));
   return MGF_OK;
 }
 
