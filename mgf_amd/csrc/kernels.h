@@ -1503,9 +1503,16 @@ __global__ __launch_bounds__(kBlock) void k_solve_flowk(float4* srec, CRec* cons
 // deadlock-free as long as all blocks are resident.
 // ------------------------------------------------------------------------------------------
 constexpr int kF5Threads = 512;
-constexpr uint32_t kF5MaxCons = 3072;                     // constraints per block
-constexpr uint32_t kF5MaxBodies = 1088;                   // bodies per block (LDS: 64 B each)
-constexpr uint32_t kF5SlotBytes = 25;                     // LDS per slot: c, aref, bref, cnt (4 each), succ (8), round (1)
+// Two LDS layouts (template parameter WIDE of k_solve_flow5), chosen by the host from last tick's largest block:
+//   WIDE = false: up to 3072 constraints per block, every slot's constants in LDS (25 B per slot);
+//   WIDE = true : up to 5120 (a settled 64^3 pile reaches ~4600), only the class-0 slots' constants in LDS (16 B each,
+//                 at most 3328), classes 1 + 2 (at most 3072) read theirs from the block's global table.
+constexpr uint32_t kF5MaxCons = 5120;                     // rows per block in the global slot tables
+constexpr uint32_t kF5NarrowCons = 3072;
+constexpr uint32_t kF5MaxFast = 3328, kF5MaxSlow = 3072;
+constexpr uint32_t kF5MaxBodies = 1100;                   // bodies per block (LDS: 64 B each; both layouts must fit 160 KB)
+constexpr uint32_t kF5LdsWide = 16u * kF5MaxFast + 5u * kF5MaxCons + 2u * (kF5MaxFast + kF5MaxSlow) + 64u;
+constexpr uint32_t kF5LdsNarrow = 25u * kF5NarrowCons + 2u * 2u * 4096u + 64u;
 constexpr uint32_t kRefGlobal = 0x80000000u;              // body ref: bit 31 = global id (sc1 path), else LDS index; kNone = static
 constexpr uint32_t kSuccLocal = 0x20000000u;              // successor word: low bits are a block-local slot
 struct Flow5 {
@@ -1523,7 +1530,9 @@ struct Flow5 {
   uint32_t* t_cnt0;        // arrival counter of iteration 0
   uint2* t_succ;           // successor words, block-local slots where possible
   uint32_t* fail;          // set when a block does not fit (the host falls back to k_solve_flow)
+  uint32_t* max_block;     // largest block of this tick (the host picks next tick's LDS layout from it)
   uint32_t nb, nblocks, n;
+  uint32_t cap_fast, cap_slow, cap_all;  // limits of the chosen layout
 };
 __device__ __forceinline__ uint32_t f5_ref(const Flow5& F, uint32_t g, uint32_t body) {
   if (body == kNone) return kNone;
@@ -1573,7 +1582,11 @@ __global__ __launch_bounds__(kBlock) void k_flow5_table(Flow5 F, ConsLinks K, co
   if (c >= *C_ptr) return;
   uint2 e = K.ab[c];
   uint32_t g = F.brank[e.x] / F.nb;
-  if (*f5_cnt(F, g, 0) + *f5_cnt(F, g, 1) + *f5_cnt(F, g, 2) > kF5MaxCons) { *F.fail = 1u; return; }
+  {
+    uint32_t n0 = *f5_cnt(F, g, 0), n12 = *f5_cnt(F, g, 1) + *f5_cnt(F, g, 2);
+    if (F.lslot[c] == 0u) atomicMax(F.max_block, n0 + n12);  // once per block: its class-0 slot 0 (or nobody, for a block without one)
+    if (n0 > F.cap_fast || n12 > F.cap_slow || n0 + n12 > F.cap_all) { *F.fail = 1u; return; }
+  }
   uint32_t slot = f5_slot(F, g, F.lslot[c]);
   size_t row = (size_t)g * kF5MaxCons + slot;
   F.t_c[row] = c;
@@ -1603,40 +1616,39 @@ __device__ __forceinline__ void f5_store_vel(float4* s_body, __amdgpu_buffer_rsr
   store_vel(s_body, ref, d);
 }
 
-// Per block-local slot, in LDS: constraint id, body refs, arrival counter, successor words, iteration counter.
-struct F5Slots {
-  uint32_t* c;      // constraint id
-  uint32_t* aref;
-  uint32_t* bref;
-  uint32_t* cnt;    // arrivals since the slot last ran (LDS-counter slots): ready at 2
-  uint2* succ;
-  uint8_t* round;   // iterations done; bit 7: queued by its poller (global-counter slots)
-};
-// Ready queues in LDS (one for the fast class, one for the rest): any lane of the serving waves may run any ready
-// node, so a wave takes up to 64 of them per trip instead of the few its own lanes would hold.
-struct F5Queue { uint16_t* ring; uint32_t* head; uint32_t* tail; };
-constexpr uint32_t kF5Ring = 4096;  // > kF5MaxCons: a slot is queued at most once at a time
+// LDS per block: slot constants (constraint id, body refs, successor words) - of every slot (narrow layout) or of the
+// class-0 slots only (wide layout; classes 1 and 2 touch global memory anyway and read theirs from the block's global
+// table) - and for EVERY slot its arrival counter and iteration counter.
+// Ready queues in LDS (one for the all-LDS class, one for the rest): any lane of the serving waves may run any ready
+// node, so a wave takes up to 64 of them per trip instead of the few its own lanes would hold.  A slot is queued at most
+// once at a time, so a ring as long as its class never overflows.
+struct F5Queue { uint16_t* ring; uint32_t* head; uint32_t* tail; uint32_t cap; };
 __device__ __forceinline__ void f5_push(const F5Queue& q, uint32_t slot) {
   uint32_t pos = __hip_atomic_fetch_add(q.tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  q.ring[pos & (kF5Ring - 1u)] = (uint16_t)(slot | 0x8000u);
+  q.ring[pos % q.cap] = (uint16_t)(slot | 0x8000u);
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* cons, ConsLinks K, Flow5 F, uint32_t* arr, uint32_t iters,
                                                             uint32_t* abort_flag, uint32_t spin_limit) {
   if (*F.fail) return;  // a block did not fit: the stand-by k_solve_flow launch behind this one does the work
+  constexpr uint32_t kMeta = WIDE ? kF5MaxFast : kF5NarrowCons;   // slots with constants in LDS
+  constexpr uint32_t kAll = WIDE ? kF5MaxCons : kF5NarrowCons;    // slots with counters in LDS
+  constexpr uint32_t kRingF = WIDE ? kF5MaxFast : 4096u, kRingS = WIDE ? kF5MaxSlow : 4096u;
   extern __shared__ float4 s_dyn[];
   float4* s_body = s_dyn;  // 4 x nb
-  F5Slots S;
-  S.c = reinterpret_cast<uint32_t*>(s_dyn + 4 * (size_t)F.nb);
-  S.aref = S.c + kF5MaxCons; S.bref = S.aref + kF5MaxCons; S.cnt = S.bref + kF5MaxCons;
-  S.succ = reinterpret_cast<uint2*>(S.cnt + kF5MaxCons);
-  uint32_t* s_ctl = reinterpret_cast<uint32_t*>(S.succ + kF5MaxCons);  // [0,1] fast head/tail, [2,3] slow head/tail, [4] nodes left
+  uint2* s_succ = reinterpret_cast<uint2*>(s_dyn + 4 * (size_t)F.nb);      // [kMeta]
+  uint32_t* s_c = reinterpret_cast<uint32_t*>(s_succ + kMeta);             // [kMeta]
+  uint32_t* s_a = s_c + kMeta;                                             // [kMeta] WIDE: aref | bref << 16; else aref
+  uint32_t* s_b = s_a + kMeta;                                             // [kMeta] narrow layout only
+  uint32_t* s_cnt = WIDE ? s_b : s_b + kMeta;                              // [kAll] arrivals since the slot last ran: ready at 2
+  uint32_t* s_ctl = s_cnt + kAll;  // [0,1] fast head/tail, [2,3] slow head/tail, [4] nodes left
   F5Queue qf, qs;
   qf.head = s_ctl; qf.tail = s_ctl + 1; qs.head = s_ctl + 2; qs.tail = s_ctl + 3;
   uint32_t* s_left = s_ctl + 4;
-  qf.ring = reinterpret_cast<uint16_t*>(s_ctl + 8);
-  qs.ring = qf.ring + kF5Ring;
-  S.round = reinterpret_cast<uint8_t*>(qs.ring + kF5Ring);
+  qf.ring = reinterpret_cast<uint16_t*>(s_ctl + 8); qf.cap = kRingF;
+  qs.ring = qf.ring + kRingF; qs.cap = kRingS;
+  uint8_t* s_round = reinterpret_cast<uint8_t*>(qs.ring + kRingS);         // [kAll] iterations done; bit 7: queued by its poller
   const uint32_t g = blockIdx.x, t = threadIdx.x;
   const uint32_t p_lo = g * F.nb, p_hi = min(F.n, p_lo + F.nb);
   __amdgpu_buffer_rsrc_t rs = make_rsrc(srec);
@@ -1646,15 +1658,23 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
     for (int k = 0; k < 4; ++k) s_body[4 * (p - p_lo) + k] = srec[4 * (size_t)x + k];
   }
   const uint32_t N0 = *f5_cnt(F, g, 0), N01 = N0 + *f5_cnt(F, g, 1), N = N01 + *f5_cnt(F, g, 2);
-  for (uint32_t e = t; e < 2u * kF5Ring / 2u; e += kF5Threads) reinterpret_cast<uint32_t*>(qf.ring)[e] = 0u;  // both rings
+  const uint32_t n_meta = WIDE ? N0 : N;
+  for (uint32_t e = t; e < (kRingF + kRingS) / 2u; e += kF5Threads) reinterpret_cast<uint32_t*>(qf.ring)[e] = 0u;  // both rings
   if (t < 8) s_ctl[t] = t == 4 ? N * iters : 0u;
   __syncthreads();
-  // the block's slot table (built once per tick by k_flow5_table): a coalesced copy
+  // the block's slot table (built once per tick by k_flow5_table): a coalesced copy of what the LDS side needs
+  const size_t row0 = (size_t)g * kF5MaxCons;
   for (uint32_t idx = t; idx < N; idx += kF5Threads) {
-    size_t row = (size_t)g * kF5MaxCons + idx;
-    uint32_t c0 = F.t_cnt0[row];
-    S.c[idx] = F.t_c[row]; S.aref[idx] = F.t_aref[row]; S.bref[idx] = F.t_bref[row]; S.cnt[idx] = c0; S.succ[idx] = F.t_succ[row];
-    S.round[idx] = 0;
+    uint32_t c0 = F.t_cnt0[row0 + idx];
+    s_cnt[idx] = c0;
+    s_round[idx] = 0;
+    if (idx < n_meta) {
+      s_c[idx] = F.t_c[row0 + idx];
+      uint32_t ar = F.t_aref[row0 + idx], br = F.t_bref[row0 + idx];
+      if (WIDE) s_a[idx] = (ar & 0xFFFFu) | ((br == kNone ? 0xFFFFu : br) << 16);  // class 0: LDS indices or static
+      else { s_a[idx] = ar; s_b[idx] = br; }
+      s_succ[idx] = F.t_succ[row0 + idx];
+    }
     // iteration 0's frontier (slots with a global counter are found by their pollers)
     if (!(idx >= N0 && idx < N01) && c0 >= 2u && iters > 0) f5_push(idx < N0 ? qf : qs, idx);
   }
@@ -1669,15 +1689,37 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
   const bool slow_wave = wave >= nwaves - nslow;
   const F5Queue& q = slow_wave ? qs : qf;
   const uint32_t poll_lanes = nslow * 64u, poll_id = (wave - (nwaves - nslow)) * 64u + lane;
+  // wide layout: a polling lane keeps the constraint ids of its first slots in registers (they index the global counters)
+  constexpr int kPollCache = WIDE ? 6 : 1;
+  uint32_t pc[kPollCache];
+#pragma unroll
+  for (int k = 0; k < kPollCache; ++k) {
+    uint32_t idx = N0 + poll_id + (uint32_t)k * poll_lanes;
+    pc[k] = (WIDE && slow_wave && idx < N01) ? F.t_c[row0 + idx] : 0u;
+  }
   uint32_t spins = 0;
   for (;;) {
     if (__hip_atomic_load(s_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
     if (slow_wave) {  // global counters that reached their iteration's threshold: queue the slot (once)
-      for (uint32_t idx = N0 + poll_id; idx < N01; idx += poll_lanes) {
-        uint32_t r = S.round[idx];
+      if (WIDE) {
+#pragma unroll
+        for (int k = 0; k < kPollCache; ++k) {
+          uint32_t idx = N0 + poll_id + (uint32_t)k * poll_lanes;
+          if (idx < N01) {
+            uint32_t r = s_round[idx];
+            if (r < iters) {
+              uint32_t av = __hip_atomic_load(&arr[pc[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (av >= 2u * (r + 1u)) { s_round[idx] = (uint8_t)(r | 0x80u); f5_push(qs, idx); }
+            }
+          }
+        }
+      }
+      for (uint32_t idx = N0 + poll_id + (WIDE ? (uint32_t)kPollCache * poll_lanes : 0u); idx < N01; idx += poll_lanes) {
+        uint32_t r = s_round[idx];
         if (r < iters) {
-          uint32_t av = __hip_atomic_load(&arr[S.c[idx]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (av >= 2u * (r + 1u)) { S.round[idx] = (uint8_t)(r | 0x80u); f5_push(qs, idx); }
+          uint32_t cid = WIDE ? F.t_c[row0 + idx] : s_c[idx];
+          uint32_t av = __hip_atomic_load(&arr[cid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (av >= 2u * (r + 1u)) { s_round[idx] = (uint8_t)(r | 0x80u); f5_push(qs, idx); }
         }
       }
     }
@@ -1696,15 +1738,22 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
     if (take) {
       spins = 0;
       if (lane < take) {
-        uint16_t* cell = &q.ring[(h + lane) & (kF5Ring - 1u)];
+        uint16_t* cell = &q.ring[(h + lane) % q.cap];
         uint32_t e;
         do { e = *reinterpret_cast<volatile uint16_t*>(cell); } while (!(e & 0x8000u));  // the pusher is between its two writes
         *cell = 0;
         const uint32_t slot = e & 0x7FFFu;
-        const uint32_t c = S.c[slot];
-        const uint32_t round = S.round[slot] & 0x7Fu;
+        const uint32_t round = s_round[slot] & 0x7Fu;
+        uint32_t c, aref, bref;
+        uint2 sw;
+        if (slot < n_meta) {
+          c = s_c[slot]; sw = s_succ[slot];
+          if (WIDE) { uint32_t ab = s_a[slot]; aref = ab & 0xFFFFu; bref = (ab >> 16) == 0xFFFFu ? kNone : (ab >> 16); }
+          else { aref = s_a[slot]; bref = s_b[slot]; }
+        } else {
+          c = F.t_c[row0 + slot]; aref = F.t_aref[row0 + slot]; bref = F.t_bref[row0 + slot]; sw = F.t_succ[row0 + slot];
+        }
         CRec rec = load_crec(&cons[c]);  // only the lane running the constraint touches its record
-        const uint32_t aref = S.aref[slot], bref = S.bref[slot];
         BodyDyn A = f5_load_body(s_body, rs, aref);
         BodyDyn Bd = f5_load_body(s_body, rs, bref);
         solve_one(rec, A, Bd);
@@ -1712,11 +1761,10 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
         f5_store_vel(s_body, rs, bref, Bd);
         cons[c].nimp = rec.nimp;
         const bool gcounter = slot >= N0 && slot < N01;
-        if (!gcounter) S.cnt[slot] = 0u;  // no arrival of the next iteration can come before this node's own releases
-        S.round[slot] = (uint8_t)(round + 1u);
+        if (!gcounter) s_cnt[slot] = 0u;  // no arrival of the next iteration can come before this node's own releases
+        s_round[slot] = (uint8_t)(round + 1u);
         // velocities and the impulse are out (LDS, write-through stores) before any successor hears of it
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        uint2 sw = S.succ[slot];
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
           if (side == 1 && bref == kNone) break;
@@ -1725,7 +1773,7 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
           uint32_t add = (w & kSuccTwo) ? 1u : 2u;
           if (w & kSuccLocal) {
             uint32_t sl = w & 0xFFFFu;
-            uint32_t old = __hip_atomic_fetch_add(&S.cnt[sl], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            uint32_t old = __hip_atomic_fetch_add(&s_cnt[sl], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (old + add >= 2u) f5_push(sl < N0 ? qf : qs, sl);
           } else {
             __hip_atomic_fetch_add(&arr[w & kSuccId], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -838,6 +838,8 @@ struct mgf_world {
   int64_t opt_debug_bvh = 0, opt_flow_trace = 0;
   int64_t opt_flow5_block = 0;     // minimum bodies per block of the block-local solver (tests)
   bool flow5_attr_set = false;
+  bool flow5_wide = false;          // LDS layout of k_solve_flow5 for this tick (chosen from the largest block of the last one)
+  uint32_t flow5_last_max = 0;
   int64_t opt_stream_ordered = 0;  // 1: the tiling calls (begin_tick, export_*, import_*) do not synchronise the ctx stream
   bool solve_pending = false;      // a dataflow launch was enqueued by mgf_world_solve_enqueue and not yet checked
   DBuf<unsigned long long> dbg;
@@ -876,7 +878,10 @@ struct mgf_world {
     F.sidx = sidx.p; F.brank = brank.p; F.shared = reinterpret_cast<uint8_t*>(f5_shared.p);
     F.gcnt = reinterpret_cast<uint8_t*>(f5_gcnt.p); F.lslot = f5_lslot.p; F.wg_cnt = f5_wg_cnt.p;
     F.t_c = f5_tc.p; F.t_aref = f5_taref.p; F.t_bref = f5_tbref.p; F.t_cnt0 = f5_tcnt0.p; F.t_succ = f5_tsucc.p;
-    F.fail = d_err() + 4; F.nb = f5_nb; F.nblocks = f5_nblocks; F.n = n;
+    F.fail = d_err() + 4; F.max_block = d_err() + 6;
+    F.cap_fast = flow5_wide ? kF5MaxFast : kF5NarrowCons; F.cap_slow = flow5_wide ? kF5MaxSlow : kF5NarrowCons;
+    F.cap_all = flow5_wide ? kF5MaxCons : kF5NarrowCons;
+    F.nb = f5_nb; F.nblocks = f5_nblocks; F.n = n;
     return F;
   }
   ConsLinks links() { ConsLinks K; K.ab = c_ab.p; K.succ = c_succ.p; K.pred = c_pred.p; return K; }
@@ -949,6 +954,21 @@ extern "C" mgf_status mgf_world_counter(const mgf_world* w, const char* name, in
     MGF_TRY(d2h(mw->ctx, h.data(), mw->f5_wg_cnt.p, h.size()));
     int k = name[11] - '0';
     for (uint32_t g = 0; g < w->f5_nblocks; ++g) *out += (int64_t)h[(size_t)(4 * g + k) * kF5CntStride];
+    return MGF_OK;
+  }
+  if (!strcmp(name, "flow5_max_block") || !strcmp(name, "flow5_max_fast")) {  // largest block (all classes / class 0) of the last prepared tick
+    *out = 0;
+    if (!w->flow5_prepped || w->f5_nblocks == 0) return MGF_OK;
+    std::vector<uint32_t> h(4 * (size_t)w->f5_nblocks * kF5CntStride);
+    mgf_world* mw = const_cast<mgf_world*>(w);
+    MGF_TRY(ctx_bind(mw->ctx));
+    MGF_TRY(d2h(mw->ctx, h.data(), mw->f5_wg_cnt.p, h.size()));
+    const bool fast = name[10] == 'f';
+    for (uint32_t g = 0; g < w->f5_nblocks; ++g) {
+      int64_t v = h[(size_t)(4 * g) * kF5CntStride];
+      if (!fast) v += (int64_t)h[(size_t)(4 * g + 1) * kF5CntStride] + h[(size_t)(4 * g + 2) * kF5CntStride];
+      *out = std::max(*out, v);
+    }
     return MGF_OK;
   }
   return fail(MGF_ERR_INVALID, "unknown counter");
@@ -1644,16 +1664,21 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
     MGF_TRY(w->f5_tc.ensure(rows, s)); MGF_TRY(w->f5_taref.ensure(rows, s)); MGF_TRY(w->f5_tbref.ensure(rows, s));
     MGF_TRY(w->f5_tcnt0.ensure(rows, s)); MGF_TRY(w->f5_tsucc.ensure(rows, s));
     if (!w->flow5_attr_set) {
-      MGF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_flow5), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(64 * (size_t)kF5MaxBodies + (size_t)kF5SlotBytes * kF5MaxCons + 4 * (size_t)kF5Ring + 64)));
+      MGF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_flow5<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(64 * (size_t)kF5MaxBodies + kF5LdsNarrow)));
+      MGF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_flow5<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(64 * (size_t)kF5MaxBodies + kF5LdsWide)));
       w->flow5_attr_set = true;
     }
+    // narrow layout (all slot constants in LDS) while the blocks are small, wide layout once they approach its limit
+    w->flow5_wide = w->flow5_last_max > kF5NarrowCons - kF5NarrowCons / 16;
     ZeroList z;
     memset(&z, 0, sizeof(z));
     z.p[0] = w->f5_shared.p; z.words[0] = n / 4 + 1;
     z.p[1] = w->f5_gcnt.p; z.words[1] = cap_c / 4 + 1;
     z.p[2] = w->d_err() + 4; z.words[2] = 1;
     z.p[3] = w->f5_wg_cnt.p; z.words[3] = 4 * w->f5_nblocks * kF5CntStride;
+    z.p[4] = w->d_err() + 6; z.words[4] = 1;  // largest block of the tick
     k_zero_many<<<64, kBlock, 0, s>>>(z);
     LAUNCH_CHECK();
     Flow5 F = w->flow5();
@@ -1698,8 +1723,13 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
   const int sleep = (int)w->opt_flow_sleep;
   if (use5) {
     Flow5 F = w->flow5();
-    const size_t lds = 64 * (size_t)F.nb + (size_t)kF5SlotBytes * kF5MaxCons + 4 * (size_t)kF5Ring + 64;
-    k_solve_flow5<<<F.nblocks, kF5Threads, lds, s>>>(w->srec.p, w->cons_nat.p, w->links(), F, w->flow_arr.p, (uint32_t)iters, abort_flag, spin_limit);
+    if (w->flow5_wide) {
+      k_solve_flow5<true><<<F.nblocks, kF5Threads, 64 * (size_t)F.nb + kF5LdsWide, s>>>(w->srec.p, w->cons_nat.p, w->links(), F, w->flow_arr.p, (uint32_t)iters,
+                                                                                      abort_flag, spin_limit);
+    } else {
+      k_solve_flow5<false><<<F.nblocks, kF5Threads, 64 * (size_t)F.nb + kF5LdsNarrow, s>>>(w->srec.p, w->cons_nat.p, w->links(), F, w->flow_arr.p, (uint32_t)iters,
+                                                                                          abort_flag, spin_limit);
+    }
     LAUNCH_CHECK();
     // stand-by: the global dataflow kernel runs only if a block did not fit its workgroup (flag raised by k_flow5_prep)
     k_solve_flow<false><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->links(), w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, nullptr, F.fail);
@@ -1778,10 +1808,13 @@ static mgf_status solve_frontier(mgf_world* w, int32_t iters) {
 // After a dataflow launch has been synchronised: abort flag, timings.
 static mgf_status solve_flow_finish(mgf_world* w) {
   uint32_t* pin = static_cast<uint32_t*>(w->ctx->pinned);
-  MGF_HIP_TRY(hipMemcpyAsync(pin + 80, w->d_err() + 2, 12, hipMemcpyDeviceToHost, w->ctx->stream));  // abort, grid-wide, flow5 fail
+  MGF_HIP_TRY(hipMemcpyAsync(pin + 80, w->d_err() + 2, 20, hipMemcpyDeviceToHost, w->ctx->stream));  // abort, grid-wide, flow5 fail, terrain-wide, flow5 max block
   MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
   if (pin[80]) return fail(MGF_ERR_HIP, "dataflow solver gave up waiting (grid not fully resident?)");
-  if (w->opt_solver_mode == 5 && w->flow5_prepped && pin[82]) w->n_flow5_fallbacks++;
+  if (w->opt_solver_mode == 5 && w->flow5_prepped) {
+    if (pin[82]) w->n_flow5_fallbacks++;
+    w->flow5_last_max = pin[84];
+  }
   w->stats.solver_kernel_launches = 1;
   w->depth = 1;
   if (w->opt_time_solver_kernels) {
