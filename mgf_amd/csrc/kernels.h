@@ -543,7 +543,7 @@ __global__ __launch_bounds__(kBlock) void k_candidates(Bodies B, uint32_t n, uin
 
 // Single-pass candidate generation into fixed-capacity global rows (the common case); bodies with more
 // hits than a row holds raise `overflow` and the host re-runs the exact two-pass path (k_candidates).
-constexpr int kRowCap = 32;   // partner row
+constexpr int kRowCap = 48;   // partner row (a settled pile has bodies with > 32 fat-box neighbours)
 constexpr int kRowCapT = 16;  // terrain row: initial capacity; the host doubles it (up to kRowCapTMax) when a body overflows
 constexpr int kRowCapTMax = 128;
 
