@@ -1533,6 +1533,7 @@ struct Flow5 {
   uint32_t* max_block;     // largest block of this tick (the host picks next tick's LDS layout from it)
   uint32_t nb, nblocks, n;
   uint32_t cap_fast, cap_slow, cap_all;  // limits of the chosen layout
+  uint32_t slow_x2;        // waves serving the slow queue = slow share of the slots x slow_x2 / 2 (tuning knob, 3)
 };
 __device__ __forceinline__ uint32_t f5_ref(const Flow5& F, uint32_t g, uint32_t body) {
   if (body == kNone) return kNone;
@@ -1682,7 +1683,7 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
   // waves [0, nfast) serve the fast queue, the rest the slow queue; the slow waves also poll the global counters
   // (a dedicated polling wave was tried: slower, it keeps the CU's memory queue busy)
   const uint32_t wave = t >> 6, lane = t & 63u, nwaves = kF5Threads / 64u;
-  uint32_t nslow = N > N0 ? (3u * nwaves * (N - N0) + 2u * N - 1u) / (2u * N) : 0u;
+  uint32_t nslow = N > N0 ? (F.slow_x2 * nwaves * (N - N0) + 2u * N - 1u) / (2u * N) : 0u;
   if (N > N0 && nslow < 1u) nslow = 1u;
   if (nslow > nwaves - 1u && N0 > 0u) nslow = nwaves - 1u;
   if (nslow > nwaves) nslow = nwaves;

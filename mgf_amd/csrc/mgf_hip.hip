@@ -836,6 +836,7 @@ struct mgf_world {
   int64_t opt_flow_blocks_per_cu = 0, opt_flow_sleep = 2;
   int flowk_grid = 0;
   int64_t opt_debug_bvh = 0, opt_flow_trace = 0;
+  int64_t opt_flow5_slow_x2 = 3;
   int64_t opt_flow5_block = 0;     // minimum bodies per block of the block-local solver (tests)
   bool flow5_attr_set = false;
   bool flow5_wide = false;          // LDS layout of k_solve_flow5 for this tick (chosen from the largest block of the last one)
@@ -881,6 +882,7 @@ struct mgf_world {
     F.fail = d_err() + 4; F.max_block = d_err() + 6;
     F.cap_fast = flow5_wide ? kF5MaxFast : kF5NarrowCons; F.cap_slow = flow5_wide ? kF5MaxSlow : kF5NarrowCons;
     F.cap_all = flow5_wide ? kF5MaxCons : kF5NarrowCons;
+    F.slow_x2 = (uint32_t)opt_flow5_slow_x2;
     F.nb = f5_nb; F.nblocks = f5_nblocks; F.n = n;
     return F;
   }
@@ -925,6 +927,7 @@ extern "C" mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_
   if (!strcmp(key, "solver_mode")) { w->opt_solver_mode = value; return MGF_OK; }
   if (!strcmp(key, "flow_blocks_per_cu")) { w->opt_flow_blocks_per_cu = value; w->flow_grid = 0; w->flowk_grid = 0; return MGF_OK; }
   if (!strcmp(key, "flow_sleep")) { w->opt_flow_sleep = value; return MGF_OK; }
+  if (!strcmp(key, "flow5_slow_x2")) { if (value < 1 || value > 16) return fail(MGF_ERR_INVALID, "flow5_slow_x2 out of range"); w->opt_flow5_slow_x2 = value; return MGF_OK; }
   if (!strcmp(key, "flow5_block")) { w->opt_flow5_block = value; w->flow5_prepped = false; return MGF_OK; }
   if (!strcmp(key, "stream_ordered")) { w->opt_stream_ordered = value; return MGF_OK; }
   if (!strcmp(key, "list_capacity")) {  // tests: force the speculative list capacities (the next tick must re-run its collide phase)
