@@ -1076,6 +1076,16 @@ __device__ __forceinline__ CRec load_crec(const CRec* src) {
   return c;
 }
 static_assert(offsetof(CRec, nimp) == 88 && offsetof(CRec, round) == 92 && offsetof(CRec, indeg) == 100, "CRec layout");
+// what ContactConstraint::solve reads: the first 96 bytes (through nimp / round)
+__device__ __forceinline__ CRec load_crec_solve(const CRec* src) {
+  CRec c;
+  const float4* s = reinterpret_cast<const float4*>(src);
+  float4* d = reinterpret_cast<float4*>(&c);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d[k] = s[k];
+  d[6] = make_float4(0, 0, 0, 0); d[7] = make_float4(0, 0, 0, 0);
+  return c;
+}
 
 __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCounts* sc, const uint32_t* p_owner, const uint32_t* p_cand,
                                                         const uint32_t* p_nc, const uint32_t* p_pre, const NContact* p_in,
@@ -1754,7 +1764,7 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
         } else {
           c = F.t_c[row0 + slot]; aref = F.t_aref[row0 + slot]; bref = F.t_bref[row0 + slot]; sw = F.t_succ[row0 + slot];
         }
-        CRec rec = load_crec(&cons[c]);  // only the lane running the constraint touches its record
+        CRec rec = load_crec_solve(&cons[c]);  // only the lane running the constraint touches its record
         BodyDyn A = f5_load_body(s_body, rs, aref);
         BodyDyn Bd = f5_load_body(s_body, rs, bref);
         solve_one(rec, A, Bd);
