@@ -108,6 +108,14 @@ typedef struct { mgf_vec3 p; mgf_vec3 d; float dt; } mgf_particle;
 /* Intersection collision.rs:151-158 */
 typedef struct { mgf_vec3 p; float t; } mgf_intersection;
 
+/* Manifold manifold.rs:112-118: time, normal (the UN-renormalised mean of the kept contacts' normals; NaN for an empty
+ * group, as in the reference), tangent_vector[2] = compute_basis(normal), the kept (local_a, local_b) pairs. */
+#define MGF_MANIFOLD_CAP 8
+typedef struct {
+  float time; mgf_vec3 normal; mgf_vec3 tangent[2]; int32_t n_contacts;
+  mgf_vec3 local_a[MGF_MANIFOLD_CAP]; mgf_vec3 local_b[MGF_MANIFOLD_CAP];
+} mgf_manifold;
+
 typedef struct mgf_ctx mgf_ctx;
 typedef struct mgf_mesh mgf_mesh;
 typedef struct mgf_bvh mgf_bvh;
@@ -222,6 +230,12 @@ MGF_API mgf_status mgf_world_read_constraints(mgf_world* w, mgf_constraint* out,
 /* Solver::add_constraint in bulk + solve on the resident RigidBodyVec (solver.rs:66-78):
  * replaces the tick's constraint list with `cons` (insertion order = array order). */
 MGF_API mgf_status mgf_world_set_constraints(mgf_world* w, const mgf_constraint* cons, int64_t n);
+/* ContactPruner::new + push(contact) for every LocalContact of a group, in order, then Manifold::from(pruner)
+ * (manifold.rs:42-148) for n groups at once: group i = contacts[offsets[i] .. offsets[i+1]).  params = NULL uses
+ * DefaultPruningParams / COLLISION_EPSILON.  The reference's pruner is unbounded; a group that keeps more than
+ * MGF_MANIFOLD_CAP contacts returns MGF_ERR_CAPACITY (its n_contacts still reports the count). */
+MGF_API mgf_status mgf_manifolds_from_contacts(mgf_ctx* ctx, const mgf_params* params, int64_t n, const uint64_t* offsets,
+                                               const mgf_local_contact* contacts, mgf_manifold* out);
 /* ---- scene I/O: the serde_json shape of the reference's persistent types (bvh.rs:29-47, pool.rs:25-41, mesh.rs:31-37,
  * geom.rs:256-260; cgmath vectors as {"x","y","z"}).  *_to_json writes a NUL-terminated string; *len is its length
  * (MGF_ERR_CAPACITY if cap < *len + 1).  *_from_json rebuilds the identical tree - entry for entry, free list included -

@@ -112,7 +112,7 @@ SYMBOLS = [
     "mgf_bvh_raytrace", "mgf_bvh_raytrace_many", "mgf_intersections_batch",
     "mgf_compound_new", "mgf_compound_free", "mgf_compound_set_pose", "mgf_compound_bounds", "mgf_compound_contacts_many",
     "mgf_compound_intersections",
-    "mgf_bvh_to_json", "mgf_bvh_from_json", "mgf_mesh_to_json", "mgf_mesh_from_json",
+    "mgf_bvh_to_json", "mgf_bvh_from_json", "mgf_mesh_to_json", "mgf_mesh_from_json", "mgf_manifolds_from_contacts",
     "mgf_world_new", "mgf_world_free", "mgf_world_set_terrain", "mgf_world_add_bodies", "mgf_world_len",
     "mgf_world_step", "mgf_world_build_constraints", "mgf_world_solve", "mgf_world_complete_motion",
     "mgf_world_integrate", "mgf_world_get", "mgf_world_set", "mgf_world_read_state", "mgf_world_write_state",
@@ -183,6 +183,7 @@ def load_library():
         "mgf_bvh_from_json": (i32, [vp, C.c_char_p, i64, P(vp)]),
         "mgf_mesh_to_json": (i32, [vp, vp, i64, P(i64)]),
         "mgf_mesh_from_json": (i32, [vp, C.c_char_p, i64, P(vp)]),
+        "mgf_manifolds_from_contacts": (i32, [vp, vp, i64, vp, vp, vp]),
         "mgf_bvh_dump": (i64, [vp, vp, vp, i64]),
         "mgf_world_new": (i32, [vp, P(Params), P(vp)]),
         "mgf_world_free": (None, [vp]),
@@ -393,6 +394,22 @@ def ray_capsule(ctx, p, d, cap_a, cap_d, cap_r):
     s = _shape(dict(kind="capsule", a=cap_a, d=cap_d, r=cap_r))
     _check(load_library().mgf_ray_capsule(ctx._h, C.byref(_v3(p)), C.byref(_v3(d)), C.byref(s), C.byref(ip), C.byref(t), C.byref(hit)))
     return (ip.tup(), t.value) if hit.value else None
+
+
+LOCAL_CONTACT_DTYPE = np.dtype([("local_a", "<f4", 3), ("local_b", "<f4", 3), ("a", "<f4", 3), ("b", "<f4", 3), ("n", "<f4", 3), ("t", "<f4")])
+MANIFOLD_CAP = 8
+MANIFOLD_DTYPE = np.dtype([("time", "<f4"), ("normal", "<f4", 3), ("tangent", "<f4", (2, 3)), ("n_contacts", "<i4"),
+                           ("local_a", "<f4", (MANIFOLD_CAP, 3)), ("local_b", "<f4", (MANIFOLD_CAP, 3))])
+
+
+def manifolds_from_contacts(ctx, offsets, contacts):
+    """ContactPruner::push for each group's LocalContacts in order, then Manifold::from(pruner) (manifold.rs:42-148)."""
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    contacts = np.ascontiguousarray(contacts, LOCAL_CONTACT_DTYPE)
+    n = len(offsets) - 1
+    out = np.zeros(max(n, 1), MANIFOLD_DTYPE)
+    _check(load_library().mgf_manifolds_from_contacts(ctx._h, None, n, offsets.ctypes.data, contacts.ctypes.data, out.ctypes.data))
+    return out[:n]
 
 
 def _to_json(fn, handle):

@@ -2012,6 +2012,51 @@ __global__ __launch_bounds__(kBlock) void k_bvh_raytrace(TerrainDev M, const Par
   if (!FILL) cnt[i] = m;
 }
 
+struct LocalOut { float la[3], lb[3]; ContactOut g; };
+// ContactPruner::push (manifold.rs:72-102) for each LocalContact of a group in order, then Manifold::from(pruner)
+// (:131-148): earliest-time contacts only (+-1e-6), points closer than sqrt(0.5) to a kept one merge (the one farther
+// from the centres stays), normal = un-renormalised mean (NaN for an empty group, as in the reference).
+constexpr int kManifoldCap = 8;  // the reference's SmallVec spills beyond 4 and never stops; groups that keep more raise `overflow`
+struct ManifoldOut { float time; float normal[3]; float t0[3]; float t1[3]; int32_t n; float la[kManifoldCap][3]; float lb[kManifoldCap][3]; };
+__global__ __launch_bounds__(kBlock) void k_manifolds(int64_t n, const unsigned long long* off, const LocalOut* lcs, float threshold_sq, float eps,
+                                                       ManifoldOut* out, uint32_t* overflow) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float min_t = kInf;
+  int cnt = 0;
+  LocalOut keep[kManifoldCap];
+  for (unsigned long long e = off[i]; e < off[i + 1]; ++e) {
+    LocalOut nc = lcs[e];
+    if (nc.g.t < min_t - eps) { cnt = 1; keep[0] = nc; min_t = nc.g.t; continue; }
+    if (nc.g.t > min_t + eps) continue;
+    bool merged = false;
+    for (int k = 0; k < cnt && !merged; ++k) {
+      V3 ra = ld3(nc.g.a) - ld3(keep[k].g.a), rb = ld3(nc.g.b) - ld3(keep[k].g.b);
+      if (mag2(ra) <= threshold_sq || mag2(rb) <= threshold_sq) {
+        float prev = mag2(ld3(keep[k].la)) + mag2(ld3(keep[k].lb)), cur = mag2(ld3(nc.la)) + mag2(ld3(nc.lb));
+        if (prev < cur) keep[k] = nc;
+        merged = true;
+      }
+    }
+    if (merged) continue;
+    if (cnt < kManifoldCap) keep[cnt] = nc; else *overflow = 1u;
+    ++cnt;
+  }
+  ManifoldOut m;
+  V3 sum = mk3(0.0f, 0.0f, 0.0f);
+  int stored = cnt < kManifoldCap ? cnt : kManifoldCap;
+  for (int k = 0; k < stored; ++k) {
+    sum = sum + ld3(keep[k].g.n);
+    for (int c = 0; c < 3; ++c) { m.la[k][c] = keep[k].la[c]; m.lb[k][c] = keep[k].lb[c]; }
+  }
+  for (int k = stored; k < kManifoldCap; ++k) for (int c = 0; c < 3; ++c) { m.la[k][c] = 0.0f; m.lb[k][c] = 0.0f; }
+  V3 avg = sum / (float)cnt;
+  V3 t0, t1;
+  compute_basis(avg, &t0, &t1);
+  m.time = min_t; st3(m.normal, avg); st3(m.t0, t0); st3(m.t1, t1); m.n = cnt;
+  out[i] = m;
+}
+
 struct MovingIn { int tag; float p[3], d[3], r; float delta[3]; };
 // ---- Compound (compound.rs:230-352): components + internal reference-built BVH + pose -------------------
 struct CompIn { int tag; float p[3], d[3], r; };
@@ -2120,7 +2165,6 @@ __global__ __launch_bounds__(kBlock) void k_compound_intersections(CompoundDev D
   if (have) { st3(out[i].p, best_p); out[i].t = best_t; }
 }
 
-struct LocalOut { float la[3], lb[3]; ContactOut g; };
 __device__ __forceinline__ Comp to_comp(const MovingIn& m) {
   Comp k; k.kind = m.tag; k.p = ld3(m.p); k.d = ld3(m.d); k.r = m.r; return k;
 }

@@ -393,6 +393,32 @@ static inline Comp comp_of(const mgf_component& c) {
   Comp k; k.kind = c.tag; k.p = mk3(c.p.x, c.p.y, c.p.z); k.d = mk3(c.d.x, c.d.y, c.d.z); k.r = c.r;
   return k;
 }
+// ContactPruner + Manifold::from for n groups of LocalContacts (manifold.rs:42-148)
+static_assert(sizeof(ManifoldOut) == sizeof(mgf_manifold), "manifold layout");
+extern "C" mgf_status mgf_manifolds_from_contacts(mgf_ctx* ctx, const mgf_params* params, int64_t n, const uint64_t* offsets,
+                                                  const mgf_local_contact* contacts, mgf_manifold* out) {
+  if (n < 0 || (n && (!offsets || !out))) return fail(MGF_ERR_INVALID, "bad argument");
+  MGF_TRY(ctx_bind(ctx));
+  if (n == 0) return MGF_OK;
+  for (int64_t i = 0; i < n; ++i) if (offsets[i + 1] < offsets[i]) return fail(MGF_ERR_INVALID, "offsets must be non-decreasing");
+  const uint64_t total = offsets[n];
+  if (total && !contacts) return fail(MGF_ERR_INVALID, "NULL contacts");
+  mgf_params P = params ? *params : mgf_default_params();
+  DBuf<unsigned long long> d_off; DBuf<LocalOut> d_lc; DBuf<ManifoldOut> d_out; DBuf<uint32_t> d_ovf;
+  MGF_TRY(d_off.ensure((size_t)n + 1, ctx->stream)); MGF_TRY(d_lc.ensure(std::max<size_t>(total, 1), ctx->stream));
+  MGF_TRY(d_out.ensure((size_t)n, ctx->stream)); MGF_TRY(d_ovf.ensure(1, ctx->stream));
+  MGF_HIP_TRY(hipMemsetAsync(d_ovf.p, 0, 4, ctx->stream));
+  MGF_TRY(h2d(ctx, d_off.p, reinterpret_cast<const unsigned long long*>(offsets), (size_t)n + 1));
+  MGF_TRY(h2d(ctx, d_lc.p, reinterpret_cast<const LocalOut*>(contacts), (size_t)total));
+  k_manifolds<<<nblk(n), kBlock, 0, ctx->stream>>>(n, d_off.p, d_lc.p, P.persistent_threshold_sq, P.collision_epsilon, d_out.p, d_ovf.p);
+  LAUNCH_CHECK();
+  MGF_TRY(d2h(ctx, reinterpret_cast<ManifoldOut*>(out), d_out.p, (size_t)n));
+  uint32_t ovf = 0;
+  MGF_TRY(d2h(ctx, &ovf, d_ovf.p, 1));
+  if (ovf) return fail(MGF_ERR_CAPACITY, "a manifold keeps more than MGF_MANIFOLD_CAP contacts (n_contacts reports how many)");
+  return MGF_OK;
+}
+
 // ---- scene I/O (serde_json shape of BVH<AABB, usize> and Mesh; scene_io.h) --------------------------------
 static mgf_status emit_json(const std::string& js, char* buf, int64_t cap, int64_t* len) {
   if (len) *len = (int64_t)js.size();

@@ -113,6 +113,7 @@ def lib():
         L.mgfo_compound_contacts.restype = C.c_int
         L.mgfo_compound_intersection.argtypes = [C.c_void_p, P(Vec3), P(Vec3), C.c_float, P(Vec3), P(C.c_float)]
         L.mgfo_compound_intersection.restype = C.c_int
+        L.mgfo_manifold_from_contacts.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, P(C.c_int32), C.c_void_p, C.c_int32]
         L.mgfo_tri_closest_point.argtypes = [P(Shape), P(Vec3), P(Vec3)]
         L.mgfo_compute_basis.argtypes = [P(Vec3), P(Vec3)]
         L.mgfo_quat_from_arc.argtypes = [P(Vec3), P(Vec3), P(Quat)]
@@ -248,6 +249,20 @@ def intersection_aabb(p, d, dt, c, r):
     box = Aabb(vec3(c), vec3(r))
     hit = lib().mgfo_intersection_aabb(C.byref(vec3(p)), C.byref(vec3(d)), C.c_float(dt), C.byref(box), C.byref(ip), C.byref(t))
     return (ip.tup(), t.value) if hit else None
+
+
+LOCAL_CONTACT_DTYPE = np.dtype([("local_a", "<f4", 3), ("local_b", "<f4", 3), ("a", "<f4", 3), ("b", "<f4", 3), ("n", "<f4", 3), ("t", "<f4")])
+
+
+def manifold_from_contacts(lcs, cap=64):
+    """ContactPruner::push for every LocalContact (LOCAL_CONTACT_DTYPE rows, in order), then Manifold::from(pruner):
+    dict(time, normal, t0, t1, pairs[(local_a, local_b)])."""
+    lcs = np.ascontiguousarray(lcs, LOCAL_CONTACT_DTYPE)
+    out = np.zeros(10, np.float32)
+    pairs = np.zeros((cap, 6), np.float32)
+    n = C.c_int32()
+    lib().mgfo_manifold_from_contacts(lcs.ctypes.data, len(lcs), out.ctypes.data, C.byref(n), pairs.ctypes.data, cap)
+    return dict(time=out[0], normal=out[1:4].copy(), t0=out[4:7].copy(), t1=out[7:10].copy(), pairs=pairs[:min(n.value, cap)].copy(), n=n.value)
 
 
 def component(tag, p, d, r):

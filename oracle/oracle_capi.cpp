@@ -201,6 +201,21 @@ int mgfo_compound_intersection(void* cp, const o_vec3* p, const o_vec3* d, float
   *ip = O(i.p); *t = i.t;
   return 1;
 }
+// ContactPruner::push for every contact of a group, then Manifold::from(pruner) (manifold.rs:72-148).
+// out: time, normal3, t0 3, t1 3 (10 floats), *n = number of contact pairs, pairs = (local_a3, local_b3) each, cap pairs.
+void mgfo_manifold_from_contacts(const o_local_contact* lcs, int64_t n_in, float* out10, int32_t* n, float* pairs, int32_t cap) {
+  ContactPruner pr;
+  for (int64_t i = 0; i < n_in; ++i) pr.push(LocalContact{V(lcs[i].local_a), V(lcs[i].local_b), Contact{V(lcs[i].global.a), V(lcs[i].global.b), V(lcs[i].global.n), lcs[i].global.t}});
+  Manifold m = manifold_from(pr);
+  out10[0] = m.time;
+  out10[1] = m.normal.x; out10[2] = m.normal.y; out10[3] = m.normal.z;
+  for (int k = 0; k < 2; ++k) { out10[4 + 3 * k] = m.tangent_vector[k].x; out10[5 + 3 * k] = m.tangent_vector[k].y; out10[6 + 3 * k] = m.tangent_vector[k].z; }
+  *n = (int32_t)m.len();
+  for (size_t k = 0; k < m.len() && (int32_t)k < cap; ++k) {
+    float* q = pairs + 6 * k;
+    q[0] = m.contacts[k].a.x; q[1] = m.contacts[k].a.y; q[2] = m.contacts[k].a.z; q[3] = m.contacts[k].b.x; q[4] = m.contacts[k].b.y; q[5] = m.contacts[k].b.z;
+  }
+}
 void mgfo_tri_closest_point(const o_shape* tri, const o_vec3* to, o_vec3* out) { *out = O(tri_closest_point(as_tri(*tri), V(*to))); }
 void mgfo_compute_basis(const o_vec3* n, o_vec3* out2) { V3 b[2]; compute_basis(V(*n), b); out2[0] = O(b[0]); out2[1] = O(b[1]); }
 void mgfo_quat_from_arc(const o_vec3* src, const o_vec3* dst, o_quat* out) { Quat q = quat_from_arc(V(*src), V(*dst)); *out = o_quat{q.s, q.v.x, q.v.y, q.v.z}; }
