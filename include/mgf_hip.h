@@ -276,6 +276,23 @@ MGF_API mgf_status mgf_world_import_ghosts(mgf_world* w, const float* src, int64
 MGF_API mgf_status mgf_world_export_velocities(mgf_world* w, const uint32_t* ids, int64_t n, float* dst);
 MGF_API mgf_status mgf_world_import_ghost_velocities(mgf_world* w, const float* src, int64_t n_ghost);
 MGF_API int64_t mgf_world_ghost_len(const mgf_world* w);
+/* ---- migration: an owned body whose centre leaves its tile's slab [x_lo, x_hi) changes owner -------
+ * mgf_world_select_tile = mgf_world_select_boundary + the migrants of this tick: counts[0..1] boundary bodies
+ * (left, right), counts[2..3] bodies with centre.x < x_lo / >= x_hi; ids_migrants receives the left-goers then the
+ * right-goers (each ascending), at most cap in total.  A tick without migrants costs one extra counting kernel and
+ * no extra host wait.  The tiles driver (mgf_amd/tiles.py) moves the selected bodies at the END of the tick:
+ * export_migrants (MGF_MIGRANT_FLOATS floats per body: the body's row of every device array, fat AABB and tag
+ * included) -> neighbour -> remove_bodies on the old owner, import_migrants (append) on the new one.  Ids of the
+ * remaining bodies shift down on removal; mgf_world_set_tags / read_tags give bodies an identity that survives. */
+#define MGF_MIGRANT_FLOATS 80
+MGF_API mgf_status mgf_world_select_tile(mgf_world* w, float x_left, float x_right, float x_lo, float x_hi,
+                                         uint32_t* ids_left, uint32_t* ids_right, uint32_t* ids_migrants, int64_t cap,
+                                         int64_t* counts /* [4] */);
+MGF_API mgf_status mgf_world_export_migrants(mgf_world* w, const uint32_t* ids, int64_t n, float* dst);
+MGF_API mgf_status mgf_world_remove_bodies(mgf_world* w, const uint32_t* ids, int64_t n);  /* distinct ids, any order */
+MGF_API mgf_status mgf_world_import_migrants(mgf_world* w, const float* src, int64_t n);
+MGF_API mgf_status mgf_world_set_tags(mgf_world* w, const uint32_t* tags /* host, one per owned body */, int64_t n);
+MGF_API mgf_status mgf_world_read_tags(mgf_world* w, uint32_t* tags /* host */, int64_t cap);
 /* Stream-ordered variant of the loop above, for a driver that issues its RCCL transfers on the context's
  * stream (mgf_ctx_set_stream): with option "stream_ordered" = 1 begin_tick / select_boundary's scatter /
  * export_* / import_* only enqueue; mgf_world_solve_enqueue is Solver::solve without the read-back, and
@@ -285,10 +302,12 @@ MGF_API mgf_status mgf_world_finish(mgf_world* w, mgf_step_stats* stats);
 /* Options (development and test knobs; defaults in brackets): "time_solver_kernels" [0] HIP events around the
  * solver kernels; "solver_mode" [5] 1 = persistent dataflow launch, 0 = one launch per dependency frontier,
  * 4 = dataflow with out-of-order slots, 5 = block-local dataflow (velocities and counters of a spatial block in LDS); "two_pass_candidates" [0]; "broadphase_tree" [0]; "terrain_tree" [0]; "stream_ordered" [0]; "list_capacity";
- * "flow_blocks_per_cu"; "flow_sleep"; "flow_trace"; "debug_bvh". */
+ * "flow_blocks_per_cu"; "flow_sleep"; "flow_trace"; "debug_bvh"; "body_kinds" (OR-in, bit0 sphere, bit1 capsule): the
+ * kinds this world's ghosts may have - a tile whose own bodies are all of one kind must be told when a neighbour's are
+ * not, because the narrowphase dispatch is chosen on the host (the tiles driver exchanges the masks with the counts). */
 MGF_API mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_t value);
 /* Diagnostics: how often a slow path was taken.  name in {"row_overflows", "capacity_retries", "flow5_fallbacks",
- * "grid_too_wide", "flow5_blocks", "flow5_class0|1|2", "terrain_grid", "terrain_row_capacity"}. */
+ * "grid_too_wide", "flow5_blocks", "flow5_class0|1|2", "terrain_grid", "terrain_row_capacity", "body_kinds"}. */
 MGF_API mgf_status mgf_world_counter(const mgf_world* w, const char* name, int64_t* out);
 /* Raw device pointers of resident state for zero-copy exchange (multi-GPU halo): name in
  * {"x","q","solver_rec","delta"}; pointer valid until the next add_bodies. */

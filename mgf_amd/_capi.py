@@ -120,6 +120,8 @@ SYMBOLS = [
     "mgf_world_device_ptr",
     "mgf_world_begin_tick", "mgf_world_collide", "mgf_world_select_boundary", "mgf_world_export_bodies",
     "mgf_world_import_ghosts", "mgf_world_export_velocities", "mgf_world_import_ghost_velocities", "mgf_world_ghost_len",
+    "mgf_world_select_tile", "mgf_world_export_migrants", "mgf_world_remove_bodies", "mgf_world_import_migrants",
+    "mgf_world_set_tags", "mgf_world_read_tags",
     "mgf_world_solve_enqueue", "mgf_world_finish", "mgf_world_counter",
 ]
 
@@ -212,6 +214,12 @@ def load_library():
         "mgf_world_export_velocities": (i32, [vp, vp, i64, vp]),
         "mgf_world_import_ghost_velocities": (i32, [vp, vp, i64]),
         "mgf_world_ghost_len": (i64, [vp]),
+        "mgf_world_select_tile": (i32, [vp, f32, f32, f32, f32, vp, vp, vp, i64, P(i64)]),
+        "mgf_world_export_migrants": (i32, [vp, vp, i64, vp]),
+        "mgf_world_remove_bodies": (i32, [vp, vp, i64]),
+        "mgf_world_import_migrants": (i32, [vp, vp, i64]),
+        "mgf_world_set_tags": (i32, [vp, vp, i64]),
+        "mgf_world_read_tags": (i32, [vp, vp, i64]),
         "mgf_world_solve_enqueue": (i32, [vp, i32]),
         "mgf_world_finish": (i32, [vp, P(StepStats)]),
         "mgf_world_counter": (i32, [vp, C.c_char_p, P(i64)]),
@@ -793,6 +801,32 @@ class World:
 
     def ghost_len(self):
         return load_library().mgf_world_ghost_len(self._h)
+
+    # ---- migration between tiles (device pointers, like the ghost calls) ----
+    def select_tile(self, x_left, x_right, x_lo, x_hi, ids_left_ptr, ids_right_ptr, ids_migrants_ptr, cap):
+        """-> (n_boundary_left, n_boundary_right, n_migrants_left, n_migrants_right)"""
+        counts = (C.c_int64 * 4)()
+        _check(load_library().mgf_world_select_tile(self._h, float(x_left), float(x_right), float(x_lo), float(x_hi), ids_left_ptr,
+                                                    ids_right_ptr, ids_migrants_ptr, int(cap), counts))
+        return tuple(int(c) for c in counts)
+
+    def export_migrants(self, ids_ptr, n, dst_ptr):
+        _check(load_library().mgf_world_export_migrants(self._h, ids_ptr, int(n), dst_ptr))
+
+    def remove_bodies(self, ids_ptr, n):
+        _check(load_library().mgf_world_remove_bodies(self._h, ids_ptr, int(n)))
+
+    def import_migrants(self, src_ptr, n):
+        _check(load_library().mgf_world_import_migrants(self._h, src_ptr, int(n)))
+
+    def set_tags(self, tags):
+        tags = np.ascontiguousarray(tags, np.uint32)
+        _check(load_library().mgf_world_set_tags(self._h, tags.ctypes.data, len(tags)))
+
+    def tags(self):
+        out = np.zeros(max(len(self), 1), np.uint32)
+        _check(load_library().mgf_world_read_tags(self._h, out.ctypes.data, len(out)))
+        return out[:len(self)].copy()
 
     def solve_enqueue(self, iters):
         _check(load_library().mgf_world_solve_enqueue(self._h, int(iters)))

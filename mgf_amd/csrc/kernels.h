@@ -1898,6 +1898,91 @@ __global__ __launch_bounds__(kBlock) void k_import_ghost_vel(float4* srec, uint3
   *p = make_float2(in[2 * t + 1].x, in[2 * t + 1].y);
 }
 
+// ---- migration of owned bodies between tiles -----------------------------------------------------
+// A migrant record is the body's row of every Bodies array, verbatim (kMigrantWords float4 = 80 floats): the
+// receiving tile continues bit-identically, persistent fat box and constructor tag (ctor.w) included.
+constexpr int kMigrantWords = 20;
+__device__ __forceinline__ float4* body_word(const Bodies& B, uint32_t e, uint32_t i) {
+  switch (e) {
+    case 0: return B.x + i;
+    case 1: return B.q + i;
+    case 2: case 3: case 4: case 5: return B.srec + 4 * (size_t)i + (e - 2);
+    case 6: return B.sp0 + i;
+    case 7: return B.sp1 + i;
+    case 8: return B.ctor + i;
+    case 9: case 10: case 11: return B.imb + 3 * (size_t)i + (e - 9);
+    case 12: return B.delta + i;
+    case 13: return B.einfo + i;
+    case 14: return B.col0 + i;
+    case 15: return B.col1 + i;
+    case 16: return B.tb_c + i;
+    case 17: return B.tb_r + i;
+    case 18: return B.fb_c + i;
+    default: return B.fb_r + i;
+  }
+}
+// cnt[0] / cnt[1] += owned bodies whose centre lies below x_lo / at or above x_hi (the slab is [x_lo, x_hi))
+__global__ __launch_bounds__(kBlock) void k_migrant_count(Bodies B, uint32_t n_owned, float x_lo, float x_hi, uint32_t* cnt) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_owned) return;
+  float cx = B.x[i].x;
+  if (cx < x_lo) atomicAdd(cnt, 1u);
+  else if (cx >= x_hi) atomicAdd(cnt + 1, 1u);
+}
+__global__ __launch_bounds__(kBlock) void k_migrant_flags(Bodies B, uint32_t n_owned, float x_lo, float x_hi, uint32_t* fl, uint32_t* fr) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i > n_owned) return;
+  uint32_t l = 0, r = 0;
+  if (i < n_owned) {
+    float cx = B.x[i].x;
+    l = (cx < x_lo) ? 1u : 0u;
+    r = (!l && cx >= x_hi) ? 1u : 0u;
+  }
+  fl[i] = l; fr[i] = r;
+}
+__global__ __launch_bounds__(kBlock) void k_export_migrants(Bodies B, const uint32_t* ids, uint32_t m, float4* out) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= m * kMigrantWords) return;
+  uint32_t b = t / kMigrantWords, e = t % kMigrantWords;
+  out[t] = *body_word(B, e, ids[b]);
+}
+__global__ __launch_bounds__(kBlock) void k_import_migrants(Bodies B, uint32_t base, uint32_t m, const float4* in) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= m * kMigrantWords) return;
+  uint32_t b = t / kMigrantWords, e = t % kMigrantWords;
+  *body_word(B, e, base + b) = in[t];
+}
+// keep[i] = 1 for i < n, keep[n] = 0 (scan total); then the listed bodies are cleared
+__global__ __launch_bounds__(kBlock) void k_keep_fill(uint32_t* keep, uint32_t n) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i <= n) keep[i] = i < n ? 1u : 0u;
+}
+__global__ __launch_bounds__(kBlock) void k_keep_clear(uint32_t* keep, const uint32_t* ids, uint32_t m, uint32_t n, uint32_t* err) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= m) return;
+  uint32_t i = ids[t];
+  if (i >= n || atomicExch(&keep[i], 0u) == 0u) atomicOr(err, 1u);  // out of range or listed twice
+}
+// stable compaction through a scratch copy: tmp[pos[i]] = row i for kept bodies, then rows [0, n_new) = tmp
+__global__ __launch_bounds__(kBlock) void k_compact_gather(Bodies B, uint32_t n, const uint32_t* keep, const uint32_t* pos, float4* tmp) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n * kMigrantWords) return;
+  uint32_t i = t / kMigrantWords, e = t % kMigrantWords;
+  if (keep[i]) tmp[(size_t)pos[i] * kMigrantWords + e] = *body_word(B, e, i);
+}
+__global__ __launch_bounds__(kBlock) void k_kind_mask(const float4* col1, uint32_t base, uint32_t m, uint32_t* mask) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t < m) atomicOr(mask, f2u(col1[base + t].w) == (uint32_t)KIND_SPHERE ? 1u : 2u);
+}
+__global__ __launch_bounds__(kBlock) void k_tags_set(float4* ctor, const uint32_t* tags, uint32_t n) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) ctor[i].w = u2f(tags[i]);
+}
+__global__ __launch_bounds__(kBlock) void k_tags_get(const float4* ctor, uint32_t* tags, uint32_t n) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) tags[i] = f2u(ctor[i].w);
+}
+
 // ------------------------------------------------------------------------------------------
 // Single-shot entry points (golden-vector parity through the C-ABI): one lane per problem.
 // ------------------------------------------------------------------------------------------

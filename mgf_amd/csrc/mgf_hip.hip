@@ -824,6 +824,8 @@ struct mgf_world {
   uint32_t n_owned = 0;  // bodies of this world's RigidBodyVec (added through add_bodies)
   bool has_sphere = false, has_capsule = false;
   DBuf<uint32_t> bflag_l, bflag_r, bscan_l, bscan_r;  // boundary selection scratch
+  DBuf<uint32_t> mig_cnt;  // migration: [0] left-goers, [1] right-goers (also remove_bodies' error word)
+  DBuf<float4> mig_tmp;    // remove_bodies: compacted copy of every body array
   // RigidBodyVec
   DBuf<float4> x, q, srec, sp0, sp1, ctor, imb, delta, einfo, col0, col1, tb_c, tb_r, fb_c, fb_r;
   // terrain (copy of the caller's Mesh)
@@ -956,6 +958,11 @@ extern "C" mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_
   if (!strcmp(key, "flow5_slow_x2")) { if (value < 1 || value > 16) return fail(MGF_ERR_INVALID, "flow5_slow_x2 out of range"); w->opt_flow5_slow_x2 = value; return MGF_OK; }
   if (!strcmp(key, "flow5_block")) { w->opt_flow5_block = value; w->flow5_prepped = false; return MGF_OK; }
   if (!strcmp(key, "stream_ordered")) { w->opt_stream_ordered = value; return MGF_OK; }
+  if (!strcmp(key, "body_kinds")) {  // OR-in: kinds (bit0 sphere, bit1 capsule) that ghosts of this world may have
+    if (value & 1) w->has_sphere = true;
+    if (value & 2) w->has_capsule = true;
+    return MGF_OK;
+  }
   if (!strcmp(key, "list_capacity")) {  // tests: force the speculative list capacities (the next tick must re-run its collide phase)
     if (value < 1 || value > 0x7FFFFFF0ll) return fail(MGF_ERR_INVALID, "list_capacity out of range");
     w->cap_t = w->cap_p = w->cap_c = (uint32_t)value;
@@ -972,6 +979,7 @@ extern "C" mgf_status mgf_world_counter(const mgf_world* w, const char* name, in
   if (!strcmp(name, "grid_too_wide")) { *out = w->grid_too_wide ? 1 : 0; return MGF_OK; }
   if (!strcmp(name, "terrain_grid")) { *out = (w->terrain && w->terrain->grid.ready && !w->terrain_grid_off && !w->opt_terrain_tree) ? 1 : 0; return MGF_OK; }
   if (!strcmp(name, "terrain_row_capacity")) { *out = (int64_t)w->row_cap_t; return MGF_OK; }
+  if (!strcmp(name, "body_kinds")) { *out = (w->has_sphere ? 1 : 0) | (w->has_capsule ? 2 : 0); return MGF_OK; }
   if (!strcmp(name, "flow5_blocks")) { *out = (int64_t)w->f5_nblocks; return MGF_OK; }
   if (!strncmp(name, "flow5_class", 11) && (name[11] == '0' || name[11] == '1' || name[11] == '2') && !name[12]) {
     // constraints of the last prepared tick in class 0 / 1 / 2 (all-LDS / global counter / LDS counter + shared body)
@@ -1639,6 +1647,149 @@ extern "C" mgf_status mgf_world_import_ghosts(mgf_world* w, const float* src, in
   w->n = (uint32_t)need;
   w->constraints_ready = false;
   return sync_unless_ordered(w);
+}
+// ---- migration of owned bodies between tiles ---------------------------------------
+// mgf_world_select_tile = select_boundary + the bodies whose centre left the slab [x_lo, x_hi).  The common tick has
+// no migrant: its cost over select_boundary is one counting kernel, and the counts ride on the same read-back.
+extern "C" mgf_status mgf_world_select_tile(mgf_world* w, float x_left, float x_right, float x_lo, float x_hi, uint32_t* ids_left,
+                                            uint32_t* ids_right, uint32_t* ids_migrants, int64_t cap, int64_t* counts) {
+  if (!w || !counts) return fail(MGF_ERR_INVALID, "NULL argument");
+  MGF_TRY(ctx_bind(w->ctx));
+  mgf_ctx* ctx = w->ctx;
+  hipStream_t s = ctx->stream;
+  uint32_t n = w->n_owned;
+  counts[0] = counts[1] = counts[2] = counts[3] = 0;
+  if (n == 0) return MGF_OK;
+  MGF_TRY(w->bflag_l.ensure(n + 1, s)); MGF_TRY(w->bflag_r.ensure(n + 1, s)); MGF_TRY(w->bscan_l.ensure(n + 1, s)); MGF_TRY(w->bscan_r.ensure(n + 1, s));
+  MGF_TRY(w->mig_cnt.ensure(2, s));
+  MGF_HIP_TRY(hipMemsetAsync(w->mig_cnt.p, 0, 8, s));
+  k_boundary_flags<<<nblk(n + 1), kBlock, 0, s>>>(w->bodies(), n, x_left, x_right, w->bflag_l.p, w->bflag_r.p);
+  LAUNCH_CHECK();
+  k_migrant_count<<<nblk(n), kBlock, 0, s>>>(w->bodies(), n, x_lo, x_hi, w->mig_cnt.p);
+  LAUNCH_CHECK();
+  MGF_TRY(prim_exclusive_scan_u32(ctx, w->bflag_l.p, w->bscan_l.p, (size_t)n + 1));
+  MGF_TRY(prim_exclusive_scan_u32(ctx, w->bflag_r.p, w->bscan_r.p, (size_t)n + 1));
+  uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
+  MGF_HIP_TRY(hipMemcpyAsync(pin, w->bscan_l.p + n, 4, hipMemcpyDeviceToHost, s));
+  MGF_HIP_TRY(hipMemcpyAsync(pin + 1, w->bscan_r.p + n, 4, hipMemcpyDeviceToHost, s));
+  MGF_HIP_TRY(hipMemcpyAsync(pin + 2, w->mig_cnt.p, 8, hipMemcpyDeviceToHost, s));
+  MGF_HIP_TRY(hipStreamSynchronize(s));
+  const uint32_t nl = pin[0], nr = pin[1], ml = pin[2], mr = pin[3];
+  counts[0] = nl; counts[1] = nr; counts[2] = ml; counts[3] = mr;
+  if ((int64_t)nl > cap || (int64_t)nr > cap || (int64_t)ml + (int64_t)mr > cap) return fail(MGF_ERR_CAPACITY, "id buffers too small");
+  if (!ids_left || !ids_right) return fail(MGF_ERR_INVALID, "NULL id buffer");
+  k_boundary_scatter<<<nblk(n), kBlock, 0, s>>>(n, w->bflag_l.p, w->bscan_l.p, w->bflag_r.p, w->bscan_r.p, ids_left, ids_right);
+  LAUNCH_CHECK();
+  if (ml + mr) {  // rare: build the two ascending lists, left-goers first
+    if (!ids_migrants) return fail(MGF_ERR_INVALID, "NULL migrant id buffer");
+    k_migrant_flags<<<nblk(n + 1), kBlock, 0, s>>>(w->bodies(), n, x_lo, x_hi, w->bflag_l.p, w->bflag_r.p);
+    LAUNCH_CHECK();
+    MGF_TRY(prim_exclusive_scan_u32(ctx, w->bflag_l.p, w->bscan_l.p, (size_t)n + 1));
+    MGF_TRY(prim_exclusive_scan_u32(ctx, w->bflag_r.p, w->bscan_r.p, (size_t)n + 1));
+    k_boundary_scatter<<<nblk(n), kBlock, 0, s>>>(n, w->bflag_l.p, w->bscan_l.p, w->bflag_r.p, w->bscan_r.p, ids_migrants, ids_migrants + ml);
+    LAUNCH_CHECK();
+  }
+  return sync_unless_ordered(w);
+}
+extern "C" mgf_status mgf_world_export_migrants(mgf_world* w, const uint32_t* ids, int64_t n, float* dst) {
+  if (!w || n < 0 || (n && (!ids || !dst))) return fail(MGF_ERR_INVALID, "bad argument");
+  MGF_TRY(ctx_bind(w->ctx));
+  if (n > 0) {
+    k_export_migrants<<<nblk((size_t)n * kMigrantWords), kBlock, 0, w->ctx->stream>>>(w->bodies(), ids, (uint32_t)n, reinterpret_cast<float4*>(dst));
+    LAUNCH_CHECK();
+  }
+  return sync_unless_ordered(w);
+}
+// Removes the listed owned bodies (distinct ids, any order); the others keep their relative order, so ids above a
+// removed one shift down.  Ghosts of the current tick are dropped.
+extern "C" mgf_status mgf_world_remove_bodies(mgf_world* w, const uint32_t* ids, int64_t n_ids) {
+  if (!w || n_ids < 0 || (n_ids && !ids)) return fail(MGF_ERR_INVALID, "bad argument");
+  MGF_TRY(ctx_bind(w->ctx));
+  mgf_ctx* ctx = w->ctx;
+  hipStream_t s = ctx->stream;
+  const uint32_t n = w->n_owned;
+  w->n = n;
+  w->constraints_ready = false;
+  if (n_ids == 0) return MGF_OK;
+  if ((uint64_t)n_ids > n) return fail(MGF_ERR_INVALID, "more ids than bodies");
+  MGF_TRY(w->bflag_l.ensure(n + 1, s)); MGF_TRY(w->bscan_l.ensure(n + 1, s));
+  MGF_TRY(w->mig_cnt.ensure(2, s));
+  MGF_TRY(w->mig_tmp.ensure((size_t)n * kMigrantWords, s));
+  MGF_HIP_TRY(hipMemsetAsync(w->mig_cnt.p, 0, 8, s));
+  k_keep_fill<<<nblk(n + 1), kBlock, 0, s>>>(w->bflag_l.p, n);
+  LAUNCH_CHECK();
+  k_keep_clear<<<nblk(n_ids), kBlock, 0, s>>>(w->bflag_l.p, ids, (uint32_t)n_ids, n, w->mig_cnt.p);
+  LAUNCH_CHECK();
+  MGF_TRY(prim_exclusive_scan_u32(ctx, w->bflag_l.p, w->bscan_l.p, (size_t)n + 1));
+  k_compact_gather<<<nblk((size_t)n * kMigrantWords), kBlock, 0, s>>>(w->bodies(), n, w->bflag_l.p, w->bscan_l.p, w->mig_tmp.p);
+  LAUNCH_CHECK();
+  uint32_t* pin = static_cast<uint32_t*>(ctx->pinned);
+  MGF_HIP_TRY(hipMemcpyAsync(pin, w->mig_cnt.p, 4, hipMemcpyDeviceToHost, s));
+  MGF_HIP_TRY(hipStreamSynchronize(s));
+  if (pin[0]) return fail(MGF_ERR_INVALID, "remove_bodies: an id is out of range or listed twice");
+  const uint32_t n_new = n - (uint32_t)n_ids;
+  if (n_new) {
+    k_import_migrants<<<nblk((size_t)n_new * kMigrantWords), kBlock, 0, s>>>(w->bodies(), 0, n_new, w->mig_tmp.p);
+    LAUNCH_CHECK();
+  }
+  w->n_owned = w->n = n_new;
+  w->stats.n_bodies = n_new;
+  return sync_unless_ordered(w);
+}
+// Appends bodies exported by another world's mgf_world_export_migrants as owned bodies (ghosts are dropped).
+extern "C" mgf_status mgf_world_import_migrants(mgf_world* w, const float* src, int64_t n_in) {
+  if (!w || n_in < 0 || (n_in && !src)) return fail(MGF_ERR_INVALID, "bad argument");
+  MGF_TRY(ctx_bind(w->ctx));
+  w->n = w->n_owned;
+  w->constraints_ready = false;
+  if (n_in == 0) return MGF_OK;
+  size_t need = (size_t)w->n_owned + (size_t)n_in;
+  if (need > 0x7FFFFFF0ull) return fail(MGF_ERR_INVALID, "too many bodies");
+  MGF_TRY(grow_keep(w, w->x, 1, need)); MGF_TRY(grow_keep(w, w->q, 1, need)); MGF_TRY(grow_keep(w, w->srec, 4, need));
+  MGF_TRY(grow_keep(w, w->sp0, 1, need)); MGF_TRY(grow_keep(w, w->sp1, 1, need)); MGF_TRY(grow_keep(w, w->ctor, 1, need));
+  MGF_TRY(grow_keep(w, w->imb, 3, need)); MGF_TRY(grow_keep(w, w->delta, 1, need)); MGF_TRY(grow_keep(w, w->einfo, 1, need));
+  MGF_TRY(grow_keep(w, w->col0, 1, need)); MGF_TRY(grow_keep(w, w->col1, 1, need)); MGF_TRY(grow_keep(w, w->tb_c, 1, need));
+  MGF_TRY(grow_keep(w, w->tb_r, 1, need)); MGF_TRY(grow_keep(w, w->fb_c, 1, need)); MGF_TRY(grow_keep(w, w->fb_r, 1, need));
+  k_import_migrants<<<nblk((size_t)n_in * kMigrantWords), kBlock, 0, w->ctx->stream>>>(w->bodies(), w->n_owned, (uint32_t)n_in,
+                                                                                      reinterpret_cast<const float4*>(src));
+  LAUNCH_CHECK();
+  w->n_owned = w->n = (uint32_t)need;
+  w->stats.n_bodies = w->n_owned;
+  // the arrivals may be of a kind this tile has not seen yet (the narrowphase dispatch is chosen on the host)
+  MGF_TRY(w->mig_cnt.ensure(2, w->ctx->stream));
+  MGF_HIP_TRY(hipMemsetAsync(w->mig_cnt.p, 0, 8, w->ctx->stream));
+  k_kind_mask<<<nblk(n_in), kBlock, 0, w->ctx->stream>>>(w->col1.p, w->n_owned - (uint32_t)n_in, (uint32_t)n_in, w->mig_cnt.p);
+  LAUNCH_CHECK();
+  uint32_t mask = 0;
+  MGF_TRY(d2h(w->ctx, &mask, w->mig_cnt.p, 1));
+  if (mask & 1) w->has_sphere = true;
+  if (mask & 2) w->has_capsule = true;
+  return MGF_OK;
+}
+// A caller-defined 32-bit tag per body (kept in the constructor record, travels with a migrant): the tiles driver
+// stores the body's global id in it.
+extern "C" mgf_status mgf_world_set_tags(mgf_world* w, const uint32_t* tags, int64_t n) {
+  if (!w || (n && !tags)) return fail(MGF_ERR_INVALID, "NULL argument");
+  if ((uint64_t)n != (uint64_t)w->n_owned) return fail(MGF_ERR_INVALID, "one tag per owned body");
+  MGF_TRY(ctx_bind(w->ctx));
+  if (n == 0) return MGF_OK;
+  MGF_TRY(w->bflag_l.ensure((size_t)n + 1, w->ctx->stream));
+  MGF_TRY(h2d(w->ctx, w->bflag_l.p, tags, (size_t)n));
+  k_tags_set<<<nblk(n), kBlock, 0, w->ctx->stream>>>(w->ctor.p, w->bflag_l.p, (uint32_t)n);
+  LAUNCH_CHECK();
+  MGF_HIP_TRY(hipStreamSynchronize(w->ctx->stream));
+  return MGF_OK;
+}
+extern "C" mgf_status mgf_world_read_tags(mgf_world* w, uint32_t* tags, int64_t cap) {
+  if (!w || (cap && !tags)) return fail(MGF_ERR_INVALID, "NULL argument");
+  if ((uint64_t)cap < (uint64_t)w->n_owned) return fail(MGF_ERR_CAPACITY, "tag buffer too small");
+  MGF_TRY(ctx_bind(w->ctx));
+  const uint32_t n = w->n_owned;
+  if (n == 0) return MGF_OK;
+  MGF_TRY(w->bflag_l.ensure((size_t)n + 1, w->ctx->stream));
+  k_tags_get<<<nblk(n), kBlock, 0, w->ctx->stream>>>(w->ctor.p, w->bflag_l.p, n);
+  LAUNCH_CHECK();
+  return d2h(w->ctx, tags, w->bflag_l.p, (size_t)n);
 }
 extern "C" mgf_status mgf_world_export_velocities(mgf_world* w, const uint32_t* ids, int64_t n, float* dst) {
   if (!w || (n && (!ids || !dst))) return fail(MGF_ERR_INVALID, "NULL argument");

@@ -111,13 +111,17 @@ def sphere_pile(nx, ny, nz, seed=SEED, iters=10, shuffle=True, x_offset=0.0):
     return _scene(f"sphere_pile_{nx}x{ny}x{nz}", _spheres(c, 0.5), terrain, v0=v0, iters=iters)
 
 
-def sphere_pile_tile(nx, ny, nz, rank, world_size, seed=SEED, iters=10):
+def sphere_pile_tile(nx, ny, nz, rank, world_size, seed=SEED, iters=10, drift=None):
     """x-slab tile `rank` of a (world_size*nx) x ny x nz pile in ONE open box (BASELINE config 4 family;
     world_size == 1 is sphere_pile).  Tile r owns lattice columns [r*nx, (r+1)*nx); its bodies, jitter and
-    velocities come from per-tile SplitMix64 streams so every rank can build its own tile independently."""
+    velocities come from per-tile SplitMix64 streams so every rank can build its own tile independently.
+    `drift` = a velocity added to every body (tests: makes bodies cross slab faces); scene["tags"] = global body ids."""
     if world_size == 1:
         sc = sphere_pile(nx, ny, nz, seed=seed, iters=iters)
         sc["x_range"] = (-np.inf, np.inf)
+        if drift is not None:
+            sc["v0"] = (sc["v0"] + np.asarray(drift, np.float32)).astype(np.float32)
+        sc["tags"] = np.arange(nx * ny * nz, dtype=np.uint32)
         return sc
     n = nx * ny * nz
     gx = world_size * nx
@@ -129,9 +133,12 @@ def sphere_pile_tile(nx, ny, nz, rank, world_size, seed=SEED, iters=10):
     c = (base + jit).astype(np.float32)
     perm = seeded_permutation(seed, n, stream=st + 7)
     c, v0 = c[perm], v0[perm]
+    if drift is not None:
+        v0 = (v0 + np.asarray(drift, np.float32)).astype(np.float32)
     terrain = box_terrain(gx / 2.0 + 1.0, ny + 2.0, (0.0, 0.0, 0.0), half_z=nz / 2.0 + 1.0)
     sc = _scene(f"sphere_pile_tile{rank}of{world_size}_{nx}x{ny}x{nz}", _spheres(c, 0.5), terrain, v0=v0, iters=iters)
     sc["x_range"] = (rank * nx - gx / 2.0, (rank + 1) * nx - gx / 2.0)
+    sc["tags"] = (rank * n + np.arange(n)).astype(np.uint32)
     return sc
 
 

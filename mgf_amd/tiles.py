@@ -8,12 +8,18 @@ data path).  The tick on every tile:
     import_ghosts, collide          broadphase / narrowphase / ContactConstraint::new on owned + ghost
     iters/R x { solve(R); <-> neighbours: velocities of the exported bodies (8 floats each) }
     finish                          the one place the host waits for the solver (status, timings)
+    migrate (only when needed)      owned bodies whose centre left the slab: full records (80 floats) to the
+                                    neighbour, removed here, appended there - selected at the start of the tick
+                                    (the counts ride on the ghost count message), moved at its end
 
 Semantics (what the oracle's tile mode reproduces exactly): Gauss-Seidel inside a tile, ghost
 velocities refreshed from their owner after every R solver iterations (block-Jacobi across tiles);
 a constraint between bodies of two tiles exists on both tiles, each tile keeping the result for the
-body it owns.  Ownership is by initial slab; a body drifting past the halo raises (migration is
-future work).
+body it owns.  A body belongs to the tile whose slab [x_lo, x_hi) holds its centre: it is handed over
+at the end of the first tick that starts with the centre outside (so it spends at most that one tick on
+the wrong side, well inside the halo).  Arrivals are appended in the order left neighbour's, then right
+neighbour's; the remaining bodies keep their relative order.  Body identity across tiles is the 32-bit
+tag (`scene["tags"]`, default: the body's index in the tile's scene).
 
 Process set-up note: `import torch` must happen before the first mgf_amd.Context (torch ships its own
 libamdhip64 with the same soname as /opt/rocm's; the first one loaded serves the whole process).
@@ -28,6 +34,7 @@ from . import scenes
 
 GHOST_FLOATS = 36
 VEL_FLOATS = 8
+MIGRANT_FLOATS = 80
 # Solver iterations between two ghost velocity refreshes (1 = refresh after every iteration).  Measured on a
 # two-tile 6x6x6 pile after 60 ticks (tests/test_tiles_cpu.py::test_seam_quality_vs_refresh_interval): mean
 # resting penetration of the sphere pairs straddling the slab face 0.043 (R=1), 0.046 (R=2), 0.055 (R=10)
@@ -56,11 +63,21 @@ class HipEngine:
         self.stream = ctx.torch_stream
         self.world = World.from_scene(ctx, scene)
         self.world.set_option("stream_ordered", 1)
-        n = max(len(self.world), 1)
-        self.n_cap = n
-        with torch.cuda.stream(self.stream):
-            self.ids = torch.zeros(2 * n, dtype=torch.int32, device=self.device)  # [0:n] left face, [n:2n] right face
+        if scene.get("tags") is not None:
+            self.world.set_tags(scene["tags"])
+        self.n_cap = 0
+        self._ensure_ids()
         self.counts = (0, 0)
+        self.migrants = (0, 0)
+
+    def _ensure_ids(self):
+        """Id lists sized for the current body count: [0:cap] left face, [cap:2cap] right face, [2cap:3cap] migrants."""
+        n = len(self.world)
+        if n <= self.n_cap:
+            return
+        self.n_cap = n + n // 4 + 64
+        with self.torch.cuda.stream(self.stream):
+            self.ids = self.torch.zeros(3 * self.n_cap, dtype=self.torch.int32, device=self.device)
 
     def stream_ctx(self):
         return self.torch.cuda.stream(self.stream)
@@ -71,10 +88,38 @@ class HipEngine:
     def begin_tick(self, dt):
         self.world.begin_tick(dt)
 
-    def select_boundary(self, x_left, x_right):
+    def select_tile(self, x_left, x_right, x_lo, x_hi):
         p = self.ids.data_ptr()
-        self.counts = tuple(self.world.select_boundary(x_left, x_right, p, p + 4 * self.n_cap, self.n_cap))
-        return self.counts
+        c = self.world.select_tile(x_left, x_right, x_lo, x_hi, p, p + 4 * self.n_cap, p + 8 * self.n_cap, self.n_cap)
+        self.counts, self.migrants = c[:2], c[2:]
+        return c
+
+    def export_migrants(self):
+        m = sum(self.migrants)
+        out = self.alloc(m, MIGRANT_FLOATS)
+        if m:
+            self.world.export_migrants(self.ids.data_ptr() + 8 * self.n_cap, m, out.data_ptr())
+        return out
+
+    def apply_migration(self, arrivals):
+        """Drop the bodies selected by the last select_tile, append the neighbours' (left neighbour's first)."""
+        m = sum(self.migrants)
+        if m:
+            self.world.remove_bodies(self.ids.data_ptr() + 8 * self.n_cap, m)
+        if arrivals.shape[0]:
+            self._keep_m = arrivals
+            self.world.import_migrants(arrivals.data_ptr(), arrivals.shape[0])
+        self.migrants = (0, 0)
+        self._ensure_ids()
+
+    def kinds(self):
+        return self.world.counter("body_kinds")
+
+    def add_kinds(self, mask):
+        self.world.set_option("body_kinds", mask)
+
+    def tags(self):
+        return self.world.tags()
 
     def _export(self, fn, width):
         ml, mr = self.counts
@@ -131,26 +176,33 @@ class DistTransport:
             for r in self.dist.batch_isend_irecv(ops):
                 r.wait()  # RCCL: orders the current stream after the transfer, does not block the host
 
-    def exchange(self, send, split, width, alloc, recv_counts=None):
+    def exchange(self, send, split, width, alloc, recv_counts=None, extra=None):
         """`send` holds split[0] rows for the left neighbour followed by split[1] rows for the right one.
         Returns the rows received: the left neighbour's first.  recv_counts = (n_from_left, n_from_right)
-        when already known (velocity refresh: one row per ghost), which saves the count round-trip."""
+        when already known (velocity refresh: one row per ghost), which saves the count round-trip.
+        extra = (ints for the left neighbour, ints for the right one) rides on the count message; the
+        neighbours' are returned as a third value ((from left), (from right)), zeros where there is none."""
         torch, dist = self.torch, self.dist
         ml, mr = split
         if self.host_staging:
             out_alloc, alloc = alloc, (lambda rows, w: torch.empty((rows, w), dtype=torch.float32))
             send = send.cpu()
+        got_extra = None
         if recv_counts is None:
             dev = send.device
-            cnt_send = torch.tensor([ml, mr], dtype=torch.int64, device=dev)
-            cnt_recv = torch.zeros(2, dtype=torch.int64, device=dev)
+            xl, xr = (list(extra[0]), list(extra[1])) if extra is not None else ([], [])
+            k = 1 + len(xl)
+            cnt_send = torch.tensor([ml] + xl + [mr] + xr, dtype=torch.int64, device=dev)
+            cnt_recv = torch.zeros(2 * k, dtype=torch.int64, device=dev)
             ops = []
             if self.left is not None:
-                ops += [dist.P2POp(dist.isend, cnt_send[0:1], self.left), dist.P2POp(dist.irecv, cnt_recv[0:1], self.left)]
+                ops += [dist.P2POp(dist.isend, cnt_send[0:k], self.left), dist.P2POp(dist.irecv, cnt_recv[0:k], self.left)]
             if self.right is not None:
-                ops += [dist.P2POp(dist.isend, cnt_send[1:2], self.right), dist.P2POp(dist.irecv, cnt_recv[1:2], self.right)]
+                ops += [dist.P2POp(dist.isend, cnt_send[k:], self.right), dist.P2POp(dist.irecv, cnt_recv[k:], self.right)]
             self._batch(ops)
-            nl, nr = (int(v) for v in cnt_recv.tolist())
+            got = [int(v) for v in cnt_recv.tolist()]
+            nl, nr = got[0], got[k]
+            got_extra = (tuple(got[1:k]), tuple(got[k + 1:]))
         else:
             nl, nr = recv_counts
         recv = alloc(nl + nr, width)
@@ -170,18 +222,23 @@ class DistTransport:
             dev_recv = out_alloc(nl + nr, width)
             dev_recv.copy_(recv)
             recv = dev_recv
+        if extra is not None:
+            return recv, (nl, nr), got_extra
         return recv, (nl, nr)
 
 
 class Tile:
     """One tile's tick, split into phases so several tiles can also be stepped in one process."""
 
-    def __init__(self, engine, x_range, rank, world_size, dt, iters, halo=1.0, refresh_every=DEFAULT_REFRESH_EVERY):
+    def __init__(self, engine, x_range, rank, world_size, dt, iters, halo=1.0, refresh_every=DEFAULT_REFRESH_EVERY, migrate=True):
         self.e, self.rank, self.world_size = engine, rank, world_size
         self.x_lo, self.x_hi = x_range
         self.dt, self.iters, self.halo = float(dt), int(iters), float(halo)
         self.has_left, self.has_right = rank > 0, rank + 1 < world_size
         self.refresh_every = max(1, int(refresh_every))
+        self.migrate = bool(migrate)
+        self.mig_split = (0, 0)  # bodies leaving to the left / right at the end of this tick
+        self.n_migrated_out = self.n_migrated_in = 0
 
     def chunks(self):
         """Solver iterations between two ghost velocity refreshes: [R, R, ..., rest]."""
@@ -195,10 +252,28 @@ class Tile:
         """-> (rows for [left | right], (n_left, n_right))"""
         e = self.e
         e.begin_tick(self.dt)
-        x_left = self.x_lo + self.halo if self.has_left else -np.inf
-        x_right = self.x_hi - self.halo if self.has_right else np.inf
-        split = e.select_boundary(np.float32(max(x_left, -3.0e38)), np.float32(min(x_right, 3.0e38)))
-        return e.export_bodies(), split
+        big = 3.0e38
+        x_left = self.x_lo + self.halo if self.has_left else -big
+        x_right = self.x_hi - self.halo if self.has_right else big
+        x_lo = self.x_lo if (self.has_left and self.migrate) else -big
+        x_hi = self.x_hi if (self.has_right and self.migrate) else big
+        c = e.select_tile(np.float32(x_left), np.float32(x_right), np.float32(x_lo), np.float32(x_hi))
+        self.mig_split = tuple(c[2:])
+        return e.export_bodies(), tuple(c[:2])
+
+    def extra(self):
+        """What rides on the ghost count message: (migrants going that way, kinds of this tile's bodies)."""
+        k = self.e.kinds()
+        return [self.mig_split[0], k], [self.mig_split[1], k]
+
+    def phase_migrate_out(self):
+        return self.e.export_migrants()
+
+    def phase_migrate_in(self, arrivals):
+        self.n_migrated_out += sum(self.mig_split)
+        self.n_migrated_in += int(arrivals.shape[0])
+        self.e.apply_migration(arrivals)
+        self.mig_split = (0, 0)
 
     def phase_collide(self, ghosts):
         self.e.import_ghosts(ghosts)
@@ -220,7 +295,9 @@ def step_tile(tile, transport):
     e = tile.e
     with e.stream_ctx():
         send, split = tile.phase_begin()
-        ghosts, counts = transport.exchange(send, split, GHOST_FLOATS, e.alloc)
+        ghosts, counts, (from_l, from_r) = transport.exchange(send, split, GHOST_FLOATS, e.alloc, extra=tile.extra())
+        arriving = (from_l[0] if from_l else 0, from_r[0] if from_r else 0)
+        e.add_kinds((from_l[1] if from_l else 0) | (from_r[1] if from_r else 0))
         stats = dict(tile.phase_collide(ghosts))
         chunks = tile.chunks()
         for ci, k in enumerate(chunks):
@@ -229,6 +306,10 @@ def step_tile(tile, transport):
                 got, _ = transport.exchange(vel, split, VEL_FLOATS, e.alloc, recv_counts=counts)
                 tile.phase_refresh(got)
         fin = tile.phase_end()
+        if sum(tile.mig_split) or sum(arriving):  # both ends of a hand-over know it from the count message
+            out = tile.phase_migrate_out()
+            got, _ = transport.exchange(out, tile.mig_split, MIGRANT_FLOATS, e.alloc, recv_counts=arriving)
+            tile.phase_migrate_in(got)
     for k in ("solver_kernel_launches", "ms_solve", "ms_solver_kernels", "n_levels", "ms_total", "iters"):
         if k in fin:
             stats[k] = fin[k]
@@ -257,6 +338,9 @@ def _step_tiles_inprocess(tiles, torch):
     begun = [t.phase_begin() for t in tiles]
     sends, splits = [b[0] for b in begun], [b[1] for b in begun]
     cat = lambda parts: torch.cat(parts, dim=0)  # noqa: E731
+    kinds = [t.e.kinds() for t in tiles]
+    for r, t in enumerate(tiles):
+        t.e.add_kinds((kinds[r - 1] if r > 0 else 0) | (kinds[r + 1] if r + 1 < P else 0))
     stats = []
     for r, t in enumerate(tiles):
         stats.append(dict(t.phase_collide(_gather_rows(tiles, sends, splits, r, cat, t.e.alloc, GHOST_FLOATS))))
@@ -268,6 +352,11 @@ def _step_tiles_inprocess(tiles, torch):
                 t.phase_refresh(_gather_rows(tiles, vels, splits, r, cat, t.e.alloc, VEL_FLOATS))
     for r, t in enumerate(tiles):
         stats[r].update(t.phase_end())
+    msplits = [t.mig_split for t in tiles]
+    if any(sum(m) for m in msplits):
+        outs = [t.phase_migrate_out() for t in tiles]
+        for r, t in enumerate(tiles):
+            t.phase_migrate_in(_gather_rows(tiles, outs, msplits, r, cat, t.e.alloc, MIGRANT_FLOATS))
     return stats
 
 
@@ -275,7 +364,7 @@ class TiledWorld:
     """bench.py's view: this rank's tile of the BASELINE sphere-pile workload."""
 
     def __init__(self, ctx, rank, world_size, nx, ny, nz, iters=10, dist=None, device=0, seed=scenes.SEED, halo=1.0,
-                 host_staging=False, refresh_every=DEFAULT_REFRESH_EVERY):
+                 host_staging=False, refresh_every=DEFAULT_REFRESH_EVERY, migrate=True):
         self.rank, self.world_size, self.dist = rank, world_size, dist
         self.iters = iters
         self.scene = scenes.sphere_pile_tile(nx, ny, nz, rank, world_size, seed=seed, iters=iters)
@@ -288,7 +377,7 @@ class TiledWorld:
             import torch
             eng = HipEngine(ctx, self.scene, device)
             self.world = eng.world
-            self.tile = Tile(eng, self.scene["x_range"], rank, world_size, self.dt, iters, halo=halo, refresh_every=refresh_every)
+            self.tile = Tile(eng, self.scene["x_range"], rank, world_size, self.dt, iters, halo=halo, refresh_every=refresh_every, migrate=migrate)
             self.transport = DistTransport(dist, rank, world_size, host_staging=host_staging)
 
     def step(self):

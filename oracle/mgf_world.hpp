@@ -92,6 +92,7 @@ struct World {
   // their terrain contacts and ghost-ghost pairs belong to their owner tile.  Mirrors the HIP path's
   // mgf_world_import_ghosts & co. so the tiled algorithm has an exact CPU counterpart.
   size_t n_owned = 0;
+  std::vector<uint32_t> tags;  // caller-defined identity per owned body (travels with a migrant)
 
   // world.rs:178-184
   bool add_body(const Component& col, float mass, float rest, float fric, V3 world_force, size_t* id_out) {
@@ -101,6 +102,7 @@ struct World {
     size_t bvh_id = bvh.insert(b + fat_margin, id);
     bvh_ids.push_back(bvh_id);
     n_owned = bodies.len();
+    tags.resize(n_owned, 0u);
     if (id_out) *id_out = id;
     return true;
   }
@@ -113,6 +115,7 @@ struct World {
     b.torque.resize(n_owned); b.restitution.resize(n_owned); b.friction.resize(n_owned); b.inv_mass.resize(n_owned);
     b.inv_moment_body.resize(n_owned, m3_zero()); b.inv_moment.resize(n_owned, m3_zero());
     b.constructor.resize(n_owned); b.collider.resize(n_owned);
+    tags.resize(n_owned, 0u);
   }
   // record: x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction (36 floats)
   void add_ghost(const float* o) {
@@ -160,6 +163,83 @@ struct World {
       if (fb.c.x - fb.r.x < x_left) left->push_back((uint32_t)i);
       if (fb.c.x + fb.r.x > x_right) right->push_back((uint32_t)i);
     }
+  }
+
+  // ---- migration between tiles (not in the reference): an owned body whose centre leaves the slab
+  // [x_lo, x_hi) is handed to the neighbouring tile with its whole state, persistent fat box included.
+  // record (kMigrantFloats): the 36 floats of export_body | force3 | inv_moment_body9 | constructor kind,r,half_h |
+  // fat box c3 r3 | tag | zero padding.
+  static constexpr int kMigrantFloats = 80;
+  void select_migrants(float x_lo, float x_hi, std::vector<uint32_t>* left, std::vector<uint32_t>* right) const {
+    left->clear(); right->clear();
+    for (size_t i = 0; i < n_owned; ++i) {
+      const float cx = bodies.x[i].x;
+      if (cx < x_lo) left->push_back((uint32_t)i);
+      else if (cx >= x_hi) right->push_back((uint32_t)i);
+    }
+  }
+  void export_migrant(size_t i, float* o) const {
+    const RigidBodyVec& b = bodies;
+    for (int k = 0; k < kMigrantFloats; ++k) o[k] = 0.0f;
+    export_body(i, o);
+    o[36] = b.force[i].x; o[37] = b.force[i].y; o[38] = b.force[i].z;
+    for (int k = 0; k < 3; ++k) { o[39 + 3 * k] = b.inv_moment_body[i].c[k].x; o[40 + 3 * k] = b.inv_moment_body[i].c[k].y; o[41 + 3 * k] = b.inv_moment_body[i].c[k].z; }
+    uint32_t kind = (uint32_t)b.constructor[i].kind;
+    std::memcpy(&o[48], &kind, 4);
+    o[49] = b.constructor[i].r; o[50] = b.constructor[i].half_h;
+    const AABB& fb = bvh[bvh_ids[i]];
+    o[51] = fb.c.x; o[52] = fb.c.y; o[53] = fb.c.z; o[54] = fb.r.x; o[55] = fb.r.y; o[56] = fb.r.z;
+    std::memcpy(&o[57], &tags[i], 4);
+  }
+  // ids ascending, all owned; the remaining bodies keep their relative order (ghosts are dropped first)
+  void remove_bodies(const uint32_t* ids, size_t m) {
+    drop_ghosts();
+    if (m == 0) return;
+    RigidBodyVec& b = bodies;
+    size_t k = 0, out = 0;
+    for (size_t i = 0; i < n_owned; ++i) {
+      if (k < m && ids[k] == i) { bvh.remove(bvh_ids[i]); ++k; continue; }
+      if (out != i) {
+        b.x[out] = b.x[i]; b.q[out] = b.q[i]; b.v[out] = b.v[i]; b.omega[out] = b.omega[i]; b.force[out] = b.force[i];
+        b.torque[out] = b.torque[i]; b.restitution[out] = b.restitution[i]; b.friction[out] = b.friction[i]; b.inv_mass[out] = b.inv_mass[i];
+        b.inv_moment_body[out] = b.inv_moment_body[i]; b.inv_moment[out] = b.inv_moment[i];
+        b.constructor[out] = b.constructor[i]; b.collider[out] = b.collider[i];
+        bvh_ids[out] = bvh_ids[i];
+        tags[out] = tags[i];
+        bvh.pool[bvh_ids[out]].leaf = out;
+      }
+      ++out;
+    }
+    n_owned = out;
+    bvh_ids.resize(out);  // the tail holds stale copies of moved entries, not ghosts
+    drop_ghosts();        // truncates every body array to n_owned
+  }
+  void import_migrant(const float* o) {
+    drop_ghosts();
+    RigidBodyVec& b = bodies;
+    Component k;
+    uint32_t tag;
+    std::memcpy(&tag, &o[16], 4);
+    if (tag == 0u) k = component(Sphere{v3(o[17], o[18], o[19]), o[23]});
+    else k = component(Capsule{v3(o[17], o[18], o[19]), v3(o[20], o[21], o[22]), o[23]});
+    b.x.push_back(v3(o[0], o[1], o[2]));
+    b.q.push_back(Quat{o[3], v3(o[4], o[5], o[6])});
+    b.v.push_back(v3(o[7], o[8], o[9]));
+    b.omega.push_back(v3(o[10], o[11], o[12]));
+    b.force.push_back(v3(o[36], o[37], o[38])); b.torque.push_back(v3(0, 0, 0));
+    b.restitution.push_back(o[34]); b.friction.push_back(o[35]); b.inv_mass.push_back(o[24]);
+    b.inv_moment.push_back(m3_new(o[25], o[26], o[27], o[28], o[29], o[30], o[31], o[32], o[33]));
+    b.inv_moment_body.push_back(m3_new(o[39], o[40], o[41], o[42], o[43], o[44], o[45], o[46], o[47]));
+    uint32_t kind;
+    std::memcpy(&kind, &o[48], 4);
+    b.constructor.push_back(ComponentConstructor{(int)kind, o[49], o[50]});
+    b.collider.push_back(sweep(k, v3(o[13], o[14], o[15])));
+    size_t id = b.len() - 1;
+    bvh_ids.push_back(bvh.insert(AABB{v3(o[51], o[52], o[53]), v3(o[54], o[55], o[56])}, id));
+    n_owned = b.len();
+    uint32_t tg;
+    std::memcpy(&tg, &o[57], 4);
+    tags.push_back(tg);
   }
 
   // world.rs:228-231

@@ -169,6 +169,12 @@ def lib():
         L.mgfo_world_collide.argtypes = [C.c_void_p, C.c_float, P(Stats)]
         L.mgfo_world_select_boundary.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, P(C.c_int64), P(C.c_int64)]
         L.mgfo_world_export_bodies.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.mgfo_world_select_migrants.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, P(C.c_int64), P(C.c_int64)]
+        L.mgfo_world_export_migrants.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.mgfo_world_remove_bodies.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.mgfo_world_import_migrants.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.mgfo_world_set_tags.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.mgfo_world_read_tags.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.mgfo_world_import_ghosts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.mgfo_world_export_velocities.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mgfo_world_import_ghost_velocities.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -450,6 +456,40 @@ class World:
     def import_ghosts(self, recs):
         recs = np.ascontiguousarray(recs, np.float32).reshape(-1, 36)
         lib().mgfo_world_import_ghosts(self.h, recs.ctypes.data, len(recs))
+
+    # ---- migration of owned bodies between tiles ----
+    MIGRANT_FLOATS = 80
+
+    def select_migrants(self, x_lo, x_hi):
+        n = len(self)
+        l = np.zeros(max(n, 1), np.uint32)
+        r = np.zeros(max(n, 1), np.uint32)
+        nl, nr = C.c_int64(), C.c_int64()
+        lib().mgfo_world_select_migrants(self.h, x_lo, x_hi, l.ctypes.data, r.ctypes.data, n, C.byref(nl), C.byref(nr))
+        return l[:nl.value].copy(), r[:nr.value].copy()
+
+    def export_migrants(self, ids):
+        ids = np.ascontiguousarray(ids, np.uint32)
+        out = np.zeros((len(ids), self.MIGRANT_FLOATS), np.float32)
+        lib().mgfo_world_export_migrants(self.h, ids.ctypes.data, len(ids), out.ctypes.data)
+        return out
+
+    def remove_bodies(self, ids):
+        ids = np.ascontiguousarray(ids, np.uint32)
+        lib().mgfo_world_remove_bodies(self.h, ids.ctypes.data, len(ids))
+
+    def import_migrants(self, recs):
+        recs = np.ascontiguousarray(recs, np.float32).reshape(-1, self.MIGRANT_FLOATS)
+        lib().mgfo_world_import_migrants(self.h, recs.ctypes.data, len(recs))
+
+    def set_tags(self, tags):
+        tags = np.ascontiguousarray(tags, np.uint32)
+        lib().mgfo_world_set_tags(self.h, tags.ctypes.data, len(tags))
+
+    def tags(self):
+        out = np.zeros(max(len(self), 1), np.uint32)
+        lib().mgfo_world_read_tags(self.h, out.ctypes.data, len(out))
+        return out[:len(self)].copy()
 
     def export_velocities(self, ids):
         ids = np.ascontiguousarray(ids, np.uint32)

@@ -368,6 +368,29 @@ void mgfo_world_import_ghosts(void* wp, const float* in, int64_t n) {
   w->drop_ghosts();
   for (int64_t i = 0; i < n; ++i) w->add_ghost(in + 36 * i);
 }
+void mgfo_world_select_migrants(void* wp, float x_lo, float x_hi, uint32_t* ids_l, uint32_t* ids_r, int64_t cap, int64_t* nl, int64_t* nr) {
+  std::vector<uint32_t> l, r;
+  ((World*)wp)->select_migrants(x_lo, x_hi, &l, &r);
+  *nl = (int64_t)l.size(); *nr = (int64_t)r.size();
+  for (size_t i = 0; i < l.size() && (int64_t)i < cap; ++i) ids_l[i] = l[i];
+  for (size_t i = 0; i < r.size() && (int64_t)i < cap; ++i) ids_r[i] = r[i];
+}
+int64_t mgfo_migrant_floats() { return World::kMigrantFloats; }
+void mgfo_world_export_migrants(void* wp, const uint32_t* ids, int64_t n, float* out) {
+  for (int64_t i = 0; i < n; ++i) ((World*)wp)->export_migrant(ids[i], out + World::kMigrantFloats * i);
+}
+void mgfo_world_remove_bodies(void* wp, const uint32_t* ids, int64_t n) { ((World*)wp)->remove_bodies(ids, (size_t)n); }
+void mgfo_world_import_migrants(void* wp, const float* in, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) ((World*)wp)->import_migrant(in + World::kMigrantFloats * i);
+}
+void mgfo_world_set_tags(void* wp, const uint32_t* t, int64_t n) {
+  World* w = (World*)wp;
+  for (int64_t i = 0; i < n && (size_t)i < w->n_owned; ++i) w->tags[i] = t[i];
+}
+void mgfo_world_read_tags(void* wp, uint32_t* t, int64_t cap) {
+  World* w = (World*)wp;
+  for (size_t i = 0; i < w->n_owned && (int64_t)i < cap; ++i) t[i] = w->tags[i];
+}
 void mgfo_world_export_velocities(void* wp, const uint32_t* ids, int64_t n, float* out) {
   World* w = (World*)wp;
   for (int64_t i = 0; i < n; ++i) {

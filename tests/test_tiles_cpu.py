@@ -15,10 +15,10 @@ from tests.util import oracle_world, rel_err
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def make_tiles(nx, ny, nz, P, engine=OracleEngine, **kw):
+def make_tiles(nx, ny, nz, P, engine=OracleEngine, drift=None, **kw):
     tiles = []
     for r in range(P):
-        sc = scenes.sphere_pile_tile(nx, ny, nz, r, P)
+        sc = scenes.sphere_pile_tile(nx, ny, nz, r, P, drift=drift)
         tiles.append(Tile(engine(sc), sc["x_range"], r, P, sc["dt"], sc["iters"], **kw))
     return tiles
 
@@ -127,18 +127,102 @@ def test_seam_quality_vs_refresh_interval():
     assert rows[1][0] < 1.25 * rows[1][1]
 
 
+DRIFT = (5.0, 0.0, 0.0)  # 0.083 per tick to the right: whole lattice columns change tile within a few dozen ticks
+
+
+def _by_tag(tiles, key):
+    tags = np.concatenate([t.e.tags() for t in tiles])
+    vals = np.concatenate([t.e.state()[key] for t in tiles])
+    assert len(np.unique(tags)) == len(tags)
+    return vals[np.argsort(tags)]
+
+
+def test_migration_hands_bodies_to_the_tile_that_holds_them():
+    """Bodies drifting to the right change owner when their centre crosses a slab face: nothing is lost or
+    duplicated, every body is owned by the tile that holds it (one tick of lag at most), identity (tag)
+    and state travel along, and the tiled run keeps tracking the undivided world."""
+    P, nx, ny, nz, ticks = 3, 3, 3, 4, 36
+    tiles = make_tiles(nx, ny, nz, P, drift=DRIFT)
+    scs = [scenes.sphere_pile_tile(nx, ny, nz, r, P, drift=DRIFT) for r in range(P)]
+    merged = dict(scs[0])
+    for key in ("comps", "mass", "restitution", "friction", "force", "v0"):
+        merged[key] = np.concatenate([s[key] for s in scs])
+    ow = oracle_world(merged)
+    n_total = P * nx * ny * nz
+    lag = 0.0
+    for tick in range(ticks):
+        step_tiles_inprocess(tiles)
+        ow.step(float(merged["dt"]), merged["iters"])
+        assert sum(len(t.e.w) for t in tiles) == n_total
+        for t in tiles:
+            x = t.e.state()["x"][:, 0]
+            if len(x):
+                lo = t.x_lo if t.has_left else -np.inf
+                hi = t.x_hi if t.has_right else np.inf
+                lag = max(lag, float(np.max(np.maximum(lo - x, x - hi))))
+    moved_out = [t.n_migrated_out for t in tiles]
+    moved_in = [t.n_migrated_in for t in tiles]
+    print(f"migrated out {moved_out} in {moved_in}, bodies per tile {[len(t.e.w) for t in tiles]}, worst lag {lag:.3f}")
+    assert sum(moved_out) == sum(moved_in) >= nx * ny  # at least a lattice layer's worth changed owner
+    assert moved_in[0] == 0 or moved_out[0] > 0        # the drift is to the right
+    assert moved_in[1] > 0 and moved_out[1] > 0        # the middle tile both receives and hands over
+    assert lag < 0.25                                  # a body is on the wrong side for at most the tick it crossed in
+    assert np.array_equal(np.sort(np.concatenate([t.e.tags() for t in tiles])), np.arange(n_total))
+    whole = ow.state()
+    dx, dv = rel_err(_by_tag(tiles, "x"), whole["x"]), rel_err(_by_tag(tiles, "v"), whole["v"])
+    # A pile hitting the box wall at 5 m/s is chaotic: the tiled and the undivided iteration drift apart smoothly with
+    # or without hand-overs (x deviation 0.11 after 40 ticks without drift, 0.34 with); what a lost or duplicated
+    # contact would show is bodies sinking into each other, so the overlap depth is the check.
+    from scipy.spatial import cKDTree
+
+    def worst_overlap(x):
+        x = x.astype(np.float64)
+        pairs = cKDTree(x).query_pairs(1.0, output_type="ndarray")
+        return float((1.0 - np.linalg.norm(x[pairs[:, 0]] - x[pairs[:, 1]], axis=1)).max())
+    ov_t, ov_w = worst_overlap(_by_tag(tiles, "x")), worst_overlap(whole["x"])
+    print(f"with migration after {ticks} ticks: deviation x {dx:.3e} v {dv:.3e}; worst sphere overlap tiled {ov_t:.3f} undivided {ov_w:.3f}")
+    assert dx < 0.6 and np.isfinite(dv)
+    assert ov_t < 1.5 * ov_w + 0.03
+
+
+def test_migrant_record_round_trip_is_exact():
+    """export -> remove -> import on the same world restores every body array bit for bit (the order changes:
+    removed bodies are re-appended), and the next ticks equal an untouched copy's, body by body."""
+    sc = scenes.sphere_pile_tile(4, 3, 4, 0, 1)
+    a, b = oracle_world(sc), oracle_world(sc)
+    for w in (a, b):
+        w.set_tags(np.arange(len(w), dtype=np.uint32))
+        for _ in range(3):
+            w.step(float(sc["dt"]), sc["iters"])
+    ids = np.array([0, 5, 6, 17, len(a) - 1], np.uint32)
+    rec = a.export_migrants(ids)
+    a.remove_bodies(ids)
+    assert len(a) == len(b) - len(ids)
+    a.import_migrants(rec)
+    order = np.argsort(a.tags())
+    assert np.array_equal(a.tags()[order], b.tags())
+    for k, v in b.state().items():
+        assert np.array_equal(a.state()[k][order], v), k
+    for _ in range(3):
+        a.step(float(sc["dt"]), sc["iters"])
+        b.step(float(sc["dt"]), sc["iters"])
+    # constraint order changed with the body order, so the Gauss-Seidel result differs in the last bits only
+    assert rel_err(a.state()["x"][order], b.state()["x"]) < 1e-3
+
+
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("ws", [2, 3])
-def test_gloo_ranks_match_inprocess_tiles(tmp_path, ws):
+@pytest.mark.parametrize("ws,drift", [(2, None), (3, None), (3, DRIFT)])
+def test_gloo_ranks_match_inprocess_tiles(tmp_path, ws, drift):
     """world_size 2 and 3 over gloo (real point-to-point transport; with 3 ranks the middle one talks to both sides)
-    == the in-process tile loop, bit for bit."""
-    nx, ny, nz, ticks = 5, 4, 5, 6
+    == the in-process tile loop, bit for bit - with bodies changing tile in the drift case."""
+    nx, ny, nz, ticks = (5, 4, 5, 6) if drift is None else (3, 3, 4, 30)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=ROOT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ws}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29515 + ws), os.path.join(ROOT, "tests", "tile_worker.py"), str(tmp_path), str(nx), str(ny), str(nz), str(ticks)]
+           "--master-port", str(29515 + ws + (10 if drift else 0)), os.path.join(ROOT, "tests", "tile_worker.py"), str(tmp_path), str(nx), str(ny),
+           str(nz), str(ticks), str(drift[0] if drift else 0.0)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    tiles = make_tiles(nx, ny, nz, ws)
+    tiles = make_tiles(nx, ny, nz, ws, drift=drift)
     ncons = [[] for _ in range(ws)]
     for _ in range(ticks):
         for k, s in enumerate(step_tiles_inprocess(tiles)):
@@ -147,5 +231,8 @@ def test_gloo_ranks_match_inprocess_tiles(tmp_path, ws):
         got = np.load(tmp_path / f"rank{rank}.npz")
         want = tiles[rank].e.state()
         assert got["ncons"].tolist() == ncons[rank]
+        assert np.array_equal(got["tags"], tiles[rank].e.tags())
         for k in want:
             assert np.array_equal(got[k], want[k]), f"rank {rank} {k}"
+    if drift is not None:
+        assert sum(t.n_migrated_in for t in tiles) > 0

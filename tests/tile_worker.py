@@ -17,16 +17,17 @@ from tests.oracle_engine import OracleEngine  # noqa: E402
 
 def main():
     out_dir, nx, ny, nz, ticks = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    drift = float(sys.argv[6]) if len(sys.argv) > 6 else 0.0
     dist.init_process_group(backend="gloo")
     rank, ws = dist.get_rank(), dist.get_world_size()
-    scene = scenes.sphere_pile_tile(nx, ny, nz, rank, ws)
+    scene = scenes.sphere_pile_tile(nx, ny, nz, rank, ws, drift=(drift, 0.0, 0.0) if drift else None)
     tile = Tile(OracleEngine(scene), scene["x_range"], rank, ws, scene["dt"], scene["iters"])
     tr = DistTransport(dist, rank, ws)
     ncons = []
     for _ in range(ticks):
         ncons.append(step_tile(tile, tr)["n_constraints"])
     s = tile.e.state()
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ncons=np.asarray(ncons), **s)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ncons=np.asarray(ncons), tags=tile.e.tags(), **s)
     dist.barrier()
     dist.destroy_process_group()
 
