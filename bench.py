@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--solver-mode", type=int, default=None, help="override the library's default solver mode (development)")
     ap.add_argument("--refresh-every", type=int, default=None, help="solver iterations between ghost velocity refreshes (multi-GPU; default: mgf_amd.tiles.DEFAULT_REFRESH_EVERY)")
+    ap.add_argument("--no-migrate", action="store_true", help="multi-GPU: keep every body on its initial tile (development: cost of the hand-over check)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo = host-staged exchange, for validating the multi-rank flow on one GPU")
     args = ap.parse_args()
@@ -68,7 +69,7 @@ def main():
     nx, ny, nz = args.tile
     ctx = mgf_amd.Context(dev_index)
     tw = TiledWorld(ctx, rank, world_size, nx, ny, nz, iters=args.iters, dist=dist, device=dev_index,
-                    host_staging=(args.backend == "gloo"), refresh_every=refresh_every)
+                    host_staging=(args.backend == "gloo"), refresh_every=refresh_every, migrate=not args.no_migrate)
     red_dev = "cuda" if args.backend == "nccl" else "cpu"
     dt = tw.dt
 
@@ -144,7 +145,7 @@ def main():
                                    + ("" if world_size == 1 else f"; {world_size} x-slab tiles side by side, ghost halo over RCCL"),
                        "bodies_per_gpu": nx * ny * nz, "bodies_total": nx * ny * nz * world_size, "iters": args.iters,
                        "dt": dt, "constraint_order": "canonical (i asc; terrain DFS; partners j<i asc)",
-                       "parallelism": "1 GPU" if world_size == 1 else f"{world_size} spatial x-slabs, neighbour halo exchange (ghost bodies once per tick, ghost velocities every {refresh_every} solver iterations)"},
+                       "parallelism": "1 GPU" if world_size == 1 else f"{world_size} spatial x-slabs, neighbour halo exchange (ghost bodies once per tick, ghost velocities every {refresh_every} solver iterations, bodies handed to the tile that holds their centre" + ("" if not args.no_migrate else " - DISABLED") + ")"},
             "physics_steps_per_sec": args.steps / elapsed,
             "constraints_per_step": cons_all / args.steps,
             "solver_levels_mean": float(np.mean(levels)), "solver_launches_per_step": launches / args.steps,

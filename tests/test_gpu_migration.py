@@ -134,6 +134,40 @@ def test_migrant_round_trip_on_one_world(ctx):
         assert values_equal(g[k], o[k]), f"{k}: rel err {rel_err(g[k], o[k])}"
 
 
+@pytest.mark.timeout(300)
+def test_three_ranks_on_one_gpu_match_oracle_tiles(tmp_path):
+    """step_tile over a real transport (3 gloo ranks, payloads staged through the host, every rank's tile on GPU 0),
+    with bodies changing tile: each rank's result equals the oracle's in-process tile loop bit for bit."""
+    import os
+    import subprocess
+    import sys
+    from mgf_amd import scenes
+    from mgf_amd.tiles import Tile, step_tiles_inprocess
+    from tests.oracle_engine import OracleEngine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ws, nx, ny, nz, ticks = 3, 4, 4, 5, 30
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ws}", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "tests", "tile_worker.py"), str(tmp_path), str(nx), str(ny), str(nz), str(ticks),
+           str(DRIFT[0]), "hip"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    scs = [scenes.sphere_pile_tile(nx, ny, nz, k, ws, drift=DRIFT) for k in range(ws)]
+    ot = [Tile(OracleEngine(sc), sc["x_range"], k, ws, sc["dt"], sc["iters"]) for k, sc in enumerate(scs)]
+    ncons = [[] for _ in range(ws)]
+    for _ in range(ticks):
+        for k, s in enumerate(step_tiles_inprocess(ot)):
+            ncons[k].append(s["n_constraints"])
+    assert sum(t.n_migrated_in for t in ot) > 0
+    for rank in range(ws):
+        got = np.load(tmp_path / f"rank{rank}.npz")
+        assert got["ncons"].tolist() == ncons[rank]
+        assert np.array_equal(got["tags"], ot[rank].e.tags())
+        want = ot[rank].e.state()
+        for k in STATE_KEYS:
+            assert values_equal(got[k], want[k]), f"rank {rank} {k}"
+
+
 def test_remove_bodies_rejects_bad_ids(ctx):
     import torch
     import mgf_amd
