@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--solver-mode", type=int, default=None, help="override the library's default solver mode (development)")
     ap.add_argument("--refresh-every", type=int, default=None, help="solver iterations between ghost velocity refreshes (multi-GPU; default: mgf_amd.tiles.DEFAULT_REFRESH_EVERY)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="library option for an experiment (mgf_world_set_option), repeatable")
     ap.add_argument("--no-migrate", action="store_true", help="multi-GPU: keep every body on its initial tile (development: cost of the hand-over check)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo = host-staged exchange, for validating the multi-rank flow on one GPU")
@@ -80,6 +81,9 @@ def main():
 
     if args.solver_mode is not None:
         tw.world.set_option("solver_mode", args.solver_mode)
+    for kv in args.opt:
+        key, val = kv.split("=")
+        tw.world.set_option(key, int(val))
     # HIP events around the dominant kernel (k_solve_flow) on the stream it is launched on, inside the timed region
     tw.world.set_option("time_solver_kernels", 1)
     for _ in range(args.warmup):

@@ -1348,13 +1348,43 @@ __device__ __forceinline__ void store_vel_sc1(__amdgpu_buffer_rsrc_t r, uint32_t
   __builtin_amdgcn_raw_buffer_store_b64(b, r, (int)(i * 64u + 16u), 0, kSc1);
 }
 
+// the same by byte offset (an offset beyond the buffer's range reads zeros / drops the store: used for "no global body")
+__device__ __forceinline__ BodyDyn load_dyn_off_sc1(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+  v4f_t s0 = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, kSc1);
+  v4f_t s1 = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off + 16u), 0, kSc1);
+  v4f_t s2 = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off + 32u), 0, kSc1);
+  v4f_t s3 = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off + 48u), 0, kSc1);
+  BodyDyn d;
+  d.v = mk3(s0.x, s0.y, s0.z); d.w = mk3(s0.w, s1.x, s1.y); d.im = s1.z;
+  d.I = m3_cols(mk3(s1.w, s2.x, s2.y), mk3(s2.z, s2.w, s3.x), mk3(s3.y, s3.z, s3.w));
+  return d;
+}
+__device__ __forceinline__ void store_vel_off_sc1(__amdgpu_buffer_rsrc_t r, uint32_t off, const BodyDyn& d) {
+  v4f_t a = {d.v.x, d.v.y, d.v.z, d.w.x};
+  v2f_t b = {d.w.y, d.w.z};
+  __builtin_amdgcn_raw_buffer_store_b128(a, r, (int)off, 0, kSc1);
+  __builtin_amdgcn_raw_buffer_store_b64(b, r, (int)(off + 16u), 0, kSc1);
+}
+__device__ __forceinline__ V3 sel3(bool c, V3 a, V3 b) { return mk3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+__device__ __forceinline__ BodyDyn select_dyn(bool c, const BodyDyn& a, const BodyDyn& b) {
+  BodyDyn d;
+  d.v = sel3(c, a.v, b.v); d.w = sel3(c, a.w, b.w); d.im = c ? a.im : b.im;
+  d.I = m3_cols(sel3(c, a.I.c[0], b.I.c[0]), sel3(c, a.I.c[1], b.I.c[1]), sel3(c, a.I.c[2], b.I.c[2]));
+  return d;
+}
+
 // arr[c] = 2 - (weighted predecessors inside iteration 0): node (c, 0) is ready at arr >= 2.
-__global__ __launch_bounds__(kBlock) void k_flow_init(const uint32_t* C_ptr, ConsLinks K, uint32_t* arr, uint32_t* abort_flag) {
+__global__ __launch_bounds__(kBlock) void k_flow_init(const uint32_t* C_ptr, ConsLinks K, uint32_t* arr, uint32_t* abort_flag, const uint32_t* rw,
+                                                       uint32_t* arr5) {
   uint32_t c = blockIdx.x * kBlock + threadIdx.x;
   if (c == 0) *abort_flag = 0;
   if (c >= *C_ptr) return;
   uint32_t d0 = links_indeg0(K, c);
   arr[c] = 2u - d0 * (K.ab[c].y != kNone ? 1u : 2u);
+  if (rw) {  // block-local solver: arrivals from other blocks, scaled to 2 per iteration; iteration 0 has the wrap edges' credit
+    uint32_t w = rw[c] & 3u, nw = (rw[c] >> 2) & 3u;
+    arr5[c] = w ? 2u - nw * (2u / w) : 0u;
+  }
 }
 
 template <bool TRACE>
@@ -1525,11 +1555,15 @@ constexpr uint32_t kF5LdsWide = 16u * kF5MaxFast + 5u * kF5MaxCons + 2u * (kF5Ma
 constexpr uint32_t kF5LdsNarrow = 25u * kF5NarrowCons + 2u * 2u * 4096u + 64u;
 constexpr uint32_t kRefGlobal = 0x80000000u;              // body ref: bit 31 = global id (sc1 path), else LDS index; kNone = static
 constexpr uint32_t kSuccLocal = 0x20000000u;              // successor word: low bits are a block-local slot
+constexpr uint32_t kRefHasLocal = 0x40000000u;            // a-ref of a class-1 slot: one of its two predecessors is in-block
+constexpr uint32_t kF5RemoteDone = 0x100u;                // class-1 LDS counter: the arrivals from other blocks are in (set by the poller)
 struct Flow5 {
   const uint32_t* sidx;    // cell-ordered body ids
   const uint32_t* brank;   // body -> position in cell order
   uint8_t* shared;         // body touched by constraints of two blocks
-  uint8_t* gcnt;           // constraint has a predecessor in another block: global arrival counter
+  uint32_t* gcnt;          // per constraint: weight of its predecessors in OTHER blocks (bits 0-1: per iteration, 2 in total with the
+                           // in-block ones; bits 2-3: those that arrive inside iteration 0).  Non-zero = class 1.
+  uint32_t* arr5;          // class 1: arrivals from other blocks, scaled to 2 per iteration (in-block arrivals count in LDS)
   uint32_t* lslot;         // constraint -> (class << 12) | index inside its block's class
   uint32_t* wg_cnt;        // per block and class k (0 all-LDS, 1 global counter, 2 LDS counter + shared body): f5_cnt(F, g, k),
                            // one 128-byte line per counter (same-line atomics serialise)
@@ -1544,6 +1578,7 @@ struct Flow5 {
   uint32_t nb, nblocks, n;
   uint32_t cap_fast, cap_slow, cap_all;  // limits of the chosen layout
   uint32_t slow_x2;        // waves serving the slow queue = slow share of the slots x slow_x2 / 2 (tuning knob, 3)
+  uint32_t poller;         // 1: the last slow wave only polls the global counters (all of them), the others only serve
 };
 __device__ __forceinline__ uint32_t f5_ref(const Flow5& F, uint32_t g, uint32_t body) {
   if (body == kNone) return kNone;
@@ -1564,11 +1599,15 @@ __global__ __launch_bounds__(kBlock) void k_flow5_mark(Flow5 F, ConsLinks K, con
   uint32_t ga = F.brank[e.x] / F.nb;
   if (e.y != kNone && F.brank[e.y] / F.nb != ga) F.shared[e.y] = 1;
   uint2 sw = K.succ[c];
-  uint32_t s0 = sw.x & kSuccId;
-  if (F.brank[K.ab[s0].x] / F.nb != ga) F.gcnt[s0] = 1;
-  if (e.y != kNone) {
-    uint32_t s1 = sw.y & kSuccId;
-    if (F.brank[K.ab[s1].x] / F.nb != ga) F.gcnt[s1] = 1;
+  uint32_t w[2] = {sw.x, sw.y};
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    if (side == 1 && e.y == kNone) break;
+    uint32_t sid = w[side] & kSuccId;
+    if (F.brank[K.ab[sid].x] / F.nb != ga) {
+      uint32_t add = (w[side] & kSuccTwo) ? 1u : 2u;
+      atomicAdd(&F.gcnt[sid], add | ((w[side] & kSuccWrap) ? 0u : add << 2));
+    }
   }
 }
 
@@ -1600,18 +1639,21 @@ __global__ __launch_bounds__(kBlock) void k_flow5_table(Flow5 F, ConsLinks K, co
   }
   uint32_t slot = f5_slot(F, g, F.lslot[c]);
   size_t row = (size_t)g * kF5MaxCons + slot;
+  const uint32_t rw = F.gcnt[c] & 3u, rnw = (F.gcnt[c] >> 2) & 3u;
   F.t_c[row] = c;
-  F.t_aref[row] = f5_ref(F, g, e.x);
+  F.t_aref[row] = f5_ref(F, g, e.x) | (rw == 1u ? kRefHasLocal : 0u);
   F.t_bref[row] = f5_ref(F, g, e.y);
-  F.t_cnt0[row] = 2u - links_indeg0(K, c) * (e.y != kNone ? 1u : 2u);
+  // the LDS counter counts in-block arrivals only: iteration 0 starts with the credit of the in-block wrap edges
+  F.t_cnt0[row] = 2u - (links_indeg0(K, c) * (e.y != kNone ? 1u : 2u) - rnw);
   uint2 sw = K.succ[c];
   uint32_t w[2] = {sw.x, sw.y};
 #pragma unroll
   for (int side = 0; side < 2; ++side) {
     if (side == 1 && e.y == kNone) { w[1] = 0u; break; }
     uint32_t sid = w[side] & kSuccId;
-    bool local = F.brank[K.ab[sid].x] / F.nb == g && !F.gcnt[sid];
+    bool local = F.brank[K.ab[sid].x] / F.nb == g;
     if (local) w[side] = (w[side] & (kSuccTwo | kSuccWrap)) | kSuccLocal | f5_slot(F, g, F.lslot[sid]);
+    else if ((F.gcnt[sid] & 3u) == 1u) w[side] &= ~kSuccTwo;  // its only arrival from outside counts 2 in arr5 (2 per iteration, uniformly)
   }
   F.t_succ[row] = make_uint2(w[0], w[1]);
 }
@@ -1639,9 +1681,9 @@ __device__ __forceinline__ void f5_push(const F5Queue& q, uint32_t slot) {
   q.ring[pos % q.cap] = (uint16_t)(slot | 0x8000u);
 }
 
-template <bool WIDE>
+template <bool WIDE, bool TRACE>
 __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* cons, ConsLinks K, Flow5 F, uint32_t* arr, uint32_t iters,
-                                                            uint32_t* abort_flag, uint32_t spin_limit) {
+                                                            uint32_t* abort_flag, uint32_t spin_limit, uint64_t* trace, uint32_t C_trace) {
   if (*F.fail) return;  // a block did not fit: the stand-by k_solve_flow launch behind this one does the work
   constexpr uint32_t kMeta = WIDE ? kF5MaxFast : kF5NarrowCons;   // slots with constants in LDS
   constexpr uint32_t kAll = WIDE ? kF5MaxCons : kF5NarrowCons;    // slots with counters in LDS
@@ -1663,6 +1705,7 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
   const uint32_t g = blockIdx.x, t = threadIdx.x;
   const uint32_t p_lo = g * F.nb, p_hi = min(F.n, p_lo + F.nb);
   __amdgpu_buffer_rsrc_t rs = make_rsrc(srec);
+  uint32_t* const arr5 = F.arr5;
   for (uint32_t p = p_lo + t; p < p_hi; p += kF5Threads) {
     uint32_t x = F.sidx[p];
 #pragma unroll
@@ -1699,39 +1742,68 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
   if (nslow > nwaves) nslow = nwaves;
   const bool slow_wave = wave >= nwaves - nslow;
   const F5Queue& q = slow_wave ? qs : qf;
-  const uint32_t poll_lanes = nslow * 64u, poll_id = (wave - (nwaves - nslow)) * 64u + lane;
+  // who polls the global counters: every slow wave a share (between its serving trips), or one wave that does nothing else
+  const bool poller_wave = F.poller != 0u && nslow >= 2u && wave == nwaves - 1u;
+  const bool polls = (F.poller != 0u && nslow >= 2u) ? poller_wave : slow_wave;
+  const uint32_t poll_lanes = poller_wave ? 64u : nslow * 64u, poll_id = poller_wave ? lane : (wave - (nwaves - nslow)) * 64u + lane;
   // wide layout: a polling lane keeps the constraint ids of its first slots in registers (they index the global counters)
   constexpr int kPollCache = WIDE ? 6 : 1;
   uint32_t pc[kPollCache];
 #pragma unroll
   for (int k = 0; k < kPollCache; ++k) {
     uint32_t idx = N0 + poll_id + (uint32_t)k * poll_lanes;
-    pc[k] = (WIDE && slow_wave && idx < N01) ? F.t_c[row0 + idx] : 0u;
+    pc[k] = (WIDE && polls && idx < N01) ? F.t_c[row0 + idx] : 0u;
   }
   uint32_t spins = 0;
   for (;;) {
     if (__hip_atomic_load(s_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
-    if (slow_wave) {  // global counters that reached their iteration's threshold: queue the slot (once)
+    if (polls) {  // global counters that reached their iteration's threshold: queue the slot (once)
+      // The counter loads of a sweep are issued back to back and tested afterwards: one memory round trip per
+      // batch instead of one per slot (a slot that needs no look this sweep reads arr[0], harmlessly).
       if (WIDE) {
+        uint32_t r[kPollCache], av[kPollCache];
 #pragma unroll
         for (int k = 0; k < kPollCache; ++k) {
           uint32_t idx = N0 + poll_id + (uint32_t)k * poll_lanes;
-          if (idx < N01) {
-            uint32_t r = s_round[idx];
-            if (r < iters) {
-              uint32_t av = __hip_atomic_load(&arr[pc[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (av >= 2u * (r + 1u)) { s_round[idx] = (uint8_t)(r | 0x80u); f5_push(qs, idx); }
-            }
+          r[k] = idx < N01 ? s_round[idx] : 0xFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < kPollCache; ++k)
+          av[k] = __hip_atomic_load(&arr5[r[k] < iters ? pc[k] : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < kPollCache; ++k) {
+          uint32_t idx = N0 + poll_id + (uint32_t)k * poll_lanes;
+          if (r[k] < iters && av[k] >= 2u * (r[k] + 1u)) {  // the outside arrivals of this round are in: say so once
+            s_round[idx] = (uint8_t)(r[k] | 0x80u);
+            uint32_t old = __hip_atomic_fetch_add(&s_cnt[idx], kF5RemoteDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old == 2u) f5_push(qs, idx);  // the in-block ones too
           }
         }
       }
-      for (uint32_t idx = N0 + poll_id + (WIDE ? (uint32_t)kPollCache * poll_lanes : 0u); idx < N01; idx += poll_lanes) {
-        uint32_t r = s_round[idx];
-        if (r < iters) {
-          uint32_t cid = WIDE ? F.t_c[row0 + idx] : s_c[idx];
-          uint32_t av = __hip_atomic_load(&arr[cid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (av >= 2u * (r + 1u)) { s_round[idx] = (uint8_t)(r | 0x80u); f5_push(qs, idx); }
+      constexpr int kPB = 4;
+      for (uint32_t base = N0 + poll_id + (WIDE ? (uint32_t)kPollCache * poll_lanes : 0u); base < N01; base += kPB * poll_lanes) {
+        uint32_t r[kPB], off[kPB], av[kPB];
+#pragma unroll
+        for (int k = 0; k < kPB; ++k) {
+          uint32_t idx = base + (uint32_t)k * poll_lanes;
+          r[k] = idx < N01 ? s_round[idx] : 0xFFu;
+          off[k] = r[k] < iters ? (WIDE ? F.t_c[row0 + idx] : s_c[idx]) : 0u;
         }
+#pragma unroll
+        for (int k = 0; k < kPB; ++k) av[k] = __hip_atomic_load(&arr5[off[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < kPB; ++k) {
+          uint32_t idx = base + (uint32_t)k * poll_lanes;
+          if (r[k] < iters && av[k] >= 2u * (r[k] + 1u)) {  // the outside arrivals of this round are in: say so once
+            s_round[idx] = (uint8_t)(r[k] | 0x80u);
+            uint32_t old = __hip_atomic_fetch_add(&s_cnt[idx], kF5RemoteDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (old == 2u) f5_push(qs, idx);  // the in-block ones too
+          }
+        }
+      }
+      if (poller_wave) {  // never serves; leaves with the others
+        if ((++spins & 1023u) == 0u && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        continue;
       }
     }
     // take up to 64 ready nodes
@@ -1751,31 +1823,71 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
       if (lane < take) {
         uint16_t* cell = &q.ring[(h + lane) % q.cap];
         uint32_t e;
-        do { e = *reinterpret_cast<volatile uint16_t*>(cell); } while (!(e & 0x8000u));  // the pusher is between its two writes
+        // (an atomic load, not a volatile one: volatile accesses keep the generic address space and become flat loads)
+        do { e = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (!(e & 0x8000u));  // the pusher is between its two writes
         *cell = 0;
         const uint32_t slot = e & 0x7FFFu;
         const uint32_t round = s_round[slot] & 0x7Fu;
+        uint64_t t_seen = 0;
+        if (TRACE) t_seen = wall_clock64();
         uint32_t c, aref, bref;
         uint2 sw;
-        if (slot < n_meta) {
-          c = s_c[slot]; sw = s_succ[slot];
-          if (WIDE) { uint32_t ab = s_a[slot]; aref = ab & 0xFFFFu; bref = (ab >> 16) == 0xFFFFu ? kNone : (ab >> 16); }
-          else { aref = s_a[slot]; bref = s_b[slot]; }
-        } else {
+        // LDS reads first, unconditionally (clamped), the global table only for the wide layout's slow classes: an
+        // if/else over the two sources is merged into flat loads through a selected pointer
+        {
+          const uint32_t ms = WIDE ? min(slot, kMeta - 1u) : slot;
+          c = s_c[ms]; sw = s_succ[ms];
+          if (WIDE) { uint32_t ab = s_a[ms]; aref = ab & 0xFFFFu; bref = (ab >> 16) == 0xFFFFu ? kNone : (ab >> 16); }
+          else { aref = s_a[ms]; bref = s_b[ms]; }
+        }
+        if (WIDE) asm volatile("" : "+v"(c), "+v"(sw.x), "+v"(sw.y));  // keeps the LDS reads above the branch (else: sunk and merged into flat loads)
+        if (WIDE && slot >= n_meta) {
           c = F.t_c[row0 + slot]; aref = F.t_aref[row0 + slot]; bref = F.t_bref[row0 + slot]; sw = F.t_succ[row0 + slot];
         }
+        const bool has_local = !WIDE || slot >= n_meta ? (aref & kRefHasLocal) != 0u : false;
+        if (!WIDE || slot >= n_meta) aref &= ~kRefHasLocal;
         CRec rec = load_crec_solve(&cons[c]);  // only the lane running the constraint touches its record
-        BodyDyn A = f5_load_body(s_body, rs, aref);
-        BodyDyn Bd = f5_load_body(s_body, rs, bref);
+        BodyDyn A, Bd;
+        // byte offsets of the bodies in the global array, or out of the buffer's range for LDS / static refs: such a
+        // load returns zeros (= the static body) and such a store is dropped, without touching memory
+        uint32_t ga = 0x80000000u, gb = 0x80000000u;
+        if (slow_wave) {
+          // both bodies' write-through loads go out back to back behind the record's, branch-free: one memory round
+          // trip per node instead of three (a branch per source made the compiler wait inside each arm)
+          if (aref & kRefGlobal) ga = (aref & ~kRefGlobal) * 64u;
+          if (bref != kNone && (bref & kRefGlobal)) gb = (bref & ~kRefGlobal) * 64u;
+          BodyDyn Ag = load_dyn_off_sc1(rs, ga), Bg = load_dyn_off_sc1(rs, gb);
+          const bool la = !(aref & kRefGlobal), lb = bref != kNone && !(bref & kRefGlobal);
+          BodyDyn Al = load_dyn(s_body, la ? aref : 0u), Bl = load_dyn(s_body, lb ? bref : 0u);
+          A = select_dyn(la, Al, Ag);
+          Bd = select_dyn(lb, Bl, Bg);
+        } else {  // the all-LDS class
+          A = load_dyn(s_body, aref);
+          Bd = bref == kNone ? static_dyn() : load_dyn(s_body, bref);
+        }
         solve_one(rec, A, Bd);
-        f5_store_vel(s_body, rs, aref, A);
-        f5_store_vel(s_body, rs, bref, Bd);
+        if (slow_wave) {
+          store_vel_off_sc1(rs, ga, A);
+          store_vel_off_sc1(rs, gb, Bd);
+          if (!(aref & kRefGlobal)) store_vel(s_body, aref, A);
+          if (bref != kNone && !(bref & kRefGlobal)) store_vel(s_body, bref, Bd);
+        } else {
+          store_vel(s_body, aref, A);
+          if (bref != kNone) store_vel(s_body, bref, Bd);
+        }
         cons[c].nimp = rec.nimp;
         const bool gcounter = slot >= N0 && slot < N01;
-        if (!gcounter) s_cnt[slot] = 0u;  // no arrival of the next iteration can come before this node's own releases
+        // re-arm (no arrival of the next iteration can come before this node's own releases); a class-1 slot counts
+        // its in-block arrivals only: one, or none when both predecessors are outside
+        s_cnt[slot] = gcounter ? (has_local ? 1u : 2u) : 0u;
         s_round[slot] = (uint8_t)(round + 1u);
         // velocities and the impulse are out (LDS, write-through stores) before any successor hears of it
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (TRACE) {  // (taken from the queue, released) + the slot's class in the low bits of the first stamp
+          const uint32_t cls = slot < N0 ? 0u : (slot < N01 ? 1u : 2u);
+          trace[2 * ((size_t)round * C_trace + c)] = (t_seen & ~3ull) | cls;
+          trace[2 * ((size_t)round * C_trace + c) + 1] = wall_clock64();
+        }
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
           if (side == 1 && bref == kNone) break;
@@ -1785,9 +1897,10 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
           if (w & kSuccLocal) {
             uint32_t sl = w & 0xFFFFu;
             uint32_t old = __hip_atomic_fetch_add(&s_cnt[sl], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (old + add >= 2u) f5_push(sl < N0 ? qf : qs, sl);
+            const bool cls1 = sl >= N0 && sl < N01;  // ready when the poller has seen the outside arrivals as well
+            if (cls1 ? old + add == (2u | kF5RemoteDone) : old + add >= 2u) f5_push(sl < N0 ? qf : qs, sl);
           } else {
-            __hip_atomic_fetch_add(&arr[w & kSuccId], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&F.arr5[w & kSuccId], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       }

@@ -843,7 +843,7 @@ struct mgf_world {
   // 0 = one launch per frontier of the dependency graph (k_solve, the independent cross-check);
   // 4 = dataflow launch with out-of-order slots per lane (k_solve_flowk)
   int64_t opt_solver_mode = 5;
-  DBuf<uint32_t> flow_arr;
+  DBuf<uint32_t> flow_arr, flow_arr5;
   DBuf<uint64_t> flow_trace;
   // block-local solver (mode 5)
   DBuf<uint32_t> brank, f5_shared, f5_gcnt, f5_lslot, f5_wg_cnt, f5_tc, f5_taref, f5_tbref, f5_tcnt0;
@@ -865,6 +865,7 @@ struct mgf_world {
   int flowk_grid = 0;
   int64_t opt_debug_bvh = 0, opt_flow_trace = 0;
   int64_t opt_flow5_slow_x2 = 3;
+  int64_t opt_flow5_poller = 0;    // 1: one slow wave only polls the global arrival counters (experiment)
   int64_t opt_flow5_block = 0;     // minimum bodies per block of the block-local solver (tests)
   bool flow5_attr_set = false;
   bool flow5_wide = false;          // LDS layout of k_solve_flow5 for this tick (chosen from the largest block of the last one)
@@ -905,12 +906,13 @@ struct mgf_world {
   Flow5 flow5() {
     Flow5 F;
     F.sidx = sidx.p; F.brank = brank.p; F.shared = reinterpret_cast<uint8_t*>(f5_shared.p);
-    F.gcnt = reinterpret_cast<uint8_t*>(f5_gcnt.p); F.lslot = f5_lslot.p; F.wg_cnt = f5_wg_cnt.p;
+    F.gcnt = f5_gcnt.p; F.arr5 = flow_arr5.p; F.lslot = f5_lslot.p; F.wg_cnt = f5_wg_cnt.p;
     F.t_c = f5_tc.p; F.t_aref = f5_taref.p; F.t_bref = f5_tbref.p; F.t_cnt0 = f5_tcnt0.p; F.t_succ = f5_tsucc.p;
     F.fail = d_err() + 4; F.max_block = d_err() + 6;
     F.cap_fast = flow5_wide ? kF5MaxFast : kF5NarrowCons; F.cap_slow = flow5_wide ? kF5MaxSlow : kF5NarrowCons;
     F.cap_all = flow5_wide ? kF5MaxCons : kF5NarrowCons;
     F.slow_x2 = (uint32_t)opt_flow5_slow_x2;
+    F.poller = (uint32_t)opt_flow5_poller;
     F.nb = f5_nb; F.nblocks = f5_nblocks; F.n = n;
     return F;
   }
@@ -955,6 +957,7 @@ extern "C" mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_
   if (!strcmp(key, "solver_mode")) { w->opt_solver_mode = value; return MGF_OK; }
   if (!strcmp(key, "flow_blocks_per_cu")) { w->opt_flow_blocks_per_cu = value; w->flow_grid = 0; w->flowk_grid = 0; return MGF_OK; }
   if (!strcmp(key, "flow_sleep")) { w->opt_flow_sleep = value; return MGF_OK; }
+  if (!strcmp(key, "flow5_poller")) { w->opt_flow5_poller = value ? 1 : 0; return MGF_OK; }
   if (!strcmp(key, "flow5_slow_x2")) { if (value < 1 || value > 16) return fail(MGF_ERR_INVALID, "flow5_slow_x2 out of range"); w->opt_flow5_slow_x2 = value; return MGF_OK; }
   if (!strcmp(key, "flow5_block")) { w->opt_flow5_block = value; w->flow5_prepped = false; return MGF_OK; }
   if (!strcmp(key, "stream_ordered")) { w->opt_stream_ordered = value; return MGF_OK; }
@@ -1813,9 +1816,15 @@ extern "C" int64_t mgf_world_ghost_len(const mgf_world* w) { return w ? (int64_t
 static mgf_status dump_flow_trace(mgf_world* w, uint32_t C, int32_t iters) {
   std::vector<uint64_t> h(2 * (size_t)iters * C);
   MGF_TRY(d2h(w->ctx, h.data(), w->flow_trace.p, h.size()));
+  // block-local solver: the body -> cell-order rank table and the block size tell which block ran a constraint
+  const bool f5 = w->opt_solver_mode == 5 && w->flow5_prepped && w->f5_nb > 0;
+  std::vector<uint32_t> rank(f5 ? (size_t)w->n + (w->n & 1u) : 0);
+  if (f5) MGF_TRY(d2h(w->ctx, rank.data(), w->brank.p, (size_t)w->n));
   if (FILE* f = fopen("/tmp/mgf_flow_trace.bin", "wb")) {
-    uint64_t hdr[2] = {C, (uint64_t)iters};
-    fwrite(hdr, 8, 2, f); fwrite(h.data(), 8, h.size(), f); fclose(f);
+    uint64_t hdr[4] = {C, (uint64_t)iters, f5 ? (uint64_t)rank.size() : 0u, f5 ? (uint64_t)w->f5_nb : 0u};
+    fwrite(hdr, 8, 4, f); fwrite(h.data(), 8, h.size(), f);
+    if (f5) fwrite(rank.data(), 4, rank.size(), f);
+    fclose(f);
   }
   return MGF_OK;
 }
@@ -1827,7 +1836,7 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
   mgf_ctx* ctx = w->ctx;
   hipStream_t s = ctx->stream;
   const bool kslots = w->opt_solver_mode == 4;
-  bool use5 = w->opt_solver_mode == 5 && w->flow5_ok && !w->opt_flow_trace && w->n > 0 && iters <= 100;  // iteration counters are 7-bit in LDS
+  bool use5 = w->opt_solver_mode == 5 && w->flow5_ok && w->n > 0 && iters <= 100;  // iteration counters are 7-bit in LDS
   if (use5) {
     // blocks of nb bodies in cell order, one workgroup each, all resident: at most one per CU
     const uint32_t need = (w->n + (uint32_t)ctx->num_cus - 1u) / (uint32_t)ctx->num_cus;
@@ -1838,16 +1847,17 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
   }
   if (use5 && !w->flow5_prepped) {
     const uint32_t n = w->n;
-    MGF_TRY(w->f5_shared.ensure(n / 4 + 1, s)); MGF_TRY(w->f5_gcnt.ensure(cap_c / 4 + 1, s)); MGF_TRY(w->f5_lslot.ensure(std::max(cap_c, 1u), s));
+    MGF_TRY(w->f5_shared.ensure(n / 4 + 1, s)); MGF_TRY(w->f5_gcnt.ensure((size_t)cap_c + 1, s)); MGF_TRY(w->f5_lslot.ensure(std::max(cap_c, 1u), s));
     const size_t rows = (size_t)w->f5_nblocks * kF5MaxCons;
     MGF_TRY(w->f5_wg_cnt.ensure(4 * (size_t)w->f5_nblocks * kF5CntStride, s));
     MGF_TRY(w->f5_tc.ensure(rows, s)); MGF_TRY(w->f5_taref.ensure(rows, s)); MGF_TRY(w->f5_tbref.ensure(rows, s));
     MGF_TRY(w->f5_tcnt0.ensure(rows, s)); MGF_TRY(w->f5_tsucc.ensure(rows, s));
     if (!w->flow5_attr_set) {
-      MGF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_flow5<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(64 * (size_t)kF5MaxBodies + kF5LdsNarrow)));
-      MGF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_flow5<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(64 * (size_t)kF5MaxBodies + kF5LdsWide)));
+      const int lds_n = (int)(64 * (size_t)kF5MaxBodies + kF5LdsNarrow), lds_w = (int)(64 * (size_t)kF5MaxBodies + kF5LdsWide);
+      MGF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_flow5<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_n));
+      MGF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_flow5<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
+      MGF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_flow5<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_n));
+      MGF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_flow5<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_w));
       w->flow5_attr_set = true;
     }
     // narrow layout (all slot constants in LDS) while the blocks are small, wide layout once they approach its limit
@@ -1855,7 +1865,7 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
     ZeroList z;
     memset(&z, 0, sizeof(z));
     z.p[0] = w->f5_shared.p; z.words[0] = n / 4 + 1;
-    z.p[1] = w->f5_gcnt.p; z.words[1] = cap_c / 4 + 1;
+    z.p[1] = w->f5_gcnt.p; z.words[1] = cap_c + 1;
     z.p[2] = w->d_err() + 4; z.words[2] = 1;
     z.p[3] = w->f5_wg_cnt.p; z.words[3] = 4 * w->f5_nblocks * kF5CntStride;
     z.p[4] = w->d_err() + 6; z.words[4] = 1;  // largest block of the tick
@@ -1886,7 +1896,8 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
   uint32_t* abort_flag = w->d_err() + 2;
   unsigned g = std::min<unsigned>((unsigned)grid, std::max(1u, nblk(cap_c)));
   MGF_TRY(w->flow_arr.ensure(std::max(cap_c, 1u), s));
-  k_flow_init<<<std::max(1u, nblk(cap_c)), kBlock, 0, s>>>(C_ptr, w->links(), w->flow_arr.p, abort_flag);
+  if (use5) MGF_TRY(w->flow_arr5.ensure(std::max(cap_c, 1u), s));
+  k_flow_init<<<std::max(1u, nblk(cap_c)), kBlock, 0, s>>>(C_ptr, w->links(), w->flow_arr.p, abort_flag, use5 ? w->f5_gcnt.p : nullptr, w->flow_arr5.p);
   LAUNCH_CHECK();
   const bool timed = w->opt_time_solver_kernels != 0;
   if (!w->solve_pending) w->kev_used = 0;  // a tiled tick enqueues several launches before it reads the events
@@ -1903,13 +1914,10 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
   const int sleep = (int)w->opt_flow_sleep;
   if (use5) {
     Flow5 F = w->flow5();
-    if (w->flow5_wide) {
-      k_solve_flow5<true><<<F.nblocks, kF5Threads, 64 * (size_t)F.nb + kF5LdsWide, s>>>(w->srec.p, w->cons_nat.p, w->links(), F, w->flow_arr.p, (uint32_t)iters,
-                                                                                      abort_flag, spin_limit);
-    } else {
-      k_solve_flow5<false><<<F.nblocks, kF5Threads, 64 * (size_t)F.nb + kF5LdsNarrow, s>>>(w->srec.p, w->cons_nat.p, w->links(), F, w->flow_arr.p, (uint32_t)iters,
-                                                                                          abort_flag, spin_limit);
-    }
+    const size_t lds = 64 * (size_t)F.nb + (w->flow5_wide ? kF5LdsWide : kF5LdsNarrow);
+    auto kern = w->flow5_wide ? (trace ? k_solve_flow5<true, true> : k_solve_flow5<true, false>)
+                              : (trace ? k_solve_flow5<false, true> : k_solve_flow5<false, false>);
+    kern<<<F.nblocks, kF5Threads, lds, s>>>(w->srec.p, w->cons_nat.p, w->links(), F, w->flow_arr.p, (uint32_t)iters, abort_flag, spin_limit, trace, w->C);
     LAUNCH_CHECK();
     // stand-by: the global dataflow kernel runs only if a block did not fit its workgroup (flag raised by k_flow5_prep)
     k_solve_flow<false><<<g, kBlock, 0, s>>>(w->srec.p, w->cons_nat.p, w->links(), w->flow_arr.p, C_ptr, (uint32_t)iters, abort_flag, spin_limit, sleep, nullptr, F.fail);

@@ -16,8 +16,13 @@ w.step(float(sc['dt']), 10)
 w.set_option('flow_trace', 0)
 cons = w.constraints()
 raw = np.fromfile('/tmp/mgf_flow_trace.bin', dtype=np.uint64)
-C, iters = int(raw[0]), int(raw[1])
-tr = raw[2:].reshape(iters, C, 2).astype(np.int64)
+C, iters, n_rank, nb_block = int(raw[0]), int(raw[1]), int(raw[2]), int(raw[3])
+tr = raw[4:4 + 2 * iters * C].reshape(iters, C, 2).astype(np.int64)
+rank = raw[4 + 2 * iters * C:].view(np.uint32)[:n_rank].astype(np.int64) if n_rank else None
+cls = (tr[0, :, 0] & 3) if mode == 5 else np.zeros(C, np.int64)   # mode 5 stamps the slot class into the low bits
+if mode == 5:
+    tr[:, :, 0] &= ~3
+    print("classes (0 all-LDS, 1 global counter, 2 shared body):", np.bincount(cls, minlength=3) / C)
 t0 = tr[:, :, 0].min()
 seen = (tr[:, :, 0] - t0) * 0.01   # us (100 MHz)
 done = (tr[:, :, 1] - t0) * 0.01
@@ -52,11 +57,24 @@ print(f"hand-off (last pred released -> seen) mean {lat.mean():.2f} us p10 {np.p
 r, c = np.unravel_index(np.argmax(done), done.shape)
 hops = 0; svc = 0.0; ho = 0.0
 path = []
+by = {}
 while (r, c) in crit_pred:
     pr, pc = crit_pred[(r, c)]
     svc += done[r, c] - seen[r, c]; ho += seen[r, c] - done[pr, pc]; hops += 1
     path.append((seen[r, c] - done[pr, pc], done[r, c] - seen[r, c]))
+    k = (int(cls[pc]), int(cls[c]))
+    if rank is not None:
+        k = k + ("same block" if rank[A[pc]] // nb_block == rank[A[c]] // nb_block else "other block",)
+    e = by.setdefault(k, [0, 0.0, 0.0]); e[0] += 1; e[1] += seen[r, c] - done[pr, pc]; e[2] += done[r, c] - seen[r, c]
     r, c = pr, pc
+if mode == 5:
+    for k in sorted(by):
+        n, h, sv = by[k]
+        print(f"  critical hops class {k[0]} -> {k[1]} {k[2] if len(k) > 2 else '':11s}: {n:4d}  hand-off {h / n:6.2f} us  service {sv / n:6.2f} us  (total {h + sv:7.1f} us)")
+    for k in range(3):
+        m = cls == k
+        if m.any():
+            print(f"  class {k}: service mean {np.mean((done - seen)[:, m]):.2f} us p50 {np.median((done - seen)[:, m]):.2f} p90 {np.percentile((done - seen)[:, m], 90):.2f}")
 print(f"critical path: {hops} hops, service {svc:.1f} us ({svc/hops:.2f}/hop), hand-off {ho:.1f} us ({ho/hops:.2f}/hop), first node seen at {seen[r,c]:.1f} us")
 h = np.array(path)
 print("hand-off on the critical path: p10 %.2f p50 %.2f p90 %.2f max %.2f" % tuple(np.percentile(h[:,0],[10,50,90,100])))
