@@ -307,7 +307,7 @@ MGF_API mgf_status mgf_world_finish(mgf_world* w, mgf_step_stats* stats);
  * not, because the narrowphase dispatch is chosen on the host (the tiles driver exchanges the masks with the counts). */
 MGF_API mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_t value);
 /* Diagnostics: how often a slow path was taken.  name in {"row_overflows", "capacity_retries", "flow5_fallbacks",
- * "grid_too_wide", "flow5_blocks", "flow5_class0|1|2", "terrain_grid", "terrain_row_capacity", "body_kinds"}. */
+ * "grid_too_wide", "flow5_blocks", "flow5_class0|1|2", "terrain_grid", "terrain_row_capacity", "rev_row_capacity", "body_kinds"}. */
 MGF_API mgf_status mgf_world_counter(const mgf_world* w, const char* name, int64_t* out);
 /* Raw device pointers of resident state for zero-copy exchange (multi-GPU halo): name in
  * {"x","q","solver_rec","delta"}; pointer valid until the next add_bodies. */

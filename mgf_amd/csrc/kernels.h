@@ -17,8 +17,8 @@
 //                      one kernel per shape-pair type over the candidate lists
 //   k_count_contacts / k_setup_pairs / k_setup_terrain
 //                      Manifold::from + ContactConstraint::new (manifold.rs:120-148, solver.rs:101-191)
-//   k_adj_fill / k_chain
-//                      order-preserving dependency links of the constraint list (compact arrays, ConsLinks)
+//   k_chain_rows       order-preserving dependency links of the tick's constraint list (compact arrays, ConsLinks);
+//   k_adj_fill / k_chain  the same for a caller-supplied list in any order (mgf_world_set_constraints)
 //   k_solve_flow5      ContactConstraint::solve (solver.rs:203-252) for a whole Solver::solve call: block-local persistent
 //                      dataflow launch (a spatial block's velocities, arrival counters and ready queues in LDS)
 //   k_solve_flow       the same graph with every hand-off through L2 (stand-by of k_solve_flow5, solver mode 1)
@@ -462,7 +462,8 @@ struct StepCounts {
   uint32_t bins[6];                            // candidates per shape-pair type (scenes mixing spheres and capsules)
   uint32_t pad;
 };
-constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u, kFailGridWide = 8u, kFailTerrainRow = 16u, kFailTerrainWide = 32u;
+constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u, kFailGridWide = 8u, kFailTerrainRow = 16u, kFailTerrainWide = 32u,
+                   kFailRevRow = 64u;  // a body's row of `b` occurrences overflowed (k_setup_pairs / k_chain_rows)
 
 __global__ void k_caps_candidates(const uint32_t* mt, const uint32_t* mp, uint32_t cap_t, uint32_t cap_p, const uint32_t* row_overflow,
                                   const uint32_t* grid_wide, const uint32_t* terrain_wide, StepCounts* sc) {
@@ -1090,7 +1091,8 @@ __device__ __forceinline__ CRec load_crec_solve(const CRec* src) {
 __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCounts* sc, const uint32_t* p_owner, const uint32_t* p_cand,
                                                         const uint32_t* p_nc, const uint32_t* p_pre, const NContact* p_in,
                                                         const uint32_t* base, float dt, float baumgarte, float slop,
-                                                        CRec* cons, uint2* ab, uint32_t* deg) {
+                                                        CRec* cons, uint2* ab, uint32_t* degb, uint32_t* rev, uint32_t rev_cap,
+                                                        uint32_t* rev_flag) {
   uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= sc->Mp || p_nc[p] == 0) return;
   uint32_t i = p_owner[p], j = p_cand[p];
@@ -1102,14 +1104,16 @@ __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCoun
                            dt, baumgarte, slop);
   store_crec(&cons[c], r);
   ab[c] = make_uint2(i, j);
-  atomicAdd(&deg[i], 1u);
-  atomicAdd(&deg[j], 1u);
+  // body j's row of the constraints it takes part in as `b` (k_chain_rows); as `a` a body owns a contiguous id range
+  uint32_t pos = atomicAdd(&degb[j], 1u);
+  if (pos < rev_cap) rev[(size_t)j * rev_cap + pos] = c;
+  else *rev_flag = 1u;
 }
 
 __global__ __launch_bounds__(kBlock) void k_setup_terrain(Bodies B, TerrainDev M, const StepCounts* sc, const uint32_t* t_owner,
                                                           const uint32_t* t_nc, const uint32_t* t_pre, const NContact* t_in,
                                                           const uint32_t* base, float dt, float baumgarte, float slop, CRec* cons,
-                                                          uint2* ab, uint32_t* deg) {
+                                                          uint2* ab) {
   uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= sc->Mt) return;
   uint32_t nc = t_nc[p];
@@ -1125,7 +1129,6 @@ __global__ __launch_bounds__(kBlock) void k_setup_terrain(Bodies B, TerrainDev M
     store_crec(&cons[base[i] + t_pre[p] + k], r);
     ab[base[i] + t_pre[p] + k] = make_uint2(i, kNone);
   }
-  atomicAdd(&deg[i], nc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1182,6 +1185,39 @@ __global__ __launch_bounds__(kBlock) void k_chain(uint32_t n, ConsLinks K, const
 }
 __device__ __forceinline__ uint32_t links_indeg0(const ConsLinks& K, uint32_t c) {
   return (uint32_t)K.pred[2 * c] + (K.ab[c].y != kNone ? (uint32_t)K.pred[2 * c + 1] : 0u);
+}
+
+// The same links for the tick's own constraint list, without the global adjacency build.  In canonical order a body x
+// is `a` exactly in the contiguous ids [base[x], base[x+1]) (its terrain contacts, then its partners j < x) and `b` only
+// in constraints of bodies i > x, whose ids are all larger: its chain is the own range followed by its row of `b`
+// occurrences (written by k_setup_pairs in arrival order, sorted here).  A row that overflowed raises kFailRevRow and
+// empties the tick (C = 0): the host widens the rows and re-runs the collide phase.
+__global__ __launch_bounds__(kBlock) void k_chain_rows(uint32_t n, ConsLinks K, const uint32_t* base, const uint32_t* degb, uint32_t* rev,
+                                                       uint32_t rev_cap, const uint32_t* rev_flag, StepCounts* sc) {
+  uint32_t x = blockIdx.x * kBlock + threadIdx.x;
+  if (*rev_flag) {
+    if (x == 0) { sc->C = 0; sc->Ct = 0; sc->fail |= kFailRevRow; }
+    return;
+  }
+  if (x >= n) return;
+  const uint32_t lo = base[x], na = base[x + 1] - lo, nb = degb[x];
+  const uint32_t total = na + nb;
+  if (total == 0) return;
+  uint32_t* row = rev + (size_t)x * rev_cap;
+  for (uint32_t a = 1; a < nb; ++a) {  // ascending constraint id = insertion order
+    uint32_t v = row[a], b = a;
+    while (b > 0 && row[b - 1] > v) { row[b] = row[b - 1]; --b; }
+    row[b] = v;
+  }
+  uint32_t* succ = reinterpret_cast<uint32_t*>(K.succ);
+  const uint32_t first = na ? lo : row[0];
+  for (uint32_t k = 0; k < total; ++k) {
+    const bool last = k + 1 == total;
+    const uint32_t u = k < na ? lo + k : row[k - na], role = k < na ? 0u : 1u;
+    const uint32_t wid = last ? first : (k + 1 < na ? lo + k + 1 : row[k + 1 - na]);
+    succ[2 * u + role] = wid | (K.ab[wid].y != kNone ? kSuccTwo : 0u) | (last ? kSuccWrap : 0u);
+    K.pred[2 * u + role] = k > 0 ? 1 : 0;  // predecessor on this body inside one iteration
+  }
 }
 
 // The solver walks the dependency graph of the WHOLE Solver::solve call (iters x constraints,

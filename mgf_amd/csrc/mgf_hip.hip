@@ -883,6 +883,8 @@ struct mgf_world {
   DBuf<uint2> c_ab, c_succ;  // compact dependency links (ConsLinks)
   DBuf<uint8_t> c_pred;
   DBuf<uint32_t> deg, adj_off, adj_fill, adj_list, order, lvl_off;
+  DBuf<uint32_t> degb, rev;      // per body: count and row (rev_cap ids) of the constraints it takes part in as `b`
+  uint32_t rev_cap = 16;          // grows on overflow (kFailRevRow), sticky
   DBuf<uint32_t> scalars;  // [0..2] rotating level counters, [3] err
   DBuf<SceneBounds> sb;
   uint32_t Mt = 0, Mp = 0, C = 0, Ct = 0, depth = 0, last_launches = 0, lvl_cap = 0;
@@ -982,6 +984,7 @@ extern "C" mgf_status mgf_world_counter(const mgf_world* w, const char* name, in
   if (!strcmp(name, "grid_too_wide")) { *out = w->grid_too_wide ? 1 : 0; return MGF_OK; }
   if (!strcmp(name, "terrain_grid")) { *out = (w->terrain && w->terrain->grid.ready && !w->terrain_grid_off && !w->opt_terrain_tree) ? 1 : 0; return MGF_OK; }
   if (!strcmp(name, "terrain_row_capacity")) { *out = (int64_t)w->row_cap_t; return MGF_OK; }
+  if (!strcmp(name, "rev_row_capacity")) { *out = (int64_t)w->rev_cap; return MGF_OK; }
   if (!strcmp(name, "body_kinds")) { *out = (w->has_sphere ? 1 : 0) | (w->has_capsule ? 2 : 0); return MGF_OK; }
   if (!strcmp(name, "flow5_blocks")) { *out = (int64_t)w->f5_nblocks; return MGF_OK; }
   if (!strncmp(name, "flow5_class", 11) && (name[11] == '0' || name[11] == '1' || name[11] == '2') && !name[12]) {
@@ -1394,13 +1397,14 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   MGF_TRY(w->t_cnt.ensure(n + 1, s)); MGF_TRY(w->p_cnt.ensure(n + 1, s)); MGF_TRY(w->t_off.ensure(n + 1, s)); MGF_TRY(w->p_off.ensure(n + 1, s));
   MGF_TRY(w->cons_nat.ensure(cap_c, s));
   MGF_TRY(links_ensure(w, cap_c));
+  MGF_TRY(w->degb.ensure(n + 1, s)); MGF_TRY(w->rev.ensure((size_t)n * w->rev_cap, s));
   {  // one launch clears every per-tick counter array
     ZeroList z;
     memset(&z, 0, sizeof(z));
     z.p[0] = w->cell_cnt.p; z.words[0] = cells + 1;
     z.p[1] = w->t_cnt.p; z.words[1] = n + 1;  // ghosts have no terrain row
-    z.p[2] = w->deg.p; z.words[2] = n + 1;
-    z.p[3] = w->adj_fill.p; z.words[3] = n + 1;
+    z.p[2] = w->degb.p; z.words[2] = n + 1;
+    z.p[3] = w->d_err() + 7; z.words[3] = 1;  // row-of-b-occurrences overflow flag
     z.p[4] = w->d_err() + 1; z.words[4] = 1;  // row-overflow flag (re-armed for a re-run inside the tick)
     z.p[5] = w->d_err() + 3; z.words[5] = 1;  // grid-too-wide flag
     z.p[6] = w->d_err() + 5; z.words[6] = 1;  // terrain-grid-too-wide flag
@@ -1510,13 +1514,17 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   LAUNCH_CHECK();
   if (M.n_nodes) {
     k_setup_terrain<<<nblk(cap_t), kBlock, 0, s>>>(B, M, sc, w->t_owner.p, w->t_nc.p, w->t_pre.p, w->t_out.p, w->base.p, dt, w->params.baumgarte,
-                                                   w->params.penetration_slop, w->cons_nat.p, w->c_ab.p, w->deg.p);
+                                                   w->params.penetration_slop, w->cons_nat.p, w->c_ab.p);
     LAUNCH_CHECK();
   }
   k_setup_pairs<<<nblk(cap_p), kBlock, 0, s>>>(B, sc, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_pre.p, w->p_out.p, w->base.p, dt,
-                                               w->params.baumgarte, w->params.penetration_slop, w->cons_nat.p, w->c_ab.p, w->deg.p);
+                                               w->params.baumgarte, w->params.penetration_slop, w->cons_nat.p, w->c_ab.p, w->degb.p, w->rev.p,
+                                               w->rev_cap, w->d_err() + 7);
   LAUNCH_CHECK();
-  MGF_TRY(build_dag(w, cap_c));
+  if (cap_c >= kSuccId) return fail(MGF_ERR_CAPACITY, "too many constraints");
+  w->depth = 0;
+  k_chain_rows<<<nblk(n), kBlock, 0, s>>>(n, w->links(), w->base.p, w->degb.p, w->rev.p, w->rev_cap, w->d_err() + 7, sc);
+  LAUNCH_CHECK();
   MGF_HIP_TRY(hipEventRecord(w->ev[4], s));
   return MGF_OK;
 }
@@ -1538,6 +1546,7 @@ static mgf_status collide_finish(mgf_world* w, bool* retry) {
   w->stats.n_refits = reinterpret_cast<SceneBounds*>(pin + 32)->n_refits;
   if (pin[64]) return fail(MGF_ERR_CAPACITY, "BVH traversal stack overflow");
   auto grown = [](uint32_t need) { return (uint32_t)std::min<uint64_t>((uint64_t)need + need / 2 + 1024, 0x7FFFFFF0ull); };
+  if (h.fail & kFailRevRow) { w->rev_cap *= 2; *retry = true; }  // wider rows from now on
   if (h.fail & kFailTerrainWide) { w->terrain_grid_off = true; *retry = true; }
   else if (h.fail & kFailGridWide) { w->grid_too_wide = true; *retry = true; }
   else if (h.fail & (kFailRowOverflow | kFailTerrainRow)) {

@@ -248,18 +248,20 @@ def test_tiled_worlds_match_oracle_tiles(ctx, refresh_every, P):
             assert values_equal(g[k], o[k]), f"tile {r} {k}: rel err {rel_err(g[k], o[k])}"
 
 
-def _crowded_scene():
-    """One big sphere (last index) touched by 80 small ones: more than the 32-entry candidate row."""
+def _crowded_scene(big_first=False):
+    """One big sphere (last index, or first) touched by 80 small ones: more than the 32-entry candidate row."""
     from mgf_amd import scenes
     rng = np.random.default_rng(11)
     d = rng.normal(size=(80, 3))
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     d[:, 1] = np.abs(d[:, 1])
     centres = np.concatenate([(d * 3.45 + [0, 4.0, 0]).astype(np.float32), np.array([[0, 4.0, 0]], np.float32)])
+    if big_first:
+        centres = centres[::-1].copy()
     comps = np.zeros(len(centres), scenes.COMPONENT_DTYPE)
     comps["p"] = centres
     comps["r"] = 0.5
-    comps["r"][-1] = 3.0
+    comps["r"][0 if big_first else -1] = 3.0
     sc = scenes._scene("crowded", comps, scenes.box_terrain(12.0, 12.0, (0, 0, 0)), v0=rng.uniform(-0.2, 0.2, (len(comps), 3)))
     return sc
 
@@ -279,6 +281,24 @@ def test_candidate_row_overflow_falls_back_exactly(ctx, force_two_pass):
         compare_constraints(gw.constraints(), ow.constraints(), check_impulse=True)
     assert so.n_pair_candidates >= 60  # the big sphere alone has > 32 partners
     _compare_state(gw, ow, "crowded scene")
+
+
+def test_body_in_many_constraints_as_b_widens_its_row(ctx):
+    """The big sphere has index 0, so it is body `b` of every contact with the 80 small ones: its row of `b`
+    occurrences (16 ids to start with) overflows, the tick is re-run with wider rows, and the result is the oracle's."""
+    import mgf_amd
+    scene = _crowded_scene(big_first=True)
+    dt, iters = float(scene["dt"]), scene["iters"]
+    ow = oracle_world(scene)
+    gw = mgf_amd.World.from_scene(ctx, scene)
+    assert gw.counter("rev_row_capacity") == 16
+    for step in range(6):
+        so, sg = ow.step(dt, iters), gw.step(dt, iters)
+        assert sg.n_constraints == so.n_constraints
+        compare_constraints(gw.constraints(), ow.constraints(), check_impulse=True)
+    assert so.n_constraints - so.n_terrain_constraints >= 60
+    assert gw.counter("rev_row_capacity") >= 64
+    _compare_state(gw, ow, "crowded scene, big sphere first")
 
 
 @pytest.mark.parametrize("mode", [0, 1])
