@@ -1410,17 +1410,12 @@ __device__ __forceinline__ BodyDyn select_dyn(bool c, const BodyDyn& a, const Bo
 }
 
 // arr[c] = 2 - (weighted predecessors inside iteration 0): node (c, 0) is ready at arr >= 2.
-__global__ __launch_bounds__(kBlock) void k_flow_init(const uint32_t* C_ptr, ConsLinks K, uint32_t* arr, uint32_t* abort_flag, const uint32_t* rw,
-                                                       uint32_t* arr5) {
+__global__ __launch_bounds__(kBlock) void k_flow_init(const uint32_t* C_ptr, ConsLinks K, uint32_t* arr, uint32_t* abort_flag) {
   uint32_t c = blockIdx.x * kBlock + threadIdx.x;
   if (c == 0) *abort_flag = 0;
   if (c >= *C_ptr) return;
   uint32_t d0 = links_indeg0(K, c);
   arr[c] = 2u - d0 * (K.ab[c].y != kNone ? 1u : 2u);
-  if (rw) {  // block-local solver: arrivals from other blocks, scaled to 2 per iteration; iteration 0 has the wrap edges' credit
-    uint32_t w = rw[c] & 3u, nw = (rw[c] >> 2) & 3u;
-    arr5[c] = w ? 2u - nw * (2u / w) : 0u;
-  }
 }
 
 template <bool TRACE>
@@ -1599,7 +1594,9 @@ struct Flow5 {
   uint8_t* shared;         // body touched by constraints of two blocks
   uint32_t* gcnt;          // per constraint: weight of its predecessors in OTHER blocks (bits 0-1: per iteration, 2 in total with the
                            // in-block ones; bits 2-3: those that arrive inside iteration 0).  Non-zero = class 1.
-  uint32_t* arr5;          // class 1: arrivals from other blocks, scaled to 2 per iteration (in-block arrivals count in LDS)
+  uint32_t* arr5;          // class 1: arrivals from other blocks, scaled to 2 per iteration (in-block arrivals count in LDS).
+                           // Indexed like the slot tables (block * kF5MaxCons + slot), so a block's counters are contiguous and
+                           // its pollers read them coalesced; written by k_flow5_table, re-armed by the solve kernel on exit.
   uint32_t* lslot;         // constraint -> (class << 12) | index inside its block's class
   uint32_t* wg_cnt;        // per block and class k (0 all-LDS, 1 global counter, 2 LDS counter + shared body): f5_cnt(F, g, k),
                            // one 128-byte line per counter (same-line atomics serialise)
@@ -1679,8 +1676,11 @@ __global__ __launch_bounds__(kBlock) void k_flow5_table(Flow5 F, ConsLinks K, co
   F.t_c[row] = c;
   F.t_aref[row] = f5_ref(F, g, e.x) | (rw == 1u ? kRefHasLocal : 0u);
   F.t_bref[row] = f5_ref(F, g, e.y);
-  // the LDS counter counts in-block arrivals only: iteration 0 starts with the credit of the in-block wrap edges
-  F.t_cnt0[row] = 2u - (links_indeg0(K, c) * (e.y != kNone ? 1u : 2u) - rnw);
+  // the LDS counter counts in-block arrivals only: iteration 0 starts with the credit of the in-block wrap edges;
+  // bits 8..: the same for the arrivals from other blocks (arr5, scaled to 2 per iteration)
+  const uint32_t remote0 = rw ? 2u - rnw * (2u / rw) : 0u;
+  F.t_cnt0[row] = (2u - (links_indeg0(K, c) * (e.y != kNone ? 1u : 2u) - rnw)) | (remote0 << 8);
+  F.arr5[row] = remote0;
   uint2 sw = K.succ[c];
   uint32_t w[2] = {sw.x, sw.y};
 #pragma unroll
@@ -1689,7 +1689,12 @@ __global__ __launch_bounds__(kBlock) void k_flow5_table(Flow5 F, ConsLinks K, co
     uint32_t sid = w[side] & kSuccId;
     bool local = F.brank[K.ab[sid].x] / F.nb == g;
     if (local) w[side] = (w[side] & (kSuccTwo | kSuccWrap)) | kSuccLocal | f5_slot(F, g, F.lslot[sid]);
-    else if ((F.gcnt[sid] & 3u) == 1u) w[side] &= ~kSuccTwo;  // its only arrival from outside counts 2 in arr5 (2 per iteration, uniformly)
+    else {  // in another block: the word names its row of arr5
+      const uint32_t gs = F.brank[K.ab[sid].x] / F.nb;
+      uint32_t flags = w[side] & (kSuccTwo | kSuccWrap);
+      if ((F.gcnt[sid] & 3u) == 1u) flags &= ~kSuccTwo;  // its only arrival from outside counts 2 (2 per iteration, uniformly)
+      w[side] = flags | (gs * kF5MaxCons + f5_slot(F, gs, F.lslot[sid]));
+    }
   }
   F.t_succ[row] = make_uint2(w[0], w[1]);
 }
@@ -1755,7 +1760,7 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
   // the block's slot table (built once per tick by k_flow5_table): a coalesced copy of what the LDS side needs
   const size_t row0 = (size_t)g * kF5MaxCons;
   for (uint32_t idx = t; idx < N; idx += kF5Threads) {
-    uint32_t c0 = F.t_cnt0[row0 + idx];
+    uint32_t c0 = F.t_cnt0[row0 + idx] & 0xFFu;
     s_cnt[idx] = c0;
     s_round[idx] = 0;
     if (idx < n_meta) {
@@ -1782,55 +1787,29 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
   const bool poller_wave = F.poller != 0u && nslow >= 2u && wave == nwaves - 1u;
   const bool polls = (F.poller != 0u && nslow >= 2u) ? poller_wave : slow_wave;
   const uint32_t poll_lanes = poller_wave ? 64u : nslow * 64u, poll_id = poller_wave ? lane : (wave - (nwaves - nslow)) * 64u + lane;
-  // wide layout: a polling lane keeps the constraint ids of its first slots in registers (they index the global counters)
-  constexpr int kPollCache = WIDE ? 6 : 1;
-  uint32_t pc[kPollCache];
-#pragma unroll
-  for (int k = 0; k < kPollCache; ++k) {
-    uint32_t idx = N0 + poll_id + (uint32_t)k * poll_lanes;
-    pc[k] = (WIDE && polls && idx < N01) ? F.t_c[row0 + idx] : 0u;
-  }
   uint32_t spins = 0;
   for (;;) {
     if (__hip_atomic_load(s_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
-    if (polls) {  // global counters that reached their iteration's threshold: queue the slot (once)
-      // The counter loads of a sweep are issued back to back and tested afterwards: one memory round trip per
-      // batch instead of one per slot (a slot that needs no look this sweep reads arr[0], harmlessly).
-      if (WIDE) {
-        uint32_t r[kPollCache], av[kPollCache];
-#pragma unroll
-        for (int k = 0; k < kPollCache; ++k) {
-          uint32_t idx = N0 + poll_id + (uint32_t)k * poll_lanes;
-          r[k] = idx < N01 ? s_round[idx] : 0xFFu;
-        }
-#pragma unroll
-        for (int k = 0; k < kPollCache; ++k)
-          av[k] = __hip_atomic_load(&arr5[r[k] < iters ? pc[k] : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int k = 0; k < kPollCache; ++k) {
-          uint32_t idx = N0 + poll_id + (uint32_t)k * poll_lanes;
-          if (r[k] < iters && av[k] >= 2u * (r[k] + 1u)) {  // the outside arrivals of this round are in: say so once
-            s_round[idx] = (uint8_t)(r[k] | 0x80u);
-            uint32_t old = __hip_atomic_fetch_add(&s_cnt[idx], kF5RemoteDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (old == 2u) f5_push(qs, idx);  // the in-block ones too
-          }
-        }
-      }
+    if (polls) {  // arrivals from other blocks that reached their iteration's threshold: say so once per round
+      // The block's counters are contiguous: a sweep is a few coalesced loads per wave, issued back to back and tested
+      // afterwards (one memory round trip per batch).
       constexpr int kPB = 4;
-      for (uint32_t base = N0 + poll_id + (WIDE ? (uint32_t)kPollCache * poll_lanes : 0u); base < N01; base += kPB * poll_lanes) {
-        uint32_t r[kPB], off[kPB], av[kPB];
+      for (uint32_t base = N0 + poll_id; base < N01; base += kPB * poll_lanes) {
+        uint32_t r[kPB], av[kPB];
 #pragma unroll
         for (int k = 0; k < kPB; ++k) {
           uint32_t idx = base + (uint32_t)k * poll_lanes;
           r[k] = idx < N01 ? s_round[idx] : 0xFFu;
-          off[k] = r[k] < iters ? (WIDE ? F.t_c[row0 + idx] : s_c[idx]) : 0u;
         }
-#pragma unroll
-        for (int k = 0; k < kPB; ++k) av[k] = __hip_atomic_load(&arr5[off[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int k = 0; k < kPB; ++k) {
           uint32_t idx = base + (uint32_t)k * poll_lanes;
-          if (r[k] < iters && av[k] >= 2u * (r[k] + 1u)) {  // the outside arrivals of this round are in: say so once
+          av[k] = __hip_atomic_load(&arr5[row0 + (idx < N01 ? idx : N0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int k = 0; k < kPB; ++k) {
+          uint32_t idx = base + (uint32_t)k * poll_lanes;
+          if (r[k] < iters && av[k] >= 2u * (r[k] + 1u)) {
             s_round[idx] = (uint8_t)(r[k] | 0x80u);
             uint32_t old = __hip_atomic_fetch_add(&s_cnt[idx], kF5RemoteDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (old == 2u) f5_push(qs, idx);  // the in-block ones too
@@ -1951,6 +1930,9 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
     }
   }
   __syncthreads();
+  // every node has run, so every arrival is in: re-arm the block's outside-arrival counters for the next Solver::solve
+  // call on this constraint list (a tiled tick makes several)
+  for (uint32_t idx = N0 + t; idx < N01; idx += kF5Threads) arr5[row0 + idx] = F.t_cnt0[row0 + idx] >> 8;
   // private bodies go back to the RigidBodyVec
   for (uint32_t p = p_lo + t; p < p_hi; p += kF5Threads) {
     uint32_t x = F.sidx[p];

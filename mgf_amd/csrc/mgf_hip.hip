@@ -865,7 +865,7 @@ struct mgf_world {
   int flowk_grid = 0;
   int64_t opt_debug_bvh = 0, opt_flow_trace = 0;
   int64_t opt_flow5_slow_x2 = 3;
-  int64_t opt_flow5_poller = 0;    // 1: one slow wave only polls the global arrival counters (experiment)
+  int64_t opt_flow5_poller = -1;   // 1: one slow wave only polls the outside-arrival counters; -1: with the narrow layout only (measured)
   int64_t opt_flow5_block = 0;     // minimum bodies per block of the block-local solver (tests)
   bool flow5_attr_set = false;
   bool flow5_wide = false;          // LDS layout of k_solve_flow5 for this tick (chosen from the largest block of the last one)
@@ -914,7 +914,7 @@ struct mgf_world {
     F.cap_fast = flow5_wide ? kF5MaxFast : kF5NarrowCons; F.cap_slow = flow5_wide ? kF5MaxSlow : kF5NarrowCons;
     F.cap_all = flow5_wide ? kF5MaxCons : kF5NarrowCons;
     F.slow_x2 = (uint32_t)opt_flow5_slow_x2;
-    F.poller = (uint32_t)opt_flow5_poller;
+    F.poller = opt_flow5_poller < 0 ? (flow5_wide ? 0u : 1u) : (uint32_t)opt_flow5_poller;
     F.nb = f5_nb; F.nblocks = f5_nblocks; F.n = n;
     return F;
   }
@@ -959,7 +959,7 @@ extern "C" mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_
   if (!strcmp(key, "solver_mode")) { w->opt_solver_mode = value; return MGF_OK; }
   if (!strcmp(key, "flow_blocks_per_cu")) { w->opt_flow_blocks_per_cu = value; w->flow_grid = 0; w->flowk_grid = 0; return MGF_OK; }
   if (!strcmp(key, "flow_sleep")) { w->opt_flow_sleep = value; return MGF_OK; }
-  if (!strcmp(key, "flow5_poller")) { w->opt_flow5_poller = value ? 1 : 0; return MGF_OK; }
+  if (!strcmp(key, "flow5_poller")) { w->opt_flow5_poller = value < 0 ? -1 : (value ? 1 : 0); return MGF_OK; }
   if (!strcmp(key, "flow5_slow_x2")) { if (value < 1 || value > 16) return fail(MGF_ERR_INVALID, "flow5_slow_x2 out of range"); w->opt_flow5_slow_x2 = value; return MGF_OK; }
   if (!strcmp(key, "flow5_block")) { w->opt_flow5_block = value; w->flow5_prepped = false; return MGF_OK; }
   if (!strcmp(key, "stream_ordered")) { w->opt_stream_ordered = value; return MGF_OK; }
@@ -1860,7 +1860,7 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
     const size_t rows = (size_t)w->f5_nblocks * kF5MaxCons;
     MGF_TRY(w->f5_wg_cnt.ensure(4 * (size_t)w->f5_nblocks * kF5CntStride, s));
     MGF_TRY(w->f5_tc.ensure(rows, s)); MGF_TRY(w->f5_taref.ensure(rows, s)); MGF_TRY(w->f5_tbref.ensure(rows, s));
-    MGF_TRY(w->f5_tcnt0.ensure(rows, s)); MGF_TRY(w->f5_tsucc.ensure(rows, s));
+    MGF_TRY(w->f5_tcnt0.ensure(rows, s)); MGF_TRY(w->f5_tsucc.ensure(rows, s)); MGF_TRY(w->flow_arr5.ensure(rows, s));
     if (!w->flow5_attr_set) {
       const int lds_n = (int)(64 * (size_t)kF5MaxBodies + kF5LdsNarrow), lds_w = (int)(64 * (size_t)kF5MaxBodies + kF5LdsWide);
       MGF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_flow5<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_n));
@@ -1905,8 +1905,7 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
   uint32_t* abort_flag = w->d_err() + 2;
   unsigned g = std::min<unsigned>((unsigned)grid, std::max(1u, nblk(cap_c)));
   MGF_TRY(w->flow_arr.ensure(std::max(cap_c, 1u), s));
-  if (use5) MGF_TRY(w->flow_arr5.ensure(std::max(cap_c, 1u), s));
-  k_flow_init<<<std::max(1u, nblk(cap_c)), kBlock, 0, s>>>(C_ptr, w->links(), w->flow_arr.p, abort_flag, use5 ? w->f5_gcnt.p : nullptr, w->flow_arr5.p);
+  k_flow_init<<<std::max(1u, nblk(cap_c)), kBlock, 0, s>>>(C_ptr, w->links(), w->flow_arr.p, abort_flag);
   LAUNCH_CHECK();
   const bool timed = w->opt_time_solver_kernels != 0;
   if (!w->solve_pending) w->kev_used = 0;  // a tiled tick enqueues several launches before it reads the events
