@@ -1588,6 +1588,16 @@ constexpr uint32_t kRefGlobal = 0x80000000u;              // body ref: bit 31 = 
 constexpr uint32_t kSuccLocal = 0x20000000u;              // successor word: low bits are a block-local slot
 constexpr uint32_t kRefHasLocal = 0x40000000u;            // a-ref of a class-1 slot: one of its two predecessors is in-block
 constexpr uint32_t kF5RemoteDone = 0x100u;                // class-1 LDS counter: the arrivals from other blocks are in (set by the poller)
+// One 32-byte row per slot (written once per tick by k_flow5_table with two 16-byte stores, read coalesced).
+struct F5Row {
+  uint32_t c;       // constraint id
+  uint32_t aref;    // body refs (LDS index, or id | kRefGlobal, or kNone); a-ref bit kRefHasLocal
+  uint32_t bref;
+  uint32_t cnt0;    // bits 0-7: in-block arrival counter of iteration 0; bits 8..: the same for arrivals from other blocks
+  uint32_t succ0, succ1;  // successor words, block-local slots or arr5 rows
+  uint32_t pad0, pad1;
+};
+static_assert(sizeof(F5Row) == 32, "F5Row is two 16-byte words");
 struct Flow5 {
   const uint32_t* sidx;    // cell-ordered body ids
   const uint32_t* brank;   // body -> position in cell order
@@ -1600,12 +1610,8 @@ struct Flow5 {
   uint32_t* lslot;         // constraint -> (class << 12) | index inside its block's class
   uint32_t* wg_cnt;        // per block and class k (0 all-LDS, 1 global counter, 2 LDS counter + shared body): f5_cnt(F, g, k),
                            // one 128-byte line per counter (same-line atomics serialise)
-  // per block, kF5MaxCons rows each, final slot order (class 0, then 1, then 2): what k_solve_flow5 copies into LDS
-  uint32_t* t_c;           // constraint id
-  uint32_t* t_aref;        // body refs (LDS index, or id | kRefGlobal, or kNone)
-  uint32_t* t_bref;
-  uint32_t* t_cnt0;        // arrival counter of iteration 0
-  uint2* t_succ;           // successor words, block-local slots where possible
+  // per block, kF5MaxCons rows, final slot order (class 0, then 1, then 2): what k_solve_flow5 copies into LDS
+  F5Row* table;
   uint32_t* fail;          // set when a block does not fit (the host falls back to k_solve_flow)
   uint32_t* max_block;     // largest block of this tick (the host picks next tick's LDS layout from it)
   uint32_t nb, nblocks, n;
@@ -1673,13 +1679,14 @@ __global__ __launch_bounds__(kBlock) void k_flow5_table(Flow5 F, ConsLinks K, co
   uint32_t slot = f5_slot(F, g, F.lslot[c]);
   size_t row = (size_t)g * kF5MaxCons + slot;
   const uint32_t rw = F.gcnt[c] & 3u, rnw = (F.gcnt[c] >> 2) & 3u;
-  F.t_c[row] = c;
-  F.t_aref[row] = f5_ref(F, g, e.x) | (rw == 1u ? kRefHasLocal : 0u);
-  F.t_bref[row] = f5_ref(F, g, e.y);
+  F5Row R;
+  R.c = c;
+  R.aref = f5_ref(F, g, e.x) | (rw == 1u ? kRefHasLocal : 0u);
+  R.bref = f5_ref(F, g, e.y);
   // the LDS counter counts in-block arrivals only: iteration 0 starts with the credit of the in-block wrap edges;
   // bits 8..: the same for the arrivals from other blocks (arr5, scaled to 2 per iteration)
   const uint32_t remote0 = rw ? 2u - rnw * (2u / rw) : 0u;
-  F.t_cnt0[row] = (2u - (links_indeg0(K, c) * (e.y != kNone ? 1u : 2u) - rnw)) | (remote0 << 8);
+  R.cnt0 = (2u - (links_indeg0(K, c) * (e.y != kNone ? 1u : 2u) - rnw)) | (remote0 << 8);
   F.arr5[row] = remote0;
   uint2 sw = K.succ[c];
   uint32_t w[2] = {sw.x, sw.y};
@@ -1696,7 +1703,10 @@ __global__ __launch_bounds__(kBlock) void k_flow5_table(Flow5 F, ConsLinks K, co
       w[side] = flags | (gs * kF5MaxCons + f5_slot(F, gs, F.lslot[sid]));
     }
   }
-  F.t_succ[row] = make_uint2(w[0], w[1]);
+  R.succ0 = w[0]; R.succ1 = w[1]; R.pad0 = R.pad1 = 0u;
+  uint4* dst = reinterpret_cast<uint4*>(&F.table[row]);
+  dst[0] = make_uint4(R.c, R.aref, R.bref, R.cnt0);
+  dst[1] = make_uint4(R.succ0, R.succ1, 0u, 0u);
 }
 
 __device__ __forceinline__ BodyDyn f5_load_body(const float4* s_body, __amdgpu_buffer_rsrc_t rs, uint32_t ref) {
@@ -1760,15 +1770,18 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
   // the block's slot table (built once per tick by k_flow5_table): a coalesced copy of what the LDS side needs
   const size_t row0 = (size_t)g * kF5MaxCons;
   for (uint32_t idx = t; idx < N; idx += kF5Threads) {
-    uint32_t c0 = F.t_cnt0[row0 + idx] & 0xFFu;
+    const uint4* src = reinterpret_cast<const uint4*>(&F.table[row0 + idx]);
+    const uint4 r0 = src[0];  // c, aref, bref, cnt0
+    uint32_t c0 = r0.w & 0xFFu;
     s_cnt[idx] = c0;
     s_round[idx] = 0;
     if (idx < n_meta) {
-      s_c[idx] = F.t_c[row0 + idx];
-      uint32_t ar = F.t_aref[row0 + idx], br = F.t_bref[row0 + idx];
+      const uint4 r1 = src[1];  // successor words
+      s_c[idx] = r0.x;
+      uint32_t ar = r0.y, br = r0.z;
       if (WIDE) s_a[idx] = (ar & 0xFFFFu) | ((br == kNone ? 0xFFFFu : br) << 16);  // class 0: LDS indices or static
       else { s_a[idx] = ar; s_b[idx] = br; }
-      s_succ[idx] = F.t_succ[row0 + idx];
+      s_succ[idx] = make_uint2(r1.x, r1.y);
     }
     // iteration 0's frontier (slots with a global counter are found by their pollers)
     if (!(idx >= N0 && idx < N01) && c0 >= 2u && iters > 0) f5_push(idx < N0 ? qf : qs, idx);
@@ -1857,7 +1870,9 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
         }
         if (WIDE) asm volatile("" : "+v"(c), "+v"(sw.x), "+v"(sw.y));  // keeps the LDS reads above the branch (else: sunk and merged into flat loads)
         if (WIDE && slot >= n_meta) {
-          c = F.t_c[row0 + slot]; aref = F.t_aref[row0 + slot]; bref = F.t_bref[row0 + slot]; sw = F.t_succ[row0 + slot];
+          const uint4* src = reinterpret_cast<const uint4*>(&F.table[row0 + slot]);
+          const uint4 r0 = src[0], r1 = src[1];
+          c = r0.x; aref = r0.y; bref = r0.z; sw = make_uint2(r1.x, r1.y);
         }
         const bool has_local = !WIDE || slot >= n_meta ? (aref & kRefHasLocal) != 0u : false;
         if (!WIDE || slot >= n_meta) aref &= ~kRefHasLocal;
@@ -1896,8 +1911,10 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
         // its in-block arrivals only: one, or none when both predecessors are outside
         s_cnt[slot] = gcounter ? (has_local ? 1u : 2u) : 0u;
         s_round[slot] = (uint8_t)(round + 1u);
-        // velocities and the impulse are out (LDS, write-through stores) before any successor hears of it
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // velocities are out (LDS, write-through stores) before any successor hears of it; the all-LDS class has nothing
+        // in flight to memory that a successor could read (the impulse is this constraint's own)
+        if (slow_wave) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (TRACE) {  // (taken from the queue, released) + the slot's class in the low bits of the first stamp
           const uint32_t cls = slot < N0 ? 0u : (slot < N01 ? 1u : 2u);
           trace[2 * ((size_t)round * C_trace + c)] = (t_seen & ~3ull) | cls;
@@ -1932,7 +1949,7 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
   __syncthreads();
   // every node has run, so every arrival is in: re-arm the block's outside-arrival counters for the next Solver::solve
   // call on this constraint list (a tiled tick makes several)
-  for (uint32_t idx = N0 + t; idx < N01; idx += kF5Threads) arr5[row0 + idx] = F.t_cnt0[row0 + idx] >> 8;
+  for (uint32_t idx = N0 + t; idx < N01; idx += kF5Threads) arr5[row0 + idx] = F.table[row0 + idx].cnt0 >> 8;
   // private bodies go back to the RigidBodyVec
   for (uint32_t p = p_lo + t; p < p_hi; p += kF5Threads) {
     uint32_t x = F.sidx[p];

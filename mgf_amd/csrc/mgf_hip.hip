@@ -846,8 +846,8 @@ struct mgf_world {
   DBuf<uint32_t> flow_arr, flow_arr5;
   DBuf<uint64_t> flow_trace;
   // block-local solver (mode 5)
-  DBuf<uint32_t> brank, f5_shared, f5_gcnt, f5_lslot, f5_wg_cnt, f5_tc, f5_taref, f5_tbref, f5_tcnt0;
-  DBuf<uint2> f5_tsucc;
+  DBuf<uint32_t> brank, f5_shared, f5_gcnt, f5_lslot, f5_wg_cnt;
+  DBuf<F5Row> f5_table;
   bool flow5_ok = false, flow5_prepped = false;  // the constraint list came from collide (own-block ranges valid) / prep done
   uint32_t f5_nb = 0, f5_nblocks = 0;
   int flow_grid = 0;
@@ -909,7 +909,7 @@ struct mgf_world {
     Flow5 F;
     F.sidx = sidx.p; F.brank = brank.p; F.shared = reinterpret_cast<uint8_t*>(f5_shared.p);
     F.gcnt = f5_gcnt.p; F.arr5 = flow_arr5.p; F.lslot = f5_lslot.p; F.wg_cnt = f5_wg_cnt.p;
-    F.t_c = f5_tc.p; F.t_aref = f5_taref.p; F.t_bref = f5_tbref.p; F.t_cnt0 = f5_tcnt0.p; F.t_succ = f5_tsucc.p;
+    F.table = f5_table.p;
     F.fail = d_err() + 4; F.max_block = d_err() + 6;
     F.cap_fast = flow5_wide ? kF5MaxFast : kF5NarrowCons; F.cap_slow = flow5_wide ? kF5MaxSlow : kF5NarrowCons;
     F.cap_all = flow5_wide ? kF5MaxCons : kF5NarrowCons;
@@ -1859,8 +1859,7 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
     MGF_TRY(w->f5_shared.ensure(n / 4 + 1, s)); MGF_TRY(w->f5_gcnt.ensure((size_t)cap_c + 1, s)); MGF_TRY(w->f5_lslot.ensure(std::max(cap_c, 1u), s));
     const size_t rows = (size_t)w->f5_nblocks * kF5MaxCons;
     MGF_TRY(w->f5_wg_cnt.ensure(4 * (size_t)w->f5_nblocks * kF5CntStride, s));
-    MGF_TRY(w->f5_tc.ensure(rows, s)); MGF_TRY(w->f5_taref.ensure(rows, s)); MGF_TRY(w->f5_tbref.ensure(rows, s));
-    MGF_TRY(w->f5_tcnt0.ensure(rows, s)); MGF_TRY(w->f5_tsucc.ensure(rows, s)); MGF_TRY(w->flow_arr5.ensure(rows, s));
+    MGF_TRY(w->f5_table.ensure(rows, s)); MGF_TRY(w->flow_arr5.ensure(rows, s));
     if (!w->flow5_attr_set) {
       const int lds_n = (int)(64 * (size_t)kF5MaxBodies + kF5LdsNarrow), lds_w = (int)(64 * (size_t)kF5MaxBodies + kF5LdsWide);
       MGF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve_flow5<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_n));
