@@ -12,7 +12,7 @@
 //   k_terrain_grid     Mesh::contacts' BVH::query by cell enumeration over the face boxes, hits stored as DFS ranks;
 //                      k_terrain_rows = the walk of the flattened reference tree in the reference's order
 //   k_candidates<FILL> the exact two-pass (count, fill) tree walk used when a candidate row overflows
-//   k_rows_to_csr      rows -> CSR, partners ascending, terrain faces in DFS order
+//   k_rows_to_csr      rows -> CSR, terrain faces in DFS order (partner contacts are ordered by k_count_contacts)
 //   k_narrow_pairs<A,B> / k_narrow_terrain<A>
 //                      one kernel per shape-pair type over the candidate lists
 //   k_count_contacts / k_setup_pairs / k_setup_terrain
@@ -848,38 +848,37 @@ __global__ __launch_bounds__(kCoopBlock) void k_terrain_grid(Bodies B, uint32_t 
   }
 }
 
-// rows -> CSR (terrain and partner candidate lists with their owners); partners sorted ascending in LDS
+// rows -> CSR (terrain and partner candidate lists with their owners)
 // (canonical insertion order).
 __global__ __launch_bounds__(kBlock) void k_rows_to_csr(const StepCounts* sc, uint32_t n, uint32_t cap_row_t, const uint32_t* face_of_rank,
                                                         const uint32_t* rows_t, const uint32_t* rows_p,
                                                         const uint32_t* t_off, const uint32_t* p_off, uint32_t* t_cand, uint32_t* t_owner,
                                                         uint32_t* p_cand, uint32_t* p_owner) {
-  __shared__ uint32_t s_row[kRowCap][kBlock];
-  const int tid = threadIdx.x;
-  uint32_t i = blockIdx.x * kBlock + tid;
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n || sc->fail) return;
   uint32_t tb = t_off[i], nt = t_off[i + 1] - tb, pb = p_off[i], np = p_off[i + 1] - pb;
   if (nt > cap_row_t || np > (uint32_t)kRowCap) return;  // overflowed body: the host re-runs with wider rows or the two-pass path
   const uint32_t* rt = rows_t + (size_t)i * cap_row_t;
-  const uint32_t* rp = rows_p + (size_t)i * kRowCap;
+  const uint4* rp = reinterpret_cast<const uint4*>(rows_p + (size_t)i * kRowCap);  // rows are 16-byte aligned (kRowCap % 4 == 0)
   if (face_of_rank) {  // the row holds DFS ranks in discovery order: sort, then name the faces
     for (uint32_t a = 0; a < nt; ++a) {
-      uint32_t v = rt[a];
+      uint32_t x = rt[a];
       uint32_t b = a;
-      while (b > 0 && t_cand[tb + b - 1] > v) { t_cand[tb + b] = t_cand[tb + b - 1]; --b; }
-      t_cand[tb + b] = v;
+      while (b > 0 && t_cand[tb + b - 1] > x) { t_cand[tb + b] = t_cand[tb + b - 1]; --b; }
+      t_cand[tb + b] = x;
     }
     for (uint32_t a = 0; a < nt; ++a) { t_cand[tb + a] = face_of_rank[t_cand[tb + a]]; t_owner[tb + a] = i; }
   } else {
     for (uint32_t a = 0; a < nt; ++a) { t_cand[tb + a] = rt[a]; t_owner[tb + a] = i; }
   }
-  for (uint32_t a = 0; a < np; ++a) {
-    uint32_t v = rp[a];
-    uint32_t b = a;
-    while (b > 0 && s_row[b - 1][tid] > v) { s_row[b][tid] = s_row[b - 1][tid]; --b; }
-    s_row[b][tid] = v;
+  // partners stay in discovery order: only the few that turn into contacts need the canonical (ascending) order, and
+  // k_count_contacts numbers those by partner id
+  for (uint32_t a = 0; a < np; a += 4) {
+    uint4 v = rp[a >> 2];
+    uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (a + k < np) { p_cand[pb + a + k] = e[k]; p_owner[pb + a + k] = i; }
   }
-  for (uint32_t a = 0; a < np; ++a) { p_cand[pb + a] = s_row[a][tid]; p_owner[pb + a] = i; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -979,16 +978,51 @@ __global__ __launch_bounds__(kBlock) void k_bin_terrain(Bodies B, const uint32_t
 // Per body: number of constraints it inserts (terrain contacts first, then partners) and the
 // running offset of each candidate inside the body's block.
 __global__ __launch_bounds__(kBlock) void k_count_contacts(const StepCounts* sc, uint32_t n, const uint32_t* t_off, const uint32_t* p_off,
-                                                           const uint32_t* t_nc, const uint32_t* p_nc, uint32_t* t_pre,
+                                                           const uint32_t* t_nc, const uint32_t* p_nc, const uint32_t* p_cand, uint32_t* t_pre,
                                                            uint32_t* p_pre, uint32_t* cnt, uint32_t* tcnt) {
+  constexpr int kHitCap = 12;  // a sphere touches at most 12 equal ones
+  __shared__ uint32_t s_j[kHitCap][kBlock], s_p[kHitCap][kBlock];
+  const int tid = threadIdx.x;
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   if (sc->fail) { cnt[i] = 0; tcnt[i] = 0; return; }
   uint32_t run = 0;
   for (uint32_t p = t_off[i]; p < t_off[i + 1]; ++p) { t_pre[p] = run; run += t_nc[p]; }
   tcnt[i] = run;
-  for (uint32_t p = p_off[i]; p < p_off[i + 1]; ++p) { p_pre[p] = run; run += p_nc[p]; }
-  cnt[i] = run;
+  // partner contacts are numbered in ascending partner order (the canonical insertion order); the candidate list itself
+  // is in discovery order, and only a few of its ~10 entries are contacts (at most one per partner): collect them, then
+  // rank them among themselves
+  const uint32_t lo = p_off[i], hi = p_off[i + 1];
+  uint32_t h = 0;
+  for (uint32_t base = lo; base < hi; base += 4) {  // four counts per round trip
+    uint32_t nc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) nc[k] = base + k < hi ? p_nc[base + k] : 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (nc[k]) {
+        if (h < (uint32_t)kHitCap) { s_j[h][tid] = p_cand[base + k]; s_p[h][tid] = base + k; }
+        ++h;
+      }
+    }
+  }
+  if (h <= (uint32_t)kHitCap) {
+    for (uint32_t a = 0; a < h; ++a) {
+      const uint32_t j = s_j[a][tid];
+      uint32_t before = 0;
+      for (uint32_t q = 0; q < h; ++q) before += s_j[q][tid] < j ? 1u : 0u;
+      p_pre[s_p[a][tid]] = run + before;
+    }
+  } else {  // a crowded body: the same by rescanning its list
+    for (uint32_t p = lo; p < hi; ++p) {
+      if (p_nc[p] == 0) continue;
+      const uint32_t j = p_cand[p];
+      uint32_t before = 0;
+      for (uint32_t q = lo; q < hi; ++q) before += (p_cand[q] < j) ? p_nc[q] : 0u;
+      p_pre[p] = run + before;
+    }
+  }
+  cnt[i] = run + h;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1506,7 +1506,7 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   MGF_HIP_TRY(hipEventRecord(w->ev[3], s));
   // 5. constraint numbering in insertion order + ContactConstraint::new
   MGF_TRY(w->cnt.ensure(n + 1, s)); MGF_TRY(w->tcnt.ensure(n + 1, s)); MGF_TRY(w->base.ensure(n + 1, s)); MGF_TRY(w->tbase.ensure(n + 1, s));
-  k_count_contacts<<<nblk(n), kBlock, 0, s>>>(sc, n, w->t_off.p, w->p_off.p, w->t_nc.p, w->p_nc.p, w->t_pre.p, w->p_pre.p, w->cnt.p, w->tcnt.p);
+  k_count_contacts<<<nblk(n), kBlock, 0, s>>>(sc, n, w->t_off.p, w->p_off.p, w->t_nc.p, w->p_nc.p, w->p_cand.p, w->t_pre.p, w->p_pre.p, w->cnt.p, w->tcnt.p);
   LAUNCH_CHECK();
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->cnt.p, w->base.p, (size_t)n + 1));
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->tcnt.p, w->tbase.p, (size_t)n + 1));
