@@ -460,7 +460,7 @@ struct StepCounts {
   uint32_t fail;                               // kFail* bits
   uint32_t need_Mt, need_Mp, need_C, need_Ct;  // actual sizes (valid up to the first failing stage)
   uint32_t bins[6];                            // candidates per shape-pair type (scenes mixing spheres and capsules)
-  uint32_t pad;
+  uint32_t ct_sum;                             // terrain constraints, accumulated by k_count_contacts (zeroed by k_caps_candidates)
 };
 constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u, kFailGridWide = 8u, kFailTerrainRow = 16u, kFailTerrainWide = 32u,
                    kFailRevRow = 64u;  // a body's row of `b` occurrences overflowed (k_setup_pairs / k_chain_rows)
@@ -477,7 +477,7 @@ __global__ void k_caps_candidates(const uint32_t* mt, const uint32_t* mp, uint32
   if (terrain_wide && *terrain_wide) r.fail |= kFailTerrainWide;
   r.Mt = r.fail ? 0u : r.need_Mt; r.Mp = r.fail ? 0u : r.need_Mp; r.C = 0; r.Ct = 0;
   for (int k = 0; k < 6; ++k) r.bins[k] = 0;
-  r.pad = 0;
+  r.ct_sum = 0;
   *sc = r;
 }
 __global__ void k_caps_constraints(const uint32_t* c, const uint32_t* ct, uint32_t cap_c, StepCounts* sc) {
@@ -977,18 +977,22 @@ __global__ __launch_bounds__(kBlock) void k_bin_terrain(Bodies B, const uint32_t
 
 // Per body: number of constraints it inserts (terrain contacts first, then partners) and the
 // running offset of each candidate inside the body's block.
-__global__ __launch_bounds__(kBlock) void k_count_contacts(const StepCounts* sc, uint32_t n, const uint32_t* t_off, const uint32_t* p_off,
+__global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint32_t n, const uint32_t* t_off, const uint32_t* p_off,
                                                            const uint32_t* t_nc, const uint32_t* p_nc, const uint32_t* p_cand, uint32_t* t_pre,
-                                                           uint32_t* p_pre, uint32_t* cnt, uint32_t* tcnt) {
+                                                           uint32_t* p_pre, uint32_t* cnt) {
   constexpr int kHitCap = 12;  // a sphere touches at most 12 equal ones
   __shared__ uint32_t s_j[kHitCap][kBlock], s_p[kHitCap][kBlock];
   const int tid = threadIdx.x;
+  __shared__ uint32_t s_ct;
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  if (sc->fail) { cnt[i] = 0; tcnt[i] = 0; return; }
+  if (tid == 0) s_ct = 0;
+  __syncthreads();
+  bool active = i < n;
+  if (active && sc->fail) { cnt[i] = 0; active = false; }
+  if (active) {
   uint32_t run = 0;
   for (uint32_t p = t_off[i]; p < t_off[i + 1]; ++p) { t_pre[p] = run; run += t_nc[p]; }
-  tcnt[i] = run;
+  if (run) atomicAdd(&s_ct, run);  // only the total is needed: one global atomic per block
   // partner contacts are numbered in ascending partner order (the canonical insertion order); the candidate list itself
   // is in discovery order, and only a few of its ~10 entries are contacts (at most one per partner): collect them, then
   // rank them among themselves
@@ -1023,6 +1027,9 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(const StepCounts* sc,
     }
   }
   cnt[i] = run + h;
+  }
+  __syncthreads();
+  if (tid == 0 && s_ct) atomicAdd(&sc->ct_sum, s_ct);
 }
 
 // ------------------------------------------------------------------------------------------

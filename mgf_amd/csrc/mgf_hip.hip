@@ -876,7 +876,7 @@ struct mgf_world {
   int64_t opt_two_pass = 0;  // 1 = always use the exact two-pass candidate path (tests the overflow fallback)
   uint64_t n_row_overflows = 0;
   // narrowphase
-  DBuf<uint32_t> t_nc, p_nc, t_pre, p_pre, cnt, tcnt, base, tbase, work_lists, work_counts;
+  DBuf<uint32_t> t_nc, p_nc, t_pre, p_pre, cnt, base, work_lists, work_counts;
   DBuf<NContact> t_out, p_out;
   // solver
   DBuf<CRec> cons_nat;
@@ -1505,12 +1505,11 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   }
   MGF_HIP_TRY(hipEventRecord(w->ev[3], s));
   // 5. constraint numbering in insertion order + ContactConstraint::new
-  MGF_TRY(w->cnt.ensure(n + 1, s)); MGF_TRY(w->tcnt.ensure(n + 1, s)); MGF_TRY(w->base.ensure(n + 1, s)); MGF_TRY(w->tbase.ensure(n + 1, s));
-  k_count_contacts<<<nblk(n), kBlock, 0, s>>>(sc, n, w->t_off.p, w->p_off.p, w->t_nc.p, w->p_nc.p, w->p_cand.p, w->t_pre.p, w->p_pre.p, w->cnt.p, w->tcnt.p);
+  MGF_TRY(w->cnt.ensure(n + 1, s)); MGF_TRY(w->base.ensure(n + 1, s));
+  k_count_contacts<<<nblk(n), kBlock, 0, s>>>(sc, n, w->t_off.p, w->p_off.p, w->t_nc.p, w->p_nc.p, w->p_cand.p, w->t_pre.p, w->p_pre.p, w->cnt.p);
   LAUNCH_CHECK();
   MGF_TRY(prim_exclusive_scan_u32(ctx, w->cnt.p, w->base.p, (size_t)n + 1));
-  MGF_TRY(prim_exclusive_scan_u32(ctx, w->tcnt.p, w->tbase.p, (size_t)n + 1));
-  k_caps_constraints<<<1, 1, 0, s>>>(w->base.p + n, w->tbase.p + n, cap_c, sc);
+  k_caps_constraints<<<1, 1, 0, s>>>(w->base.p + n, &sc->ct_sum, cap_c, sc);
   LAUNCH_CHECK();
   if (M.n_nodes) {
     k_setup_terrain<<<nblk(cap_t), kBlock, 0, s>>>(B, M, sc, w->t_owner.p, w->t_nc.p, w->t_pre.p, w->t_out.p, w->base.p, dt, w->params.baumgarte,
