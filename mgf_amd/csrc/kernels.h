@@ -239,6 +239,7 @@ struct Lbvh {
   QNode* nodes;        // (4^levels - 1) / 3 internal nodes
   LeafRec* leaves;     // n records in Morton order
   uint32_t* sidx;      // body index of every leaf record
+  float4* lcol;        // optional, 2 per leaf record: collider (p.xyz, r) and motion (delta.xyz) of the body (k_pair_grid<true>)
   uint32_t* cell_lo;   // 4^levels + 1 entries: cell c holds the leaf records [cell_lo[c], cell_lo[c + 1])
   uint32_t n;          // live bodies
   uint32_t levels;     // internal levels L >= 4; 4^L leaf cells
@@ -256,12 +257,13 @@ __device__ __forceinline__ void box_min_max(V3& lo, V3& hi, V3 l, V3 h) {
 
 // Bodies -> leaf records in cell order (counting sort, second half).
 __global__ __launch_bounds__(kBlock) void k_scatter_leaves(Lbvh T, const float4* fb_c, const float4* fb_r, const uint32_t* cell_of,
-                                                           const uint32_t* rank, uint32_t* brank) {
+                                                           const uint32_t* rank, uint32_t* brank, const float4* col0, const float4* delta) {
   uint32_t body = blockIdx.x * kBlock + threadIdx.x;
   if (body >= T.n) return;
   uint32_t p = T.cell_lo[cell_of[body]] + rank[body];
   LeafRec lr; lr.c = mk4(xyz(fb_c[body]), u2f(body)); lr.r = mk4(xyz(fb_r[body]), 0.0f);
   T.leaves[p] = lr;
+  if (T.lcol) { T.lcol[2 * p] = col0[body]; T.lcol[2 * p + 1] = delta[body]; }
   T.sidx[p] = body;
   brank[body] = p;  // position in cell order (the block-local solver groups bodies by it)
 }
@@ -663,6 +665,12 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_rows(Bodies B, uint32_t n, 
   }
 }
 
+__device__ __forceinline__ Comp load_comp(const Bodies& B, uint32_t i) {
+  float4 c0 = B.col0[i], c1 = B.col1[i];
+  Comp k; k.p = xyz(c0); k.r = c0.w; k.d = xyz(c1); k.kind = (int)f2u(c1.w);
+  return k;
+}
+
 // Partner bodies per body without a tree walk.  The leaf level of the Morton-cell tree IS a uniform grid: cell
 // (cx, cy, cz) is the 2L-bit Morton prefix of its interleaved coordinates, and cell_lo gives its bodies.
 // A body j can only be accepted by query i (tight_i overlaps fat_j) if its fat-box centre lies within
@@ -672,18 +680,27 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_rows(Bodies B, uint32_t n, 
 // lane per round.  Scenes whose largest body spans many cells raise `too_wide` and the host switches to the
 // tree walk (k_pair_rows) - the accepted set is the same either way (the reference's predicate on the leaf
 // records).
+// SPHERES (a world of spheres only): an accepted partner goes straight through the sphere-sphere narrowphase test
+// (the same function k_narrow_pairs runs) and only contacts are written to the row - a dense pile accepts ~11 partners
+// per body by their fat boxes and keeps ~2, so everything downstream of the rows handles a sixth of the entries.  The
+// accepted partners are still counted (World::step's candidate statistic): per wave into one of 64 words of pair_stat.
 constexpr uint32_t kGridMaxCells = 512;
+template <bool SPHERES>
 __global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, uint32_t n_owned, Lbvh T, const SceneBounds* sb, float pad_abs,
-                                                          uint32_t* rows_p, uint32_t* p_cnt, uint32_t* overflow, uint32_t* too_wide) {
+                                                          uint32_t* rows_p, uint32_t* p_cnt, uint32_t* overflow, uint32_t* too_wide,
+                                                          uint32_t* pair_stat) {
+  __shared__ uint32_t s_acc[SPHERES ? kCoopBlock / kCoopLanes : 1][SPHERES ? kRowCap : 1];  // accepted partners of a query (leaf positions)
   const int lane = threadIdx.x & 63;
   const int sub = lane & 7;
   const int gbase = lane & ~7;
   uint32_t kq = xcd_logical_block_coop() * (kCoopBlock / kCoopLanes) + (threadIdx.x >> 3);
-  if (kq >= n) return;  // whole group leaves together
-  uint32_t i = T.sidx[kq];
-  uint32_t np = 0;
-  if (i != 0 && T.n >= 2) {  // world.rs:256
+  const bool live = kq < n;  // whole groups are live or not
+  uint32_t i = live ? T.sidx[kq] : 0u;
+  uint32_t np = 0, n_accepted = 0;
+  if (live && i != 0 && T.n >= 2) {  // world.rs:256
     Box q; q.c = xyz(B.tb_c[i]); q.r = xyz(B.tb_r[i]);
+    Comp A; V3 vA = mk3(0, 0, 0);
+    if (SPHERES) { A = load_comp(B, i); A.kind = KIND_SPHERE; vA = xyz(B.delta[i]); }
     float pad = pad_abs + 1e-5f * (fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z);
     const uint32_t P = 2u * T.levels;
     const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};  // prefix bits per axis (x is the most significant)
@@ -726,22 +743,74 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, 
               Box fb; fb.c = xyz(lr.c); fb.r = xyz(lr.r);
               hit = box_overlaps(q, fb);  // the reference's own acceptance test (bvh.rs:297)
             }
+            if (SPHERES) j = p0;  // the row holds leaf positions until the second phase below
             ++p0;
           }
           unsigned long long hb = __ballot(hit);
           uint32_t gm = (uint32_t)(hb >> gbase) & 255u;
           if (hit) {
             uint32_t slot = np + __popc(gm & ((1u << sub) - 1u));
-            if (slot < (uint32_t)kRowCap) row[slot] = j;
+            if (slot < (uint32_t)kRowCap) {
+              if (SPHERES) s_acc[threadIdx.x >> 3][slot] = j;
+              else row[slot] = j;
+            }
           }
           np += __popc(gm);
         }
       }
+      if (SPHERES) {
+        // second phase: the accepted partners (staged in LDS), sixteen at a time - two per lane, so a typical query
+        // needs one round trip for its partners' records - through the sphere-sphere test; contacts go to the row
+        n_accepted = np;
+        if (np > (uint32_t)kRowCap) atomicOr(overflow, 1u);
+        const uint32_t na = min(np, (uint32_t)kRowCap);
+        const uint32_t* acc = s_acc[threadIdx.x >> 3];
+        uint32_t nc = 0;
+        for (uint32_t a0 = 0; a0 < na; a0 += 2 * kCoopLanes) {
+          bool hit[2] = {false, false};
+          uint32_t jj[2] = {0, 0};
+          float4 c0[2], d0[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const uint32_t a = a0 + (uint32_t)u * kCoopLanes + (uint32_t)sub;
+            const uint32_t pj = a < na ? acc[a] : 0u;
+            c0[u] = T.lcol[2 * pj]; d0[u] = T.lcol[2 * pj + 1];
+            jj[u] = T.sidx[pj];
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const uint32_t a = a0 + (uint32_t)u * kCoopLanes + (uint32_t)sub;
+            if (a < na) {
+              // cheap and conservative first: the centres never come closer than |d| - |v| during the tick
+              const V3 d = xyz(c0[u]) - A.p, v = xyz(d0[u]) - vA;
+              const float lim = A.r + c0[u].w + __builtin_sqrtf(dot(v, v));
+              if (dot(d, d) <= lim * lim * 1.001f) {
+                Comp Bc; Bc.kind = KIND_SPHERE; Bc.p = xyz(c0[u]); Bc.r = c0[u].w; Bc.d = mk3(0, 0, 0);
+                LocalContact lc;
+                hit[u] = comp_pair_local(A, vA, Bc, xyz(d0[u]), &lc);
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const uint32_t gm = (uint32_t)(__ballot(hit[u]) >> gbase) & 255u;
+            if (hit[u]) row[nc + __popc(gm & ((1u << sub) - 1u))] = jj[u];
+            nc += __popc(gm);
+          }
+        }
+        np = nc;
+      }
     }
   }
-  if (sub == 0) {
+  if (live && sub == 0) {
     p_cnt[i] = np;
-    if (np > (uint32_t)kRowCap) atomicOr(overflow, 1u);
+    if (!SPHERES && np > (uint32_t)kRowCap) atomicOr(overflow, 1u);
+  }
+  if (SPHERES) {  // accepted partners of the wave's 8 queries -> one atomic
+    uint32_t v = (live && sub == 0) ? n_accepted : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0 && v) atomicAdd(&pair_stat[(blockIdx.x * (kCoopBlock / 64) + (threadIdx.x >> 6)) & 63u], v);
   }
 }
 
@@ -887,11 +956,6 @@ __global__ __launch_bounds__(kBlock) void k_rows_to_csr(const StepCounts* sc, ui
 // ------------------------------------------------------------------------------------------
 struct NContact { float4 la, lb, n; };  // la.xyz + t, lb.xyz, n.xyz
 
-__device__ __forceinline__ Comp load_comp(const Bodies& B, uint32_t i) {
-  float4 c0 = B.col0[i], c1 = B.col1[i];
-  Comp k; k.p = xyz(c0); k.r = c0.w; k.d = xyz(c1); k.kind = (int)f2u(c1.w);
-  return k;
-}
 
 // work = nullptr: dense over [0, m); else the m candidate ids of this pair type.
 template <int KA, int KB>

@@ -170,11 +170,15 @@ struct mgf_mesh {
     DBuf<float4> fb_c, fb_r;
     DBuf<uint32_t> cell_of, cell_rank, cell_cnt, cell_lo, sidx, brank, rank_of_face, face_of_rank, leaf_of_face, parent;
     DBuf<LeafRec> leaves;
+  DBuf<float4> lcol;             // cell-ordered (collider, motion) copies for the fused sphere test of k_pair_grid
+  DBuf<uint32_t> pair_stat;      // 64 partial sums of the partners accepted by the fused broadphase
+  bool tick_fused = false;
+  int64_t opt_no_fused_narrowphase = 0;
     DBuf<SceneBounds> sb;
   } grid;
   FaceGrid face_grid() const {
     FaceGrid G;
-    G.T.nodes = nullptr; G.T.leaves = grid.leaves.p; G.T.sidx = grid.sidx.p; G.T.cell_lo = grid.cell_lo.p;
+    G.T.nodes = nullptr; G.T.leaves = grid.leaves.p; G.T.sidx = grid.sidx.p; G.T.cell_lo = grid.cell_lo.p; G.T.lcol = nullptr;
     G.T.n = grid.n_faces; G.T.levels = grid.levels; G.T.err = nullptr; G.T.dbg = nullptr;
     G.sb = grid.sb.p; G.rank_of_face = grid.rank_of_face.p; G.leaf_of_face = grid.leaf_of_face.p; G.parent = grid.parent.p;
     return G;
@@ -834,6 +838,10 @@ struct mgf_world {
   DBuf<uint32_t> cell_of, cell_rank, sidx;
   DBuf<QNode> lnodes;
   DBuf<LeafRec> leaves;
+  DBuf<float4> lcol;             // cell-ordered (collider, motion) copies for the fused sphere test of k_pair_grid
+  DBuf<uint32_t> pair_stat;      // 64 partial sums of the partners accepted by the fused broadphase
+  bool tick_fused = false;
+  int64_t opt_no_fused_narrowphase = 0;
   DBuf<float4> sub_lo, sub_hi, sub2_lo, sub2_hi;
   DBuf<uint32_t> cell_lo, cell_cnt;
   DBuf<uint32_t> t_cnt, p_cnt, t_off, p_off, t_cand, t_owner, p_cand, p_owner, rows, rows_t;
@@ -962,6 +970,7 @@ extern "C" mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_
   if (!strcmp(key, "flow5_poller")) { w->opt_flow5_poller = value < 0 ? -1 : (value ? 1 : 0); return MGF_OK; }
   if (!strcmp(key, "flow5_slow_x2")) { if (value < 1 || value > 16) return fail(MGF_ERR_INVALID, "flow5_slow_x2 out of range"); w->opt_flow5_slow_x2 = value; return MGF_OK; }
   if (!strcmp(key, "flow5_block")) { w->opt_flow5_block = value; w->flow5_prepped = false; return MGF_OK; }
+  if (!strcmp(key, "no_fused_narrowphase")) { w->opt_no_fused_narrowphase = value; return MGF_OK; }
   if (!strcmp(key, "stream_ordered")) { w->opt_stream_ordered = value; return MGF_OK; }
   if (!strcmp(key, "body_kinds")) {  // OR-in: kinds (bit0 sphere, bit1 capsule) that ghosts of this world may have
     if (value & 1) w->has_sphere = true;
@@ -1057,7 +1066,7 @@ static mgf_status build_face_grid(mgf_mesh* t) {
   LAUNCH_CHECK();
   MGF_TRY(prim_exclusive_scan_u32(ctx, G.cell_cnt.p, G.cell_lo.p, (size_t)cells + 1));
   FaceGrid FG = t->face_grid();
-  k_scatter_leaves<<<nblk(nf), kBlock, 0, s>>>(FG.T, G.fb_c.p, G.fb_r.p, G.cell_of.p, G.cell_rank.p, G.brank.p);
+  k_scatter_leaves<<<nblk(nf), kBlock, 0, s>>>(FG.T, G.fb_c.p, G.fb_r.p, G.cell_of.p, G.cell_rank.p, G.brank.p, nullptr, nullptr);
   LAUNCH_CHECK();
   MGF_HIP_TRY(hipStreamSynchronize(s));
   G.ready = true;
@@ -1397,7 +1406,7 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   MGF_TRY(w->t_cnt.ensure(n + 1, s)); MGF_TRY(w->p_cnt.ensure(n + 1, s)); MGF_TRY(w->t_off.ensure(n + 1, s)); MGF_TRY(w->p_off.ensure(n + 1, s));
   MGF_TRY(w->cons_nat.ensure(cap_c, s));
   MGF_TRY(links_ensure(w, cap_c));
-  MGF_TRY(w->degb.ensure(n + 1, s)); MGF_TRY(w->rev.ensure((size_t)n * w->rev_cap, s));
+  MGF_TRY(w->degb.ensure(n + 1, s)); MGF_TRY(w->rev.ensure((size_t)n * w->rev_cap, s)); MGF_TRY(w->pair_stat.ensure(64, s));
   {  // one launch clears every per-tick counter array
     ZeroList z;
     memset(&z, 0, sizeof(z));
@@ -1408,6 +1417,7 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
     z.p[4] = w->d_err() + 1; z.words[4] = 1;  // row-overflow flag (re-armed for a re-run inside the tick)
     z.p[5] = w->d_err() + 3; z.words[5] = 1;  // grid-too-wide flag
     z.p[6] = w->d_err() + 5; z.words[6] = 1;  // terrain-grid-too-wide flag
+    z.p[7] = w->pair_stat.p; z.words[7] = 64;
     k_zero_many<<<256, kBlock, 0, s>>>(z);
     LAUNCH_CHECK();
   }
@@ -1420,15 +1430,20 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   T.nodes = w->lnodes.p; T.leaves = w->leaves.p; T.sidx = w->sidx.p; T.cell_lo = w->cell_lo.p;
   T.n = n; T.levels = levels; T.err = w->d_err();
   T.dbg = nullptr;
+  const bool two_pass = w->opt_two_pass != 0 || w->tick_two_pass;
+  const bool use_grid = !two_pass && !w->opt_broadphase_tree && !w->grid_too_wide;
+  // a world of spheres: the grid broadphase runs the sphere-sphere test on the partners it accepts and lists contacts only
+  const bool fused = use_grid && !w->has_capsule && !w->opt_no_fused_narrowphase;
+  w->tick_fused = fused;
+  T.lcol = nullptr;
+  if (fused) { MGF_TRY(w->lcol.ensure(2 * (size_t)n, s)); T.lcol = w->lcol.p; }
   if (w->opt_debug_bvh) {
     MGF_TRY(w->dbg.ensure(4, s));
     MGF_HIP_TRY(hipMemsetAsync(w->dbg.p, 0, 32, s));
     T.dbg = w->dbg.p;
   }
-  k_scatter_leaves<<<nblk(n), kBlock, 0, s>>>(T, w->fb_c.p, w->fb_r.p, w->cell_of.p, w->cell_rank.p, w->brank.p);
+  k_scatter_leaves<<<nblk(n), kBlock, 0, s>>>(T, w->fb_c.p, w->fb_r.p, w->cell_of.p, w->cell_rank.p, w->brank.p, w->col0.p, w->delta.p);
   LAUNCH_CHECK();
-  const bool two_pass = w->opt_two_pass != 0 || w->tick_two_pass;
-  const bool use_grid = !two_pass && !w->opt_broadphase_tree && !w->grid_too_wide;
   if (!use_grid) {  // inner nodes are only needed by the tree walks
     k_lbvh_low<<<nblocks, kBlock, 0, s>>>(T, w->sub_lo.p, w->sub_hi.p);
     LAUNCH_CHECK();
@@ -1463,7 +1478,8 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
     {
       const uint32_t per_block = kCoopBlock / kCoopLanes;
       const uint32_t grid = 8 * (((n + per_block - 1) / per_block + 7) / 8);
-      if (use_grid) k_pair_grid<<<grid, kCoopBlock, 0, s>>>(B, n, w->n_owned, T, w->sb.p, 1e-3f, w->rows.p, w->p_cnt.p, w->d_err() + 1, w->d_err() + 3);
+      if (fused) k_pair_grid<true><<<grid, kCoopBlock, 0, s>>>(B, n, w->n_owned, T, w->sb.p, 1e-3f, w->rows.p, w->p_cnt.p, w->d_err() + 1, w->d_err() + 3, w->pair_stat.p);
+      else if (use_grid) k_pair_grid<false><<<grid, kCoopBlock, 0, s>>>(B, n, w->n_owned, T, w->sb.p, 1e-3f, w->rows.p, w->p_cnt.p, w->d_err() + 1, w->d_err() + 3, nullptr);
       else k_pair_rows<<<grid, kCoopBlock, 0, s>>>(B, n, w->n_owned, T, 1e-3f, w->rows.p, w->p_cnt.p, w->d_err() + 1);
       LAUNCH_CHECK();
     }
@@ -1540,6 +1556,7 @@ static mgf_status collide_finish(mgf_world* w, bool* retry) {
   MGF_HIP_TRY(hipMemcpyAsync(pin, w->sc.p, sizeof(StepCounts), hipMemcpyDeviceToHost, s));
   MGF_HIP_TRY(hipMemcpyAsync(pin + 32, w->sb.p, sizeof(SceneBounds), hipMemcpyDeviceToHost, s));
   MGF_HIP_TRY(hipMemcpyAsync(pin + 64, w->d_err(), 12, hipMemcpyDeviceToHost, s));
+  if (w->tick_fused) MGF_HIP_TRY(hipMemcpyAsync(pin + 96, w->pair_stat.p, 256, hipMemcpyDeviceToHost, s));
   MGF_HIP_TRY(hipStreamSynchronize(s));
   StepCounts h = *reinterpret_cast<StepCounts*>(pin);
   w->stats.n_refits = reinterpret_cast<SceneBounds*>(pin + 32)->n_refits;
@@ -1571,6 +1588,11 @@ static mgf_status collide_finish(mgf_world* w, bool* retry) {
   if ((uint64_t)h.need_C * 5 > (uint64_t)w->cap_c * 4) w->cap_c = grown(h.need_C);
   w->Mt = h.Mt; w->Mp = h.Mp; w->C = h.C; w->Ct = h.Ct;
   w->stats.n_terrain_candidates = h.Mt; w->stats.n_pair_candidates = h.Mp;
+  if (w->tick_fused) {  // the candidate lists hold contacts only; the accepted partners were counted on the way
+    uint64_t acc = 0;
+    for (int k = 0; k < 64; ++k) acc += pin[96 + k];
+    w->stats.n_pair_candidates = acc;
+  }
   w->stats.n_constraints = h.C; w->stats.n_terrain_constraints = h.Ct;
   w->constraints_ready = true;
   if (w->opt_debug_bvh) {

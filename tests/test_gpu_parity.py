@@ -283,6 +283,25 @@ def test_candidate_row_overflow_falls_back_exactly(ctx, force_two_pass):
     _compare_state(gw, ow, "crowded scene")
 
 
+def test_fused_sphere_filter_equals_the_separate_narrowphase(ctx):
+    """A world of spheres runs the sphere-sphere test inside the grid broadphase and lists contacts only; the candidate
+    statistic, the constraints and the state must equal the path that lists every accepted partner."""
+    import mgf_amd
+    from mgf_amd import scenes
+    scene = scenes.sphere_pile(12, 10, 12)
+    dt, iters = float(scene["dt"]), scene["iters"]
+    a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
+    b.set_option("no_fused_narrowphase", 1)
+    ow = oracle_world(scene)
+    for step in range(25):
+        sa, sb, so = a.step(dt, iters), b.step(dt, iters), ow.step(dt, iters)
+        assert (sa.n_constraints, sa.n_pair_candidates, sa.n_terrain_candidates) == (sb.n_constraints, sb.n_pair_candidates, sb.n_terrain_candidates)
+        assert sa.n_pair_candidates == so.n_pair_candidates and sa.n_constraints == so.n_constraints
+    assert sa.n_pair_candidates > 4 * (sa.n_constraints - sa.n_terrain_constraints) > 0  # most accepted partners are not contacts
+    compare_constraints(a.constraints(), b.constraints(), check_impulse=True)
+    _compare_state(a, ow, "fused sphere filter")
+
+
 def test_body_in_many_constraints_as_b_widens_its_row(ctx):
     """The big sphere has index 0, so it is body `b` of every contact with the 80 small ones: its row of `b`
     occurrences (16 ids to start with) overflows, the tick is re-run with wider rows, and the result is the oracle's."""
