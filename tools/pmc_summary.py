@@ -3,7 +3,8 @@
 MI355X_MICROARCH.md prescribes).  Counter unit: KiB.  On gfx950 FETCH_SIZE reads exactly 1/2 of a wide
 coalesced read stream (guide §HBM); both the raw and the x2-corrected read side are reported.
 
-    python tools/pmc_summary.py gpurun_out/pmc_fetch/pmc_counter_collection.csv gpurun_out/pmc_write/pmc_counter_collection.csv
+    python tools/pmc_summary.py gpurun_out/pmc_fetch/pmc_counter_collection.csv gpurun_out/pmc_write/pmc_counter_collection.csv [out.json]
+    (or the two pmc_results.db files of rocprofv3's default rocpd output)
 """
 import csv
 import json
@@ -13,6 +14,14 @@ from collections import defaultdict
 
 def load(path, counter):
     tot, cnt = defaultdict(float), defaultdict(int)
+    if path.endswith(".db"):  # rocprofv3's rocpd sqlite output (view counters_collection)
+        import sqlite3
+        db = sqlite3.connect(path)
+        for name, value in db.execute("select kernel_name, value from counters_collection where counter_name = ? order by start", (counter,)):
+            name = name.split("(")[0]
+            tot[name] += float(value)
+            cnt[name] += 1
+        return tot, cnt
     with open(path) as f:
         for row in csv.DictReader(f):
             if row["Counter_Name"] != counter:
