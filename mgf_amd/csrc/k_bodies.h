@@ -1,0 +1,157 @@
+// Resident body state, integration and the small per-tick helpers.  (Part of the kernel set described in kernels.h.)
+#pragma once
+#include <stddef.h>
+
+#include <type_traits>
+
+#include "dev_geom.h"
+#include "host_bvh.h"
+
+namespace mgf {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float4 ld4(const float4* p) { return *p; }
+__device__ __forceinline__ V3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
+__device__ __forceinline__ float4 mk4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+// Resident rigid-body state (RigidBodyVec, physics.rs:141-155), SoA of 16-byte words so every
+// streaming access is a coalesced dwordx4 per lane.
+struct Bodies {
+  float4* x;      // x.xyz, -
+  float4* q;      // s, v.xyz
+  float4* srec;   // 4 words/body, the record the solver gathers:
+                  //   [0] v.xyz, w.x   [1] w.y, w.z, inv_mass, I00   [2] I01 I02 I10 I11   [3] I12 I20 I21 I22
+                  //   (I = world inv_moment, column-major Icr)
+  float4* sp0;    // force.xyz, restitution
+  float4* sp1;    // torque.xyz, friction
+  float4* ctor;   // constructor: kind bits, r, half_h, -
+  float4* imb;    // 3 words/body: inv_moment_body columns
+  float4* delta;  // collider.1 (= v*dt), friction
+  float4* einfo;  // x + delta (RigidBodyInfo.x, physics.rs:282), restitution
+  float4* col0;   // collider shape: p.xyz, r
+  float4* col1;   //                 d.xyz, kind bits
+  float4* tb_c;   // tight swept AABB centre / half extents
+  float4* tb_r;
+  float4* fb_c;   // fat AABB (persistent; world.rs:181,237)
+  float4* fb_r;
+};
+
+struct SceneBounds { int lo[3]; int hi[3]; uint32_t n_refits; uint32_t pad; int rmax[3]; uint32_t pad2; };  // ordered-int encoded floats; rmax = largest fat half extent
+
+__device__ __forceinline__ int f_ord(float f) { int i = __builtin_bit_cast(int, f); return i >= 0 ? i : (i ^ 0x7FFFFFFF); }
+__host__ __device__ __forceinline__ float ord_f(int i) { int j = i >= 0 ? i : (i ^ 0x7FFFFFFF); return __builtin_bit_cast(float, j); }
+
+__device__ __forceinline__ M3 load_imb(const float4* imb, uint32_t i) {
+  float4 a = imb[3 * i], b = imb[3 * i + 1], c = imb[3 * i + 2];
+  return m3_cols(xyz(a), xyz(b), xyz(c));
+}
+
+// ------------------------------------------------------------------------------------------
+// complete_motion + integrate, one pass.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, float dt, float fat_margin, int do_complete,
+                                                      int do_integrate, SceneBounds* sb) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  bool live = i < n;
+  bool refit = false;
+  if (live) {
+    float4 xw = B.x[i];
+    float4 dl = B.delta[i];
+    V3 x = xyz(xw);
+    if (do_complete) x = x + xyz(dl);  // physics.rs:262-269
+    if (do_integrate) {
+      float4 qw = B.q[i];
+      float4 s0 = B.srec[4 * i], s1 = B.srec[4 * i + 1];
+      float4 p0 = B.sp0[i], p1 = B.sp1[i], ct = B.ctor[i];
+      V3 v = mk3(s0.x, s0.y, s0.z), w = mk3(s0.w, s1.x, s1.y);
+      float inv_mass = s1.z;
+      Quat q = mkq(qw.x, mk3(qw.y, qw.z, qw.w));
+      // physics.rs:226-227
+      q = normalize(q + mkq(0.0f, w * dt) * 0.5f * q);
+      // physics.rs:231-232
+      M3 R = m3_from_quat(q);
+      M3 I = R * load_imb(B.imb, i) * transpose(R);
+      // physics.rs:236, 240
+      v = v + xyz(p0) * inv_mass * dt;
+      w = w + I * xyz(p1) * dt;
+      // physics.rs:244-250
+      int kind = (int)f2u(ct.x);
+      Comp col = construct(kind, ct.y, ct.z, x, q);
+      V3 d = v * dt;
+      B.q[i] = make_float4(q.s, q.v.x, q.v.y, q.v.z);
+      B.srec[4 * i] = make_float4(v.x, v.y, v.z, w.x);
+      B.srec[4 * i + 1] = make_float4(w.y, w.z, inv_mass, I.c[0].x);
+      B.srec[4 * i + 2] = make_float4(I.c[0].y, I.c[0].z, I.c[1].x, I.c[1].y);
+      B.srec[4 * i + 3] = make_float4(I.c[1].z, I.c[2].x, I.c[2].y, I.c[2].z);
+      B.delta[i] = mk4(d, p1.w);
+      B.einfo[i] = mk4(x + d, p0.w);
+      B.col0[i] = mk4(col.p, col.r);
+      B.col1[i] = mk4(col.d, u2f((uint32_t)col.kind));
+      Box tb = swept_bounds(col, d);
+      B.tb_c[i] = mk4(tb.c, 0.0f);
+      B.tb_r[i] = mk4(tb.r, 0.0f);
+      Box fb; fb.c = xyz(B.fb_c[i]); fb.r = xyz(B.fb_r[i]);
+      if (!box_contains(fb, tb)) {  // world.rs:235-238
+        fb.c = tb.c;
+        fb.r = tb.r + mk3(fat_margin, fat_margin, fat_margin);
+        B.fb_c[i] = mk4(fb.c, 0.0f);
+        B.fb_r[i] = mk4(fb.r, 0.0f);
+        refit = true;
+      }
+    } else if (do_complete) {
+      B.einfo[i] = mk4(x + xyz(dl), B.einfo[i].w);
+    }
+    if (do_complete) B.x[i] = mk4(x, 0.0f);
+  }
+  if (!do_integrate || sb == nullptr) return;
+  // refit count: one atomic per block
+  int nref = __syncthreads_count(refit ? 1 : 0);
+  if (threadIdx.x == 0 && nref) atomicAdd(&sb->n_refits, (uint32_t)nref);
+}
+
+// Scene bounds of the fat-box centres (Morton quantisation): grid-stride, block reduce in LDS,
+// one atomic per block and axis.
+__global__ __launch_bounds__(kBlock) void k_scene_bounds(const float4* fb_c, const float4* fb_r, uint32_t n, SceneBounds* sb) {
+  int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  int rm[3] = {0, 0, 0};  // half extents are >= 0: plain int order
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    float4 c = fb_c[i], r = fb_r[i];
+    int o[3] = {f_ord(c.x), f_ord(c.y), f_ord(c.z)};
+    int e[3] = {f_ord(r.x), f_ord(r.y), f_ord(r.z)};
+    for (int k = 0; k < 3; ++k) { lo[k] = min(lo[k], o[k]); hi[k] = max(hi[k], o[k]); rm[k] = max(rm[k], e[k]); }
+  }
+  __shared__ int s_lo[3][kBlock / 64], s_hi[3][kBlock / 64], s_rm[3][kBlock / 64];
+  for (int k = 0; k < 3; ++k) {
+    int a = lo[k], b = hi[k], c = rm[k];
+    for (int off = 32; off > 0; off >>= 1) { a = min(a, __shfl_xor(a, off)); b = max(b, __shfl_xor(b, off)); c = max(c, __shfl_xor(c, off)); }
+    if ((threadIdx.x & 63) == 0) { s_lo[k][threadIdx.x >> 6] = a; s_hi[k][threadIdx.x >> 6] = b; s_rm[k][threadIdx.x >> 6] = c; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    int k = threadIdx.x, a = s_lo[k][0], b = s_hi[k][0], c = s_rm[k][0];
+    for (int w = 1; w < kBlock / 64; ++w) { a = min(a, s_lo[k][w]); b = max(b, s_hi[k][w]); c = max(c, s_rm[k][w]); }
+    atomicMin(&sb->lo[k], a);
+    atomicMax(&sb->hi[k], b);
+    atomicMax(&sb->rmax[k], c);
+  }
+}
+
+// RigidBodyInfo.x after a state write (physics.rs:282).
+__global__ __launch_bounds__(kBlock) void k_refresh_einfo(Bodies B, uint32_t n) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) B.einfo[i] = mk4(xyz(B.x[i]) + xyz(B.delta[i]), B.einfo[i].w);
+}
+__global__ void k_reset_step(SceneBounds* sb, uint32_t* err) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    for (int k = 0; k < 3; ++k) { sb->lo[k] = 0x7FFFFFFF; sb->hi[k] = (int)0x80000000; }
+    sb->n_refits = 0; sb->pad = 0; sb->pad2 = 0;
+    for (int k = 0; k < 3; ++k) sb->rmax[k] = 0;
+    err[0] = 0; err[1] = 0;  // traversal stack overflow, candidate row overflow
+  }
+}
+
+}  // namespace mgf

@@ -1,0 +1,775 @@
+// Broadphase: Morton cells, the implicit 4-ary tree over them, grid and tree queries, terrain rows, candidate lists.  (Part of the kernel set described in kernels.h.)
+#pragma once
+#include "k_bodies.h"
+
+namespace mgf {
+
+// ------------------------------------------------------------------------------------------
+// Linear BVH over the fat AABBs.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t expand10(uint32_t v) {
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+// 10-bit coordinate of the Morton code: monotone in v (the grid broadphase relies on that)
+__device__ __forceinline__ uint32_t morton_quant(float v, float lo, float hi) {
+  float ext = hi - lo;
+  float t = ext > 0.0f ? (v - lo) / ext : 0.0f;
+  int qv = (int)(t * 1023.0f);
+  return (uint32_t)(qv < 0 ? 0 : (qv > 1023 ? 1023 : qv));
+}
+// Counting sort of the bodies into Morton cells (a cell = one 2L-bit prefix of the 30-bit code): cell of every
+// body + its arrival rank inside the cell.  After a scan of the per-cell counts k_scatter_leaves places body i
+// at cell_lo[cell] + rank.  The order INSIDE a cell is arrival order (it varies from run to run); nothing
+// downstream depends on it - candidate rows are sorted by body index before they are used.
+__global__ __launch_bounds__(kBlock) void k_morton_count(const float4* fb_c, uint32_t n, const SceneBounds* sb, int shift, uint32_t* cell_of,
+                                                         uint32_t* rank, uint32_t* cell_cnt) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  V3 c = xyz(fb_c[i]);
+  uint32_t code = 0;
+  for (int k = 0; k < 3; ++k) code |= expand10(morton_quant(at(c, k), ord_f(sb->lo[k]), ord_f(sb->hi[k]))) << (2 - k);
+  uint32_t cell = code >> shift;
+  cell_of[i] = cell;
+  rank[i] = atomicAdd(&cell_cnt[cell], 1u);
+}
+
+// Zero several small arrays with one launch (instead of one fill kernel each).
+struct ZeroList { uint32_t* p[8]; uint32_t words[8]; };
+__global__ __launch_bounds__(kBlock) void k_zero_many(ZeroList z) {
+  for (int a = 0; a < 8; ++a) {
+    uint32_t* p = z.p[a];
+    if (!p) continue;
+    for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < z.words[a]; e += gridDim.x * kBlock) p[e] = 0u;
+  }
+}
+
+// Linear BVH as an implicit complete 4-ary tree over MORTON CELLS.  A leaf is the cell of one 2L-bit
+// Morton prefix (an axis-aligned region of the scene) and owns the contiguous range of sorted bodies
+// whose key has that prefix; internal nodes are shorter prefixes, so every node is a spatial region
+// by construction and its box (union of the contained fat boxes) stays compact however the bodies
+// move.  An internal node stores the boxes of its four children (128 bytes: one fetch decides four
+// subtrees); last-level nodes also carry their children's body ranges in the .w words.  Level l
+// holds 4^l nodes at heap offset (4^l - 1) / 3; node k's children are 4k+1 .. 4k+4.  Built by plain
+// reductions (no atomics, no fences); traversed with a register-only bitmask trail; top levels in LDS.
+struct QNode { float4 lo[4], hi[4]; };     // child c: min = lo[c].xyz, max = hi[c].xyz; last level: lo.w = first body, hi.w = end
+struct LeafRec { float4 c, r; };           // fat box centre | body index, half extents (sorted order)
+struct Lbvh {
+  QNode* nodes;        // (4^levels - 1) / 3 internal nodes
+  LeafRec* leaves;     // n records in Morton order
+  uint32_t* sidx;      // body index of every leaf record
+  float4* lcol;        // optional, 2 per leaf record: collider (p.xyz, r) and motion (delta.xyz) of the body (k_pair_grid<true>)
+  uint32_t* cell_lo;   // 4^levels + 1 entries: cell c holds the leaf records [cell_lo[c], cell_lo[c + 1])
+  uint32_t n;          // live bodies
+  uint32_t levels;     // internal levels L >= 4; 4^L leaf cells
+  uint32_t* err;
+  unsigned long long* dbg;  // optional: [0] node fetches, [1] leaf records tested, [2] max fetches of one query
+};
+constexpr int kLdsQNodes = 341;  // levels 0..4 (1 + 4 + 16 + 64 + 256 nodes), 43 KB
+constexpr int kMortonBits = 30;
+__host__ __device__ __forceinline__ uint32_t qlevel_offset(uint32_t l) { return ((1u << (2 * l)) - 1u) / 3u; }
+
+__device__ __forceinline__ void box_min_max(V3& lo, V3& hi, V3 l, V3 h) {
+  lo = mk3(fminf(lo.x, l.x), fminf(lo.y, l.y), fminf(lo.z, l.z));
+  hi = mk3(fmaxf(hi.x, h.x), fmaxf(hi.y, h.y), fmaxf(hi.z, h.z));
+}
+
+// Bodies -> leaf records in cell order (counting sort, second half).
+__global__ __launch_bounds__(kBlock) void k_scatter_leaves(Lbvh T, const float4* fb_c, const float4* fb_r, const uint32_t* cell_of,
+                                                           const uint32_t* rank, uint32_t* brank, const float4* col0, const float4* delta) {
+  uint32_t body = blockIdx.x * kBlock + threadIdx.x;
+  if (body >= T.n) return;
+  uint32_t p = T.cell_lo[cell_of[body]] + rank[body];
+  LeafRec lr; lr.c = mk4(xyz(fb_c[body]), u2f(body)); lr.r = mk4(xyz(fb_r[body]), 0.0f);
+  T.leaves[p] = lr;
+  if (T.lcol) { T.lcol[2 * p] = col0[body]; T.lcol[2 * p + 1] = delta[body]; }
+  T.sidx[p] = body;
+  brank[body] = p;  // position in cell order (the block-local solver groups bodies by it)
+}
+
+// One block per 256 consecutive cells: the 4 internal levels above them.
+// Block b owns the subtree rooted at level L-4, index b; its union box goes to sub_lo/sub_hi[b].
+__global__ __launch_bounds__(kBlock) void k_lbvh_low(Lbvh T, float4* sub_lo, float4* sub_hi) {
+  __shared__ float s_lo[3][kBlock], s_hi[3][kBlock];
+  __shared__ uint32_t s_rng[2][kBlock];
+  const int t = threadIdx.x;
+  uint32_t g = blockIdx.x * kBlock + t;
+  V3 lo = mk3(kInf, kInf, kInf), hi = mk3(-kInf, -kInf, -kInf);
+  uint32_t b0 = T.cell_lo[g], b1 = T.cell_lo[g + 1];
+  for (uint32_t p = b0; p < b1; ++p) {
+    LeafRec lr = T.leaves[p];
+    box_min_max(lo, hi, xyz(lr.c) - xyz(lr.r), xyz(lr.c) + xyz(lr.r));
+  }
+  s_lo[0][t] = lo.x; s_lo[1][t] = lo.y; s_lo[2][t] = lo.z;
+  s_hi[0][t] = hi.x; s_hi[1][t] = hi.y; s_hi[2][t] = hi.z;
+  s_rng[0][t] = b0; s_rng[1][t] = b1;
+  __syncthreads();
+  // widths 64, 16, 4, 1 at levels L-1 .. L-4
+  uint32_t lvl = T.levels;
+  uint32_t first = blockIdx.x * kBlock;  // index of this block's first entry within the level below
+  for (int w = kBlock / 4; w >= 1; w >>= 2) {
+    lvl -= 1;
+    first >>= 2;
+    QNode nd;
+    V3 ulo = mk3(kInf, kInf, kInf), uhi = mk3(-kInf, -kInf, -kInf);
+    if (t < w) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        V3 l = mk3(s_lo[0][4 * t + c], s_lo[1][4 * t + c], s_lo[2][4 * t + c]);
+        V3 h = mk3(s_hi[0][4 * t + c], s_hi[1][4 * t + c], s_hi[2][4 * t + c]);
+        bool leaf_level = (w == kBlock / 4);
+        nd.lo[c] = mk4(l, leaf_level ? u2f(s_rng[0][4 * t + c]) : 0.0f);
+        nd.hi[c] = mk4(h, leaf_level ? u2f(s_rng[1][4 * t + c]) : 0.0f);
+        box_min_max(ulo, uhi, l, h);
+      }
+      T.nodes[qlevel_offset(lvl) + first + t] = nd;
+    }
+    __syncthreads();
+    if (t < w) {
+      s_lo[0][t] = ulo.x; s_lo[1][t] = ulo.y; s_lo[2][t] = ulo.z;
+      s_hi[0][t] = uhi.x; s_hi[1][t] = uhi.y; s_hi[2][t] = uhi.z;
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    sub_lo[blockIdx.x] = make_float4(s_lo[0][0], s_lo[1][0], s_lo[2][0], 0.0f);
+    sub_hi[blockIdx.x] = make_float4(s_hi[0][0], s_hi[1][0], s_hi[2][0], 0.0f);
+  }
+}
+// Single block: levels L-5 .. 0 above the per-block subtree roots (4^(L-4) of them), ping-ponging the
+// per-node union boxes between two scratch arrays.
+__global__ __launch_bounds__(1024) void k_lbvh_top(Lbvh T, float4* a_lo, float4* a_hi, float4* b_lo, float4* b_hi) {
+  uint32_t m = 1u << (2 * (T.levels - 4));  // entries in a_lo/a_hi
+  for (int lvl = (int)T.levels - 5; lvl >= 0; --lvl) {
+    uint32_t w = m >> 2;
+    for (uint32_t e = threadIdx.x; e < w; e += blockDim.x) {
+      QNode nd;
+      V3 ulo = mk3(kInf, kInf, kInf), uhi = mk3(-kInf, -kInf, -kInf);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float4 l = a_lo[4 * e + c], h = a_hi[4 * e + c];
+        nd.lo[c] = l; nd.hi[c] = h;
+        box_min_max(ulo, uhi, xyz(l), xyz(h));
+      }
+      T.nodes[qlevel_offset((uint32_t)lvl) + e] = nd;
+      b_lo[e] = mk4(ulo, 0.0f); b_hi[e] = mk4(uhi, 0.0f);
+    }
+    __syncthreads();
+    float4* t;
+    t = a_lo; a_lo = b_lo; b_lo = t;
+    t = a_hi; a_hi = b_hi; b_hi = t;
+    m = w;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Candidate generation: for body i, terrain faces (mesh BVH, reference DFS order) and partner
+// bodies j < i whose fat AABB overlaps i's tight swept AABB (world.rs:240-290).
+// ------------------------------------------------------------------------------------------
+struct TerrainDev {
+  const DevNode* nodes;   // flattened reference-faithful mesh BVH (host_bvh.h)
+  const float4* verts;    // mesh.verts
+  const uint4* faces;     // mesh.faces (a, b, c, -)
+  uint32_t root;
+  uint32_t n_nodes;       // 0 = no terrain
+  float x[3];             // mesh.x
+  uint32_t* err;          // set to 1 if a traversal stack overflows
+};
+
+constexpr int kStack = 32;  // reference-built trees are AVL-balanced: depth <= 1.44 log2(faces)
+
+// bvh.rs:283-310 with the reference's order: push lchild, push rchild, pop rchild first.
+template <class F>
+__device__ __forceinline__ void terrain_traverse(const TerrainDev& M, const Box& q, F&& emit) {
+  if (M.n_nodes == 0) return;
+  uint32_t stack[kStack];
+  int sp = 0;
+  stack[sp++] = M.root;
+  while (sp > 0) {
+    uint32_t top = stack[--sp];
+    const float4* raw = reinterpret_cast<const float4*>(&M.nodes[top]);
+    float4 n0 = raw[0], n1 = raw[1];
+    Box nb; nb.c = xyz(n0); nb.r = xyz(n1);
+    if (box_overlaps(q, nb)) {
+      uint32_t w0 = f2u(n0.w), w1 = f2u(n1.w);
+      if (w0 & 0x80000000u) emit(w0 & 0x7FFFFFFFu);
+      else if (sp + 2 <= kStack) { stack[sp++] = w0; stack[sp++] = w1; }
+      else if (M.err) *M.err = 1u;
+    }
+  }
+}
+
+// Depth-first traversal of the implicit 4-ary tree with a bitmask trail (4 pending-child bits per level)
+// instead of a stack.  `top` = LDS copy of nodes [0, kLdsQNodes).
+template <class F>
+__device__ __forceinline__ void lbvh_traverse(const Lbvh& T, const QNode* top, uint32_t i, const Box& q, float pad_abs, F&& emit) {
+  if (T.n < 2) return;  // a single body has no partner
+  // Inner nodes hold min/max unions: test them against a query padded well past f32 rounding so the
+  // exact (centre, half-extent) acceptance test at the leaves is never pre-empted.
+  float pad = pad_abs + 1e-5f * (fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z);
+  V3 qlo = q.c - q.r - mk3(pad, pad, pad), qhi = q.c + q.r + mk3(pad, pad, pad);
+  const int last = (int)T.levels - 1;
+  uint64_t trail = 0;
+  uint32_t k = 0;
+  int lvl = 0;
+  bool fresh = true;
+  uint32_t dbg_nodes = 0, dbg_leaves = 0;
+  for (;;) {
+    uint32_t m;
+    if (fresh) {
+      ++dbg_nodes;
+      const QNode* nd = (k < (uint32_t)kLdsQNodes) ? &top[k] : &T.nodes[k];
+      m = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float4 lo = nd->lo[c], hi = nd->hi[c];
+        bool ov = qlo.x <= hi.x && lo.x <= qhi.x && qlo.y <= hi.y && lo.y <= qhi.y && qlo.z <= hi.z && lo.z <= qhi.z;
+        m |= ov ? (1u << c) : 0u;
+      }
+    } else {
+      m = (uint32_t)(trail >> (4 * lvl)) & 15u;
+    }
+    if (m) {
+      int c = __builtin_ctz(m);
+      m &= m - 1;
+      trail = (trail & ~(15ull << (4 * lvl))) | ((uint64_t)m << (4 * lvl));
+      if (lvl == last) {
+        // child c is a Morton cell: its body range rides in the node's .w words
+        const QNode* nd = (k < (uint32_t)kLdsQNodes) ? &top[k] : &T.nodes[k];
+        uint32_t p0 = f2u(nd->lo[c].w), p1 = f2u(nd->hi[c].w);
+        dbg_leaves += p1 - p0;
+        for (uint32_t pb = p0; pb < p1; pb += 4) {
+          LeafRec lr[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lr[e] = T.leaves[min(pb + e, p1 - 1)];  // independent loads in flight together
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            uint32_t j = f2u(lr[e].c.w);
+            if (pb + e < p1 && j < i) {  // world.rs:266
+              Box fb; fb.c = xyz(lr[e].c); fb.r = xyz(lr[e].r);
+              if (box_overlaps(q, fb)) emit(j);  // the reference's own acceptance test (bvh.rs:297)
+            }
+          }
+        }
+        fresh = false;
+        continue;
+      }
+      k = 4 * k + 1 + (uint32_t)c;
+      ++lvl;
+      fresh = true;
+      continue;
+    }
+    if (lvl == 0) break;
+    k = (k - 1) >> 2;
+    --lvl;
+    fresh = false;
+  }
+  if (T.dbg) {
+    atomicAdd(&T.dbg[0], (unsigned long long)dbg_nodes);
+    atomicAdd(&T.dbg[1], (unsigned long long)dbg_leaves);
+    atomicMax(&T.dbg[2], (unsigned long long)dbg_nodes);
+  }
+}
+
+// Sizes of the tick's variable-length lists, kept on the device so that the host can enqueue the whole
+// tick without reading them back: buffers and grids are sized from host-side capacities (last tick's
+// sizes plus slack), kernels take the real sizes from here.  If a capacity turns out too small the
+// effective sizes become 0 (every later kernel of the tick is a no-op), `fail` says why, and the host
+// grows the buffers and re-runs the collide phase.
+struct StepCounts {
+  uint32_t Mt, Mp, C, Ct;                      // effective: terrain / pair candidates, constraints, terrain constraints
+  uint32_t fail;                               // kFail* bits
+  uint32_t need_Mt, need_Mp, need_C, need_Ct;  // actual sizes (valid up to the first failing stage)
+  uint32_t bins[6];                            // candidates per shape-pair type (scenes mixing spheres and capsules)
+  uint32_t ct_sum;                             // terrain constraints, accumulated by k_count_contacts (zeroed by k_caps_candidates)
+};
+constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u, kFailGridWide = 8u, kFailTerrainRow = 16u, kFailTerrainWide = 32u,
+                   kFailRevRow = 64u;  // a body's row of `b` occurrences overflowed (k_setup_pairs / k_chain_rows)
+
+__global__ void k_caps_candidates(const uint32_t* mt, const uint32_t* mp, uint32_t cap_t, uint32_t cap_p, const uint32_t* row_overflow,
+                                  const uint32_t* grid_wide, const uint32_t* terrain_wide, StepCounts* sc) {
+  StepCounts r;
+  r.need_Mt = *mt; r.need_Mp = *mp; r.need_C = 0; r.need_Ct = 0;
+  r.fail = 0;
+  if (r.need_Mt > cap_t || r.need_Mp > cap_p) r.fail |= kFailCandCap;
+  if (row_overflow && (*row_overflow & 1u)) r.fail |= kFailRowOverflow;
+  if (row_overflow && (*row_overflow & 2u)) r.fail |= kFailTerrainRow;
+  if (grid_wide && *grid_wide) r.fail |= kFailGridWide;
+  if (terrain_wide && *terrain_wide) r.fail |= kFailTerrainWide;
+  r.Mt = r.fail ? 0u : r.need_Mt; r.Mp = r.fail ? 0u : r.need_Mp; r.C = 0; r.Ct = 0;
+  for (int k = 0; k < 6; ++k) r.bins[k] = 0;
+  r.ct_sum = 0;
+  *sc = r;
+}
+__global__ void k_caps_constraints(const uint32_t* c, const uint32_t* ct, uint32_t cap_c, StepCounts* sc) {
+  if (sc->fail) return;
+  sc->need_C = *c; sc->need_Ct = *ct;
+  if (*c > cap_c) { sc->fail |= kFailConsCap; sc->Mt = 0; sc->Mp = 0; sc->C = 0; sc->Ct = 0; return; }
+  sc->C = *c; sc->Ct = *ct;
+}
+
+// XCD-aware query mapping: workgroup b is observed to run on XCD b % 8, each with a private 4 MB L2.
+// Give XCD x the x-th contiguous eighth of the Morton-ordered queries, so the part of the tree it
+// walks (a spatial eighth of the scene) stays resident in its own L2.  Launch xcd_grid(n) blocks.
+__host__ __device__ __forceinline__ uint32_t xcd_blocks_per(uint32_t n) { return ((n + kBlock - 1) / kBlock + 7) / 8; }
+__device__ __forceinline__ uint32_t xcd_logical_block() { return (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3); }
+
+// FILL = false: count hits per body.  FILL = true: write them (CSR), partners sorted ascending.
+// Bodies [n_owned, n) are ghosts (copies of a neighbouring tile's bodies): they query the tree like
+// any body, but their terrain contacts and ghost-ghost pairs belong to their owner tile.
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void k_candidates(Bodies B, uint32_t n, uint32_t n_owned, Lbvh T, TerrainDev M, float pad,
+                                                       uint32_t* t_cnt, uint32_t* p_cnt, const uint32_t* t_off,
+                                                       const uint32_t* p_off, uint32_t* t_cand, uint32_t* t_owner,
+                                                       uint32_t* p_cand, uint32_t* p_owner, const StepCounts* sc) {
+  __shared__ QNode s_top[kLdsQNodes];
+  if (FILL && sc->fail) return;
+  {
+    uint32_t total = qlevel_offset(T.levels);
+    uint32_t lim = T.n >= 2 ? min((uint32_t)kLdsQNodes, total) : 0u;
+    const float4* src = reinterpret_cast<const float4*>(T.nodes);
+    float4* dst = reinterpret_cast<float4*>(s_top);
+    for (uint32_t e = threadIdx.x; e < lim * 8u; e += kBlock) dst[e] = src[e];
+    __syncthreads();
+  }
+  uint32_t k = xcd_logical_block() * kBlock + threadIdx.x;
+  if (k >= n) return;
+  uint32_t i = T.n >= 1 ? T.sidx[k] : k;  // walk bodies in Morton order: neighbouring lanes share tree paths
+  Box q; q.c = xyz(B.tb_c[i]); q.r = xyz(B.tb_r[i]);
+  // terrain: Mesh::contacts queries bounds - mesh.x (mesh.rs:121)
+  Box qm = q; qm.c = q.c + -mk3(M.x[0], M.x[1], M.x[2]);
+  uint32_t nt = 0, np = 0;
+  uint32_t tb = FILL ? t_off[i] : 0, pb = FILL ? p_off[i] : 0;
+  if (i < n_owned) {
+    terrain_traverse(M, qm, [&](uint32_t face) {
+      if (FILL) { t_cand[tb + nt] = face; t_owner[tb + nt] = i; }
+      ++nt;
+    });
+  }
+  if (i != 0) {  // world.rs:256
+    lbvh_traverse(T, s_top, i, q, pad, [&](uint32_t j) {
+      if (j >= n_owned) return;  // ghost-ghost: the owners' business
+      if (FILL) { p_cand[pb + np] = j; p_owner[pb + np] = i; }
+      ++np;
+    });
+  }
+  if (!FILL) { t_cnt[i] = nt; p_cnt[i] = np; return; }
+  // canonical partner order: ascending j (insertion sort, segments are ~10 long)
+  for (uint32_t a = 1; a < np; ++a) {
+    uint32_t v = p_cand[pb + a];
+    uint32_t b = a;
+    while (b > 0 && p_cand[pb + b - 1] > v) { p_cand[pb + b] = p_cand[pb + b - 1]; --b; }
+    p_cand[pb + b] = v;
+  }
+}
+
+// Single-pass candidate generation into fixed-capacity global rows (the common case); bodies with more
+// hits than a row holds raise `overflow` and the host re-runs the exact two-pass path (k_candidates).
+constexpr int kRowCap = 48;   // partner row (a settled pile has bodies with > 32 fat-box neighbours)
+constexpr int kRowCapT = 16;  // terrain row: initial capacity; the host doubles it (up to kRowCapTMax) when a body overflows
+constexpr int kRowCapTMax = 128;
+
+// Terrain faces per body, reference DFS order (mesh.rs:121, bvh.rs:283-310).  One lane per body.
+__global__ __launch_bounds__(kBlock) void k_terrain_rows(Bodies B, uint32_t n_owned, TerrainDev M, uint32_t cap_row, uint32_t* rows_t,
+                                                         uint32_t* t_cnt, uint32_t* overflow) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_owned) return;
+  Box q; q.c = xyz(B.tb_c[i]) + -mk3(M.x[0], M.x[1], M.x[2]); q.r = xyz(B.tb_r[i]);
+  uint32_t* row = rows_t + (size_t)i * cap_row;
+  uint32_t nt = 0;
+  terrain_traverse(M, q, [&](uint32_t face) {
+    if (nt < cap_row) row[nt] = face;
+    ++nt;
+  });
+  t_cnt[i] = nt;
+  if (nt > cap_row) atomicOr(overflow, 2u);  // bit 1: a terrain row, bit 0: a partner row
+}
+
+// Partner bodies per body: cooperative traversal, 8 lanes per query.  A 4-ary node is eight 16-byte
+// words (lo[0..3], hi[0..3]); lane s of the group loads word s, so a node costs ONE cache-line lookup
+// per query instead of eight per lane (the per-lane form is bound by L1 tag lookups once neighbouring
+// queries stop walking in lock-step).  Lanes 0-3 test child s against the query (hi comes from lane
+// s+4 by shuffle), a ballot yields the 4-bit child mask, and the traversal state (node, level, trail)
+// is replicated in the group's lanes so its control flow stays uniform.  Leaf cells: lane pairs load
+// one 32-byte record each (4 records per step).
+constexpr int kCoopLanes = 8;
+constexpr int kCoopBlock = 512;                 // 64 queries per block
+constexpr int kCoopLdsNodes = 85;               // levels 0..3 staged in LDS (10.9 KB)
+__device__ __forceinline__ uint32_t xcd_logical_block_coop() { return (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3); }
+
+__global__ __launch_bounds__(kCoopBlock) void k_pair_rows(Bodies B, uint32_t n, uint32_t n_owned, Lbvh T, float pad_abs, uint32_t* rows_p,
+                                                          uint32_t* p_cnt, uint32_t* overflow) {
+  __shared__ float4 s_top[kCoopLdsNodes * 8];
+  {
+    uint32_t total = qlevel_offset(T.levels);
+    uint32_t lim = T.n >= 2 ? min((uint32_t)kCoopLdsNodes, total) : 0u;
+    const float4* src = reinterpret_cast<const float4*>(T.nodes);
+    for (uint32_t e = threadIdx.x; e < lim * 8u; e += kCoopBlock) s_top[e] = src[e];
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7;
+  const int gbase = lane & ~7;
+  uint32_t kq = xcd_logical_block_coop() * (kCoopBlock / kCoopLanes) + (threadIdx.x >> 3);
+  if (kq >= n) return;  // whole group leaves together
+  uint32_t i = T.sidx[kq];  // Morton order: neighbouring groups walk neighbouring subtrees
+  uint32_t np = 0;
+  if (i != 0 && T.n >= 2) {  // world.rs:256
+    Box q; q.c = xyz(B.tb_c[i]); q.r = xyz(B.tb_r[i]);
+    float pad = pad_abs + 1e-5f * (fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z);
+    V3 qlo = q.c - q.r - mk3(pad, pad, pad), qhi = q.c + q.r + mk3(pad, pad, pad);
+    uint32_t* row = rows_p + (size_t)i * kRowCap;
+    const float4* gnodes = reinterpret_cast<const float4*>(T.nodes);
+    const float4* gleaves = reinterpret_cast<const float4*>(T.leaves);
+    const int last = (int)T.levels - 1;
+    uint64_t trail = 0;
+    uint32_t k = 0;
+    int lvl = 0;
+    bool fresh = true;
+    float4 v = make_float4(0, 0, 0, 0);  // this lane's word of the current node
+    for (;;) {
+      uint32_t m;
+      if (fresh) {
+        v = (k < (uint32_t)kCoopLdsNodes) ? s_top[k * 8 + sub] : gnodes[(size_t)k * 8 + sub];
+        // lanes 0-3: lo[sub]; their hi[sub] sits in lane sub + 4
+        float hx = __shfl(v.x, gbase + (sub & 3) + 4), hy = __shfl(v.y, gbase + (sub & 3) + 4), hz = __shfl(v.z, gbase + (sub & 3) + 4);
+        bool ov = sub < 4 && qlo.x <= hx && v.x <= qhi.x && qlo.y <= hy && v.y <= qhi.y && qlo.z <= hz && v.z <= qhi.z;
+        unsigned long long bal = __ballot(ov);
+        m = (uint32_t)(bal >> gbase) & 15u;
+      } else {
+        m = (uint32_t)(trail >> (4 * lvl)) & 15u;
+      }
+      if (m) {
+        int c = __builtin_ctz(m);
+        m &= m - 1;
+        trail = (trail & ~(15ull << (4 * lvl))) | ((uint64_t)m << (4 * lvl));
+        if (lvl == last) {
+          // child c is a Morton cell; its body range rides in the .w words of lo[c] / hi[c]
+          uint32_t p0 = f2u(__shfl(v.w, gbase + c)), p1 = f2u(__shfl(v.w, gbase + c + 4));
+          for (uint32_t pb = p0; pb < p1; pb += 4) {
+            uint32_t rec = min(pb + (uint32_t)(sub >> 1), p1 - 1);
+            float4 w = gleaves[(size_t)rec * 2 + (sub & 1)];  // even lane: centre | body, odd lane: half extents
+            float rx = __shfl(w.x, lane | 1), ry = __shfl(w.y, lane | 1), rz = __shfl(w.z, lane | 1);
+            uint32_t j = f2u(w.w);
+            bool hit = false;
+            if (!(sub & 1) && pb + (uint32_t)(sub >> 1) < p1 && j < i && j < n_owned) {  // world.rs:266; ghost-ghost skipped
+              Box fb; fb.c = xyz(w); fb.r = mk3(rx, ry, rz);
+              hit = box_overlaps(q, fb);  // the reference's own acceptance test (bvh.rs:297)
+            }
+            unsigned long long hb = __ballot(hit);
+            uint32_t gm = (uint32_t)(hb >> gbase) & 255u;
+            if (hit) {
+              uint32_t slot = np + __popc(gm & ((1u << sub) - 1u));
+              if (slot < (uint32_t)kRowCap) row[slot] = j;
+            }
+            np += __popc(gm);
+          }
+          fresh = false;
+          continue;
+        }
+        k = 4 * k + 1 + (uint32_t)c;
+        ++lvl;
+        fresh = true;
+        continue;
+      }
+      if (lvl == 0) break;
+      k = (k - 1) >> 2;
+      --lvl;
+      fresh = false;
+    }
+  }
+  if (sub == 0) {
+    p_cnt[i] = np;
+    if (np > (uint32_t)kRowCap) atomicOr(overflow, 1u);
+  }
+}
+
+__device__ __forceinline__ Comp load_comp(const Bodies& B, uint32_t i) {
+  float4 c0 = B.col0[i], c1 = B.col1[i];
+  Comp k; k.p = xyz(c0); k.r = c0.w; k.d = xyz(c1); k.kind = (int)f2u(c1.w);
+  return k;
+}
+
+// Partner bodies per body without a tree walk.  The leaf level of the Morton-cell tree IS a uniform grid: cell
+// (cx, cy, cz) is the 2L-bit Morton prefix of its interleaved coordinates, and cell_lo gives its bodies.
+// A body j can only be accepted by query i (tight_i overlaps fat_j) if its fat-box centre lies within
+// tight_i grown by the largest fat half extent of the scene (SceneBounds::rmax), so the query enumerates the
+// cells of that region directly: ~50 independent 8-byte look-ups and as many independent leaf records, two
+// dependent memory round trips instead of the ~30 of the top-down walk.  8 lanes share a query, one cell per
+// lane per round.  Scenes whose largest body spans many cells raise `too_wide` and the host switches to the
+// tree walk (k_pair_rows) - the accepted set is the same either way (the reference's predicate on the leaf
+// records).
+// SPHERES (a world of spheres only): an accepted partner goes straight through the sphere-sphere narrowphase test
+// (the same function k_narrow_pairs runs) and only contacts are written to the row - a dense pile accepts ~11 partners
+// per body by their fat boxes and keeps ~2, so everything downstream of the rows handles a sixth of the entries.  The
+// accepted partners are still counted (World::step's candidate statistic): per wave into one of 64 words of pair_stat.
+constexpr uint32_t kGridMaxCells = 512;
+template <bool SPHERES>
+__global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, uint32_t n_owned, Lbvh T, const SceneBounds* sb, float pad_abs,
+                                                          uint32_t* rows_p, uint32_t* p_cnt, uint32_t* overflow, uint32_t* too_wide,
+                                                          uint32_t* pair_stat) {
+  __shared__ uint32_t s_acc[SPHERES ? kCoopBlock / kCoopLanes : 1][SPHERES ? kRowCap : 1];  // accepted partners of a query (leaf positions)
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7;
+  const int gbase = lane & ~7;
+  uint32_t kq = xcd_logical_block_coop() * (kCoopBlock / kCoopLanes) + (threadIdx.x >> 3);
+  const bool live = kq < n;  // whole groups are live or not
+  uint32_t i = live ? T.sidx[kq] : 0u;
+  uint32_t np = 0, n_accepted = 0;
+  if (live && i != 0 && T.n >= 2) {  // world.rs:256
+    Box q; q.c = xyz(B.tb_c[i]); q.r = xyz(B.tb_r[i]);
+    Comp A; V3 vA = mk3(0, 0, 0);
+    if (SPHERES) { A = load_comp(B, i); A.kind = KIND_SPHERE; vA = xyz(B.delta[i]); }
+    float pad = pad_abs + 1e-5f * (fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z);
+    const uint32_t P = 2u * T.levels;
+    const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};  // prefix bits per axis (x is the most significant)
+    uint32_t ca[3], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float lo = ord_f(sb->lo[k]), hi = ord_f(sb->hi[k]), rm = ord_f(sb->rmax[k]);
+      float a = at(q.c, k) - at(q.r, k) - rm - pad, b = at(q.c, k) + at(q.r, k) + rm + pad;
+      uint32_t c0 = morton_quant(a, lo, hi) >> (10u - nb[k]), c1 = morton_quant(b, lo, hi) >> (10u - nb[k]);
+      ca[k] = c0; d[k] = c1 - c0 + 1u;
+    }
+    const uint32_t ncell = d[0] * d[1] * d[2];
+    if (ncell > kGridMaxCells) {
+      if (sub == 0) *too_wide = 1u;
+    } else {
+      uint32_t* row = rows_p + (size_t)i * kRowCap;
+      const int shift = kMortonBits - (int)P;
+      for (uint32_t cb = 0; cb < ncell; cb += kCoopLanes) {
+        uint32_t idx = cb + (uint32_t)sub;
+        uint32_t p0 = 0, p1 = 0;
+        if (idx < ncell) {
+          uint32_t cz = idx % d[2], t = idx / d[2];
+          uint32_t cy = t % d[1], cx = t / d[1];
+          uint32_t code = (expand10((ca[0] + cx) << (10u - nb[0])) << 2) | (expand10((ca[1] + cy) << (10u - nb[1])) << 1) |
+                          expand10((ca[2] + cz) << (10u - nb[2]));
+          uint32_t cell = code >> shift;
+          p0 = T.cell_lo[cell]; p1 = T.cell_lo[cell + 1];
+        }
+        // every lane walks its own cell's bodies; the group stays together for the ballots
+        for (;;) {
+          bool more = p0 < p1;
+          unsigned long long mb = __ballot(more);
+          if (((uint32_t)(mb >> gbase) & 255u) == 0u) break;
+          bool hit = false;
+          uint32_t j = 0;
+          if (more) {
+            LeafRec lr = T.leaves[p0];
+            j = f2u(lr.c.w);
+            if (j < i && j < n_owned) {  // world.rs:266; ghost-ghost skipped
+              Box fb; fb.c = xyz(lr.c); fb.r = xyz(lr.r);
+              hit = box_overlaps(q, fb);  // the reference's own acceptance test (bvh.rs:297)
+            }
+            if (SPHERES) j = p0;  // the row holds leaf positions until the second phase below
+            ++p0;
+          }
+          unsigned long long hb = __ballot(hit);
+          uint32_t gm = (uint32_t)(hb >> gbase) & 255u;
+          if (hit) {
+            uint32_t slot = np + __popc(gm & ((1u << sub) - 1u));
+            if (slot < (uint32_t)kRowCap) {
+              if (SPHERES) s_acc[threadIdx.x >> 3][slot] = j;
+              else row[slot] = j;
+            }
+          }
+          np += __popc(gm);
+        }
+      }
+      if (SPHERES) {
+        // second phase: the accepted partners (staged in LDS), sixteen at a time - two per lane, so a typical query
+        // needs one round trip for its partners' records - through the sphere-sphere test; contacts go to the row
+        n_accepted = np;
+        if (np > (uint32_t)kRowCap) atomicOr(overflow, 1u);
+        const uint32_t na = min(np, (uint32_t)kRowCap);
+        const uint32_t* acc = s_acc[threadIdx.x >> 3];
+        uint32_t nc = 0;
+        for (uint32_t a0 = 0; a0 < na; a0 += 2 * kCoopLanes) {
+          bool hit[2] = {false, false};
+          uint32_t jj[2] = {0, 0};
+          float4 c0[2], d0[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const uint32_t a = a0 + (uint32_t)u * kCoopLanes + (uint32_t)sub;
+            const uint32_t pj = a < na ? acc[a] : 0u;
+            c0[u] = T.lcol[2 * pj]; d0[u] = T.lcol[2 * pj + 1];
+            jj[u] = T.sidx[pj];
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const uint32_t a = a0 + (uint32_t)u * kCoopLanes + (uint32_t)sub;
+            if (a < na) {
+              // cheap and conservative first: the centres never come closer than |d| - |v| during the tick
+              const V3 d = xyz(c0[u]) - A.p, v = xyz(d0[u]) - vA;
+              const float lim = A.r + c0[u].w + __builtin_sqrtf(dot(v, v));
+              if (dot(d, d) <= lim * lim * 1.001f) {
+                Comp Bc; Bc.kind = KIND_SPHERE; Bc.p = xyz(c0[u]); Bc.r = c0[u].w; Bc.d = mk3(0, 0, 0);
+                LocalContact lc;
+                hit[u] = comp_pair_local(A, vA, Bc, xyz(d0[u]), &lc);
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const uint32_t gm = (uint32_t)(__ballot(hit[u]) >> gbase) & 255u;
+            if (hit[u]) row[nc + __popc(gm & ((1u << sub) - 1u))] = jj[u];
+            nc += __popc(gm);
+          }
+        }
+        np = nc;
+      }
+    }
+  }
+  if (live && sub == 0) {
+    p_cnt[i] = np;
+    if (!SPHERES && np > (uint32_t)kRowCap) atomicOr(overflow, 1u);
+  }
+  if (SPHERES) {  // accepted partners of the wave's 8 queries -> one atomic
+    uint32_t v = (live && sub == 0) ? n_accepted : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0 && v) atomicAdd(&pair_stat[(blockIdx.x * (kCoopBlock / 64) + (threadIdx.x >> 6)) & 63u], v);
+  }
+}
+
+// Terrain faces per body without walking the reference tree.  A static mesh gets the same Morton-cell grid as the
+// bodies (cells over the face boxes, built once per set_terrain); a query enumerates the cells its box can reach,
+// applies Mesh::contacts' own acceptance test (query overlaps the face's leaf bounds, bvh.rs:297) and - because the
+// reference only reaches a leaf through its ancestors - re-checks the ancestors' boxes for hits that are within
+// rounding distance of not overlapping (an ancestor box is the union of its children up to f32 rounding, so a clear
+// overlap with the leaf implies an overlap with every ancestor).  Hits are stored as DFS RANKS: BVH::query reports
+// leaves in one fixed order whatever it prunes (HostBvh::dfs_ranks), so sorting a body's row by rank restores the
+// reference's callback order.  Meshes whose faces span many cells raise `too_wide`; the host then uses the tree walk.
+struct FaceGrid {
+  Lbvh T;                      // cells over the face boxes: leaves[].c.w = face id
+  const SceneBounds* sb;
+  const uint32_t* rank_of_face;
+  const uint32_t* leaf_of_face;  // node id of the face's leaf in the reference tree
+  const uint32_t* parent;        // per node of the reference tree
+};
+__global__ __launch_bounds__(kCoopBlock) void k_terrain_grid(Bodies B, uint32_t n_owned, const uint32_t* order, TerrainDev M, FaceGrid G,
+                                                             float pad_abs, uint32_t cap_row, uint32_t* rows_t, uint32_t* t_cnt,
+                                                             uint32_t* overflow, uint32_t* too_wide) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7;
+  const int gbase = lane & ~7;
+  uint32_t kq = xcd_logical_block_coop() * (kCoopBlock / kCoopLanes) + (threadIdx.x >> 3);
+  if (kq >= n_owned) return;  // whole group leaves together
+  uint32_t i = order ? order[kq] : kq;
+  if (i >= n_owned) {  // cell order runs over owned + ghost bodies: ghosts have no terrain row
+    return;
+  }
+  Box q; q.c = xyz(B.tb_c[i]) + -mk3(M.x[0], M.x[1], M.x[2]); q.r = xyz(B.tb_r[i]);
+  float mag = fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z;
+  float pad = pad_abs + 1e-5f * mag;
+  const uint32_t P = 2u * G.T.levels;
+  const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};
+  uint32_t ca[3], d[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float lo = ord_f(G.sb->lo[k]), hi = ord_f(G.sb->hi[k]), rm = ord_f(G.sb->rmax[k]);
+    float a = at(q.c, k) - at(q.r, k) - rm - pad, b = at(q.c, k) + at(q.r, k) + rm + pad;
+    uint32_t c0 = morton_quant(a, lo, hi) >> (10u - nb[k]), c1 = morton_quant(b, lo, hi) >> (10u - nb[k]);
+    ca[k] = c0; d[k] = c1 - c0 + 1u;
+  }
+  const uint32_t ncell = d[0] * d[1] * d[2];
+  uint32_t nt = 0;
+  if (ncell > kGridMaxCells) {
+    if (sub == 0) *too_wide = 1u;
+  } else {
+    uint32_t* row = rows_t + (size_t)i * cap_row;
+    const int shift = kMortonBits - (int)P;
+    for (uint32_t cb = 0; cb < ncell; cb += kCoopLanes) {
+      uint32_t idx = cb + (uint32_t)sub;
+      uint32_t p0 = 0, p1 = 0;
+      if (idx < ncell) {
+        uint32_t cz = idx % d[2], t = idx / d[2];
+        uint32_t cy = t % d[1], cx = t / d[1];
+        uint32_t code = (expand10((ca[0] + cx) << (10u - nb[0])) << 2) | (expand10((ca[1] + cy) << (10u - nb[1])) << 1) |
+                        expand10((ca[2] + cz) << (10u - nb[2]));
+        uint32_t cell = code >> shift;
+        p0 = G.T.cell_lo[cell]; p1 = G.T.cell_lo[cell + 1];
+      }
+      for (;;) {
+        bool more = p0 < p1;
+        unsigned long long mb = __ballot(more);
+        if (((uint32_t)(mb >> gbase) & 255u) == 0u) break;
+        bool hit = false;
+        uint32_t rank = 0;
+        if (more) {
+          LeafRec lr = G.T.leaves[p0];
+          uint32_t face = f2u(lr.c.w);
+          Box fb; fb.c = xyz(lr.c); fb.r = xyz(lr.r);
+          if (box_overlaps(q, fb)) {  // the reference's acceptance test at the leaf (bvh.rs:297)
+            hit = true;
+            // by how much?  a clear overlap needs no ancestor check
+            float gap = fmin_rs(fmin_rs(q.r.x + fb.r.x - fabs_rs(q.c.x - fb.c.x), q.r.y + fb.r.y - fabs_rs(q.c.y - fb.c.y)),
+                                q.r.z + fb.r.z - fabs_rs(q.c.z - fb.c.z));
+            float tol = 1e-4f * (mag + fabs_rs(fb.c.x) + fabs_rs(fb.c.y) + fabs_rs(fb.c.z) + fb.r.x + fb.r.y + fb.r.z);
+            if (!(gap > tol)) {
+              uint32_t node = G.leaf_of_face[face];
+              while (node != M.root) {
+                node = G.parent[node];
+                const float4* raw = reinterpret_cast<const float4*>(&M.nodes[node]);
+                Box nbx; nbx.c = xyz(raw[0]); nbx.r = xyz(raw[1]);
+                if (!box_overlaps(q, nbx)) { hit = false; break; }
+              }
+            }
+            rank = G.rank_of_face[face];
+          }
+          ++p0;
+        }
+        unsigned long long hb = __ballot(hit);
+        uint32_t gm = (uint32_t)(hb >> gbase) & 255u;
+        if (hit) {
+          uint32_t slot = nt + __popc(gm & ((1u << sub) - 1u));
+          if (slot < cap_row) row[slot] = rank;
+        }
+        nt += __popc(gm);
+      }
+    }
+  }
+  if (sub == 0) {
+    t_cnt[i] = nt;
+    if (nt > cap_row) atomicOr(overflow, 2u);
+  }
+}
+
+// rows -> CSR (terrain and partner candidate lists with their owners)
+// (canonical insertion order).
+__global__ __launch_bounds__(kBlock) void k_rows_to_csr(const StepCounts* sc, uint32_t n, uint32_t cap_row_t, const uint32_t* face_of_rank,
+                                                        const uint32_t* rows_t, const uint32_t* rows_p,
+                                                        const uint32_t* t_off, const uint32_t* p_off, uint32_t* t_cand, uint32_t* t_owner,
+                                                        uint32_t* p_cand, uint32_t* p_owner) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n || sc->fail) return;
+  uint32_t tb = t_off[i], nt = t_off[i + 1] - tb, pb = p_off[i], np = p_off[i + 1] - pb;
+  if (nt > cap_row_t || np > (uint32_t)kRowCap) return;  // overflowed body: the host re-runs with wider rows or the two-pass path
+  const uint32_t* rt = rows_t + (size_t)i * cap_row_t;
+  const uint4* rp = reinterpret_cast<const uint4*>(rows_p + (size_t)i * kRowCap);  // rows are 16-byte aligned (kRowCap % 4 == 0)
+  if (face_of_rank) {  // the row holds DFS ranks in discovery order: sort, then name the faces
+    for (uint32_t a = 0; a < nt; ++a) {
+      uint32_t x = rt[a];
+      uint32_t b = a;
+      while (b > 0 && t_cand[tb + b - 1] > x) { t_cand[tb + b] = t_cand[tb + b - 1]; --b; }
+      t_cand[tb + b] = x;
+    }
+    for (uint32_t a = 0; a < nt; ++a) { t_cand[tb + a] = face_of_rank[t_cand[tb + a]]; t_owner[tb + a] = i; }
+  } else {
+    for (uint32_t a = 0; a < nt; ++a) { t_cand[tb + a] = rt[a]; t_owner[tb + a] = i; }
+  }
+  // partners stay in discovery order: only the few that turn into contacts need the canonical (ascending) order, and
+  // k_count_contacts numbers those by partner id
+  for (uint32_t a = 0; a < np; a += 4) {
+    uint4 v = rp[a >> 2];
+    uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (a + k < np) { p_cand[pb + a + k] = e[k]; p_owner[pb + a + k] = i; }
+  }
+}
+
+}  // namespace mgf

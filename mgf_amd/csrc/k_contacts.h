@@ -1,0 +1,293 @@
+// Narrowphase per shape-pair type, contact numbering, ContactConstraint records and their setup.  (Part of the kernel set described in kernels.h.)
+#pragma once
+#include "k_broadphase.h"
+
+namespace mgf {
+
+// ------------------------------------------------------------------------------------------
+// Narrowphase, one kernel per shape-pair type.  Output per candidate: contact count and the
+// LocalContact reduced to what Manifold/ContactConstraint::new consume (local_a, local_b, n).
+// ------------------------------------------------------------------------------------------
+struct NContact { float4 la, lb, n; };  // la.xyz + t, lb.xyz, n.xyz
+
+
+// work = nullptr: dense over [0, m); else the m candidate ids of this pair type.
+template <int KA, int KB>
+__global__ __launch_bounds__(kBlock) void k_narrow_pairs(Bodies B, const uint32_t* work, const uint32_t* m_ptr, const uint32_t* p_owner,
+                                                         const uint32_t* p_cand, uint32_t* p_nc, NContact* p_out) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= *m_ptr) return;
+  uint32_t p = work ? work[t] : t;
+  uint32_t i = p_owner[p], j = p_cand[p];
+  Comp A = load_comp(B, i), Bc = load_comp(B, j);
+  A.kind = KA; Bc.kind = KB;  // compile-time dispatch: the list holds only this pair type
+  V3 vA = xyz(B.delta[i]), vB = xyz(B.delta[j]);
+  LocalContact lc;
+  bool hit = comp_pair_local(A, vA, Bc, vB, &lc);
+  p_nc[p] = hit ? 1u : 0u;
+  if (hit) {
+    // ContactPruner::push on an empty pruner keeps the contact (manifold.rs:73-79);
+    // Manifold::from(pruner): normal = (0 + n) / 1 (manifold.rs:135-140)
+    V3 nrm = (mk3(0.0f, 0.0f, 0.0f) + lc.g.n) / 1.0f;
+    NContact o; o.la = mk4(lc.la, lc.g.t); o.lb = mk4(lc.lb, 0.0f); o.n = mk4(nrm, 0.0f);
+    p_out[p] = o;
+  }
+}
+
+template <int KA>
+__global__ __launch_bounds__(kBlock) void k_narrow_terrain(Bodies B, TerrainDev M, const uint32_t* work, const uint32_t* m_ptr,
+                                                           const uint32_t* t_owner, const uint32_t* t_cand, uint32_t* t_nc,
+                                                           NContact* t_out /* 2 per candidate */) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= *m_ptr) return;
+  uint32_t p = work ? work[t] : t;
+  uint32_t i = t_owner[p], f = t_cand[p];
+  Comp A = load_comp(B, i);
+  A.kind = KA;
+  V3 vA = xyz(B.delta[i]);
+  uint4 fi = M.faces[f];
+  V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
+  Triangle tri = mkt(xyz(M.verts[fi.x]) + mx, xyz(M.verts[fi.y]) + mx, xyz(M.verts[fi.z]) + mx);  // mesh.rs:122-126
+  LocalContact lc[2];
+  int nc = comp_tri_local(A, vA, tri, mx, lc);
+  t_nc[p] = (uint32_t)nc;
+  for (int k = 0; k < nc; ++k) {
+    NContact o; o.la = mk4(lc[k].la, lc[k].g.t); o.lb = mk4(lc[k].lb, 0.0f); o.n = mk4(lc[k].g.n, 0.0f);  // Manifold::from(lc) manifold.rs:120-128
+    t_out[2 * p + k] = o;
+  }
+}
+
+// Bin candidate ids by pair type (only launched for scenes that mix spheres and capsules).
+__global__ __launch_bounds__(kBlock) void k_bin_pairs(Bodies B, const uint32_t* m_ptr, uint32_t stride, const uint32_t* p_owner,
+                                                      const uint32_t* p_cand, uint32_t* lists /* 4 x stride */, uint32_t* counts /* 4 */) {
+  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t m = *m_ptr;
+  int type = -1;
+  if (p < m) type = (int)(f2u(B.col1[p_owner[p]].w) * 2u + f2u(B.col1[p_cand[p]].w));
+  for (int ty = 0; ty < 4; ++ty) {  // wave-aggregated append: one atomic per wave per type
+    unsigned long long mask = __ballot(type == ty);
+    if (mask == 0) continue;
+    uint32_t base = 0;
+    int lane = threadIdx.x & 63;
+    int leader = __ffsll((long long)mask) - 1;
+    if (lane == leader) base = atomicAdd(&counts[ty], (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (type == ty) lists[(size_t)ty * stride + base + __popcll(mask & ((1ull << lane) - 1ull))] = p;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_bin_terrain(Bodies B, const uint32_t* m_ptr, uint32_t stride, const uint32_t* t_owner,
+                                                        uint32_t* lists /* 2 x stride */, uint32_t* counts /* 2 */) {
+  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t m = *m_ptr;
+  int type = -1;
+  if (p < m) type = (int)f2u(B.col1[t_owner[p]].w);
+  for (int ty = 0; ty < 2; ++ty) {
+    unsigned long long mask = __ballot(type == ty);
+    if (mask == 0) continue;
+    uint32_t base = 0;
+    int lane = threadIdx.x & 63;
+    int leader = __ffsll((long long)mask) - 1;
+    if (lane == leader) base = atomicAdd(&counts[ty], (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (type == ty) lists[(size_t)ty * stride + base + __popcll(mask & ((1ull << lane) - 1ull))] = p;
+  }
+}
+
+// Per body: number of constraints it inserts (terrain contacts first, then partners) and the
+// running offset of each candidate inside the body's block.
+__global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint32_t n, const uint32_t* t_off, const uint32_t* p_off,
+                                                           const uint32_t* t_nc, const uint32_t* p_nc, const uint32_t* p_cand, uint32_t* t_pre,
+                                                           uint32_t* p_pre, uint32_t* cnt) {
+  constexpr int kHitCap = 12;  // a sphere touches at most 12 equal ones
+  __shared__ uint32_t s_j[kHitCap][kBlock], s_p[kHitCap][kBlock];
+  const int tid = threadIdx.x;
+  __shared__ uint32_t s_ct;
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (tid == 0) s_ct = 0;
+  __syncthreads();
+  bool active = i < n;
+  if (active && sc->fail) { cnt[i] = 0; active = false; }
+  if (active) {
+  uint32_t run = 0;
+  for (uint32_t p = t_off[i]; p < t_off[i + 1]; ++p) { t_pre[p] = run; run += t_nc[p]; }
+  if (run) atomicAdd(&s_ct, run);  // only the total is needed: one global atomic per block
+  // partner contacts are numbered in ascending partner order (the canonical insertion order); the candidate list itself
+  // is in discovery order, and only a few of its ~10 entries are contacts (at most one per partner): collect them, then
+  // rank them among themselves
+  const uint32_t lo = p_off[i], hi = p_off[i + 1];
+  uint32_t h = 0;
+  for (uint32_t base = lo; base < hi; base += 4) {  // four counts per round trip
+    uint32_t nc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) nc[k] = base + k < hi ? p_nc[base + k] : 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (nc[k]) {
+        if (h < (uint32_t)kHitCap) { s_j[h][tid] = p_cand[base + k]; s_p[h][tid] = base + k; }
+        ++h;
+      }
+    }
+  }
+  if (h <= (uint32_t)kHitCap) {
+    for (uint32_t a = 0; a < h; ++a) {
+      const uint32_t j = s_j[a][tid];
+      uint32_t before = 0;
+      for (uint32_t q = 0; q < h; ++q) before += s_j[q][tid] < j ? 1u : 0u;
+      p_pre[s_p[a][tid]] = run + before;
+    }
+  } else {  // a crowded body: the same by rescanning its list
+    for (uint32_t p = lo; p < hi; ++p) {
+      if (p_nc[p] == 0) continue;
+      const uint32_t j = p_cand[p];
+      uint32_t before = 0;
+      for (uint32_t q = lo; q < hi; ++q) before += (p_cand[q] < j) ? p_nc[q] : 0u;
+      p_pre[p] = run + before;
+    }
+  }
+  cnt[i] = run + h;
+  }
+  __syncthreads();
+  if (tid == 0 && s_ct) atomicAdd(&sc->ct_sum, s_ct);
+}
+
+// ------------------------------------------------------------------------------------------
+// ContactConstraint (solver.rs:82-93, 256-262), single contact.  96-byte record.
+// ------------------------------------------------------------------------------------------
+struct CRec {
+  uint32_t a, b;       // body indices; b = kNone for RigidBodyRef::Static
+  float n[3], t0[3], t1[3], ra[3], rb[3];
+  float bias, nmass, tmass0, tmass1;
+  uint32_t pad0;
+  float nimp;          // ContactState::normal_impulse            (word 22: 8-byte aligned with round)
+  uint32_t round;      // solver iterations already applied in the current Solver::solve call (launch-per-frontier mode)
+  uint32_t pad1;
+  uint32_t indeg;      // predecessors still pending for the next round (atomics; launch-per-frontier mode)
+  uint32_t pad2;
+  float friction;      // dead state in the reference (solver.rs:223-226), kept for read-back
+  uint32_t pad3[4];
+};
+// Dependency links live outside the records, in compact arrays (ConsLinks): building them touches 4-16 bytes per
+// constraint instead of a 128-byte line.
+struct ConsLinks {
+  uint2* ab;           // (a, b) of every constraint
+  uint2* succ;         // successor words on body a / body b (see k_chain)
+  uint8_t* pred;       // pred[2c + role] = 1 if the constraint has a predecessor on that body inside one iteration
+};
+static_assert(sizeof(CRec) == 128, "CRec is one 128-byte line");
+
+struct BodyDyn { V3 v, w; float im; M3 I; };
+__device__ __forceinline__ BodyDyn load_dyn(const float4* srec, uint32_t i) {
+  float4 s0 = srec[4 * i], s1 = srec[4 * i + 1], s2 = srec[4 * i + 2], s3 = srec[4 * i + 3];
+  BodyDyn d;
+  d.v = mk3(s0.x, s0.y, s0.z); d.w = mk3(s0.w, s1.x, s1.y); d.im = s1.z;
+  d.I = m3_cols(mk3(s1.w, s2.x, s2.y), mk3(s2.z, s2.w, s3.x), mk3(s3.y, s3.z, s3.w));
+  return d;
+}
+__device__ __forceinline__ BodyDyn static_dyn() {  // physics.rs:289-302
+  BodyDyn d; d.v = mk3(0, 0, 0); d.w = mk3(0, 0, 0); d.im = 0.0f;
+  d.I = m3_cols(mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0));
+  return d;
+}
+__device__ __forceinline__ void st3(float* p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+__device__ __forceinline__ V3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
+// ContactConstraint::new solver.rs:101-191 for one contact.
+__device__ __forceinline__ CRec make_constraint(uint32_t ia, uint32_t ib, const BodyDyn& A, V3 xa, float rest_a, float fric_a,
+                                                const BodyDyn& Bd, V3 xb, float rest_b, float fric_b, V3 normal, V3 ra, V3 rb,
+                                                float dt, float baumgarte, float slop) {
+  CRec c;
+  c.a = ia; c.b = ib;
+  float restitution = fmax_rs(rest_a, rest_b);
+  c.friction = __builtin_sqrtf(fric_a * fric_b);
+  V3 t0, t1;
+  compute_basis(normal, &t0, &t1);  // manifold.rs:125,144
+  V3 ca = ra + xa, cb = rb + xb;
+  V3 ra_cn = cross(ra, normal), rb_cn = cross(rb, normal);
+  float pen = dot(cb - ca, normal);
+  V3 dv = Bd.v + cross(Bd.w, rb) - A.v - cross(A.w, ra);
+  float rel_v = dot(dv, normal);
+  float bias = -baumgarte / dt * (pen > 0.0f ? 0.0f : pen + slop) + (rel_v < -1.0f ? -restitution * rel_v : 0.0f);
+  c.nmass = 1.0f / (A.im + dot(ra_cn, A.I * ra_cn) + Bd.im + dot(rb_cn, Bd.I * rb_cn));
+  V3 ra_ct = cross(ra, t0), rb_ct = cross(rb, t0);
+  c.tmass0 = 1.0f / (A.im + dot(ra_ct, A.I * ra_ct) + Bd.im + dot(rb_ct, Bd.I * rb_ct));
+  ra_ct = cross(ra, t1); rb_ct = cross(rb, t1);
+  c.tmass1 = 1.0f / (A.im + dot(ra_ct, A.I * ra_ct) + Bd.im + dot(rb_ct, Bd.I * rb_ct));
+  c.bias = bias;
+  c.nimp = 0.0f;
+  c.round = 0; c.indeg = 0; c.pad0 = c.pad1 = c.pad2 = 0;
+  c.pad3[0] = c.pad3[1] = c.pad3[2] = c.pad3[3] = 0;
+  st3(c.n, normal); st3(c.t0, t0); st3(c.t1, t1); st3(c.ra, ra); st3(c.rb, rb);
+  return c;
+}
+
+__device__ __forceinline__ void store_crec(CRec* dst, const CRec& c) {
+  const float4* s = reinterpret_cast<const float4*>(&c);
+  float4* d = reinterpret_cast<float4*>(dst);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) d[k] = s[k];
+}
+// the whole 128-byte line
+__device__ __forceinline__ CRec load_crec(const CRec* src) {
+  CRec c;
+  const float4* s = reinterpret_cast<const float4*>(src);
+  float4* d = reinterpret_cast<float4*>(&c);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) d[k] = s[k];
+  return c;
+}
+static_assert(offsetof(CRec, nimp) == 88 && offsetof(CRec, round) == 92 && offsetof(CRec, indeg) == 100, "CRec layout");
+// what ContactConstraint::solve reads: the first 96 bytes (through nimp / round)
+__device__ __forceinline__ CRec load_crec_solve(const CRec* src) {
+  CRec c;
+  const float4* s = reinterpret_cast<const float4*>(src);
+  float4* d = reinterpret_cast<float4*>(&c);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d[k] = s[k];
+  d[6] = make_float4(0, 0, 0, 0); d[7] = make_float4(0, 0, 0, 0);
+  return c;
+}
+
+__global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCounts* sc, const uint32_t* p_owner, const uint32_t* p_cand,
+                                                        const uint32_t* p_nc, const uint32_t* p_pre, const NContact* p_in,
+                                                        const uint32_t* base, float dt, float baumgarte, float slop,
+                                                        CRec* cons, uint2* ab, uint32_t* degb, uint32_t* rev, uint32_t rev_cap,
+                                                        uint32_t* rev_flag) {
+  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= sc->Mp || p_nc[p] == 0) return;
+  uint32_t i = p_owner[p], j = p_cand[p];
+  uint32_t c = base[i] + p_pre[p];
+  NContact k = p_in[p];
+  BodyDyn A = load_dyn(B.srec, i), Bd = load_dyn(B.srec, j);
+  float4 ea = B.einfo[i], eb = B.einfo[j];
+  CRec r = make_constraint(i, j, A, xyz(ea), ea.w, B.delta[i].w, Bd, xyz(eb), eb.w, B.delta[j].w, xyz(k.n), xyz(k.la), xyz(k.lb),
+                           dt, baumgarte, slop);
+  store_crec(&cons[c], r);
+  ab[c] = make_uint2(i, j);
+  // body j's row of the constraints it takes part in as `b` (k_chain_rows); as `a` a body owns a contiguous id range
+  uint32_t pos = atomicAdd(&degb[j], 1u);
+  if (pos < rev_cap) rev[(size_t)j * rev_cap + pos] = c;
+  else *rev_flag = 1u;
+}
+
+__global__ __launch_bounds__(kBlock) void k_setup_terrain(Bodies B, TerrainDev M, const StepCounts* sc, const uint32_t* t_owner,
+                                                          const uint32_t* t_nc, const uint32_t* t_pre, const NContact* t_in,
+                                                          const uint32_t* base, float dt, float baumgarte, float slop, CRec* cons,
+                                                          uint2* ab) {
+  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= sc->Mt) return;
+  uint32_t nc = t_nc[p];
+  if (nc == 0) return;
+  uint32_t i = t_owner[p];
+  BodyDyn A = load_dyn(B.srec, i), S = static_dyn();
+  float4 ea = B.einfo[i];
+  V3 center = mk3(M.x[0], M.x[1], M.x[2]);  // Static{ center: terrain.center(), friction: 0.0 } world.rs:247
+  for (uint32_t k = 0; k < nc; ++k) {
+    NContact in = t_in[2 * p + k];
+    CRec r = make_constraint(i, kNone, A, xyz(ea), ea.w, B.delta[i].w, S, center, 0.0f, 0.0f, xyz(in.n), xyz(in.la), xyz(in.lb), dt,
+                             baumgarte, slop);
+    store_crec(&cons[base[i] + t_pre[p] + k], r);
+    ab[base[i] + t_pre[p] + k] = make_uint2(i, kNone);
+  }
+}
+
+}  // namespace mgf

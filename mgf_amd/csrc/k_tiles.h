@@ -1,0 +1,177 @@
+// Spatial tiling: boundary selection, ghost and migrant records.  (Part of the kernel set described in kernels.h.)
+#pragma once
+#include "k_solver_flow.h"
+
+namespace mgf {
+
+// ------------------------------------------------------------------------------------------
+// Spatial tiling (one process per GPU): boundary selection, ghost export / import.
+// Ghost record, 36 floats: x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction.
+// ------------------------------------------------------------------------------------------
+constexpr int kGhostFloats = 36;
+
+// flags[i] bit0: owned body i's fat box reaches below x_left; bit1: above x_right.
+__global__ __launch_bounds__(kBlock) void k_boundary_flags(Bodies B, uint32_t n_owned, float x_left, float x_right, uint32_t* fl,
+                                                           uint32_t* fr) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i > n_owned) return;
+  uint32_t l = 0, r = 0;
+  if (i < n_owned) {
+    float c = B.fb_c[i].x, h = B.fb_r[i].x;
+    l = (c - h < x_left) ? 1u : 0u;
+    r = (c + h > x_right) ? 1u : 0u;
+  }
+  fl[i] = l; fr[i] = r;  // slot n_owned = 0 so the exclusive scan yields the total there
+}
+__global__ __launch_bounds__(kBlock) void k_boundary_scatter(uint32_t n_owned, const uint32_t* fl, const uint32_t* sl, const uint32_t* fr,
+                                                             const uint32_t* sr, uint32_t* ids_l, uint32_t* ids_r) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_owned) return;
+  if (fl[i]) ids_l[sl[i]] = i;
+  if (fr[i]) ids_r[sr[i]] = i;
+}
+__global__ __launch_bounds__(kBlock) void k_export_bodies(Bodies B, const uint32_t* ids, uint32_t m, float* out) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= m) return;
+  uint32_t i = ids[t];
+  float* o = out + (size_t)t * kGhostFloats;
+  float4 x = B.x[i], q = B.q[i], s0 = B.srec[4 * i], s1 = B.srec[4 * i + 1], s2 = B.srec[4 * i + 2], s3 = B.srec[4 * i + 3];
+  float4 d = B.delta[i], e = B.einfo[i], c0 = B.col0[i], c1 = B.col1[i];
+  o[0] = x.x; o[1] = x.y; o[2] = x.z;
+  o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
+  o[7] = s0.x; o[8] = s0.y; o[9] = s0.z;
+  o[10] = s0.w; o[11] = s1.x; o[12] = s1.y;
+  o[13] = d.x; o[14] = d.y; o[15] = d.z;
+  o[16] = c1.w; o[17] = c0.x; o[18] = c0.y; o[19] = c0.z; o[20] = c1.x; o[21] = c1.y; o[22] = c1.z; o[23] = c0.w;
+  o[24] = s1.z;
+  o[25] = s1.w; o[26] = s2.x; o[27] = s2.y; o[28] = s2.z; o[29] = s2.w; o[30] = s3.x; o[31] = s3.y; o[32] = s3.z; o[33] = s3.w;
+  o[34] = e.w; o[35] = d.w;
+}
+__global__ __launch_bounds__(kBlock) void k_import_ghosts(Bodies B, uint32_t n_owned, uint32_t m, const float* in, float fat_margin) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= m) return;
+  uint32_t i = n_owned + t;
+  const float* o = in + (size_t)t * kGhostFloats;
+  V3 x = mk3(o[0], o[1], o[2]), d = mk3(o[13], o[14], o[15]);
+  B.x[i] = mk4(x, 0.0f);
+  B.q[i] = make_float4(o[3], o[4], o[5], o[6]);
+  B.srec[4 * i] = make_float4(o[7], o[8], o[9], o[10]);
+  B.srec[4 * i + 1] = make_float4(o[11], o[12], o[24], o[25]);
+  B.srec[4 * i + 2] = make_float4(o[26], o[27], o[28], o[29]);
+  B.srec[4 * i + 3] = make_float4(o[30], o[31], o[32], o[33]);
+  B.delta[i] = mk4(d, o[35]);
+  B.einfo[i] = mk4(x + d, o[34]);  // RigidBodyInfo.x = x + delta (physics.rs:282)
+  Comp k; k.kind = (int)f2u(o[16]); k.p = mk3(o[17], o[18], o[19]); k.d = mk3(o[20], o[21], o[22]); k.r = o[23];
+  B.col0[i] = mk4(k.p, k.r);
+  B.col1[i] = mk4(k.d, o[16]);
+  Box tb = swept_bounds(k, d);
+  B.tb_c[i] = mk4(tb.c, 0.0f); B.tb_r[i] = mk4(tb.r, 0.0f);
+  B.fb_c[i] = mk4(tb.c, 0.0f); B.fb_r[i] = mk4(tb.r + mk3(fat_margin, fat_margin, fat_margin), 0.0f);
+  B.sp0[i] = make_float4(0, 0, 0, o[34]); B.sp1[i] = make_float4(0, 0, 0, o[35]);
+  B.ctor[i] = make_float4(o[16], k.r, 0.0f, 0.0f);
+  B.imb[3 * i] = make_float4(0, 0, 0, 0); B.imb[3 * i + 1] = make_float4(0, 0, 0, 0); B.imb[3 * i + 2] = make_float4(0, 0, 0, 0);
+}
+// velocity record: 8 floats (v3, w3, 0, 0)
+__global__ __launch_bounds__(kBlock) void k_export_vel(const float4* srec, const uint32_t* ids, uint32_t m, float4* out) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= m) return;
+  uint32_t i = ids[t];
+  float4 s0 = srec[4 * i], s1 = srec[4 * i + 1];
+  out[2 * t] = s0;
+  out[2 * t + 1] = make_float4(s1.x, s1.y, 0.0f, 0.0f);
+}
+__global__ __launch_bounds__(kBlock) void k_import_ghost_vel(float4* srec, uint32_t n_owned, uint32_t m, const float4* in) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= m) return;
+  uint32_t i = n_owned + t;
+  srec[4 * i] = in[2 * t];
+  float2* p = reinterpret_cast<float2*>(&srec[4 * i + 1]);
+  *p = make_float2(in[2 * t + 1].x, in[2 * t + 1].y);
+}
+
+// ---- migration of owned bodies between tiles -----------------------------------------------------
+// A migrant record is the body's row of every Bodies array, verbatim (kMigrantWords float4 = 80 floats): the
+// receiving tile continues bit-identically, persistent fat box and constructor tag (ctor.w) included.
+constexpr int kMigrantWords = 20;
+__device__ __forceinline__ float4* body_word(const Bodies& B, uint32_t e, uint32_t i) {
+  switch (e) {
+    case 0: return B.x + i;
+    case 1: return B.q + i;
+    case 2: case 3: case 4: case 5: return B.srec + 4 * (size_t)i + (e - 2);
+    case 6: return B.sp0 + i;
+    case 7: return B.sp1 + i;
+    case 8: return B.ctor + i;
+    case 9: case 10: case 11: return B.imb + 3 * (size_t)i + (e - 9);
+    case 12: return B.delta + i;
+    case 13: return B.einfo + i;
+    case 14: return B.col0 + i;
+    case 15: return B.col1 + i;
+    case 16: return B.tb_c + i;
+    case 17: return B.tb_r + i;
+    case 18: return B.fb_c + i;
+    default: return B.fb_r + i;
+  }
+}
+// cnt[0] / cnt[1] += owned bodies whose centre lies below x_lo / at or above x_hi (the slab is [x_lo, x_hi))
+__global__ __launch_bounds__(kBlock) void k_migrant_count(Bodies B, uint32_t n_owned, float x_lo, float x_hi, uint32_t* cnt) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_owned) return;
+  float cx = B.x[i].x;
+  if (cx < x_lo) atomicAdd(cnt, 1u);
+  else if (cx >= x_hi) atomicAdd(cnt + 1, 1u);
+}
+__global__ __launch_bounds__(kBlock) void k_migrant_flags(Bodies B, uint32_t n_owned, float x_lo, float x_hi, uint32_t* fl, uint32_t* fr) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i > n_owned) return;
+  uint32_t l = 0, r = 0;
+  if (i < n_owned) {
+    float cx = B.x[i].x;
+    l = (cx < x_lo) ? 1u : 0u;
+    r = (!l && cx >= x_hi) ? 1u : 0u;
+  }
+  fl[i] = l; fr[i] = r;
+}
+__global__ __launch_bounds__(kBlock) void k_export_migrants(Bodies B, const uint32_t* ids, uint32_t m, float4* out) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= m * kMigrantWords) return;
+  uint32_t b = t / kMigrantWords, e = t % kMigrantWords;
+  out[t] = *body_word(B, e, ids[b]);
+}
+__global__ __launch_bounds__(kBlock) void k_import_migrants(Bodies B, uint32_t base, uint32_t m, const float4* in) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= m * kMigrantWords) return;
+  uint32_t b = t / kMigrantWords, e = t % kMigrantWords;
+  *body_word(B, e, base + b) = in[t];
+}
+// keep[i] = 1 for i < n, keep[n] = 0 (scan total); then the listed bodies are cleared
+__global__ __launch_bounds__(kBlock) void k_keep_fill(uint32_t* keep, uint32_t n) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i <= n) keep[i] = i < n ? 1u : 0u;
+}
+__global__ __launch_bounds__(kBlock) void k_keep_clear(uint32_t* keep, const uint32_t* ids, uint32_t m, uint32_t n, uint32_t* err) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= m) return;
+  uint32_t i = ids[t];
+  if (i >= n || atomicExch(&keep[i], 0u) == 0u) atomicOr(err, 1u);  // out of range or listed twice
+}
+// stable compaction through a scratch copy: tmp[pos[i]] = row i for kept bodies, then rows [0, n_new) = tmp
+__global__ __launch_bounds__(kBlock) void k_compact_gather(Bodies B, uint32_t n, const uint32_t* keep, const uint32_t* pos, float4* tmp) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n * kMigrantWords) return;
+  uint32_t i = t / kMigrantWords, e = t % kMigrantWords;
+  if (keep[i]) tmp[(size_t)pos[i] * kMigrantWords + e] = *body_word(B, e, i);
+}
+__global__ __launch_bounds__(kBlock) void k_kind_mask(const float4* col1, uint32_t base, uint32_t m, uint32_t* mask) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t < m) atomicOr(mask, f2u(col1[base + t].w) == (uint32_t)KIND_SPHERE ? 1u : 2u);
+}
+__global__ __launch_bounds__(kBlock) void k_tags_set(float4* ctor, const uint32_t* tags, uint32_t n) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) ctor[i].w = u2f(tags[i]);
+}
+__global__ __launch_bounds__(kBlock) void k_tags_get(const float4* ctor, uint32_t* tags, uint32_t n) {
+  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) tags[i] = f2u(ctor[i].w);
+}
+
+}  // namespace mgf
