@@ -206,6 +206,18 @@ MGF_API mgf_status mgf_world_set_terrain(mgf_world* w, const mgf_mesh* mesh);   
 MGF_API mgf_status mgf_world_add_bodies(mgf_world* w, const mgf_component* comps, int64_t n, const float* mass,
                                         const float* restitution, const float* friction, const mgf_vec3* world_force,
                                         uint64_t* first_id);
+/* Bodies of several components (BASELINE config 5).  NOT in the reference - physics.rs:200 takes one Component - so the
+ * definition is this build's (oracle: RigidBodyVec::add_compound_body): body b is made of comps[offsets[b] ..
+ * offsets[b + 1]) (1..2 components, world coordinates at creation) with masses comp_mass[..]; mass = sum, x = centre of
+ * mass, q = identity, inertia = sum of the components' tensors about the centre of mass (the reference's Inertia,
+ * physics.rs:30-93); the parts are fixed in the body frame and rebuilt from (x, q) every tick like a single collider
+ * (physics.rs:243-251).  Contacts: every pair of parts (Contacts, compound.rs:180-190), local points relative to the
+ * bodies' centres, ContactPruner + Manifold::from(pruner) (manifold.rs:72-148) - up to 4 contacts per pair of bodies, each
+ * a consecutive single-contact constraint record with the manifold's normal (equivalent to solver.rs:219-248).
+ * Single-process worlds only: the tiling calls refuse worlds that hold such bodies. */
+MGF_API mgf_status mgf_world_add_compound_bodies(mgf_world* w, const mgf_component* comps, const float* comp_mass,
+                                                 const int64_t* offsets /* n + 1 */, int64_t n, const float* restitution,
+                                                 const float* friction, const mgf_vec3* world_force, uint64_t* first_id);
 MGF_API int64_t mgf_world_len(const mgf_world* w);
 /* One tick (world.rs:227-294): complete_motion, integrate, broadphase, narrowphase,
  * ContactConstraint::new for every contact, Solver::solve(iters). */

@@ -113,7 +113,7 @@ SYMBOLS = [
     "mgf_compound_new", "mgf_compound_free", "mgf_compound_set_pose", "mgf_compound_bounds", "mgf_compound_contacts_many",
     "mgf_compound_intersections",
     "mgf_bvh_to_json", "mgf_bvh_from_json", "mgf_mesh_to_json", "mgf_mesh_from_json", "mgf_manifolds_from_contacts",
-    "mgf_world_new", "mgf_world_free", "mgf_world_set_terrain", "mgf_world_add_bodies", "mgf_world_len",
+    "mgf_world_new", "mgf_world_free", "mgf_world_set_terrain", "mgf_world_add_bodies", "mgf_world_add_compound_bodies", "mgf_world_len",
     "mgf_world_step", "mgf_world_build_constraints", "mgf_world_solve", "mgf_world_complete_motion",
     "mgf_world_integrate", "mgf_world_get", "mgf_world_set", "mgf_world_read_state", "mgf_world_write_state",
     "mgf_world_read_colliders", "mgf_world_read_constraints", "mgf_world_set_constraints", "mgf_world_set_option",
@@ -191,6 +191,7 @@ def load_library():
         "mgf_world_free": (None, [vp]),
         "mgf_world_set_terrain": (i32, [vp, vp]),
         "mgf_world_add_bodies": (i32, [vp, vp, i64, vp, vp, vp, vp, P(u64)]),
+        "mgf_world_add_compound_bodies": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, P(u64)]),
         "mgf_world_len": (i64, [vp]),
         "mgf_world_step": (i32, [vp, f32, i32, P(StepStats)]),
         "mgf_world_build_constraints": (i32, [vp, f32, P(StepStats)]),
@@ -681,7 +682,11 @@ class World:
             m.build(t["verts"], t["faces"])
             m.set_pos(t["pos"])
             w.set_terrain(m)
-        w.add_bodies(scene["comps"], scene["mass"], scene["restitution"], scene["friction"], scene["force"])
+        if len(scene["comps"]):
+            w.add_bodies(scene["comps"], scene["mass"], scene["restitution"], scene["friction"], scene["force"])
+        cb = scene.get("compound")  # bodies of several components, appended after the ordinary ones
+        if cb is not None:
+            w.add_compound_bodies(cb["comps"], cb["comp_mass"], cb["offsets"], cb["restitution"], cb["friction"], cb["force"])
         if scene.get("v0") is not None:
             w.write_state(v=scene["v0"])
         return w
@@ -699,6 +704,20 @@ class World:
         first = C.c_uint64()
         _check(load_library().mgf_world_add_bodies(self._h, comps.ctypes.data, n, mass.ctypes.data, rest.ctypes.data,
                                                    fric.ctypes.data, force.ctypes.data, C.byref(first)))
+        return first.value
+
+    def add_compound_bodies(self, comps, comp_mass, offsets, restitution, friction, world_force):
+        """Bodies of several components (mgf_world_add_compound_bodies): body b = comps[offsets[b]:offsets[b + 1]]."""
+        comps = np.ascontiguousarray(comps, dtype=COMPONENT_DTYPE)
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        n = len(offsets) - 1
+        cm = np.ascontiguousarray(np.broadcast_to(np.asarray(comp_mass, np.float32), (len(comps),)))
+        rest = np.ascontiguousarray(np.broadcast_to(np.asarray(restitution, np.float32), (n,)))
+        fric = np.ascontiguousarray(np.broadcast_to(np.asarray(friction, np.float32), (n,)))
+        force = np.ascontiguousarray(np.broadcast_to(np.asarray(world_force, np.float32), (n, 3)))
+        first = C.c_uint64()
+        _check(load_library().mgf_world_add_compound_bodies(self._h, comps.ctypes.data, cm.ctypes.data, offsets.ctypes.data, n,
+                                                            rest.ctypes.data, fric.ctypes.data, force.ctypes.data, C.byref(first)))
         return first.value
 
     def __len__(self):

@@ -591,19 +591,24 @@ __device__ inline bool comp_pair_local(const Comp& A, V3 vA, const Comp& B, V3 v
 // Body vs one terrain face.  mesh.rs:115-139 (tri rebuilt at verts + x; a/b swapped, n negated)
 // over compound.rs:180-190 (negated once) gives the Mesh-side contact k = raw Triangle contact;
 // collision.rs:1490-1506 then forms the LocalContact with global = -k.
-__device__ inline int comp_tri_local(const Comp& A, V3 vA, const Triangle& tri, V3 mesh_center, LocalContact out[2]) {
+// `centre`: the body's centre the local point is taken from (the component's own for an ordinary body; the centre of
+// mass for a part of a body of several components).
+__device__ inline int comp_tri_local_at(const Comp& A, V3 vA, const Triangle& tri, V3 mesh_center, V3 centre, LocalContact out[2]) {
   Contact raw[2];
   int n;
   if (A.kind == KIND_SPHERE) n = tri_msphere(tri, mks(A.p, A.r), vA, &raw[0]) ? 1 : 0;
   else n = tri_mcapsule(tri, mkcap(A.p, A.d, A.r), vA, raw);
   for (int k = 0; k < n; ++k) {
     Contact m = raw[k];  // Mesh::contacts callback value: a on the mesh, b on the body, n = face normal
-    V3 a_c = comp_center(A) + vA * m.t;
+    V3 a_c = centre + vA * m.t;
     out[k].la = m.b + -a_c;
     out[k].lb = m.a + -mesh_center;
     out[k].g = neg(m);
   }
   return n;
+}
+__device__ inline int comp_tri_local(const Comp& A, V3 vA, const Triangle& tri, V3 mesh_center, LocalContact out[2]) {
+  return comp_tri_local_at(A, vA, tri, mesh_center, comp_center(A), out);
 }
 
 // compute_basis geom.rs:1138-1145

@@ -38,7 +38,16 @@ struct Bodies {
   float4* tb_r;
   float4* fb_c;   // fat AABB (persistent; world.rs:181,237)
   float4* fb_r;
+  // Bodies of several components (BASELINE config 5; not in the reference): null unless the world has
+  // one.  kMaxParts slots per body; pcount 0 = an ordinary body.  Local parts are fixed in the body frame relative to
+  // the centre of mass; world parts are rebuilt by k_integrate like the single collider (physics.rs:243-251).
+  uint32_t* pcount;
+  float4* lp0;    // local part: p.xyz (sphere centre / capsule start), r
+  float4* lp1;    //             d.xyz (capsule axis), kind bits
+  float4* wp0;    // world part at the start of the tick's motion, same layout
+  float4* wp1;
 };
+constexpr int kMaxParts = 2;
 
 struct SceneBounds { int lo[3]; int hi[3]; uint32_t n_refits; uint32_t pad; int rmax[3]; uint32_t pad2; };  // ordered-int encoded floats; rmax = largest fat half extent
 
@@ -80,8 +89,26 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
       w = w + I * xyz(p1) * dt;
       // physics.rs:244-250
       int kind = (int)f2u(ct.x);
-      Comp col = construct(kind, ct.y, ct.z, x, q);
       V3 d = v * dt;
+      Comp col;
+      Box tb;
+      const uint32_t pc = B.pcount ? B.pcount[i] : 0u;
+      if (pc) {  // a body of several parts: the collider slot carries the centre (a radius-0 sphere), the parts collide
+        col.kind = KIND_SPHERE; col.p = x; col.d = mk3(0.0f, 0.0f, 0.0f); col.r = 0.0f;
+        for (uint32_t k = 0; k < pc; ++k) {
+          float4 l0 = B.lp0[kMaxParts * i + k], l1 = B.lp1[kMaxParts * i + k];
+          Comp part; part.kind = (int)f2u(l1.w); part.r = l0.w;
+          part.p = x + rotate(q, xyz(l0));
+          part.d = part.kind == KIND_SPHERE ? mk3(0.0f, 0.0f, 0.0f) : rotate(q, xyz(l1));
+          B.wp0[kMaxParts * i + k] = mk4(part.p, part.r);
+          B.wp1[kMaxParts * i + k] = mk4(part.d, l1.w);
+          Box pb = swept_bounds(part, d);
+          tb = k == 0 ? pb : box_combine(tb, pb);
+        }
+      } else {
+        col = construct(kind, ct.y, ct.z, x, q);
+        tb = swept_bounds(col, d);
+      }
       B.q[i] = make_float4(q.s, q.v.x, q.v.y, q.v.z);
       B.srec[4 * i] = make_float4(v.x, v.y, v.z, w.x);
       B.srec[4 * i + 1] = make_float4(w.y, w.z, inv_mass, I.c[0].x);
@@ -91,7 +118,6 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
       B.einfo[i] = mk4(x + d, p0.w);
       B.col0[i] = mk4(col.p, col.r);
       B.col1[i] = mk4(col.d, u2f((uint32_t)col.kind));
-      Box tb = swept_bounds(col, d);
       B.tb_c[i] = mk4(tb.c, 0.0f);
       B.tb_r[i] = mk4(tb.r, 0.0f);
       Box fb; fb.c = xyz(B.fb_c[i]); fb.r = xyz(B.fb_r[i]);

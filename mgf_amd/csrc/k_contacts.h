@@ -57,6 +57,92 @@ __global__ __launch_bounds__(kBlock) void k_narrow_terrain(Bodies B, TerrainDev 
   }
 }
 
+// ---- worlds with bodies of several parts (BASELINE config 5; not in the reference) -------------------------------
+// The same steps over every pair of parts: Contacts (compound.rs:180-190) per part pair in order (parts of i outer),
+// local points relative to the BODIES' centres (LocalContacts, compound.rs:192-207), ContactPruner::push
+// (manifold.rs:72-102), Manifold::from(pruner) (:131-148).  An ordinary body is a body of one part (its collider), so
+// these kernels serve mixed worlds too.  At most kMaxParts^2 = 4 contacts per pair (every part pair emits <= 1).
+constexpr float kPersistentThresholdSq = 0.5f;  // manifold.rs:38
+constexpr int kPairContacts = kMaxParts * kMaxParts;
+constexpr int kTerrainContacts = 2 * kMaxParts;  // per (body, face): a capsule part emits up to 2
+__device__ __forceinline__ int load_parts(const Bodies& B, uint32_t i, Comp out[kMaxParts], V3* centre) {
+  const uint32_t pc = B.pcount ? B.pcount[i] : 0u;
+  if (pc == 0) { out[0] = load_comp(B, i); *centre = comp_center(out[0]); return 1; }
+  for (uint32_t k = 0; k < pc; ++k) {
+    float4 a = B.wp0[kMaxParts * i + k], b = B.wp1[kMaxParts * i + k];
+    out[k].kind = (int)f2u(b.w); out[k].p = xyz(a); out[k].r = a.w; out[k].d = xyz(b);
+  }
+  *centre = xyz(B.col0[i]);  // the carrier: the body's centre of mass
+  return (int)pc;
+}
+__global__ __launch_bounds__(kBlock) void k_narrow_pairs_parts(Bodies B, const uint32_t* m_ptr, const uint32_t* p_owner, const uint32_t* p_cand,
+                                                               uint32_t* p_nc, NContact* p_out /* kPairContacts per candidate */) {
+  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= *m_ptr) return;
+  const uint32_t i = p_owner[p], j = p_cand[p];
+  Comp Pa[kMaxParts], Pb[kMaxParts];
+  V3 ci, cj;
+  const int na = load_parts(B, i, Pa, &ci), nb = load_parts(B, j, Pb, &cj);
+  const V3 vA = xyz(B.delta[i]), vB = xyz(B.delta[j]);
+  float min_t = kInf;
+  int cnt = 0;
+  LocalContact keep[kPairContacts];
+  for (int a = 0; a < na; ++a) {
+    for (int b = 0; b < nb; ++b) {
+      Contact c;
+      if (!comp_pair_contact(Pa[a], vA, Pb[b], vB, &c)) continue;
+      LocalContact nc; nc.la = c.a + -(ci + vA * c.t); nc.lb = c.b + -(cj + vB * c.t); nc.g = c;
+      if (nc.g.t < min_t - kCollisionEps) { cnt = 1; keep[0] = nc; min_t = nc.g.t; continue; }
+      if (nc.g.t > min_t + kCollisionEps) continue;
+      bool merged = false;
+      for (int k = 0; k < cnt && !merged; ++k) {
+        V3 ra = nc.g.a - keep[k].g.a, rb = nc.g.b - keep[k].g.b;
+        if (mag2(ra) <= kPersistentThresholdSq || mag2(rb) <= kPersistentThresholdSq) {
+          float prev = mag2(keep[k].la) + mag2(keep[k].lb), cur = mag2(nc.la) + mag2(nc.lb);
+          if (prev < cur) keep[k] = nc;
+          merged = true;
+        }
+      }
+      if (!merged) keep[cnt++] = nc;  // cnt <= na * nb <= kPairContacts
+    }
+  }
+  p_nc[p] = (uint32_t)cnt;
+  if (cnt == 0) return;
+  V3 sum = mk3(0.0f, 0.0f, 0.0f);
+  for (int k = 0; k < cnt; ++k) sum = sum + keep[k].g.n;
+  const V3 avg = sum / (float)cnt;
+  for (int k = 0; k < cnt; ++k) {
+    NContact o; o.la = mk4(keep[k].la, min_t); o.lb = mk4(keep[k].lb, 0.0f); o.n = mk4(avg, 0.0f);
+    p_out[(size_t)kPairContacts * p + k] = o;
+  }
+}
+// Terrain: per face (the candidate list is in the mesh's DFS order) the body's parts in order; every contact is its own
+// constraint (world.rs:243-251).
+__global__ __launch_bounds__(kBlock) void k_narrow_terrain_parts(Bodies B, TerrainDev M, const uint32_t* m_ptr, const uint32_t* t_owner,
+                                                                 const uint32_t* t_cand, uint32_t* t_nc,
+                                                                 NContact* t_out /* kTerrainContacts per candidate */) {
+  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= *m_ptr) return;
+  const uint32_t i = t_owner[p], f = t_cand[p];
+  Comp Pa[kMaxParts];
+  V3 ci;
+  const int na = load_parts(B, i, Pa, &ci);
+  const V3 vA = xyz(B.delta[i]);
+  uint4 fi = M.faces[f];
+  V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
+  Triangle tri = mkt(xyz(M.verts[fi.x]) + mx, xyz(M.verts[fi.y]) + mx, xyz(M.verts[fi.z]) + mx);  // mesh.rs:122-126
+  uint32_t cnt = 0;
+  for (int a = 0; a < na; ++a) {
+    LocalContact lc[2];
+    int nc = comp_tri_local_at(Pa[a], vA, tri, mx, ci, lc);
+    for (int k = 0; k < nc; ++k) {
+      NContact o; o.la = mk4(lc[k].la, lc[k].g.t); o.lb = mk4(lc[k].lb, 0.0f); o.n = mk4(lc[k].g.n, 0.0f);
+      t_out[(size_t)kTerrainContacts * p + cnt++] = o;
+    }
+  }
+  t_nc[p] = cnt;
+}
+
 // Bin candidate ids by pair type (only launched for scenes that mix spheres and capsules).
 __global__ __launch_bounds__(kBlock) void k_bin_pairs(Bodies B, const uint32_t* m_ptr, uint32_t stride, const uint32_t* p_owner,
                                                       const uint32_t* p_cand, uint32_t* lists /* 4 x stride */, uint32_t* counts /* 4 */) {
@@ -115,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint3
   // is in discovery order, and only a few of its ~10 entries are contacts (at most one per partner): collect them, then
   // rank them among themselves
   const uint32_t lo = p_off[i], hi = p_off[i + 1];
-  uint32_t h = 0;
+  uint32_t h = 0, total = 0;
   for (uint32_t base = lo; base < hi; base += 4) {  // four counts per round trip
     uint32_t nc[4];
 #pragma unroll
@@ -123,8 +209,9 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint3
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (nc[k]) {
-        if (h < (uint32_t)kHitCap) { s_j[h][tid] = p_cand[base + k]; s_p[h][tid] = base + k; }
+        if (h < (uint32_t)kHitCap) { s_j[h][tid] = p_cand[base + k]; s_p[h][tid] = (base + k) | (nc[k] << 28); }
         ++h;
+        total += nc[k];
       }
     }
   }
@@ -132,8 +219,8 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint3
     for (uint32_t a = 0; a < h; ++a) {
       const uint32_t j = s_j[a][tid];
       uint32_t before = 0;
-      for (uint32_t q = 0; q < h; ++q) before += s_j[q][tid] < j ? 1u : 0u;
-      p_pre[s_p[a][tid]] = run + before;
+      for (uint32_t q = 0; q < h; ++q) before += s_j[q][tid] < j ? (s_p[q][tid] >> 28) : 0u;  // a partner's contacts (1, or up to 4 for bodies of several parts)
+      p_pre[s_p[a][tid] & 0x0FFFFFFFu] = run + before;
     }
   } else {  // a crowded body: the same by rescanning its list
     for (uint32_t p = lo; p < hi; ++p) {
@@ -144,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint3
       p_pre[p] = run + before;
     }
   }
-  cnt[i] = run + h;
+  cnt[i] = run + total;
   }
   __syncthreads();
   if (tid == 0 && s_ct) atomicAdd(&sc->ct_sum, s_ct);
@@ -251,28 +338,35 @@ __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCoun
                                                         const uint32_t* p_nc, const uint32_t* p_pre, const NContact* p_in,
                                                         const uint32_t* base, float dt, float baumgarte, float slop,
                                                         CRec* cons, uint2* ab, uint32_t* degb, uint32_t* rev, uint32_t rev_cap,
-                                                        uint32_t* rev_flag) {
+                                                        uint32_t* rev_flag, uint32_t in_stride) {
   uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-  if (p >= sc->Mp || p_nc[p] == 0) return;
+  if (p >= sc->Mp) return;
+  const uint32_t nc = p_nc[p];
+  if (nc == 0) return;
   uint32_t i = p_owner[p], j = p_cand[p];
-  uint32_t c = base[i] + p_pre[p];
-  NContact k = p_in[p];
   BodyDyn A = load_dyn(B.srec, i), Bd = load_dyn(B.srec, j);
   float4 ea = B.einfo[i], eb = B.einfo[j];
-  CRec r = make_constraint(i, j, A, xyz(ea), ea.w, B.delta[i].w, Bd, xyz(eb), eb.w, B.delta[j].w, xyz(k.n), xyz(k.la), xyz(k.lb),
-                           dt, baumgarte, slop);
-  store_crec(&cons[c], r);
-  ab[c] = make_uint2(i, j);
-  // body j's row of the constraints it takes part in as `b` (k_chain_rows); as `a` a body owns a contiguous id range
-  uint32_t pos = atomicAdd(&degb[j], 1u);
-  if (pos < rev_cap) rev[(size_t)j * rev_cap + pos] = c;
-  else *rev_flag = 1u;
+  // A manifold of m contacts (bodies of several parts only) becomes m consecutive single-contact records that share
+  // its normal and tangents: ContactConstraint::solve (solver.rs:219-248) handles the contacts of a constraint one after
+  // the other on the same velocities, which is exactly what consecutive records do.
+  for (uint32_t q = 0; q < nc; ++q) {
+    const uint32_t c = base[i] + p_pre[p] + q;
+    NContact k = p_in[(size_t)in_stride * p + q];
+    CRec r = make_constraint(i, j, A, xyz(ea), ea.w, B.delta[i].w, Bd, xyz(eb), eb.w, B.delta[j].w, xyz(k.n), xyz(k.la), xyz(k.lb),
+                             dt, baumgarte, slop);
+    store_crec(&cons[c], r);
+    ab[c] = make_uint2(i, j);
+    // body j's row of the constraints it takes part in as `b` (k_chain_rows); as `a` a body owns a contiguous id range
+    uint32_t pos = atomicAdd(&degb[j], 1u);
+    if (pos < rev_cap) rev[(size_t)j * rev_cap + pos] = c;
+    else *rev_flag = 1u;
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_setup_terrain(Bodies B, TerrainDev M, const StepCounts* sc, const uint32_t* t_owner,
                                                           const uint32_t* t_nc, const uint32_t* t_pre, const NContact* t_in,
                                                           const uint32_t* base, float dt, float baumgarte, float slop, CRec* cons,
-                                                          uint2* ab) {
+                                                          uint2* ab, uint32_t in_stride) {
   uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= sc->Mt) return;
   uint32_t nc = t_nc[p];
@@ -282,7 +376,7 @@ __global__ __launch_bounds__(kBlock) void k_setup_terrain(Bodies B, TerrainDev M
   float4 ea = B.einfo[i];
   V3 center = mk3(M.x[0], M.x[1], M.x[2]);  // Static{ center: terrain.center(), friction: 0.0 } world.rs:247
   for (uint32_t k = 0; k < nc; ++k) {
-    NContact in = t_in[2 * p + k];
+    NContact in = t_in[(size_t)in_stride * p + k];
     CRec r = make_constraint(i, kNone, A, xyz(ea), ea.w, B.delta[i].w, S, center, 0.0f, 0.0f, xyz(in.n), xyz(in.la), xyz(in.lb), dt,
                              baumgarte, slop);
     store_crec(&cons[base[i] + t_pre[p] + k], r);

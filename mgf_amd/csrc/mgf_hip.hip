@@ -827,6 +827,9 @@ struct mgf_world {
   uint32_t n = 0;        // local bodies = owned + ghosts of the current tick
   uint32_t n_owned = 0;  // bodies of this world's RigidBodyVec (added through add_bodies)
   bool has_sphere = false, has_capsule = false;
+  bool has_compound = false;      // a body of several parts exists: the *_parts narrowphase kernels serve every pair
+  DBuf<uint32_t> pcount;          // parts per body (0: an ordinary body); the four part arrays hold kMaxParts slots per body
+  DBuf<float4> lp0, lp1, wp0, wp1;
   DBuf<uint32_t> bflag_l, bflag_r, bscan_l, bscan_r;  // boundary selection scratch
   DBuf<uint32_t> mig_cnt;  // migration: [0] left-goers, [1] right-goers (also remove_bodies' error word)
   DBuf<float4> mig_tmp;    // remove_bodies: compacted copy of every body array
@@ -909,6 +912,7 @@ struct mgf_world {
     Bodies B;
     B.x = x.p; B.q = q.p; B.srec = srec.p; B.sp0 = sp0.p; B.sp1 = sp1.p; B.ctor = ctor.p; B.imb = imb.p; B.delta = delta.p;
     B.einfo = einfo.p; B.col0 = col0.p; B.col1 = col1.p; B.tb_c = tb_c.p; B.tb_r = tb_r.p; B.fb_c = fb_c.p; B.fb_r = fb_r.p;
+    B.pcount = has_compound ? pcount.p : nullptr; B.lp0 = lp0.p; B.lp1 = lp1.p; B.wp0 = wp0.p; B.wp1 = wp1.p;
     return B;
   }
   uint32_t* d_cnt() { return scalars.p; }
@@ -1159,6 +1163,110 @@ extern "C" mgf_status mgf_world_add_bodies(mgf_world* w, const mgf_component* co
   MGF_TRY(append(ctx, w->imb, 3 * o, hi)); MGF_TRY(append(ctx, w->delta, o, hd)); MGF_TRY(append(ctx, w->einfo, o, he));
   MGF_TRY(append(ctx, w->col0, o, c0)); MGF_TRY(append(ctx, w->col1, o, c1)); MGF_TRY(append(ctx, w->tb_c, o, tc));
   MGF_TRY(append(ctx, w->tb_r, o, tr)); MGF_TRY(append(ctx, w->fb_c, o, fc)); MGF_TRY(append(ctx, w->fb_r, o, fr));
+  if (w->has_compound) {  // ordinary bodies in a world that has bodies of several parts: empty part slots
+    std::vector<uint32_t> pz(N, 0u);
+    std::vector<float4> fz(kMaxParts * N, make_float4(0, 0, 0, 0));
+    MGF_TRY(append(ctx, w->pcount, o, pz));
+    MGF_TRY(append(ctx, w->lp0, kMaxParts * o, fz)); MGF_TRY(append(ctx, w->lp1, kMaxParts * o, fz));
+    MGF_TRY(append(ctx, w->wp0, kMaxParts * o, fz)); MGF_TRY(append(ctx, w->wp1, kMaxParts * o, fz));
+  }
+  w->n_owned += (uint32_t)n;
+  w->n = w->n_owned;
+  w->has_sphere = hs_; w->has_capsule = hc_;
+  w->constraints_ready = false;
+  return MGF_OK;
+}
+
+// Bodies of several components (BASELINE config 5).  NOT in the reference (physics.rs:200 takes one Component); the
+// definition is the oracle's RigidBodyVec::add_compound_body: mass = sum, x = centre of mass, q = identity, tensor = sum
+// of the components' tensors about the centre of mass (physics.rs:30-93), parts fixed in the body frame.
+extern "C" mgf_status mgf_world_add_compound_bodies(mgf_world* w, const mgf_component* comps, const float* comp_mass, const int64_t* offsets,
+                                                    int64_t n, const float* restitution, const float* friction, const mgf_vec3* world_force,
+                                                    uint64_t* first_id) {
+  if (!w || (n && (!comps || !comp_mass || !offsets || !restitution || !friction || !world_force))) return fail(MGF_ERR_INVALID, "NULL argument");
+  MGF_TRY(ctx_bind(w->ctx));
+  w->n = w->n_owned;
+  if (first_id) *first_id = w->n_owned;
+  if (n <= 0) return MGF_OK;
+  if ((uint64_t)w->n_owned + (uint64_t)n > 0x7FFFFFF0ull) return fail(MGF_ERR_INVALID, "too many bodies");
+  const size_t N = (size_t)n, o = w->n_owned;
+  std::vector<float4> hx(N), hq(N), hs(4 * N), h0(N), h1(N), hc(N), hi(3 * N), hd(N), he(N), c0(N), c1(N), tc(N), tr(N), fc(N), fr(N);
+  std::vector<uint32_t> hp(N);
+  std::vector<float4> l0(kMaxParts * N, make_float4(0, 0, 0, 0)), l1(l0), w0(l0), w1(l0);
+  bool hs_ = w->has_sphere, hc_ = w->has_capsule;
+  for (size_t b = 0; b < N; ++b) {
+    const int64_t k0 = offsets[b], k1 = offsets[b + 1];
+    if (k1 <= k0 || k1 - k0 > kMaxParts) return fail(MGF_ERR_INVALID, "a body needs 1..2 components");
+    Comp part[kMaxParts];
+    float total = 0.0f;
+    V3 acc = mk3(0, 0, 0);
+    for (int64_t k = k0; k < k1; ++k) {
+      const mgf_component& mc = comps[k];
+      if (mc.tag != MGF_SPHERE && mc.tag != MGF_CAPSULE) return fail(MGF_ERR_INVALID, "component tag must be sphere or capsule");
+      if (!(mc.r > 0.0f)) return fail(MGF_ERR_INVALID, "radius must be > 0 (geom.rs:300,328)");
+      Comp c = comp_of(mc);
+      if (c.kind == KIND_SPHERE) { c.d = mk3(0, 0, 0); hs_ = true; } else hc_ = true;
+      part[k - k0] = c;
+      total += comp_mass[k];
+      acc = acc + comp_center(c) * comp_mass[k];
+    }
+    const V3 com = acc / total;
+    M3 t = m3_cols(mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0));
+    for (int64_t k = k0; k < k1; ++k) { Comp l = part[k - k0]; l.p = l.p + -com; t = t + tensor_of(l, comp_mass[k]); }
+    M3 inv;
+    if (!invert(t, &inv)) return fail(MGF_ERR_SINGULAR, "inertia tensor is not invertible");
+    const float inv_mass = 1.0f / total;
+    const V3 force = mk3(world_force[b].x, world_force[b].y, world_force[b].z) * total;
+    hx[b] = make_float4(com.x, com.y, com.z, 0.0f);
+    hq[b] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+    hs[4 * b] = make_float4(0, 0, 0, 0);
+    hs[4 * b + 1] = make_float4(0, 0, inv_mass, inv.c[0].x);
+    hs[4 * b + 2] = make_float4(inv.c[0].y, inv.c[0].z, inv.c[1].x, inv.c[1].y);
+    hs[4 * b + 3] = make_float4(inv.c[1].z, inv.c[2].x, inv.c[2].y, inv.c[2].z);
+    h0[b] = make_float4(force.x, force.y, force.z, restitution[b]);
+    h1[b] = make_float4(0, 0, 0, friction[b]);
+    uint32_t kind_bits = 2u;  // constructor kind: a body of several parts
+    float kf; memcpy(&kf, &kind_bits, 4);
+    hc[b] = make_float4(kf, 0.0f, 0.0f, 0.0f);
+    for (int c = 0; c < 3; ++c) hi[3 * b + c] = make_float4(inv.c[c].x, inv.c[c].y, inv.c[c].z, 0.0f);
+    hd[b] = make_float4(0, 0, 0, friction[b]);
+    he[b] = make_float4(com.x, com.y, com.z, restitution[b]);
+    uint32_t sph = (uint32_t)KIND_SPHERE; float sf; memcpy(&sf, &sph, 4);
+    c0[b] = make_float4(com.x, com.y, com.z, 0.0f);  // the carrier: a radius-0 sphere at the centre of mass
+    c1[b] = make_float4(0, 0, 0, sf);
+    Box tb;
+    for (int64_t k = k0; k < k1; ++k) {
+      const Comp& c = part[k - k0];
+      uint32_t kb = (uint32_t)c.kind; float kbf; memcpy(&kbf, &kb, 4);
+      const V3 lp = c.p + -com;
+      l0[kMaxParts * b + (k - k0)] = make_float4(lp.x, lp.y, lp.z, c.r);
+      l1[kMaxParts * b + (k - k0)] = make_float4(c.d.x, c.d.y, c.d.z, kbf);
+      w0[kMaxParts * b + (k - k0)] = make_float4(c.p.x, c.p.y, c.p.z, c.r);
+      w1[kMaxParts * b + (k - k0)] = make_float4(c.d.x, c.d.y, c.d.z, kbf);
+      Box pb = swept_bounds(c, mk3(0, 0, 0));
+      tb = k == k0 ? pb : box_combine(tb, pb);
+    }
+    hp[b] = (uint32_t)(k1 - k0);
+    tc[b] = make_float4(tb.c.x, tb.c.y, tb.c.z, 0); tr[b] = make_float4(tb.r.x, tb.r.y, tb.r.z, 0);
+    const V3 fm = mk3(w->params.fat_margin, w->params.fat_margin, w->params.fat_margin), frr = tb.r + fm;
+    fc[b] = tc[b]; fr[b] = make_float4(frr.x, frr.y, frr.z, 0);
+  }
+  mgf_ctx* ctx = w->ctx;
+  if (!w->has_compound && o > 0) {  // the bodies added so far are ordinary: empty part slots for them
+    std::vector<uint32_t> pz(o, 0u);
+    std::vector<float4> fz(kMaxParts * o, make_float4(0, 0, 0, 0));
+    MGF_TRY(append(ctx, w->pcount, 0, pz));
+    MGF_TRY(append(ctx, w->lp0, 0, fz)); MGF_TRY(append(ctx, w->lp1, 0, fz)); MGF_TRY(append(ctx, w->wp0, 0, fz)); MGF_TRY(append(ctx, w->wp1, 0, fz));
+  }
+  MGF_TRY(append(ctx, w->x, o, hx)); MGF_TRY(append(ctx, w->q, o, hq)); MGF_TRY(append(ctx, w->srec, 4 * o, hs));
+  MGF_TRY(append(ctx, w->sp0, o, h0)); MGF_TRY(append(ctx, w->sp1, o, h1)); MGF_TRY(append(ctx, w->ctor, o, hc));
+  MGF_TRY(append(ctx, w->imb, 3 * o, hi)); MGF_TRY(append(ctx, w->delta, o, hd)); MGF_TRY(append(ctx, w->einfo, o, he));
+  MGF_TRY(append(ctx, w->col0, o, c0)); MGF_TRY(append(ctx, w->col1, o, c1)); MGF_TRY(append(ctx, w->tb_c, o, tc));
+  MGF_TRY(append(ctx, w->tb_r, o, tr)); MGF_TRY(append(ctx, w->fb_c, o, fc)); MGF_TRY(append(ctx, w->fb_r, o, fr));
+  MGF_TRY(append(ctx, w->pcount, o, hp));
+  MGF_TRY(append(ctx, w->lp0, kMaxParts * o, l0)); MGF_TRY(append(ctx, w->lp1, kMaxParts * o, l1));
+  MGF_TRY(append(ctx, w->wp0, kMaxParts * o, w0)); MGF_TRY(append(ctx, w->wp1, kMaxParts * o, w1));
+  w->has_compound = true;
   w->n_owned += (uint32_t)n;
   w->n = w->n_owned;
   w->has_sphere = hs_; w->has_capsule = hc_;
@@ -1433,7 +1541,7 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   const bool two_pass = w->opt_two_pass != 0 || w->tick_two_pass;
   const bool use_grid = !two_pass && !w->opt_broadphase_tree && !w->grid_too_wide;
   // a world of spheres: the grid broadphase runs the sphere-sphere test on the partners it accepts and lists contacts only
-  const bool fused = use_grid && !w->has_capsule && !w->opt_no_fused_narrowphase;
+  const bool fused = use_grid && !w->has_capsule && !w->has_compound && !w->opt_no_fused_narrowphase;
   w->tick_fused = fused;
   T.lcol = nullptr;
   if (fused) { MGF_TRY(w->lcol.ensure(2 * (size_t)n, s)); T.lcol = w->lcol.p; }
@@ -1458,7 +1566,8 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   MGF_TRY(w->p_cand.ensure(cap_p, s)); MGF_TRY(w->p_owner.ensure(cap_p, s));
   MGF_TRY(w->t_nc.ensure(cap_t, s)); MGF_TRY(w->p_nc.ensure(cap_p, s));
   MGF_TRY(w->t_pre.ensure(cap_t, s)); MGF_TRY(w->p_pre.ensure(cap_p, s));
-  MGF_TRY(w->t_out.ensure(2 * (size_t)cap_t, s)); MGF_TRY(w->p_out.ensure(cap_p, s));
+  const uint32_t t_stride = w->has_compound ? (uint32_t)kTerrainContacts : 2u, p_stride = w->has_compound ? (uint32_t)kPairContacts : 1u;
+  MGF_TRY(w->t_out.ensure((size_t)t_stride * cap_t, s)); MGF_TRY(w->p_out.ensure((size_t)p_stride * cap_p, s));
   const bool terrain_grid = !two_pass && M.n_nodes && w->terrain->grid.ready && !w->terrain_grid_off && !w->opt_terrain_tree;
   if (!two_pass) {
     // fast path: one pass, hits written to fixed-capacity rows
@@ -1502,7 +1611,10 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   MGF_HIP_TRY(hipEventRecord(w->ev[2], s));
   // 4. narrowphase, one kernel per shape-pair type
   bool mixed = w->has_sphere && w->has_capsule;
-  if (!mixed) {
+  if (w->has_compound) {  // bodies of several parts: one kernel over every pair of parts (ordinary bodies are bodies of one part)
+    if (cap_p) { k_narrow_pairs_parts<<<nblk(cap_p), kBlock, 0, s>>>(B, &sc->Mp, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_out.p); LAUNCH_CHECK(); }
+    if (M.n_nodes && cap_t) { k_narrow_terrain_parts<<<nblk(cap_t), kBlock, 0, s>>>(B, M, &sc->Mt, w->t_owner.p, w->t_cand.p, w->t_nc.p, w->t_out.p); LAUNCH_CHECK(); }
+  } else if (!mixed) {
     int k = w->has_capsule ? 1 : 0;
     MGF_TRY(launch_pairs(w, k, k, nullptr, &sc->Mp, cap_p));
     if (M.n_nodes) MGF_TRY(launch_terrain(w, k, M, nullptr, &sc->Mt, cap_t));
@@ -1529,12 +1641,12 @@ static mgf_status collide_enqueue(mgf_world* w, float dt) {
   LAUNCH_CHECK();
   if (M.n_nodes) {
     k_setup_terrain<<<nblk(cap_t), kBlock, 0, s>>>(B, M, sc, w->t_owner.p, w->t_nc.p, w->t_pre.p, w->t_out.p, w->base.p, dt, w->params.baumgarte,
-                                                   w->params.penetration_slop, w->cons_nat.p, w->c_ab.p);
+                                                   w->params.penetration_slop, w->cons_nat.p, w->c_ab.p, t_stride);
     LAUNCH_CHECK();
   }
   k_setup_pairs<<<nblk(cap_p), kBlock, 0, s>>>(B, sc, w->p_owner.p, w->p_cand.p, w->p_nc.p, w->p_pre.p, w->p_out.p, w->base.p, dt,
                                                w->params.baumgarte, w->params.penetration_slop, w->cons_nat.p, w->c_ab.p, w->degb.p, w->rev.p,
-                                               w->rev_cap, w->d_err() + 7);
+                                               w->rev_cap, w->d_err() + 7, p_stride);
   LAUNCH_CHECK();
   if (cap_c >= kSuccId) return fail(MGF_ERR_CAPACITY, "too many constraints");
   w->depth = 0;
@@ -1654,6 +1766,7 @@ extern "C" mgf_status mgf_world_select_boundary(mgf_world* w, float x_left, floa
   return sync_unless_ordered(w);
 }
 extern "C" mgf_status mgf_world_export_bodies(mgf_world* w, const uint32_t* ids, int64_t n, float* dst) {
+  if (w && w->has_compound) return fail(MGF_ERR_INVALID, "bodies of several parts are supported in single-process worlds only (no ghost / migrant records)");
   if (!w || (n && (!ids || !dst))) return fail(MGF_ERR_INVALID, "NULL argument");
   MGF_TRY(ctx_bind(w->ctx));
   if (n > 0) { k_export_bodies<<<nblk(n), kBlock, 0, w->ctx->stream>>>(w->bodies(), ids, (uint32_t)n, dst); LAUNCH_CHECK(); }
@@ -1664,6 +1777,7 @@ static mgf_status grow_keep(mgf_world* w, DBuf<T>& b, size_t per, size_t need) {
   return b.ensure(per * need, w->ctx->stream, true, per * (size_t)w->n_owned);
 }
 extern "C" mgf_status mgf_world_import_ghosts(mgf_world* w, const float* src, int64_t n_ghost) {
+  if (w && w->has_compound) return fail(MGF_ERR_INVALID, "bodies of several parts are supported in single-process worlds only (no ghost / migrant records)");
   if (!w || (n_ghost && !src) || n_ghost < 0) return fail(MGF_ERR_INVALID, "bad argument");
   MGF_TRY(ctx_bind(w->ctx));
   size_t need = (size_t)w->n_owned + (size_t)n_ghost;
@@ -1725,6 +1839,7 @@ extern "C" mgf_status mgf_world_select_tile(mgf_world* w, float x_left, float x_
   return sync_unless_ordered(w);
 }
 extern "C" mgf_status mgf_world_export_migrants(mgf_world* w, const uint32_t* ids, int64_t n, float* dst) {
+  if (w && w->has_compound) return fail(MGF_ERR_INVALID, "bodies of several parts are supported in single-process worlds only (no ghost / migrant records)");
   if (!w || n < 0 || (n && (!ids || !dst))) return fail(MGF_ERR_INVALID, "bad argument");
   MGF_TRY(ctx_bind(w->ctx));
   if (n > 0) {
@@ -1736,6 +1851,7 @@ extern "C" mgf_status mgf_world_export_migrants(mgf_world* w, const uint32_t* id
 // Removes the listed owned bodies (distinct ids, any order); the others keep their relative order, so ids above a
 // removed one shift down.  Ghosts of the current tick are dropped.
 extern "C" mgf_status mgf_world_remove_bodies(mgf_world* w, const uint32_t* ids, int64_t n_ids) {
+  if (w && w->has_compound) return fail(MGF_ERR_INVALID, "bodies of several parts are supported in single-process worlds only (no ghost / migrant records)");
   if (!w || n_ids < 0 || (n_ids && !ids)) return fail(MGF_ERR_INVALID, "bad argument");
   MGF_TRY(ctx_bind(w->ctx));
   mgf_ctx* ctx = w->ctx;
@@ -1771,6 +1887,7 @@ extern "C" mgf_status mgf_world_remove_bodies(mgf_world* w, const uint32_t* ids,
 }
 // Appends bodies exported by another world's mgf_world_export_migrants as owned bodies (ghosts are dropped).
 extern "C" mgf_status mgf_world_import_migrants(mgf_world* w, const float* src, int64_t n_in) {
+  if (w && w->has_compound) return fail(MGF_ERR_INVALID, "bodies of several parts are supported in single-process worlds only (no ghost / migrant records)");
   if (!w || n_in < 0 || (n_in && !src)) return fail(MGF_ERR_INVALID, "bad argument");
   MGF_TRY(ctx_bind(w->ctx));
   w->n = w->n_owned;

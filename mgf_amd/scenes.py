@@ -204,6 +204,42 @@ def capsule_field(nx, ny, nz, quads=None, seed=SEED, iters=10, pitch=1.6, y0=1.2
     return _scene(f"capsule_field_{nx}x{ny}x{nz}_q{quads}", comps, terrain, v0=v0, iters=iters)
 
 
+def dumbbell_field(nx, ny, nz, n_plain=0, seed=SEED, iters=10, pitch=2.2, y0=1.5):
+    """BASELINE config 5 family: nx*ny*nz bodies of two components each - a sphere (r = 0.5) and a capsule (|d| = 1,
+    r = 0.3) side by side, randomly oriented about the vertical - on a lattice above the floor of an open box, plus
+    `n_plain` ordinary spheres dropped on top.  Ordinary bodies come first in the body order, the two-part bodies after."""
+    n = nx * ny * nz
+    i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    base = np.stack([(i.ravel() - (nx - 1) / 2.0) * pitch, y0 + j.ravel() * pitch, (k.ravel() - (nz - 1) / 2.0) * pitch], axis=1)
+    jit = np.stack([uniform(seed, n, -0.1, 0.1, stream=31 + s) for s in range(3)], axis=1)
+    c = (base + jit).astype(np.float32)
+    phi = uniform(seed, n, 0.0, 2.0 * np.pi, stream=34).astype(np.float64)
+    ax = np.stack([np.cos(phi), np.zeros(n), np.sin(phi)], axis=1).astype(np.float32)   # body axis in the horizontal plane
+    comps = np.zeros(2 * n, dtype=COMPONENT_DTYPE)
+    # part 0: the sphere, 0.45 along -axis; part 1: the capsule standing next to it, 0.45 along +axis
+    comps["tag"][0::2] = 0
+    comps["p"][0::2] = c - np.float32(0.45) * ax
+    comps["r"][0::2] = 0.5
+    comps["tag"][1::2] = 1
+    comps["p"][1::2] = c + np.float32(0.45) * ax - np.float32([0.0, 0.5, 0.0])
+    comps["d"][1::2] = np.float32([0.0, 1.0, 0.0])
+    comps["r"][1::2] = 0.3
+    half = max(nx, nz) * pitch / 2.0 + 2.0
+    terrain = box_terrain(half, ny * pitch + 6.0, (0.0, 0.0, 0.0))
+    pc = np.zeros((n_plain, 3), np.float32)
+    if n_plain:
+        pc[:, 0] = uniform(seed, n_plain, -half + 1.5, half - 1.5, stream=35)
+        pc[:, 2] = uniform(seed, n_plain, -half + 1.5, half - 1.5, stream=36)
+        pc[:, 1] = y0 + ny * pitch + 1.0 + 1.2 * np.arange(n_plain)
+    sc = _scene(f"dumbbell_field_{nx}x{ny}x{nz}+{n_plain}", _spheres(pc, 0.5), terrain, iters=iters)
+    v0c = np.stack([uniform(seed, n, -0.5, 0.5, stream=37 + s) for s in range(3)], axis=1)
+    sc["compound"] = dict(comps=comps, comp_mass=np.tile(np.float32([1.0, 0.8]), n), offsets=np.arange(0, 2 * n + 1, 2, dtype=np.int64),
+                          restitution=np.full(n, 0.3, np.float32), friction=np.full(n, 0.6, np.float32),
+                          force=np.tile(np.float32([0.0, -9.8, 0.0]), (n, 1)))
+    sc["v0"] = np.concatenate([np.zeros((n_plain, 3), np.float32), v0c.astype(np.float32)])
+    return sc
+
+
 def config(idx):
     """BASELINE.json configs by index."""
     if idx == 0:

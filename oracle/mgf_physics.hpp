@@ -87,8 +87,58 @@ struct RigidBodyVec {
   std::vector<M3> inv_moment_body, inv_moment;
   std::vector<ComponentConstructor> constructor;
   std::vector<Moving<Component>> collider;
+  // Bodies made of several components (BASELINE config 5).  NOT in the reference: physics.rs:200 takes one Component.
+  // Definition used by this build (and mirrored by the HIP path): the components are fixed in the body frame, relative
+  // to the centre of mass; mass = sum, tensor = sum of the components' tensors about the centre of mass (the reference's
+  // own Inertia, physics.rs:30-93); the swept parts are rebuilt from (x, q) every tick like the reference rebuilds a
+  // single collider (physics.rs:243-251).  `collider[i]` of such a body is a radius-0 sphere at x: it carries the
+  // centre and the motion (complete_motion, ConstrainedSet::get) and never collides.  Empty for ordinary bodies.
+  std::vector<std::vector<Component>> parts_local;
+  std::vector<std::vector<Moving<Component>>> parts;
+  static constexpr int KIND_COMPOUND = 2;
 
   size_t len() const { return x.size(); }
+  void sync_parts() { parts_local.resize(x.size()); parts.resize(x.size()); }
+  size_t n_parts(size_t i) const { return i < parts_local.size() && !parts_local[i].empty() ? parts_local[i].size() : 1; }
+  const Moving<Component>& part(size_t i, size_t k) const {
+    return i < parts_local.size() && !parts_local[i].empty() ? parts[i][k] : collider[i];
+  }
+  static Component part_world(const Component& l, V3 px, Quat pq) {
+    if (l.kind == COMP_SPHERE) return component(Sphere{px + rotate_vector(pq, l.s.c), l.s.r});
+    return component(Capsule{px + rotate_vector(pq, l.c.a), rotate_vector(pq, l.c.d), l.c.r});
+  }
+  bool add_compound_body(const Component* comps, const float* masses, size_t k, float rest, float fric, V3 world_force, size_t* id_out) {
+    if (k == 0) return false;
+    size_t id = x.size();
+    float total = 0.0f;
+    V3 acc = v3(0, 0, 0);
+    for (size_t c = 0; c < k; ++c) { total += masses[c]; acc = acc + center(comps[c]) * masses[c]; }
+    V3 com = acc / total;
+    M3 t = m3_zero();
+    for (size_t c = 0; c < k; ++c) t = t + tensor(comps[c] - com, masses[c]);
+    M3 inv;
+    if (!invert(t, &inv)) return false;
+    x.push_back(com);
+    q.push_back(quat_one());
+    v.push_back(v3(0, 0, 0));
+    omega.push_back(v3(0, 0, 0));
+    force.push_back(world_force * total);
+    torque.push_back(v3(0, 0, 0));
+    restitution.push_back(rest);
+    friction.push_back(fric);
+    inv_mass.push_back(1.0f / total);
+    inv_moment_body.push_back(inv);
+    inv_moment.push_back(inv);
+    constructor.push_back(ComponentConstructor{KIND_COMPOUND, 0.0f, 0.0f});
+    collider.push_back(sweep(component(Sphere{com, 0.0f}), v3(0, 0, 0)));
+    sync_parts();
+    for (size_t c = 0; c < k; ++c) {
+      parts_local[id].push_back(comps[c] - com);
+      parts[id].push_back(sweep(comps[c], v3(0, 0, 0)));
+    }
+    if (id_out) *id_out = id;
+    return true;
+  }
 
   // physics.rs:200-218.  Returns false where the reference's `.unwrap()` panics.
   bool add_body(const Component& col, float mass, float rest, float fric, V3 world_force, size_t* id_out) {
@@ -125,7 +175,14 @@ struct RigidBodyVec {
     }
     for (size_t i = 0; i < n; ++i) v[i] += force[i] * inv_mass[i] * dt;
     for (size_t i = 0; i < n; ++i) omega[i] += inv_moment[i] * torque[i] * dt;
-    for (size_t i = 0; i < n; ++i) collider[i] = sweep(construct(constructor[i], x[i], q[i]), v[i] * dt);
+    for (size_t i = 0; i < n; ++i) {
+      if (constructor[i].kind == KIND_COMPOUND) {
+        collider[i] = sweep(component(Sphere{x[i], 0.0f}), v[i] * dt);
+        for (size_t k = 0; k < parts_local[i].size(); ++k) parts[i][k] = sweep(part_world(parts_local[i][k], x[i], q[i]), v[i] * dt);
+      } else {
+        collider[i] = sweep(construct(constructor[i], x[i], q[i]), v[i] * dt);
+      }
+    }
   }
 
   // physics.rs:262-269

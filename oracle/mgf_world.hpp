@@ -40,6 +40,14 @@ struct Mesh {  // mesh.rs:32-37
   V3 center() const { return x; }                      // mesh.rs:89-91
   void set_pos(V3 p) { V3 disp = p - center(); x += disp; }  // geom.rs:459-462 + mesh.rs:76-80
 
+  // the face loop of Mesh::contacts (mesh.rs:115-139) with the body's test left to the caller: f(triangle at x)
+  template <class F>
+  void for_faces(const AABB& query, F&& f) const {
+    bvh.query(query - x, [&](size_t face_index) {
+      const auto& fc = faces[face_index];
+      f(Triangle{verts[fc[0]] + x, verts[fc[1]] + x, verts[fc[2]] + x});
+    });
+  }
   // Contacts<RHS> for Mesh, RHS = Moving<Component>  mesh.rs:115-139
   template <class F>
   bool contacts(const Moving<Component>& rhs, F&& cb) const {
@@ -103,8 +111,25 @@ struct World {
     bvh_ids.push_back(bvh_id);
     n_owned = bodies.len();
     tags.resize(n_owned, 0u);
+    bodies.sync_parts();
     if (id_out) *id_out = id;
     return true;
+  }
+  // a body of several components (see RigidBodyVec::add_compound_body); single-process worlds only
+  bool add_compound_body(const Component* comps, const float* masses, size_t k, float rest, float fric, V3 world_force, size_t* id_out) {
+    size_t id;
+    if (!bodies.add_compound_body(comps, masses, k, rest, fric, world_force, &id)) return false;
+    bvh_ids.push_back(bvh.insert(body_bounds(id) + fat_margin, id));
+    n_owned = bodies.len();
+    tags.resize(n_owned, 0u);
+    if (id_out) *id_out = id;
+    return true;
+  }
+  // swept bounds of a body: its collider's, or the union over its parts
+  AABB body_bounds(size_t i) const {
+    AABB b = bounds(bodies.part(i, 0));
+    for (size_t k = 1; k < bodies.n_parts(i); ++k) b = aabb_combine(b, bounds(bodies.part(i, k)));
+    return b;
   }
 
   void drop_ghosts() {
@@ -115,6 +140,7 @@ struct World {
     b.torque.resize(n_owned); b.restitution.resize(n_owned); b.friction.resize(n_owned); b.inv_mass.resize(n_owned);
     b.inv_moment_body.resize(n_owned, m3_zero()); b.inv_moment.resize(n_owned, m3_zero());
     b.constructor.resize(n_owned); b.collider.resize(n_owned);
+    b.sync_parts();
     tags.resize(n_owned, 0u);
   }
   // record: x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction (36 floats)
@@ -136,6 +162,7 @@ struct World {
     b.inv_moment_body.push_back(m3_zero()); b.inv_moment.push_back(I);
     b.constructor.push_back(ComponentConstructor{k.kind, o[23], 0.0f});
     b.collider.push_back(sweep(k, delta));
+    b.sync_parts();
     size_t id = b.len() - 1;
     bvh_ids.push_back(bvh.insert(bounds(b.collider[id]) + fat_margin, id));
   }
@@ -204,6 +231,7 @@ struct World {
         b.torque[out] = b.torque[i]; b.restitution[out] = b.restitution[i]; b.friction[out] = b.friction[i]; b.inv_mass[out] = b.inv_mass[i];
         b.inv_moment_body[out] = b.inv_moment_body[i]; b.inv_moment[out] = b.inv_moment[i];
         b.constructor[out] = b.constructor[i]; b.collider[out] = b.collider[i];
+        b.parts_local[out] = b.parts_local[i]; b.parts[out] = b.parts[i];
         bvh_ids[out] = bvh_ids[i];
         tags[out] = tags[i];
         bvh.pool[bvh_ids[out]].leaf = out;
@@ -234,6 +262,7 @@ struct World {
     std::memcpy(&kind, &o[48], 4);
     b.constructor.push_back(ComponentConstructor{(int)kind, o[49], o[50]});
     b.collider.push_back(sweep(k, v3(o[13], o[14], o[15])));
+    b.sync_parts();
     size_t id = b.len() - 1;
     bvh_ids.push_back(bvh.insert(AABB{v3(o[51], o[52], o[53]), v3(o[54], o[55], o[56])}, id));
     n_owned = b.len();
@@ -265,24 +294,41 @@ struct World {
     std::vector<size_t> hits;
     const size_t n = bodies.len();
     for (size_t i = 0; i < n; ++i) {
+      // the body's centre and motion (for a body of several parts: its centre of mass; `collider` is then a carrier)
       const Moving<Component> collider = bodies.collider[i];
-      AABB b = bounds(collider);
+      const V3 ci = center(collider.shape), vi = collider.vel;
+      const size_t np_i = bodies.n_parts(i);
+      AABB b = body_bounds(i);
       if (i < n_owned) {
         if (!aabb_contains(bvh[bvh_ids[i]], b)) {
           bvh.remove(bvh_ids[i]);
           bvh_ids[i] = bvh.insert(b + fat_margin, i);
           stats.n_refits++;
         }
-        local_contacts(collider, terrain, [&](const LocalContact& lc) {
-          solver.add_constraint(ContactConstraint::make(bodies, dynamic_ref(i), static_ref(terrain.center(), 0.0f),
-                                                        manifold_from(lc), dt, params));
-          stats.n_terrain_constraints++;
+        // Mesh::contacts (mesh.rs:115-139) + LocalContacts (collision.rs:1490-1506): faces in DFS order, per face the
+        // body's parts in order; every contact is its own constraint (world.rs:243-251)
+        terrain.for_faces(b, [&](const Triangle& tri) {
+          for (size_t pa = 0; pa < np_i; ++pa) {
+            mgfo::contacts(bodies.part(i, pa), tri, [&](const Contact& k) {
+              const Contact c{k.b, k.a, -k.n, k.t};  // the mesh-side view (mesh.rs:131-134)
+              const LocalContact lc{c.b + -(ci + vi * c.t), c.a + -terrain.center(), neg(c)};
+              solver.add_constraint(ContactConstraint::make(bodies, dynamic_ref(i), static_ref(terrain.center(), 0.0f),
+                                                            manifold_from(lc), dt, params));
+              stats.n_terrain_constraints++;
+            });
+          }
         });
       }
       if (i == 0) continue;
       auto on_hit = [&](size_t j) {
         ContactPruner pruner;
-        local_contacts(collider, bodies.collider[j], [&](const LocalContact& lc) { pruner.push(lc); });
+        // LocalContacts (compound.rs:192-207) over every pair of parts, local points relative to the bodies' centres
+        const V3 cj = center(bodies.collider[j].shape), vj = bodies.collider[j].vel;
+        for (size_t pa = 0; pa < np_i; ++pa)
+          for (size_t pb = 0; pb < bodies.n_parts(j); ++pb)
+            mgfo::contacts(bodies.part(i, pa), bodies.part(j, pb), [&](const Contact& c) {
+              pruner.push(LocalContact{c.a + -(ci + vi * c.t), c.b + -(cj + vj * c.t), c});
+            });
         Manifold manifold = manifold_from(pruner);
         if (manifold.len() == 0) return;
         solver.add_constraint(ContactConstraint::make(bodies, dynamic_ref(i), dynamic_ref(j), manifold, dt, params));
@@ -302,7 +348,8 @@ struct World {
       }
     }
     auto t2 = clk::now();
-    stats.n_constraints = solver.len();
+    stats.n_constraints = 0;  // counted per contact (= per constraint on the reference's path, where every manifold has one)
+    for (const ContactConstraint& c : solver.constraints) stats.n_constraints += c.states.size();
     stats.t_collide = std::chrono::duration<double>(t2 - t1).count();
   }
 

@@ -160,6 +160,9 @@ def lib():
         L.mgfo_world_set_terrain.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, P(Vec3)]
         L.mgfo_world_add_bodies.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mgfo_world_add_bodies.restype = C.c_int64
+        L.mgfo_world_add_compound_bodies.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mgfo_world_add_compound_bodies.restype = C.c_int64
+        L.mgfo_world_body_info.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.mgfo_world_len.argtypes = [C.c_void_p]
         L.mgfo_world_len.restype = C.c_int64
         L.mgfo_world_step.argtypes = [C.c_void_p, C.c_float, C.c_int64, P(Stats)]
@@ -416,6 +419,27 @@ class World:
         if r < 0:
             raise ValueError("singular inertia tensor (reference panics, physics.rs:212)")
         return r
+
+    def add_compound_bodies(self, comps, comp_mass, offsets, rest, fric, force):
+        """Bodies of several components (not in the reference; see RigidBodyVec::add_compound_body): body b is made of
+        comps[offsets[b]:offsets[b + 1]] with masses comp_mass[...]."""
+        comps = np.ascontiguousarray(comps, dtype=COMPONENT_DTYPE)
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        n = len(offsets) - 1
+        comp_mass = np.ascontiguousarray(np.broadcast_to(np.asarray(comp_mass, np.float32), (len(comps),)))
+        rest = np.ascontiguousarray(np.broadcast_to(np.asarray(rest, np.float32), (n,)))
+        fric = np.ascontiguousarray(np.broadcast_to(np.asarray(fric, np.float32), (n,)))
+        force = np.ascontiguousarray(np.broadcast_to(np.asarray(force, np.float32), (n, 3)))
+        r = lib().mgfo_world_add_compound_bodies(self.h, comps.ctypes.data, comp_mass.ctypes.data, offsets.ctypes.data, n,
+                                                 rest.ctypes.data, fric.ctypes.data, force.ctypes.data)
+        if r < 0:
+            raise ValueError("empty body or singular inertia tensor")
+        return r
+
+    def body_info(self, i):
+        out = np.zeros(10, np.float32)
+        lib().mgfo_world_body_info(self.h, int(i), out.ctypes.data)
+        return dict(inv_mass=float(out[0]), inv_moment=out[1:].copy())
 
     def __len__(self):
         return lib().mgfo_world_len(self.h)

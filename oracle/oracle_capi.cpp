@@ -323,6 +323,24 @@ int64_t mgfo_world_add_bodies(void* wp, const o_component* comps, int64_t n, con
   }
   return (int64_t)w->bodies.len();
 }
+// bodies of several components: components of body b are comps[offsets[b] .. offsets[b + 1]) with masses comp_mass[..]
+int64_t mgfo_world_add_compound_bodies(void* wp, const o_component* comps, const float* comp_mass, const int64_t* offsets, int64_t n,
+                                       const float* rest, const float* fric, const o_vec3* force) {
+  World* w = (World*)wp;
+  for (int64_t b = 0; b < n; ++b) {
+    std::vector<Component> cs;
+    for (int64_t k = offsets[b]; k < offsets[b + 1]; ++k) cs.push_back(as_component(comps[k]));
+    size_t id;
+    if (!w->add_compound_body(cs.data(), comp_mass + offsets[b], cs.size(), rest[b], fric[b], V(force[b]), &id)) return -1;
+  }
+  return (int64_t)w->bodies.len();
+}
+// inv_mass, then inv_moment_body column by column (10 floats)
+void mgfo_world_body_info(void* wp, int64_t i, float* out) {
+  const RigidBodyVec& b = ((World*)wp)->bodies;
+  out[0] = b.inv_mass[(size_t)i];
+  for (int c = 0; c < 3; ++c) { const V3 col = b.inv_moment_body[(size_t)i].c[c]; out[1 + 3 * c] = col.x; out[2 + 3 * c] = col.y; out[3 + 3 * c] = col.z; }
+}
 int64_t mgfo_world_len(void* wp) { return (int64_t)((World*)wp)->n_owned; }
 void mgfo_world_step(void* wp, float dt, int64_t iters, o_stats* st) {
   World* w = (World*)wp;
@@ -409,30 +427,32 @@ void mgfo_world_import_ghost_velocities(void* wp, const float* in, int64_t n) {
 }
 void mgfo_world_solve(void* wp, int64_t iters) { World* w = (World*)wp; w->solver.solve(w->bodies, (size_t)iters); }
 uint32_t mgfo_world_constraint_depth(void* wp, uint32_t iters) { return ((World*)wp)->constraint_depth(iters); }
+// One row per CONTACT: a constraint with m contacts (bodies of several parts only) gives m consecutive rows that share
+// its bodies, normal, tangents and friction - the flattened form the HIP path stores (see k_setup_pairs).
 int64_t mgfo_world_get_constraints(void* wp, o_constraint* out, int64_t cap) {
   World* w = (World*)wp;
-  int64_t n = (int64_t)w->solver.constraints.size();
-  for (int64_t i = 0; i < n && i < cap; ++i) {
-    const ContactConstraint& c = w->solver.constraints[(size_t)i];
-    o_constraint o;
-    std::memset(&o, 0, sizeof(o));
-    o.a = c.obj_a.is_static ? -1 : (int32_t)c.obj_a.index;
-    o.b = c.obj_b.is_static ? -1 : (int32_t)c.obj_b.index;
-    o.n_contacts = (int32_t)c.states.size();
-    o.normal = O(c.manifold.normal);
-    o.t0 = O(c.manifold.tangent_vector[0]);
-    o.t1 = O(c.manifold.tangent_vector[1]);
-    o.friction = c.friction;
-    if (c.states.size() > 0) {
-      o.ra = O(c.manifold.contacts[0].a);
-      o.rb = O(c.manifold.contacts[0].b);
-      const ContactState& s = c.states[0];
-      o.bias = s.bias; o.normal_mass = s.normal_mass; o.tangent_mass0 = s.tangent_mass[0]; o.tangent_mass1 = s.tangent_mass[1];
-      o.normal_impulse = s.normal_impulse;
+  int64_t row = 0;
+  for (const ContactConstraint& c : w->solver.constraints) {
+    for (size_t k = 0; k < c.states.size(); ++k, ++row) {
+      if (row >= cap) continue;
+      o_constraint o;
+      std::memset(&o, 0, sizeof(o));
+      o.a = c.obj_a.is_static ? -1 : (int32_t)c.obj_a.index;
+      o.b = c.obj_b.is_static ? -1 : (int32_t)c.obj_b.index;
+      o.n_contacts = 1;
+      o.normal = O(c.manifold.normal);
+      o.t0 = O(c.manifold.tangent_vector[0]);
+      o.t1 = O(c.manifold.tangent_vector[1]);
+      o.friction = c.friction;
+      o.ra = O(c.manifold.contacts[k].a);
+      o.rb = O(c.manifold.contacts[k].b);
+      const ContactState& st = c.states[k];
+      o.bias = st.bias; o.normal_mass = st.normal_mass; o.tangent_mass0 = st.tangent_mass[0]; o.tangent_mass1 = st.tangent_mass[1];
+      o.normal_impulse = st.normal_impulse;
+      out[row] = o;
     }
-    out[i] = o;
   }
-  return n;
+  return row;
 }
 // State access: x, q, v, omega, delta (collider.1) — the snapshot SURVEY §5 calls for.
 void mgfo_world_get_state(void* wp, o_vec3* x, o_quat* q, o_vec3* v, o_vec3* omega, o_vec3* delta) {

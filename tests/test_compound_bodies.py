@@ -1,0 +1,155 @@
+"""Bodies of several components (BASELINE config 5).  The reference has no such body (physics.rs:200 takes one
+Component), so the authority is this build's own definition, stated in RigidBodyVec::add_compound_body
+(oracle/mgf_physics.hpp) and include/mgf_hip.h.  CPU part: the definition checked against hand-derived values and
+against the ordinary-body path it must reduce to.  GPU part: the HIP path against the oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from mgf_amd import scenes
+from tests.util import compare_constraints, oracle_world, rel_err, values_equal
+
+
+def _sphere(c, r):
+    k = np.zeros(1, O.COMPONENT_DTYPE)
+    k["tag"], k["p"], k["r"] = 0, c, r
+    return k
+
+
+def _world(terrain=True):
+    w = O.World(O.ORDER_CANONICAL)
+    if terrain:
+        t = scenes.box_terrain(8.0, 10.0, (0.0, 0.0, 0.0))
+        w.set_terrain(t["verts"], t["faces"], t["pos"])
+    return w
+
+
+def test_dumbbell_mass_centre_and_inertia():
+    """Two spheres m = 1 and m = 3, r = 0.5, at x = -1 and x = +1: centre of mass at x = 0.5; about it the tensor is
+    sum_k (0.4 m r^2 I + m (|c|^2 I - c c^T)) with c = (-1.5, 0, 0) and (0.5, 0, 0):
+    Ixx = 0.4*0.25*(1+3) = 0.4, Iyy = Izz = 0.4 + 1*2.25 + 3*0.25 = 3.4."""
+    w = _world(terrain=False)
+    comps = np.concatenate([_sphere([-1, 2, 0], 0.5), _sphere([1, 2, 0], 0.5)])
+    w.add_compound_bodies(comps, [1.0, 3.0], [0, 2], 0.3, 0.6, [0, -9.8, 0])
+    s = w.state()
+    assert np.allclose(s["x"][0], [0.5, 2.0, 0.0], atol=1e-6)
+    info = w.body_info(0)
+    assert abs(info["inv_mass"] - 0.25) < 1e-7
+    inv = np.asarray(info["inv_moment"]).reshape(3, 3)
+    assert np.allclose(np.diag(inv), [1 / 0.4, 1 / 3.4, 1 / 3.4], rtol=1e-6) and np.allclose(inv - np.diag(np.diag(inv)), 0, atol=1e-7)
+
+
+def test_one_part_body_equals_the_ordinary_body():
+    """A body of ONE sphere is the reference's body: same tensor, same collider, same contacts - the two worlds must stay
+    bit-identical through a fall and a collision."""
+    a, b = _world(), _world()
+    cs = np.concatenate([_sphere([0.0, 1.2, 0.0], 0.5), _sphere([0.3, 2.4, 0.1], 0.5)])
+    a.add_bodies(cs, 1.0, 0.3, 0.6, [0, -9.8, 0])
+    b.add_compound_bodies(cs, [1.0, 1.0], [0, 1, 2], 0.3, 0.6, [0, -9.8, 0])
+    for _ in range(80):
+        sa, sb = a.step(1 / 60, 10), b.step(1 / 60, 10)
+        assert sa.n_constraints == sb.n_constraints
+    assert sa.n_constraints > 0
+    for k, v in a.state().items():
+        assert np.array_equal(v, b.state()[k]), k
+
+
+def test_two_part_body_rests_on_both_parts():
+    """A dumbbell lying on the floor touches it with both spheres: two terrain constraints on one body, no spin."""
+    w = _world()
+    comps = np.concatenate([_sphere([-0.6, 0.6, 0], 0.5), _sphere([0.6, 0.6, 0], 0.5)])
+    w.add_compound_bodies(comps, [1.0, 1.0], [0, 2], 0.0, 0.6, [0, -9.8, 0])
+    for _ in range(240):
+        st = w.step(1 / 60, 10)
+    s = w.state()
+    assert st.n_terrain_constraints == 2 and st.n_constraints == 2
+    assert 0.40 < s["x"][0, 1] < 0.52 and abs(s["v"][0]).max() < 0.25 and abs(s["omega"][0]).max() < 1e-3
+    cons = w.constraints()
+    assert cons["a"].tolist() == [0, 0] and cons["b"].tolist() == [-1, -1]
+    assert np.allclose(np.sort(cons["ra"][:, 0]), [-0.6, 0.6], atol=1e-3)  # local points relative to the centre of mass
+
+
+def test_body_pair_keeps_up_to_four_contacts_in_one_manifold():
+    """Two dumbbells stacked crosswise... lying parallel, one on top of the other: both spheres of the upper touch a
+    sphere of the lower - one ContactConstraint with two contacts (ContactPruner keeps points farther apart than
+    sqrt(0.5)), exported as two consecutive rows with the same normal."""
+    w = _world()
+    low = np.concatenate([_sphere([-0.6, 0.5, 0], 0.5), _sphere([0.6, 0.5, 0], 0.5)])
+    up = np.concatenate([_sphere([-0.6, 1.52, 0], 0.5), _sphere([0.6, 1.52, 0], 0.5)])
+    w.add_compound_bodies(np.concatenate([low, up]), 1.0, [0, 2, 4], 0.0, 0.6, [0, -9.8, 0])
+    for _ in range(60):
+        st = w.step(1 / 60, 10)
+    cons = w.constraints()
+    pair = cons[(cons["a"] == 1) & (cons["b"] == 0)]
+    assert len(pair) == 2 and np.array_equal(pair["normal"][0], pair["normal"][1])
+    assert abs(pair["normal"][0][1]) > 0.99 and st.n_constraints == len(cons)
+
+
+def test_config5_scene_runs_and_settles():
+    sc = scenes.dumbbell_field(4, 2, 4, n_plain=6)
+    w = oracle_world(sc)
+    for _ in range(120):
+        st = w.step(float(sc["dt"]), sc["iters"])
+    s = w.state()
+    assert np.isfinite(s["x"]).all() and s["x"][:, 1].min() > 0.2 and st.n_constraints > 30
+
+
+# ---- HIP path -------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ctx():
+    import mgf_amd
+    c = mgf_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_plain,mode", [(0, 5), (6, 5), (6, 0), (6, 1)])
+def test_hip_dumbbell_field_equals_oracle(ctx, n_plain, mode):
+    import mgf_amd
+    sc = scenes.dumbbell_field(4, 2, 4, n_plain=n_plain)
+    dt, iters = float(sc["dt"]), sc["iters"]
+    gw, ow = mgf_amd.World.from_scene(ctx, sc), oracle_world(sc)
+    gw.set_option("solver_mode", mode)
+    multi = 0
+    for tick in range(100):
+        sg, so = gw.step(dt, iters), ow.step(dt, iters)
+        assert (sg.n_constraints, sg.n_terrain_constraints, sg.n_pair_candidates) == (so.n_constraints, so.n_terrain_constraints, so.n_pair_candidates), f"tick {tick}"
+        if tick % 20 == 19:
+            got, want = gw.constraints(), ow.constraints()
+            compare_constraints(got, want, check_impulse=True)
+            ab = list(zip(want["a"].tolist(), want["b"].tolist()))
+            multi += sum(1 for k in range(1, len(ab)) if ab[k] == ab[k - 1] and ab[k][1] >= 0)
+    assert so.n_constraints > 30 and multi > 0  # manifolds of several contacts occurred
+    g, o = gw.state(), ow.state()
+    for k in ("x", "q", "v", "omega", "delta"):
+        assert values_equal(g[k], o[k]), f"{k}: rel err {rel_err(g[k], o[k])}"
+
+
+@pytest.mark.gpu
+def test_hip_larger_config5_scene(ctx):
+    """8 x 3 x 8 two-part bodies + 30 spheres, 60 ticks: counts and state equal to the oracle's."""
+    import mgf_amd
+    sc = scenes.dumbbell_field(8, 3, 8, n_plain=30)
+    dt, iters = float(sc["dt"]), sc["iters"]
+    gw, ow = mgf_amd.World.from_scene(ctx, sc), oracle_world(sc)
+    for tick in range(60):
+        sg, so = gw.step(dt, iters), ow.step(dt, iters)
+        assert sg.n_constraints == so.n_constraints and sg.n_pair_candidates == so.n_pair_candidates, f"tick {tick}"
+    g, o = gw.state(), ow.state()
+    for k in ("x", "q", "v", "omega"):
+        assert values_equal(g[k], o[k]), f"{k}: rel err {rel_err(g[k], o[k])}"
+
+
+@pytest.mark.gpu
+def test_hip_compound_worlds_refuse_the_tiling_calls(ctx):
+    import torch
+    import mgf_amd
+    sc = scenes.dumbbell_field(2, 1, 2)
+    gw = mgf_amd.World.from_scene(ctx, sc)
+    ids = torch.zeros(4, dtype=torch.int32, device="cuda")
+    out = torch.zeros((4, 36), dtype=torch.float32, device="cuda")
+    with pytest.raises(mgf_amd.MgfError):
+        gw.export_bodies(ids.data_ptr(), 1, out.data_ptr())
+    with pytest.raises(mgf_amd.MgfError):
+        gw.add_compound_bodies(sc["compound"]["comps"][:3], 1.0, [0, 3], 0.3, 0.6, [0, -9.8, 0])  # three parts: over the limit

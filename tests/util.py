@@ -9,7 +9,11 @@ def oracle_world(scene, order=O.ORDER_CANONICAL):
     t = scene["terrain"]
     if t is not None:
         w.set_terrain(t["verts"], t["faces"], t["pos"])
-    w.add_bodies(scene["comps"], scene["mass"], scene["restitution"], scene["friction"], scene["force"])
+    if len(scene["comps"]):
+        w.add_bodies(scene["comps"], scene["mass"], scene["restitution"], scene["friction"], scene["force"])
+    cb = scene.get("compound")
+    if cb is not None:
+        w.add_compound_bodies(cb["comps"], cb["comp_mass"], cb["offsets"], cb["restitution"], cb["friction"], cb["force"])
     if scene.get("v0") is not None:
         w.set_state(v=scene["v0"])
     return w
