@@ -213,6 +213,7 @@ def dumbbell_field(nx, ny, nz, n_plain=0, seed=SEED, iters=10, pitch=2.2, y0=1.5
     base = np.stack([(i.ravel() - (nx - 1) / 2.0) * pitch, y0 + j.ravel() * pitch, (k.ravel() - (nz - 1) / 2.0) * pitch], axis=1)
     jit = np.stack([uniform(seed, n, -0.1, 0.1, stream=31 + s) for s in range(3)], axis=1)
     c = (base + jit).astype(np.float32)
+    c = c[seeded_permutation(seed, n, stream=38)]  # body order independent of position (bounds the dependency depth)
     phi = uniform(seed, n, 0.0, 2.0 * np.pi, stream=34).astype(np.float64)
     ax = np.stack([np.cos(phi), np.zeros(n), np.sin(phi)], axis=1).astype(np.float32)   # body axis in the horizontal plane
     comps = np.zeros(2 * n, dtype=COMPONENT_DTYPE)

@@ -17,11 +17,15 @@ def main():
     ap.add_argument("--plain", type=int, default=0)
     ap.add_argument("--warmup", type=int, default=80)
     ap.add_argument("--ticks", type=int, default=40)
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE")
     a = ap.parse_args()
     sc = scenes.dumbbell_field(*a.dims, n_plain=a.plain)
     ctx = mgf_amd.Context(0)
     w = mgf_amd.World.from_scene(ctx, sc)
     dt, iters = float(sc["dt"]), sc["iters"]
+    for kv in a.opt:
+        key, val = kv.split("=")
+        w.set_option(key, int(val))
     for _ in range(a.warmup):
         w.step(dt, iters)
     acc = dict(ms_integrate=0.0, ms_broadphase=0.0, ms_narrowphase=0.0, ms_setup=0.0, ms_solve=0.0, ms_total=0.0)
