@@ -1987,7 +1987,9 @@ static mgf_status solve_flow_enqueue(mgf_world* w, int32_t iters, uint32_t cap_c
   if (use5) {
     // blocks of nb bodies in cell order, one workgroup each, all resident: at most one per CU
     const uint32_t need = (w->n + (uint32_t)ctx->num_cus - 1u) / (uint32_t)ctx->num_cus;
-    uint32_t nb = std::max(need, std::min(w->n, 1024u));
+    // one block per CU when there are enough bodies (262 144 -> 1024 per block); smaller worlds keep every CU busy with
+    // blocks down to 256 bodies (config 5, 65 536 bodies: 0.52 -> 0.45 ms solve)
+    uint32_t nb = std::max(need, std::min(w->n, 256u));
     if (w->opt_flow5_block > 0) nb = std::max(need, (uint32_t)w->opt_flow5_block);  // tests: small blocks on small scenes
     if (nb > kF5MaxBodies) use5 = false;
     else { w->f5_nb = nb; w->f5_nblocks = (w->n + nb - 1u) / nb; }
