@@ -19,7 +19,7 @@ UNITS = ["prims.hip", "mgf_hip.hip"]
 
 def _deps(unit):
     srcs = [os.path.join(CSRC, unit)]
-    srcs += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    srcs += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     srcs.append(os.path.join(HERE, "..", "include", "mgf_hip.h"))
     return srcs
 
