@@ -214,7 +214,7 @@ MGF_API mgf_status mgf_world_add_bodies(mgf_world* w, const mgf_component* comps
  * (physics.rs:243-251).  Contacts: every pair of parts (Contacts, compound.rs:180-190), local points relative to the
  * bodies' centres, ContactPruner + Manifold::from(pruner) (manifold.rs:72-148) - up to 4 contacts per pair of bodies, each
  * a consecutive single-contact constraint record with the manifold's normal (equivalent to solver.rs:219-248).
- * Single-process worlds only: the tiling calls refuse worlds that hold such bodies. */
+ * Ghost and migrant records carry the parts, so such bodies cross tiles like the others (kind bit 2 of "body_kinds"). */
 MGF_API mgf_status mgf_world_add_compound_bodies(mgf_world* w, const mgf_component* comps, const float* comp_mass,
                                                  const int64_t* offsets /* n + 1 */, int64_t n, const float* restitution,
                                                  const float* friction, const mgf_vec3* world_force, uint64_t* first_id);
@@ -276,7 +276,8 @@ MGF_API mgf_status mgf_compound_intersections(mgf_compound* c, const mgf_particl
  * Ghost bodies are local copies of a neighbour tile's boundary bodies; they collide with owned
  * bodies only (their terrain contacts and ghost-ghost pairs belong to their owner).  All buffers
  * below are DEVICE pointers owned by the caller (e.g. the exchange buffers handed to RCCL).
- * Ghost record: 36 floats  x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction;
+ * Ghost record: 56 floats  x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction | n_parts, 3 pad |
+ * 2 x (p3 r d3 kind) world parts of a body of several components (zeros otherwise);
  * velocity record: 8 floats v3 w3 0 0. */
 MGF_API mgf_status mgf_world_begin_tick(mgf_world* w, float dt);     /* complete_motion + integrate (world.rs:230-231) */
 MGF_API mgf_status mgf_world_collide(mgf_world* w, float dt, mgf_step_stats* stats); /* world.rs:233-291 */
@@ -296,7 +297,7 @@ MGF_API int64_t mgf_world_ghost_len(const mgf_world* w);
  * export_migrants (MGF_MIGRANT_FLOATS floats per body: the body's row of every device array, fat AABB and tag
  * included) -> neighbour -> remove_bodies on the old owner, import_migrants (append) on the new one.  Ids of the
  * remaining bodies shift down on removal; mgf_world_set_tags / read_tags give bodies an identity that survives. */
-#define MGF_MIGRANT_FLOATS 80
+#define MGF_MIGRANT_FLOATS 116
 MGF_API mgf_status mgf_world_select_tile(mgf_world* w, float x_left, float x_right, float x_lo, float x_hi,
                                          uint32_t* ids_left, uint32_t* ids_right, uint32_t* ids_migrants, int64_t cap,
                                          int64_t* counts /* [4] */);

@@ -6,9 +6,10 @@ namespace mgf {
 
 // ------------------------------------------------------------------------------------------
 // Spatial tiling (one process per GPU): boundary selection, ghost export / import.
-// Ghost record, 36 floats: x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction.
+// Ghost record, 56 floats: x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction | n_parts, 3 pad |
+// 2 x (p3 r d3 kind) world parts of a body of several components (zeros for an ordinary body).
 // ------------------------------------------------------------------------------------------
-constexpr int kGhostFloats = 36;
+constexpr int kGhostFloats = 56;
 
 // flags[i] bit0: owned body i's fat box reaches below x_left; bit1: above x_right.
 __global__ __launch_bounds__(kBlock) void k_boundary_flags(Bodies B, uint32_t n_owned, float x_left, float x_right, uint32_t* fl,
@@ -46,6 +47,14 @@ __global__ __launch_bounds__(kBlock) void k_export_bodies(Bodies B, const uint32
   o[24] = s1.z;
   o[25] = s1.w; o[26] = s2.x; o[27] = s2.y; o[28] = s2.z; o[29] = s2.w; o[30] = s3.x; o[31] = s3.y; o[32] = s3.z; o[33] = s3.w;
   o[34] = e.w; o[35] = d.w;
+  const uint32_t pc = B.pcount ? B.pcount[i] : 0u;
+  o[36] = u2f(pc); o[37] = o[38] = o[39] = 0.0f;
+  for (uint32_t k = 0; k < (uint32_t)kMaxParts; ++k) {
+    float4 a = make_float4(0, 0, 0, 0), b = a;
+    if (k < pc) { a = B.wp0[kMaxParts * i + k]; b = B.wp1[kMaxParts * i + k]; }
+    float* q8 = o + 40 + 8 * k;
+    q8[0] = a.x; q8[1] = a.y; q8[2] = a.z; q8[3] = a.w; q8[4] = b.x; q8[5] = b.y; q8[6] = b.z; q8[7] = b.w;
+  }
 }
 __global__ __launch_bounds__(kBlock) void k_import_ghosts(Bodies B, uint32_t n_owned, uint32_t m, const float* in, float fat_margin) {
   uint32_t t = blockIdx.x * kBlock + threadIdx.x;
@@ -65,10 +74,25 @@ __global__ __launch_bounds__(kBlock) void k_import_ghosts(Bodies B, uint32_t n_o
   B.col0[i] = mk4(k.p, k.r);
   B.col1[i] = mk4(k.d, o[16]);
   Box tb = swept_bounds(k, d);
+  const uint32_t pc = min(f2u(o[36]), (uint32_t)kMaxParts);
+  if (B.pcount) {
+    B.pcount[i] = pc;
+    for (uint32_t pk = 0; pk < (uint32_t)kMaxParts; ++pk) {  // a ghost is never integrated here: its world parts are all that matters
+      const float* q8 = o + 40 + 8 * pk;
+      float4 a = make_float4(q8[0], q8[1], q8[2], q8[3]), b = make_float4(q8[4], q8[5], q8[6], q8[7]);
+      B.wp0[kMaxParts * i + pk] = a; B.wp1[kMaxParts * i + pk] = b;
+      B.lp0[kMaxParts * i + pk] = a; B.lp1[kMaxParts * i + pk] = b;
+      if (pk < pc) {
+        Comp part; part.kind = (int)f2u(b.w); part.p = xyz(a); part.r = a.w; part.d = xyz(b);
+        Box pb = swept_bounds(part, d);
+        tb = pk == 0 ? pb : box_combine(tb, pb);
+      }
+    }
+  }
   B.tb_c[i] = mk4(tb.c, 0.0f); B.tb_r[i] = mk4(tb.r, 0.0f);
   B.fb_c[i] = mk4(tb.c, 0.0f); B.fb_r[i] = mk4(tb.r + mk3(fat_margin, fat_margin, fat_margin), 0.0f);
   B.sp0[i] = make_float4(0, 0, 0, o[34]); B.sp1[i] = make_float4(0, 0, 0, o[35]);
-  B.ctor[i] = make_float4(o[16], k.r, 0.0f, 0.0f);
+  B.ctor[i] = make_float4(pc ? u2f(2u) : o[16], k.r, 0.0f, 0.0f);
   B.imb[3 * i] = make_float4(0, 0, 0, 0); B.imb[3 * i + 1] = make_float4(0, 0, 0, 0); B.imb[3 * i + 2] = make_float4(0, 0, 0, 0);
 }
 // velocity record: 8 floats (v3, w3, 0, 0)
@@ -90,9 +114,9 @@ __global__ __launch_bounds__(kBlock) void k_import_ghost_vel(float4* srec, uint3
 }
 
 // ---- migration of owned bodies between tiles -----------------------------------------------------
-// A migrant record is the body's row of every Bodies array, verbatim (kMigrantWords float4 = 80 floats): the
+// A migrant record is the body's row of every Bodies array, verbatim (kMigrantWords float4 = 116 floats): the
 // receiving tile continues bit-identically, persistent fat box and constructor tag (ctor.w) included.
-constexpr int kMigrantWords = 20;
+constexpr int kMigrantWords = 29;  // 20 words of the ordinary arrays + part count + 2 slots of each of the four part arrays
 __device__ __forceinline__ float4* body_word(const Bodies& B, uint32_t e, uint32_t i) {
   switch (e) {
     case 0: return B.x + i;
@@ -109,8 +133,25 @@ __device__ __forceinline__ float4* body_word(const Bodies& B, uint32_t e, uint32
     case 16: return B.tb_c + i;
     case 17: return B.tb_r + i;
     case 18: return B.fb_c + i;
-    default: return B.fb_r + i;
+    case 19: return B.fb_r + i;
+    case 21: case 22: return B.lp0 + (size_t)kMaxParts * i + (e - 21);
+    case 23: case 24: return B.lp1 + (size_t)kMaxParts * i + (e - 23);
+    case 25: case 26: return B.wp0 + (size_t)kMaxParts * i + (e - 25);
+    default: return B.wp1 + (size_t)kMaxParts * i + (e - 27);
   }
+}
+// words 20.. exist only in worlds that hold bodies of several parts (elsewhere they read as zeros and writes are dropped)
+__device__ __forceinline__ float4 migrant_get(const Bodies& B, uint32_t e, uint32_t i) {
+  if (e < 20u) return *body_word(B, e, i);
+  if (!B.pcount) return make_float4(0, 0, 0, 0);
+  if (e == 20u) return make_float4(u2f(B.pcount[i]), 0, 0, 0);
+  return *body_word(B, e, i);
+}
+__device__ __forceinline__ void migrant_put(const Bodies& B, uint32_t e, uint32_t i, float4 v) {
+  if (e < 20u) { *body_word(B, e, i) = v; return; }
+  if (!B.pcount) return;
+  if (e == 20u) { B.pcount[i] = f2u(v.x); return; }
+  *body_word(B, e, i) = v;
 }
 // cnt[0] / cnt[1] += owned bodies whose centre lies below x_lo / at or above x_hi (the slab is [x_lo, x_hi))
 __global__ __launch_bounds__(kBlock) void k_migrant_count(Bodies B, uint32_t n_owned, float x_lo, float x_hi, uint32_t* cnt) {
@@ -135,13 +176,13 @@ __global__ __launch_bounds__(kBlock) void k_export_migrants(Bodies B, const uint
   uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= m * kMigrantWords) return;
   uint32_t b = t / kMigrantWords, e = t % kMigrantWords;
-  out[t] = *body_word(B, e, ids[b]);
+  out[t] = migrant_get(B, e, ids[b]);
 }
 __global__ __launch_bounds__(kBlock) void k_import_migrants(Bodies B, uint32_t base, uint32_t m, const float4* in) {
   uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= m * kMigrantWords) return;
   uint32_t b = t / kMigrantWords, e = t % kMigrantWords;
-  *body_word(B, e, base + b) = in[t];
+  migrant_put(B, e, base + b, in[t]);
 }
 // keep[i] = 1 for i < n, keep[n] = 0 (scan total); then the listed bodies are cleared
 __global__ __launch_bounds__(kBlock) void k_keep_fill(uint32_t* keep, uint32_t n) {
@@ -159,11 +200,11 @@ __global__ __launch_bounds__(kBlock) void k_compact_gather(Bodies B, uint32_t n,
   uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= n * kMigrantWords) return;
   uint32_t i = t / kMigrantWords, e = t % kMigrantWords;
-  if (keep[i]) tmp[(size_t)pos[i] * kMigrantWords + e] = *body_word(B, e, i);
+  if (keep[i]) tmp[(size_t)pos[i] * kMigrantWords + e] = migrant_get(B, e, i);
 }
-__global__ __launch_bounds__(kBlock) void k_kind_mask(const float4* col1, uint32_t base, uint32_t m, uint32_t* mask) {
+__global__ __launch_bounds__(kBlock) void k_kind_mask(const float4* col1, const uint32_t* pcount, uint32_t base, uint32_t m, uint32_t* mask) {
   uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t < m) atomicOr(mask, f2u(col1[base + t].w) == (uint32_t)KIND_SPHERE ? 1u : 2u);
+  if (t < m) atomicOr(mask, (pcount && pcount[base + t]) ? 4u : (f2u(col1[base + t].w) == (uint32_t)KIND_SPHERE ? 1u : 2u));
 }
 __global__ __launch_bounds__(kBlock) void k_tags_set(float4* ctor, const uint32_t* tags, uint32_t n) {
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;

@@ -107,6 +107,13 @@ static mgf_status d2h(mgf_ctx* ctx, T* dst, const T* src, size_t n) {
   return MGF_OK;
 }
 
+// append `add` behind the first old_n elements of a device array
+template <class T>
+static mgf_status append(mgf_ctx* ctx, DBuf<T>& buf, size_t old_n, const std::vector<T>& add) {
+  MGF_TRY(buf.ensure(old_n + add.size(), ctx->stream, true, old_n));
+  return h2d(ctx, buf.p + old_n, add.data(), add.size());
+}
+
 #include "host_trees.inc"
 #include "host_single_shot.inc"
 #include "host_world.inc"

@@ -241,6 +241,40 @@ def dumbbell_field(nx, ny, nz, n_plain=0, seed=SEED, iters=10, pitch=2.2, y0=1.5
     return sc
 
 
+def split_by_slabs(scene, world_size, half_x):
+    """x-slab tiles of a scene built by dumbbell_field: tile r gets the bodies whose centre lies in its slab of
+    [-half_x, half_x), in their original order; `tags` are the bodies' indices in the undivided scene."""
+    cb = scene["compound"]
+    n_plain = len(scene["comps"])
+    off = cb["offsets"]
+    nb = len(off) - 1
+    m = np.asarray(cb["comp_mass"], np.float64)
+    ctr = cb["comps"]["p"].astype(np.float64) + 0.5 * cb["comps"]["d"].astype(np.float64) * (cb["comps"]["tag"][:, None] == 1)
+    com_x = np.array([np.sum(ctr[off[b]:off[b + 1], 0] * m[off[b]:off[b + 1]]) / np.sum(m[off[b]:off[b + 1]]) for b in range(nb)])
+    plain_x = scene["comps"]["p"][:, 0].astype(np.float64)
+    edges = np.linspace(-half_x, half_x, world_size + 1)
+    tiles = []
+    for r in range(world_size):
+        lo = -np.inf if r == 0 else edges[r]
+        hi = np.inf if r + 1 == world_size else edges[r + 1]
+        pi = np.nonzero((plain_x >= lo) & (plain_x < hi))[0]
+        bi = np.nonzero((com_x >= lo) & (com_x < hi))[0]
+        sc = dict(scene)
+        for key in ("comps", "mass", "restitution", "friction", "force"):
+            sc[key] = scene[key][pi]
+        parts = np.concatenate([np.arange(off[b], off[b + 1]) for b in bi]) if len(bi) else np.zeros(0, np.int64)
+        sizes = np.array([off[b + 1] - off[b] for b in bi], np.int64)
+        sc["compound"] = dict(comps=cb["comps"][parts], comp_mass=np.asarray(cb["comp_mass"], np.float32)[parts],
+                              offsets=np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64),
+                              restitution=cb["restitution"][bi], friction=cb["friction"][bi], force=cb["force"][bi])
+        sc["v0"] = np.concatenate([scene["v0"][pi], scene["v0"][n_plain + bi]])
+        sc["tags"] = np.concatenate([pi, n_plain + bi]).astype(np.uint32)
+        sc["x_range"] = (float(edges[r]), float(edges[r + 1]))
+        sc["name"] = f"{scene['name']}_tile{r}of{world_size}"
+        tiles.append(sc)
+    return tiles
+
+
 def config(idx):
     """BASELINE.json configs by index."""
     if idx == 0:

@@ -143,7 +143,21 @@ struct World {
     b.sync_parts();
     tags.resize(n_owned, 0u);
   }
-  // record: x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction (36 floats)
+  // record (kGhostFloats = 56): x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction | n_parts, 3 pad |
+  // 2 x (p3 r d3 kind) world parts of a body of several components (zeros for an ordinary body)
+  static constexpr int kGhostFloats = 56;
+  static void put_part(float* o, const Component& c) {
+    uint32_t kind = (uint32_t)c.kind;
+    if (c.kind == COMP_SPHERE) { o[0] = c.s.c.x; o[1] = c.s.c.y; o[2] = c.s.c.z; o[3] = c.s.r; o[4] = o[5] = o[6] = 0.0f; }
+    else { o[0] = c.c.a.x; o[1] = c.c.a.y; o[2] = c.c.a.z; o[3] = c.c.r; o[4] = c.c.d.x; o[5] = c.c.d.y; o[6] = c.c.d.z; }
+    std::memcpy(&o[7], &kind, 4);
+  }
+  static Component get_part(const float* o) {
+    uint32_t kind;
+    std::memcpy(&kind, &o[7], 4);
+    if (kind == (uint32_t)COMP_SPHERE) return component(Sphere{v3(o[0], o[1], o[2]), o[3]});
+    return component(Capsule{v3(o[0], o[1], o[2]), v3(o[4], o[5], o[6]), o[3]});
+  }
   void add_ghost(const float* o) {
     RigidBodyVec& b = bodies;
     Component k;
@@ -160,11 +174,18 @@ struct World {
     b.restitution.push_back(o[34]); b.friction.push_back(o[35]); b.inv_mass.push_back(o[24]);
     M3 I = m3_new(o[25], o[26], o[27], o[28], o[29], o[30], o[31], o[32], o[33]);
     b.inv_moment_body.push_back(m3_zero()); b.inv_moment.push_back(I);
-    b.constructor.push_back(ComponentConstructor{k.kind, o[23], 0.0f});
+    uint32_t n_parts;
+    std::memcpy(&n_parts, &o[36], 4);
+    b.constructor.push_back(ComponentConstructor{n_parts ? RigidBodyVec::KIND_COMPOUND : k.kind, o[23], 0.0f});
     b.collider.push_back(sweep(k, delta));
     b.sync_parts();
     size_t id = b.len() - 1;
-    bvh_ids.push_back(bvh.insert(bounds(b.collider[id]) + fat_margin, id));
+    for (uint32_t pk = 0; pk < n_parts; ++pk) {
+      Component wc = get_part(o + 40 + 8 * pk);
+      b.parts[id].push_back(sweep(wc, delta));
+      b.parts_local[id].push_back(wc);  // a ghost is never integrated here: only the count matters
+    }
+    bvh_ids.push_back(bvh.insert(body_bounds(id) + fat_margin, id));
   }
   void export_body(size_t i, float* o) const {
     const RigidBodyVec& b = bodies;
@@ -181,6 +202,10 @@ struct World {
     o[24] = b.inv_mass[i];
     for (int k = 0; k < 3; ++k) { o[25 + 3 * k] = b.inv_moment[i].c[k].x; o[26 + 3 * k] = b.inv_moment[i].c[k].y; o[27 + 3 * k] = b.inv_moment[i].c[k].z; }
     o[34] = b.restitution[i]; o[35] = b.friction[i];
+    for (int k = 36; k < kGhostFloats; ++k) o[k] = 0.0f;
+    const uint32_t n_parts = b.constructor[i].kind == RigidBodyVec::KIND_COMPOUND ? (uint32_t)b.parts[i].size() : 0u;
+    std::memcpy(&o[36], &n_parts, 4);
+    for (uint32_t pk = 0; pk < n_parts; ++pk) put_part(o + 40 + 8 * pk, b.parts[i][pk].shape);
   }
   // owned bodies whose fat box reaches below x_left / above x_right (ascending ids)
   void select_boundary(float x_left, float x_right, std::vector<uint32_t>* left, std::vector<uint32_t>* right) const {
@@ -194,9 +219,7 @@ struct World {
 
   // ---- migration between tiles (not in the reference): an owned body whose centre leaves the slab
   // [x_lo, x_hi) is handed to the neighbouring tile with its whole state, persistent fat box included.
-  // record (kMigrantFloats): the 36 floats of export_body | force3 | inv_moment_body9 | constructor kind,r,half_h |
-  // fat box c3 r3 | tag | zero padding.
-  static constexpr int kMigrantFloats = 80;
+  static constexpr int kMigrantFloats = 116;  // the ghost record (56) | force3 inv_moment_body9 constructor3 fat box6 tag, 2 pad | 2 local parts | padding (the HIP path's record is 116 floats)
   void select_migrants(float x_lo, float x_hi, std::vector<uint32_t>* left, std::vector<uint32_t>* right) const {
     left->clear(); right->clear();
     for (size_t i = 0; i < n_owned; ++i) {
@@ -208,15 +231,18 @@ struct World {
   void export_migrant(size_t i, float* o) const {
     const RigidBodyVec& b = bodies;
     for (int k = 0; k < kMigrantFloats; ++k) o[k] = 0.0f;
-    export_body(i, o);
-    o[36] = b.force[i].x; o[37] = b.force[i].y; o[38] = b.force[i].z;
-    for (int k = 0; k < 3; ++k) { o[39 + 3 * k] = b.inv_moment_body[i].c[k].x; o[40 + 3 * k] = b.inv_moment_body[i].c[k].y; o[41 + 3 * k] = b.inv_moment_body[i].c[k].z; }
+    export_body(i, o);  // the ghost record, world parts included
+    float* e = o + kGhostFloats;
+    e[0] = b.force[i].x; e[1] = b.force[i].y; e[2] = b.force[i].z;
+    for (int k = 0; k < 3; ++k) { e[3 + 3 * k] = b.inv_moment_body[i].c[k].x; e[4 + 3 * k] = b.inv_moment_body[i].c[k].y; e[5 + 3 * k] = b.inv_moment_body[i].c[k].z; }
     uint32_t kind = (uint32_t)b.constructor[i].kind;
-    std::memcpy(&o[48], &kind, 4);
-    o[49] = b.constructor[i].r; o[50] = b.constructor[i].half_h;
+    std::memcpy(&e[12], &kind, 4);
+    e[13] = b.constructor[i].r; e[14] = b.constructor[i].half_h;
     const AABB& fb = bvh[bvh_ids[i]];
-    o[51] = fb.c.x; o[52] = fb.c.y; o[53] = fb.c.z; o[54] = fb.r.x; o[55] = fb.r.y; o[56] = fb.r.z;
-    std::memcpy(&o[57], &tags[i], 4);
+    e[15] = fb.c.x; e[16] = fb.c.y; e[17] = fb.c.z; e[18] = fb.r.x; e[19] = fb.r.y; e[20] = fb.r.z;
+    std::memcpy(&e[21], &tags[i], 4);
+    if (b.constructor[i].kind == RigidBodyVec::KIND_COMPOUND)
+      for (size_t pk = 0; pk < b.parts_local[i].size(); ++pk) put_part(e + 24 + 8 * pk, b.parts_local[i][pk]);
   }
   // ids ascending, all owned; the remaining bodies keep their relative order (ghosts are dropped first)
   void remove_bodies(const uint32_t* ids, size_t m) {
@@ -245,29 +271,37 @@ struct World {
   void import_migrant(const float* o) {
     drop_ghosts();
     RigidBodyVec& b = bodies;
+    const float* e = o + kGhostFloats;
     Component k;
     uint32_t tag;
     std::memcpy(&tag, &o[16], 4);
     if (tag == 0u) k = component(Sphere{v3(o[17], o[18], o[19]), o[23]});
     else k = component(Capsule{v3(o[17], o[18], o[19]), v3(o[20], o[21], o[22]), o[23]});
+    const V3 delta = v3(o[13], o[14], o[15]);
     b.x.push_back(v3(o[0], o[1], o[2]));
     b.q.push_back(Quat{o[3], v3(o[4], o[5], o[6])});
     b.v.push_back(v3(o[7], o[8], o[9]));
     b.omega.push_back(v3(o[10], o[11], o[12]));
-    b.force.push_back(v3(o[36], o[37], o[38])); b.torque.push_back(v3(0, 0, 0));
+    b.force.push_back(v3(e[0], e[1], e[2])); b.torque.push_back(v3(0, 0, 0));
     b.restitution.push_back(o[34]); b.friction.push_back(o[35]); b.inv_mass.push_back(o[24]);
     b.inv_moment.push_back(m3_new(o[25], o[26], o[27], o[28], o[29], o[30], o[31], o[32], o[33]));
-    b.inv_moment_body.push_back(m3_new(o[39], o[40], o[41], o[42], o[43], o[44], o[45], o[46], o[47]));
+    b.inv_moment_body.push_back(m3_new(e[3], e[4], e[5], e[6], e[7], e[8], e[9], e[10], e[11]));
     uint32_t kind;
-    std::memcpy(&kind, &o[48], 4);
-    b.constructor.push_back(ComponentConstructor{(int)kind, o[49], o[50]});
-    b.collider.push_back(sweep(k, v3(o[13], o[14], o[15])));
+    std::memcpy(&kind, &e[12], 4);
+    b.constructor.push_back(ComponentConstructor{(int)kind, e[13], e[14]});
+    b.collider.push_back(sweep(k, delta));
     b.sync_parts();
     size_t id = b.len() - 1;
-    bvh_ids.push_back(bvh.insert(AABB{v3(o[51], o[52], o[53]), v3(o[54], o[55], o[56])}, id));
+    uint32_t n_parts;
+    std::memcpy(&n_parts, &o[36], 4);
+    for (uint32_t pk = 0; pk < n_parts; ++pk) {
+      b.parts[id].push_back(sweep(get_part(o + 40 + 8 * pk), delta));
+      b.parts_local[id].push_back(get_part(e + 24 + 8 * pk));
+    }
+    bvh_ids.push_back(bvh.insert(AABB{v3(e[15], e[16], e[17]), v3(e[18], e[19], e[20])}, id));
     n_owned = b.len();
     uint32_t tg;
-    std::memcpy(&tg, &o[57], 4);
+    std::memcpy(&tg, &e[21], 4);
     tags.push_back(tg);
   }
 

@@ -389,6 +389,9 @@ class Bvh:
         return nodes[:n], bounds[:n]
 
 
+GHOST_FLOATS = 56  # World::kGhostFloats
+
+
 class World:
     """World::step harness of mgf_demo/world.rs — oracle copy."""
 
@@ -473,16 +476,16 @@ class World:
 
     def export_bodies(self, ids):
         ids = np.ascontiguousarray(ids, np.uint32)
-        out = np.zeros((len(ids), 36), np.float32)
+        out = np.zeros((len(ids), GHOST_FLOATS), np.float32)
         lib().mgfo_world_export_bodies(self.h, ids.ctypes.data, len(ids), out.ctypes.data)
         return out
 
     def import_ghosts(self, recs):
-        recs = np.ascontiguousarray(recs, np.float32).reshape(-1, 36)
+        recs = np.ascontiguousarray(recs, np.float32).reshape(-1, GHOST_FLOATS)
         lib().mgfo_world_import_ghosts(self.h, recs.ctypes.data, len(recs))
 
     # ---- migration of owned bodies between tiles ----
-    MIGRANT_FLOATS = 80
+    MIGRANT_FLOATS = 116
 
     def select_migrants(self, x_lo, x_hi):
         n = len(self)

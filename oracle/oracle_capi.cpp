@@ -379,12 +379,12 @@ void mgfo_world_select_boundary(void* wp, float x_left, float x_right, uint32_t*
   for (size_t i = 0; i < r.size() && (int64_t)i < cap; ++i) ids_r[i] = r[i];
 }
 void mgfo_world_export_bodies(void* wp, const uint32_t* ids, int64_t n, float* out) {
-  for (int64_t i = 0; i < n; ++i) ((World*)wp)->export_body(ids[i], out + 36 * i);
+  for (int64_t i = 0; i < n; ++i) ((World*)wp)->export_body(ids[i], out + World::kGhostFloats * i);
 }
 void mgfo_world_import_ghosts(void* wp, const float* in, int64_t n) {
   World* w = (World*)wp;
   w->drop_ghosts();
-  for (int64_t i = 0; i < n; ++i) w->add_ghost(in + 36 * i);
+  for (int64_t i = 0; i < n; ++i) w->add_ghost(in + World::kGhostFloats * i);
 }
 void mgfo_world_select_migrants(void* wp, float x_lo, float x_hi, uint32_t* ids_l, uint32_t* ids_r, int64_t cap, int64_t* nl, int64_t* nr) {
   std::vector<uint32_t> l, r;

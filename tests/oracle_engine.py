@@ -54,7 +54,7 @@ class OracleEngine:
         return self.w.tags()
 
     def export_bodies(self):
-        return torch.from_numpy(np.concatenate([self.w.export_bodies(self.ids[0]).reshape(-1, 36), self.w.export_bodies(self.ids[1]).reshape(-1, 36)]))
+        return torch.from_numpy(np.concatenate([self.w.export_bodies(self.ids[0]).reshape(-1, O.GHOST_FLOATS), self.w.export_bodies(self.ids[1]).reshape(-1, O.GHOST_FLOATS)]))
 
     def import_ghosts(self, recs):
         self.w.import_ghosts(np.ascontiguousarray(recs.numpy()))

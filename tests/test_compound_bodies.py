@@ -94,6 +94,34 @@ def test_config5_scene_runs_and_settles():
     assert np.isfinite(s["x"]).all() and s["x"][:, 1].min() > 0.2 and st.n_constraints > 30
 
 
+def _tiled_setup(engine_factory, P, drift=0.0):
+    from mgf_amd.tiles import Tile
+    sc = scenes.dumbbell_field(6, 2, 4, n_plain=8)
+    if drift:
+        sc["v0"] = (sc["v0"] + np.float32([drift, 0.0, 0.0])).astype(np.float32)
+    half = 6 * 2.2 / 2.0 + 2.0
+    return sc, [Tile(engine_factory(t), t["x_range"], r, P, t["dt"], t["iters"]) for r, t in enumerate(scenes.split_by_slabs(sc, P, half))]
+
+
+def test_two_part_bodies_across_oracle_tiles():
+    """Ghost and migrant records carry the parts: a drifting field of two-part bodies over three tiles keeps every body,
+    hands bodies over, and stays close to the undivided world."""
+    from mgf_amd.tiles import step_tiles_inprocess
+    from tests.oracle_engine import OracleEngine
+    sc, tiles = _tiled_setup(OracleEngine, 3, drift=3.0)
+    ow = oracle_world(sc)
+    n_total = len(ow)
+    for _ in range(40):
+        stats = step_tiles_inprocess(tiles)
+        ow.step(float(sc["dt"]), sc["iters"])
+        assert sum(len(t.e.w) for t in tiles) == n_total
+    assert sum(t.n_migrated_in for t in tiles) > 0 and sum(s["n_constraints"] for s in stats) > 20
+    tags = np.concatenate([t.e.tags() for t in tiles])
+    assert np.array_equal(np.sort(tags), np.arange(n_total))
+    x = np.concatenate([t.e.state()["x"] for t in tiles])[np.argsort(tags)]
+    assert rel_err(x, ow.state()["x"]) < 0.2 and np.isfinite(x).all()
+
+
 # ---- HIP path -------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def ctx():
@@ -142,14 +170,33 @@ def test_hip_larger_config5_scene(ctx):
 
 
 @pytest.mark.gpu
-def test_hip_compound_worlds_refuse_the_tiling_calls(ctx):
-    import torch
+@pytest.mark.parametrize("P,drift", [(2, 0.0), (3, 3.0)])
+def test_hip_two_part_bodies_across_tiles_equal_oracle_tiles(ctx, P, drift):
+    """The tile protocol with bodies of several parts (ghost records with parts, hand-overs with the part arrays, kind
+    masks telling a tile that its neighbours hold such bodies): every tile bit-identical to the oracle's."""
+    from mgf_amd.tiles import HipEngine, step_tiles_inprocess
+    from tests.oracle_engine import OracleEngine
+    _, gt = _tiled_setup(lambda t: HipEngine(ctx, t, 0), P, drift)
+    _, ot = _tiled_setup(OracleEngine, P, drift)
+    for tick in range(40):
+        sg, so = step_tiles_inprocess(gt), step_tiles_inprocess(ot)
+        for r in range(P):
+            assert sg[r]["n_constraints"] == so[r]["n_constraints"], f"tick {tick} tile {r}"
+        assert [t.n_migrated_in for t in gt] == [t.n_migrated_in for t in ot]
+    if drift:
+        assert sum(t.n_migrated_in for t in gt) > 0
+    assert sum(s["n_constraints"] for s in sg) > 20
+    for r in range(P):
+        assert np.array_equal(gt[r].e.tags(), ot[r].e.tags())
+        g, o = gt[r].e.state(), ot[r].e.state()
+        for k in ("x", "q", "v", "omega", "delta"):
+            assert values_equal(g[k], o[k]), f"tile {r} {k}: rel err {rel_err(g[k], o[k])}"
+
+
+@pytest.mark.gpu
+def test_hip_bodies_of_more_than_two_parts_are_refused(ctx):
     import mgf_amd
     sc = scenes.dumbbell_field(2, 1, 2)
     gw = mgf_amd.World.from_scene(ctx, sc)
-    ids = torch.zeros(4, dtype=torch.int32, device="cuda")
-    out = torch.zeros((4, 36), dtype=torch.float32, device="cuda")
-    with pytest.raises(mgf_amd.MgfError):
-        gw.export_bodies(ids.data_ptr(), 1, out.data_ptr())
     with pytest.raises(mgf_amd.MgfError):
         gw.add_compound_bodies(sc["compound"]["comps"][:3], 1.0, [0, 3], 0.3, 0.6, [0, -9.8, 0])  # three parts: over the limit
