@@ -369,17 +369,6 @@ __global__ __launch_bounds__(kBlock) void k_flow5_table(Flow5 F, ConsLinks K, co
   dst[1] = make_uint4(R.succ0, R.succ1, 0u, 0u);
 }
 
-__device__ __forceinline__ BodyDyn f5_load_body(const float4* s_body, __amdgpu_buffer_rsrc_t rs, uint32_t ref) {
-  if (ref == kNone) return static_dyn();
-  if (ref & kRefGlobal) return load_dyn_sc1(rs, ref & ~kRefGlobal);
-  return load_dyn(s_body, ref);
-}
-__device__ __forceinline__ void f5_store_vel(float4* s_body, __amdgpu_buffer_rsrc_t rs, uint32_t ref, const BodyDyn& d) {
-  if (ref == kNone) return;
-  if (ref & kRefGlobal) { store_vel_sc1(rs, ref & ~kRefGlobal, d); return; }
-  store_vel(s_body, ref, d);
-}
-
 // LDS per block: slot constants (constraint id, body refs, successor words) - of every slot (narrow layout) or of the
 // class-0 slots only (wide layout; classes 1 and 2 touch global memory anyway and read theirs from the block's global
 // table) - and for EVERY slot its arrival counter and iteration counter.

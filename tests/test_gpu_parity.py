@@ -394,6 +394,30 @@ def test_two_pass_and_row_paths_agree(ctx):
         assert bits_equal(s1[k], s2[k]), k
 
 
+def test_block_that_does_not_fit_falls_back_on_the_device(ctx):
+    """When a spatial block holds more constraints than its workgroup's LDS layout (forced here by a tiny test limit), a
+    device flag turns k_solve_flow5 into a no-op and the k_solve_flow launch enqueued behind it does the work - no host
+    round trip inside the tick, the same result, and the counter says it happened."""
+    import mgf_amd
+    from mgf_amd import scenes
+    scene = scenes.sphere_pile(10, 10, 10)
+    dt, iters = float(scene["dt"]), scene["iters"]
+    ow, gw = oracle_world(scene), mgf_amd.World.from_scene(ctx, scene)
+    gw.set_option("flow5_test_cap", 40)
+    for step in range(40):
+        so, sg = ow.step(dt, iters), gw.step(dt, iters)
+        assert sg.n_constraints == so.n_constraints
+    assert so.n_constraints > 500 and gw.counter("flow5_fallbacks") > 10
+    compare_constraints(gw.constraints(), ow.constraints(), check_impulse=True)
+    _compare_state(gw, ow, "stand-by solver")
+    gw.set_option("flow5_test_cap", 0)  # back to the block-local kernel: same world, same results
+    n0 = gw.counter("flow5_fallbacks")
+    for step in range(10):
+        so, sg = ow.step(dt, iters), gw.step(dt, iters)
+    assert gw.counter("flow5_fallbacks") == n0
+    _compare_state(gw, ow, "after the stand-by phase")
+
+
 @pytest.mark.parametrize("mode", [1, 4, 5, 105])
 @pytest.mark.parametrize("scene_name", ["pile12", "mixed", "balls8"])
 def test_dataflow_solver_matches_oracle(ctx, scene_name, mode):
