@@ -505,8 +505,9 @@ __device__ __forceinline__ Comp load_comp(const Bodies& B, uint32_t i) {
 // SPHERES (a world of spheres only): an accepted partner goes straight through the sphere-sphere narrowphase test
 // (the same function k_narrow_pairs runs) and only contacts are written to the row - a dense pile accepts ~11 partners
 // per body by their fat boxes and keeps ~2, so everything downstream of the rows handles a sixth of the entries.  The
-// accepted partners are still counted (World::step's candidate statistic): per wave into one of 64 words of pair_stat.
+// accepted partners are still counted (World::step's candidate statistic): per block into one of kPairStatWords words.
 constexpr uint32_t kGridMaxCells = 512;
+constexpr uint32_t kPairStatWords = 1024;  // partial sums of the accepted partners (same-word atomics from many CUs serialise: ~0.3 us each)
 template <bool SPHERES>
 __global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, uint32_t n_owned, Lbvh T, const SceneBounds* sb, float pad_abs,
                                                           uint32_t* rows_p, uint32_t* p_cnt, uint32_t* overflow, uint32_t* too_wide,
@@ -628,11 +629,16 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, 
     p_cnt[i] = np;
     if (!SPHERES && np > (uint32_t)kRowCap) atomicOr(overflow, 1u);
   }
-  if (SPHERES) {  // accepted partners of the wave's 8 queries -> one atomic
+  if (SPHERES) {  // accepted partners: one atomic per block, spread over many words
+    __shared__ uint32_t s_sum;
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
     uint32_t v = (live && sub == 0) ? n_accepted : 0u;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    if (lane == 0 && v) atomicAdd(&pair_stat[(blockIdx.x * (kCoopBlock / 64) + (threadIdx.x >> 6)) & 63u], v);
+    if (lane == 0 && v) atomicAdd(&s_sum, v);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_sum) atomicAdd(&pair_stat[blockIdx.x & (kPairStatWords - 1u)], s_sum);
   }
 }
 
