@@ -131,6 +131,9 @@ MGF_API mgf_status mgf_ctx_set_stream(mgf_ctx* ctx, void* hip_stream);
 MGF_API const char* mgf_last_error(void);        /* thread-local message for the last non-OK status */
 MGF_API mgf_params mgf_default_params(void);     /* DefaultContactConstraintParams / DefaultPruningParams */
 MGF_API const char* mgf_version(void);
+/* The device-wide exclusive scan the tick uses for its list offsets (csrc/prims.hip: rocPRIM), on host arrays:
+ * out[i] = sum of in[0..i).  Exposed so that the primitive can be tested on its own. */
+MGF_API mgf_status mgf_exclusive_scan_u32(mgf_ctx* ctx, const uint32_t* in, int64_t n, uint32_t* out);
 
 /* ---- single-shot narrowphase (unit parity; runs the same device functions as the step) ---
  * Contacts::contacts (collision.rs:471-482) for `a` [moving by vel_a] vs `b` [moving by vel_b];

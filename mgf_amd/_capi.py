@@ -103,7 +103,7 @@ assert CONSTRAINT_DTYPE.itemsize == 96
 
 # every symbol include/mgf_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "mgf_ctx_create", "mgf_ctx_destroy", "mgf_ctx_set_stream", "mgf_last_error", "mgf_default_params", "mgf_version",
+    "mgf_ctx_create", "mgf_ctx_destroy", "mgf_ctx_set_stream", "mgf_last_error", "mgf_default_params", "mgf_version", "mgf_exclusive_scan_u32",
     "mgf_contacts", "mgf_contacts_batch", "mgf_local_contacts_pair", "mgf_ray_capsule", "mgf_inertia_tensor",
     "mgf_mesh_new", "mgf_mesh_free", "mgf_mesh_push_vert", "mgf_mesh_push_face", "mgf_mesh_set_pos", "mgf_mesh_build",
     "mgf_local_contacts_mesh",
@@ -147,6 +147,7 @@ def load_library():
         "mgf_last_error": (C.c_char_p, []),
         "mgf_default_params": (Params, []),
         "mgf_version": (C.c_char_p, []),
+        "mgf_exclusive_scan_u32": (i32, [vp, vp, i64, vp]),
         "mgf_contacts": (i32, [vp, P(Shape), P(Vec3), P(Shape), P(Vec3), P(Contact), i32, P(i32)]),
         "mgf_contacts_batch": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp]),
         "mgf_local_contacts_pair": (i32, [vp, P(MovingComponent), P(MovingComponent), P(LocalContact), i32, P(i32)]),
@@ -263,6 +264,13 @@ class Context:
 
     def _adopt(self, obj):
         self._children.add(obj)
+
+    def exclusive_scan(self, counts):
+        """out[i] = sum(counts[:i]) on the device (the tick's own scan primitive)."""
+        a = np.ascontiguousarray(counts, np.uint32)
+        out = np.zeros(len(a), np.uint32)
+        _check(load_library().mgf_exclusive_scan_u32(self._h, a.ctypes.data, len(a), out.ctypes.data))
+        return out
 
     def set_stream(self, hip_stream):
         """Enqueue this context's work on a caller-owned hipStream_t (an int handle, e.g. torch's cuda_stream)."""

@@ -114,6 +114,17 @@ static mgf_status append(mgf_ctx* ctx, DBuf<T>& buf, size_t old_n, const std::ve
   return h2d(ctx, buf.p + old_n, add.data(), add.size());
 }
 
+extern "C" mgf_status mgf_exclusive_scan_u32(mgf_ctx* ctx, const uint32_t* in, int64_t n, uint32_t* out) {
+  MGF_TRY(ctx_bind(ctx));
+  if (n < 0 || (n && (!in || !out))) return fail(MGF_ERR_INVALID, "bad argument");
+  if (n == 0) return MGF_OK;
+  DBuf<uint32_t> d_in, d_out;
+  MGF_TRY(d_in.ensure((size_t)n, ctx->stream)); MGF_TRY(d_out.ensure((size_t)n, ctx->stream));
+  MGF_TRY(h2d(ctx, d_in.p, in, (size_t)n));
+  MGF_TRY(prim_exclusive_scan_u32(ctx, d_in.p, d_out.p, (size_t)n));
+  return d2h(ctx, out, d_out.p, (size_t)n);
+}
+
 #include "host_trees.inc"
 #include "host_single_shot.inc"
 #include "host_world.inc"

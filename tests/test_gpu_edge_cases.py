@@ -130,3 +130,20 @@ def test_solve_called_twice_and_set_constraints_empty(ctx):
     v = gw.state()["v"].copy()
     gw.solve(5)
     assert bits_equal(gw.state()["v"], v)
+
+
+@pytest.mark.gpu
+def test_device_scan_around_tile_boundaries():
+    """The scan behind every list offset of the tick, on its own: sizes around tile and vector boundaries, many blocks,
+    repeated calls, wrap-around sums."""
+    import mgf_amd
+    ctx = mgf_amd.Context(0)
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 3, 4, 5, 1023, 1024, 1025, 4093, 4095, 4096, 4097, 8191, 8192, 8193, 262145, 1048577, 3000001):
+        a = rng.integers(0, 50, n, dtype=np.uint32)
+        want = np.concatenate([[0], np.cumsum(a[:-1], dtype=np.uint64)]).astype(np.uint32)
+        for _ in range(3):
+            assert np.array_equal(ctx.exclusive_scan(a), want), n
+    big = np.full(70000, 0x00010001, np.uint32)  # sums wrap modulo 2^32 like the host's
+    assert np.array_equal(ctx.exclusive_scan(big), (np.arange(70000, dtype=np.uint64) * 0x00010001).astype(np.uint32))
+    ctx.close()
