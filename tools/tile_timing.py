@@ -37,11 +37,13 @@ def main():
     ap.add_argument("--nz", type=int, default=64)
     ap.add_argument("--ticks", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--refresh-every", type=int, nargs="*", default=[2])
     a = ap.parse_args()
     ctx = mgf_amd.Context(0)
-    for migrate in (False, True, False, True):
-        ms, moved = run(ctx, a.tiles, a.nx, a.ny, a.nz, a.ticks, a.warmup, migrate=migrate)
-        print(f"tiles={a.tiles} bodies/tile={a.nx * a.ny * a.nz} migrate={migrate}: {ms:.3f} ms/tick ({moved} hand-overs)")
+    for R in a.refresh_every:
+        for migrate in (False, True):
+            ms, moved = run(ctx, a.tiles, a.nx, a.ny, a.nz, a.ticks, a.warmup, migrate=migrate, refresh_every=R)
+            print(f"tiles={a.tiles} bodies/tile={a.nx * a.ny * a.nz} refresh_every={R} migrate={migrate}: {ms:.3f} ms/tick ({moved} hand-overs)")
 
 
 if __name__ == "__main__":
