@@ -81,11 +81,29 @@ __global__ __launch_bounds__(kBlock) void k_flow_init(const uint32_t* C_ptr, Con
 template <bool TRACE>
 __global__ __launch_bounds__(kBlock) void k_solve_flow(float4* srec, CRec* cons, ConsLinks K, uint32_t* arr, const uint32_t* C_ptr, uint32_t iters,
                                                        uint32_t* abort_flag, uint32_t spin_limit, int sleep_mode, uint64_t* trace,
-                                                       const uint32_t* run_if) {
+                                                       const uint32_t* run_if, uint32_t* standby_bar) {
   if (run_if && *run_if == 0u) return;  // stand-by launch behind the block-local solver: runs only if that one declined
   const uint32_t C = *C_ptr;
   const uint32_t L = gridDim.x * kBlock;
   const uint32_t gl = blockIdx.x * kBlock + threadIdx.x;
+  if (run_if) {
+    // The stand-by initialises the arrival counters itself (what k_flow_init does for the other modes), so the common
+    // tick does not pay a launch for a path it does not take.  Every block of this launch is resident (the grid is
+    // sized from the occupancy), so a counting barrier between the initialisation and the first poll is safe.
+    for (uint32_t i = gl; i < C; i += L)
+      __hip_atomic_store(&arr[i], 2u - links_indeg0(K, i) * (K.ab[i].y != kNone ? 1u : 2u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(standby_bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t sp = 0;
+      while (__hip_atomic_load(standby_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++sp > spin_limit) { __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+    __syncthreads();
+  }
   __amdgpu_buffer_rsrc_t rs = make_rsrc(srec);
   uint32_t c = gl, round = 0;
   bool done = (c >= C) || iters == 0;
@@ -132,6 +150,13 @@ __global__ __launch_bounds__(kBlock) void k_solve_flow(float4* srec, CRec* cons,
       bool give_up = spins > spin_limit;
       if (give_up) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (give_up || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
+  }
+  if (run_if) {  // the last block to leave re-arms the stand-by's barrier
+    __syncthreads();
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(standby_bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x) {
+      __hip_atomic_store(standby_bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(standby_bar + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
