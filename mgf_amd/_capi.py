@@ -90,6 +90,9 @@ class StepStats(C.Structure):
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
+    def __getitem__(self, key):  # a read-only mapping view: callers in a hot loop need not build the dict
+        return getattr(self, key)
+
 
 COMPONENT_DTYPE = np.dtype([("tag", "<i4"), ("p", "<f4", 3), ("d", "<f4", 3), ("r", "<f4")])
 MOVING_DTYPE = np.dtype([("tag", "<i4"), ("p", "<f4", 3), ("d", "<f4", 3), ("r", "<f4"), ("delta", "<f4", 3)])

@@ -382,5 +382,5 @@ class TiledWorld:
 
     def step(self):
         if self.tile is None:
-            return self.world.step(self.dt, self.iters).as_dict()
+            return self.world.step(self.dt, self.iters)  # StepStats: indexable by field name
         return step_tile(self.tile, self.transport)
