@@ -267,7 +267,7 @@ constexpr uint32_t kF5MaxCons = 5120;                     // rows per block in t
 constexpr uint32_t kF5NarrowCons = 3072;
 constexpr uint32_t kF5MaxFast = 3328, kF5MaxSlow = 3072;
 constexpr uint32_t kF5MaxBodies = 1100;                   // bodies per block (LDS: 64 B each; both layouts must fit 160 KB)
-constexpr uint32_t kF5LdsWide = 16u * kF5MaxFast + 5u * kF5MaxCons + 2u * (kF5MaxFast + kF5MaxSlow) + 64u;
+constexpr uint32_t kF5LdsWide = 8u * kF5MaxFast + 9u * kF5MaxCons + 2u * (kF5MaxFast + kF5MaxSlow) + 64u;
 constexpr uint32_t kF5LdsNarrow = 25u * kF5NarrowCons + 2u * 2u * 4096u + 64u;
 constexpr uint32_t kRefGlobal = 0x80000000u;              // body ref: bit 31 = global id (sc1 path), else LDS index; kNone = static
 constexpr uint32_t kSuccLocal = 0x20000000u;              // successor word: low bits are a block-local slot
@@ -406,6 +406,13 @@ __device__ __forceinline__ void f5_push(const F5Queue& q, uint32_t slot) {
   q.ring[pos % q.cap] = (uint16_t)(slot | 0x8000u);
 }
 
+// a class-0 slot's successor word in 16 bits (its successors are in-block): slot | two << 13 | wrap << 14 | valid << 15
+__device__ __forceinline__ uint32_t f5_pack_succ(uint32_t w) {
+  return (w & 0x1FFFu) | ((w & kSuccTwo) ? 0x2000u : 0u) | ((w & kSuccWrap) ? 0x4000u : 0u) | ((w & kSuccLocal) ? 0x8000u : 0u);
+}
+__device__ __forceinline__ uint32_t f5_unpack_succ(uint32_t h) {
+  return (h & 0x1FFFu) | ((h & 0x2000u) ? kSuccTwo : 0u) | ((h & 0x4000u) ? kSuccWrap : 0u) | ((h & 0x8000u) ? kSuccLocal : 0u);
+}
 template <bool WIDE, bool TRACE>
 __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* cons, ConsLinks K, Flow5 F, uint32_t* arr, uint32_t iters,
                                                             uint32_t* abort_flag, uint32_t spin_limit, uint64_t* trace, uint32_t C_trace) {
@@ -415,9 +422,15 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
   constexpr uint32_t kRingF = WIDE ? kF5MaxFast : 4096u, kRingS = WIDE ? kF5MaxSlow : 4096u;
   extern __shared__ float4 s_dyn[];
   float4* s_body = s_dyn;  // 4 x nb
-  uint2* s_succ = reinterpret_cast<uint2*>(s_dyn + 4 * (size_t)F.nb);      // [kMeta]
-  uint32_t* s_c = reinterpret_cast<uint32_t*>(s_succ + kMeta);             // [kMeta]
-  uint32_t* s_a = s_c + kMeta;                                             // [kMeta] WIDE: aref | bref << 16; else aref
+  // narrow: succ (8 B), c, aref, bref for every slot.  wide: the constraint id of EVERY slot (so a slow node's record
+  // fetch does not wait for its table row: the row and the record travel together), and for the class-0 slots the body
+  // refs (two 16-bit LDS indices) and both successor words packed into 32 bits (their successors are always in-block:
+  // slot 13 bits | "two predecessors" | wrap | valid, per half).
+  uint32_t* s_w0 = reinterpret_cast<uint32_t*>(s_dyn + 4 * (size_t)F.nb);
+  uint2* s_succ = reinterpret_cast<uint2*>(s_w0);                          // narrow: [kMeta]
+  uint32_t* s_succ32 = s_w0;                                               // wide:   [kMeta]
+  uint32_t* s_c = WIDE ? s_w0 + kMeta : s_w0 + 2 * kMeta;                  // [kAll] (wide) / [kMeta] (narrow)
+  uint32_t* s_a = s_c + (WIDE ? kAll : kMeta);                             // [kMeta] WIDE: aref | bref << 16; else aref
   uint32_t* s_b = s_a + kMeta;                                             // [kMeta] narrow layout only
   uint32_t* s_cnt = WIDE ? s_b : s_b + kMeta;                              // [kAll] arrivals since the slot last ran: ready at 2
   uint32_t* s_ctl = s_cnt + kAll;  // [0,1] fast head/tail, [2,3] slow head/tail, [4] nodes left
@@ -449,13 +462,17 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
     uint32_t c0 = r0.w & 0xFFu;
     s_cnt[idx] = c0;
     s_round[idx] = 0;
+    if (WIDE) s_c[idx] = r0.x;
     if (idx < n_meta) {
       const uint4 r1 = src[1];  // successor words
-      s_c[idx] = r0.x;
       uint32_t ar = r0.y, br = r0.z;
-      if (WIDE) s_a[idx] = (ar & 0xFFFFu) | ((br == kNone ? 0xFFFFu : br) << 16);  // class 0: LDS indices or static
-      else { s_a[idx] = ar; s_b[idx] = br; }
-      s_succ[idx] = make_uint2(r1.x, r1.y);
+      if (WIDE) {
+        s_a[idx] = (ar & 0xFFFFu) | ((br == kNone ? 0xFFFFu : br) << 16);  // class 0: LDS indices or static
+        s_succ32[idx] = f5_pack_succ(r1.x) | (f5_pack_succ(r1.y) << 16);
+      } else {
+        s_c[idx] = r0.x; s_a[idx] = ar; s_b[idx] = br;
+        s_succ[idx] = make_uint2(r1.x, r1.y);
+      }
     }
     // iteration 0's frontier (slots with a global counter are found by their pollers)
     if (!(idx >= N0 && idx < N01) && c0 >= 2u && iters > 0) f5_push(idx < N0 ? qf : qs, idx);
@@ -536,17 +553,21 @@ __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* 
         uint2 sw;
         // LDS reads first, unconditionally (clamped), the global table only for the wide layout's slow classes: an
         // if/else over the two sources is merged into flat loads through a selected pointer
-        {
-          const uint32_t ms = WIDE ? min(slot, kMeta - 1u) : slot;
-          c = s_c[ms]; sw = s_succ[ms];
-          if (WIDE) { uint32_t ab = s_a[ms]; aref = ab & 0xFFFFu; bref = (ab >> 16) == 0xFFFFu ? kNone : (ab >> 16); }
-          else { aref = s_a[ms]; bref = s_b[ms]; }
-        }
-        if (WIDE) asm volatile("" : "+v"(c), "+v"(sw.x), "+v"(sw.y));  // keeps the LDS reads above the branch (else: sunk and merged into flat loads)
-        if (WIDE && slot >= n_meta) {
-          const uint4* src = reinterpret_cast<const uint4*>(&F.table[row0 + slot]);
-          const uint4 r0 = src[0], r1 = src[1];
-          c = r0.x; aref = r0.y; bref = r0.z; sw = make_uint2(r1.x, r1.y);
+        if (WIDE) {
+          const uint32_t ms = min(slot, kMeta - 1u);
+          c = s_c[slot];
+          const uint32_t ab = s_a[ms], s32 = s_succ32[ms];
+          aref = ab & 0xFFFFu; bref = (ab >> 16) == 0xFFFFu ? kNone : (ab >> 16);
+          sw = make_uint2(f5_unpack_succ(s32 & 0xFFFFu), f5_unpack_succ(s32 >> 16));
+          asm volatile("" : "+v"(c), "+v"(sw.x), "+v"(sw.y), "+v"(aref), "+v"(bref));  // keeps the LDS reads above the branch (else: sunk and merged into flat loads)
+          if (slot >= n_meta) {  // a slow slot: its refs and successor words come from the block's table row (the record fetch below does not wait for it)
+            const uint4* src = reinterpret_cast<const uint4*>(&F.table[row0 + slot]);
+            const uint4 r0 = src[0], r1 = src[1];
+            aref = r0.y; bref = r0.z; sw = make_uint2(r1.x, r1.y);
+          }
+        } else {
+          c = s_c[slot]; sw = s_succ[slot];
+          aref = s_a[slot]; bref = s_b[slot];
         }
         const bool has_local = !WIDE || slot >= n_meta ? (aref & kRefHasLocal) != 0u : false;
         if (!WIDE || slot >= n_meta) aref &= ~kRefHasLocal;
