@@ -96,8 +96,15 @@ def main():
     launches = 0
     levels = []
     kms = 0.0
-    for _ in range(args.steps):
-        st = tw.step()
+    if tw.tile is None:
+        # one GPU: the K ticks through the C-ABI's own loop (mgf_world_step_many: World::step K times, one synchronisation
+        # per tick as always) - what a compiled host does; the per-tick statistics come back as an array
+        per_tick = tw.world.step_many(dt, args.iters, args.steps)
+    else:
+        per_tick = [tw.step() for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    for st in per_tick:
         units += st["n_constraints"] * args.iters
         cons += st["n_constraints"]
         launches += st["solver_kernel_launches"]
@@ -105,8 +112,6 @@ def main():
         kms += st["ms_solver_kernels"]
         for k in phase:
             phase[k] += st[k]
-    barrier()
-    elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -225,6 +225,8 @@ MGF_API int64_t mgf_world_len(const mgf_world* w);
 /* One tick (world.rs:227-294): complete_motion, integrate, broadphase, narrowphase,
  * ContactConstraint::new for every contact, Solver::solve(iters). */
 MGF_API mgf_status mgf_world_step(mgf_world* w, float dt, int32_t iters, mgf_step_stats* stats);
+/* n ticks back to back; stats (optional) receives one record per tick. */
+MGF_API mgf_status mgf_world_step_many(mgf_world* w, float dt, int32_t iters, int64_t n, mgf_step_stats* stats);
 /* Same tick split at the solver boundary (for parity tests of the constraint list). */
 MGF_API mgf_status mgf_world_build_constraints(mgf_world* w, float dt, mgf_step_stats* stats);
 MGF_API mgf_status mgf_world_solve(mgf_world* w, int32_t iters, mgf_step_stats* stats);   /* Solver::solve solver.rs:72 */

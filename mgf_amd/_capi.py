@@ -117,7 +117,7 @@ SYMBOLS = [
     "mgf_compound_intersections",
     "mgf_bvh_to_json", "mgf_bvh_from_json", "mgf_mesh_to_json", "mgf_mesh_from_json", "mgf_manifolds_from_contacts",
     "mgf_world_new", "mgf_world_free", "mgf_world_set_terrain", "mgf_world_add_bodies", "mgf_world_add_compound_bodies", "mgf_world_len",
-    "mgf_world_step", "mgf_world_build_constraints", "mgf_world_solve", "mgf_world_complete_motion",
+    "mgf_world_step", "mgf_world_step_many", "mgf_world_build_constraints", "mgf_world_solve", "mgf_world_complete_motion",
     "mgf_world_integrate", "mgf_world_get", "mgf_world_set", "mgf_world_read_state", "mgf_world_write_state",
     "mgf_world_read_colliders", "mgf_world_read_constraints", "mgf_world_set_constraints", "mgf_world_set_option",
     "mgf_world_device_ptr",
@@ -198,6 +198,7 @@ def load_library():
         "mgf_world_add_compound_bodies": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, P(u64)]),
         "mgf_world_len": (i64, [vp]),
         "mgf_world_step": (i32, [vp, f32, i32, P(StepStats)]),
+        "mgf_world_step_many": (i32, [vp, f32, i32, i64, vp]),
         "mgf_world_build_constraints": (i32, [vp, f32, P(StepStats)]),
         "mgf_world_solve": (i32, [vp, i32, P(StepStats)]),
         "mgf_world_complete_motion": (i32, [vp]),
@@ -737,6 +738,14 @@ class World:
     def step(self, dt, iters):
         _check(load_library().mgf_world_step(self._h, float(dt), int(iters), C.byref(self.stats)))
         return self.stats
+
+    def step_many(self, dt, iters, n):
+        """n ticks in one call; returns the per-tick statistics (a ctypes array of StepStats)."""
+        arr = (StepStats * int(n))()
+        _check(load_library().mgf_world_step_many(self._h, float(dt), int(iters), int(n), arr))
+        if n:
+            self.stats = arr[int(n) - 1]
+        return arr
 
     def build_constraints(self, dt):
         _check(load_library().mgf_world_build_constraints(self._h, float(dt), C.byref(self.stats)))

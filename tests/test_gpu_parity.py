@@ -394,6 +394,20 @@ def test_two_pass_and_row_paths_agree(ctx):
         assert bits_equal(s1[k], s2[k]), k
 
 
+def test_step_many_equals_single_steps(ctx):
+    import mgf_amd
+    from mgf_amd import scenes
+    scene = scenes.sphere_pile(8, 8, 8)
+    dt, iters = float(scene["dt"]), scene["iters"]
+    a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
+    per_tick = a.step_many(dt, iters, 25)
+    singles = [b.step(dt, iters).n_constraints for _ in range(25)]
+    assert [st.n_constraints for st in per_tick] == singles and singles[-1] > 100
+    sa, sb = a.state(), b.state()
+    for k in sa:
+        assert bits_equal(sa[k], sb[k]), k
+
+
 def test_block_that_does_not_fit_falls_back_on_the_device(ctx):
     """When a spatial block holds more constraints than its workgroup's LDS layout (forced here by a tiny test limit), a
     device flag turns k_solve_flow5 into a no-op and the k_solve_flow launch enqueued behind it does the work - no host
