@@ -63,7 +63,8 @@ __device__ __forceinline__ M3 load_imb(const float4* imb, uint32_t i) {
 // complete_motion + integrate, one pass.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, float dt, float fat_margin, int do_complete,
-                                                      int do_integrate, SceneBounds* sb) {
+                                                      int do_integrate, SceneBounds* sb, const uint32_t* guard) {
+  if (guard && *guard) return;  // a speculative tick behind a failed one (see k_reset_step)
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   bool live = i < n;
   bool refit = false;
@@ -171,8 +172,13 @@ __global__ __launch_bounds__(kBlock) void k_refresh_einfo(Bodies B, uint32_t n) 
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i < n) B.einfo[i] = mk4(xyz(B.x[i]) + xyz(B.delta[i]), B.einfo[i].w);
 }
-__global__ void k_reset_step(SceneBounds* sb, uint32_t* err) {
+// `spec`: the tick is being enqueued before the previous one has been read back (mgf_world_step_many).  If that one
+// turns out to have failed a capacity check (its StepCounts still sit in `sc`), this tick must not touch the state: the
+// guard word makes k_integrate and the whole collide phase no-ops, and the host re-runs both ticks.
+__global__ void k_reset_step(SceneBounds* sb, uint32_t* err, uint32_t* guard, const uint32_t* prev_fail, int spec) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (spec && *prev_fail) { *guard = 1u; return; }
+    *guard = 0u;
     for (int k = 0; k < 3; ++k) { sb->lo[k] = 0x7FFFFFFF; sb->hi[k] = (int)0x80000000; }
     sb->n_refits = 0; sb->pad = 0; sb->pad2 = 0;
     for (int k = 0; k < 3; ++k) sb->rmax[k] = 0;

@@ -287,10 +287,11 @@ struct StepCounts {
   uint32_t ct_sum;                             // terrain constraints, accumulated by k_count_contacts (zeroed by k_caps_candidates)
 };
 constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u, kFailGridWide = 8u, kFailTerrainRow = 16u, kFailTerrainWide = 32u,
-                   kFailRevRow = 64u;  // a body's row of `b` occurrences overflowed (k_setup_pairs / k_chain_rows)
+                   kFailRevRow = 64u,  // a body's row of `b` occurrences overflowed (k_setup_pairs / k_chain_rows)
+                   kFailSkipped = 128u;  // a speculative tick behind a failed one: nothing was done (k_reset_step)
 
 __global__ void k_caps_candidates(const uint32_t* mt, const uint32_t* mp, uint32_t cap_t, uint32_t cap_p, const uint32_t* row_overflow,
-                                  const uint32_t* grid_wide, const uint32_t* terrain_wide, StepCounts* sc) {
+                                  const uint32_t* grid_wide, const uint32_t* terrain_wide, StepCounts* sc, const uint32_t* guard) {
   StepCounts r;
   r.need_Mt = *mt; r.need_Mp = *mp; r.need_C = 0; r.need_Ct = 0;
   r.fail = 0;
@@ -299,6 +300,7 @@ __global__ void k_caps_candidates(const uint32_t* mt, const uint32_t* mp, uint32
   if (row_overflow && (*row_overflow & 2u)) r.fail |= kFailTerrainRow;
   if (grid_wide && *grid_wide) r.fail |= kFailGridWide;
   if (terrain_wide && *terrain_wide) r.fail |= kFailTerrainWide;
+  if (*guard) r.fail |= kFailSkipped;
   r.Mt = r.fail ? 0u : r.need_Mt; r.Mp = r.fail ? 0u : r.need_Mp; r.C = 0; r.Ct = 0;
   for (int k = 0; k < 6; ++k) r.bins[k] = 0;
   r.ct_sum = 0;

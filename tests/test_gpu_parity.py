@@ -408,6 +408,36 @@ def test_step_many_equals_single_steps(ctx):
         assert bits_equal(sa[k], sb[k]), k
 
 
+@pytest.mark.parametrize("scene_name", ["pile", "mixed", "dumbbells"])
+def test_pipelined_step_many_with_capacity_misses(ctx, scene_name):
+    """step_many enqueues tick k + 1 before it has read tick k back.  When tick k then fails a capacity check the device
+    guard must have turned tick k + 1 into a no-op: the batch gives the statistics and the state of single steps, bit for
+    bit, through forced misses (tiny list capacities before every batch) and with the pipeline switched off."""
+    import mgf_amd
+    from mgf_amd import scenes
+    scene = {"pile": lambda: scenes.sphere_pile(10, 10, 10), "mixed": lambda: scenes.capsule_field(8, 3, 8, sphere_fraction=0.5),
+             "dumbbells": lambda: scenes.dumbbell_field(6, 4, 6, 60)}[scene_name]()
+    dt, iters = float(scene["dt"]), scene["iters"]
+    a, b, c = (mgf_amd.World.from_scene(ctx, scene) for _ in range(3))
+    c.set_option("pipeline", 0)
+    for batch in range(6):
+        a.set_option("list_capacity", 5 + batch)  # the first tick of the batch misses; the tick enqueued behind it must not run
+        many = a.step_many(dt, iters, 9)
+        plain = c.step_many(dt, iters, 9)
+        keys = ("n_constraints", "n_terrain_constraints", "n_pair_candidates", "n_terrain_candidates", "n_refits")
+        singles = []
+        for _ in range(9):
+            st = b.step(dt, iters)
+            singles.append({key: st[key] for key in keys})
+        for key in keys:
+            assert [st[key] for st in many] == [st[key] for st in singles] == [st[key] for st in plain], (batch, key)
+        sa, sb, sc = a.state(), b.state(), c.state()
+        for k in sa:
+            assert bits_equal(sa[k], sb[k]) and bits_equal(sc[k], sb[k]), (batch, k)
+    assert singles[-1]["n_constraints"] > 100
+    assert a.counter("capacity_retries") >= 6
+
+
 def test_block_that_does_not_fit_falls_back_on_the_device(ctx):
     """When a spatial block holds more constraints than its workgroup's LDS layout (forced here by a tiny test limit), a
     device flag turns k_solve_flow5 into a no-op and the k_solve_flow launch enqueued behind it does the work - no host
