@@ -225,7 +225,9 @@ MGF_API int64_t mgf_world_len(const mgf_world* w);
 /* One tick (world.rs:227-294): complete_motion, integrate, broadphase, narrowphase,
  * ContactConstraint::new for every contact, Solver::solve(iters). */
 MGF_API mgf_status mgf_world_step(mgf_world* w, float dt, int32_t iters, mgf_step_stats* stats);
-/* n ticks back to back; stats (optional) receives one record per tick. */
+/* n ticks back to back (World::step in a host loop); stats (optional) receives one record per tick.  Same results as n
+ * calls of mgf_world_step; with a dataflow solver tick k + 1 is enqueued before tick k's counts are read back, and a
+ * device-side guard makes it a no-op when tick k has to be re-run with larger lists (option "pipeline" [1]). */
 MGF_API mgf_status mgf_world_step_many(mgf_world* w, float dt, int32_t iters, int64_t n, mgf_step_stats* stats);
 /* Same tick split at the solver boundary (for parity tests of the constraint list). */
 MGF_API mgf_status mgf_world_build_constraints(mgf_world* w, float dt, mgf_step_stats* stats);
@@ -319,7 +321,7 @@ MGF_API mgf_status mgf_world_solve_enqueue(mgf_world* w, int32_t iters);
 MGF_API mgf_status mgf_world_finish(mgf_world* w, mgf_step_stats* stats);
 /* Options (development and test knobs; defaults in brackets): "time_solver_kernels" [0] HIP events around the
  * solver kernels; "solver_mode" [5] 1 = persistent dataflow launch, 0 = one launch per dependency frontier,
- * 4 = dataflow with out-of-order slots, 5 = block-local dataflow (velocities and counters of a spatial block in LDS); "two_pass_candidates" [0]; "broadphase_tree" [0]; "terrain_tree" [0]; "no_fused_narrowphase" [0] (a world of spheres only runs the sphere-sphere test inside the grid broadphase and lists contacts only; 1 = list every accepted partner); "stream_ordered" [0]; "spin_wait" [1] (the tick's one wait polls an event instead of blocking); "list_capacity";
+ * 4 = dataflow with out-of-order slots, 5 = block-local dataflow (velocities and counters of a spatial block in LDS); "two_pass_candidates" [0]; "broadphase_tree" [0]; "terrain_tree" [0]; "no_fused_narrowphase" [0] (a world of spheres only runs the sphere-sphere test inside the grid broadphase and lists contacts only; 1 = list every accepted partner); "stream_ordered" [0]; "spin_wait" [1] (the tick's one wait polls an event instead of blocking); "pipeline" [1] (mgf_world_step_many enqueues the next tick before it waits for this one); "list_capacity";
  * "flow_blocks_per_cu"; "flow_sleep"; "flow_trace"; "debug_bvh"; "flow5_block", "flow5_slow_x2", "flow5_poller", "flow5_test_cap" (block-local solver: block size, wave split, polling wave, a test limit that forces the stand-by kernel); "body_kinds" (OR-in, bit0 sphere, bit1 capsule): the
  * kinds this world's ghosts may have - a tile whose own bodies are all of one kind must be told when a neighbour's are
  * not, because the narrowphase dispatch is chosen on the host (the tiles driver exchanges the masks with the counts). */

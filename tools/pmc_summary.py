@@ -5,6 +5,8 @@ coalesced read stream (guide §HBM); both the raw and the x2-corrected read side
 
     python tools/pmc_summary.py gpurun_out/pmc_fetch/pmc_counter_collection.csv gpurun_out/pmc_write/pmc_counter_collection.csv [out.json]
     (or the two pmc_results.db files of rocprofv3's default rocpd output)
+    ... --timed <kernel substring> <count> <out.json>: the average over the LAST <count> launches of the kernels whose
+    name holds the substring (bench.py's timed region; .db inputs only), written in the form bench.py reads.
 """
 import csv
 import json
@@ -32,7 +34,25 @@ def load(path, counter):
     return tot, cnt
 
 
+def last_launches(path, counter, pattern, count):
+    import sqlite3
+    db = sqlite3.connect(path)
+    vals = [float(v) for (v,) in db.execute("select value from counters_collection where counter_name = ? and kernel_name like ? order by start",
+                                            (counter, f"%{pattern}%"))]
+    vals = vals[-count:]
+    return sum(vals) * 1024.0 / len(vals), len(vals)
+
+
 def main():
+    if "--timed" in sys.argv:
+        k = sys.argv.index("--timed")
+        pattern, count, out = sys.argv[k + 1], int(sys.argv[k + 2]), sys.argv[k + 3]
+        f, n = last_launches(sys.argv[1], "FETCH_SIZE", pattern, count)
+        w, _ = last_launches(sys.argv[2], "WRITE_SIZE", pattern, count)
+        json.dump(dict(kernel=pattern, launches=n, fetch_bytes_per_launch_raw=f, write_bytes_per_launch=w, hbm_bytes_per_launch_raw=f + w,
+                       hbm_bytes_per_launch=2 * f + w), open(out, "w"), indent=1)
+        print(f"# {pattern}: last {n} launches: fetch {f:.0f} B, write {w:.0f} B, raw {f + w:.0f} B, fetch x2 {2 * f + w:.0f} B per launch")
+        sys.argv = sys.argv[:k]
     fetch, fc = load(sys.argv[1], "FETCH_SIZE")
     write, wc = load(sys.argv[2], "WRITE_SIZE")
     rows = []
