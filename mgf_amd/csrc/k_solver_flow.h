@@ -260,15 +260,24 @@ __global__ __launch_bounds__(kBlock) void k_solve_flowk(float4* srec, CRec* cons
 // ------------------------------------------------------------------------------------------
 constexpr int kF5Threads = 512;
 // Two LDS layouts (template parameter WIDE of k_solve_flow5), chosen by the host from last tick's largest block:
-//   WIDE = false: up to 3072 constraints per block, every slot's constants in LDS (25 B per slot);
+//   WIDE = false: every slot's constants in LDS (25 B per slot); as many slots as fit beside the block's bodies in 160 KB
+//                 (f5_narrow_cap: 3264 for blocks of 1024 bodies);
 //   WIDE = true : up to 5120 (a settled 64^3 pile reaches ~4600), only the class-0 slots' constants in LDS (16 B each,
 //                 at most 3328), classes 1 + 2 (at most 3072) read theirs from the block's global table.
 constexpr uint32_t kF5MaxCons = 5120;                     // rows per block in the global slot tables
-constexpr uint32_t kF5NarrowCons = 3072;
+constexpr uint32_t kF5LdsBytes = 160u * 1024u;            // LDS of a CU: one workgroup per CU takes all of it
 constexpr uint32_t kF5MaxFast = 3328, kF5MaxSlow = 3072;
 constexpr uint32_t kF5MaxBodies = 1100;                   // bodies per block (LDS: 64 B each; both layouts must fit 160 KB)
 constexpr uint32_t kF5LdsWide = 8u * kF5MaxFast + 9u * kF5MaxCons + 2u * (kF5MaxFast + kF5MaxSlow) + 64u;
-constexpr uint32_t kF5LdsNarrow = 25u * kF5NarrowCons + 2u * 2u * 4096u + 64u;
+// narrow layout: slots that fit beside nb bodies and the two rings (25 B each: succ 8, c 4, aref 4, bref 4, counter 4, round 1);
+// the rings keep a power-of-two length (their positions wrap with a mask), which also bounds the slots
+constexpr uint32_t kF5NarrowRing = 4096u;
+__host__ __device__ constexpr uint32_t f5_narrow_cap(uint32_t nb) {
+  const uint32_t fit = ((kF5LdsBytes - 64u - 2u * 2u * kF5NarrowRing - 64u * nb) / 25u) & ~63u;
+  return fit < kF5NarrowRing ? fit : kF5NarrowRing;
+}
+__host__ __device__ constexpr uint32_t f5_lds_narrow(uint32_t cap) { return 25u * cap + 2u * 2u * kF5NarrowRing + 64u; }
+static_assert(f5_narrow_cap(kF5MaxBodies) >= 3072u, "narrow layout smaller than it was");
 constexpr uint32_t kRefGlobal = 0x80000000u;              // body ref: bit 31 = global id (sc1 path), else LDS index; kNone = static
 constexpr uint32_t kSuccLocal = 0x20000000u;              // successor word: low bits are a block-local slot
 constexpr uint32_t kRefHasLocal = 0x40000000u;            // a-ref of a class-1 slot: one of its two predecessors is in-block
@@ -417,9 +426,10 @@ template <bool WIDE, bool TRACE>
 __global__ __launch_bounds__(kF5Threads) void k_solve_flow5(float4* srec, CRec* cons, ConsLinks K, Flow5 F, uint32_t* arr, uint32_t iters,
                                                             uint32_t* abort_flag, uint32_t spin_limit, uint64_t* trace, uint32_t C_trace) {
   if (*F.fail) return;  // a block did not fit: the stand-by k_solve_flow launch behind this one does the work
-  constexpr uint32_t kMeta = WIDE ? kF5MaxFast : kF5NarrowCons;   // slots with constants in LDS
-  constexpr uint32_t kAll = WIDE ? kF5MaxCons : kF5NarrowCons;    // slots with counters in LDS
-  constexpr uint32_t kRingF = WIDE ? kF5MaxFast : 4096u, kRingS = WIDE ? kF5MaxSlow : 4096u;
+  const uint32_t kNarrow = f5_narrow_cap(F.nb);         // (the wide layout's sizes are compile-time constants)
+  const uint32_t kMeta = WIDE ? kF5MaxFast : kNarrow;   // slots with constants in LDS
+  const uint32_t kAll = WIDE ? kF5MaxCons : kNarrow;    // slots with counters in LDS
+  constexpr uint32_t kRingF = WIDE ? kF5MaxFast : kF5NarrowRing, kRingS = WIDE ? kF5MaxSlow : kF5NarrowRing;
   extern __shared__ float4 s_dyn[];
   float4* s_body = s_dyn;  // 4 x nb
   // narrow: succ (8 B), c, aref, bref for every slot.  wide: the constraint id of EVERY slot (so a slow node's record
