@@ -62,8 +62,12 @@ __device__ __forceinline__ M3 load_imb(const float4* imb, uint32_t i) {
 // ------------------------------------------------------------------------------------------
 // complete_motion + integrate, one pass.
 // ------------------------------------------------------------------------------------------
+// `tail(i, tight box)` runs for every integrated body while its new bounds are still in registers (the terrain candidate
+// rows of the one-synchronisation tick, k_broadphase.h); NoTail for everything else.
+struct NoTail { __device__ __forceinline__ void operator()(uint32_t, const Box&) const {} };
+template <class Tail>
 __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, float dt, float fat_margin, int do_complete,
-                                                      int do_integrate, SceneBounds* sb, const uint32_t* guard) {
+                                                      int do_integrate, SceneBounds* sb, const uint32_t* guard, Tail tail) {
   if (guard && *guard) return;  // a speculative tick behind a failed one (see k_reset_step)
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   bool live = i < n;
@@ -129,6 +133,7 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
         B.fb_r[i] = mk4(fb.r, 0.0f);
         refit = true;
       }
+      tail(i, tb);
     } else if (do_complete) {
       B.einfo[i] = mk4(x + xyz(dl), B.einfo[i].w);
     }

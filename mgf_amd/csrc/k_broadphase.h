@@ -390,6 +390,23 @@ __global__ __launch_bounds__(kBlock) void k_terrain_rows(Bodies B, uint32_t n_ow
   if (nt > cap_row) atomicOr(overflow, 2u);  // bit 1: a terrain row, bit 0: a partner row
 }
 
+// the same rows written from k_integrate's tail (no second pass over the bodies)
+struct TerrainRowsTail {
+  TerrainDev M; uint32_t cap_row; uint32_t* rows_t; uint32_t* t_cnt; uint32_t* overflow;
+  __device__ __forceinline__ void operator()(uint32_t i, const Box& tb) const {
+    Box q; q.c = tb.c + -mk3(M.x[0], M.x[1], M.x[2]); q.r = tb.r;
+    uint32_t* row = rows_t + (size_t)i * cap_row;
+    uint32_t nt = 0;
+    const uint32_t cap = cap_row;
+    terrain_traverse(M, q, [&](uint32_t face) {
+      if (nt < cap) row[nt] = face;
+      ++nt;
+    });
+    t_cnt[i] = nt;
+    if (nt > cap) atomicOr(overflow, 2u);
+  }
+};
+
 // Partner bodies per body: cooperative traversal, 8 lanes per query.  A 4-ary node is eight 16-byte
 // words (lo[0..3], hi[0..3]); lane s of the group loads word s, so a node costs ONE cache-line lookup
 // per query instead of eight per lane (the per-lane form is bound by L1 tag lookups once neighbouring

@@ -438,6 +438,26 @@ def test_pipelined_step_many_with_capacity_misses(ctx, scene_name):
     assert a.counter("capacity_retries") >= 6
 
 
+def test_terrain_rows_from_integrate_equal_the_separate_kernel(ctx):
+    """mgf_world_step lists a body's terrain faces at the end of k_integrate (the bounds are in registers); the separate
+    kernel remains for split ticks, re-runs and tiles.  Same rows, same tick - also when a row overflows and is widened."""
+    import mgf_amd
+    from mgf_amd import scenes
+    scene = scenes.balls_demo(8)
+    dt, iters = float(scene["dt"]), scene["iters"]
+    a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
+    b.set_option("no_fused_terrain_rows", 1)
+    for step in range(150):
+        sa, sb = a.step(dt, iters), b.step(dt, iters)
+        for key in ("n_constraints", "n_terrain_constraints", "n_terrain_candidates", "n_pair_candidates"):
+            assert sa[key] == sb[key], (step, key)
+    assert sa.n_terrain_constraints > 0
+    xa, xb = a.state(), b.state()
+    for k in xa:
+        assert bits_equal(xa[k], xb[k]), k
+    compare_constraints(a.constraints(), b.constraints(), check_impulse=True)
+
+
 def test_block_that_does_not_fit_falls_back_on_the_device(ctx):
     """When a spatial block holds more constraints than its workgroup's LDS layout (forced here by a tiny test limit), a
     device flag turns k_solve_flow5 into a no-op and the k_solve_flow launch enqueued behind it does the work - no host
