@@ -187,7 +187,7 @@ __global__ void k_reset_step(SceneBounds* sb, uint32_t* err, uint32_t* guard, co
     for (int k = 0; k < 3; ++k) { sb->lo[k] = 0x7FFFFFFF; sb->hi[k] = (int)0x80000000; }
     sb->n_refits = 0; sb->pad = 0; sb->pad2 = 0;
     for (int k = 0; k < 3; ++k) sb->rmax[k] = 0;
-    err[0] = 0; err[1] = 0;  // traversal stack overflow, candidate row overflow
+    err[0] = 0; err[1] = 0; err[8] = 0;  // traversal stack overflow, candidate row overflow, fused narrowphase mismatch
   }
 }
 

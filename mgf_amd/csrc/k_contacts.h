@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint3
   for (uint32_t base = lo; base < hi; base += 4) {  // four counts per round trip
     uint32_t nc[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) nc[k] = base + k < hi ? p_nc[base + k] : 0u;
+    for (int k = 0; k < 4; ++k) nc[k] = base + k < hi ? (p_nc ? p_nc[base + k] : 1u) : 0u;  // p_nc == nullptr: the list holds contacts only
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (nc[k]) {
@@ -224,10 +224,10 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint3
     }
   } else {  // a crowded body: the same by rescanning its list
     for (uint32_t p = lo; p < hi; ++p) {
-      if (p_nc[p] == 0) continue;
+      if (p_nc && p_nc[p] == 0) continue;
       const uint32_t j = p_cand[p];
       uint32_t before = 0;
-      for (uint32_t q = lo; q < hi; ++q) before += (p_cand[q] < j) ? p_nc[q] : 0u;
+      for (uint32_t q = lo; q < hi; ++q) before += (p_cand[q] < j) ? (p_nc ? p_nc[q] : 1u) : 0u;
       p_pre[p] = run + before;
     }
   }
@@ -334,16 +334,29 @@ __device__ __forceinline__ CRec load_crec_solve(const CRec* src) {
   return c;
 }
 
+// SPHERES = true: a world of spheres whose broadphase ran the sphere-sphere test itself (k_pair_grid<true>): the list
+// holds contacts only, one per pair, and the contact is computed here from the colliders (no k_narrow_pairs pass, no
+// NContact round trip through memory).  `flag` is raised if the two evaluations of the same test ever disagreed.
+template <bool SPHERES>
 __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCounts* sc, const uint32_t* p_owner, const uint32_t* p_cand,
                                                         const uint32_t* p_nc, const uint32_t* p_pre, const NContact* p_in,
                                                         const uint32_t* base, float dt, float baumgarte, float slop,
                                                         CRec* cons, uint2* ab, uint32_t* degb, uint32_t* rev, uint32_t rev_cap,
-                                                        uint32_t* rev_flag, uint32_t in_stride) {
+                                                        uint32_t* rev_flag, uint32_t in_stride, uint32_t* flag) {
   uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= sc->Mp) return;
-  const uint32_t nc = p_nc[p];
+  const uint32_t nc = SPHERES ? 1u : p_nc[p];
   if (nc == 0) return;
   uint32_t i = p_owner[p], j = p_cand[p];
+  NContact own;
+  if (SPHERES) {  // as k_narrow_pairs<0, 0>
+    Comp A = load_comp(B, i), Bc = load_comp(B, j);
+    A.kind = KIND_SPHERE; Bc.kind = KIND_SPHERE;
+    LocalContact lc;
+    if (!comp_pair_local(A, xyz(B.delta[i]), Bc, xyz(B.delta[j]), &lc)) { *flag = 1u; return; }
+    V3 nrm = (mk3(0.0f, 0.0f, 0.0f) + lc.g.n) / 1.0f;  // Manifold::from(pruner) of one contact (manifold.rs:135-140)
+    own.la = mk4(lc.la, lc.g.t); own.lb = mk4(lc.lb, 0.0f); own.n = mk4(nrm, 0.0f);
+  }
   BodyDyn A = load_dyn(B.srec, i), Bd = load_dyn(B.srec, j);
   float4 ea = B.einfo[i], eb = B.einfo[j];
   // A manifold of m contacts (bodies of several parts only) becomes m consecutive single-contact records that share
@@ -351,7 +364,7 @@ __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCoun
   // the other on the same velocities, which is exactly what consecutive records do.
   for (uint32_t q = 0; q < nc; ++q) {
     const uint32_t c = base[i] + p_pre[p] + q;
-    NContact k = p_in[(size_t)in_stride * p + q];
+    NContact k = SPHERES ? own : p_in[(size_t)in_stride * p + q];
     CRec r = make_constraint(i, j, A, xyz(ea), ea.w, B.delta[i].w, Bd, xyz(eb), eb.w, B.delta[j].w, xyz(k.n), xyz(k.la), xyz(k.lb),
                              dt, baumgarte, slop);
     store_crec(&cons[c], r);
