@@ -38,9 +38,10 @@ __global__ __launch_bounds__(kBlock) void k_morton_count(const float4* fb_c, uin
 }
 
 // Zero several small arrays with one launch (instead of one fill kernel each).
-struct ZeroList { uint32_t* p[8]; uint32_t words[8]; };
+constexpr int kZeroSlots = 16;
+struct ZeroList { uint32_t* p[kZeroSlots]; uint32_t words[kZeroSlots]; };
 __global__ __launch_bounds__(kBlock) void k_zero_many(ZeroList z) {
-  for (int a = 0; a < 8; ++a) {
+  for (int a = 0; a < kZeroSlots; ++a) {
     uint32_t* p = z.p[a];
     if (!p) continue;
     for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < z.words[a]; e += gridDim.x * kBlock) p[e] = 0u;
