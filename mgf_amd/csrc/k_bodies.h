@@ -49,6 +49,7 @@ struct Bodies {
 };
 constexpr int kMaxParts = 2;
 
+constexpr int kBoundSlots = 64, kBoundSlotInts = 32;  // partial scene bounds: lo[3], hi[3], rmax[3] per slot, one 128-byte line each
 struct SceneBounds { int lo[3]; int hi[3]; uint32_t n_refits; uint32_t pad; int rmax[3]; uint32_t pad2; };  // ordered-int encoded floats; rmax = largest fat half extent
 
 __device__ __forceinline__ int f_ord(float f) { int i = __builtin_bit_cast(int, f); return i >= 0 ? i : (i ^ 0x7FFFFFFF); }
@@ -67,11 +68,12 @@ __device__ __forceinline__ M3 load_imb(const float4* imb, uint32_t i) {
 struct NoTail { __device__ __forceinline__ void operator()(uint32_t, const Box&) const {} };
 template <class Tail>
 __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, float dt, float fat_margin, int do_complete,
-                                                      int do_integrate, SceneBounds* sb, const uint32_t* guard, Tail tail) {
+                                                      int do_integrate, SceneBounds* sb, const uint32_t* guard, Tail tail, int* sb_part) {
   if (guard && *guard) return;  // a speculative tick behind a failed one (see k_reset_step)
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   bool live = i < n;
   bool refit = false;
+  int blo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, bhi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000}, brm[3] = {0, 0, 0};
   if (live) {
     float4 xw = B.x[i];
     float4 dl = B.delta[i];
@@ -133,6 +135,8 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
         B.fb_r[i] = mk4(fb.r, 0.0f);
         refit = true;
       }
+      blo[0] = bhi[0] = f_ord(fb.c.x); blo[1] = bhi[1] = f_ord(fb.c.y); blo[2] = bhi[2] = f_ord(fb.c.z);
+      brm[0] = f_ord(fb.r.x); brm[1] = f_ord(fb.r.y); brm[2] = f_ord(fb.r.z);
       tail(i, tb);
     } else if (do_complete) {
       B.einfo[i] = mk4(x + xyz(dl), B.einfo[i].w);
@@ -143,6 +147,24 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
   // refit count: one atomic per block
   int nref = __syncthreads_count(refit ? 1 : 0);
   if (threadIdx.x == 0 && nref) atomicAdd(&sb->n_refits, (uint32_t)nref);
+  if (!sb_part) return;
+  // scene bounds of the fat boxes (what k_scene_bounds computes), while they are in registers: block reduce, then nine
+  // atomics into one of kBoundSlots partial records, each on its own cache line (same-line atomics serialise); the next
+  // launch (k_zero_many) folds the partial records into *sb
+  __shared__ int s_red[9][kBlock / 64];
+  for (int k = 0; k < 3; ++k) {
+    int a = blo[k], b = bhi[k], c = brm[k];
+    for (int off = 32; off > 0; off >>= 1) { a = min(a, __shfl_xor(a, off)); b = max(b, __shfl_xor(b, off)); c = max(c, __shfl_xor(c, off)); }
+    if ((threadIdx.x & 63) == 0) { s_red[k][threadIdx.x >> 6] = a; s_red[3 + k][threadIdx.x >> 6] = b; s_red[6 + k][threadIdx.x >> 6] = c; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) {
+    const int k = threadIdx.x;
+    int v = s_red[k][0];
+    for (int w = 1; w < kBlock / 64; ++w) v = k < 3 ? min(v, s_red[k][w]) : max(v, s_red[k][w]);
+    int* slot = sb_part + (size_t)(blockIdx.x % kBoundSlots) * kBoundSlotInts + k;
+    if (k < 3) atomicMin(slot, v); else atomicMax(slot, v);
+  }
 }
 
 // Scene bounds of the fat-box centres (Morton quantisation): grid-stride, block reduce in LDS,
@@ -180,9 +202,13 @@ __global__ __launch_bounds__(kBlock) void k_refresh_einfo(Bodies B, uint32_t n) 
 // `spec`: the tick is being enqueued before the previous one has been read back (mgf_world_step_many).  If that one
 // turns out to have failed a capacity check (its StepCounts still sit in `sc`), this tick must not touch the state: the
 // guard word makes k_integrate and the whole collide phase no-ops, and the host re-runs both ticks.
-__global__ void k_reset_step(SceneBounds* sb, uint32_t* err, uint32_t* guard, const uint32_t* prev_fail, int spec) {
+__global__ void k_reset_step(SceneBounds* sb, uint32_t* err, uint32_t* guard, const uint32_t* prev_fail, int spec, int* sb_part) {
+  if (spec && *prev_fail) { if (threadIdx.x == 0) *guard = 1u; return; }
+  if (sb_part && threadIdx.x < kBoundSlots) {  // launched with 64 threads: one partial record each
+    int* slot = sb_part + (size_t)threadIdx.x * kBoundSlotInts;
+    for (int k = 0; k < 3; ++k) { slot[k] = 0x7FFFFFFF; slot[3 + k] = (int)0x80000000; slot[6 + k] = 0; }
+  }
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    if (spec && *prev_fail) { *guard = 1u; return; }
     *guard = 0u;
     for (int k = 0; k < 3; ++k) { sb->lo[k] = 0x7FFFFFFF; sb->hi[k] = (int)0x80000000; }
     sb->n_refits = 0; sb->pad = 0; sb->pad2 = 0;

@@ -39,8 +39,14 @@ __global__ __launch_bounds__(kBlock) void k_morton_count(const float4* fb_c, uin
 
 // Zero several small arrays with one launch (instead of one fill kernel each).
 constexpr int kZeroSlots = 16;
-struct ZeroList { uint32_t* p[kZeroSlots]; uint32_t words[kZeroSlots]; };
+struct ZeroList { uint32_t* p[kZeroSlots]; uint32_t words[kZeroSlots]; SceneBounds* sb; const int* sb_part; };
 __global__ __launch_bounds__(kBlock) void k_zero_many(ZeroList z) {
+  if (z.sb_part && blockIdx.x == 0 && threadIdx.x < 9) {  // fold k_integrate's partial scene bounds (see there)
+    const int k = threadIdx.x;
+    int v = z.sb_part[k];
+    for (int a = 1; a < kBoundSlots; ++a) { int u = z.sb_part[(size_t)a * kBoundSlotInts + k]; v = k < 3 ? min(v, u) : max(v, u); }
+    if (k < 3) z.sb->lo[k] = v; else if (k < 6) z.sb->hi[k - 3] = v; else z.sb->rmax[k - 6] = v;
+  }
   for (int a = 0; a < kZeroSlots; ++a) {
     uint32_t* p = z.p[a];
     if (!p) continue;

@@ -447,6 +447,7 @@ def test_terrain_rows_from_integrate_equal_the_separate_kernel(ctx):
     dt, iters = float(scene["dt"]), scene["iters"]
     a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
     b.set_option("no_fused_terrain_rows", 1)
+    b.set_option("no_fused_scene_bounds", 1)  # likewise the scene bounds: gathered by k_integrate / by their own kernel
     for step in range(150):
         sa, sb = a.step(dt, iters), b.step(dt, iters)
         for key in ("n_constraints", "n_terrain_constraints", "n_terrain_candidates", "n_pair_candidates"):
