@@ -65,11 +65,18 @@ __device__ __forceinline__ M3 load_imb(const float4* imb, uint32_t i) {
 // ------------------------------------------------------------------------------------------
 // `tail(i, tight box)` runs for every integrated body while its new bounds are still in registers (the terrain candidate
 // rows of the one-synchronisation tick, k_broadphase.h); NoTail for everything else.
-struct NoTail { __device__ __forceinline__ void operator()(uint32_t, const Box&) const {} };
+struct NoTail {
+  static constexpr int kLdsWords = 1;
+  __device__ __forceinline__ void stage(float4*) const {}
+  __device__ __forceinline__ void operator()(uint32_t, const Box&, const float4*) const {}
+};
 template <class Tail>
 __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, float dt, float fat_margin, int do_complete,
                                                       int do_integrate, SceneBounds* sb, const uint32_t* guard, Tail tail, int* sb_part) {
   if (guard && *guard) return;  // a speculative tick behind a failed one (see k_reset_step)
+  __shared__ float4 s_tail[Tail::kLdsWords];
+  tail.stage(s_tail);
+  if (Tail::kLdsWords > 1) __syncthreads();
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   bool live = i < n;
   bool refit = false;
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
       }
       blo[0] = bhi[0] = f_ord(fb.c.x); blo[1] = bhi[1] = f_ord(fb.c.y); blo[2] = bhi[2] = f_ord(fb.c.z);
       brm[0] = f_ord(fb.r.x); brm[1] = f_ord(fb.r.y); brm[2] = f_ord(fb.r.z);
-      tail(i, tb);
+      tail(i, tb, s_tail);
     } else if (do_complete) {
       B.einfo[i] = mk4(x + xyz(dl), B.einfo[i].w);
     }

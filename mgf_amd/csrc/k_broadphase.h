@@ -189,15 +189,16 @@ struct TerrainDev {
 constexpr int kStack = 32;  // reference-built trees are AVL-balanced: depth <= 1.44 log2(faces)
 
 // bvh.rs:283-310 with the reference's order: push lchild, push rchild, pop rchild first.
+// `nodes`: the tree's nodes as float4 pairs, in global memory or (small meshes, k_integrate's tail) staged in LDS
 template <class F>
-__device__ __forceinline__ void terrain_traverse(const TerrainDev& M, const Box& q, F&& emit) {
+__device__ __forceinline__ void terrain_traverse_at(const TerrainDev& M, const float4* nodes, const Box& q, F&& emit) {
   if (M.n_nodes == 0) return;
   uint32_t stack[kStack];
   int sp = 0;
   stack[sp++] = M.root;
   while (sp > 0) {
     uint32_t top = stack[--sp];
-    const float4* raw = reinterpret_cast<const float4*>(&M.nodes[top]);
+    const float4* raw = nodes + 2 * (size_t)top;
     float4 n0 = raw[0], n1 = raw[1];
     Box nb; nb.c = xyz(n0); nb.r = xyz(n1);
     if (box_overlaps(q, nb)) {
@@ -207,6 +208,11 @@ __device__ __forceinline__ void terrain_traverse(const TerrainDev& M, const Box&
       else if (M.err) *M.err = 1u;
     }
   }
+}
+
+template <class F>
+__device__ __forceinline__ void terrain_traverse(const TerrainDev& M, const Box& q, F&& emit) {
+  terrain_traverse_at(M, reinterpret_cast<const float4*>(M.nodes), q, emit);
 }
 
 // Depth-first traversal of the implicit 4-ary tree with a bitmask trail (4 pending-child bits per level)
@@ -399,16 +405,24 @@ __global__ __launch_bounds__(kBlock) void k_terrain_rows(Bodies B, uint32_t n_ow
 
 // the same rows written from k_integrate's tail (no second pass over the bodies)
 struct TerrainRowsTail {
+  static constexpr int kLdsWords = 2 * 64;  // a mesh of up to 64 tree nodes (the demo's 10-face box: 19) is walked in LDS
   TerrainDev M; uint32_t cap_row; uint32_t* rows_t; uint32_t* t_cnt; uint32_t* overflow;
-  __device__ __forceinline__ void operator()(uint32_t i, const Box& tb) const {
+  __device__ __forceinline__ void stage(float4* s) const {
+    if (2u * M.n_nodes > (uint32_t)kLdsWords) return;
+    const float4* src = reinterpret_cast<const float4*>(M.nodes);
+    for (uint32_t e = threadIdx.x; e < 2u * M.n_nodes; e += blockDim.x) s[e] = src[e];
+  }
+  __device__ __forceinline__ void operator()(uint32_t i, const Box& tb, const float4* s) const {
     Box q; q.c = tb.c + -mk3(M.x[0], M.x[1], M.x[2]); q.r = tb.r;
     uint32_t* row = rows_t + (size_t)i * cap_row;
     uint32_t nt = 0;
     const uint32_t cap = cap_row;
-    terrain_traverse(M, q, [&](uint32_t face) {
+    auto emit = [&](uint32_t face) {
       if (nt < cap) row[nt] = face;
       ++nt;
-    });
+    };
+    if (2u * M.n_nodes <= (uint32_t)kLdsWords) terrain_traverse_at(M, s, q, emit);  // (two calls: a selected pointer would make the loads flat)
+    else terrain_traverse(M, q, emit);
     t_cnt[i] = nt;
     if (nt > cap) atomicOr(overflow, 2u);
   }
