@@ -1,7 +1,9 @@
 // Hand-written HIP kernels of the mgf per-tick hot path for gfx950 (wave64).
 //
-//   k_integrate        RigidBodyVec::complete_motion + integrate (physics.rs:222-269), swept AABB
-//                      (bounds.rs:60-68), fat-AABB refit test (world.rs:234-238)
+//   k_integrate<Tail>  RigidBodyVec::complete_motion + integrate (physics.rs:222-269), swept AABB
+//                      (bounds.rs:60-68), fat-AABB refit test (world.rs:234-238).  In mgf_world_step (collide follows at
+//                      once on the same bodies) its tail also lists each body's terrain faces (what k_terrain_rows does)
+//                      and the blocks gather the scene bounds (what k_scene_bounds does; folded by k_zero_many)
 //   k_scene_bounds / k_morton_count / k_scatter_leaves
 //                      bodies counting-sorted into Morton cells (cell = 2L-bit prefix of the 30-bit code of the fat-box
 //                      centre); the same kernels build the static grid over a terrain mesh's face boxes
@@ -15,8 +17,10 @@
 //   k_rows_to_csr      rows -> CSR, terrain faces in DFS order (partner contacts are ordered by k_count_contacts)
 //   k_narrow_pairs<A,B> / k_narrow_terrain<A>
 //                      one kernel per shape-pair type over the candidate lists
-//   k_count_contacts / k_setup_pairs / k_setup_terrain
-//                      Manifold::from + ContactConstraint::new (manifold.rs:120-148, solver.rs:101-191)
+//   k_count_contacts / k_setup_pairs<SPHERES> / k_setup_terrain
+//                      Manifold::from + ContactConstraint::new (manifold.rs:120-148, solver.rs:101-191); in a world of
+//                      spheres only the broadphase lists contacts (k_pair_grid<true> runs the sphere test) and
+//                      k_setup_pairs<true> evaluates each one itself, so k_narrow_pairs is not launched
 //   k_chain_rows       order-preserving dependency links of the tick's constraint list (compact arrays, ConsLinks);
 //   k_adj_fill / k_chain  the same for a caller-supplied list in any order (mgf_world_set_constraints)
 //   k_solve_flow5      ContactConstraint::solve (solver.rs:203-252) for a whole Solver::solve call: block-local persistent
