@@ -103,8 +103,8 @@ def test_outlier_body_stretches_the_morton_range(ctx):
 def test_mixed_radii_fall_back_to_the_tree_walk(ctx):
     # a sphere 12x larger than the rest spans many cells: the tick switches to the tree walk and stays exact
     rng = np.random.default_rng(4)
-    c = rng.uniform(-5, 5, (300, 3)).astype(np.float32)
-    c[:, 1] = rng.uniform(0.5, 6, 300)
+    c = rng.uniform(-5, 5, (700, 3)).astype(np.float32)  # enough bodies for a 1024-cell grid
+    c[:, 1] = rng.uniform(0.5, 6, 700)
     sc = _scene(np.concatenate([c, [[0, 9.0, 0]]]))
     sc["comps"]["r"][-1] = 6.0
     gw, _ = _run(ctx, sc, 10, expect_constraints=True)
