@@ -63,6 +63,27 @@ __device__ __forceinline__ M3 load_imb(const float4* imb, uint32_t i) {
 // ------------------------------------------------------------------------------------------
 // complete_motion + integrate, one pass.
 // ------------------------------------------------------------------------------------------
+// Scene bounds of the fat boxes (what k_scene_bounds computes) while they are in a kernel's registers: every thread of the
+// block brings its body's ordered-int centre (lo = hi) and half extents, or the identity; block reduce, then nine atomics into
+// one of kBoundSlots partial records, each on its own cache line (same-line atomics serialise).  The clearing launch of the
+// collide phase (k_zero_many) folds the partial records into *sb.
+__device__ __forceinline__ void bounds_block_accumulate(const int blo[3], const int bhi[3], const int brm[3], int* sb_part) {
+  __shared__ int s_red[9][kBlock / 64];
+  for (int k = 0; k < 3; ++k) {
+    int a = blo[k], b = bhi[k], c = brm[k];
+    for (int off = 32; off > 0; off >>= 1) { a = min(a, __shfl_xor(a, off)); b = max(b, __shfl_xor(b, off)); c = max(c, __shfl_xor(c, off)); }
+    if ((threadIdx.x & 63) == 0) { s_red[k][threadIdx.x >> 6] = a; s_red[3 + k][threadIdx.x >> 6] = b; s_red[6 + k][threadIdx.x >> 6] = c; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) {
+    const int k = threadIdx.x;
+    int v = s_red[k][0];
+    for (int w = 1; w < kBlock / 64; ++w) v = k < 3 ? min(v, s_red[k][w]) : max(v, s_red[k][w]);
+    int* slot = sb_part + (size_t)(blockIdx.x % kBoundSlots) * kBoundSlotInts + k;
+    if (k < 3) atomicMin(slot, v); else atomicMax(slot, v);
+  }
+}
+
 // `tail(i, tight box)` runs for every integrated body while its new bounds are still in registers (the terrain candidate
 // rows of the one-synchronisation tick, k_broadphase.h); NoTail for everything else.
 struct NoTail {
@@ -155,23 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
   int nref = __syncthreads_count(refit ? 1 : 0);
   if (threadIdx.x == 0 && nref) atomicAdd(&sb->n_refits, (uint32_t)nref);
   if (!sb_part) return;
-  // scene bounds of the fat boxes (what k_scene_bounds computes), while they are in registers: block reduce, then nine
-  // atomics into one of kBoundSlots partial records, each on its own cache line (same-line atomics serialise); the next
-  // launch (k_zero_many) folds the partial records into *sb
-  __shared__ int s_red[9][kBlock / 64];
-  for (int k = 0; k < 3; ++k) {
-    int a = blo[k], b = bhi[k], c = brm[k];
-    for (int off = 32; off > 0; off >>= 1) { a = min(a, __shfl_xor(a, off)); b = max(b, __shfl_xor(b, off)); c = max(c, __shfl_xor(c, off)); }
-    if ((threadIdx.x & 63) == 0) { s_red[k][threadIdx.x >> 6] = a; s_red[3 + k][threadIdx.x >> 6] = b; s_red[6 + k][threadIdx.x >> 6] = c; }
-  }
-  __syncthreads();
-  if (threadIdx.x < 9) {
-    const int k = threadIdx.x;
-    int v = s_red[k][0];
-    for (int w = 1; w < kBlock / 64; ++w) v = k < 3 ? min(v, s_red[k][w]) : max(v, s_red[k][w]);
-    int* slot = sb_part + (size_t)(blockIdx.x % kBoundSlots) * kBoundSlotInts + k;
-    if (k < 3) atomicMin(slot, v); else atomicMax(slot, v);
-  }
+  bounds_block_accumulate(blo, bhi, brm, sb_part);
 }
 
 // Scene bounds of the fat-box centres (Morton quantisation): grid-stride, block reduce in LDS,

@@ -56,11 +56,7 @@ __global__ __launch_bounds__(kBlock) void k_export_bodies(Bodies B, const uint32
     q8[0] = a.x; q8[1] = a.y; q8[2] = a.z; q8[3] = a.w; q8[4] = b.x; q8[5] = b.y; q8[6] = b.z; q8[7] = b.w;
   }
 }
-__global__ __launch_bounds__(kBlock) void k_import_ghosts(Bodies B, uint32_t n_owned, uint32_t m, const float* in, float fat_margin) {
-  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= m) return;
-  uint32_t i = n_owned + t;
-  const float* o = in + (size_t)t * kGhostFloats;
+__device__ __forceinline__ void import_ghost(Bodies B, uint32_t i, const float* o, float fat_margin, int blo[3], int bhi[3], int brm[3]) {
   V3 x = mk3(o[0], o[1], o[2]), d = mk3(o[13], o[14], o[15]);
   B.x[i] = mk4(x, 0.0f);
   B.q[i] = make_float4(o[3], o[4], o[5], o[6]);
@@ -90,10 +86,19 @@ __global__ __launch_bounds__(kBlock) void k_import_ghosts(Bodies B, uint32_t n_o
     }
   }
   B.tb_c[i] = mk4(tb.c, 0.0f); B.tb_r[i] = mk4(tb.r, 0.0f);
-  B.fb_c[i] = mk4(tb.c, 0.0f); B.fb_r[i] = mk4(tb.r + mk3(fat_margin, fat_margin, fat_margin), 0.0f);
+  const V3 fr = tb.r + mk3(fat_margin, fat_margin, fat_margin);
+  B.fb_c[i] = mk4(tb.c, 0.0f); B.fb_r[i] = mk4(fr, 0.0f);
+  blo[0] = bhi[0] = f_ord(tb.c.x); blo[1] = bhi[1] = f_ord(tb.c.y); blo[2] = bhi[2] = f_ord(tb.c.z);
+  brm[0] = f_ord(fr.x); brm[1] = f_ord(fr.y); brm[2] = f_ord(fr.z);
   B.sp0[i] = make_float4(0, 0, 0, o[34]); B.sp1[i] = make_float4(0, 0, 0, o[35]);
   B.ctor[i] = make_float4(pc ? u2f(2u) : o[16], k.r, 0.0f, 0.0f);
   B.imb[3 * i] = make_float4(0, 0, 0, 0); B.imb[3 * i + 1] = make_float4(0, 0, 0, 0); B.imb[3 * i + 2] = make_float4(0, 0, 0, 0);
+}
+__global__ __launch_bounds__(kBlock) void k_import_ghosts(Bodies B, uint32_t n_owned, uint32_t m, const float* in, float fat_margin, int* sb_part) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  int blo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, bhi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000}, brm[3] = {0, 0, 0};
+  if (t < m) import_ghost(B, n_owned + t, in + (size_t)t * kGhostFloats, fat_margin, blo, bhi, brm);
+  if (sb_part) bounds_block_accumulate(blo, bhi, brm, sb_part);  // the scene bounds gathered by this tick's k_integrate take the ghosts in
 }
 // velocity record: 8 floats (v3, w3, 0, 0)
 __global__ __launch_bounds__(kBlock) void k_export_vel(const float4* srec, const uint32_t* ids, uint32_t m, float4* out) {
