@@ -459,6 +459,37 @@ def test_terrain_rows_from_integrate_equal_the_separate_kernel(ctx):
     compare_constraints(a.constraints(), b.constraints(), check_impulse=True)
 
 
+def test_body_added_between_begin_and_collide_is_seen(ctx):
+    """A split tick (begin_tick, ..., collide) may change the bodies in between; whatever k_integrate gathered on the way
+    (scene bounds, terrain rows) must then be dropped.  A sphere added outside the old bounds, touching the floor, gets
+    its terrain constraint and its place in the grid exactly as in a world that never fuses."""
+    import mgf_amd
+    from mgf_amd import scenes
+    scene = scenes.balls_demo(6)
+    dt, iters = float(scene["dt"]), scene["iters"]
+    a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
+    b.set_option("no_fused_terrain_rows", 1)
+    b.set_option("no_fused_scene_bounds", 1)
+    extra = np.zeros(2, dtype=scene["comps"].dtype)
+    extra["tag"] = 0
+    extra["p"] = [(8.5, -9.5, 8.5), (8.5, -8.45, 8.5)]  # in a corner of the box, on the floor and on top of each other
+    extra["r"] = 0.5
+    for tick in range(40):
+        for w in (a, b):
+            w.begin_tick(dt)
+            if tick == 5:
+                w.add_bodies(extra, 1.0, 0.3, 0.6, (0.0, -9.8, 0.0))
+        sa, sb = a.collide(dt), b.collide(dt)
+        for key in ("n_bodies", "n_constraints", "n_terrain_constraints", "n_pair_candidates"):
+            assert sa[key] == sb[key], (tick, key)
+        if tick == 5:
+            assert sa.n_terrain_constraints >= 1
+        a.solve(iters); b.solve(iters)
+    xa, xb = a.state(), b.state()
+    for k in xa:
+        assert bits_equal(xa[k], xb[k]), k
+
+
 def test_block_that_does_not_fit_falls_back_on_the_device(ctx):
     """When a spatial block holds more constraints than its workgroup's LDS layout (forced here by a tiny test limit), a
     device flag turns k_solve_flow5 into a no-op and the k_solve_flow launch enqueued behind it does the work - no host
