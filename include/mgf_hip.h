@@ -321,7 +321,7 @@ MGF_API mgf_status mgf_world_solve_enqueue(mgf_world* w, int32_t iters);
 MGF_API mgf_status mgf_world_finish(mgf_world* w, mgf_step_stats* stats);
 /* Options (development and test knobs; defaults in brackets): "time_solver_kernels" [0] HIP events around the
  * solver kernels; "solver_mode" [5] 1 = persistent dataflow launch, 0 = one launch per dependency frontier,
- * 4 = dataflow with out-of-order slots, 5 = block-local dataflow (velocities and counters of a spatial block in LDS); "two_pass_candidates" [0]; "broadphase_tree" [0]; "terrain_tree" [0]; "no_fused_narrowphase" [0] (a world of spheres only runs the sphere-sphere test inside the grid broadphase and lists contacts only; 1 = list every accepted partner); "stream_ordered" [0]; "spin_wait" [1] (the tick's one wait polls an event instead of blocking); "pipeline" [1] (mgf_world_step_many enqueues the next tick before it waits for this one); "no_fused_terrain_rows" [0], "no_fused_scene_bounds" [0] (mgf_world_step lists the terrain faces of a body and gathers the scene bounds inside the integration kernel; 1 = always the separate kernels); "list_capacity";
+ * 4 = dataflow with out-of-order slots, 5 = block-local dataflow (velocities and counters of a spatial block in LDS); "two_pass_candidates" [0]; "broadphase_tree" [0]; "terrain_tree" [0]; "no_fused_narrowphase" [0] (a world of spheres only runs the sphere-sphere test inside the grid broadphase and lists contacts only; 1 = list every accepted partner); "stream_ordered" [0]; "spin_wait" [1] (the tick's one wait polls an event instead of blocking); "pipeline" [1] (mgf_world_step_many enqueues the next tick before it waits for this one); "cell_fill" [16] (bodies per Morton cell, in eighths, beyond which the broadphase grid gets another level); "no_fused_terrain_rows" [0], "no_fused_scene_bounds" [0] (mgf_world_step and mgf_world_begin_tick list the terrain faces of a body and gather the scene bounds inside the integration kernel; 1 = always the separate kernels); "list_capacity";
  * "flow_blocks_per_cu"; "flow_sleep"; "flow_trace"; "debug_bvh"; "flow5_block", "flow5_slow_x2", "flow5_poller", "flow5_test_cap" (block-local solver: block size, wave split, polling wave, a test limit that forces the stand-by kernel); "body_kinds" (OR-in, bit0 sphere, bit1 capsule): the
  * kinds this world's ghosts may have - a tile whose own bodies are all of one kind must be told when a neighbour's are
  * not, because the narrowphase dispatch is chosen on the host (the tiles driver exchanges the masks with the counts). */
