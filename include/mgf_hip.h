@@ -50,7 +50,8 @@ typedef struct mgf_quat { float s, x, y, z; } mgf_quat;            /* cgmath Qua
 typedef struct mgf_aabb { mgf_vec3 c, r; } mgf_aabb;               /* geom.rs:257-260 centre + half extents */
 
 /* Component (compound.rs:33): tag 0 = Sphere{c = p, r}; tag 1 = Capsule{a = p, d, r}. */
-enum { MGF_SPHERE = 0, MGF_CAPSULE = 1, MGF_TRIANGLE = 2, MGF_RECTANGLE = 3, MGF_PLANE = 4 };
+enum { MGF_SPHERE = 0, MGF_CAPSULE = 1, MGF_TRIANGLE = 2, MGF_RECTANGLE = 3, MGF_PLANE = 4,
+       MGF_RAY = 5, MGF_SEGMENT = 6, MGF_AABB = 7 /* scene I/O only (mgf_geom_to_json): v = {p, d} / {a, b} / {c, r} */ };
 typedef struct mgf_component { int32_t tag; mgf_vec3 p; mgf_vec3 d; float r; } mgf_component;
 /* Moving<Component> (geom.rs:357): shape + per-step displacement. */
 typedef struct mgf_moving_component { mgf_component shape; mgf_vec3 delta; } mgf_moving_component;
@@ -121,6 +122,7 @@ typedef struct mgf_mesh mgf_mesh;
 typedef struct mgf_bvh mgf_bvh;
 typedef struct mgf_world mgf_world;
 typedef struct mgf_compound mgf_compound;
+typedef struct mgf_solver mgf_solver;
 
 /* ---- context ---------------------------------------------------------------------- */
 MGF_API mgf_status mgf_ctx_create(int device, mgf_ctx** out);
@@ -249,6 +251,33 @@ MGF_API mgf_status mgf_world_read_constraints(mgf_world* w, mgf_constraint* out,
 /* Solver::add_constraint in bulk + solve on the resident RigidBodyVec (solver.rs:66-78):
  * replaces the tick's constraint list with `cons` (insertion order = array order). */
 MGF_API mgf_status mgf_world_set_constraints(mgf_world* w, const mgf_constraint* cons, int64_t n);
+/* ---- the library-level pieces World::step is assembled from, on their own (a caller that does its own collision
+ * detection builds manifolds, constraints and a Solver exactly as mgf_demo/world.rs:243-251,279-291 does) ----
+ * ContactConstraint::new(pool, obj_a, obj_b, manifold, dt) (solver.rs:101-191) for n caller-built manifolds on the world's
+ * resident RigidBodyVec (mix of restitution / friction, bias, normal and tangent masses from ConstrainedSet::get of both
+ * bodies).  refs_a[i] must be Dynamic (MGF_ERR_STATIC_REF otherwise: every call site of the reference passes one);
+ * refs_b[i] Dynamic or Static{center, friction}.  The manifold's normal and tangent vectors are used as given.  A manifold
+ * of m contacts yields m consecutive single-contact records that share its normal and tangents - equivalent under
+ * ContactConstraint::solve (solver.rs:219-248: the contacts one after the other on the same velocities).  *count = records
+ * written (MGF_ERR_CAPACITY if cap is smaller; *count still reports the number required). */
+MGF_API mgf_status mgf_constraints_new(mgf_world* w, const mgf_body_ref* refs_a, const mgf_body_ref* refs_b, const mgf_manifold* manifolds,
+                                       int64_t n, float dt, mgf_constraint* out, int64_t cap, int64_t* count);
+/* Solver<ContactConstraint> (solver.rs:53-79): new / add_constraint (bulk form too) / solve(&mut rbv, iters) / len.  The
+ * handle owns its insertion-ordered list; solve runs it on the world's RigidBodyVec in the exact sequential order, with
+ * the tick's executors (the world's own tick list is replaced, as by mgf_world_set_constraints), and the constraints keep
+ * their state (normal_impulse) between solve calls as the reference's do.  mgf_solver_clear is `Solver::new()` again
+ * (world.rs:228 rebuilds the solver every tick). */
+MGF_API mgf_status mgf_solver_new(mgf_solver** out);                                              /* Solver::new            solver.rs:59 */
+MGF_API void mgf_solver_free(mgf_solver* s);
+MGF_API mgf_status mgf_solver_add_constraint(mgf_solver* s, const mgf_constraint* c);             /* Solver::add_constraint solver.rs:66 */
+MGF_API mgf_status mgf_solver_add_constraints(mgf_solver* s, const mgf_constraint* cons, int64_t n);
+MGF_API int64_t mgf_solver_len(const mgf_solver* s);
+MGF_API mgf_status mgf_solver_clear(mgf_solver* s);
+MGF_API mgf_status mgf_solver_read_constraints(const mgf_solver* s, mgf_constraint* out, int64_t cap, int64_t* count);
+MGF_API mgf_status mgf_solver_solve(mgf_solver* s, mgf_world* w, int32_t iters, mgf_step_stats* stats); /* Solver::solve solver.rs:72 */
+/* RigidBodyVec: Clone (physics.rs:140), with the rest of the world it lives in (terrain copy, parameters, options): an
+ * independent world on the same context that steps bit-identically.  Ghosts and the tick's lists are not copied. */
+MGF_API mgf_status mgf_world_clone(mgf_world* src, mgf_world** out);
 /* ContactPruner::new + push(contact) for every LocalContact of a group, in order, then Manifold::from(pruner)
  * (manifold.rs:42-148) for n groups at once: group i = contacts[offsets[i] .. offsets[i+1]).  params = NULL uses
  * DefaultPruningParams / COLLISION_EPSILON.  The reference's pruner is unbounded; a group that keeps more than
@@ -263,6 +292,13 @@ MGF_API mgf_status mgf_bvh_to_json(const mgf_bvh* b, char* buf, int64_t cap, int
 MGF_API mgf_status mgf_bvh_from_json(mgf_ctx* ctx, const char* json, int64_t len, mgf_bvh** out);
 MGF_API mgf_status mgf_mesh_to_json(const mgf_mesh* m, char* buf, int64_t cap, int64_t* len);
 MGF_API mgf_status mgf_mesh_from_json(mgf_ctx* ctx, const char* json, int64_t len, mgf_mesh** out);
+/* The geometry structs of geom.rs:31-357 in serde_json's shape: s->kind selects the struct - MGF_SPHERE {"c","r"},
+ * MGF_CAPSULE {"a","d","r"}, MGF_TRIANGLE {"a","b","c"}, MGF_PLANE {"n","d"}, MGF_RECTANGLE {"c","u":[V,V],"e":[f,f]} (v = c, u0,
+ * u1, e0, e1), MGF_RAY {"p","d"}, MGF_SEGMENT {"a","b"}, MGF_AABB {"c","r"}; V = {"x","y","z"}.  moving != NULL writes / reads
+ * Moving<T>(T, Vector3<f32>), a tuple struct, i.e. [T, V] (geom.rs:356-357; `Component` itself derives no Serialize).
+ * Reading follows serde's struct rules: fields in any order, unknown fields ignored, missing or duplicate field = error. */
+MGF_API mgf_status mgf_geom_to_json(const mgf_shape* s, const mgf_vec3* moving, char* buf, int64_t cap, int64_t* len);
+MGF_API mgf_status mgf_geom_from_json(int32_t kind, const char* json, int64_t len, mgf_shape* out, mgf_vec3* moving);
 /* ---- Compound (compound.rs:230-352): a static aggregate of spheres and capsules with a pose and an internal BVH ----
  * mgf_compound_new = Compound::new (components inserted into the BVH in order); set_pose writes the pub fields
  * disp / rot (rot is assumed normalised, as in the reference); contacts_many = Contacts<RHS> for Compound with

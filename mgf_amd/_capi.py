@@ -23,7 +23,7 @@ class MgfError(RuntimeError):
 _STATUS_NAMES = {0: "OK", 1: "EMPTY", 2: "NOT_OCCUPIED", 3: "NOT_LEAF", 4: "STATIC_REF", 5: "SINGULAR", 6: "INVALID",
                  7: "CAPACITY", 8: "HIP", 9: "OOM"}
 OK, ERR_EMPTY, ERR_NOT_OCCUPIED, ERR_NOT_LEAF, ERR_STATIC_REF, ERR_SINGULAR, ERR_INVALID, ERR_CAPACITY, ERR_HIP, ERR_OOM = range(10)
-SPHERE, CAPSULE, TRIANGLE, RECTANGLE, PLANE = 0, 1, 2, 3, 4
+SPHERE, CAPSULE, TRIANGLE, RECTANGLE, PLANE, RAY, SEGMENT, AABB = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class Vec3(C.Structure):
@@ -126,10 +126,14 @@ SYMBOLS = [
     "mgf_world_select_tile", "mgf_world_export_migrants", "mgf_world_remove_bodies", "mgf_world_import_migrants",
     "mgf_world_set_tags", "mgf_world_read_tags",
     "mgf_world_solve_enqueue", "mgf_world_finish", "mgf_world_counter",
+    "mgf_constraints_new", "mgf_solver_new", "mgf_solver_free", "mgf_solver_add_constraint", "mgf_solver_add_constraints",
+    "mgf_solver_len", "mgf_solver_clear", "mgf_solver_read_constraints", "mgf_solver_solve", "mgf_world_clone",
+    "mgf_geom_to_json", "mgf_geom_from_json",
 ]
 
 _lib = None
 HIT_FN = C.CFUNCTYPE(None, C.POINTER(C.c_uint64), C.c_void_p)
+RAY_FN = C.CFUNCTYPE(None, C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p)
 
 
 def load_library():
@@ -176,7 +180,7 @@ def load_library():
         "mgf_bvh_bounds": (i32, [vp, u64, P(Aabb)]),
         "mgf_bvh_query": (i32, [vp, P(Aabb), HIT_FN, vp]),
         "mgf_bvh_query_many": (i32, [vp, vp, i64, vp, vp, i64, P(i64)]),
-        "mgf_bvh_raytrace": (i32, [vp, vp, vp, vp]),
+        "mgf_bvh_raytrace": (i32, [vp, vp, RAY_FN, vp]),
         "mgf_bvh_raytrace_many": (i32, [vp, vp, i64, vp, vp, vp, i64, P(i64)]),
         "mgf_intersections_batch": (i32, [vp, i64, vp, vp, vp, vp, vp]),
         "mgf_compound_new": (i32, [vp, vp, i64, P(vp)]),
@@ -229,6 +233,18 @@ def load_library():
         "mgf_world_solve_enqueue": (i32, [vp, i32]),
         "mgf_world_finish": (i32, [vp, P(StepStats)]),
         "mgf_world_counter": (i32, [vp, C.c_char_p, P(i64)]),
+        "mgf_constraints_new": (i32, [vp, vp, vp, vp, i64, f32, vp, i64, P(i64)]),
+        "mgf_solver_new": (i32, [P(vp)]),
+        "mgf_solver_free": (None, [vp]),
+        "mgf_solver_add_constraint": (i32, [vp, vp]),
+        "mgf_solver_add_constraints": (i32, [vp, vp, i64]),
+        "mgf_solver_len": (i64, [vp]),
+        "mgf_solver_clear": (i32, [vp]),
+        "mgf_solver_read_constraints": (i32, [vp, vp, i64, P(i64)]),
+        "mgf_solver_solve": (i32, [vp, vp, i32, P(StepStats)]),
+        "mgf_world_clone": (i32, [vp, P(vp)]),
+        "mgf_geom_to_json": (i32, [P(Shape), P(Vec3), vp, i64, P(i64)]),
+        "mgf_geom_from_json": (i32, [i32, C.c_char_p, i64, P(Shape), P(Vec3)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -308,11 +324,50 @@ def _shape(d):
         s.kind, vals = PLANE, list(d["n"]) + [d["d"]]
     elif k == "rectangle":
         s.kind, vals = RECTANGLE, list(d["c"]) + list(d["u0"]) + list(d["u1"]) + list(d["e"])
+    elif k == "ray":
+        s.kind, vals = RAY, list(d["p"]) + list(d["d"])
+    elif k == "segment":
+        s.kind, vals = SEGMENT, list(d["a"]) + list(d["b"])
+    elif k == "aabb":
+        s.kind, vals = AABB, list(d["c"]) + list(d["r"])
     else:
         raise ValueError(k)
     for i, x in enumerate(vals):
         s.v[i] = float(x)
     return s
+
+
+_GEOM_FIELDS = {"sphere": (SPHERE, [("c", 3), ("r", 1)]), "capsule": (CAPSULE, [("a", 3), ("d", 3), ("r", 1)]),
+                "triangle": (TRIANGLE, [("a", 3), ("b", 3), ("c", 3)]), "plane": (PLANE, [("n", 3), ("d", 1)]),
+                "rectangle": (RECTANGLE, [("c", 3), ("u0", 3), ("u1", 3), ("e", 2)]), "ray": (RAY, [("p", 3), ("d", 3)]),
+                "segment": (SEGMENT, [("a", 3), ("b", 3)]), "aabb": (AABB, [("c", 3), ("r", 3)])}
+
+
+def geom_to_json(shape, moving=None):
+    """serde_json text of a geom.rs struct given as a shape dict (kind + fields); moving = the Vector3 of Moving<T>."""
+    n = C.c_int64()
+    sh = _shape(shape)
+    mv = C.byref(_v3(moving)) if moving is not None else None
+    st = load_library().mgf_geom_to_json(C.byref(sh), mv, None, 0, C.byref(n))
+    if st != ERR_CAPACITY:
+        _check(st)
+    buf = C.create_string_buffer(n.value + 1)
+    _check(load_library().mgf_geom_to_json(C.byref(sh), mv, buf, n.value + 1, C.byref(n)))
+    return buf.value.decode()
+
+
+def geom_from_json(kind, text, moving=False):
+    """the shape dict of `kind` ("sphere", "capsule", ...) read from serde_json text; moving=True reads Moving<T> and returns
+    (shape, velocity)."""
+    code, fields = _GEOM_FIELDS[kind]
+    raw = text.encode()
+    out, vel = Shape(), Vec3()
+    _check(load_library().mgf_geom_from_json(code, raw, len(raw), C.byref(out), C.byref(vel) if moving else None))
+    d, at = dict(kind=kind), 0
+    for name, w in fields:
+        d[name] = out.v[at] if w == 1 else [out.v[at + i] for i in range(w)]
+        at += w
+    return (d, vel.tup()) if moving else d
 
 
 def _contact_dict(c):
@@ -645,6 +700,20 @@ class Bvh:
             break
         return off.astype(np.int64), vals[:total.value].astype(np.int64)
 
+    def raytrace(self, p, d, dt=float("inf")):
+        """BVH::raytrace (bvh.rs:345-369) for one particle through the callback form: [(value, point, t)] in the
+        reference's visiting order."""
+        part = np.zeros(1, PARTICLE_DTYPE)
+        part["p"], part["d"], part["dt"] = p, d, dt
+        hits = []
+
+        def on_hit(pv, pi, _u):
+            rec = np.ctypeslib.as_array(C.cast(pi, C.POINTER(C.c_float)), (4,))
+            hits.append((int(pv[0]), (float(rec[0]), float(rec[1]), float(rec[2])), float(rec[3])))
+        cb = RAY_FN(on_hit)
+        _check(load_library().mgf_bvh_raytrace(self._h, part.ctypes.data, cb, None))
+        return hits
+
     def raytrace_many(self, parts):
         """BVH::raytrace for each particle: (offsets, values, intersections with the leaf bounds)."""
         parts = np.ascontiguousarray(parts, PARTICLE_DTYPE)
@@ -666,6 +735,44 @@ class Bvh:
 
     def dump(self):
         return _bvh_dump(self._h)
+
+
+class Solver:
+    """Solver<ContactConstraint> (solver.rs:53-79): an insertion-ordered constraint list that is solved on a World's
+    RigidBodyVec; the constraints keep their accumulated impulses between solve calls."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(load_library().mgf_solver_new(C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load_library().mgf_solver_free(self._h)
+            self._h = None
+
+    def add_constraint(self, row):
+        row = np.ascontiguousarray(row, CONSTRAINT_DTYPE).reshape(1)
+        _check(load_library().mgf_solver_add_constraint(self._h, row.ctypes.data))
+
+    def add_constraints(self, rows):
+        rows = np.ascontiguousarray(rows, CONSTRAINT_DTYPE)
+        _check(load_library().mgf_solver_add_constraints(self._h, rows.ctypes.data, len(rows)))
+
+    def __len__(self):
+        return load_library().mgf_solver_len(self._h)
+
+    def clear(self):
+        _check(load_library().mgf_solver_clear(self._h))
+
+    def constraints(self):
+        n = len(self)
+        out = np.zeros(max(n, 1), CONSTRAINT_DTYPE)
+        _check(load_library().mgf_solver_read_constraints(self._h, out.ctypes.data, len(out), None))
+        return out[:n]
+
+    def solve(self, world, iters):
+        _check(load_library().mgf_solver_solve(self._h, world._h, int(iters), C.byref(world.stats)))
+        return world.stats
 
 
 class World:
@@ -811,6 +918,31 @@ class World:
     def set_constraints(self, cons):
         cons = np.ascontiguousarray(cons, CONSTRAINT_DTYPE)
         _check(load_library().mgf_world_set_constraints(self._h, cons.ctypes.data, len(cons)))
+
+    def clone(self):
+        """RigidBodyVec: Clone (physics.rs:140) with the world around it: an independent world that steps identically."""
+        w = World.__new__(World)
+        w._ctx, w._h, w.stats = self._ctx, C.c_void_p(), StepStats()
+        _check(load_library().mgf_world_clone(self._h, C.byref(w._h)))
+        self._ctx._adopt(w)
+        return w
+
+    def constraints_new(self, refs_a, refs_b, manifolds, dt):
+        """ContactConstraint::new (solver.rs:101-191) for caller-built manifolds: refs are body indices (obj_b: an index, or
+        (center, friction) for RigidBodyRef::Static); manifolds a MANIFOLD_DTYPE array.  -> flattened CONSTRAINT_DTYPE rows."""
+        manifolds = np.ascontiguousarray(manifolds, MANIFOLD_DTYPE)
+        n = len(manifolds)
+        ra = (BodyRef * max(n, 1))()
+        rb = (BodyRef * max(n, 1))()
+        for i in range(n):
+            a, b = refs_a[i], refs_b[i]
+            ra[i] = BodyRef(0, int(a), Vec3(), 0.0) if not isinstance(a, tuple) else BodyRef(1, 0, _v3(a[0]), float(a[1]))
+            rb[i] = BodyRef(0, int(b), Vec3(), 0.0) if not isinstance(b, tuple) else BodyRef(1, 0, _v3(b[0]), float(b[1]))
+        cap = int(manifolds["n_contacts"].sum()) if n else 0
+        out = np.zeros(max(cap, 1), CONSTRAINT_DTYPE)
+        cnt = C.c_int64()
+        _check(load_library().mgf_constraints_new(self._h, ra, rb, manifolds.ctypes.data, n, float(dt), out.ctypes.data, cap, C.byref(cnt)))
+        return out[:cnt.value]
 
     # ---- tiling (device pointers of the caller) ----
     def begin_tick(self, dt):

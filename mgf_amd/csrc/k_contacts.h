@@ -279,15 +279,15 @@ __device__ __forceinline__ void st3(float* p, V3 v) { p[0] = v.x; p[1] = v.y; p[
 __device__ __forceinline__ V3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
 // ContactConstraint::new solver.rs:101-191 for one contact.
-__device__ __forceinline__ CRec make_constraint(uint32_t ia, uint32_t ib, const BodyDyn& A, V3 xa, float rest_a, float fric_a,
-                                                const BodyDyn& Bd, V3 xb, float rest_b, float fric_b, V3 normal, V3 ra, V3 rb,
-                                                float dt, float baumgarte, float slop) {
+// (the manifold's tangent_vector is the caller's: Manifold::from computes it with compute_basis, a caller-built Manifold
+// may hold anything - ContactConstraint::new only reads the fields)
+__device__ __forceinline__ CRec make_constraint_basis(uint32_t ia, uint32_t ib, const BodyDyn& A, V3 xa, float rest_a, float fric_a,
+                                                      const BodyDyn& Bd, V3 xb, float rest_b, float fric_b, V3 normal, V3 t0, V3 t1,
+                                                      V3 ra, V3 rb, float dt, float baumgarte, float slop) {
   CRec c;
   c.a = ia; c.b = ib;
   float restitution = fmax_rs(rest_a, rest_b);
   c.friction = __builtin_sqrtf(fric_a * fric_b);
-  V3 t0, t1;
-  compute_basis(normal, &t0, &t1);  // manifold.rs:125,144
   V3 ca = ra + xa, cb = rb + xb;
   V3 ra_cn = cross(ra, normal), rb_cn = cross(rb, normal);
   float pen = dot(cb - ca, normal);
@@ -305,6 +305,13 @@ __device__ __forceinline__ CRec make_constraint(uint32_t ia, uint32_t ib, const 
   c.pad3[0] = c.pad3[1] = c.pad3[2] = c.pad3[3] = 0;
   st3(c.n, normal); st3(c.t0, t0); st3(c.t1, t1); st3(c.ra, ra); st3(c.rb, rb);
   return c;
+}
+__device__ __forceinline__ CRec make_constraint(uint32_t ia, uint32_t ib, const BodyDyn& A, V3 xa, float rest_a, float fric_a,
+                                                const BodyDyn& Bd, V3 xb, float rest_b, float fric_b, V3 normal, V3 ra, V3 rb,
+                                                float dt, float baumgarte, float slop) {
+  V3 t0, t1;
+  compute_basis(normal, &t0, &t1);  // manifold.rs:125,144
+  return make_constraint_basis(ia, ib, A, xa, rest_a, fric_a, Bd, xb, rest_b, fric_b, normal, t0, t1, ra, rb, dt, baumgarte, slop);
 }
 
 __device__ __forceinline__ void store_crec(CRec* dst, const CRec& c) {
@@ -395,6 +402,29 @@ __global__ __launch_bounds__(kBlock) void k_setup_terrain(Bodies B, TerrainDev M
     store_crec(&cons[base[i] + t_pre[p] + k], r);
     ab[base[i] + t_pre[p] + k] = make_uint2(i, kNone);
   }
+}
+
+// ContactConstraint::new (solver.rs:101-191) for caller-built manifolds on the resident RigidBodyVec (mgf_constraints_new):
+// one thread per (manifold, contact) row.  obj_a is Dynamic; obj_b Dynamic or Static{center, friction} (b == kNone).
+struct ManifoldRow { uint32_t a, b; float cb[3], fric_b; float n[3], t0[3], t1[3], la[3], lb[3]; };
+__global__ __launch_bounds__(kBlock) void k_constraints_new(Bodies B, const ManifoldRow* rows, uint32_t m, float dt, float baumgarte, float slop,
+                                                            CRec* out) {
+  uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+  if (r >= m) return;
+  const ManifoldRow R = rows[r];
+  BodyDyn A = load_dyn(B.srec, R.a);
+  float4 ea = B.einfo[R.a];
+  BodyDyn Bd = static_dyn();
+  V3 xb = ld3(R.cb);
+  float rest_b = 0.0f, fric_b = R.fric_b;  // physics.rs:289-302
+  if (R.b != kNone) {
+    Bd = load_dyn(B.srec, R.b);
+    float4 eb = B.einfo[R.b];
+    xb = xyz(eb); rest_b = eb.w; fric_b = B.delta[R.b].w;
+  }
+  CRec c = make_constraint_basis(R.a, R.b, A, xyz(ea), ea.w, B.delta[R.a].w, Bd, xb, rest_b, fric_b, ld3(R.n), ld3(R.t0), ld3(R.t1),
+                                 ld3(R.la), ld3(R.lb), dt, baumgarte, slop);
+  store_crec(&out[r], c);
 }
 
 }  // namespace mgf

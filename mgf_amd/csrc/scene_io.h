@@ -201,13 +201,43 @@ inline bool read_bvh(const Val& v, HostBvh* t, std::string* err) {
   if (occupied != len) return bad("Pool: len does not match the occupied entries");
   if (len && (root >= n || nodes[root].state != HostBvh::kUsed)) return bad("BVH: root is not an occupied entry");
   if (has_free && (free_head >= n || nodes[free_head].state == HostBvh::kUsed)) return bad("Pool: free_list points at an occupied entry");
+  // a tree: every occupied entry but the root is the child of exactly one parent, the root of none (no cycle can then
+  // be reached from the root: a walk down never meets an entry twice)
+  std::vector<uint8_t> refs(n, 0);
   for (uint64_t i = 0; i < n; ++i) {
     const HostBvh::Node& nd = nodes[i];
     if (nd.state != HostBvh::kUsed) continue;
     if (nd.parent >= n && i != root) return bad("BVHNode: parent out of range");
-    if (!nd.leaf)
-      for (int k = 0; k < 2; ++k)
+    if (!nd.leaf) {
+      if (nd.kid[0] == nd.kid[1]) return bad("BVHNode: both children are the same entry");
+      for (int k = 0; k < 2; ++k) {
         if (nd.kid[k] >= n || nodes[nd.kid[k]].state != HostBvh::kUsed || nodes[nd.kid[k]].parent != i) return bad("BVHNode: child link does not match the child's parent");
+        if (nd.kid[k] == root) return bad("BVHNode: the root is listed as a child");
+        if (++refs[nd.kid[k]] > 1) return bad("BVHNode: an entry is the child of two parents");
+      }
+    }
+  }
+  for (uint64_t i = 0; i < n; ++i)
+    if (nodes[i].state == HostBvh::kUsed && i != root && refs[i] != 1) return bad("BVHNode: an occupied entry has no parent entry");
+  if (len) {  // ... and the walk from the root meets all of them (a detached ring of entries would pass the checks above)
+    std::vector<uint64_t> stack(1, root);
+    uint64_t seen = 0;
+    while (!stack.empty()) {
+      const uint64_t at = stack.back(); stack.pop_back();
+      if (++seen > len) break;
+      if (!nodes[at].leaf) { stack.push_back(nodes[at].kid[0]); stack.push_back(nodes[at].kid[1]); }
+    }
+    if (seen != len) return bad("BVH: the entries do not form one tree under the root");
+  }
+  // the free list visits each free entry at most once and ends at a FreeListEnd
+  if (has_free) {
+    uint64_t at = free_head, steps = 0;
+    for (;;) {
+      if (at >= n || nodes[at].state == HostBvh::kUsed) return bad("Pool: the free list runs into an occupied entry");
+      if (nodes[at].state == HostBvh::kFreeEnd) break;
+      if (++steps > n) return bad("Pool: the free list has a cycle");
+      at = nodes[at].next_free;
+    }
   }
   t->restore(std::move(nodes), root, len, has_free, free_head);
   return true;

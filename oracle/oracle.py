@@ -196,6 +196,12 @@ def lib():
         L.mgfo_world_terrain_bvh.restype = C.c_void_p
         L.mgfo_world_bvh.argtypes = [C.c_void_p]
         L.mgfo_world_bvh.restype = C.c_void_p
+        L.mgfo_world_integrate.argtypes = [C.c_void_p, C.c_float]
+        L.mgfo_world_complete_motion.argtypes = [C.c_void_p]
+        L.mgfo_world_get.argtypes = [C.c_void_p, C.c_int32, C.c_int64, P(Vec3), C.c_float, C.c_void_p]
+        L.mgfo_constraint_new.argtypes = [C.c_void_p, C.c_int64, C.c_int64, P(Vec3), C.c_float, P(Vec3), C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        L.mgfo_solver_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
         _lib = L
     return _lib
 
@@ -573,6 +579,44 @@ class World:
 
     def set_velocity(self, i, lin, ang):
         lib().mgfo_world_set_velocity(self.h, i, C.byref(vec3(lin)), C.byref(vec3(ang)))
+
+    # ---- the RigidBodyVec / ConstrainedSet / ContactConstraint / Solver surface on its own ----
+    def integrate(self, dt):
+        """RigidBodyVec::integrate physics.rs:222-253 alone"""
+        lib().mgfo_world_integrate(self.h, dt)
+
+    def complete_motion(self):
+        """RigidBodyVec::complete_motion physics.rs:262-269 alone"""
+        lib().mgfo_world_complete_motion(self.h)
+
+    def get(self, index=None, static=None):
+        """ConstrainedSet::get physics.rs:273-304 -> dict(linear, angular, x, restitution, friction, inv_mass, inv_moment[9])"""
+        out = np.zeros(21, np.float32)
+        if static is None:
+            lib().mgfo_world_get(self.h, 0, int(index), C.byref(vec3((0, 0, 0))), 0.0, out.ctypes.data)
+        else:
+            lib().mgfo_world_get(self.h, 1, 0, C.byref(vec3(static[0])), float(static[1]), out.ctypes.data)
+        return dict(linear=out[0:3].copy(), angular=out[3:6].copy(), x=out[6:9].copy(), restitution=out[9], friction=out[10],
+                    inv_mass=out[11], inv_moment=out[12:21].copy())
+
+    def constraint_new(self, a, b, normal, tangents, local_a, local_b, dt, static_b=None):
+        """ContactConstraint::new solver.rs:101-191 for one caller-built manifold -> m flattened rows (CONSTRAINT_DTYPE).
+        b = None with static_b = (center, friction) for RigidBodyRef::Static."""
+        la = np.ascontiguousarray(local_a, np.float32).reshape(-1, 3)
+        lb = np.ascontiguousarray(local_b, np.float32).reshape(-1, 3)
+        tg = np.ascontiguousarray(tangents, np.float32).reshape(2, 3)
+        out = np.zeros(len(la), CONSTRAINT_DTYPE)
+        cb, fb = (static_b if static_b is not None else ((0, 0, 0), 0.0))
+        lib().mgfo_constraint_new(self.h, int(a), -1 if b is None else int(b), C.byref(vec3(cb)), float(fb), C.byref(vec3(normal)),
+                                  tg.ctypes.data, len(la), la.ctypes.data, lb.ctypes.data, dt, out.ctypes.data)
+        return out
+
+    def solver_solve(self, rows, iters):
+        """Solver::new, add_constraint for every row in order, solve(iters) solver.rs:59-78 on this world's bodies;
+        returns the rows with their normal_impulse after the call."""
+        rows = np.ascontiguousarray(rows, CONSTRAINT_DTYPE).copy()
+        lib().mgfo_solver_solve(self.h, rows.ctypes.data, len(rows), int(iters))
+        return rows
 
     def terrain_contacts(self, i, cap=16):
         out = (LocalContact * cap)()

@@ -511,4 +511,67 @@ int64_t mgfo_world_terrain_contacts(void* wp, int64_t i, o_local_contact* out, i
 void* mgfo_world_terrain_bvh(void* wp) { return &((World*)wp)->terrain.bvh; }
 void* mgfo_world_bvh(void* wp) { return &((World*)wp)->bvh; }
 
+// ---- the RigidBodyVec / ConstrainedSet / ContactConstraint / Solver surface on its own (boundary tests) ----
+// RigidBodyVec::integrate physics.rs:222 and ::complete_motion :262, each alone
+void mgfo_world_integrate(void* wp, float dt) { ((World*)wp)->bodies.integrate(dt); }
+void mgfo_world_complete_motion(void* wp) { ((World*)wp)->bodies.complete_motion(); }
+// ConstrainedSet::get physics.rs:273-304: out = linear3 angular3 | x3 restitution friction inv_mass | inv_moment9 (column-major)
+void mgfo_world_get(void* wp, int32_t is_static, int64_t index, const o_vec3* center, float friction, float* out) {
+  const RigidBodyVec& b = ((World*)wp)->bodies;
+  RigidBodyRef r = is_static ? static_ref(V(*center), friction) : dynamic_ref((size_t)index);
+  Velocity vel; RigidBodyInfo info;
+  b.get(r, &vel, &info);
+  out[0] = vel.linear.x; out[1] = vel.linear.y; out[2] = vel.linear.z; out[3] = vel.angular.x; out[4] = vel.angular.y; out[5] = vel.angular.z;
+  out[6] = info.x.x; out[7] = info.x.y; out[8] = info.x.z; out[9] = info.restitution; out[10] = info.friction; out[11] = info.inv_mass;
+  for (int c = 0; c < 3; ++c) { out[12 + 3 * c] = info.inv_moment.c[c].x; out[13 + 3 * c] = info.inv_moment.c[c].y; out[14 + 3 * c] = info.inv_moment.c[c].z; }
+}
+// ContactConstraint::new solver.rs:101-191 for ONE caller-built Manifold (normal, tangent_vector[2], m contact pairs) on the
+// world's RigidBodyVec; obj_a Dynamic(index_a), obj_b Dynamic(index_b) or Static{center_b, friction_b} (index_b < 0).
+// Writes m flattened rows (as mgfo_world_get_constraints does).
+void mgfo_constraint_new(void* wp, int64_t index_a, int64_t index_b, const o_vec3* center_b, float friction_b, const o_vec3* normal,
+                         const o_vec3* tangents /* 2 */, int64_t m, const o_vec3* local_a, const o_vec3* local_b, float dt,
+                         o_constraint* out) {
+  const RigidBodyVec& b = ((World*)wp)->bodies;
+  Manifold mf;
+  mf.time = 0.0f; mf.normal = V(*normal); mf.tangent_vector[0] = V(tangents[0]); mf.tangent_vector[1] = V(tangents[1]);
+  for (int64_t k = 0; k < m; ++k) mf.contacts.push_back(ContactPair{V(local_a[k]), V(local_b[k])});
+  RigidBodyRef ra = dynamic_ref((size_t)index_a);
+  RigidBodyRef rb = index_b < 0 ? static_ref(V(*center_b), friction_b) : dynamic_ref((size_t)index_b);
+  ContactConstraint c = ContactConstraint::make(b, ra, rb, mf, dt, ((World*)wp)->params);
+  for (size_t k = 0; k < c.states.size(); ++k) {
+    o_constraint o;
+    std::memset(&o, 0, sizeof(o));
+    o.a = (int32_t)index_a; o.b = index_b < 0 ? -1 : (int32_t)index_b; o.n_contacts = 1;
+    o.normal = O(c.manifold.normal); o.t0 = O(c.manifold.tangent_vector[0]); o.t1 = O(c.manifold.tangent_vector[1]);
+    o.friction = c.friction; o.ra = O(c.manifold.contacts[k].a); o.rb = O(c.manifold.contacts[k].b);
+    const ContactState& st = c.states[k];
+    o.bias = st.bias; o.normal_mass = st.normal_mass; o.tangent_mass0 = st.tangent_mass[0]; o.tangent_mass1 = st.tangent_mass[1];
+    o.normal_impulse = st.normal_impulse;
+    out[k] = o;
+  }
+}
+// Solver::new + add_constraint x n + solve(iters) solver.rs:59-78 on the world's RigidBodyVec, from flattened single-contact
+// rows (a Static obj_b's velocity and inverse masses are zero whatever its centre, physics.rs:289-302, so the rows need not
+// carry it); normal_impulse is read from and written back to the rows (the Solver owns its constraints' state).
+void mgfo_solver_solve(void* wp, o_constraint* rows, int64_t n, int64_t iters) {
+  RigidBodyVec& b = ((World*)wp)->bodies;
+  Solver s;
+  for (int64_t i = 0; i < n; ++i) {
+    const o_constraint& o = rows[i];
+    ContactConstraint c;
+    c.obj_a = dynamic_ref((size_t)o.a);
+    c.obj_b = o.b < 0 ? static_ref(v3(0, 0, 0), 0.0f) : dynamic_ref((size_t)o.b);
+    c.manifold.time = 0.0f; c.manifold.normal = V(o.normal); c.manifold.tangent_vector[0] = V(o.t0); c.manifold.tangent_vector[1] = V(o.t1);
+    c.manifold.contacts.push_back(ContactPair{V(o.ra), V(o.rb)});
+    c.friction = o.friction;
+    ContactState st;
+    st.bias = o.bias; st.normal_mass = o.normal_mass; st.normal_impulse = o.normal_impulse;
+    st.tangent_mass[0] = o.tangent_mass0; st.tangent_mass[1] = o.tangent_mass1; st.tangent_impulse[0] = st.tangent_impulse[1] = 0.0f;
+    c.states.push_back(st);
+    s.add_constraint(std::move(c));
+  }
+  s.solve(b, (size_t)iters);
+  for (int64_t i = 0; i < n; ++i) rows[i].normal_impulse = s.constraints[(size_t)i].states[0].normal_impulse;
+}
+
 }  // extern "C"

@@ -1,0 +1,167 @@
+"""Entry points of include/mgf_hip.h that no other test reached ("exported but untested ABI"): the bulk and
+callback forms of the BVH queries, the single-shot LocalContacts calls, Mesh::push_vert / push_face one by one, the
+zero-copy device pointers and the ghost count.  Each against the oracle, bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import mgf_amd
+from mgf_amd import scenes
+from oracle import oracle as O
+from tests.util import bits_equal, oracle_world, values_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = mgf_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _trees(ctx, rng, n):
+    gb, ob = mgf_amd.Bvh(ctx), O.Bvh()
+    for i in range(n):
+        c, r = rng.uniform(-20, 20, 3).astype(np.float32), rng.uniform(0.2, 2.5, 3).astype(np.float32)
+        assert gb.insert(c, r, 1000 + i) == ob.insert(tuple(c), tuple(r), 1000 + i)
+    return gb, ob
+
+
+def test_bvh_query_many_equals_the_callback_form_and_the_oracle(ctx):
+    """BVH::query (bvh.rs:283-310): the bulk form lists every query's hits in the reference's DFS order."""
+    rng = np.random.default_rng(21)
+    gb, ob = _trees(ctx, rng, 300)
+    boxes = np.concatenate([rng.uniform(-20, 20, (200, 3)), rng.uniform(0.5, 6, (200, 3))], axis=1).astype(np.float32)
+    boxes[7, 3:] = 100.0  # everything
+    boxes[8, :3], boxes[8, 3:] = 500.0, 0.1  # nothing
+    off, vals = gb.query_many(boxes)
+    assert off[0] == 0 and off[-1] == len(vals) and len(off) == len(boxes) + 1
+    for k, bx in enumerate(boxes):
+        want = ob.query(tuple(bx[:3]), tuple(bx[3:]))
+        assert vals[off[k]:off[k + 1]].tolist() == want, f"query {k}"
+        if k % 25 == 0:
+            assert gb.query(bx[:3], bx[3:]) == want
+    assert off[9] - off[8] == 0 and off[8] - off[7] == 300
+
+
+def test_bvh_raytrace_callback_form(ctx):
+    """BVH::raytrace (bvh.rs:345-369) one particle at a time through the callback, as the reference's signature has it."""
+    rng = np.random.default_rng(22)
+    gb, ob = _trees(ctx, rng, 200)
+    n_hit = 0
+    for k in range(120):
+        p, d = rng.uniform(-25, 25, 3).astype(np.float32), rng.normal(size=3).astype(np.float32)
+        dt = float("inf") if k % 2 == 0 else 1.0
+        if dt == 1.0:
+            d *= np.float32(30.0)
+        got, want = gb.raytrace(p, d, dt), ob.raytrace(tuple(p), tuple(d), dt)
+        assert [g[0] for g in got] == [w[0] for w in want]
+        for g, w in zip(got, want):
+            assert values_equal(g[1], w[1]) and values_equal([g[2]], [w[2]])
+        n_hit += len(want)
+    assert n_hit > 20
+
+
+def test_single_shot_local_contacts_pair_and_mesh(ctx):
+    """LocalContacts<Moving<Component>> for Moving<Component> (compound.rs:192-207) and LocalContacts<Mesh>
+    (collision.rs:1490-1506 over mesh.rs:115-139) called once per pair, like world.rs:241,277 does."""
+    rng = np.random.default_rng(23)
+    n_hit = 0
+    for k in range(300):
+        ta, tb = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        pa, pb = rng.uniform(-1.5, 1.5, 3).astype(np.float32), rng.uniform(-1.5, 1.5, 3).astype(np.float32)
+        da = rng.uniform(-1, 1, 3).astype(np.float32) if ta else np.zeros(3, np.float32)
+        db = rng.uniform(-1, 1, 3).astype(np.float32) if tb else np.zeros(3, np.float32)
+        ra, rb = float(rng.uniform(0.3, 0.9)), float(rng.uniform(0.3, 0.9))
+        va, vb = rng.uniform(-1, 1, 3).astype(np.float32), rng.uniform(-1, 1, 3).astype(np.float32)
+        got = mgf_amd.local_contacts_pair(ctx, (ta, pa, da, ra, va), (tb, pb, db, rb, vb))
+        want = O.local_contacts_pair(O.component(ta, pa, da, ra), va, O.component(tb, pb, db, rb), vb)
+        assert len(got) == len(want), k
+        for g, w in zip(got, want):
+            for f in ("local_a", "local_b", "a", "b", "n"):
+                assert values_equal(g[f], w[f]), (k, f)
+            assert values_equal([g["t"]], [w["t"]])
+        n_hit += len(want)
+    assert n_hit > 30
+    # body against the terrain mesh: the oracle world's own terrain contacts for a few resting capsules
+    scene = scenes.capsule_field(6, 2, 6)
+    gw, ow = mgf_amd.World.from_scene(ctx, scene), oracle_world(scene)
+    dt = float(scene["dt"])
+    for _ in range(45):
+        gw.step(dt, 10)
+        ow.step(dt, 10)
+    t = scene["terrain"]
+    mesh = mgf_amd.Mesh(ctx)
+    mesh.build(t["verts"], t["faces"])
+    mesh.set_pos(t["pos"])
+    col = gw.colliders()
+    n_hit = 0
+    for i in range(len(col)):
+        c = col[i]
+        got = mgf_amd.local_contacts_mesh(ctx, (int(c["tag"]), c["p"], c["d"], float(c["r"]), c["delta"]), mesh)
+        want = ow.terrain_contacts(i)
+        assert len(got) == len(want), i
+        for g, w in zip(got, want):
+            for f in ("local_a", "local_b", "a", "b", "n"):
+                assert values_equal(g[f], w[f]), (i, f)
+        n_hit += len(want)
+    assert n_hit > 10
+
+
+def test_mesh_pushed_vertex_by_vertex_equals_the_bulk_build(ctx):
+    """Mesh::push_vert / push_face (mesh.rs:58-73): the face BVH grows by insert + balance per face, so the one-by-one
+    mesh and the bulk one serialise to the same tree, and a world steps identically on either."""
+    t = scenes.heightfield_terrain(6, 6, 12.0, 12.0, 0.2)
+    a, b = mgf_amd.Mesh(ctx), mgf_amd.Mesh(ctx)
+    a.build(t["verts"], t["faces"])
+    for k, v in enumerate(t["verts"]):
+        assert b.push_vert(v) == k
+    for k, f in enumerate(t["faces"]):
+        assert b.push_face(int(f[0]), int(f[1]), int(f[2])) == k
+    a.set_pos(t["pos"])
+    b.set_pos(t["pos"])
+    assert a.to_json() == b.to_json()
+
+
+def test_device_pointers_and_ghost_len(ctx):
+    """mgf_world_device_ptr hands out the resident arrays (x, q, solver records, delta) for zero-copy exchange; what is read
+    through them is the state the ordinary read-back returns.  mgf_world_ghost_len counts the tick's imported ghosts."""
+    import torch
+    scene = scenes.sphere_pile(5, 5, 5)
+    w = mgf_amd.World.from_scene(ctx, scene)
+    for _ in range(5):
+        w.step(float(scene["dt"]), 10)
+    st, n = w.state(), len(w)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    for name, per in (("x", 4), ("q", 4), ("solver_rec", 16), ("delta", 4)):
+        p, nbytes = w.device_ptr(name)
+        assert p and nbytes == 4 * per * n
+        host = np.zeros((n, per), np.float32)
+        assert hip.hipMemcpy(host.ctypes.data, C.c_void_p(p), nbytes, 2) == 0  # hipMemcpyDeviceToHost
+        if name == "x":
+            assert bits_equal(host[:, :3], st["x"])
+        elif name == "q":
+            assert bits_equal(host, st["q"])
+        elif name == "delta":
+            assert bits_equal(host[:, :3], st["delta"])
+        else:
+            assert bits_equal(host[:, :3], st["v"]) and bits_equal(host[:, 3:6], st["omega"])
+    with pytest.raises(mgf_amd.MgfError):
+        w.device_ptr("nonsense")
+    assert w.ghost_len() == 0
+    # ghosts: export three bodies of a second world and import them here
+    w2 = mgf_amd.World.from_scene(ctx, scenes.sphere_pile(4, 4, 4))
+    w2.begin_tick(float(scene["dt"]))
+    ids = torch.tensor([1, 5, 9], dtype=torch.int32, device="cuda")
+    recs = torch.zeros((3, 56), dtype=torch.float32, device="cuda")
+    w2.export_bodies(ids.data_ptr(), 3, recs.data_ptr())
+    w.begin_tick(float(scene["dt"]))
+    w.import_ghosts(recs.data_ptr(), 3)
+    assert w.ghost_len() == 3 and len(w) == n
+    w.collide(float(scene["dt"]))
+    w.solve_enqueue(2)
+    w.finish()
+    torch.cuda.synchronize()
