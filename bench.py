@@ -127,7 +127,7 @@ def main():
     if rank == 0 and kms > 0 and launches > 0:
         achieved = units * SOLVE_BYTES_PER_UNIT / (kms * 1e-3) / 1e9
         mode = args.solver_mode if args.solver_mode is not None else 5
-        kname = {5: "k_solve_flow5 (ContactConstraint::solve, block-local persistent dataflow launch", 1: "k_solve_flow (ContactConstraint::solve, persistent dataflow launch",
+        kname = {6: "k_solve_flow6 (ContactConstraint::solve, block-local persistent dataflow launch with message channels", 5: "k_solve_flow5 (ContactConstraint::solve, block-local persistent dataflow launch", 1: "k_solve_flow (ContactConstraint::solve, persistent dataflow launch",
                  4: "k_solve_flowk (ContactConstraint::solve, persistent dataflow launch", 0: "k_solve (ContactConstraint::solve, one launch per dependency frontier"}[mode]
         roofline = {"bound": "hbm", "kernel": kname + ": " + ("all iterations of a tick" if world_size == 1 else f"{refresh_every} iteration(s) between ghost refreshes") + ")",
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

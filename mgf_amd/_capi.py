@@ -9,7 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "libmgf_hip.so")
+    # (MGF_AMD_LIB: a differently built libmgf_hip.so for an A/B experiment; never a different implementation)
+    return os.environ.get("MGF_AMD_LIB") or os.path.join(_HERE, "libmgf_hip.so")
 
 
 class MgfError(RuntimeError):

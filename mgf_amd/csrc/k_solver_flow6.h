@@ -1,0 +1,559 @@
+// Block-local dataflow solver with message channels (solver mode 6).  (Part of the kernel set described in kernels.h.)
+#pragma once
+#include "k_solver_flow.h"
+
+namespace mgf {
+
+// ------------------------------------------------------------------------------------------
+// Same dependency graph, same arrival-counter protocol and the same spatial blocks as k_solve_flow5 (bodies in cell order,
+// `nb` per block, one 512-thread workgroup per block, one block per CU, a constraint belongs to the block of its body a) -
+// but NO body record is exchanged through global memory while the solve runs:
+//   * every body a block's constraints touch has a slot in that block's LDS: its own `nb` bodies and the FOREIGN bodies its
+//     constraints meet as `b` (velocity only, 32 B; the constant inverse mass / inertia come from the RigidBodyVec by plain
+//     cached loads that travel beside the constraint record's);
+//   * every constraint's arrival counter is in LDS, and every node runs LDS-to-LDS (one class, one ready queue);
+//   * a dependency edge that crosses a block face is a 48-byte MESSAGE: the producer writes the body's new velocity, the
+//     successor's slot and a tag with three write-through 16-byte stores into a FIFO channel in global memory (one channel
+//     per ordered pair of neighbouring blocks, position taken from an LDS counter) and goes on - no store acknowledgement, no
+//     separate flag (MI355X guide, price list "handoff-1to1" vs "handoff-flag"); the consumer block's polling wave reads
+//     the next few positions of each of its incoming channels, and when all three granules of a message carry this launch's
+//     tag it copies the velocity into the block's LDS slot of that body and counts the arrival like a local one.
+// A body's velocity therefore travels along its chain of constraints: LDS -> (message) -> LDS.  The constraint that ends a
+// body's chain in the last iteration writes the result to the RigidBodyVec if the body is foreign to its block; every block
+// writes back its own bodies except those ("skipwb").
+// Deadlock-free like k_solve_flow5: every block is resident, every ready node is eventually taken, every message is
+// eventually seen.  Bit-identical to the sequential order: any topological order of the graph is.
+// ------------------------------------------------------------------------------------------
+#ifndef MGF_F6_THREADS
+#define MGF_F6_THREADS 512
+#endif
+constexpr int kF6Threads = MGF_F6_THREADS;
+constexpr uint32_t kF6Chan = 64;                       // neighbour blocks per block, each direction (hash slots)
+constexpr uint32_t kF6SlotBits = 13, kF6BodyBits = 11;
+constexpr uint32_t kF6MaxSlots = (1u << kF6SlotBits) - 1u;  // per block
+constexpr uint32_t kF6NoBody = (1u << kF6BodyBits) - 1u;    // b-ref of a constraint against a Static body
+constexpr uint32_t kF6Remote = 0x80000000u, kF6Wrap = 0x40000000u;
+constexpr uint32_t kF6RefFinalA = 1u << 22, kF6RefFinalB = 1u << 23;
+constexpr uint32_t kF6MsgWords = 3;                    // uint4 granules per message
+constexpr uint32_t kF6MaxIters = 64;                   // (ring positions are reduced with a 32-bit reciprocal)
+constexpr uint32_t kF6WlLen = 128;                     // work items (channel, position) a polling wave lists per sweep
+constexpr uint32_t kF6MaxPollers = 4;
+constexpr uint32_t kF6CntStride = 32;                  // words between per-block counters (same-line atomics serialise)
+
+// One 32-byte row per slot, written once per tick by k_flow6_table, copied into LDS by the solve kernel.
+struct F6Row {
+  uint32_t c;        // constraint id
+  uint32_t ref;      // a's LDS index (bits 0-10) | b's (bits 11-21, kF6NoBody = Static) | kF6RefFinalA/B
+  uint32_t succ0, succ1;  // local: slot | kF6Wrap;  remote: kF6Remote | kF6Wrap | out channel << 24 | LDS index of the body in the
+                          // successor's block << 13 | the successor's slot there
+  uint32_t state0;   // arrivals still missing in iteration 0 (bits 0-7); bits 8-15 count the iterations done
+  uint32_t pad[3];
+};
+static_assert(sizeof(F6Row) == 32, "F6Row is two 16-byte words");
+
+struct Flow6 {
+  const uint32_t* C_ptr;     // constraints of the list (0: the tick's collide phase failed a capacity check and is re-run: nothing to do)
+  const uint32_t* sidx;      // cell-ordered body ids
+  const uint32_t* brank;     // body -> position in cell order
+  const uint32_t* base;      // body -> id of its first own constraint (canonical order: a body's `a` constraints are contiguous)
+  uint32_t* slot_base;       // body -> slot of its first own constraint inside its block
+  uint32_t* bref;            // constraint -> LDS index of its body b in the constraint's block
+  uint8_t* skipwb;           // body -> 1: the chain's last constraint runs in another block, which writes the result
+  uint32_t* fcnt;            // per block (stride kF6CntStride): foreign bodies
+  uint32_t* fbody;           // [nblocks * fcap] their ids
+  uint32_t* nslots;          // per block (stride kF6CntStride): constraints
+  F6Row* table;              // [nblocks * rows]
+  uint32_t* in_key;          // [nblocks * kF6Chan] incoming channels of a block: source block + 1 (0 = empty hash slot)
+  uint32_t* in_cnt;          // ... and the edges they carry per iteration
+  uint32_t* out_key;         // outgoing: destination block + 1
+  uint32_t* out_val;         // ... and the hash slot of this block in the destination's in_key
+  uint32_t* chan_prefix;     // [nblocks * kF6Chan] exclusive prefix of in_cnt inside the block: a channel's first message (per iteration)
+  unsigned long long* tails; // [nblocks * kF6Chan] per incoming channel: (launch tag << 32) | positions handed out so far - a HINT that lets
+                             // the consumer read only what was sent (a message counts when its own granules carry the tag)
+  uint4* mbox;               // the channels: every block owns mbox_cap / nblocks messages; a channel starts chan_prefix * iters into
+                             // its consumer's region; kF6MsgWords granules per message
+  uint32_t mbox_cap;         // messages the buffer holds
+  uint32_t* fail;            // a limit was exceeded (1 foreign slots, 2 constraint slots, 4 channels, 8 channel buffer, 16 index width):
+                             // the stand-by k_solve_flow launch does the work; fail[1] = edges across block faces per iteration
+  uint32_t* max_slots;       // largest block / most foreign bodies of this tick (the host sizes the next tick's LDS split)
+  uint32_t* max_foreign;
+  uint32_t nb, nblocks, n;
+  uint32_t rows;             // table rows per block
+  uint32_t fcap, slot_cap;   // LDS split of this launch: foreign body slots, constraint slots
+  uint32_t poll_waves, poll_k;  // waves that poll the incoming channels; (unused)
+};
+__host__ __device__ constexpr uint32_t f6_lds_bytes(uint32_t nb, uint32_t fcap, uint32_t slot_cap, bool const_lds = false) {
+  return 32u * (nb + fcap) + (const_lds ? 40u * nb : 0u) + 20u * slot_cap + 2u * slot_cap + 4u * (16u + 8u * kF6Chan) + 4u * (2u * kF6WlLen + 16u) + 32u;
+}
+
+// ---- preparation, once per constraint list ------------------------------------------------------------------------------
+// Per block, one workgroup: (1) the slot of every own body's first constraint (prefix sum of the own-constraint counts in cell
+// order); (2) the block's FOREIGN bodies - bodies of other blocks that its constraints meet as `b` - numbered through an LDS
+// hash set (no global counters: 256 contended words cost 160 us here), and for every constraint of the block the LDS index
+// of its body b.
+constexpr uint32_t kF6Hash = 4096;
+constexpr uint32_t kF6PrepThreads = 1024;
+__global__ __launch_bounds__(kF6PrepThreads) void k_flow6_blocks(Flow6 F, ConsLinks K) {
+  constexpr uint32_t kBlock = kF6PrepThreads;  // (this kernel's own block size)
+  __shared__ uint32_t s_part[kBlock];
+  __shared__ uint32_t s_key[kF6Hash], s_val[kF6Hash];
+  __shared__ uint32_t s_cnt;
+  const uint32_t g = blockIdx.x, t = threadIdx.x;
+  if (*F.C_ptr == 0u) return;  // (an empty or failed list: the solve kernel does nothing either)
+  const uint32_t p_lo = g * F.nb, p_hi = min(F.n, p_lo + F.nb);
+  const uint32_t per = (F.nb + kBlock - 1) / kBlock;
+  const uint32_t lo = min(p_hi, p_lo + t * per), hi = min(p_hi, lo + per);
+  uint32_t sum = 0;
+  for (uint32_t p = lo; p < hi; ++p) { const uint32_t x = F.sidx[p]; sum += F.base[x + 1] - F.base[x]; }
+  s_part[t] = sum;
+  for (uint32_t e = t; e < kF6Hash; e += kBlock) { s_key[e] = 0u; s_val[e] = 0u; }
+  if (t == 0) s_cnt = 0u;
+  __syncthreads();
+  for (uint32_t off = 1; off < kBlock; off <<= 1) {  // inclusive scan of the partial sums
+    uint32_t v = t >= off ? s_part[t - off] : 0u;
+    __syncthreads();
+    s_part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = s_part[t] - sum;
+  for (uint32_t p = lo; p < hi; ++p) { const uint32_t x = F.sidx[p]; F.slot_base[x] = run; run += F.base[x + 1] - F.base[x]; }
+  if (t == kBlock - 1) {
+    const uint32_t total = s_part[t];
+    F.nslots[(size_t)g * kF6CntStride] = total;
+    atomicMax(F.max_slots, total);
+    if (total > F.slot_cap || total > kF6MaxSlots) atomicOr(F.fail, 2u);
+  }
+  // the set of foreign bodies (one thread per own body, its constraints in turn)
+  for (uint32_t p = p_lo + t; p < p_hi; p += kBlock) {
+    const uint32_t x = F.sidx[p];
+    for (uint32_t c = F.base[x]; c < F.base[x + 1]; ++c) {
+      const uint32_t b = K.ab[c].y;
+      if (b == kNone || F.brank[b] / F.nb == g) continue;
+      uint32_t i = (b * 2654435761u) >> 20;
+      for (uint32_t probe = 0; probe < kF6Hash; ++probe, i = (i + 1u) & (kF6Hash - 1u)) {
+        const uint32_t cur = atomicCAS(&s_key[i], 0u, b + 1u);
+        if (cur == 0u || cur == b + 1u) break;
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t e = t; e < kF6Hash; e += kBlock) {
+    if (s_key[e]) {
+      const uint32_t k = atomicAdd(&s_cnt, 1u);
+      s_val[e] = k;
+      if (k < F.fcap) F.fbody[(size_t)g * F.fcap + k] = s_key[e] - 1u;
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    F.fcnt[(size_t)g * kF6CntStride] = s_cnt;
+    atomicMax(F.max_foreign, s_cnt);
+    if (s_cnt > F.fcap || s_cnt >= kF6Hash / 2u) atomicOr(F.fail, 1u);
+  }
+  for (uint32_t p = p_lo + t; p < p_hi; p += kBlock) {
+    const uint32_t x = F.sidx[p];
+    for (uint32_t c = F.base[x]; c < F.base[x + 1]; ++c) {
+      const uint32_t b = K.ab[c].y;
+      if (b == kNone) continue;
+      if (F.brank[b] / F.nb == g) { F.bref[c] = F.brank[b] - g * F.nb; continue; }
+      uint32_t i = (b * 2654435761u) >> 20;
+      while (s_key[i] != b + 1u) i = (i + 1u) & (kF6Hash - 1u);
+      F.bref[c] = F.nb + s_val[i];
+    }
+  }
+}
+// hash slot of `key1` (= key + 1, never 0) in a table of kF6Chan words; inserts it if absent
+__device__ __forceinline__ uint32_t f6_chan_slot(uint32_t* keys, uint32_t key1, uint32_t* fail) {
+  const uint32_t h = (key1 * 2654435761u) >> 26;
+  for (uint32_t probe = 0; probe < kF6Chan; ++probe) {
+    const uint32_t i = (h + probe) & (kF6Chan - 1u);
+    uint32_t cur = __hip_atomic_load(&keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0u) cur = atomicCAS(&keys[i], 0u, key1);
+    if (cur == 0u || cur == key1) return i;
+  }
+  atomicOr(fail, 4u);
+  return 0u;
+}
+__device__ __forceinline__ uint32_t f6_slot_of(const Flow6& F, uint32_t a, uint32_t c) { return F.slot_base[a] + (c - F.base[a]); }
+// Per constraint: its row of the block's slot table.
+__global__ __launch_bounds__(kBlock) void k_flow6_table(Flow6 F, ConsLinks K, const uint32_t* C_ptr) {
+  const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= *C_ptr) return;
+  const uint2 e = K.ab[c];
+  const uint32_t g = F.brank[e.x] / F.nb;
+  const uint32_t slot = f6_slot_of(F, e.x, c);
+  if (slot >= F.slot_cap || slot >= kF6MaxSlots) { atomicOr(F.fail, 2u); return; }
+  F6Row R;
+  R.c = c;
+  const uint32_t aref = F.brank[e.x] - g * F.nb;
+  const uint32_t bref = e.y == kNone ? kF6NoBody : F.bref[c];
+  if (aref >= kF6NoBody || (e.y != kNone && bref >= kF6NoBody)) { atomicOr(F.fail, 16u); return; }
+  // this constraint ends the chain of its body b (its successor word wraps to the next iteration) and b lives in another
+  // block: it writes b's result, and b's own block does not (a is always the block's own)
+  const bool final_b = e.y != kNone && (K.succ[c].y & kSuccWrap) && F.brank[e.y] / F.nb != g;
+  if (final_b) F.skipwb[e.y] = 1;
+  R.ref = aref | (bref << kF6BodyBits) | (final_b ? kF6RefFinalB : 0u);
+  R.state0 = links_indeg0(K, c);
+  const uint2 sw = K.succ[c];
+  uint32_t w[2] = {sw.x, sw.y};
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    if (side == 1 && e.y == kNone) { w[1] = 0u; break; }
+    const uint32_t sid = w[side] & kSuccId, wrap = (w[side] & kSuccWrap) ? kF6Wrap : 0u;
+    const uint2 se = K.ab[sid];
+    const uint32_t hs = F.brank[se.x] / F.nb;
+    const uint32_t sslot = f6_slot_of(F, se.x, sid);
+    if (hs == g) { w[side] = wrap | sslot; continue; }
+    // the edge crosses a block face: a message on the channel g -> hs
+    const uint32_t body = side == 0 ? e.x : e.y;
+    const uint32_t dbody = se.x == body ? F.brank[body] - hs * F.nb : F.bref[sid];  // as a: own there; as b: what k_flow6_bodies gave it
+    const uint32_t k_in = f6_chan_slot(F.in_key + (size_t)hs * kF6Chan, g + 1u, F.fail);
+    atomicAdd(&F.in_cnt[(size_t)hs * kF6Chan + k_in], 1u);
+    const uint32_t k_out = f6_chan_slot(F.out_key + (size_t)g * kF6Chan, hs + 1u, F.fail);
+    F.out_val[(size_t)g * kF6Chan + k_out] = k_in;
+    if (sslot >= kF6MaxSlots || dbody >= kF6NoBody) atomicOr(F.fail, 16u);
+    w[side] = kF6Remote | wrap | (k_out << 24) | (dbody << kF6SlotBits) | sslot;
+  }
+  R.succ0 = w[0]; R.succ1 = w[1];
+  uint4* dst = reinterpret_cast<uint4*>(&F.table[(size_t)g * F.rows + slot]);
+  dst[0] = make_uint4(R.c, R.ref, R.succ0, R.succ1);
+  dst[1] = make_uint4(R.state0, 0u, 0u, 0u);
+}
+// One wave per block (its kF6Chan hash slots = the wave's lanes): where each incoming channel's messages start inside the
+// block's region of the channel buffer (exclusive prefix of the per-iteration edge counts), and whether the region suffices.
+__global__ __launch_bounds__(kBlock) void k_flow6_chan(Flow6 F, uint32_t iters) {
+  static_assert(kF6Chan == 64, "one lane per hash slot");
+  const uint32_t hs = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (hs >= F.nblocks) return;
+  const uint32_t cnt = F.in_cnt[(size_t)hs * kF6Chan + lane];
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if ((int)lane >= d) incl += v; }
+  F.chan_prefix[(size_t)hs * kF6Chan + lane] = incl - cnt;
+  if (lane == 63u) {
+    atomicAdd(&F.fail[1], incl);  // edges that cross a block face, per iteration (the host sizes the channel buffer from it)
+    atomicMax(&F.fail[2], incl);  // ... the most any block receives
+    if ((uint64_t)incl * iters > F.mbox_cap / F.nblocks) atomicOr(F.fail, 8u);
+  }
+}
+
+// ---- the solve ------------------------------------------------------------------------------------------------------------
+struct F6Ring { uint16_t* ring; uint32_t* head; uint32_t* tail; uint32_t cap, magic; };
+__device__ __forceinline__ uint32_t f6_wrap(const F6Ring& q, uint32_t pos) {  // pos % cap for pos < cap * kF6MaxIters
+  return pos - __umulhi(pos, q.magic) * q.cap;
+}
+__device__ __forceinline__ void f6_push(const F6Ring& q, uint32_t slot) {
+  const uint32_t pos = __hip_atomic_fetch_add(q.tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  q.ring[f6_wrap(q, pos)] = (uint16_t)(slot | 0x8000u);
+}
+// one arrival at `slot`: the last one queues it
+__device__ __forceinline__ void f6_arrive(const F6Ring& q, uint32_t* s_state, uint32_t slot) {
+  const uint32_t old = __hip_atomic_fetch_sub(&s_state[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if ((old & 0xFFu) == 1u) f6_push(q, slot);
+}
+
+// CL: the constant half of the own bodies' solver records (inverse mass, world inverse inertia: 40 B) is kept in LDS as well -
+// chosen by the host when the block's constraints leave room for it (the first ~100 ticks of the bench pile); otherwise the
+// lanes read it from the RigidBodyVec beside the constraint record.
+template <bool TRACE, bool CL>
+__global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* cons, Flow6 F, uint32_t iters, uint32_t epoch, uint32_t* abort_flag,
+                                                            uint32_t spin_limit, uint64_t* trace, uint32_t C_trace) {
+  if (*F.fail || *F.C_ptr == 0u) return;  // a limit was exceeded: the stand-by k_solve_flow launch behind this one does the work
+  extern __shared__ float4 s_dyn[];
+  const uint32_t nbod = F.nb + F.fcap, cap = F.slot_cap;
+  float4* s_body = s_dyn;                                              // [2 * nbod]: {v, w.x}, {w.y, w.z, body id, -}
+  float2* s_const = reinterpret_cast<float2*>(s_dyn + 2 * (size_t)nbod);  // CL: [5 * nb] inverse mass and inertia of the own bodies
+  uint2* s_succ = reinterpret_cast<uint2*>(s_const + (CL ? 5 * (size_t)F.nb : 0));  // [cap]
+  uint32_t* s_c = reinterpret_cast<uint32_t*>(s_succ + cap);           // [cap]
+  uint32_t* s_ref = s_c + cap;                                         // [cap]
+  uint32_t* s_state = s_ref + cap;                                     // [cap] arrivals missing (bits 0-7), iterations done (8-15)
+  uint32_t* s_ctl = s_state + cap;                                     // [16]: 0 head, 1 tail, 2 nodes left, 3 incoming channels
+  uint32_t* s_out_base = s_ctl + 16;                                   // [kF6Chan] first message of the outgoing channel
+  uint32_t* s_out_tail = s_out_base + kF6Chan;                         // [kF6Chan] messages sent
+  uint32_t* s_out_tidx = s_out_tail + kF6Chan;                         // [kF6Chan] the channel's word of F.tails
+  uint32_t* s_in_base = s_out_tidx + kF6Chan;                          // [kF6Chan] incoming channels, compacted
+  uint32_t* s_in_lim = s_in_base + kF6Chan;                            // [kF6Chan] messages the channel can carry in this launch
+  uint32_t* s_in_head = s_in_lim + kF6Chan;                            // [kF6Chan] first position not yet consumed
+  uint32_t* s_in_mask = s_in_head + kF6Chan;                           // [kF6Chan] consumed positions of the window behind the head
+  uint32_t* s_in_slot = s_in_mask + kF6Chan;                           // [kF6Chan] the channel's hash slot (its word of F.tails)
+  F6Ring q;
+  q.head = s_ctl; q.tail = s_ctl + 1; q.cap = cap; q.magic = 0xFFFFFFFFu / cap + 1u;
+  uint32_t* s_wl_cnt = s_in_slot + kF6Chan;                            // [16] per polling wave: items listed in this sweep
+  uint16_t* s_wl = reinterpret_cast<uint16_t*>(s_wl_cnt + 16);          // [kF6MaxPollers * kF6WlLen] (channel << 8) | position behind its head
+  q.ring = s_wl + kF6MaxPollers * kF6WlLen;                            // [cap]
+  uint32_t* s_left = s_ctl + 2;
+  const uint32_t g = blockIdx.x, t = threadIdx.x;
+  const uint32_t p_lo = g * F.nb, p_hi = min(F.n, p_lo + F.nb), n_own = p_hi - p_lo;
+  const uint32_t n_for = min(F.fcnt[(size_t)g * kF6CntStride], F.fcap);
+  const uint32_t N = F.nslots[(size_t)g * kF6CntStride];
+  __amdgpu_buffer_rsrc_t rmb = make_rsrc(F.mbox);
+  // every body this block touches: its own, then the foreign ones
+  for (uint32_t i = t; i < n_own + n_for; i += kF6Threads) {
+    const uint32_t x = i < n_own ? F.sidx[p_lo + i] : F.fbody[(size_t)g * F.fcap + (i - n_own)];
+    const uint32_t idx = i < n_own ? i : F.nb + (i - n_own);
+    const float4 r0 = srec[4 * (size_t)x], r1 = srec[4 * (size_t)x + 1];
+    s_body[2 * idx] = r0;
+    s_body[2 * idx + 1] = make_float4(r1.x, r1.y, u2f(x), 0.0f);
+    if (CL && i < n_own) {
+      const float4 r2 = srec[4 * (size_t)x + 2], r3 = srec[4 * (size_t)x + 3];
+      s_const[5 * idx] = make_float2(r1.z, r1.w); s_const[5 * idx + 1] = make_float2(r2.x, r2.y); s_const[5 * idx + 2] = make_float2(r2.z, r2.w);
+      s_const[5 * idx + 3] = make_float2(r3.x, r3.y); s_const[5 * idx + 4] = make_float2(r3.z, r3.w);
+    }
+  }
+  for (uint32_t e = t; e < (cap + 1u) / 2u; e += kF6Threads) reinterpret_cast<uint32_t*>(q.ring)[e] = 0u;
+  if (t < 16) s_ctl[t] = t == 2 ? N * iters : 0u;
+  const uint32_t region = F.mbox_cap / F.nblocks;  // messages of the channel buffer each block owns
+  if (t < 64) {  // wave 0: channel tables (the incoming ones compacted: the polling wave gives every channel a few lanes)
+    uint32_t okey = 0, ikey = 0;
+    if (t < kF6Chan) { okey = F.out_key[(size_t)g * kF6Chan + t]; ikey = F.in_key[(size_t)g * kF6Chan + t]; }
+    if (t < kF6Chan) {
+      s_out_tail[t] = 0u;
+      const uint32_t tix = okey ? (okey - 1u) * kF6Chan + F.out_val[(size_t)g * kF6Chan + t] : 0u;
+      s_out_base[t] = okey ? (okey - 1u) * region + F.chan_prefix[tix] * iters : 0u;
+      s_out_tidx[t] = tix;
+      s_in_head[t] = 0u; s_in_mask[t] = 0u; s_in_lim[t] = 0u; s_in_base[t] = 0u;
+    }
+    const unsigned long long m = __ballot(ikey != 0u);
+    if (ikey) {
+      const uint32_t r = (uint32_t)__popcll(m & ((1ull << t) - 1ull));
+      s_in_base[r] = g * region + F.chan_prefix[(size_t)g * kF6Chan + t] * iters;
+      s_in_lim[r] = F.in_cnt[(size_t)g * kF6Chan + t] * iters;
+      s_in_slot[r] = t;
+    }
+    if (t == 0) s_ctl[3] = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  // the block's slot table (built once per tick by k_flow6_table)
+  const F6Row* rows = F.table + (size_t)g * F.rows;
+  for (uint32_t idx = t; idx < N; idx += kF6Threads) {
+    const uint4* src = reinterpret_cast<const uint4*>(&rows[idx]);
+    const uint4 r0 = src[0];
+    const uint32_t st0 = src[1].x;
+    s_c[idx] = r0.x; s_ref[idx] = r0.y; s_succ[idx] = make_uint2(r0.z, r0.w); s_state[idx] = st0;
+    if (st0 == 0u && iters > 0) f6_push(q, idx);  // iteration 0's frontier
+  }
+  __syncthreads();
+  const uint32_t wave = t >> 6, lane = t & 63u, nwaves = kF6Threads / 64u;
+  const uint32_t n_in = s_ctl[3];
+  // the last F.poll_waves waves poll the incoming channels (channel r belongs to poller r % P), the others serve the queue
+  const uint32_t P = n_in == 0u ? 0u : min(min(F.poll_waves, kF6MaxPollers), n_in);
+  const bool poller = wave + P >= nwaves;
+  uint32_t spins = 0;
+  if (poller) {
+    // Polling wave pw serves the incoming channels r = pw, pw + P, ...; lane i OWNS channel i of them: its head (first position
+    // not yet consumed), the consumed bits of the 32 positions behind it and the producers' HINT (positions handed out so far,
+    // tagged with the launch) live in that lane's registers.  Every sweep the owners list the positions worth reading - what
+    // the last hint says was sent and is not consumed, and the head itself on spec (a lone message then costs one memory
+    // round trip) - in an LDS worklist; the wave's 64 lanes take one item each, read the message, and the owners read the
+    // hint anew: four load instructions per sweep whatever the traffic, nothing read that was not sent (apart from one slot
+    // per channel), and a burst on one channel is drained as fast as a trickle on all of them.
+    // A message counts when its three granules carry this launch's tag (granules land whole; their order is not defined).
+    const uint32_t pw = wave - (nwaves - P);
+    const uint32_t n_loc = (n_in - pw + P - 1u) / P;
+    const bool owner = lane < n_loc;
+    const uint32_t ch = lane * P + pw;
+    const uint32_t lim = owner ? s_in_lim[ch] : 0u;
+    const unsigned long long* tail_ptr = F.tails + (size_t)g * kF6Chan + (owner ? s_in_slot[ch] : 0u);
+    uint32_t* wl_cnt = s_wl_cnt + pw;
+    uint16_t* wl = s_wl + pw * kF6WlLen;
+    uint32_t head = 0, mask = 0, known = 0;
+    uint32_t st_sweeps = 0, st_hits = 0, st_lat_sum = 0, st_lat_max = 0, st_full = 0, st_wait = 0;  // TRACE: polling statistics
+    if (lane == 0) __hip_atomic_store(wl_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;;) {
+      if (__hip_atomic_load(s_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
+      uint64_t tq0 = 0;
+      if (TRACE) { ++st_sweeps; tq0 = wall_clock64(); }
+      // the owners list their positions
+      if (owner) {
+        const uint32_t pend = known > head ? min(known - head, 32u) : 0u;
+        uint32_t todo = ~mask & (pend >= 32u ? 0xFFFFFFFFu : (1u << pend) - 1u);
+        if (head < lim) todo |= 1u & ~mask;  // the head, on spec
+        const uint32_t need = (uint32_t)__popc(todo);
+        if (need) {
+          uint32_t at = __hip_atomic_fetch_add(wl_cnt, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(&s_in_head[ch], head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          while (todo) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(todo);
+            todo &= todo - 1u;
+            if (at < kF6WlLen) wl[at] = (uint16_t)((lane << 8) | bit);
+            ++at;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const uint32_t total = min(__hip_atomic_load(wl_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), kF6WlLen);
+      if (TRACE && total >= 64u) ++st_full;
+      unsigned long long hits = 0;
+      for (uint32_t b = 0; b < total || b == 0u; b += 64u) {
+        const uint32_t j = b + lane;
+        const bool have = j < total;
+        const uint32_t item = have ? wl[j] : 0u;
+        const uint32_t oi = item >> 8, bit = item & 0xFFu, chn = oi * P + pw;
+        const uint32_t pos = have ? __hip_atomic_load(&s_in_head[chn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + bit : 0u;
+        const uint32_t byte = have ? (s_in_base[chn] + pos) * (16u * kF6MsgWords) : 0x80000000u;  // (out of range: zeros, no traffic)
+        const v4f_t g0 = __builtin_amdgcn_raw_buffer_load_b128(rmb, (int)byte, 0, kSc1);
+        const v4f_t g1 = __builtin_amdgcn_raw_buffer_load_b128(rmb, (int)(byte + 16u), 0, kSc1);
+        const v4f_t g2 = __builtin_amdgcn_raw_buffer_load_b128(rmb, (int)(byte + 32u), 0, kSc1);
+        if (b == 0u && owner) {
+          const unsigned long long tv = __hip_atomic_load(tail_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          known = (uint32_t)(tv >> 32) == epoch ? min((uint32_t)tv, lim) : 0u;
+        }
+        if (TRACE && b == 0u) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st_wait += (uint32_t)(wall_clock64() - tq0); }
+        const bool hit = have && f2u(g0.w) == epoch && f2u(g1.w) == epoch && f2u(g2.w) == epoch;
+        if (hit) {
+          const uint32_t addr = f2u(g2.x);
+          const uint32_t slot = addr & ((1u << kF6SlotBits) - 1u), bi = addr >> kF6SlotBits;
+          s_body[2 * bi] = make_float4(g0.x, g0.y, g0.z, g1.x);
+          *reinterpret_cast<float2*>(&s_body[2 * bi + 1]) = make_float2(g1.y, g1.z);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the velocity is in LDS before the arrival counts
+          f6_arrive(q, s_state, slot);
+          __hip_atomic_fetch_or(&s_in_mask[chn], 1u << bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (TRACE) { const uint32_t lat = (uint32_t)wall_clock64() - f2u(g2.y); ++st_hits; st_lat_sum += lat; st_lat_max = max(st_lat_max, lat); }
+        }
+        hits |= __ballot(hit);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(wl_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (owner && hits) {  // what was consumed of this lane's channel (these words are this wave's alone: program order holds)
+        mask |= __hip_atomic_exchange(&s_in_mask[ch], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t k = mask == 0xFFFFFFFFu ? 32u : (uint32_t)__builtin_ctz(~mask);
+        head += k; mask = k >= 32u ? 0u : mask >> k;
+      }
+      if (hits) { spins = 0; continue; }
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 1023u) == 0u) {
+        bool give_up = spins > spin_limit;
+        if (give_up) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (give_up || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      }
+    }
+    if (TRACE) {  // per block: sweeps of the first polling lane, messages, latency sum / max (clock ticks), full batches
+      uint64_t* st = trace + 2 * (size_t)iters * C_trace + 8 * (size_t)g;
+      if (lane == 0 && pw == 0) st[0] = st_sweeps;
+      atomicAdd(reinterpret_cast<unsigned long long*>(&st[1]), (unsigned long long)st_hits);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&st[2]), (unsigned long long)st_lat_sum);
+      atomicMax(reinterpret_cast<unsigned long long*>(&st[3]), (unsigned long long)st_lat_max);
+      if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&st[4]), (unsigned long long)st_full);
+      if (lane == 0 && pw == 0) { st[5] = n_in; st[6] = st_wait; }
+    }
+  } else {
+    for (;;) {
+      if (__hip_atomic_load(s_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
+      // take up to 64 ready nodes
+      uint32_t h = 0, take = 0;
+      if (lane == 0) {
+        h = __hip_atomic_load(q.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t tl = __hip_atomic_load(q.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        take = min(tl - h, 64u);
+        if (take) {
+          uint32_t expect = h;
+          if (!__hip_atomic_compare_exchange_strong(q.head, &expect, h + take, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) take = 0;
+        }
+      }
+      h = __shfl(h, 0); take = __shfl(take, 0);
+      if (take) {
+        spins = 0;
+        if (lane < take) {
+          uint16_t* cell = &q.ring[f6_wrap(q, h + lane)];
+          uint32_t e;
+          do { e = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (!(e & 0x8000u));  // the pusher is between its two writes
+          *cell = 0;
+          const uint32_t slot = e & 0x7FFFu;
+          const uint32_t round = (__hip_atomic_load(&s_state[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 8) & 0xFFu;
+          uint64_t t_seen = 0;
+          if (TRACE) t_seen = wall_clock64();
+          const uint32_t c = s_c[slot], ref = s_ref[slot];
+          const uint2 sw = s_succ[slot];
+          const uint32_t ai = ref & kF6NoBody, bi_raw = (ref >> kF6BodyBits) & kF6NoBody;
+          const bool has_b = bi_raw != kF6NoBody;
+          const uint32_t bi = has_b ? bi_raw : ai;
+          CRec rec = load_crec_solve(&cons[c]);  // only the lane running the constraint touches its record
+          const float4 a0 = s_body[2 * ai], a1 = s_body[2 * ai + 1], b0 = s_body[2 * bi], b1 = s_body[2 * bi + 1];
+          const uint32_t ga = f2u(a1.z), gb = f2u(b1.z);
+          // the constant half of ConstrainedSet::get (inverse mass, world inverse inertia): from LDS for own bodies (CL), else plain
+          // loads beside the record's
+          float4 ca1, ca2, ca3, cb1, cb2, cb3;
+          if (CL) {
+            const float2 k0 = s_const[5 * ai], k1 = s_const[5 * ai + 1], k2 = s_const[5 * ai + 2], k3 = s_const[5 * ai + 3], k4 = s_const[5 * ai + 4];
+            ca1 = make_float4(0, 0, k0.x, k0.y); ca2 = make_float4(k1.x, k1.y, k2.x, k2.y); ca3 = make_float4(k3.x, k3.y, k4.x, k4.y);
+            if (bi < F.nb) {
+              const float2 j0 = s_const[5 * bi], j1 = s_const[5 * bi + 1], j2 = s_const[5 * bi + 2], j3 = s_const[5 * bi + 3], j4 = s_const[5 * bi + 4];
+              cb1 = make_float4(0, 0, j0.x, j0.y); cb2 = make_float4(j1.x, j1.y, j2.x, j2.y); cb3 = make_float4(j3.x, j3.y, j4.x, j4.y);
+            } else {
+              cb1 = srec[4 * (size_t)gb + 1]; cb2 = srec[4 * (size_t)gb + 2]; cb3 = srec[4 * (size_t)gb + 3];
+            }
+          } else {
+            ca1 = srec[4 * (size_t)ga + 1]; ca2 = srec[4 * (size_t)ga + 2]; ca3 = srec[4 * (size_t)ga + 3];
+            cb1 = srec[4 * (size_t)gb + 1]; cb2 = srec[4 * (size_t)gb + 2]; cb3 = srec[4 * (size_t)gb + 3];
+          }
+          BodyDyn A, Bd;
+          A.v = mk3(a0.x, a0.y, a0.z); A.w = mk3(a0.w, a1.x, a1.y); A.im = ca1.z;
+          A.I = m3_cols(mk3(ca1.w, ca2.x, ca2.y), mk3(ca2.z, ca2.w, ca3.x), mk3(ca3.y, ca3.z, ca3.w));
+          Bd.v = mk3(b0.x, b0.y, b0.z); Bd.w = mk3(b0.w, b1.x, b1.y); Bd.im = cb1.z;
+          Bd.I = m3_cols(mk3(cb1.w, cb2.x, cb2.y), mk3(cb2.z, cb2.w, cb3.x), mk3(cb3.y, cb3.z, cb3.w));
+          if (!has_b) Bd = static_dyn();
+          solve_one(rec, A, Bd);
+          s_body[2 * ai] = make_float4(A.v.x, A.v.y, A.v.z, A.w.x);
+          *reinterpret_cast<float2*>(&s_body[2 * ai + 1]) = make_float2(A.w.y, A.w.z);
+          if (has_b) {
+            s_body[2 * bi] = make_float4(Bd.v.x, Bd.v.y, Bd.v.z, Bd.w.x);
+            *reinterpret_cast<float2*>(&s_body[2 * bi + 1]) = make_float2(Bd.w.y, Bd.w.z);
+          }
+          cons[c].nimp = rec.nimp;
+          // re-arm: one arrival per dynamic body and iteration from now on (no arrival of the next iteration can come before
+          // this node's own releases), and one more iteration done
+          __hip_atomic_fetch_add(&s_state[slot], 0x100u + (has_b ? 2u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (round + 1u == iters) {  // the end of a foreign body's chain: its home block does not write it back
+            if (ref & kF6RefFinalA) store_vel(srec, ga, A);
+            if (ref & kF6RefFinalB) store_vel(srec, gb, Bd);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // velocities are in LDS before any local successor hears of it
+          if (TRACE) {
+            trace[2 * ((size_t)round * C_trace + c)] = t_seen & ~3ull;
+            trace[2 * ((size_t)round * C_trace + c) + 1] = wall_clock64();
+          }
+#pragma unroll
+          for (int side = 0; side < 2; ++side) {
+            if (side == 1 && !has_b) break;
+            const uint32_t w = side == 0 ? sw.x : sw.y;
+            if (round + ((w & kF6Wrap) ? 1u : 0u) >= iters) continue;
+            if (!(w & kF6Remote)) {
+              f6_arrive(q, s_state, w & ((1u << kF6SlotBits) - 1u));
+            } else {  // a message: the body's velocity, where it goes, the launch's tag in every granule - and on we go
+              const uint32_t chn = (w >> 24) & (kF6Chan - 1u);  // (6 bits)
+              const uint32_t pos = __hip_atomic_fetch_add(&s_out_tail[chn], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              const uint32_t byte = (s_out_base[chn] + pos) * (16u * kF6MsgWords);
+              const BodyDyn& X = side == 0 ? A : Bd;
+              const float tg = u2f(epoch);
+              v4f_t m0 = {X.v.x, X.v.y, X.v.z, tg}, m1 = {X.w.x, X.w.y, X.w.z, tg}, m2 = {u2f(w & 0x00FFFFFFu), TRACE ? u2f((uint32_t)wall_clock64()) : 0.0f, 0.0f, tg};
+              __builtin_amdgcn_raw_buffer_store_b128(m0, rmb, (int)byte, 0, kSc1);
+              __builtin_amdgcn_raw_buffer_store_b128(m1, rmb, (int)(byte + 16u), 0, kSc1);
+              __builtin_amdgcn_raw_buffer_store_b128(m2, rmb, (int)(byte + 32u), 0, kSc1);
+              __hip_atomic_fetch_max(F.tails + s_out_tidx[chn], ((unsigned long long)epoch << 32) | (pos + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
+        if (lane == 0) __hip_atomic_fetch_sub(s_left, take, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        continue;
+      }
+      __builtin_amdgcn_s_sleep(2);
+      if ((++spins & 255u) == 0u) {
+        bool give_up = spins > spin_limit;
+        if (give_up) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (give_up || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      }
+    }
+  }
+  __syncthreads();
+  // own bodies go back to the RigidBodyVec (a body whose chain ends in another block was written there)
+  for (uint32_t i = t; i < n_own; i += kF6Threads) {
+    const uint32_t x = F.sidx[p_lo + i];
+    if (!F.skipwb[x]) {
+      srec[4 * (size_t)x] = s_body[2 * i];
+      const float4 s1 = s_body[2 * i + 1];
+      *reinterpret_cast<float2*>(&srec[4 * (size_t)x + 1]) = make_float2(s1.x, s1.y);
+    }
+  }
+}
+
+}  // namespace mgf

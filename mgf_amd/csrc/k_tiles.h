@@ -1,6 +1,6 @@
 // Spatial tiling: boundary selection, ghost and migrant records.  (Part of the kernel set described in kernels.h.)
 #pragma once
-#include "k_solver_flow.h"
+#include "k_solver_flow6.h"
 
 namespace mgf {
 

@@ -132,7 +132,7 @@ def ctx():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_plain,mode", [(0, 5), (6, 5), (6, 0), (6, 1)])
+@pytest.mark.parametrize("n_plain,mode", [(0, 6), (6, 6), (6, 5), (6, 0), (6, 1)])
 def test_hip_dumbbell_field_equals_oracle(ctx, n_plain, mode):
     import mgf_amd
     sc = scenes.dumbbell_field(4, 2, 4, n_plain=n_plain)

@@ -156,7 +156,7 @@ def test_contact_constraint_new_for_caller_built_manifolds(ctx):
     assert len(gw.constraints_new([], [], m[:0], dt)) == 0
 
 
-@pytest.mark.parametrize("mode", [5, 1, 0])
+@pytest.mark.parametrize("mode", [6, 5, 1, 0])
 def test_solver_handle_runs_a_callers_list_in_insertion_order(ctx, mode):
     """Solver::new / add_constraint / solve(rbv, iters) (solver.rs:59-78) with constraints made by mgf_constraints_new: the
     exact sequential result, state kept between two solve calls, len / clear."""

@@ -104,7 +104,7 @@ def test_pair_constraints_conserve_momentum(ctx):
     assert np.abs(p1 - p0).max() < 1e-2 * np.sqrt(len(gw)), (p0, p1)
 
 
-@pytest.mark.parametrize("mode", [1, 4, 5])
+@pytest.mark.parametrize("mode", [1, 4, 5, 6])
 def test_dataflow_solver_full_size_stress(ctx, mode):
     """262 144 spheres, 40 ticks: the persistent dataflow solver and the launch-per-frontier solver must
     agree bit for bit (any stale cross-CU read would change bits somewhere in ~200 M constraint solves)."""

@@ -490,31 +490,33 @@ def test_body_added_between_begin_and_collide_is_seen(ctx):
         assert bits_equal(xa[k], xb[k]), k
 
 
-def test_block_that_does_not_fit_falls_back_on_the_device(ctx):
+@pytest.mark.parametrize("mode", [5, 6])
+def test_block_that_does_not_fit_falls_back_on_the_device(ctx, mode):
     """When a spatial block holds more constraints than its workgroup's LDS layout (forced here by a tiny test limit), a
-    device flag turns k_solve_flow5 into a no-op and the k_solve_flow launch enqueued behind it does the work - no host
-    round trip inside the tick, the same result, and the counter says it happened."""
+    device flag turns k_solve_flow5 / k_solve_flow6 into a no-op and the k_solve_flow launch enqueued behind it does the work -
+    no host round trip inside the tick, the same result, and the counter says it happened."""
     import mgf_amd
     from mgf_amd import scenes
     scene = scenes.sphere_pile(10, 10, 10)
     dt, iters = float(scene["dt"]), scene["iters"]
     ow, gw = oracle_world(scene), mgf_amd.World.from_scene(ctx, scene)
-    gw.set_option("flow5_test_cap", 40)
+    gw.set_option("solver_mode", mode)
+    gw.set_option(f"flow{mode}_test_cap", 40)
     for step in range(40):
         so, sg = ow.step(dt, iters), gw.step(dt, iters)
         assert sg.n_constraints == so.n_constraints
-    assert so.n_constraints > 500 and gw.counter("flow5_fallbacks") > 10
+    assert so.n_constraints > 500 and gw.counter(f"flow{mode}_fallbacks") > 10
     compare_constraints(gw.constraints(), ow.constraints(), check_impulse=True)
     _compare_state(gw, ow, "stand-by solver")
-    gw.set_option("flow5_test_cap", 0)  # back to the block-local kernel: same world, same results
-    n0 = gw.counter("flow5_fallbacks")
+    gw.set_option(f"flow{mode}_test_cap", 0)  # back to the block-local kernel: same world, same results
+    n0 = gw.counter(f"flow{mode}_fallbacks")
     for step in range(10):
         so, sg = ow.step(dt, iters), gw.step(dt, iters)
-    assert gw.counter("flow5_fallbacks") == n0
+    assert gw.counter(f"flow{mode}_fallbacks") == n0
     _compare_state(gw, ow, "after the stand-by phase")
 
 
-@pytest.mark.parametrize("mode", [1, 4, 5, 105])
+@pytest.mark.parametrize("mode", [1, 4, 5, 105, 6, 106, 206])
 @pytest.mark.parametrize("scene_name", ["pile12", "mixed", "balls8"])
 def test_dataflow_solver_matches_oracle(ctx, scene_name, mode):
     """solver_mode=1 (one persistent dataflow launch) must give the sequential Gauss-Seidel result too."""
@@ -526,8 +528,10 @@ def test_dataflow_solver_matches_oracle(ctx, scene_name, mode):
     ow = oracle_world(scene)
     gw = mgf_amd.World.from_scene(ctx, scene)
     gw.set_option("solver_mode", mode % 100)
-    if mode == 105:  # block-local solver with small blocks: many block faces on a small scene
-        gw.set_option("flow5_block", 96)
+    if mode >= 100:  # block-local solvers with small blocks: many block faces on a small scene
+        gw.set_option("flow5_block", 96 if mode < 200 else 40)
+    if mode == 206:  # ... and hardly any foreign slots: ticks that need more run on the stand-by, the others on k_solve_flow6
+        gw.set_option("flow6_fcap", 24)
     n_ticks = 160 if scene_name == "balls8" else 60
     for step in range(n_ticks):
         so = ow.step(dt, iters)

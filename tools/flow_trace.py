@@ -10,6 +10,8 @@ ctx = mgf_amd.Context(0)
 sc = scenes.sphere_pile(n, n, n)
 w = mgf_amd.World.from_scene(ctx, sc)
 w.set_option('solver_mode', mode)
+import os
+for kv in [kv.split('=') for kv in os.environ.get('MGF_F6_OPTS', '').split(',') if kv]: w.set_option(kv[0], int(kv[1]))
 for s in range(ticks): w.step(float(sc['dt']), 10)
 w.set_option('flow_trace', 1)
 w.step(float(sc['dt']), 10)
@@ -19,8 +21,8 @@ raw = np.fromfile('/tmp/mgf_flow_trace.bin', dtype=np.uint64)
 C, iters, n_rank, nb_block = int(raw[0]), int(raw[1]), int(raw[2]), int(raw[3])
 tr = raw[4:4 + 2 * iters * C].reshape(iters, C, 2).astype(np.int64)
 rank = raw[4 + 2 * iters * C:].view(np.uint32)[:n_rank].astype(np.int64) if n_rank else None
-cls = (tr[0, :, 0] & 3) if mode == 5 else np.zeros(C, np.int64)   # mode 5 stamps the slot class into the low bits
-if mode == 5:
+cls = (tr[0, :, 0] & 3) if mode in (5, 6) else np.zeros(C, np.int64)   # mode 5 stamps the slot class into the low bits
+if mode in (5, 6):
     tr[:, :, 0] &= ~3
     print("classes (0 all-LDS, 1 global counter, 2 shared body):", np.bincount(cls, minlength=3) / C)
 t0 = tr[:, :, 0].min()
@@ -67,7 +69,7 @@ while (r, c) in crit_pred:
         k = k + ("same block" if rank[A[pc]] // nb_block == rank[A[c]] // nb_block else "other block",)
     e = by.setdefault(k, [0, 0.0, 0.0]); e[0] += 1; e[1] += seen[r, c] - done[pr, pc]; e[2] += done[r, c] - seen[r, c]
     r, c = pr, pc
-if mode == 5:
+if mode in (5, 6):
     for k in sorted(by):
         n, h, sv = by[k]
         print(f"  critical hops class {k[0]} -> {k[1]} {k[2] if len(k) > 2 else '':11s}: {n:4d}  hand-off {h / n:6.2f} us  service {sv / n:6.2f} us  (total {h + sv:7.1f} us)")
@@ -79,3 +81,11 @@ print(f"critical path: {hops} hops, service {svc:.1f} us ({svc/hops:.2f}/hop), h
 h = np.array(path)
 print("hand-off on the critical path: p10 %.2f p50 %.2f p90 %.2f max %.2f" % tuple(np.percentile(h[:,0],[10,50,90,100])))
 print("service  on the critical path: p10 %.2f p50 %.2f p90 %.2f max %.2f" % tuple(np.percentile(h[:,1],[10,50,90,100])))
+
+if mode == 6 and os.path.exists('/tmp/mgf_flow6_poll.bin'):
+    st = np.fromfile('/tmp/mgf_flow6_poll.bin', dtype=np.uint64).reshape(-1, 8).astype(np.float64)
+    span = done.max()
+    print(f"polling: sweeps/block mean {st[:,0].mean():.0f} (period {span / max(st[:,0].mean(),1):.2f} us), messages/block {st[:,1].mean():.0f}, "
+          f"message latency sent->consumed mean {st[:,2].sum() / max(st[:,1].sum(),1) * 0.01:.2f} us, max {st[:,3].max() * 0.01:.1f} us, "
+          f"full windows/block {st[:,4].mean():.1f}, incoming channels mean {st[:,5].mean():.1f} max {st[:,5].max():.0f}; "
+          f"time a sweep waits for its loads {st[:,6].sum() / max(st[:,0].sum(),1) * 0.01:.2f} us")
