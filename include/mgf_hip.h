@@ -123,6 +123,7 @@ typedef struct mgf_bvh mgf_bvh;
 typedef struct mgf_world mgf_world;
 typedef struct mgf_compound mgf_compound;
 typedef struct mgf_solver mgf_solver;
+typedef struct mgf_tiles mgf_tiles;
 
 /* ---- context ---------------------------------------------------------------------- */
 MGF_API mgf_status mgf_ctx_create(int device, mgf_ctx** out);
@@ -355,6 +356,28 @@ MGF_API mgf_status mgf_world_read_tags(mgf_world* w, uint32_t* tags /* host */, 
  * mgf_world_finish synchronises once and reports the outcome (status, timings) of everything enqueued. */
 MGF_API mgf_status mgf_world_solve_enqueue(mgf_world* w, int32_t iters);
 MGF_API mgf_status mgf_world_finish(mgf_world* w, mgf_step_stats* stats);
+/* ---- the whole tile protocol under the C-ABI (what a Rust host calls once per tick; mgf_amd/tiles.py is the same protocol in
+ * Python, kept as the transport-agnostic reference driver of the CPU tests).  A process owns n_local consecutive x-slab
+ * tiles [first_tile, first_tile + n_local) of n_tiles_total, each a mgf_world on the same context with its slab
+ * [x_lo, x_hi).  mgf_tiles_step runs one tick of all of them: begin_tick + boundary / migrant selection of every tile with ONE
+ * host wait, ghost bodies to the neighbours, collide of every tile enqueued before the first read-back is waited for,
+ * iters / refresh_every x { Solver::solve(refresh_every); ghost velocities from their owners }, finish, hand-over of bodies
+ * whose centre left their slab.  Between tiles of one process the exchange is a device copy; between processes (one per GPU)
+ * it is RCCL point-to-point (ncclSend / ncclRecv in one group per exchange step, on the context's stream, over xGMI):
+ * rank 0 calls mgf_rccl_unique_id, the host program hands the 128 bytes to the other ranks, every rank calls
+ * mgf_tiles_connect(rank, n_ranks) - rank r's tile range follows rank r - 1's - and mgf_tiles_preflight sums a 1 from every
+ * rank over the communicator (0 = not connected).  librccl is loaded at run time, on the first of these calls.
+ * stats (optional) receives one record per local tile.  Results are bit-identical to mgf_amd/tiles.py and to the oracle's
+ * tile mode, and independent of how the tiles are spread over processes. */
+MGF_API mgf_status mgf_tiles_create(mgf_ctx* ctx, int32_t n_local, mgf_world* const* worlds, const float* x_lo, const float* x_hi,
+                                    int32_t first_tile, int32_t n_tiles_total, float halo, int32_t refresh_every, int32_t migrate,
+                                    mgf_tiles** out);
+MGF_API void mgf_tiles_free(mgf_tiles* t);
+MGF_API mgf_status mgf_rccl_unique_id(void* id128);
+MGF_API mgf_status mgf_tiles_connect(mgf_tiles* t, const void* id128, int32_t rank, int32_t n_ranks);
+MGF_API mgf_status mgf_tiles_preflight(mgf_tiles* t, int32_t* n_ranks_seen);
+MGF_API mgf_status mgf_tiles_step(mgf_tiles* t, float dt, int32_t iters, mgf_step_stats* stats /* n_local, or NULL */);
+MGF_API int64_t mgf_tiles_migrated(const mgf_tiles* t, int32_t tile, int32_t direction_in); /* bodies handed over so far */
 /* Options (development and test knobs; defaults in brackets): "time_solver_kernels" [0] HIP events around the
  * solver kernels; "solver_mode" [5] 1 = persistent dataflow launch, 0 = one launch per dependency frontier,
  * 4 = dataflow with out-of-order slots, 5 = block-local dataflow (velocities and counters of a spatial block in LDS); "two_pass_candidates" [0]; "broadphase_tree" [0]; "terrain_tree" [0]; "no_fused_narrowphase" [0] (a world of spheres only runs the sphere-sphere test inside the grid broadphase and lists contacts only; 1 = list every accepted partner); "stream_ordered" [0]; "spin_wait" [1] (the tick's one wait polls an event instead of blocking); "pipeline" [1] (mgf_world_step_many enqueues the next tick before it waits for this one); "cell_fill" [16] (bodies per Morton cell, in eighths, beyond which the broadphase grid gets another level); "no_fused_terrain_rows" [0], "no_fused_scene_bounds" [0] (mgf_world_step and mgf_world_begin_tick list the terrain faces of a body and gather the scene bounds inside the integration kernel; 1 = always the separate kernels); "list_capacity";

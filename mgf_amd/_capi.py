@@ -130,6 +130,8 @@ SYMBOLS = [
     "mgf_constraints_new", "mgf_solver_new", "mgf_solver_free", "mgf_solver_add_constraint", "mgf_solver_add_constraints",
     "mgf_solver_len", "mgf_solver_clear", "mgf_solver_read_constraints", "mgf_solver_solve", "mgf_world_clone",
     "mgf_geom_to_json", "mgf_geom_from_json",
+    "mgf_tiles_create", "mgf_tiles_free", "mgf_rccl_unique_id", "mgf_tiles_connect", "mgf_tiles_preflight", "mgf_tiles_step",
+    "mgf_tiles_migrated",
 ]
 
 _lib = None
@@ -246,6 +248,13 @@ def load_library():
         "mgf_world_clone": (i32, [vp, P(vp)]),
         "mgf_geom_to_json": (i32, [P(Shape), P(Vec3), vp, i64, P(i64)]),
         "mgf_geom_from_json": (i32, [i32, C.c_char_p, i64, P(Shape), P(Vec3)]),
+        "mgf_tiles_create": (i32, [vp, i32, vp, vp, vp, i32, i32, f32, i32, i32, P(vp)]),
+        "mgf_tiles_free": (None, [vp]),
+        "mgf_rccl_unique_id": (i32, [vp]),
+        "mgf_tiles_connect": (i32, [vp, vp, i32, i32]),
+        "mgf_tiles_preflight": (i32, [vp, P(i32)]),
+        "mgf_tiles_step": (i32, [vp, f32, i32, vp]),
+        "mgf_tiles_migrated": (i64, [vp, i32, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -1020,3 +1029,50 @@ class World:
         nb = C.c_int64()
         _check(load_library().mgf_world_device_ptr(self._h, name.encode(), C.byref(p), C.byref(nb)))
         return p.value, nb.value
+
+
+def rccl_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 calls this and hands the bytes to the other ranks)."""
+    buf = (C.c_ubyte * 128)()
+    _check(load_library().mgf_rccl_unique_id(buf))
+    return bytes(buf)
+
+
+class Tiles:
+    """This process's x-slab tiles of one scene behind mgf_tiles_* (the whole tile protocol under the C-ABI; mgf_amd.tiles is
+    the same protocol in Python).  worlds[i] owns the slab x_ranges[i]; the tiles are first_tile .. of n_tiles_total."""
+
+    def __init__(self, ctx, worlds, x_ranges, first_tile=0, n_tiles_total=None, halo=1.0, refresh_every=2, migrate=True):
+        self._ctx, self.worlds = ctx, list(worlds)
+        n = len(self.worlds)
+        total = n if n_tiles_total is None else int(n_tiles_total)
+        big = 3.0e38
+        lo = (C.c_float * n)(*[float(max(min(r[0], big), -big)) for r in x_ranges])
+        hi = (C.c_float * n)(*[float(max(min(r[1], big), -big)) for r in x_ranges])
+        hs = (C.c_void_p * n)(*[w._h for w in self.worlds])
+        self._h = C.c_void_p()
+        _check(load_library().mgf_tiles_create(ctx._h, n, hs, lo, hi, int(first_tile), total, float(halo), int(refresh_every),
+                                               1 if migrate else 0, C.byref(self._h)))
+        ctx._adopt(self)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load_library().mgf_tiles_free(self._h)
+            self._h = None
+
+    def connect(self, unique_id, rank, n_ranks):
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        _check(load_library().mgf_tiles_connect(self._h, buf, int(rank), int(n_ranks)))
+
+    def preflight(self):
+        n = C.c_int32()
+        _check(load_library().mgf_tiles_preflight(self._h, C.byref(n)))
+        return n.value
+
+    def step(self, dt, iters):
+        arr = (StepStats * len(self.worlds))()
+        _check(load_library().mgf_tiles_step(self._h, float(dt), int(iters), arr))
+        return arr
+
+    def migrated(self, tile, incoming=True):
+        return load_library().mgf_tiles_migrated(self._h, int(tile), 1 if incoming else 0)

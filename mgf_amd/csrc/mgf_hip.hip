@@ -133,3 +133,4 @@ extern "C" mgf_status mgf_exclusive_scan_u32(mgf_ctx* ctx, const uint32_t* in, i
 #include "host_tiles.inc"
 #include "host_solver.inc"
 #include "host_boundary.inc"
+#include "host_tiles_native.inc"

@@ -1,0 +1,133 @@
+"""The tile protocol under the C-ABI (mgf_tiles_*: SURVEY.md §8e) against the oracle's tile mode: several
+x-slab tiles of one scene stepped in ONE process on one GPU (the exchange between them is then a device copy; between
+processes it is RCCL - same code path apart from the transfer primitive), bit for bit, tile by tile.  Includes BASELINE
+config 4 at full size: 1 048 576 spheres as 8 tiles of 16 x 128 x 64."""
+import numpy as np
+import pytest
+
+import mgf_amd
+from mgf_amd import scenes
+from tests.util import values_equal
+
+pytestmark = pytest.mark.gpu
+STATE_KEYS = ("x", "q", "v", "omega", "delta")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = mgf_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _native(ctx, tile_scenes, **kw):
+    worlds = []
+    for sc in tile_scenes:
+        w = mgf_amd.World.from_scene(ctx, sc)
+        w.set_tags(sc["tags"])
+        worlds.append(w)
+    return mgf_amd.Tiles(ctx, worlds, [sc["x_range"] for sc in tile_scenes], **kw), worlds
+
+
+def _oracle_tiles(tile_scenes, **kw):
+    from mgf_amd.tiles import Tile
+    from tests.oracle_engine import OracleEngine
+    P = len(tile_scenes)
+    return [Tile(OracleEngine(sc), sc["x_range"], r, P, sc["dt"], sc["iters"], **kw) for r, sc in enumerate(tile_scenes)]
+
+
+def _assert_equal(worlds, ot, what):
+    for r, (w, o) in enumerate(zip(worlds, ot)):
+        assert len(w) == len(o.e.w), f"{what}: tile {r} owns {len(w)} bodies, oracle {len(o.e.w)}"
+        assert np.array_equal(w.tags(), o.e.tags()), f"{what}: tile {r} body order"
+        sg, so = w.state(), o.e.state()
+        for k in STATE_KEYS:
+            assert values_equal(sg[k], so[k]), f"{what}: tile {r} {k}"
+
+
+@pytest.mark.parametrize("P,refresh_every", [(2, 2), (3, 2), (4, 1), (3, 10)])
+def test_native_tiles_match_the_oracle_tiles_with_hand_overs(ctx, P, refresh_every):
+    """A pile drifting at 5 m/s through P tiles: ghost exchange, velocity refresh every R iterations, bodies changing owner."""
+    from mgf_amd.tiles import step_tiles_inprocess
+    nx, ny, nz = 4, 4, 5
+    tile_scenes = [scenes.sphere_pile_tile(nx, ny, nz, r, P, drift=(5.0, 0.0, 0.0)) for r in range(P)]
+    T, worlds = _native(ctx, tile_scenes, refresh_every=refresh_every)
+    ot = _oracle_tiles(tile_scenes, refresh_every=refresh_every)
+    dt, iters = float(tile_scenes[0]["dt"]), tile_scenes[0]["iters"]
+    for tick in range(40):
+        sg, so = T.step(dt, iters), step_tiles_inprocess(ot)
+        for r in range(P):
+            assert sg[r].n_constraints == so[r]["n_constraints"], f"tick {tick} tile {r}"
+        assert [T.migrated(r) for r in range(P)] == [t.n_migrated_in for t in ot], f"tick {tick}"
+        if tick % 8 == 7:
+            _assert_equal(worlds, ot, f"tick {tick}")
+    assert sum(T.migrated(r) for r in range(P)) >= ny * nz and T.migrated(P - 1) > 0 and T.migrated(0, incoming=False) > 0
+    _assert_equal(worlds, ot, "end")
+    assert np.array_equal(np.sort(np.concatenate([w.tags() for w in worlds])), np.arange(P * nx * ny * nz))
+
+
+def test_native_tiles_equal_the_python_driver(ctx):
+    """mgf_tiles_step and mgf_amd.tiles.step_tiles_inprocess are the same protocol: same bits, capsules over a heightfield
+    included (terrain constraints stay with the owner, ghosts bring another body kind)."""
+    from mgf_amd.tiles import HipEngine, Tile, step_tiles_inprocess
+    P = 3
+    tile_scenes = [scenes.sphere_pile_tile(5, 4, 4, r, P, drift=(-3.0, 0.0, 0.0)) for r in range(P)]
+    T, worlds = _native(ctx, tile_scenes)
+    py = [Tile(HipEngine(ctx, sc, 0), sc["x_range"], r, P, sc["dt"], sc["iters"]) for r, sc in enumerate(tile_scenes)]
+    dt, iters = float(tile_scenes[0]["dt"]), tile_scenes[0]["iters"]
+    for tick in range(30):
+        sg, sp = T.step(dt, iters), step_tiles_inprocess(py)
+        assert [int(s.n_constraints) for s in sg] == [int(s["n_constraints"]) for s in sp], tick
+    for r in range(P):
+        assert np.array_equal(worlds[r].tags(), py[r].e.tags())
+        a, b = worlds[r].state(), py[r].e.state()
+        for k in STATE_KEYS:
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (r, k)
+    assert sum(T.migrated(r) for r in range(P)) > 0
+
+
+def test_one_rank_communicator_and_preflight(ctx):
+    """RCCL is loaded at run time and a communicator of one rank comes up on the box's GPU: the pre-flight sum sees 1 rank,
+    and a connected set of tiles without remote neighbours steps like an unconnected one."""
+    tile_scenes = [scenes.sphere_pile_tile(4, 4, 4, r, 2) for r in range(2)]
+    A, wa = _native(ctx, tile_scenes)
+    B, wb = _native(ctx, tile_scenes)
+    assert A.preflight() == 0
+    uid = mgf_amd.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    A.connect(uid, 0, 1)
+    assert A.preflight() == 1
+    dt, iters = float(tile_scenes[0]["dt"]), tile_scenes[0]["iters"]
+    for _ in range(12):
+        A.step(dt, iters)
+        B.step(dt, iters)
+    for x, y in zip(wa, wb):
+        sx, sy = x.state(), y.state()
+        for k in STATE_KEYS:
+            assert np.array_equal(sx[k].view(np.uint32), sy[k].view(np.uint32)), k
+
+
+def test_config4_one_million_spheres_as_eight_tiles(ctx):
+    """BASELINE config 4 at full size on one GPU: 128 x 128 x 64 spheres cut into 8 x-slabs of 16 lattice columns, the first
+    tick and a later, contact-rich tick (the oracle teacher-forced from the GPU's state) bit-identical to the oracle's 8 tiles."""
+    from mgf_amd.tiles import step_tiles_inprocess
+    P, nx, ny, nz = 8, 16, 128, 64
+    tile_scenes = [scenes.sphere_pile_tile(nx, ny, nz, r, P) for r in range(P)]
+    assert sum(len(sc["comps"]) for sc in tile_scenes) == 1048576
+    T, worlds = _native(ctx, tile_scenes)
+    ot = _oracle_tiles(tile_scenes)
+    dt, iters = float(tile_scenes[0]["dt"]), tile_scenes[0]["iters"]
+    sg, so = T.step(dt, iters), step_tiles_inprocess(ot)
+    assert [int(s.n_constraints) for s in sg] == [int(s["n_constraints"]) for s in so]
+    _assert_equal(worlds, ot, "first tick")
+    for _ in range(14):
+        sg = T.step(dt, iters)
+    assert sum(int(s.n_constraints) for s in sg) > 1000000
+    for w, o in zip(worlds, ot):  # no body has changed tile yet: the oracle tiles take the GPU's state as it is
+        assert np.array_equal(w.tags(), o.e.tags())
+        s = w.state()
+        o.e.w.set_state(x=s["x"], q=s["q"], v=s["v"], omega=s["omega"], delta=s["delta"])
+    sg, so = T.step(dt, iters), step_tiles_inprocess(ot)
+    assert [int(s.n_constraints) for s in sg] == [int(s["n_constraints"]) for s in so]
+    _assert_equal(worlds, ot, "later tick")
+    print("config 4, 8 tiles: constraints per tile", [int(s.n_constraints) for s in sg])
