@@ -3,11 +3,21 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A "step" is one physics tick (mgf_demo/world.rs::World::step) of the BASELINE.json config-2
-workload: a 262 144-sphere pile (64^3 jittered lattice, r = 0.5, seed 0x6D6766) in an open box,
-dt = 1/60, 10 solver iterations, per GPU (weak scaling: x-slab tiles side by side for N > 1).
-metric = contact-constraint-iterations per second over the WHOLE tick (one unit = one
-ContactConstraint::solve call, solver.rs:203), whole-job aggregate over all ranks.
+A "step" is one physics tick (mgf_demo/world.rs::World::step): complete_motion, integrate, broadphase, narrowphase,
+ContactConstraint::new for every contact, Solver::solve(10 iterations).
+metric = contact-constraint-iterations per second over the WHOLE tick (one unit = one ContactConstraint::solve call,
+solver.rs:203), whole-job aggregate over all ranks; a constraint across a tile face is counted once.
+
+Workloads (BASELINE.json `configs`):
+  N = 1   config 2 - a 262 144-sphere pile (64^3 jittered lattice, r = 0.5, seed 0x6D6766) in an open box, one world.
+          The K timed ticks follow the W warm-up ticks of the falling pile; the window is repeated from a snapshot until a
+          second of GPU time has been measured (median window reported), and a second window after tick 400 (the settled
+          pile, twice the constraints) is reported under "settled".
+  N > 1   config 4 - 1 048 576 spheres (128 x 128 x 64) cut into 8 x-slab tiles of 16 lattice columns; rank r owns 8 / N
+          consecutive tiles (strong scaling: the same scene, the same 8-tile decomposition and the same results at every N),
+          neighbour exchange between tiles of a rank by device copies and between ranks by RCCL send/recv over xGMI, all
+          under the C-ABI (mgf_tiles_*).  `--scene weak` gives every rank one tile of --tile spheres instead;
+          `--gpus 1 --scene config4` runs the 8 tiles on one GPU.
 """
 import argparse
 import json
@@ -22,6 +32,13 @@ sys.path.insert(0, ROOT)
 
 SOLVE_BYTES_PER_UNIT = 288  # algorithmic bytes per ContactConstraint::solve call
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
+KERNEL_NAMES = {6: "k_solve_flow6 (ContactConstraint::solve, block-local persistent dataflow launch with message channels",
+                5: "k_solve_flow5 (ContactConstraint::solve, block-local persistent dataflow launch",
+                1: "k_solve_flow (ContactConstraint::solve, persistent dataflow launch",
+                4: "k_solve_flowk (ContactConstraint::solve, persistent dataflow launch",
+                0: "k_solve (ContactConstraint::solve, one launch per dependency frontier"}
+SCENE_NOTE = ("body order = argsort of SplitMix64 keys (SURVEY 8d names a Fisher-Yates shuffle of the same generator: another "
+              "fixed permutation, same statistics)")
 
 
 def main():
@@ -29,16 +46,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--tile", type=int, nargs=3, default=[64, 64, 64], help="spheres per GPU (nx ny nz)")
+    ap.add_argument("--scene", default="auto", choices=["auto", "config2", "config4", "weak"])
+    ap.add_argument("--tile", type=int, nargs=3, default=[64, 64, 64], help="spheres per tile (nx ny nz): config 2's world, or --scene weak's tile")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="N = 1: repeat the timed window from a snapshot until this much has been measured")
+    ap.add_argument("--no-settled", action="store_true", help="N = 1: skip the second window after tick 400")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--solver-mode", type=int, default=None, help="override the library's default solver mode (development)")
-    ap.add_argument("--refresh-every", type=int, default=None, help="solver iterations between ghost velocity refreshes (multi-GPU; default: mgf_amd.tiles.DEFAULT_REFRESH_EVERY)")
+    ap.add_argument("--refresh-every", type=int, default=None, help="solver iterations between ghost velocity refreshes (tiles)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="library option for an experiment (mgf_world_set_option), repeatable")
-    ap.add_argument("--no-migrate", action="store_true", help="multi-GPU: keep every body on its initial tile (development: cost of the hand-over check)")
+    ap.add_argument("--no-migrate", action="store_true", help="tiles: keep every body on its initial tile (development)")
+    ap.add_argument("--transport", default="native", choices=["native", "torch"],
+                    help="native = mgf_tiles_* (RCCL under the C-ABI); torch = the Python driver over torch.distributed (--scene weak only)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI (default); gloo = host-staged exchange, for validating the multi-rank flow on one GPU")
+                    help="torch.distributed backend of the rendezvous / barrier (and of --transport torch): nccl = RCCL; gloo = host-staged, "
+                         "for validating the multi-rank flow on one GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -49,6 +71,13 @@ def main():
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
+    scene_kind = args.scene
+    if scene_kind == "auto":
+        scene_kind = "config2" if world_size == 1 else "config4"
+    if scene_kind == "config2" and world_size > 1:
+        raise SystemExit("config 2 is the single-GPU workload; use --scene config4 or --scene weak with --gpus N")
+    if scene_kind == "config4" and 8 % world_size:
+        raise SystemExit("config 4 is cut into 8 tiles: --gpus must be 1, 2, 4 or 8")
 
     import torch
     dist = None
@@ -61,57 +90,182 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world_size)
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     import mgf_amd
     from mgf_amd import scenes
-    from mgf_amd.tiles import DEFAULT_REFRESH_EVERY, TiledWorld
+    from mgf_amd.tiles import DEFAULT_REFRESH_EVERY
     refresh_every = args.refresh_every or DEFAULT_REFRESH_EVERY
-
-    nx, ny, nz = args.tile
     ctx = mgf_amd.Context(dev_index)
-    tw = TiledWorld(ctx, rank, world_size, nx, ny, nz, iters=args.iters, dist=dist, device=dev_index,
-                    host_staging=(args.backend == "gloo"), refresh_every=refresh_every, migrate=not args.no_migrate)
-    red_dev = "cuda" if args.backend == "nccl" else "cpu"
-    dt = tw.dt
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize() if torch.cuda.is_available() else None
 
-    if args.solver_mode is not None:
-        tw.world.set_option("solver_mode", args.solver_mode)
-    for kv in args.opt:
-        key, val = kv.split("=")
-        tw.world.set_option(key, int(val))
-    # HIP events around the dominant kernel (k_solve_flow) on the stream it is launched on, inside the timed region
-    tw.world.set_option("time_solver_kernels", 1)
+    def configure(world):
+        if args.solver_mode is not None:
+            world.set_option("solver_mode", args.solver_mode)
+        for kv in args.opt:
+            key, val = kv.split("=")
+            world.set_option(key, int(val))
+        world.set_option("time_solver_kernels", 1)  # HIP events around the dominant kernel on the stream it is launched on
+
+    mode = args.solver_mode if args.solver_mode is not None else 6
+    if scene_kind == "config2":
+        out = bench_single_world(args, ctx, mgf_amd, scenes, configure, mode)
+    else:
+        out = bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, world_size, dist, torch, red_dev, barrier, refresh_every)
+    if rank == 0:
+        if world_size == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.iters)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _window_stats(per_tick, iters):
+    units = sum(int(st["n_constraints"]) * iters for st in per_tick)
+    cons = sum(int(st["n_constraints"]) for st in per_tick)
+    launches = sum(int(st["solver_kernel_launches"]) for st in per_tick)
+    kms = sum(float(st["ms_solver_kernels"]) for st in per_tick)
+    phase = {k: sum(float(st[k]) for st in per_tick) / len(per_tick) for k in ("ms_integrate", "ms_broadphase", "ms_narrowphase", "ms_setup", "ms_solve")}
+    return units, cons, launches, kms, phase
+
+
+def _roofline(units, launches, kms, mode, what, window):
+    if not (kms > 0 and launches > 0):
+        return None
+    achieved = units * SOLVE_BYTES_PER_UNIT / (kms * 1e-3) / 1e9
+    traffic, source = _pmc_traffic(mode, window)
+    return {"bound": "hbm", "kernel": KERNEL_NAMES[mode] + ": " + what + ")", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": source, "bytes_per_unit": SOLVE_BYTES_PER_UNIT,
+            "avg_launch_us": round(kms * 1e3 / launches, 3), "avg_units_per_launch": round(units / launches, 1), "launches_timed": int(launches)}
+
+
+def bench_single_world(args, ctx, mgf_amd, scenes, configure, mode):
+    nx, ny, nz = args.tile
+    scene = scenes.sphere_pile(nx, ny, nz)
+    dt = float(scene["dt"])
+    world = mgf_amd.World.from_scene(ctx, scene)
+    configure(world)
     for _ in range(args.warmup):
-        tw.step()
+        world.step(dt, args.iters)
+    # the timed window: K ticks through the C-ABI's own loop (mgf_world_step_many: World::step K times, one synchronisation per
+    # tick), repeated from a snapshot (mgf_world_clone) so that the measurement covers >= --min-seconds whatever K is
+    snap = world.clone()
+    windows = []
+    total = 0.0
+    while not windows or (total < args.min_seconds and len(windows) < 200):
+        w = snap.clone()
+        configure(w)
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        per_tick = w.step_many(dt, args.iters, args.steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        windows.append((el, _window_stats(per_tick, args.iters)))
+        total += el
+        del w
+    windows.sort(key=lambda x: x[0])
+    elapsed, (units, cons, launches, kms, phase) = windows[len(windows) // 2]
+    window_name = f"ticks {args.warmup}..{args.warmup + args.steps} of the falling pile"
+    out = {
+        "metric": "contact_constraint_iters_per_sec", "value": units / elapsed, "unit": "constraint-iters/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 2: {nx * ny * nz} spheres ({nx}x{ny}x{nz} jittered lattice pile, r=0.5, seed 0x6D6766) in an open "
+                               f"box, dt=1/60, {args.iters} solver iters; {window_name}; {SCENE_NOTE}",
+                   "bodies_total": nx * ny * nz, "iters": args.iters, "dt": dt,
+                   "constraint_order": "canonical (i asc; terrain DFS; partners j<i asc)", "parallelism": "1 GPU"},
+        "timed_region": {"windows": len(windows), "seconds": round(total, 3), "reported": "median window",
+                         "ms_per_step_min": windows[0][0] * 1e3 / args.steps, "ms_per_step_max": windows[-1][0] * 1e3 / args.steps},
+        "physics_steps_per_sec": args.steps / elapsed, "constraints_per_step": cons / args.steps,
+        "solver_launches_per_step": launches / args.steps, "phase_ms_per_step_rank0": phase,
+        "solve_phase_constraint_iters_per_sec_rank0": units / (phase["ms_solve"] * args.steps * 1e-3) if phase["ms_solve"] > 0 else None,
+        "roofline": _roofline(units, launches, kms, mode, "all iterations of a tick", ("transient", args.warmup, args.steps)),
+    }
+    if not args.no_settled:
+        # the settled pile (what the workload spends its life in): twice the constraints, deeper dependency graph
+        while_ticks = max(0, 400 - args.warmup - args.steps)
+        w = world
+        w.step_many(dt, args.iters, args.steps)
+        if while_ticks:
+            w.step_many(dt, args.iters, while_ticks)
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        per_tick = w.step_many(dt, args.iters, args.steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        u2, c2, l2, k2, p2 = _window_stats(per_tick, args.iters)
+        out["settled"] = {"window": f"ticks {args.warmup + args.steps + while_ticks}..{args.warmup + 2 * args.steps + while_ticks}", "value": u2 / el,
+                          "ms_per_step": el * 1e3 / args.steps, "constraints_per_step": c2 / args.steps, "phase_ms_per_step": p2,
+                          "roofline": _roofline(u2, l2, k2, mode, "all iterations of a tick", ("settled", 400, args.steps))}
+    return out
+
+
+def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, world_size, dist, torch, red_dev, barrier, refresh_every):
+    if scene_kind == "config4":
+        total_tiles, (nx, ny, nz) = 8, (16, 128, 64)
+    else:
+        total_tiles, (nx, ny, nz) = world_size, tuple(args.tile)
+    per_rank = total_tiles // world_size
+    first = rank * per_rank
+    tile_scenes = [scenes.sphere_pile_tile(nx, ny, nz, first + k, total_tiles, iters=args.iters) for k in range(per_rank)]
+    dt = float(tile_scenes[0]["dt"])
+    transport = args.transport
+    ranks_seen = None
+    if transport == "torch":
+        if scene_kind != "weak" or per_rank != 1:
+            raise SystemExit("--transport torch drives one tile per rank (--scene weak)")
+        from mgf_amd.tiles import TiledWorld
+        tw = TiledWorld(ctx, rank, world_size, nx, ny, nz, iters=args.iters, dist=dist, device=int(os.environ.get("MGF_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0"))),
+                        host_staging=(args.backend == "gloo"), refresh_every=refresh_every, migrate=not args.no_migrate)
+        configure(tw.world)
+        step = lambda: [tw.step()]  # noqa: E731
+    else:
+        worlds = []
+        for sc in tile_scenes:
+            w = mgf_amd.World.from_scene(ctx, sc)
+            w.set_tags(sc["tags"])
+            configure(w)
+            worlds.append(w)
+        tiles = mgf_amd.Tiles(ctx, worlds, [sc["x_range"] for sc in tile_scenes], first_tile=first, n_tiles_total=total_tiles,
+                              refresh_every=refresh_every, migrate=not args.no_migrate)
+        if world_size > 1:
+            # pre-flight: the RCCL communicator under the C-ABI comes up and sees every rank (rank 0's id travels by torch.distributed)
+            uid = torch.zeros(128, dtype=torch.uint8, device=red_dev)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(mgf_amd.rccl_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            tiles.connect(bytes(uid.cpu().numpy().tobytes()), rank, world_size)
+            ranks_seen = tiles.preflight()
+            if ranks_seen != world_size:
+                raise SystemExit(f"RCCL pre-flight: {ranks_seen} ranks answered, {world_size} expected")
+        step = lambda: tiles.step(dt, args.iters)  # noqa: E731
+    for _ in range(args.warmup):
+        step()
     barrier()
     t0 = time.perf_counter()
-    units = 0
-    cons = 0
-    phase = dict(ms_integrate=0.0, ms_broadphase=0.0, ms_narrowphase=0.0, ms_setup=0.0, ms_solve=0.0)
-    launches = 0
-    levels = []
-    kms = 0.0
-    if tw.tile is None:
-        # one GPU: the K ticks through the C-ABI's own loop (mgf_world_step_many: World::step K times, one synchronisation
-        # per tick as always) - what a compiled host does; the per-tick statistics come back as an array
-        per_tick = tw.world.step_many(dt, args.iters, args.steps)
-    else:
-        per_tick = [tw.step() for _ in range(args.steps)]
+    ticks = [step() for _ in range(args.steps)]
     barrier()
     elapsed = time.perf_counter() - t0
-    for st in per_tick:
-        units += st["n_constraints"] * args.iters
-        cons += st["n_constraints"]
-        launches += st["solver_kernel_launches"]
-        levels.append(st["n_levels"])
-        kms += st["ms_solver_kernels"]
-        for k in phase:
-            phase[k] += st[k]
+    units = cons = launches = 0
+    kms = 0.0
+    phase = dict(ms_integrate=0.0, ms_broadphase=0.0, ms_narrowphase=0.0, ms_setup=0.0, ms_solve=0.0)
+    for tick in ticks:
+        for st in tick:
+            ghost = int(st["n_ghost_constraints"]) if "n_ghost_constraints" in _keys(st) else 0
+            c = int(st["n_constraints"]) - ghost / 2.0  # a constraint across a tile face exists on both tiles: half each
+            cons += c
+            units += c * args.iters
+            launches += int(st["solver_kernel_launches"])
+            kms += float(st["ms_solver_kernels"])
+            for k in phase:
+                phase[k] += float(st[k])
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -121,87 +275,99 @@ def main():
         units_all, cons_all = float(u[0].item()), float(u[1].item())
     else:
         units_all, cons_all = float(units), float(cons)
-
-    # ---- roofline of the dominant kernel, rank 0: algorithmic bytes of the timed launches / their HIP-event time
-    roofline = None
-    if rank == 0 and kms > 0 and launches > 0:
-        achieved = units * SOLVE_BYTES_PER_UNIT / (kms * 1e-3) / 1e9
-        mode = args.solver_mode if args.solver_mode is not None else 5
-        kname = {6: "k_solve_flow6 (ContactConstraint::solve, block-local persistent dataflow launch with message channels", 5: "k_solve_flow5 (ContactConstraint::solve, block-local persistent dataflow launch", 1: "k_solve_flow (ContactConstraint::solve, persistent dataflow launch",
-                 4: "k_solve_flowk (ContactConstraint::solve, persistent dataflow launch", 0: "k_solve (ContactConstraint::solve, one launch per dependency frontier"}[mode]
-        roofline = {"bound": "hbm", "kernel": kname + ": " + ("all iterations of a tick" if world_size == 1 else f"{refresh_every} iteration(s) between ghost refreshes") + ")",
-                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": _pmc_traffic(),
-                    "bytes_per_unit": SOLVE_BYTES_PER_UNIT,
-                    "avg_launch_us": round(kms * 1e3 / launches, 3), "launches_per_step": round(launches / args.steps, 2),
-                    "avg_units_per_launch": round(units / launches, 1),
-                    "launches_timed": int(launches)}
-
-    # ---- CPU baseline: the oracle (C++ restatement of mgf), 1 core, bounded sample -------------
-    cpu = None
-    if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(nx, ny, nz, args.iters, args.cpu_steps)
-
-    if rank == 0:
-        out = {
-            "metric": "contact_constraint_iters_per_sec", "value": units_all / elapsed,
-            "unit": "constraint-iters/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 2: {nx * ny * nz} spheres/GPU ({nx}x{ny}x{nz} jittered lattice pile, r=0.5, "
-                                   f"seed 0x6D6766) in an open box, dt=1/60, {args.iters} solver iters"
-                                   + ("" if world_size == 1 else f"; {world_size} x-slab tiles side by side, ghost halo over RCCL"),
-                       "bodies_per_gpu": nx * ny * nz, "bodies_total": nx * ny * nz * world_size, "iters": args.iters,
-                       "dt": dt, "constraint_order": "canonical (i asc; terrain DFS; partners j<i asc)",
-                       "parallelism": "1 GPU" if world_size == 1 else f"{world_size} spatial x-slabs, neighbour halo exchange (ghost bodies once per tick, ghost velocities every {refresh_every} solver iterations, bodies handed to the tile that holds their centre" + ("" if not args.no_migrate else " - DISABLED") + ")"},
-            "physics_steps_per_sec": args.steps / elapsed,
-            "constraints_per_step": cons_all / args.steps,
-            "solver_levels_mean": float(np.mean(levels)), "solver_launches_per_step": launches / args.steps,
-            "phase_ms_per_step_rank0": {k: v / args.steps for k, v in phase.items()},
-            "solve_phase_constraint_iters_per_sec_rank0": units / (phase["ms_solve"] * 1e-3) if phase["ms_solve"] > 0 else None,
-            "roofline": roofline, "cpu_baseline": cpu,
-        }
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    n_total = nx * ny * nz * total_tiles
+    name = (f"BASELINE config 4: {n_total} spheres ({total_tiles * nx}x{ny}x{nz} jittered lattice pile, r=0.5, seed 0x6D6766) in one open box, cut into "
+            f"{total_tiles} x-slab tiles of {nx} lattice columns" if scene_kind == "config4" else
+            f"{n_total} spheres: {total_tiles} x-slab tiles of {nx}x{ny}x{nz} side by side in one open box (weak scaling of BASELINE config 2's tile)")
+    return {
+        "metric": "contact_constraint_iters_per_sec", "value": units_all / elapsed, "unit": "constraint-iters/s", "n_gpus": world_size,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+        "scaling": "strong" if scene_kind == "config4" else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{name}, dt=1/60, {args.iters} solver iters; {per_rank} tile(s) per GPU; ghost bodies once per tick, ghost velocities every "
+                               f"{refresh_every} solver iterations, bodies handed to the tile that holds their centre"
+                               + (" - DISABLED" if args.no_migrate else "") + f"; {SCENE_NOTE}",
+                   "bodies_total": n_total, "tiles_total": total_tiles, "tiles_per_gpu": per_rank, "iters": args.iters, "dt": dt,
+                   "constraint_order": "canonical inside a tile (i asc; terrain DFS; partners j<i asc); block-Jacobi across tile faces",
+                   "parallelism": f"{world_size} GPU(s) x {per_rank} tile(s); exchange between a rank's tiles by device copies"
+                                  + ("" if world_size == 1 else (", between ranks by RCCL send/recv over xGMI under the C-ABI (mgf_tiles_*)" if transport == "native"
+                                                                 else f", between ranks by torch.distributed ({args.backend})"))},
+        "transport": transport, "rccl_ranks_seen": ranks_seen,
+        "physics_steps_per_sec": args.steps / elapsed, "constraints_per_step": cons_all / args.steps,
+        "solver_launches_per_step_rank0": launches / args.steps,
+        # (a rank's tiles share one stream and their phases are enqueued interleaved: per-phase event spans of one tile include
+        # the other tiles' work, so only the solver kernels' own event time is reported)
+        "solver_kernel_ms_per_tile_tick_rank0": kms / (args.steps * per_rank),
+        "tile_tick_ms_rank0": elapsed * 1e3 / (args.steps * per_rank),
+        "roofline": _roofline(units, launches, kms, mode, f"{refresh_every} iteration(s) of one tile between ghost refreshes", ("tiles", args.warmup, args.steps)),
+    }
 
 
-def _pmc_traffic():
-    """HBM bytes per k_solve launch from committed rocprofv3 PMC passes (profiles/), or None."""
-    p = os.path.join(ROOT, "profiles", "pmc_k_solve_flow5.json")
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get("hbm_bytes_per_launch")
-        except Exception:
-            return None
-    return None
+def _keys(st):
+    return [f[0] for f in st._fields_] if hasattr(st, "_fields_") else list(st.keys())
 
 
-def cpu_baseline(nx, ny, nz, iters, steps):
-    """The reference is single-threaded Rust that cannot be built here; its CPU path is timed as the
-    oracle's C++ restatement ("port") on 1 host core, on the first `steps` ticks of the same scene."""
+def _pmc_traffic(mode, window):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_k_solve_flow*.json),
+    only when they were collected on the window this run timed; else (None, why)."""
+    p = os.path.join(ROOT, "profiles", f"pmc_k_solve_flow{mode}.json")
+    if not os.path.exists(p):
+        return None, "no PMC pass committed for this kernel"
+    try:
+        d = json.load(open(p))
+    except Exception:
+        return None, "unreadable PMC summary"
+    if d.get("window") != list(window):
+        return None, f"the committed PMC pass covers window {d.get('window')}, this run {list(window)}"
+    return d.get("hbm_bytes_per_launch"), f"{os.path.relpath(p, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same window)"
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(iters):
+    """The reference is single-threaded Rust that cannot be built here; its CPU path is timed as the oracle's C++ restatement
+    ("port") on 1 host core, in the reference's own (world.rs) constraint order, on bounded samples of BASELINE configs 1-3."""
     from mgf_amd import scenes
     from oracle import oracle as O
-    scene = scenes.sphere_pile(nx, ny, nz)
-    w = O.World(O.ORDER_DEMO)
-    t = scene["terrain"]
-    w.set_terrain(t["verts"], t["faces"], t["pos"])
-    w.add_bodies(scene["comps"], scene["mass"], scene["restitution"], scene["friction"], scene["force"])
-    w.set_state(v=scene["v0"])
-    units = 0
-    solve_s = 0.0
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        st = w.step(float(scene["dt"]), iters)
-        units += st.n_constraints * iters
-        solve_s += st.t_solve
-    el = time.perf_counter() - t0
-    return {"value": units / el, "unit": "constraint-iters/s", "cores": 1, "kind": "port",
-            "sample": f"first {steps} ticks of the same {nx * ny * nz}-sphere scene, world.rs order, {el:.1f} s of CPU work",
-            "physics_steps_per_sec": steps / el, "solve_phase_constraint_iters_per_sec": units / solve_s if solve_s > 0 else None,
-            "host_cpus_visible": os.cpu_count()}
+
+    def run(scene, steps, budget_s):
+        w = O.World(O.ORDER_DEMO)
+        t = scene["terrain"]
+        w.set_terrain(t["verts"], t["faces"], t["pos"])
+        w.add_bodies(scene["comps"], scene["mass"], scene["restitution"], scene["friction"], scene["force"])
+        if scene.get("v0") is not None:
+            w.set_state(v=scene["v0"])
+        units, solve_s, done = 0, 0.0, 0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st = w.step(float(scene["dt"]), iters)
+            units += st.n_constraints * iters
+            solve_s += st.t_solve
+            done += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+        el = time.perf_counter() - t0
+        return {"constraint_iters_per_sec": units / el if el > 0 else None, "physics_steps_per_sec": done / el, "steps": done, "seconds": round(el, 2),
+                "solve_phase_constraint_iters_per_sec": units / solve_s if solve_s > 0 else None}
+
+    c2 = run(scenes.sphere_pile(64, 64, 64), 3, 12.0)
+    c1 = run(scenes.balls_demo(8), 400, 6.0)
+    c3 = run(scenes.capsule_field(128, 32, 32, quads=158, y0=0.9), 2, 8.0)
+    return {"value": c2["constraint_iters_per_sec"], "unit": "constraint-iters/s", "cores": 1, "kind": "port",
+            "sample": f"first {c2['steps']} ticks of config 2 (262144 spheres), world.rs order, {c2['seconds']} s of CPU work",
+            "physics_steps_per_sec": c2["physics_steps_per_sec"], "solve_phase_constraint_iters_per_sec": c2["solve_phase_constraint_iters_per_sec"],
+            "cpu_model": _cpu_model(), "nproc": os.cpu_count(),
+            "config1_balls_512": c1, "config3_capsules_131072": c3,
+            "note": "C++ restatement of mgf (g++ -O2 -ffp-contract=off), not rustc output; the reference is single-threaded"}
 
 
 if __name__ == "__main__":

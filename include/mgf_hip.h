@@ -102,6 +102,8 @@ typedef struct mgf_step_stats {
   float ms_integrate, ms_broadphase, ms_narrowphase, ms_setup, ms_solve, ms_total; /* HIP-event times */
   uint64_t solver_kernel_launches; /* number of solver kernel launches this tick     */
   float ms_solver_kernels;         /* sum of their HIP-event durations (0 if not timed) */
+  uint64_t n_ghost_constraints;    /* of n_constraints: those whose obj_a is a ghost body of a neighbouring tile - a constraint across
+                                      a tile face exists on both tiles, on each with the other tile's body as obj_a (0 without tiles) */
 } mgf_step_stats;
 
 /* Particle (geom.rs:802-855): a Ray { p, d } has dt = INFINITY; a Segment { a, b } is p = a, d = b - a, dt = 1. */

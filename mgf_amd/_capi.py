@@ -86,7 +86,7 @@ class StepStats(C.Structure):
                 ("n_levels", C.c_uint32), ("iters", C.c_uint32),
                 ("ms_integrate", C.c_float), ("ms_broadphase", C.c_float), ("ms_narrowphase", C.c_float),
                 ("ms_setup", C.c_float), ("ms_solve", C.c_float), ("ms_total", C.c_float),
-                ("solver_kernel_launches", C.c_uint64), ("ms_solver_kernels", C.c_float)]
+                ("solver_kernel_launches", C.c_uint64), ("ms_solver_kernels", C.c_float), ("n_ghost_constraints", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -319,8 +319,11 @@ __global__ void k_caps_candidates(const uint32_t* mt, const uint32_t* mp, uint32
   r.ct_sum = 0;
   *sc = r;
 }
-__global__ void k_caps_constraints(const uint32_t* c, const uint32_t* ct, uint32_t cap_c, StepCounts* sc) {
+__global__ void k_caps_constraints(const uint32_t* c, const uint32_t* ct, uint32_t cap_c, StepCounts* sc, const uint32_t* first_ghost,
+                                   uint32_t* n_ghost_cons) {
+  *n_ghost_cons = 0;
   if (sc->fail) return;
+  *n_ghost_cons = *c - *first_ghost;  // constraints whose obj_a is a ghost (ids are ascending in obj_a): the copies of seam constraints
   sc->need_C = *c; sc->need_Ct = *ct;
   if (*c > cap_c) { sc->fail |= kFailConsCap; sc->Mt = 0; sc->Mp = 0; sc->C = 0; sc->Ct = 0; return; }
   sc->C = *c; sc->Ct = *ct;
