@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=1.0, help="N = 1: repeat the timed window from a snapshot until this much has been measured")
     ap.add_argument("--no-settled", action="store_true", help="N = 1: skip the second window after tick 400")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-order-check", action="store_true", help="N = 1: skip the canonical-vs-world.rs-order deviation (a few seconds of host BVH replay)")
     ap.add_argument("--solver-mode", type=int, default=None, help="override the library's default solver mode (development)")
     ap.add_argument("--refresh-every", type=int, default=None, help="solver iterations between ghost velocity refreshes (tiles)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="library option for an experiment (mgf_world_set_option), repeatable")
@@ -187,6 +188,8 @@ def bench_single_world(args, ctx, mgf_amd, scenes, configure, mode):
         "solve_phase_constraint_iters_per_sec_rank0": units / (phase["ms_solve"] * args.steps * 1e-3) if phase["ms_solve"] > 0 else None,
         "roofline": _roofline(units, launches, kms, mode, "all iterations of a tick", ("transient", args.warmup, args.steps)),
     }
+    if not args.no_order_check:
+        out["constraint_order_deviation"] = order_deviation(ctx, mgf_amd, scene, dt, args.iters)
     if not args.no_settled:
         # the settled pile (what the workload spends its life in): twice the constraints, deeper dependency graph
         while_ticks = max(0, 400 - args.warmup - args.steps)
@@ -204,6 +207,24 @@ def bench_single_world(args, ctx, mgf_amd, scenes, configure, mode):
         out["settled"] = {"window": f"ticks {args.warmup + args.steps + while_ticks}..{args.warmup + 2 * args.steps + while_ticks}", "value": u2 / el,
                           "ms_per_step": el * 1e3 / args.steps, "constraints_per_step": c2 / args.steps, "phase_ms_per_step": p2,
                           "roofline": _roofline(u2, l2, k2, mode, "all iterations of a tick", ("settled", 400, args.steps))}
+    return out
+
+
+def order_deviation(ctx, mgf_amd, scene, dt, iters, ticks=(1,)):
+    """The HIP path inserts constraints in canonical order; the reference's own order (world.rs:233-291) is available as
+    option constraint_order = 1 (host replay of the world BVH).  Same constraint SET, different Gauss-Seidel order: the
+    deviation between the two on this scene, max |a - b| / max(1, |b|) over x, q, v, omega after the given ticks."""
+    a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
+    b.set_option("constraint_order", 1)
+    out, k = {}, 0
+    for target in ticks:
+        while k < target:
+            sa, sb = a.step(dt, iters), b.step(dt, iters)
+            k += 1
+        x, y = a.state(), b.state()
+        dev = max(float(np.max(np.abs(x[f].astype(np.float64) - y[f].astype(np.float64)) / np.maximum(1.0, np.abs(y[f].astype(np.float64))))) for f in ("x", "q", "v", "omega"))
+        out[f"after_tick_{target}"] = {"max_rel_deviation": dev, "constraints": int(sa.n_constraints), "same_constraint_count": int(sa.n_constraints) == int(sb.n_constraints)}
+    out["note"] = "canonical order (the timed path) vs the reference's world.rs order (option constraint_order = demo); the contract bar is 1e-4"
     return out
 
 

@@ -109,6 +109,21 @@ class HostBvh {
     }
   }
 
+  // BVH::query bvh.rs:283-310 on the host: every leaf whose bounds overlap `arg` (arg.overlaps(node), collision.rs:22-29), in the
+  // reference's visiting order (push lchild, push rchild, pop).
+  template <class F>
+  void query(const Box& arg, F&& on_leaf) const {
+    if (empty()) return;
+    std::vector<uint64_t> stack{root_};
+    while (!stack.empty()) {
+      const uint64_t top = stack.back(); stack.pop_back();
+      const Node& n = nodes_[top];
+      if (!box_overlaps(arg, n.box)) continue;
+      if (n.leaf) on_leaf(n.value);
+      else { stack.push_back(n.kid[0]); stack.push_back(n.kid[1]); }
+    }
+  }
+
   // Leaves in the order a full BVH::query visits them (bvh.rs:283-310: push lchild, push rchild, pop rchild first).
   // Any query reports its hits in this order, whatever it prunes - so a hit list can be found by other means and
   // sorted by rank.  rank_of_value[v] for leaf value v (values must be dense indices), leaf_of_value[v] = node id.

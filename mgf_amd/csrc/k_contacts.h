@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_terrain(Bodies B, const uint32_t
 // running offset of each candidate inside the body's block.
 __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint32_t n, const uint32_t* t_off, const uint32_t* p_off,
                                                            const uint32_t* t_nc, const uint32_t* p_nc, const uint32_t* p_cand, uint32_t* t_pre,
-                                                           uint32_t* p_pre, uint32_t* cnt) {
+                                                           uint32_t* p_pre, uint32_t* cnt, int keep_order) {
   constexpr int kHitCap = 12;  // a sphere touches at most 12 equal ones
   __shared__ uint32_t s_j[kHitCap][kBlock], s_p[kHitCap][kBlock];
   const int tid = threadIdx.x;
@@ -219,7 +219,8 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint3
     for (uint32_t a = 0; a < h; ++a) {
       const uint32_t j = s_j[a][tid];
       uint32_t before = 0;
-      for (uint32_t q = 0; q < h; ++q) before += s_j[q][tid] < j ? (s_p[q][tid] >> 28) : 0u;  // a partner's contacts (1, or up to 4 for bodies of several parts)
+      // a partner's contacts (1, or up to 4 for bodies of several parts); keep_order: the list IS the insertion order (world.rs order)
+      for (uint32_t q = 0; q < h; ++q) before += (keep_order ? q < a : s_j[q][tid] < j) ? (s_p[q][tid] >> 28) : 0u;
       p_pre[s_p[a][tid] & 0x0FFFFFFFu] = run + before;
     }
   } else {  // a crowded body: the same by rescanning its list
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint3
       if (p_nc && p_nc[p] == 0) continue;
       const uint32_t j = p_cand[p];
       uint32_t before = 0;
-      for (uint32_t q = lo; q < hi; ++q) before += (p_cand[q] < j) ? (p_nc ? p_nc[q] : 1u) : 0u;
+      for (uint32_t q = lo; q < hi; ++q) before += (keep_order ? q < p : p_cand[q] < j) ? (p_nc ? p_nc[q] : 1u) : 0u;
       p_pre[p] = run + before;
     }
   }

@@ -88,6 +88,68 @@ def test_full_size_tick_matches_oracle_and_properties(ctx, name):
           f"{st.n_pair_candidates} pair candidates, {st.n_terrain_candidates} terrain candidates")
 
 
+def test_config2_full_size_in_the_references_own_order(ctx):
+    """262 144 spheres with option constraint_order = demo: the host replays world.rs:233-291 (world BVH refit inside the
+    loop, partners in BVH::query order) and the device builds and solves the constraints in THAT order - the first ticks
+    bit-identical to the oracle run in world.rs order, i.e. comparable with the reference as the reference runs."""
+    import mgf_amd
+    from mgf_amd import scenes
+    scene = scenes.sphere_pile(64, 64, 64)
+    dt, iters = float(scene["dt"]), scene["iters"]
+    gw, ow = mgf_amd.World.from_scene(ctx, scene), oracle_world(scene, order=O.ORDER_DEMO)
+    gw.set_option("constraint_order", 1)
+    for tick in range(2):
+        ow.build_constraints(dt)
+        st = gw.build_constraints(dt)
+        got, want = gw.constraints(), ow.constraints()
+        compare_constraints(got, want)
+        if tick == 0:
+            a, b = want["a"], want["b"]
+            same = (a[1:] == a[:-1]) & (b[1:] >= 0) & (b[:-1] >= 0)
+            assert np.any(b[1:][same] < b[:-1][same])  # the order really is not the canonical one (partners not ascending)
+        ow.solve(iters)
+        gw.solve(iters)
+        g, o = gw.state(), ow.state()
+        for k in ("x", "q", "v", "omega", "delta"):
+            assert values_equal(g[k], o[k]), f"tick {tick}: {k} not bit-identical (rel err {rel_err(g[k], o[k])})"
+    assert st.n_constraints > 400000
+
+
+def test_config5_full_size_two_part_bodies(ctx):
+    """BASELINE config 5 at size: 65 536 bodies of two components (sphere + capsule).  The reference has no such body (the
+    definition is this build's); the HIP path is held to the oracle's statement of it: the first tick and
+    a later, contact-rich tick (oracle teacher-forced from the GPU's state) bit for bit - constraint rows of the
+    multi-contact manifolds included."""
+    import mgf_amd
+    from mgf_amd import scenes
+    scene = scenes.dumbbell_field(64, 16, 64)
+    dt, iters = float(scene["dt"]), scene["iters"]
+    gw, ow = mgf_amd.World.from_scene(ctx, scene), oracle_world(scene)
+    assert len(gw) == 65536 == len(ow)
+    sg, so = gw.step(dt, iters), ow.step(dt, iters)
+    assert (sg.n_constraints, sg.n_terrain_constraints, sg.n_pair_candidates) == (so.n_constraints, so.n_terrain_constraints, so.n_pair_candidates)
+    g, o = gw.state(), ow.state()
+    for k in ("x", "q", "v", "omega", "delta"):
+        assert values_equal(g[k], o[k]), f"first tick: {k}"
+    for _ in range(110):
+        gw.step(dt, iters)
+    s = gw.state()
+    ow.set_state(x=s["x"], q=s["q"], v=s["v"], omega=s["omega"], delta=s["delta"])
+    ow.build_constraints(dt)
+    st = gw.build_constraints(dt)
+    got, want = gw.constraints(), ow.constraints()
+    compare_constraints(got, want)
+    ab = np.stack([want["a"], want["b"]], axis=1)
+    multi = int(np.sum((ab[1:] == ab[:-1]).all(axis=1) & (ab[1:, 1] >= 0)))
+    assert st.n_constraints > 30000 and multi > 100, (st.n_constraints, multi)  # manifolds of several contacts are there
+    ow.solve(iters)
+    gw.solve(iters)
+    g, o = gw.state(), ow.state()
+    for k in ("x", "q", "v", "omega", "delta"):
+        assert values_equal(g[k], o[k]), f"later tick: {k} (rel err {rel_err(g[k], o[k])})"
+    print(f"config 5: {st.n_constraints} constraints ({st.n_terrain_constraints} terrain), {multi} rows continue a multi-contact manifold")
+
+
 def test_pair_constraints_conserve_momentum(ctx):
     """Solve only the body-body constraints of a large pile (no gravity step, no terrain): total linear
     momentum is unchanged up to f32 accumulation (every impulse is applied +/- to the two bodies)."""

@@ -40,6 +40,39 @@ def test_oracle_reproduces_snapshots(name, oname, order):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(SCENES))
+def test_hip_world_in_the_references_own_order(name):
+    """Option constraint_order = demo: the host replays world.rs:233-291 on the reference-built world BVH (refits inside the
+    loop, partners in BVH::query's order) and the device inserts the constraints in that order - the HIP result is then
+    comparable with the reference AS THE REFERENCE RUNS: bit-identical to the oracle's world.rs-order snapshots."""
+    import mgf_amd
+    scene = scenes.balls_demo(**SCENES[name])
+    ctx = mgf_amd.Context(0)
+    w = mgf_amd.World.from_scene(ctx, scene)
+    w.set_option("constraint_order", 1)
+    k = 0
+    for target in STEPS:
+        while k < target:
+            st = w.step(float(scene["dt"]), scene["iters"])
+            k += 1
+        _check(name, "demo", target, w.state(), int(st.n_constraints))
+    # ... constraint by constraint, against the oracle run in the same order (a clone taken mid-run carries the tree along)
+    ow = oracle_world(scene, order=O.ORDER_DEMO)
+    for _ in range(STEPS[-1]):
+        ow.step(float(scene["dt"]), scene["iters"])
+    w2 = w.clone()
+    for tick in range(5):
+        so, sg, sc = ow.step(float(scene["dt"]), scene["iters"]), w.step(float(scene["dt"]), scene["iters"]), w2.step(float(scene["dt"]), scene["iters"])
+        assert (sg.n_constraints, sg.n_pair_candidates) == (so.n_constraints, so.n_pair_candidates) == (sc.n_constraints, sc.n_pair_candidates)
+        got, want = w.constraints(), ow.constraints()
+        assert np.array_equal(got["a"], want["a"]) and np.array_equal(got["b"], want["b"])
+        assert bits_equal(got["normal_impulse"], want["normal_impulse"])
+    for f in FIELDS:
+        assert bits_equal(w.state()[f], ow.state()[f]) and bits_equal(w2.state()[f], ow.state()[f]), f
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(SCENES))
 def test_hip_world_reproduces_snapshots(name):
     import mgf_amd
     scene = scenes.balls_demo(**SCENES[name])
