@@ -141,6 +141,9 @@ class HipEngine:
     def collide(self, dt):
         return self.world.collide(dt).as_dict()
 
+    def max_fat_half_extent_x(self):
+        return self.world.counter("max_fat_half_extent_x_milli") / 1000.0
+
     def solve_iterations(self, k):
         self.world.solve_enqueue(k)
 
@@ -277,7 +280,15 @@ class Tile:
 
     def phase_collide(self, ghosts):
         self.e.import_ghosts(ghosts)
-        return self.e.collide(self.dt)
+        st = self.e.collide(self.dt)
+        # A body is sent to the neighbour when its fat box comes within `halo` of the slab face; it can touch a body the
+        # neighbour owns only through that body's fat half extent, which must not exceed the halo (else a contact across the
+        # face is dropped silently).  Engines that know the extent report it.
+        rmax = getattr(self.e, "max_fat_half_extent_x", lambda: 0.0)()
+        if self.world_size > 1 and rmax > self.halo:
+            raise ValueError(f"tiles: a body's fat half extent along x ({rmax:.3f}) exceeds the halo ({self.halo:.3f}): "
+                             "contacts across tile faces would be missed - use a larger halo")
+        return st
 
     def phase_solve(self, k):
         self.e.solve_iterations(k)

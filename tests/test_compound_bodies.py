@@ -100,7 +100,8 @@ def _tiled_setup(engine_factory, P, drift=0.0):
     if drift:
         sc["v0"] = (sc["v0"] + np.float32([drift, 0.0, 0.0])).astype(np.float32)
     half = 6 * 2.2 / 2.0 + 2.0
-    return sc, [Tile(engine_factory(t), t["x_range"], r, P, t["dt"], t["iters"]) for r, t in enumerate(scenes.split_by_slabs(sc, P, half))]
+    # (halo 2: a dumbbell's fat half extent along x reaches ~1.5 - the drivers refuse a halo smaller than that)
+    return sc, [Tile(engine_factory(t), t["x_range"], r, P, t["dt"], t["iters"], halo=2.0) for r, t in enumerate(scenes.split_by_slabs(sc, P, half))]
 
 
 def test_two_part_bodies_across_oracle_tiles():

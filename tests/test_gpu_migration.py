@@ -79,7 +79,7 @@ def test_tiles_of_different_body_kinds(ctx):
     """The narrowphase dispatch is chosen on the host from the kinds a world holds: ghosts and arrivals of another
     kind must switch it to the mixed path (kind masks ride on the count message / are read from the arrivals)."""
     from mgf_amd.tiles import step_tiles_inprocess
-    gt, ot = _pair_of_tile_sets(ctx, _two_kind_scenes())
+    gt, ot = _pair_of_tile_sets(ctx, _two_kind_scenes(), halo=1.25)  # (the capsules' cube bounds reach 1.0 and more with their motion)
     assert gt[0].e.kinds() == 1 and gt[1].e.kinds() == 2
     cross = 0
     for tick in range(45):

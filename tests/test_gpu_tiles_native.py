@@ -131,3 +131,17 @@ def test_config4_one_million_spheres_as_eight_tiles(ctx):
     assert [int(s.n_constraints) for s in sg] == [int(s["n_constraints"]) for s in so]
     _assert_equal(worlds, ot, "later tick")
     print("config 4, 8 tiles: constraints per tile", [int(s.n_constraints) for s in sg])
+
+
+def test_halo_smaller_than_a_body_is_refused(ctx):
+    """a body whose fat half extent exceeds the halo could touch a neighbour's body that was never exported.  Both
+    drivers fail loudly instead of dropping the contact."""
+    from mgf_amd.tiles import HipEngine, Tile, step_tiles_inprocess
+    tile_scenes = [scenes.sphere_pile_tile(4, 4, 4, r, 2) for r in range(2)]
+    T, _ = _native(ctx, tile_scenes, halo=0.5)  # spheres of radius 0.5 + fat margin 0.25 + motion: 0.75 and more
+    with pytest.raises(mgf_amd.MgfError) as e:
+        T.step(float(tile_scenes[0]["dt"]), 10)
+    assert e.value.status == 6 and "halo" in str(e.value)
+    py = [Tile(HipEngine(ctx, sc, 0), sc["x_range"], r, 2, sc["dt"], sc["iters"], halo=0.5) for r, sc in enumerate(tile_scenes)]
+    with pytest.raises(ValueError):
+        step_tiles_inprocess(py)
