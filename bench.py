@@ -147,7 +147,8 @@ def _roofline(units, launches, kms, mode, what, window):
 
 def bench_single_world(args, ctx, mgf_amd, scenes, configure, mode):
     nx, ny, nz = args.tile
-    scene = scenes.sphere_pile(nx, ny, nz)
+    raster = os.environ.get("MGF_BENCH_BODY_ORDER", "shuffled") == "raster"  # development probe: how much the gathers cost (NOT the workload)
+    scene = scenes.sphere_pile(nx, ny, nz, shuffle=not raster)
     dt = float(scene["dt"])
     world = mgf_amd.World.from_scene(ctx, scene)
     configure(world)
@@ -178,7 +179,7 @@ def bench_single_world(args, ctx, mgf_amd, scenes, configure, mode):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE config 2: {nx * ny * nz} spheres ({nx}x{ny}x{nz} jittered lattice pile, r=0.5, seed 0x6D6766) in an open "
-                               f"box, dt=1/60, {args.iters} solver iters; {window_name}; {SCENE_NOTE}",
+                               f"box, dt=1/60, {args.iters} solver iters; {window_name}; " + ("BODY ORDER = LATTICE RASTER (development probe, not the BASELINE workload)" if raster else SCENE_NOTE),
                    "bodies_total": nx * ny * nz, "iters": args.iters, "dt": dt,
                    "constraint_order": "canonical (i asc; terrain DFS; partners j<i asc)", "parallelism": "1 GPU"},
         "timed_region": {"windows": len(windows), "seconds": round(total, 3), "reported": "median window",

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(kBlock) void k_morton_count(const float4* fb_c, uin
 }
 
 // Zero several small arrays with one launch (instead of one fill kernel each).
-constexpr int kZeroSlots = 16;
+constexpr int kZeroSlots = 20;
 struct ZeroList { uint32_t* p[kZeroSlots]; uint32_t words[kZeroSlots]; SceneBounds* sb; const int* sb_part; };
 __global__ __launch_bounds__(kBlock) void k_zero_many(ZeroList z) {
   if (z.sb_part && blockIdx.x == 0 && threadIdx.x < 9) {  // fold k_integrate's partial scene bounds (see there)
@@ -69,6 +69,8 @@ struct Lbvh {
   LeafRec* leaves;     // n records in Morton order
   uint32_t* sidx;      // body index of every leaf record
   float4* lcol;        // optional, 2 per leaf record: collider (p.xyz, r) and motion (delta.xyz) of the body (k_pair_grid<true>)
+  float4* ltb;         // optional, 2 per leaf record: the body's tight box = its query, and in the .w words the cells that query has to
+                       // look at: (centre, ca packed 10 bits per axis), (half extents, d packed likewise) (k_pair_brick)
   uint32_t* cell_lo;   // 4^levels + 1 entries: cell c holds the leaf records [cell_lo[c], cell_lo[c + 1])
   uint32_t n;          // live bodies
   uint32_t levels;     // internal levels L >= 4; 4^L leaf cells
@@ -84,15 +86,41 @@ __device__ __forceinline__ void box_min_max(V3& lo, V3& hi, V3 l, V3 h) {
   hi = mk3(fmaxf(hi.x, h.x), fmaxf(hi.y, h.y), fmaxf(hi.z, h.z));
 }
 
+// The cells a query (a body's tight box) has to look at in the grid broadphase: a body j can only be accepted by query i
+// (tight_i overlaps fat_j) if its fat-box centre lies within tight_i grown by the largest fat half extent of the scene.
+// [ca, ca + d) per axis, in cells of nb[k] prefix bits.
+__device__ __forceinline__ float pair_query_pad(const V3& c, const V3& r, float pad_abs) {
+  return pad_abs + 1e-5f * (fabs_rs(c.x) + fabs_rs(c.y) + fabs_rs(c.z) + r.x + r.y + r.z);
+}
+__device__ __forceinline__ void pair_query_region(const V3& qc, const V3& qr, float pad, const SceneBounds* sb, const uint32_t* nb, uint32_t* ca, uint32_t* d) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float lo = ord_f(sb->lo[k]), hi = ord_f(sb->hi[k]), rm = ord_f(sb->rmax[k]);
+    float a = at(qc, k) - at(qr, k) - rm - pad, b = at(qc, k) + at(qr, k) + rm + pad;
+    uint32_t c0 = morton_quant(a, lo, hi) >> (10u - nb[k]), c1 = morton_quant(b, lo, hi) >> (10u - nb[k]);
+    ca[k] = c0; d[k] = c1 - c0 + 1u;
+  }
+}
+
 // Bodies -> leaf records in cell order (counting sort, second half).
 __global__ __launch_bounds__(kBlock) void k_scatter_leaves(Lbvh T, const float4* fb_c, const float4* fb_r, const uint32_t* cell_of,
-                                                           const uint32_t* rank, uint32_t* brank, const float4* col0, const float4* delta) {
+                                                           const uint32_t* rank, uint32_t* brank, const float4* col0, const float4* delta, const float4* tb_c,
+                                                           const float4* tb_r, const SceneBounds* sb, float pad_abs) {
   uint32_t body = blockIdx.x * kBlock + threadIdx.x;
   if (body >= T.n) return;
   uint32_t p = T.cell_lo[cell_of[body]] + rank[body];
   LeafRec lr; lr.c = mk4(xyz(fb_c[body]), u2f(body)); lr.r = mk4(xyz(fb_r[body]), 0.0f);
   T.leaves[p] = lr;
   if (T.lcol) { T.lcol[2 * p] = col0[body]; T.lcol[2 * p + 1] = delta[body]; }
+  if (T.ltb) {
+    const float4 c = tb_c[body], r = tb_r[body];
+    const uint32_t P = 2u * T.levels;
+    const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};
+    uint32_t ca[3], d[3];
+    pair_query_region(xyz(c), xyz(r), pair_query_pad(xyz(c), xyz(r), pad_abs), sb, nb, ca, d);
+    T.ltb[2 * p] = mk4(xyz(c), u2f(ca[0] | (ca[1] << 10) | (ca[2] << 20)));  // (ca < 1024, d <= 1024 - ca)
+    T.ltb[2 * p + 1] = mk4(xyz(r), u2f(d[0] | (d[1] << 10) | (d[2] << 20)));
+  }
   T.sidx[p] = body;
   brank[body] = p;  // position in cell order (the block-local solver groups bodies by it)
 }
@@ -551,6 +579,105 @@ __device__ __forceinline__ Comp load_comp(const Bodies& B, uint32_t i) {
 // accepted partners are still counted (World::step's candidate statistic): per block into one of kPairStatWords words.
 constexpr uint32_t kGridMaxCells = 512;
 constexpr uint32_t kPairStatWords = 1024;  // partial sums of the accepted partners (same-word atomics from many CUs serialise: ~0.3 us each)
+
+// Where a query's cells and leaf records come from: global memory (the sorted arrays themselves) ...
+struct PairSrcGlobal {
+  Lbvh T;
+  __device__ __forceinline__ void range(uint32_t cell, const uint32_t*, uint32_t& p0, uint32_t& p1) const { p0 = T.cell_lo[cell]; p1 = T.cell_lo[cell + 1]; }
+  __device__ __forceinline__ void leaf(uint32_t p, float4& c, float4& r) const { LeafRec lr = T.leaves[p]; c = lr.c; r = lr.r; }
+  __device__ __forceinline__ void col(uint32_t p, float4& c0, float4& d0, uint32_t& j) const { c0 = T.lcol[2 * p]; d0 = T.lcol[2 * p + 1]; j = T.sidx[p]; }
+};
+// One query (8 lanes) over the cells [ca, ca + d): the reference's acceptance test on every leaf record of those cells, and -
+// SPHERES - the sphere-sphere test on the accepted ones (staged in `acc`).  np = entries written to the row; n_accepted = fat-box
+// partners.  The lanes of a group stay together (ballots).
+template <bool SPHERES, class Src, class AccT>
+__device__ __forceinline__ void pair_query_cells(const Src& S, const Box& q, const Comp& A, V3 vA, uint32_t i, uint32_t n_owned, const uint32_t* ca,
+                                                 const uint32_t* d, const uint32_t* nb, int shift, int sub, int gbase, uint32_t* row, AccT* acc,
+                                                 uint32_t* overflow, uint32_t& np, uint32_t& n_accepted) {
+  const uint32_t ncell = d[0] * d[1] * d[2];
+  np = 0;
+  for (uint32_t cb = 0; cb < ncell; cb += kCoopLanes) {
+    uint32_t idx = cb + (uint32_t)sub;
+    uint32_t p0 = 0, p1 = 0;
+    if (idx < ncell) {
+      uint32_t cz = idx % d[2], t = idx / d[2];
+      uint32_t cy = t % d[1], cx = t / d[1];
+      const uint32_t cc3[3] = {ca[0] + cx, ca[1] + cy, ca[2] + cz};
+      uint32_t code = (expand10(cc3[0] << (10u - nb[0])) << 2) | (expand10(cc3[1] << (10u - nb[1])) << 1) | expand10(cc3[2] << (10u - nb[2]));
+      S.range(code >> shift, cc3, p0, p1);
+    }
+    // every lane walks its own cell's bodies; the group stays together for the ballots
+    for (;;) {
+      bool more = p0 < p1;
+      unsigned long long mb = __ballot(more);
+      if (((uint32_t)(mb >> gbase) & 255u) == 0u) break;
+      bool hit = false;
+      uint32_t j = 0;
+      if (more) {
+        float4 lc, lr;
+        S.leaf(p0, lc, lr);
+        j = f2u(lc.w);
+        if (j < i && j < n_owned) {  // world.rs:266; ghost-ghost skipped
+          Box fb; fb.c = xyz(lc); fb.r = xyz(lr);
+          hit = box_overlaps(q, fb);  // the reference's own acceptance test (bvh.rs:297)
+        }
+        if (SPHERES) j = p0;  // the staging row holds record positions until the second phase below
+        ++p0;
+      }
+      unsigned long long hb = __ballot(hit);
+      uint32_t gm = (uint32_t)(hb >> gbase) & 255u;
+      if (hit) {
+        uint32_t slot = np + __popc(gm & ((1u << sub) - 1u));
+        if (slot < (uint32_t)kRowCap) {
+          if (SPHERES) acc[slot] = (AccT)j;
+          else row[slot] = j;
+        }
+      }
+      np += __popc(gm);
+    }
+  }
+  n_accepted = np;
+  if (SPHERES) {
+    // second phase: the accepted partners, sixteen at a time - two per lane, so a typical query needs one round trip for its
+    // partners' records - through the sphere-sphere test; contacts go to the row
+    if (np > (uint32_t)kRowCap) atomicOr(overflow, 1u);
+    const uint32_t na = min(np, (uint32_t)kRowCap);
+    uint32_t nc = 0;
+    for (uint32_t a0 = 0; a0 < na; a0 += 2 * kCoopLanes) {
+      bool hit[2] = {false, false};
+      uint32_t jj[2] = {0, 0};
+      float4 c0[2], d0[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint32_t a = a0 + (uint32_t)u * kCoopLanes + (uint32_t)sub;
+        const uint32_t pj = a < na ? (uint32_t)acc[a] : (uint32_t)acc[0];
+        S.col(pj, c0[u], d0[u], jj[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint32_t a = a0 + (uint32_t)u * kCoopLanes + (uint32_t)sub;
+        if (a < na) {
+          // cheap and conservative first: the centres never come closer than |d| - |v| during the tick
+          const V3 dd = xyz(c0[u]) - A.p, v = xyz(d0[u]) - vA;
+          const float lim = A.r + c0[u].w + __builtin_sqrtf(dot(v, v));
+          if (dot(dd, dd) <= lim * lim * 1.001f) {
+            Comp Bc; Bc.kind = KIND_SPHERE; Bc.p = xyz(c0[u]); Bc.r = c0[u].w; Bc.d = mk3(0, 0, 0);
+            LocalContact lc;
+            hit[u] = comp_pair_local(A, vA, Bc, xyz(d0[u]), &lc);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint32_t gm = (uint32_t)(__ballot(hit[u]) >> gbase) & 255u;
+        if (hit[u]) row[nc + __popc(gm & ((1u << sub) - 1u))] = jj[u];
+        nc += __popc(gm);
+      }
+    }
+    np = nc;
+  }
+}
+
 template <bool SPHERES>
 __global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, uint32_t n_owned, Lbvh T, const SceneBounds* sb, float pad_abs,
                                                           uint32_t* rows_p, uint32_t* p_cnt, uint32_t* overflow, uint32_t* too_wide,
@@ -571,101 +698,13 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, 
     const uint32_t P = 2u * T.levels;
     const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};  // prefix bits per axis (x is the most significant)
     uint32_t ca[3], d[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      float lo = ord_f(sb->lo[k]), hi = ord_f(sb->hi[k]), rm = ord_f(sb->rmax[k]);
-      float a = at(q.c, k) - at(q.r, k) - rm - pad, b = at(q.c, k) + at(q.r, k) + rm + pad;
-      uint32_t c0 = morton_quant(a, lo, hi) >> (10u - nb[k]), c1 = morton_quant(b, lo, hi) >> (10u - nb[k]);
-      ca[k] = c0; d[k] = c1 - c0 + 1u;
-    }
-    const uint32_t ncell = d[0] * d[1] * d[2];
-    if (ncell > kGridMaxCells) {
+    pair_query_region(q.c, q.r, pad, sb, nb, ca, d);
+    if (d[0] * d[1] * d[2] > kGridMaxCells) {
       if (sub == 0) *too_wide = 1u;
     } else {
-      uint32_t* row = rows_p + (size_t)i * kRowCap;
-      const int shift = kMortonBits - (int)P;
-      for (uint32_t cb = 0; cb < ncell; cb += kCoopLanes) {
-        uint32_t idx = cb + (uint32_t)sub;
-        uint32_t p0 = 0, p1 = 0;
-        if (idx < ncell) {
-          uint32_t cz = idx % d[2], t = idx / d[2];
-          uint32_t cy = t % d[1], cx = t / d[1];
-          uint32_t code = (expand10((ca[0] + cx) << (10u - nb[0])) << 2) | (expand10((ca[1] + cy) << (10u - nb[1])) << 1) |
-                          expand10((ca[2] + cz) << (10u - nb[2]));
-          uint32_t cell = code >> shift;
-          p0 = T.cell_lo[cell]; p1 = T.cell_lo[cell + 1];
-        }
-        // every lane walks its own cell's bodies; the group stays together for the ballots
-        for (;;) {
-          bool more = p0 < p1;
-          unsigned long long mb = __ballot(more);
-          if (((uint32_t)(mb >> gbase) & 255u) == 0u) break;
-          bool hit = false;
-          uint32_t j = 0;
-          if (more) {
-            LeafRec lr = T.leaves[p0];
-            j = f2u(lr.c.w);
-            if (j < i && j < n_owned) {  // world.rs:266; ghost-ghost skipped
-              Box fb; fb.c = xyz(lr.c); fb.r = xyz(lr.r);
-              hit = box_overlaps(q, fb);  // the reference's own acceptance test (bvh.rs:297)
-            }
-            if (SPHERES) j = p0;  // the row holds leaf positions until the second phase below
-            ++p0;
-          }
-          unsigned long long hb = __ballot(hit);
-          uint32_t gm = (uint32_t)(hb >> gbase) & 255u;
-          if (hit) {
-            uint32_t slot = np + __popc(gm & ((1u << sub) - 1u));
-            if (slot < (uint32_t)kRowCap) {
-              if (SPHERES) s_acc[threadIdx.x >> 3][slot] = j;
-              else row[slot] = j;
-            }
-          }
-          np += __popc(gm);
-        }
-      }
-      if (SPHERES) {
-        // second phase: the accepted partners (staged in LDS), sixteen at a time - two per lane, so a typical query
-        // needs one round trip for its partners' records - through the sphere-sphere test; contacts go to the row
-        n_accepted = np;
-        if (np > (uint32_t)kRowCap) atomicOr(overflow, 1u);
-        const uint32_t na = min(np, (uint32_t)kRowCap);
-        const uint32_t* acc = s_acc[threadIdx.x >> 3];
-        uint32_t nc = 0;
-        for (uint32_t a0 = 0; a0 < na; a0 += 2 * kCoopLanes) {
-          bool hit[2] = {false, false};
-          uint32_t jj[2] = {0, 0};
-          float4 c0[2], d0[2];
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const uint32_t a = a0 + (uint32_t)u * kCoopLanes + (uint32_t)sub;
-            const uint32_t pj = a < na ? acc[a] : 0u;
-            c0[u] = T.lcol[2 * pj]; d0[u] = T.lcol[2 * pj + 1];
-            jj[u] = T.sidx[pj];
-          }
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const uint32_t a = a0 + (uint32_t)u * kCoopLanes + (uint32_t)sub;
-            if (a < na) {
-              // cheap and conservative first: the centres never come closer than |d| - |v| during the tick
-              const V3 d = xyz(c0[u]) - A.p, v = xyz(d0[u]) - vA;
-              const float lim = A.r + c0[u].w + __builtin_sqrtf(dot(v, v));
-              if (dot(d, d) <= lim * lim * 1.001f) {
-                Comp Bc; Bc.kind = KIND_SPHERE; Bc.p = xyz(c0[u]); Bc.r = c0[u].w; Bc.d = mk3(0, 0, 0);
-                LocalContact lc;
-                hit[u] = comp_pair_local(A, vA, Bc, xyz(d0[u]), &lc);
-              }
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const uint32_t gm = (uint32_t)(__ballot(hit[u]) >> gbase) & 255u;
-            if (hit[u]) row[nc + __popc(gm & ((1u << sub) - 1u))] = jj[u];
-            nc += __popc(gm);
-          }
-        }
-        np = nc;
-      }
+      PairSrcGlobal S; S.T = T;
+      pair_query_cells<SPHERES>(S, q, A, vA, i, n_owned, ca, d, nb, kMortonBits - (int)P, sub, gbase, rows_p + (size_t)i * kRowCap,
+                                s_acc[SPHERES ? threadIdx.x >> 3 : 0], overflow, np, n_accepted);
     }
   }
   if (live && sub == 0) {
@@ -684,6 +723,241 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, 
     if (threadIdx.x == 0 && s_sum) atomicAdd(&pair_stat[blockIdx.x & (kPairStatWords - 1u)], s_sum);
   }
 }
+
+// k_pair_grid with the cells in LDS.  k_pair_grid is bound by instruction issue, not by memory: 8 lanes share a query and
+// spend ~1900 wave instructions per 8 queries on cell arithmetic (divisions, Morton interleaves), ballots and lanes that
+// wait for each other.  Here a block takes a BRICK of 4 x 4 x 4 cells (64 consecutive Morton cells: its queries are one
+// contiguous range of the sorted bodies) and copies the 8 x 8 x 8 cells around it into LDS once - one thread per cell,
+// records re-sorted x-major so that a column of cells along z is one contiguous range - and 8 lanes share a query: lane s
+// takes the z-columns s, s + 8, ... of the query's cells (a column is typically 3-4 cells, ~4 records, read four at a time);
+// hits are appended through an LDS counter.  A query whose cells reach outside the box (a body much larger than a cell), or a brick whose box holds
+// more records than the LDS copy has room for, is answered by one lane from global memory with the same code: the accepted
+// set never depends on which way it was found (the order inside a row never mattered: contacts are numbered by partner id).
+__device__ __forceinline__ uint32_t compact10(uint32_t v) {  // inverse of expand10
+  v &= 0x09249249u;
+  v = (v ^ (v >> 2)) & 0x030C30C3u;
+  v = (v ^ (v >> 4)) & 0x0300F00Fu;
+  v = (v ^ (v >> 8)) & 0xFF0000FFu;
+  v = (v ^ (v >> 16)) & 0x000003FFu;
+  return v;
+}
+constexpr int kBrickLanes = 8;                                  // lanes per query
+constexpr int kBrickQueries = kCoopBlock / kBrickLanes;         // queries per pass of a block
+constexpr uint32_t kBrickCap = 672;                             // leaf records staged per brick (64 B each; 32 B when the sphere test is not fused)
+struct BrickSrcLds {   // the staged box: records in x-major cell order, start[] = first record of every cell (+ end)
+  const float4 *rc, *rr, *cc, *cd;
+  const uint16_t* start;
+  int hb[3];
+  static constexpr bool kColumns = true;
+  __device__ __forceinline__ void column(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t dz, uint32_t& p0, uint32_t& p1) const {
+    const uint32_t c = ((uint32_t)((int)cx - hb[0]) << 6) | ((uint32_t)((int)cy - hb[1]) << 3) | (uint32_t)((int)cz - hb[2]);
+    p0 = start[c]; p1 = start[c + dz];
+  }
+  __device__ __forceinline__ void leaf(uint32_t p, float4& c, float4& r) const { c = rc[p]; r = rr[p]; }
+  __device__ __forceinline__ void col(uint32_t p, float4& c0, float4& d0, uint32_t& j) const { c0 = cc[p]; d0 = cd[p]; j = f2u(rc[p].w); }
+};
+struct BrickSrcGlobal {  // the sorted arrays themselves, one cell at a time
+  Lbvh T;
+  uint32_t nb[3];
+  int shift;
+  static constexpr bool kColumns = false;
+  __device__ __forceinline__ void column(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t, uint32_t& p0, uint32_t& p1) const {
+    const uint32_t code = (expand10(cx << (10u - nb[0])) << 2) | (expand10(cy << (10u - nb[1])) << 1) | expand10(cz << (10u - nb[2]));
+    const uint32_t cell = code >> shift;
+    p0 = T.cell_lo[cell]; p1 = T.cell_lo[cell + 1];
+  }
+  __device__ __forceinline__ void leaf(uint32_t p, float4& c, float4& r) const { LeafRec lr = T.leaves[p]; c = lr.c; r = lr.r; }
+  __device__ __forceinline__ void col(uint32_t p, float4& c0, float4& d0, uint32_t& j) const { c0 = T.lcol[2 * p]; d0 = T.lcol[2 * p + 1]; j = T.sidx[p]; }
+};
+// Lane s of LQ over the cells [ca, ca + d) of one query.  cnt[0..2] (LDS, zero on entry): fat-box partners, partners that pass
+// the conservative distance test, contacts.  acc: staging row of record positions (kRowCap entries).
+template <bool SPHERES, class Src, class AccT>
+__device__ __forceinline__ void brick_query(const Src& S, const Box& q, const Comp& A, V3 vA, uint32_t i, uint32_t n_owned, const uint32_t* ca,
+                                            const uint32_t* d, uint32_t s, uint32_t LQ, uint32_t* row, AccT* acc, uint32_t* cnt) {
+  // lane s takes the z-columns s, s + LQ, ... of the d[0] x d[1] columns (division by the small d[1] through a multiplier)
+  const uint32_t ncol = d[0] * d[1];
+  const uint32_t magic = d[1] <= 8u ? ((65536u + d[1] - 1u) / d[1]) : 0u;  // (constant divisors: the compiler folds the eight cases)
+  for (uint32_t m = s; m < ncol; m += LQ) {
+    const uint32_t cx = magic ? (m * magic) >> 16 : m / d[1], cy = m - cx * d[1];
+    {
+      for (uint32_t cz = 0; cz < (Src::kColumns ? 1u : d[2]); ++cz) {
+        uint32_t p0, p1;
+        S.column(ca[0] + cx, ca[1] + cy, ca[2] + cz, d[2], p0, p1);
+        for (uint32_t p = p0; p < p1; p += 4) {  // four records in flight
+          float4 lc[4], lr[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) S.leaf(min(p + (uint32_t)u, p1 - 1u), lc[u], lr[u]);
+          uint32_t hits = 0;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t j = f2u(lc[u].w);
+            Box fb; fb.c = xyz(lc[u]); fb.r = xyz(lr[u]);
+            // world.rs:266 (ghost-ghost skipped) and the reference's own acceptance test (bvh.rs:297)
+            if (p + (uint32_t)u < p1 && j < i && j < n_owned && box_overlaps(q, fb)) hits |= 1u << u;
+          }
+          if (hits) {
+            uint32_t slot = atomicAdd(&cnt[0], (uint32_t)__popc(hits));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if ((hits >> u) & 1u) {
+                if (slot < (uint32_t)kRowCap) {
+                  if (SPHERES) acc[slot] = (AccT)(p + (uint32_t)u);
+                  else row[slot] = f2u(lc[u].w);
+                }
+                ++slot;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!SPHERES) return;
+  // the accepted partners through the sphere-sphere test: first the cheap conservative reject (the centres never come closer
+  // than |d| - |v| during the tick), survivors compacted in place, then the narrowphase's own function on those
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const uint32_t na = min(*(volatile uint32_t*)&cnt[0], (uint32_t)kRowCap);
+  for (uint32_t a = s; a < na; a += LQ) {
+    const uint32_t pj = (uint32_t)acc[a];
+    float4 c0, d0; uint32_t jj;
+    S.col(pj, c0, d0, jj);
+    const V3 dd = xyz(c0) - A.p, v = xyz(d0) - vA;
+    const float lim = A.r + c0.w + __builtin_sqrtf(dot(v, v));
+    if (dot(dd, dd) <= lim * lim * 1.001f) acc[atomicAdd(&cnt[1], 1u)] = (AccT)pj;  // (entries below a + LQ have been read: the lanes of a query move together)
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const uint32_t ns = *(volatile uint32_t*)&cnt[1];
+  for (uint32_t a = s; a < ns; a += LQ) {
+    const uint32_t pj = (uint32_t)acc[a];
+    float4 c0, d0; uint32_t jj;
+    S.col(pj, c0, d0, jj);
+    Comp Bc; Bc.kind = KIND_SPHERE; Bc.p = xyz(c0); Bc.r = c0.w; Bc.d = mk3(0, 0, 0);
+    LocalContact lc;
+    if (comp_pair_local(A, vA, Bc, xyz(d0), &lc)) row[atomicAdd(&cnt[2], 1u)] = jj;
+  }
+}
+
+template <bool SPHERES>
+__global__ __launch_bounds__(kCoopBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_pair_brick(uint32_t n, uint32_t n_owned, Lbvh T,
+                                                           uint32_t* rows_p, uint32_t* p_cnt, uint32_t* overflow, uint32_t* too_wide,
+                                                           uint32_t* pair_stat, uint32_t* slow_queries) {
+  extern __shared__ float4 s_dyn[];                      // records: rc | rr | (cc | cd), kBrickCap each
+  __shared__ uint16_t s_start[516];
+  __shared__ uint32_t s_wsum[kCoopBlock / 64];
+  __shared__ uint16_t s_acc[SPHERES ? kBrickQueries : 1][SPHERES ? kRowCap : 1];
+  __shared__ uint32_t s_cnt[kBrickQueries][3];
+  __shared__ uint32_t s_sum, s_slow, s_q[2];
+  const uint32_t P = 2u * T.levels;
+  const uint32_t nbricks = (1u << P) >> 6;
+  const uint32_t brick = xcd_logical_block_coop();
+  if (brick >= nbricks) return;
+  const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};  // prefix bits per axis (x is the most significant)
+  const int shift = kMortonBits - (int)P;
+  BrickSrcLds L;
+  L.rc = s_dyn; L.rr = s_dyn + kBrickCap; L.cc = s_dyn + 2 * kBrickCap; L.cd = s_dyn + 3 * kBrickCap; L.start = s_start;
+  {
+    const uint32_t code = (brick * 64u) << shift;
+    L.hb[0] = (int)(compact10(code >> 2) >> (10u - nb[0])) - 2;
+    L.hb[1] = (int)(compact10(code >> 1) >> (10u - nb[1])) - 2;
+    L.hb[2] = (int)(compact10(code) >> (10u - nb[2])) - 2;
+  }
+  // round trip 1: this thread's cell of the box (x-major) and its range of leaf records
+  const uint32_t t = threadIdx.x;
+  const int lane = t & 63;
+  uint32_t g0 = 0, cnt = 0;
+  {
+    const int c[3] = {L.hb[0] + (int)(t >> 6), L.hb[1] + (int)((t >> 3) & 7u), L.hb[2] + (int)(t & 7u)};
+    if (c[0] >= 0 && c[1] >= 0 && c[2] >= 0 && c[0] < (1 << nb[0]) && c[1] < (1 << nb[1]) && c[2] < (1 << nb[2])) {
+      const uint32_t cd = (expand10((uint32_t)c[0] << (10u - nb[0])) << 2) | (expand10((uint32_t)c[1] << (10u - nb[1])) << 1) |
+                          expand10((uint32_t)c[2] << (10u - nb[2]));
+      g0 = T.cell_lo[cd >> shift];
+      cnt = T.cell_lo[(size_t)(cd >> shift) + 1] - g0;
+    }
+  }
+  if (t == 0) { s_sum = 0; s_slow = 0; }
+  uint32_t inc = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+  if (lane == 63) s_wsum[t >> 6] = inc;
+  if (t == ((2u << 6) | (2u << 3) | 2u)) s_q[0] = g0;         // the brick's own cells are (2..5)^3 of the box: the Morton-first ...
+  if (t == ((5u << 6) | (5u << 3) | 5u)) s_q[1] = g0 + cnt;   // ... and the Morton-last one bound its queries
+  __syncthreads();
+  const uint32_t q0 = s_q[0], q1 = s_q[1];
+  if (q0 == q1) return;  // nobody lives here
+  uint32_t base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kCoopBlock / 64; ++w) { const uint32_t u = s_wsum[w]; if (w < (int)(t >> 6)) base += u; total += u; }
+  const uint32_t start = base + inc - cnt;
+  const bool staged = total <= kBrickCap;
+  s_start[t] = (uint16_t)min(start, 0xFFFFu);
+  if (t == 0) { s_start[512] = (uint16_t)min(total, 0xFFFFu); s_start[513] = s_start[512]; }
+  // round trip 2: the cell's records into the box copy, and the first pass's queries (cell-ordered copies: no look-up through
+  // the body index)
+  uint32_t kq = q0 + t / (uint32_t)kBrickLanes;
+  float4 qc, qr, qa, qv;
+  qc = qr = qa = qv = make_float4(0, 0, 0, 0);
+  uint32_t qi = 0;
+  uint2 qreg = make_uint2(0, 0);
+  if (kq < q1) { qc = T.ltb[2 * kq]; qr = T.ltb[2 * kq + 1]; if (SPHERES) { qa = T.lcol[2 * kq]; qv = T.lcol[2 * kq + 1]; } qi = T.sidx[kq]; qreg = make_uint2(f2u(qc.w), f2u(qr.w)); }
+  if (staged) {
+    float4* rc = s_dyn; float4* rr = s_dyn + kBrickCap; float4* cc = s_dyn + 2 * kBrickCap; float4* cd = s_dyn + 3 * kBrickCap;
+    for (uint32_t r = 0; r < cnt; ++r) {
+      LeafRec lr = T.leaves[g0 + r];
+      rc[start + r] = lr.c; rr[start + r] = lr.r;
+      if (SPHERES) { cc[start + r] = T.lcol[2 * (g0 + r)]; cd[start + r] = T.lcol[2 * (g0 + r) + 1]; }
+    }
+  }
+  __syncthreads();
+  const uint32_t sub = t & (uint32_t)(kBrickLanes - 1), qg = t / (uint32_t)kBrickLanes;
+  uint32_t acc_total = 0, slow = 0;
+  for (;;) {
+    const bool live = kq < q1;  // whole groups are live or not
+    const uint32_t i = qi;
+    uint32_t np = 0;
+    if (sub == 0) { s_cnt[qg][0] = 0; s_cnt[qg][1] = 0; s_cnt[qg][2] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (live && i != 0 && T.n >= 2) {  // world.rs:256
+      Box q; q.c = xyz(qc); q.r = xyz(qr);
+      Comp A; A.p = xyz(qa); A.r = qa.w; A.d = mk3(0, 0, 0); A.kind = KIND_SPHERE;
+      const V3 vA = xyz(qv);
+      const uint32_t ca[3] = {qreg.x & 1023u, (qreg.x >> 10) & 1023u, qreg.x >> 20}, d[3] = {qreg.y & 1023u, (qreg.y >> 10) & 1023u, qreg.y >> 20};
+      uint32_t* row = rows_p + (size_t)i * kRowCap;
+      if (d[0] * d[1] * d[2] > kGridMaxCells) {
+        if (sub == 0) *too_wide = 1u;
+      } else if (staged && (int)ca[0] >= L.hb[0] && (int)ca[1] >= L.hb[1] && (int)ca[2] >= L.hb[2] && (int)(ca[0] + d[0]) <= L.hb[0] + 8 &&
+                 (int)(ca[1] + d[1]) <= L.hb[1] + 8 && (int)(ca[2] + d[2]) <= L.hb[2] + 8) {
+        brick_query<SPHERES>(L, q, A, vA, i, n_owned, ca, d, sub, (uint32_t)kBrickLanes, row, s_acc[SPHERES ? qg : 0], s_cnt[qg]);
+      } else if (sub == 0) {
+        BrickSrcGlobal S; S.T = T; S.nb[0] = nb[0]; S.nb[1] = nb[1]; S.nb[2] = nb[2]; S.shift = shift;
+        brick_query<SPHERES>(S, q, A, vA, i, n_owned, ca, d, 0u, 1u, row, row, s_cnt[qg]);  // (the row itself stages the accepted partners)
+        ++slow;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const uint32_t accepted = *(volatile uint32_t*)&s_cnt[qg][0];
+      np = SPHERES ? *(volatile uint32_t*)&s_cnt[qg][2] : accepted;
+      if (sub == 0) {
+        acc_total += accepted;
+        if (accepted > (uint32_t)kRowCap) atomicOr(overflow, 1u);
+      }
+    }
+    if (live && sub == 0) p_cnt[i] = np;
+    kq += kBrickQueries;
+    if (kq - qg >= q1) break;  // (the block's decision: every group sees the same pass base)
+    qi = 0;
+    if (kq < q1) { qc = T.ltb[2 * kq]; qr = T.ltb[2 * kq + 1]; if (SPHERES) { qa = T.lcol[2 * kq]; qv = T.lcol[2 * kq + 1]; } qi = T.sidx[kq]; qreg = make_uint2(f2u(qc.w), f2u(qr.w)); }
+  }
+  {  // accepted partners: one atomic per block, spread over many words
+    uint32_t v = acc_total, u = slow;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { v += __shfl_xor(v, o); u += __shfl_xor(u, o); }
+    if (lane == 0 && v) atomicAdd(&s_sum, v);
+    if (lane == 0 && u) atomicAdd(&s_slow, u);
+    __syncthreads();
+    if (SPHERES && t == 0 && s_sum) atomicAdd(&pair_stat[blockIdx.x & (kPairStatWords - 1u)], s_sum);
+    if (t == 0 && s_slow) atomicAdd(slow_queries, s_slow);
+  }
+}
+constexpr size_t brick_lds_bytes(bool spheres) { return (size_t)kBrickCap * 16u * (spheres ? 4u : 2u); }
 
 // Terrain faces per body without walking the reference tree.  A static mesh gets the same Morton-cell grid as the
 // bodies (cells over the face boxes, built once per set_terrain); a query enumerates the cells its box can reach,

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kBlock) void k_chain_rows(uint32_t n, ConsLinks K, 
     if (x == 0) { sc->C = 0; sc->Ct = 0; sc->fail |= kFailRevRow; }
     return;
   }
-  if (x >= n) return;
+  if (x >= n || sc->fail) return;  // (a list-capacity miss: base[] counts constraints that were never written; the tick is re-run)
   const uint32_t lo = base[x], na = base[x + 1] - lo, nb = degb[x];
   const uint32_t total = na + nb;
   if (total == 0) return;
