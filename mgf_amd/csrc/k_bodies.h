@@ -34,6 +34,9 @@ struct Bodies {
   float4* einfo;  // x + delta (RigidBodyInfo.x, physics.rs:282), restitution
   float4* col0;   // collider shape: p.xyz, r
   float4* col1;   //                 d.xyz, kind bits
+  float4* bpk;    // 4 words/body, or null: col0, delta, einfo, col1 once more, side by side - what ContactConstraint::new needs of a body
+                  // besides srec, in ONE 64-byte sector instead of four (k_setup_*; written by k_integrate / k_import_ghosts, valid from
+                  // there until the bodies change: the host passes null otherwise)
   float4* tb_c;   // tight swept AABB centre / half extents
   float4* tb_r;
   float4* fb_c;   // fat AABB (persistent; world.rs:181,237)
@@ -98,6 +101,8 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
   __shared__ float4 s_tail[Tail::kLdsWords];
   tail.stage(s_tail);
   if (Tail::kLdsWords > 1) __syncthreads();
+  __shared__ float4 s_rec[kBlock / 64][8 * 65];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   bool live = i < n;
   bool refit = false;
@@ -145,14 +150,18 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
         tb = swept_bounds(col, d);
       }
       B.q[i] = make_float4(q.s, q.v.x, q.v.y, q.v.z);
-      B.srec[4 * i] = make_float4(v.x, v.y, v.z, w.x);
-      B.srec[4 * i + 1] = make_float4(w.y, w.z, inv_mass, I.c[0].x);
-      B.srec[4 * i + 2] = make_float4(I.c[0].y, I.c[0].z, I.c[1].x, I.c[1].y);
-      B.srec[4 * i + 3] = make_float4(I.c[1].z, I.c[2].x, I.c[2].y, I.c[2].z);
+      // the two 64-byte records of the body leave through LDS (below): stored by their own lanes they would be 16-byte pieces
+      // 64 bytes apart, 64 partial lines per instruction
+      s_rec[wv][0 * 65 + lane] = make_float4(v.x, v.y, v.z, w.x);
+      s_rec[wv][1 * 65 + lane] = make_float4(w.y, w.z, inv_mass, I.c[0].x);
+      s_rec[wv][2 * 65 + lane] = make_float4(I.c[0].y, I.c[0].z, I.c[1].x, I.c[1].y);
+      s_rec[wv][3 * 65 + lane] = make_float4(I.c[1].z, I.c[2].x, I.c[2].y, I.c[2].z);
       B.delta[i] = mk4(d, p1.w);
       B.einfo[i] = mk4(x + d, p0.w);
       B.col0[i] = mk4(col.p, col.r);
       B.col1[i] = mk4(col.d, u2f((uint32_t)col.kind));
+      s_rec[wv][4 * 65 + lane] = mk4(col.p, col.r); s_rec[wv][5 * 65 + lane] = mk4(d, p1.w);
+      s_rec[wv][6 * 65 + lane] = mk4(x + d, p0.w); s_rec[wv][7 * 65 + lane] = mk4(col.d, u2f((uint32_t)col.kind));
       B.tb_c[i] = mk4(tb.c, 0.0f);
       B.tb_r[i] = mk4(tb.r, 0.0f);
       Box fb; fb.c = xyz(B.fb_c[i]); fb.r = xyz(B.fb_r[i]);
@@ -170,6 +179,18 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
       B.einfo[i] = mk4(x + xyz(dl), B.einfo[i].w);
     }
     if (do_complete) B.x[i] = mk4(x, 0.0f);
+  }
+  if (do_integrate) {  // srec (and the packed copy of collider, motion, info): the wave's 64 records are one contiguous 4 KB each
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (a wave's LDS accesses are served in order; it reads only what it wrote)
+    const uint32_t i0 = blockIdx.x * kBlock + (uint32_t)wv * 64u;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int f = it * 64 + lane, rec = f >> 2, k = f & 3;
+      if (i0 + (uint32_t)rec < n) {
+        B.srec[4 * (size_t)i0 + f] = s_rec[wv][k * 65 + rec];
+        if (B.bpk) B.bpk[4 * (size_t)i0 + f] = s_rec[wv][(4 + k) * 65 + rec];
+      }
+    }
   }
   if (!do_integrate || sb == nullptr) return;
   // refit count: one atomic per block

@@ -342,6 +342,16 @@ __device__ __forceinline__ CRec load_crec_solve(const CRec* src) {
   return c;
 }
 
+// What ContactConstraint::new needs of a body besides srec: collider word 0 (sphere centre, radius), delta (motion, friction),
+// einfo (x + delta, restitution).  From the packed copy (one sector) when the host vouches for it, else from the arrays.
+struct BodyPack { float4 c0, dl, ei; };
+__device__ __forceinline__ BodyPack load_pack(const Bodies& B, uint32_t i, bool with_collider) {
+  BodyPack P;
+  if (B.bpk) { P.c0 = B.bpk[4 * i]; P.dl = B.bpk[4 * i + 1]; P.ei = B.bpk[4 * i + 2]; }
+  else { P.c0 = with_collider ? B.col0[i] : make_float4(0, 0, 0, 0); P.dl = B.delta[i]; P.ei = B.einfo[i]; }
+  return P;
+}
+
 // SPHERES = true: a world of spheres whose broadphase ran the sphere-sphere test itself (k_pair_grid<true>): the list
 // holds contacts only, one per pair, and the contact is computed here from the colliders (no k_narrow_pairs pass, no
 // NContact round trip through memory).  `flag` is raised if the two evaluations of the same test ever disagreed.
@@ -352,28 +362,64 @@ __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCoun
                                                         CRec* cons, uint2* ab, uint32_t* degb, uint32_t* rev, uint32_t rev_cap,
                                                         uint32_t* rev_flag, uint32_t in_stride, uint32_t* flag) {
   uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (SPHERES) {
+    // One contact per listed pair.  The 128-byte records leave through LDS: a lane storing its own record issues eight
+    // 16-byte stores 128 bytes apart from its neighbours' (64 partial lines per instruction); handed round, consecutive lanes
+    // store consecutive words of the same records (8 full lines per instruction).  A record's id is looked up per word, so
+    // ids need not be contiguous (a body's terrain constraints sit between its neighbours' pair constraints).
+    __shared__ float4 s_w[kBlock / 64][7 * 65];  // (the record's eighth 16-byte word is padding: not written)
+    __shared__ uint32_t s_c[kBlock / 64][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t c = kNone;
+    if (p < sc->Mp) {
+      const uint32_t i = p_owner[p], j = p_cand[p];
+      const BodyPack Pa = load_pack(B, i, true), Pb = load_pack(B, j, true);
+      Comp Ca, Cb;  // as k_narrow_pairs<0, 0>
+      Ca.p = xyz(Pa.c0); Ca.r = Pa.c0.w; Ca.d = mk3(0.0f, 0.0f, 0.0f); Ca.kind = KIND_SPHERE;
+      Cb.p = xyz(Pb.c0); Cb.r = Pb.c0.w; Cb.d = mk3(0.0f, 0.0f, 0.0f); Cb.kind = KIND_SPHERE;
+      LocalContact lc;
+      if (!comp_pair_local(Ca, xyz(Pa.dl), Cb, xyz(Pb.dl), &lc)) {
+        *flag = 1u;
+      } else {
+        const V3 nrm = (mk3(0.0f, 0.0f, 0.0f) + lc.g.n) / 1.0f;  // Manifold::from(pruner) of one contact (manifold.rs:135-140)
+        const BodyDyn A = load_dyn(B.srec, i), Bd = load_dyn(B.srec, j);
+        c = base[i] + p_pre[p];
+        const CRec r = make_constraint(i, j, A, xyz(Pa.ei), Pa.ei.w, Pa.dl.w, Bd, xyz(Pb.ei), Pb.ei.w, Pb.dl.w, nrm, lc.la, lc.lb, dt, baumgarte, slop);
+        const float4* rw = reinterpret_cast<const float4*>(&r);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) s_w[wv][k * 65 + lane] = rw[k];
+        ab[c] = make_uint2(i, j);
+        // body j's row of the constraints it takes part in as `b` (k_chain_rows); as `a` a body owns a contiguous id range
+        const uint32_t pos = atomicAdd(&degb[j], 1u);
+        if (pos < rev_cap) rev[(size_t)j * rev_cap + pos] = c;
+        else *rev_flag = 1u;
+      }
+    }
+    s_c[wv][lane] = c;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (a wave's LDS accesses are served in order; the wave reads only what it wrote)
+    float4* out = reinterpret_cast<float4*>(cons);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int rec = it * 8 + (lane >> 3), k = lane & 7;
+      const uint32_t cr = s_c[wv][rec];
+      if (cr != kNone && k < 7) out[(size_t)cr * 8 + k] = s_w[wv][k * 65 + rec];
+    }
+    return;
+  }
   if (p >= sc->Mp) return;
-  const uint32_t nc = SPHERES ? 1u : p_nc[p];
+  const uint32_t nc = p_nc[p];
   if (nc == 0) return;
   uint32_t i = p_owner[p], j = p_cand[p];
-  NContact own;
-  if (SPHERES) {  // as k_narrow_pairs<0, 0>
-    Comp A = load_comp(B, i), Bc = load_comp(B, j);
-    A.kind = KIND_SPHERE; Bc.kind = KIND_SPHERE;
-    LocalContact lc;
-    if (!comp_pair_local(A, xyz(B.delta[i]), Bc, xyz(B.delta[j]), &lc)) { *flag = 1u; return; }
-    V3 nrm = (mk3(0.0f, 0.0f, 0.0f) + lc.g.n) / 1.0f;  // Manifold::from(pruner) of one contact (manifold.rs:135-140)
-    own.la = mk4(lc.la, lc.g.t); own.lb = mk4(lc.lb, 0.0f); own.n = mk4(nrm, 0.0f);
-  }
+  BodyPack Pa = load_pack(B, i, false), Pb = load_pack(B, j, false);
   BodyDyn A = load_dyn(B.srec, i), Bd = load_dyn(B.srec, j);
-  float4 ea = B.einfo[i], eb = B.einfo[j];
+  float4 ea = Pa.ei, eb = Pb.ei;
   // A manifold of m contacts (bodies of several parts only) becomes m consecutive single-contact records that share
   // its normal and tangents: ContactConstraint::solve (solver.rs:219-248) handles the contacts of a constraint one after
   // the other on the same velocities, which is exactly what consecutive records do.
   for (uint32_t q = 0; q < nc; ++q) {
     const uint32_t c = base[i] + p_pre[p] + q;
-    NContact k = SPHERES ? own : p_in[(size_t)in_stride * p + q];
-    CRec r = make_constraint(i, j, A, xyz(ea), ea.w, B.delta[i].w, Bd, xyz(eb), eb.w, B.delta[j].w, xyz(k.n), xyz(k.la), xyz(k.lb),
+    NContact k = p_in[(size_t)in_stride * p + q];
+    CRec r = make_constraint(i, j, A, xyz(ea), ea.w, Pa.dl.w, Bd, xyz(eb), eb.w, Pb.dl.w, xyz(k.n), xyz(k.la), xyz(k.lb),
                              dt, baumgarte, slop);
     store_crec(&cons[c], r);
     ab[c] = make_uint2(i, j);
@@ -394,11 +440,12 @@ __global__ __launch_bounds__(kBlock) void k_setup_terrain(Bodies B, TerrainDev M
   if (nc == 0) return;
   uint32_t i = t_owner[p];
   BodyDyn A = load_dyn(B.srec, i), S = static_dyn();
-  float4 ea = B.einfo[i];
+  const BodyPack Pa = load_pack(B, i, false);
+  float4 ea = Pa.ei;
   V3 center = mk3(M.x[0], M.x[1], M.x[2]);  // Static{ center: terrain.center(), friction: 0.0 } world.rs:247
   for (uint32_t k = 0; k < nc; ++k) {
     NContact in = t_in[(size_t)in_stride * p + k];
-    CRec r = make_constraint(i, kNone, A, xyz(ea), ea.w, B.delta[i].w, S, center, 0.0f, 0.0f, xyz(in.n), xyz(in.la), xyz(in.lb), dt,
+    CRec r = make_constraint(i, kNone, A, xyz(ea), ea.w, Pa.dl.w, S, center, 0.0f, 0.0f, xyz(in.n), xyz(in.la), xyz(in.lb), dt,
                              baumgarte, slop);
     store_crec(&cons[base[i] + t_pre[p] + k], r);
     ab[base[i] + t_pre[p] + k] = make_uint2(i, kNone);

@@ -69,6 +69,7 @@ __device__ __forceinline__ void import_ghost(Bodies B, uint32_t i, const float* 
   Comp k; k.kind = (int)f2u(o[16]); k.p = mk3(o[17], o[18], o[19]); k.d = mk3(o[20], o[21], o[22]); k.r = o[23];
   B.col0[i] = mk4(k.p, k.r);
   B.col1[i] = mk4(k.d, o[16]);
+  if (B.bpk) { B.bpk[4 * i] = mk4(k.p, k.r); B.bpk[4 * i + 1] = mk4(d, o[35]); B.bpk[4 * i + 2] = mk4(x + d, o[34]); B.bpk[4 * i + 3] = mk4(k.d, o[16]); }
   Box tb = swept_bounds(k, d);
   const uint32_t pc = min(f2u(o[36]), (uint32_t)kMaxParts);
   if (B.pcount) {
