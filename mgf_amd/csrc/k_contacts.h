@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_terrain(Bodies B, const uint32_t
 // running offset of each candidate inside the body's block.
 __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint32_t n, const uint32_t* t_off, const uint32_t* p_off,
                                                            const uint32_t* t_nc, const uint32_t* p_nc, const uint32_t* p_cand, uint32_t* t_pre,
-                                                           uint32_t* p_pre, uint32_t* cnt, int keep_order) {
+                                                           uint32_t* p_pre, uint32_t* cnt, int keep_order, uint32_t* tcn) {
   constexpr int kHitCap = 12;  // a sphere touches at most 12 equal ones
   __shared__ uint32_t s_j[kHitCap][kBlock], s_p[kHitCap][kBlock];
   const int tid = threadIdx.x;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint3
   if (tid == 0) s_ct = 0;
   __syncthreads();
   bool active = i < n;
-  if (active && sc->fail) { cnt[i] = 0; active = false; }
+  if (active && sc->fail) { cnt[i] = 0; tcn[i] = 0; active = false; }
   if (active) {
   uint32_t run = 0;
   for (uint32_t p = t_off[i]; p < t_off[i + 1]; ++p) { t_pre[p] = run; run += t_nc[p]; }
@@ -233,6 +233,7 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint3
     }
   }
   cnt[i] = run + total;
+  tcn[i] = run;  // the body's terrain constraints come first in its range (k_chain_rows)
   }
   __syncthreads();
   if (tid == 0 && s_ct) atomicAdd(&sc->ct_sum, s_ct);

@@ -66,7 +66,7 @@ __device__ __forceinline__ uint32_t links_indeg0(const ConsLinks& K, uint32_t c)
 // occurrences (written by k_setup_pairs in arrival order, sorted here).  A row that overflowed raises kFailRevRow and
 // empties the tick (C = 0): the host widens the rows and re-runs the collide phase.
 __global__ __launch_bounds__(kBlock) void k_chain_rows(uint32_t n, ConsLinks K, const uint32_t* base, const uint32_t* degb, uint32_t* rev,
-                                                       uint32_t rev_cap, const uint32_t* rev_flag, StepCounts* sc) {
+                                                       uint32_t rev_cap, const uint32_t* rev_flag, StepCounts* sc, const uint32_t* tcn) {
   uint32_t x = blockIdx.x * kBlock + threadIdx.x;
   if (*rev_flag) {
     if (x == 0) { sc->C = 0; sc->Ct = 0; sc->fail |= kFailRevRow; }
@@ -76,6 +76,7 @@ __global__ __launch_bounds__(kBlock) void k_chain_rows(uint32_t n, ConsLinks K, 
   const uint32_t lo = base[x], na = base[x + 1] - lo, nb = degb[x];
   const uint32_t total = na + nb;
   if (total == 0) return;
+  const uint32_t nt = tcn[x];
   uint32_t* row = rev + (size_t)x * rev_cap;
   for (uint32_t a = 1; a < nb; ++a) {  // ascending constraint id = insertion order
     uint32_t v = row[a], b = a;
@@ -88,7 +89,10 @@ __global__ __launch_bounds__(kBlock) void k_chain_rows(uint32_t n, ConsLinks K, 
     const bool last = k + 1 == total;
     const uint32_t u = k < na ? lo + k : row[k - na], role = k < na ? 0u : 1u;
     const uint32_t wid = last ? first : (k + 1 < na ? lo + k + 1 : row[k + 1 - na]);
-    succ[2 * u + role] = wid | (K.ab[wid].y != kNone ? kSuccTwo : 0u) | (last ? kSuccWrap : 0u);
+    // the successor has two dynamic bodies unless it is one of this body's own terrain constraints - the first tcn[x] of its
+    // range (no look-up of the successor's (a, b): that was a dependent gather per link)
+    const bool two = !(wid >= lo && wid - lo < nt);
+    succ[2 * u + role] = wid | (two ? kSuccTwo : 0u) | (last ? kSuccWrap : 0u);
     K.pred[2 * u + role] = k > 0 ? 1 : 0;  // predecessor on this body inside one iteration
   }
 }

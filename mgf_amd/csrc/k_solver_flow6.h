@@ -56,7 +56,8 @@ struct Flow6 {
   const uint32_t* sidx;      // cell-ordered body ids
   const uint32_t* brank;     // body -> position in cell order
   const uint32_t* base;      // body -> id of its first own constraint (canonical order: a body's `a` constraints are contiguous)
-  uint32_t* slot_base;       // body -> slot of its first own constraint inside its block
+  uint4* binfo;              // body -> (position in cell order, slot of its first own constraint inside its block, id of that constraint, -):
+                             // what a constraint's row needs of a body, one 16-byte look-up instead of three
   uint32_t* bref;            // constraint -> LDS index of its body b in the constraint's block
   uint8_t* skipwb;           // body -> 1: the chain's last constraint runs in another block, which writes the result
   uint32_t* fcnt;            // per block (stride kF6CntStride): foreign bodies
@@ -116,7 +117,11 @@ __global__ __launch_bounds__(kF6PrepThreads) void k_flow6_blocks(Flow6 F, ConsLi
     __syncthreads();
   }
   uint32_t run = s_part[t] - sum;
-  for (uint32_t p = lo; p < hi; ++p) { const uint32_t x = F.sidx[p]; F.slot_base[x] = run; run += F.base[x + 1] - F.base[x]; }
+  for (uint32_t p = lo; p < hi; ++p) {
+    const uint32_t x = F.sidx[p], b0 = F.base[x], b1 = F.base[x + 1];
+    F.binfo[x] = make_uint4(p, run, b0, b1 - b0);
+    run += b1 - b0;
+  }
   if (t == kBlock - 1) {
     const uint32_t total = s_part[t];
     F.nslots[(size_t)g * kF6CntStride] = total;
@@ -174,39 +179,40 @@ __device__ __forceinline__ uint32_t f6_chan_slot(uint32_t* keys, uint32_t key1, 
   atomicOr(fail, 4u);
   return 0u;
 }
-__device__ __forceinline__ uint32_t f6_slot_of(const Flow6& F, uint32_t a, uint32_t c) { return F.slot_base[a] + (c - F.base[a]); }
 // Per constraint: its row of the block's slot table.
 __global__ __launch_bounds__(kBlock) void k_flow6_table(Flow6 F, ConsLinks K, const uint32_t* C_ptr) {
   const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
   if (c >= *C_ptr) return;
   const uint2 e = K.ab[c];
-  const uint32_t g = F.brank[e.x] / F.nb;
-  const uint32_t slot = f6_slot_of(F, e.x, c);
+  const uint4 ia = F.binfo[e.x];  // (position, first slot, first constraint) of body a: the block's own
+  const uint32_t g = ia.x / F.nb;
+  const uint32_t slot = ia.y + (c - ia.z);
   if (slot >= F.slot_cap || slot >= kF6MaxSlots) { atomicOr(F.fail, 2u); return; }
   F6Row R;
   R.c = c;
-  const uint32_t aref = F.brank[e.x] - g * F.nb;
+  const uint32_t aref = ia.x - g * F.nb;
   const uint32_t bref = e.y == kNone ? kF6NoBody : F.bref[c];
   if (aref >= kF6NoBody || (e.y != kNone && bref >= kF6NoBody)) { atomicOr(F.fail, 16u); return; }
+  const uint2 sw = K.succ[c];
   // this constraint ends the chain of its body b (its successor word wraps to the next iteration) and b lives in another
   // block: it writes b's result, and b's own block does not (a is always the block's own)
-  const bool final_b = e.y != kNone && (K.succ[c].y & kSuccWrap) && F.brank[e.y] / F.nb != g;
+  const bool final_b = e.y != kNone && (sw.y & kSuccWrap) && F.brank[e.y] / F.nb != g;
   if (final_b) F.skipwb[e.y] = 1;
   R.ref = aref | (bref << kF6BodyBits) | (final_b ? kF6RefFinalB : 0u);
-  R.state0 = links_indeg0(K, c);
-  const uint2 sw = K.succ[c];
+  R.state0 = (uint32_t)K.pred[2 * c] + (e.y != kNone ? (uint32_t)K.pred[2 * c + 1] : 0u);  // links_indeg0
   uint32_t w[2] = {sw.x, sw.y};
 #pragma unroll
   for (int side = 0; side < 2; ++side) {
     if (side == 1 && e.y == kNone) { w[1] = 0u; break; }
     const uint32_t sid = w[side] & kSuccId, wrap = (w[side] & kSuccWrap) ? kF6Wrap : 0u;
-    const uint2 se = K.ab[sid];
-    const uint32_t hs = F.brank[se.x] / F.nb;
-    const uint32_t sslot = f6_slot_of(F, se.x, sid);
+    const uint32_t body = side == 0 ? e.x : e.y;
+    const uint32_t sa = K.ab[sid].x;  // the successor's home is its body a's block
+    const uint4 is = F.binfo[sa];
+    const uint32_t hs = is.x / F.nb;
+    const uint32_t sslot = is.y + (sid - is.z);
     if (hs == g) { w[side] = wrap | sslot; continue; }
     // the edge crosses a block face: a message on the channel g -> hs
-    const uint32_t body = side == 0 ? e.x : e.y;
-    const uint32_t dbody = se.x == body ? F.brank[body] - hs * F.nb : F.bref[sid];  // as a: own there; as b: what k_flow6_bodies gave it
+    const uint32_t dbody = sa == body ? is.x - hs * F.nb : F.bref[sid];  // as a: own there; as b: what k_flow6_blocks gave it
     const uint32_t k_in = f6_chan_slot(F.in_key + (size_t)hs * kF6Chan, g + 1u, F.fail);
     atomicAdd(&F.in_cnt[(size_t)hs * kF6Chan + k_in], 1u);
     const uint32_t k_out = f6_chan_slot(F.out_key + (size_t)g * kF6Chan, hs + 1u, F.fail);
