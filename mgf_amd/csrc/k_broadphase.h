@@ -54,6 +54,171 @@ __global__ __launch_bounds__(kBlock) void k_zero_many(ZeroList z) {
   }
 }
 
+struct StepCounts {
+  uint32_t Mt, Mp, C, Ct;                      // effective: terrain / pair candidates, constraints, terrain constraints
+  uint32_t fail;                               // kFail* bits
+  uint32_t need_Mt, need_Mp, need_C, need_Ct;  // actual sizes (valid up to the first failing stage)
+  uint32_t bins[6];                            // candidates per shape-pair type (scenes mixing spheres and capsules)
+  uint32_t ct_sum;                             // terrain constraints, accumulated by k_count_contacts (zeroed by k_caps_candidates)
+};
+constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u, kFailGridWide = 8u, kFailTerrainRow = 16u, kFailTerrainWide = 32u,
+                   kFailRevRow = 64u,  // a body's row of `b` occurrences overflowed (k_setup_pairs / k_chain_rows)
+                   kFailSkipped = 128u;  // a speculative tick behind a failed one: nothing was done (k_reset_step)
+
+// The list sizes of the tick, checked against the capacities the lists were allocated with, at the end of the scans that
+// produce them (the thread of k_scan that writes the last prefix runs these: no launch of their own).
+struct ScanEpilogue {
+  int kind;                       // 0 none, 1 candidate lists (after the scan of the terrain / partner rows), 2 constraint list
+  uint32_t cap_a, cap_b;          // kind 1: cap_t, cap_p; kind 2: cap_c
+  const uint32_t *row_overflow, *grid_wide, *terrain_wide, *guard;  // kind 1 (each may be null but guard)
+  StepCounts* sc;
+};
+__device__ __forceinline__ void caps_candidates(const ScanEpilogue& E, uint32_t mt, uint32_t mp) {
+  StepCounts r;
+  r.need_Mt = mt; r.need_Mp = mp; r.need_C = 0; r.need_Ct = 0;
+  r.fail = 0;
+  if (r.need_Mt > E.cap_a || r.need_Mp > E.cap_b) r.fail |= kFailCandCap;
+  if (E.row_overflow && (*E.row_overflow & 1u)) r.fail |= kFailRowOverflow;
+  if (E.row_overflow && (*E.row_overflow & 2u)) r.fail |= kFailTerrainRow;
+  if (E.grid_wide && *E.grid_wide) r.fail |= kFailGridWide;
+  if (E.terrain_wide && *E.terrain_wide) r.fail |= kFailTerrainWide;
+  if (*E.guard) r.fail |= kFailSkipped;
+  r.Mt = r.fail ? 0u : r.need_Mt; r.Mp = r.fail ? 0u : r.need_Mp; r.C = 0; r.Ct = 0;
+  for (int k = 0; k < 6; ++k) r.bins[k] = 0;
+  r.ct_sum = 0;
+  *E.sc = r;
+}
+__device__ __forceinline__ void caps_constraints(const ScanEpilogue& E, uint32_t c) {
+  StepCounts* sc = E.sc;
+  if (sc->fail) return;
+  sc->need_C = c; sc->need_Ct = sc->ct_sum;
+  if (c > E.cap_a) { sc->fail |= kFailConsCap; sc->Mt = 0; sc->Mp = 0; sc->C = 0; sc->Ct = 0; return; }
+  sc->C = c; sc->Ct = sc->ct_sum;
+}
+
+// Device-wide exclusive prefix sum in ONE launch (the tick's three scans: cells, candidate rows, constraints per body).
+// Tiles of kScanTile items are handed out through a ticket (so a tile's predecessors are always running: no assumption about
+// dispatch order); a block publishes its tile's total at once and then looks back - one wave, 64 predecessors per step -
+// until it meets a tile whose inclusive prefix is known (decoupled look-back).  The status words and the ticket are
+// zeroed by the tick's clearing launch (k_zero_many).  W = 2 scans two arrays of equal length together (both totals share a
+// status word: 31 bits each).
+constexpr int kScanBlock = 256, kScanRounds = 4, kScanTile = kScanBlock * 4 * kScanRounds;  // 4096 items per tile
+constexpr unsigned long long kScanAgg = 1ull << 62, kScanInc = 2ull << 62, kScanFlag = 3ull << 62;
+struct ScanJob { const uint32_t* in[2]; uint32_t* out[2]; uint32_t n; unsigned long long* status; uint32_t* ticket; ScanEpilogue epi; };
+template <int W>
+__global__ __launch_bounds__(kScanBlock) void k_scan(ScanJob J) {
+  __shared__ uint32_t s_tile;
+  __shared__ uint32_t s_wave[W][kScanBlock / 64];
+  __shared__ uint32_t s_prev[W];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t == 0) s_tile = atomicAdd(J.ticket, 1u);
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const uint32_t i0 = tile * (uint32_t)kScanTile;
+  // the tile in registers: kScanRounds rounds of 4 consecutive items per thread (one 16-byte load per lane, coalesced)
+  uint4 v[W][kScanRounds];
+  uint32_t tot[W];
+#pragma unroll
+  for (int a = 0; a < W; ++a) {
+    tot[a] = 0;
+#pragma unroll
+    for (int r = 0; r < kScanRounds; ++r) {
+      const uint32_t i = i0 + (uint32_t)r * (kScanBlock * 4) + (uint32_t)t * 4u;
+      uint4 x = make_uint4(0, 0, 0, 0);
+      if (i + 3u < J.n) x = *reinterpret_cast<const uint4*>(J.in[a] + i);
+      else { if (i < J.n) x.x = J.in[a][i]; if (i + 1u < J.n) x.y = J.in[a][i + 1]; if (i + 2u < J.n) x.z = J.in[a][i + 2]; }
+      v[a][r] = x;
+      tot[a] += x.x + x.y + x.z + x.w;
+    }
+  }
+  // the tile's total
+#pragma unroll
+  for (int a = 0; a < W; ++a) {
+    uint32_t u = tot[a];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) u += __shfl_xor(u, o);
+    if (lane == 0) s_wave[a][wv] = u;
+  }
+  __syncthreads();
+  uint32_t agg[W];
+#pragma unroll
+  for (int a = 0; a < W; ++a) { agg[a] = 0; for (int k = 0; k < kScanBlock / 64; ++k) agg[a] += s_wave[a][k]; }
+  auto pack = [](const uint32_t* x) -> unsigned long long { return W == 1 ? (unsigned long long)x[0] : ((unsigned long long)x[0] | ((unsigned long long)x[W - 1] << 31)); };
+  if (wv == 0) {
+    uint32_t prev[W];
+#pragma unroll
+    for (int a = 0; a < W; ++a) prev[a] = 0;
+    if (tile == 0) {
+      if (lane == 0) __hip_atomic_store(&J.status[0], kScanInc | pack(agg), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0) __hip_atomic_store(&J.status[tile], kScanAgg | pack(agg), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      int back = (int)tile - 1;  // nearest predecessor not yet summed
+      for (;;) {
+        const int idx = back - lane;
+        unsigned long long st = kScanInc;  // (lanes before tile 0 read as "inclusive, 0")
+        if (idx >= 0) {
+          do { st = __hip_atomic_load(&J.status[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while ((st & kScanFlag) == 0ull);
+        }
+        const unsigned long long inc = __ballot((st & kScanFlag) == kScanInc);
+        const int first = inc ? __builtin_ctzll(inc) : 64;  // lanes 0..first contribute (first = the nearest inclusive prefix)
+        uint32_t c[W];
+        c[0] = lane <= first ? (uint32_t)(W == 1 ? (st & 0xFFFFFFFFull) : (st & 0x7FFFFFFFull)) : 0u;
+        if (W == 2) c[W - 1] = lane <= first ? (uint32_t)((st >> 31) & 0x7FFFFFFFull) : 0u;
+#pragma unroll
+        for (int a = 0; a < W; ++a) {
+          uint32_t u = c[a];
+#pragma unroll
+          for (int o = 32; o >= 1; o >>= 1) u += __shfl_xor(u, o);
+          prev[a] += u;
+        }
+        if (inc) break;
+        back -= 64;
+      }
+      uint32_t incl[W];
+#pragma unroll
+      for (int a = 0; a < W; ++a) incl[a] = prev[a] + agg[a];
+      if (lane == 0) __hip_atomic_store(&J.status[tile], kScanInc | pack(incl), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < W; ++a) s_prev[a] = prev[a];
+    }
+  }
+  __syncthreads();
+  // exclusive prefixes inside the tile: round by round, wave scan + the waves before + the rounds before + the tiles before
+  uint32_t last[W];
+  bool is_last = false;
+#pragma unroll
+  for (int a = 0; a < W; ++a) last[a] = 0;
+#pragma unroll
+  for (int a = 0; a < W; ++a) {
+    uint32_t carry = s_prev[a];
+#pragma unroll
+    for (int r = 0; r < kScanRounds; ++r) {
+      const uint4 x = v[a][r];
+      const uint32_t mine = x.x + x.y + x.z + x.w;
+      uint32_t inc = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+      __syncthreads();  // (s_wave of the previous use has been read)
+      if (lane == 63) s_wave[a][wv] = inc;
+      __syncthreads();
+      uint32_t before = carry, round_total = 0;
+      for (int k = 0; k < kScanBlock / 64; ++k) { const uint32_t u = s_wave[a][k]; if (k < wv) before += u; round_total += u; }
+      const uint32_t e0 = before + inc - mine;
+      const uint32_t i = i0 + (uint32_t)r * (kScanBlock * 4) + (uint32_t)t * 4u;
+      const uint4 o4 = make_uint4(e0, e0 + x.x, e0 + x.x + x.y, e0 + x.x + x.y + x.z);
+      if (i + 3u < J.n) *reinterpret_cast<uint4*>(J.out[a] + i) = o4;
+      else { if (i < J.n) J.out[a][i] = o4.x; if (i + 1u < J.n) J.out[a][i + 1] = o4.y; if (i + 2u < J.n) J.out[a][i + 2] = o4.z; }
+      if (J.n - 1u - i < 4u) { const uint32_t k = J.n - 1u - i; last[a] = k == 0 ? o4.x : k == 1 ? o4.y : k == 2 ? o4.z : o4.w; is_last = true; }
+      carry += round_total;
+    }
+  }
+  // the thread that wrote the last prefix (= the sum of everything before the closing element) checks the list sizes
+  if (is_last && J.epi.kind == 1) caps_candidates(J.epi, last[0], last[W - 1]);
+  if (is_last && J.epi.kind == 2) caps_constraints(J.epi, last[0]);
+}
+
 // Linear BVH as an implicit complete 4-ary tree over MORTON CELLS.  A leaf is the cell of one 2L-bit
 // Morton prefix (an axis-aligned region of the scene) and owns the contiguous range of sorted bodies
 // whose key has that prefix; internal nodes are shorter prefixes, so every node is a spatial region
@@ -320,43 +485,6 @@ __device__ __forceinline__ void lbvh_traverse(const Lbvh& T, const QNode* top, u
 // sizes plus slack), kernels take the real sizes from here.  If a capacity turns out too small the
 // effective sizes become 0 (every later kernel of the tick is a no-op), `fail` says why, and the host
 // grows the buffers and re-runs the collide phase.
-struct StepCounts {
-  uint32_t Mt, Mp, C, Ct;                      // effective: terrain / pair candidates, constraints, terrain constraints
-  uint32_t fail;                               // kFail* bits
-  uint32_t need_Mt, need_Mp, need_C, need_Ct;  // actual sizes (valid up to the first failing stage)
-  uint32_t bins[6];                            // candidates per shape-pair type (scenes mixing spheres and capsules)
-  uint32_t ct_sum;                             // terrain constraints, accumulated by k_count_contacts (zeroed by k_caps_candidates)
-};
-constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u, kFailGridWide = 8u, kFailTerrainRow = 16u, kFailTerrainWide = 32u,
-                   kFailRevRow = 64u,  // a body's row of `b` occurrences overflowed (k_setup_pairs / k_chain_rows)
-                   kFailSkipped = 128u;  // a speculative tick behind a failed one: nothing was done (k_reset_step)
-
-__global__ void k_caps_candidates(const uint32_t* mt, const uint32_t* mp, uint32_t cap_t, uint32_t cap_p, const uint32_t* row_overflow,
-                                  const uint32_t* grid_wide, const uint32_t* terrain_wide, StepCounts* sc, const uint32_t* guard) {
-  StepCounts r;
-  r.need_Mt = *mt; r.need_Mp = *mp; r.need_C = 0; r.need_Ct = 0;
-  r.fail = 0;
-  if (r.need_Mt > cap_t || r.need_Mp > cap_p) r.fail |= kFailCandCap;
-  if (row_overflow && (*row_overflow & 1u)) r.fail |= kFailRowOverflow;
-  if (row_overflow && (*row_overflow & 2u)) r.fail |= kFailTerrainRow;
-  if (grid_wide && *grid_wide) r.fail |= kFailGridWide;
-  if (terrain_wide && *terrain_wide) r.fail |= kFailTerrainWide;
-  if (*guard) r.fail |= kFailSkipped;
-  r.Mt = r.fail ? 0u : r.need_Mt; r.Mp = r.fail ? 0u : r.need_Mp; r.C = 0; r.Ct = 0;
-  for (int k = 0; k < 6; ++k) r.bins[k] = 0;
-  r.ct_sum = 0;
-  *sc = r;
-}
-__global__ void k_caps_constraints(const uint32_t* c, const uint32_t* ct, uint32_t cap_c, StepCounts* sc, const uint32_t* first_ghost,
-                                   uint32_t* n_ghost_cons) {
-  *n_ghost_cons = 0;
-  if (sc->fail) return;
-  *n_ghost_cons = *c - *first_ghost;  // constraints whose obj_a is a ghost (ids are ascending in obj_a): the copies of seam constraints
-  sc->need_C = *c; sc->need_Ct = *ct;
-  if (*c > cap_c) { sc->fail |= kFailConsCap; sc->Mt = 0; sc->Mp = 0; sc->C = 0; sc->Ct = 0; return; }
-  sc->C = *c; sc->Ct = *ct;
-}
-
 // XCD-aware query mapping: workgroup b is observed to run on XCD b % 8, each with a private 4 MB L2.
 // Give XCD x the x-th contiguous eighth of the Morton-ordered queries, so the part of the tree it
 // walks (a spatial eighth of the scene) stays resident in its own L2.  Launch xcd_grid(n) blocks.
