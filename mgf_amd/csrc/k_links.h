@@ -67,10 +67,12 @@ __device__ __forceinline__ uint32_t links_indeg0(const ConsLinks& K, uint32_t c)
 // empties the tick (C = 0): the host widens the rows and re-runs the collide phase.
 __global__ __launch_bounds__(kBlock) void k_chain_rows(uint32_t n, ConsLinks K, const uint32_t* base, const uint32_t* degb, uint32_t* rev,
                                                        uint32_t rev_cap, const uint32_t* rev_flag, StepCounts* sc, const uint32_t* tcn, uint32_t n_owned,
-                                                       uint32_t* n_ghost_cons) {
+                                                       uint32_t* n_ghost_cons, const uint32_t* only_if) {
+  // (behind k_flow6_links, which has done the tick's bookkeeping: the links are only needed if the block-local solver declined)
+  if (only_if && *only_if == 0u) return;
   uint32_t x = blockIdx.x * kBlock + threadIdx.x;
   // constraints whose obj_a is a ghost (ids are ascending in obj_a): the copies of seam constraints (tiles count them once)
-  if (x == 0) *n_ghost_cons = (sc->fail || *rev_flag) ? 0u : base[n] - base[n_owned];
+  if (x == 0 && n_ghost_cons) *n_ghost_cons = (sc->fail || *rev_flag) ? 0u : base[n] - base[n_owned];
   if (*rev_flag) {
     if (x == 0) { sc->C = 0; sc->Ct = 0; sc->fail |= kFailRevRow; }
     return;

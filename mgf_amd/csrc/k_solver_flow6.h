@@ -33,21 +33,22 @@ constexpr uint32_t kF6SlotBits = 13, kF6BodyBits = 11;
 constexpr uint32_t kF6MaxSlots = (1u << kF6SlotBits) - 1u;  // per block
 constexpr uint32_t kF6NoBody = (1u << kF6BodyBits) - 1u;    // b-ref of a constraint against a Static body
 constexpr uint32_t kF6Remote = 0x80000000u, kF6Wrap = 0x40000000u;
-constexpr uint32_t kF6RefFinalA = 1u << 22, kF6RefFinalB = 1u << 23;
 constexpr uint32_t kF6MsgWords = 3;                    // uint4 granules per message
 constexpr uint32_t kF6MaxIters = 64;                   // (ring positions are reduced with a 32-bit reciprocal)
 constexpr uint32_t kF6WlLen = 128;                     // work items (channel, position) a polling wave lists per sweep
 constexpr uint32_t kF6MaxPollers = 4;
 constexpr uint32_t kF6CntStride = 32;                  // words between per-block counters (same-line atomics serialise)
 
-// One 32-byte row per slot, written once per tick by k_flow6_table, copied into LDS by the solve kernel.
+// One 32-byte row per slot, written once per tick - the constraint's own part and the links inside a body's own range by
+// k_flow6_blocks, the links that need the body's whole chain by k_flow6_links - and copied into LDS by the solve kernel.
 struct F6Row {
   uint32_t c;        // constraint id
-  uint32_t ref;      // a's LDS index (bits 0-10) | b's (bits 11-21, kF6NoBody = Static) | kF6RefFinalA/B
+  uint32_t ref;      // a's LDS index (bits 0-10) | b's (bits 11-21, kF6NoBody = Static)
   uint32_t succ0, succ1;  // local: slot | kF6Wrap;  remote: kF6Remote | kF6Wrap | out channel << 24 | LDS index of the body in the
                           // successor's block << 13 | the successor's slot there
-  uint32_t state0;   // arrivals still missing in iteration 0 (bits 0-7); bits 8-15 count the iterations done
-  uint32_t pad[3];
+  uint32_t pred_a;   // 1: the constraint has a predecessor on body a inside an iteration (k_flow6_blocks)
+  uint32_t pred_b;   // ... on body b (1 by default, cleared by k_flow6_links where the chain starts); their sum = arrivals missing in iteration 0
+  uint32_t pad[2];
 };
 static_assert(sizeof(F6Row) == 32, "F6Row is two 16-byte words");
 
@@ -96,43 +97,31 @@ constexpr uint32_t kF6Hash = 4096;
 constexpr uint32_t kF6PrepThreads = 1024;
 __global__ __launch_bounds__(kF6PrepThreads) void k_flow6_blocks(Flow6 F, ConsLinks K) {
   constexpr uint32_t kBlock = kF6PrepThreads;  // (this kernel's own block size)
-  __shared__ uint32_t s_part[kBlock];
+  __shared__ uint32_t s_wave[kBlock / 64];
   __shared__ uint32_t s_key[kF6Hash], s_val[kF6Hash];
-  __shared__ uint32_t s_cnt;
-  const uint32_t g = blockIdx.x, t = threadIdx.x;
+  __shared__ uint32_t s_cnt, s_run;
+  const uint32_t g = blockIdx.x, t = threadIdx.x, lane = t & 63u, wv = t >> 6;
   if (*F.C_ptr == 0u) return;  // (an empty or failed list: the solve kernel does nothing either)
   const uint32_t p_lo = g * F.nb, p_hi = min(F.n, p_lo + F.nb);
-  const uint32_t per = (F.nb + kBlock - 1) / kBlock;
-  const uint32_t lo = min(p_hi, p_lo + t * per), hi = min(p_hi, lo + per);
-  uint32_t sum = 0;
-  for (uint32_t p = lo; p < hi; ++p) { const uint32_t x = F.sidx[p]; sum += F.base[x + 1] - F.base[x]; }
-  s_part[t] = sum;
   for (uint32_t e = t; e < kF6Hash; e += kBlock) { s_key[e] = 0u; s_val[e] = 0u; }
-  if (t == 0) s_cnt = 0u;
+  if (t == 0) { s_cnt = 0u; s_run = 0u; }
   __syncthreads();
-  for (uint32_t off = 1; off < kBlock; off <<= 1) {  // inclusive scan of the partial sums
-    uint32_t v = t >= off ? s_part[t - off] : 0u;
+  // (1) slots: a running prefix over the block's bodies in cell order, kBlock bodies per round (wave scan + the waves before)
+  // (2) on the way, the foreign bodies among each body's partners go into the hash set
+  for (uint32_t p0 = p_lo; p0 < p_hi; p0 += kBlock) {
+    const uint32_t p = p0 + t;
+    uint32_t x = 0, b0 = 0, cnt = 0;
+    if (p < p_hi) { x = F.sidx[p]; b0 = F.base[x]; cnt = F.base[x + 1] - b0; }
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if ((int)lane >= o) inc += u; }
+    if (lane == 63u) s_wave[wv] = inc;
     __syncthreads();
-    s_part[t] += v;
-    __syncthreads();
-  }
-  uint32_t run = s_part[t] - sum;
-  for (uint32_t p = lo; p < hi; ++p) {
-    const uint32_t x = F.sidx[p], b0 = F.base[x], b1 = F.base[x + 1];
-    F.binfo[x] = make_uint4(p, run, b0, b1 - b0);
-    run += b1 - b0;
-  }
-  if (t == kBlock - 1) {
-    const uint32_t total = s_part[t];
-    F.nslots[(size_t)g * kF6CntStride] = total;
-    atomicMax(F.max_slots, total);
-    if (total > F.slot_cap || total > kF6MaxSlots) atomicOr(F.fail, 2u);
-  }
-  // the set of foreign bodies (one thread per own body, its constraints in turn)
-  for (uint32_t p = p_lo + t; p < p_hi; p += kBlock) {
-    const uint32_t x = F.sidx[p];
-    for (uint32_t c = F.base[x]; c < F.base[x + 1]; ++c) {
-      const uint32_t b = K.ab[c].y;
+    uint32_t before = s_run, total = 0;
+    for (uint32_t k = 0; k < kBlock / 64; ++k) { const uint32_t u = s_wave[k]; if (k < wv) before += u; total += u; }
+    if (p < p_hi) F.binfo[x] = make_uint4(p, before + inc - cnt, b0, cnt);
+    for (uint32_t k = 0; k < cnt; ++k) {
+      const uint32_t b = K.ab[b0 + k].y;
       if (b == kNone || F.brank[b] / F.nb == g) continue;
       uint32_t i = (b * 2654435761u) >> 20;
       for (uint32_t probe = 0; probe < kF6Hash; ++probe, i = (i + 1u) & (kF6Hash - 1u)) {
@@ -140,8 +129,16 @@ __global__ __launch_bounds__(kF6PrepThreads) void k_flow6_blocks(Flow6 F, ConsLi
         if (cur == 0u || cur == b + 1u) break;
       }
     }
+    __syncthreads();
+    if (t == 0) s_run += total;
+    __syncthreads();
   }
-  __syncthreads();
+  if (t == 0) {
+    const uint32_t total = s_run;
+    F.nslots[(size_t)g * kF6CntStride] = total;
+    atomicMax(F.max_slots, total);
+    if (total > F.slot_cap || total > kF6MaxSlots) atomicOr(F.fail, 2u);
+  }
   for (uint32_t e = t; e < kF6Hash; e += kBlock) {
     if (s_key[e]) {
       const uint32_t k = atomicAdd(&s_cnt, 1u);
@@ -155,15 +152,40 @@ __global__ __launch_bounds__(kF6PrepThreads) void k_flow6_blocks(Flow6 F, ConsLi
     atomicMax(F.max_foreign, s_cnt);
     if (s_cnt > F.fcap || s_cnt >= kF6Hash / 2u) atomicOr(F.fail, 1u);
   }
+  // every own constraint's row: id, LDS indices of its bodies, the link to the next constraint of body a's own range (the
+  // last of the range is linked by k_flow6_links, which knows where the body's chain goes on)
   for (uint32_t p = p_lo + t; p < p_hi; p += kBlock) {
     const uint32_t x = F.sidx[p];
-    for (uint32_t c = F.base[x]; c < F.base[x + 1]; ++c) {
-      const uint32_t b = K.ab[c].y;
-      if (b == kNone) continue;
-      if (F.brank[b] / F.nb == g) { F.bref[c] = F.brank[b] - g * F.nb; continue; }
-      uint32_t i = (b * 2654435761u) >> 20;
-      while (s_key[i] != b + 1u) i = (i + 1u) & (kF6Hash - 1u);
-      F.bref[c] = F.nb + s_val[i];
+    const uint4 ix = F.binfo[x];
+    const uint32_t aref = p - g * F.nb;
+    if (aref >= kF6NoBody) atomicOr(F.fail, 16u);
+    for (uint32_t k0 = 0; k0 < ix.w; k0 += 4u) {  // four constraints' look-ups in flight
+      uint32_t b[4], pb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = k0 + (uint32_t)j < ix.w ? K.ab[ix.z + k0 + (uint32_t)j].y : kNone;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pb[j] = b[j] != kNone ? F.brank[b[j]] : 0u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t k = k0 + (uint32_t)j;
+        if (k >= ix.w) break;
+        const uint32_t c = ix.z + k, slot = ix.y + k;
+        uint32_t bref = kF6NoBody;
+        if (b[j] != kNone) {
+          if (pb[j] / F.nb == g) bref = pb[j] - g * F.nb;
+          else {
+            uint32_t i = (b[j] * 2654435761u) >> 20;
+            while (s_key[i] != b[j] + 1u) i = (i + 1u) & (kF6Hash - 1u);
+            bref = F.nb + s_val[i];
+          }
+          F.bref[c] = bref;
+          if (bref >= kF6NoBody) atomicOr(F.fail, 16u);
+        }
+        if (slot >= F.slot_cap || slot >= kF6MaxSlots) continue;  // (fail bit 2 is up)
+        uint4* dst = reinterpret_cast<uint4*>(&F.table[(size_t)g * F.rows + slot]);
+        dst[0] = make_uint4(c, aref | (min(bref, kF6NoBody) << kF6BodyBits), k + 1u < ix.w ? slot + 1u : 0u, 0u);
+        dst[1] = make_uint4(k > 0u ? 1u : 0u, b[j] != kNone ? 1u : 0u, 0u, 0u);  // (pred_b: all but the first constraint of a chain without own ones - k_flow6_links clears that one)
+      }
     }
   }
 }
@@ -179,51 +201,101 @@ __device__ __forceinline__ uint32_t f6_chan_slot(uint32_t* keys, uint32_t key1, 
   atomicOr(fail, 4u);
   return 0u;
 }
-// Per constraint: its row of the block's slot table.
-__global__ __launch_bounds__(kBlock) void k_flow6_table(Flow6 F, ConsLinks K, const uint32_t* C_ptr) {
-  const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
-  if (c >= *C_ptr) return;
-  const uint2 e = K.ab[c];
-  const uint4 ia = F.binfo[e.x];  // (position, first slot, first constraint) of body a: the block's own
-  const uint32_t g = ia.x / F.nb;
-  const uint32_t slot = ia.y + (c - ia.z);
-  if (slot >= F.slot_cap || slot >= kF6MaxSlots) { atomicOr(F.fail, 2u); return; }
-  F6Row R;
-  R.c = c;
-  const uint32_t aref = ia.x - g * F.nb;
-  const uint32_t bref = e.y == kNone ? kF6NoBody : F.bref[c];
-  if (aref >= kF6NoBody || (e.y != kNone && bref >= kF6NoBody)) { atomicOr(F.fail, 16u); return; }
-  const uint2 sw = K.succ[c];
-  // this constraint ends the chain of its body b (its successor word wraps to the next iteration) and b lives in another
-  // block: it writes b's result, and b's own block does not (a is always the block's own)
-  const bool final_b = e.y != kNone && (sw.y & kSuccWrap) && F.brank[e.y] / F.nb != g;
-  if (final_b) F.skipwb[e.y] = 1;
-  R.ref = aref | (bref << kF6BodyBits) | (final_b ? kF6RefFinalB : 0u);
-  R.state0 = (uint32_t)K.pred[2 * c] + (e.y != kNone ? (uint32_t)K.pred[2 * c + 1] : 0u);  // links_indeg0
-  uint32_t w[2] = {sw.x, sw.y};
-#pragma unroll
-  for (int side = 0; side < 2; ++side) {
-    if (side == 1 && e.y == kNone) { w[1] = 0u; break; }
-    const uint32_t sid = w[side] & kSuccId, wrap = (w[side] & kSuccWrap) ? kF6Wrap : 0u;
-    const uint32_t body = side == 0 ? e.x : e.y;
-    const uint32_t sa = K.ab[sid].x;  // the successor's home is its body a's block
-    const uint4 is = F.binfo[sa];
-    const uint32_t hs = is.x / F.nb;
-    const uint32_t sslot = is.y + (sid - is.z);
-    if (hs == g) { w[side] = wrap | sslot; continue; }
-    // the edge crosses a block face: a message on the channel g -> hs
-    const uint32_t dbody = sa == body ? is.x - hs * F.nb : F.bref[sid];  // as a: own there; as b: what k_flow6_blocks gave it
-    const uint32_t k_in = f6_chan_slot(F.in_key + (size_t)hs * kF6Chan, g + 1u, F.fail);
-    atomicAdd(&F.in_cnt[(size_t)hs * kF6Chan + k_in], 1u);
-    const uint32_t k_out = f6_chan_slot(F.out_key + (size_t)g * kF6Chan, hs + 1u, F.fail);
-    F.out_val[(size_t)g * kF6Chan + k_out] = k_in;
-    if (sslot >= kF6MaxSlots || dbody >= kF6NoBody) atomicOr(F.fail, 16u);
-    w[side] = kF6Remote | wrap | (k_out << 24) | (dbody << kF6SlotBits) | sslot;
+// Per body, in cell order: the links of its chain that leave its own range of constraints - last own constraint -> first
+// constraint it takes part in as `b` (its row of such constraints, written by k_setup_pairs in arrival order, sorted here)
+// -> ... -> back to the first (the wrap to the next iteration) - written straight into the rows of the block tables, with
+// the channel of every link that crosses a block face.  This is k_chain_rows and the old per-constraint table kernel in
+// one: no (succ, pred) arrays in between (k_chain_rows still builds them for the other solver modes, and - launched behind
+// this kernel with a guard - for the stand-by when a block did not fit).
+struct F6Ent { uint32_t home, slot, role, c, bref; };
+__global__ __launch_bounds__(kBlock) void k_flow6_links(Flow6 F, ConsLinks K, uint32_t n, const uint32_t* degb, uint32_t* rev, uint32_t rev_cap,
+                                                        const uint32_t* rev_flag, StepCounts* sc, uint32_t n_owned, uint32_t* n_ghost_cons) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  // constraints whose obj_a is a ghost (ids are ascending in obj_a): the copies of seam constraints (tiles count them once)
+  if (t == 0) *n_ghost_cons = (sc->fail || *rev_flag) ? 0u : F.base[n] - F.base[n_owned];
+  if (*rev_flag) {
+    if (t == 0) { sc->C = 0; sc->Ct = 0; sc->fail |= kFailRevRow; }
+    return;
   }
-  R.succ0 = w[0]; R.succ1 = w[1];
-  uint4* dst = reinterpret_cast<uint4*>(&F.table[(size_t)g * F.rows + slot]);
-  dst[0] = make_uint4(R.c, R.ref, R.succ0, R.succ1);
-  dst[1] = make_uint4(R.state0, 0u, 0u, 0u);
+  if (t >= n || sc->fail) return;
+  const uint32_t x = F.sidx[t];
+  const uint4 ix = F.binfo[x];  // (position = t, first slot, first constraint, constraints of its own)
+  const uint32_t g = t / F.nb, na = ix.w, nbr = degb[x];
+  if (na + nbr == 0u) return;
+  uint32_t* row = rev + (size_t)x * rev_cap;
+  // the row in ascending constraint id = insertion order: up to four entries (most bodies) sorted in registers from one
+  // 16-byte load, longer rows in place
+  const bool small = nbr <= 4u && (rev_cap & 3u) == 0u;
+  uint32_t s4[4] = {kNone, kNone, kNone, kNone};
+  if (small) {
+    const uint4 r4 = *reinterpret_cast<const uint4*>(row);
+    s4[0] = nbr > 0u ? r4.x : kNone; s4[1] = nbr > 1u ? r4.y : kNone; s4[2] = nbr > 2u ? r4.z : kNone; s4[3] = nbr > 3u ? r4.w : kNone;
+    auto cx = [&](int p, int q) { const uint32_t lo = min(s4[p], s4[q]), hi = max(s4[p], s4[q]); s4[p] = lo; s4[q] = hi; };
+    cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);  // (kNone = 0xFFFFFFFF sorts behind every id)
+  } else {
+    for (uint32_t a = 1; a < nbr; ++a) {
+      uint32_t v = row[a], b = a;
+      while (b > 0 && row[b - 1] > v) { row[b] = row[b - 1]; --b; }
+      row[b] = v;
+    }
+  }
+  // the chain: [last own constraint,] b_0 .. b_{nbr-1}, and back to its FIRST constraint (first own, else b_0)
+  F6Ent first;
+  first.home = g; first.slot = ix.y; first.role = 0u; first.c = ix.z; first.bref = 0u;  // (na > 0; else set from the first `b` entry below)
+  F6Ent u = first;
+  if (na) { u.slot = ix.y + na - 1u; u.c = ix.z + na - 1u; }
+  bool have_u = na != 0u;
+  // the `b` entries four at a time: their look-ups (constraint -> body a -> block, slot; LDS index of x over there) are
+  // independent of each other and go out together; the links are then written in order
+  for (uint32_t k0 = 0; k0 <= nbr; k0 += 4u) {
+    uint32_t c[4];
+    uint4 ii[4];
+    uint32_t br[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = small ? (k0 == 0u ? s4[j] : kNone) : (k0 + (uint32_t)j < nbr ? row[k0 + (uint32_t)j] : kNone);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ii[j] = make_uint4(0, 0, 0, 0); br[j] = 0u;
+      if (c[j] != kNone) { ii[j] = F.binfo[K.ab[c[j]].x]; br[j] = F.bref[c[j]]; }  // the constraint lives in its body a's block
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t kb = k0 + (uint32_t)j;
+      if (kb > nbr) break;
+      const bool last = kb == nbr;
+      F6Ent w;
+      if (last) w = first;
+      else { w.c = c[j]; w.role = 1u; w.home = ii[j].x / F.nb; w.slot = ii[j].y + (c[j] - ii[j].z); w.bref = br[j]; }
+      if (!have_u) {  // (no own constraints: the chain starts at the first `b` entry, which has no predecessor on this body)
+        first = w; u = w; have_u = true;
+        if (w.slot < F.rows) reinterpret_cast<uint32_t*>(&F.table[(size_t)w.home * F.rows + w.slot])[5] = 0u;  // pred_b (1 by default)
+        continue;
+      }
+      const uint32_t wrap = last ? kF6Wrap : 0u;
+      uint32_t word;
+      if (u.home == w.home) {
+        word = wrap | w.slot;
+      } else {  // the link crosses a block face: a message on the channel u.home -> w.home
+        const uint32_t dbody = w.role == 0u ? t - w.home * F.nb : w.bref;  // as a: own there; as b: what k_flow6_blocks gave it
+        uint32_t* ik = F.in_key + (size_t)w.home * kF6Chan;
+        uint32_t* ok = F.out_key + (size_t)u.home * kF6Chan;
+        // both hash tables at their home slots first (one round trip); the probing / inserting path only on a miss
+        const uint32_t hi = ((u.home + 1u) * 2654435761u) >> 26, ho = ((w.home + 1u) * 2654435761u) >> 26;
+        const uint32_t ci = __hip_atomic_load(&ik[hi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t co = __hip_atomic_load(&ok[ho], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t k_in = ci == u.home + 1u ? hi : f6_chan_slot(ik, u.home + 1u, F.fail);
+        const uint32_t k_out = co == w.home + 1u ? ho : f6_chan_slot(ok, w.home + 1u, F.fail);
+        atomicAdd(&F.in_cnt[(size_t)w.home * kF6Chan + k_in], 1u);
+        F.out_val[(size_t)u.home * kF6Chan + k_out] = k_in;
+        if (w.slot >= kF6MaxSlots || dbody >= kF6NoBody) atomicOr(F.fail, 16u);
+        word = kF6Remote | wrap | (k_out << 24) | (dbody << kF6SlotBits) | w.slot;
+      }
+      if (u.slot < F.rows) reinterpret_cast<uint32_t*>(&F.table[(size_t)u.home * F.rows + u.slot])[2 + u.role] = word;
+      // the chain ends in a constraint of another block: that block writes the body's result, its own does not
+      if (last && u.role == 1u && u.home != g) F.skipwb[x] = 1;
+      u = w;
+    }
+  }
 }
 // One wave per block (its kF6Chan hash slots = the wave's lanes): where each incoming channel's messages start inside the
 // block's region of the channel buffer (exclusive prefix of the per-iteration edge counts), and whether the region suffices.
@@ -334,7 +406,8 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
   for (uint32_t idx = t; idx < N; idx += kF6Threads) {
     const uint4* src = reinterpret_cast<const uint4*>(&rows[idx]);
     const uint4 r0 = src[0];
-    const uint32_t st0 = src[1].x;
+    const uint4 r1 = src[1];
+    const uint32_t st0 = r1.x + r1.y;
     s_c[idx] = r0.x; s_ref[idx] = r0.y; s_succ[idx] = make_uint2(r0.z, r0.w); s_state[idx] = st0;
     if (st0 == 0u && iters > 0) f6_push(q, idx);  // iteration 0's frontier
   }
@@ -510,8 +583,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
           // this node's own releases), and one more iteration done
           __hip_atomic_fetch_add(&s_state[slot], 0x100u + (has_b ? 2u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           if (round + 1u == iters) {  // the end of a foreign body's chain: its home block does not write it back
-            if (ref & kF6RefFinalA) store_vel(srec, ga, A);
-            if (ref & kF6RefFinalB) store_vel(srec, gb, Bd);
+            if (has_b && (sw.y & kF6Wrap) && bi >= F.nb) store_vel(srec, gb, Bd);  // (a is always the block's own)
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // velocities are in LDS before any local successor hears of it
           if (TRACE) {
