@@ -1,5 +1,6 @@
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace -d $R/gpurun_out/c4_trace -o bench -- python $R/bench.py --gpus 1 --scene config4 --no-cpu-baseline --steps 20 --warmup 5 > $R/gpurun_out/c4_trace.log 2>&1
-cd $R
-python tools/rocprof_summary.py gpurun_out/c4_trace/bench_results.db 160 | head -24 | cut -c1-150
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | grep -a "passed\|failed" | tail -3
+B="python bench.py --no-cpu-baseline --no-order-check --min-seconds 1"
+for k in 1 2; do
+$B | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],4), round(d['value']/1e9,3), d['roofline']['avg_launch_us'], d['roofline']['frac'], d['settled']['ms_per_step'], d['settled']['roofline']['avg_launch_us'], d['settled']['roofline']['frac'])"
+done
