@@ -389,6 +389,7 @@ def cpu_baseline(iters):
             "physics_steps_per_sec": c2["physics_steps_per_sec"], "solve_phase_constraint_iters_per_sec": c2["solve_phase_constraint_iters_per_sec"],
             "cpu_model": _cpu_model(), "nproc": os.cpu_count(),
             "config1_balls_512": c1, "config3_capsules_131072": c3,
+            "config3_note": "capsule_field(128, 32, 32) at pitch 1.6 over a 158 x 158-quad heightfield (SURVEY 8d names pitch 2.6: a sparser field, fewer contacts)",
             "note": "C++ restatement of mgf (g++ -O2 -ffp-contract=off), not rustc output; the reference is single-threaded"}
 
 

@@ -271,9 +271,10 @@ __device__ __forceinline__ void box_min_max(V3& lo, V3& hi, V3 l, V3 h) {
 __device__ __forceinline__ float pair_query_pad(const V3& c, const V3& r, float pad_abs) {
   return pad_abs + 1e-5f * (fabs_rs(c.x) + fabs_rs(c.y) + fabs_rs(c.z) + r.x + r.y + r.z);
 }
-__device__ __forceinline__ void pair_query_region(const V3& qc, const V3& qr, float pad, const SceneBounds* sb, const uint32_t* nb, uint32_t* ca, uint32_t* d) {
+__device__ __forceinline__ void pair_query_region(const V3& qc, const V3& qr, float pad, const SceneBounds* sb, const uint32_t* nb, uint32_t* ca, uint32_t* d,
+                                                  float min_frac) {
   float glo[3], ghi[3];
-  grid_box(sb, kBodyGridMinFrac, glo, ghi);
+  grid_box(sb, min_frac, glo, ghi);
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     float lo = glo[k], hi = ghi[k], rm = ord_f(sb->rmax[k]);
@@ -286,7 +287,7 @@ __device__ __forceinline__ void pair_query_region(const V3& qc, const V3& qr, fl
 // Bodies -> leaf records in cell order (counting sort, second half).
 __global__ __launch_bounds__(kBlock) void k_scatter_leaves(Lbvh T, const float4* fb_c, const float4* fb_r, const uint32_t* cell_of,
                                                            const uint32_t* rank, uint32_t* brank, const float4* col0, const float4* delta, const float4* tb_c,
-                                                           const float4* tb_r, const SceneBounds* sb, float pad_abs) {
+                                                           const float4* tb_r, const SceneBounds* sb, float pad_abs, float min_frac) {
   uint32_t body = blockIdx.x * kBlock + threadIdx.x;
   if (body >= T.n) return;
   uint32_t p = T.cell_lo[cell_of[body]] + rank[body];
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter_leaves(Lbvh T, const float4*
     const uint32_t P = 2u * T.levels;
     const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};
     uint32_t ca[3], d[3];
-    pair_query_region(xyz(c), xyz(r), pair_query_pad(xyz(c), xyz(r), pad_abs), sb, nb, ca, d);
+    pair_query_region(xyz(c), xyz(r), pair_query_pad(xyz(c), xyz(r), pad_abs), sb, nb, ca, d, min_frac);
     T.ltb[2 * p] = mk4(xyz(c), u2f(ca[0] | (ca[1] << 10) | (ca[2] << 20)));  // (ca < 1024, d <= 1024 - ca)
     T.ltb[2 * p + 1] = mk4(xyz(r), u2f(d[0] | (d[1] << 10) | (d[2] << 20)));
   }
@@ -825,7 +826,7 @@ __device__ __forceinline__ void pair_query_cells(const Src& S, const Box& q, con
 template <bool SPHERES>
 __global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, uint32_t n_owned, Lbvh T, const SceneBounds* sb, float pad_abs,
                                                           uint32_t* rows_p, uint32_t* p_cnt, uint32_t* overflow, uint32_t* too_wide,
-                                                          uint32_t* pair_stat) {
+                                                          uint32_t* pair_stat, float min_frac) {
   __shared__ uint32_t s_acc[SPHERES ? kCoopBlock / kCoopLanes : 1][SPHERES ? kRowCap : 1];  // accepted partners of a query (leaf positions)
   const int lane = threadIdx.x & 63;
   const int sub = lane & 7;
@@ -842,7 +843,7 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, 
     const uint32_t P = 2u * T.levels;
     const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};  // prefix bits per axis (x is the most significant)
     uint32_t ca[3], d[3];
-    pair_query_region(q.c, q.r, pad, sb, nb, ca, d);
+    pair_query_region(q.c, q.r, pad, sb, nb, ca, d, min_frac);
     if (d[0] * d[1] * d[2] > kGridMaxCells) {
       if (sub == 0) *too_wide = 1u;
     } else {
