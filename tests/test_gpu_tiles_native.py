@@ -145,3 +145,50 @@ def test_halo_smaller_than_a_body_is_refused(ctx):
     py = [Tile(HipEngine(ctx, sc, 0), sc["x_range"], r, 2, sc["dt"], sc["iters"], halo=0.5) for r, sc in enumerate(tile_scenes)]
     with pytest.raises(ValueError):
         step_tiles_inprocess(py)
+
+
+def _penetration(x, owner, radius=0.5):
+    """mean overlap depth of touching sphere pairs: (pairs whose bodies have different owners, the others, #different)"""
+    from scipy.spatial import cKDTree
+    x = x.astype(np.float64)
+    pairs = cKDTree(x).query_pairs(2 * radius, output_type="ndarray")
+    pen = 2 * radius - np.linalg.norm(x[pairs[:, 0]] - x[pairs[:, 1]], axis=1)
+    cross = owner[pairs[:, 0]] != owner[pairs[:, 1]]
+    return float(pen[cross].mean()), float(pen[~cross].mean()), int(cross.sum())
+
+
+def test_seam_quality_at_scale_against_the_undivided_world(ctx):
+    """What the block-Jacobi coupling across a slab face costs physically, at a size the CPU test cannot reach ("only
+    characterised on a 6x6x6 pile"): 4 tiles of 16 x 24 x 32 spheres (49 152 bodies) for 240 ticks with the ghost velocities
+    refreshed every R = 1, 2, 10 iterations, against the same pile as ONE world in the exact Gauss-Seidel order.  Measured: mean
+    resting penetration of touching pairs across a slab face vs inside a tile, and the same two sets of pairs in the undivided
+    world (its "seam" = the pairs that straddle the planes where the tiles' faces would be)."""
+    P, nx, ny, nz, ticks = 4, 16, 24, 32, 240
+    tile_scenes = [scenes.sphere_pile_tile(nx, ny, nz, r, P) for r in range(P)]
+    merged = dict(tile_scenes[0])
+    for key in ("comps", "mass", "restitution", "friction", "force", "v0"):
+        merged[key] = np.concatenate([s[key] for s in tile_scenes])
+    one = mgf_amd.World.from_scene(ctx, merged)
+    dt, iters = float(merged["dt"]), merged["iters"]
+    for _ in range(ticks):
+        one.step(dt, iters)
+    x1 = one.state()["x"]
+    edges = np.array([sc["x_range"][1] for sc in tile_scenes[:-1]])
+    ref_seam, ref_in, ref_n = _penetration(x1, np.searchsorted(edges, x1[:, 0]))
+    print(f"undivided world: pairs across the would-be faces {ref_seam:.4f} ({ref_n} pairs), the others {ref_in:.4f}")
+    rows = {}
+    for R in (1, 2, 10):
+        T, worlds = _native(ctx, tile_scenes, refresh_every=R)
+        for _ in range(ticks):
+            T.step(dt, iters)
+        x = np.concatenate([w.state()["x"][:len(w)] for w in worlds])
+        owner = np.concatenate([np.full(len(w), r) for r, w in enumerate(worlds)])
+        rows[R] = _penetration(x, owner)
+        # how far the tiled pile is from the undivided one, body by body (tags are global ids)
+        tags = np.concatenate([w.tags()[:len(w)] for w in worlds])
+        dev = np.linalg.norm(x[np.argsort(tags)].astype(np.float64) - x1.astype(np.float64), axis=1)
+        print(f"tiles, refresh every {R:2d} iterations: seam penetration {rows[R][0]:.4f} ({rows[R][2]} pairs), interior {rows[R][1]:.4f}; "
+              f"distance from the undivided world: median {np.median(dev):.4f}, 99th percentile {np.percentile(dev, 99):.4f}")
+    assert ref_n > 500 and rows[2][2] > 500
+    assert rows[2][0] < 1.25 * rows[2][1] and rows[1][0] < 1.25 * rows[1][1]   # the default keeps the seam at the interior's level
+    assert rows[2][1] < 1.1 * ref_in                                          # ... and the interior at the undivided world's
