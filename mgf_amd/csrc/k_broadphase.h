@@ -77,7 +77,8 @@ struct StepCounts {
 };
 constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u, kFailGridWide = 8u, kFailTerrainRow = 16u, kFailTerrainWide = 32u,
                    kFailRevRow = 64u,  // a body's row of `b` occurrences overflowed (k_setup_pairs / k_chain_rows)
-                   kFailSkipped = 128u;  // a speculative tick behind a failed one: nothing was done (k_reset_step)
+                   kFailSkipped = 128u,  // a speculative tick behind a failed one: nothing was done (k_reset_step)
+                   kFailFlow6 = 256u;    // the block-local solver's tables did not fit (k_flow6_*): the solve did nothing; the tick is re-run with the global dataflow solver
 
 // The list sizes of the tick, checked against the capacities the lists were allocated with, at the end of the scans that
 // produce them (the thread of k_scan that writes the last prefix runs these: no launch of their own).

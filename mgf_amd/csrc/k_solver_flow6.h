@@ -77,6 +77,7 @@ struct Flow6 {
   uint32_t mbox_cap;         // messages the buffer holds
   uint32_t* fail;            // a limit was exceeded (1 foreign slots, 2 constraint slots, 4 channels, 8 channel buffer, 16 index width):
                              // the stand-by k_solve_flow launch does the work; fail[1] = edges across block faces per iteration
+  uint32_t* tick_fail;       // the tick's StepCounts::fail: gets kFailFlow6 when `fail` is up after the preparation (the host re-runs the tick)
   uint32_t* max_slots;       // largest block / most foreign bodies of this tick (the host sizes the next tick's LDS split)
   uint32_t* max_foreign;
   uint32_t nb, nblocks, n;
@@ -312,6 +313,8 @@ __global__ __launch_bounds__(kBlock) void k_flow6_chan(Flow6 F, uint32_t iters) 
     atomicAdd(&F.fail[1], incl);  // edges that cross a block face, per iteration (the host sizes the channel buffer from it)
     atomicMax(&F.fail[2], incl);  // ... the most any block receives
     if ((uint64_t)incl * iters > F.mbox_cap / F.nblocks) atomicOr(F.fail, 8u);
+    // the preparation ends here: whatever went wrong in it is now visible - tell the tick (its read-back carries the word)
+    if (__hip_atomic_load(F.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicOr(F.tick_fail, kFailFlow6);
   }
 }
 

@@ -493,8 +493,9 @@ def test_body_added_between_begin_and_collide_is_seen(ctx):
 @pytest.mark.parametrize("mode", [5, 6])
 def test_block_that_does_not_fit_falls_back_on_the_device(ctx, mode):
     """When a spatial block holds more constraints than its workgroup's LDS layout (forced here by a tiny test limit), a
-    device flag turns k_solve_flow5 / k_solve_flow6 into a no-op and the k_solve_flow launch enqueued behind it does the work -
-    no host round trip inside the tick, the same result, and the counter says it happened."""
+    device flag turns k_solve_flow5 / k_solve_flow6 into a no-op and k_solve_flow does the work - enqueued behind it, no host round
+    trip inside the tick (mode 5), or in a re-run of the tick that the read-back asks for (mode 6) - with the same result, and the
+    counter says it happened."""
     import mgf_amd
     from mgf_amd import scenes
     scene = scenes.sphere_pile(10, 10, 10)
@@ -514,6 +515,51 @@ def test_block_that_does_not_fit_falls_back_on_the_device(ctx, mode):
         so, sg = ow.step(dt, iters), gw.step(dt, iters)
     assert gw.counter(f"flow{mode}_fallbacks") == n0
     _compare_state(gw, ow, "after the stand-by phase")
+
+
+def test_mode6_tables_that_do_not_fit_rerun_the_tick_also_in_the_pipelined_loop(ctx):
+    """Mode 6 builds its block tables inside the collide phase; when they do not fit (forced by a tiny limit) the tick's
+    read-back says so (kFailFlow6), the solver launch has done nothing, and the tick is re-run with the global dataflow solver -
+    in mgf_world_step_many the speculative tick behind it is turned into a no-op by the device-side guard first."""
+    import mgf_amd
+    from mgf_amd import scenes
+    scene = scenes.sphere_pile(10, 10, 10)
+    dt, iters = float(scene["dt"]), scene["iters"]
+    ow, gw = oracle_world(scene), mgf_amd.World.from_scene(ctx, scene)
+    gw.step_many(dt, iters, 6)
+    for _ in range(6):
+        ow.step(dt, iters)
+    gw.set_option("flow6_test_cap", 40)
+    got = [int(s.n_constraints) for s in gw.step_many(dt, iters, 24)]
+    want = [int(ow.step(dt, iters).n_constraints) for _ in range(24)]
+    assert got == want and gw.counter("flow6_fallbacks") >= 20 and gw.counter("flow6_fail_reason") & 2
+    _compare_state(gw, ow, "re-run ticks")
+    gw.set_option("flow6_test_cap", 0)
+    n0 = gw.counter("flow6_fallbacks")
+    got = [int(s.n_constraints) for s in gw.step_many(dt, iters, 10)]
+    want = [int(ow.step(dt, iters).n_constraints) for _ in range(10)]
+    assert got == want and gw.counter("flow6_fallbacks") == n0
+    _compare_state(gw, ow, "after the re-run phase")
+
+
+def test_mode6_chosen_after_the_collide_phase_keeps_its_stand_by(ctx):
+    """A caller that builds the constraints in another solver mode and switches to 6 before Solver::solve: the tables are built at
+    solve time, too late for a re-run of the collide phase, so the guarded stand-by launch (and its links) stay behind the solver."""
+    import mgf_amd
+    from mgf_amd import scenes
+    scene = scenes.sphere_pile(9, 9, 9)
+    dt, iters = float(scene["dt"]), scene["iters"]
+    ow, gw = oracle_world(scene), mgf_amd.World.from_scene(ctx, scene)
+    for cap in (0, 40):  # the block-local kernel itself, then its stand-by
+        for _ in range(12):
+            ow.step(dt, iters)
+            gw.set_option("solver_mode", 1)
+            gw.build_constraints(dt)
+            gw.set_option("solver_mode", 6)
+            gw.set_option("flow6_test_cap", cap)
+            gw.solve(iters)
+        _compare_state(gw, ow, f"mode 6 after the collide phase, test cap {cap}")
+    assert gw.counter("flow6_fallbacks") >= 10
 
 
 @pytest.mark.parametrize("mode", [1, 4, 5, 105, 6, 106, 206])
