@@ -33,8 +33,12 @@ constexpr uint32_t kF6SlotBits = 13, kF6BodyBits = 11;
 constexpr uint32_t kF6MaxSlots = (1u << kF6SlotBits) - 1u;  // per block
 constexpr uint32_t kF6NoBody = (1u << kF6BodyBits) - 1u;    // b-ref of a constraint against a Static body
 constexpr uint32_t kF6Remote = 0x80000000u, kF6Wrap = 0x40000000u;
+// a slot's state word in LDS: arrivals still missing (bits 0-1: 0..2), iterations done (bits 2-8: <= kF6MaxIters), and - constant -
+// the row's body references (bits 10-31)
+constexpr uint32_t kF6StArrMask = 3u, kF6StIterShift = 2u, kF6StIterMask = 0x7Fu, kF6StRefShift = 10u;
+static_assert(2u * kF6BodyBits + kF6StRefShift <= 32u, "the body references fit above the counters");
 constexpr uint32_t kF6MsgWords = 3;                    // uint4 granules per message
-constexpr uint32_t kF6MaxIters = 64;                   // (ring positions are reduced with a 32-bit reciprocal)
+constexpr uint32_t kF6MaxIters = 64;                   // (ring positions are reduced with a 32-bit reciprocal; 7 bits in the state word)
 constexpr uint32_t kF6WlLen = 128;                     // work items (channel, position) a polling wave lists per sweep
 constexpr uint32_t kF6MaxPollers = 4;
 constexpr uint32_t kF6CntStride = 32;                  // words between per-block counters (same-line atomics serialise)
@@ -85,8 +89,9 @@ struct Flow6 {
   uint32_t fcap, slot_cap;   // LDS split of this launch: foreign body slots, constraint slots
   uint32_t poll_waves, poll_k;  // waves that poll the incoming channels; (unused)
 };
-__host__ __device__ constexpr uint32_t f6_lds_bytes(uint32_t nb, uint32_t fcap, uint32_t slot_cap, bool const_lds = false) {
-  return 32u * (nb + fcap) + (const_lds ? 40u * nb : 0u) + 20u * slot_cap + 2u * slot_cap + 4u * (16u + 8u * kF6Chan) + 4u * (2u * kF6WlLen + 16u) + 32u;
+__host__ __device__ constexpr uint32_t f6_slot_bytes(bool nimp_lds) { return nimp_lds ? 22u : 18u; }  // successor words 8, id 4, state 4, ring 2 (+ impulse 4)
+__host__ __device__ constexpr uint32_t f6_lds_bytes(uint32_t nb, uint32_t fcap, uint32_t slot_cap, bool const_lds = false, bool nimp_lds = false) {
+  return 32u * (nb + fcap) + (const_lds ? 40u * nb : 0u) + f6_slot_bytes(nimp_lds) * slot_cap + 4u * (16u + 8u * kF6Chan) + 4u * (2u * kF6WlLen + 16u) + 32u;
 }
 
 // ---- preparation, once per constraint list ------------------------------------------------------------------------------
@@ -330,13 +335,14 @@ __device__ __forceinline__ void f6_push(const F6Ring& q, uint32_t slot) {
 // one arrival at `slot`: the last one queues it
 __device__ __forceinline__ void f6_arrive(const F6Ring& q, uint32_t* s_state, uint32_t slot) {
   const uint32_t old = __hip_atomic_fetch_sub(&s_state[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  if ((old & 0xFFu) == 1u) f6_push(q, slot);
+  if ((old & kF6StArrMask) == 1u) f6_push(q, slot);
 }
 
 // CL: the constant half of the own bodies' solver records (inverse mass, world inverse inertia: 40 B) is kept in LDS as well -
 // chosen by the host when the block's constraints leave room for it (the first ~100 ticks of the bench pile); otherwise the
 // lanes read it from the RigidBodyVec beside the constraint record.
-template <bool TRACE, bool CL>
+// NL: ContactState::normal_impulse of every slot's constraint lives in LDS for the launch as well (4 bytes per slot, when there is room).
+template <bool TRACE, bool CL, bool NL>
 __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* cons, Flow6 F, uint32_t iters, uint32_t epoch, uint32_t* abort_flag,
                                                             uint32_t spin_limit, uint64_t* trace, uint32_t C_trace) {
   if (*F.fail || *F.C_ptr == 0u) return;  // a limit was exceeded: the stand-by k_solve_flow launch behind this one does the work
@@ -346,9 +352,11 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
   float2* s_const = reinterpret_cast<float2*>(s_dyn + 2 * (size_t)nbod);  // CL: [5 * nb] inverse mass and inertia of the own bodies
   uint2* s_succ = reinterpret_cast<uint2*>(s_const + (CL ? 5 * (size_t)F.nb : 0));  // [cap]
   uint32_t* s_c = reinterpret_cast<uint32_t*>(s_succ + cap);           // [cap]
-  uint32_t* s_ref = s_c + cap;                                         // [cap]
-  uint32_t* s_state = s_ref + cap;                                     // [cap] arrivals missing (bits 0-7), iterations done (8-15)
-  uint32_t* s_ctl = s_state + cap;                                     // [16]: 0 head, 1 tail, 2 nodes left, 3 incoming channels
+  uint32_t* s_state = s_c + cap;                                       // [cap] arrivals missing | iterations done | body references (kF6St*)
+  float* s_nimp = reinterpret_cast<float*>(s_state + cap);            // [cap] ContactState::normal_impulse of the slot's constraint: read and written
+                                                                       // once per solve - in LDS (NL), not in the record (a 4-byte store per solve
+                                                                       // costs the launch 8 %: it queues in front of the next records' loads)
+  uint32_t* s_ctl = reinterpret_cast<uint32_t*>(s_nimp + (NL ? cap : 0u));  // [16]: 0 head, 1 tail, 2 nodes left, 3 incoming channels
   uint32_t* s_out_base = s_ctl + 16;                                   // [kF6Chan] first message of the outgoing channel
   uint32_t* s_out_tail = s_out_base + kF6Chan;                         // [kF6Chan] messages sent
   uint32_t* s_out_tidx = s_out_tail + kF6Chan;                         // [kF6Chan] the channel's word of F.tails
@@ -411,7 +419,8 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
     const uint4 r0 = src[0];
     const uint4 r1 = src[1];
     const uint32_t st0 = r1.x + r1.y;
-    s_c[idx] = r0.x; s_ref[idx] = r0.y; s_succ[idx] = make_uint2(r0.z, r0.w); s_state[idx] = st0;
+    s_c[idx] = r0.x; s_succ[idx] = make_uint2(r0.z, r0.w); s_state[idx] = st0 | (r0.y << kF6StRefShift);
+    if (NL) s_nimp[idx] = cons[r0.x].nimp;  // (0 in a tick's first Solver::solve; what the last one left in a later one)
     if (st0 == 0u && iters > 0) f6_push(q, idx);  // iteration 0's frontier
   }
   __syncthreads();
@@ -541,15 +550,17 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
           do { e = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (!(e & 0x8000u));  // the pusher is between its two writes
           *cell = 0;
           const uint32_t slot = e & 0x7FFFu;
-          const uint32_t round = (__hip_atomic_load(&s_state[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 8) & 0xFFu;
+          const uint32_t stw = __hip_atomic_load(&s_state[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const uint32_t round = (stw >> kF6StIterShift) & kF6StIterMask;
           uint64_t t_seen = 0;
           if (TRACE) t_seen = wall_clock64();
-          const uint32_t c = s_c[slot], ref = s_ref[slot];
+          const uint32_t c = s_c[slot], ref = stw >> kF6StRefShift;
           const uint2 sw = s_succ[slot];
           const uint32_t ai = ref & kF6NoBody, bi_raw = (ref >> kF6BodyBits) & kF6NoBody;
           const bool has_b = bi_raw != kF6NoBody;
           const uint32_t bi = has_b ? bi_raw : ai;
           CRec rec = load_crec_solve(&cons[c]);  // only the lane running the constraint touches its record
+          if (NL) rec.nimp = s_nimp[slot];
           const float4 a0 = s_body[2 * ai], a1 = s_body[2 * ai + 1], b0 = s_body[2 * bi], b1 = s_body[2 * bi + 1];
           const uint32_t ga = f2u(a1.z), gb = f2u(b1.z);
           // the constant half of ConstrainedSet::get (inverse mass, world inverse inertia): from LDS for own bodies (CL), else plain
@@ -581,10 +592,10 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
             s_body[2 * bi] = make_float4(Bd.v.x, Bd.v.y, Bd.v.z, Bd.w.x);
             *reinterpret_cast<float2*>(&s_body[2 * bi + 1]) = make_float2(Bd.w.y, Bd.w.z);
           }
-          cons[c].nimp = rec.nimp;
+          if (NL) s_nimp[slot] = rec.nimp; else cons[c].nimp = rec.nimp;
           // re-arm: one arrival per dynamic body and iteration from now on (no arrival of the next iteration can come before
           // this node's own releases), and one more iteration done
-          __hip_atomic_fetch_add(&s_state[slot], 0x100u + (has_b ? 2u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&s_state[slot], (1u << kF6StIterShift) + (has_b ? 2u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           if (round + 1u == iters) {  // the end of a foreign body's chain: its home block does not write it back
             if (has_b && (sw.y & kF6Wrap) && bi >= F.nb) store_vel(srec, gb, Bd);  // (a is always the block's own)
           }
@@ -626,6 +637,8 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
     }
   }
   __syncthreads();
+  // the accumulated normal impulses go back to the records (ContactState lives on: mgf_world_read_constraints, a later solve)
+  if (NL) for (uint32_t idx = t; idx < N; idx += kF6Threads) cons[s_c[idx]].nimp = s_nimp[idx];
   // own bodies go back to the RigidBodyVec (a body whose chain ends in another block was written there)
   for (uint32_t i = t; i < n_own; i += kF6Threads) {
     const uint32_t x = F.sidx[p_lo + i];
