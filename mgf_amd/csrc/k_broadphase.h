@@ -73,7 +73,7 @@ struct StepCounts {
   uint32_t fail;                               // kFail* bits
   uint32_t need_Mt, need_Mp, need_C, need_Ct;  // actual sizes (valid up to the first failing stage)
   uint32_t bins[6];                            // candidates per shape-pair type (scenes mixing spheres and capsules)
-  uint32_t ct_sum;                             // terrain constraints, accumulated by k_count_contacts (zeroed by k_caps_candidates)
+  uint32_t ct_sum;                             // terrain constraints, accumulated by k_count_contacts (zeroed by the candidate scan's epilogue, caps_candidates)
 };
 constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u, kFailGridWide = 8u, kFailTerrainRow = 16u, kFailTerrainWide = 32u,
                    kFailRevRow = 64u,  // a body's row of `b` occurrences overflowed (k_setup_pairs / k_chain_rows)

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
     if (t == 0) s_ctl[3] = (uint32_t)__popcll(m);
   }
   __syncthreads();
-  // the block's slot table (built once per tick by k_flow6_table)
+  // the block's slot table (built once per tick by k_flow6_blocks and k_flow6_links)
   const F6Row* rows = F.table + (size_t)g * F.rows;
   for (uint32_t idx = t; idx < N; idx += kF6Threads) {
     const uint4* src = reinterpret_cast<const uint4*>(&rows[idx]);

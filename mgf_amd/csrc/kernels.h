@@ -7,7 +7,11 @@
 //   k_scene_bounds / k_morton_count / k_scatter_leaves
 //                      bodies counting-sorted into Morton cells (cell = 2L-bit prefix of the 30-bit code of the fat-box
 //                      centre); the same kernels build the static grid over a terrain mesh's face boxes
-//   k_pair_grid        BVH::query (bvh.rs:283-310) of the world tree for every body at once by cell enumeration;
+//   k_scan<W>          the tick's prefix sums (cells, candidate rows, constraints per body): single pass, ticketed tiles, wave-wide
+//                      decoupled look-back; its last thread checks the list capacities (caps_candidates / caps_constraints)
+//   k_pair_brick       BVH::query (bvh.rs:283-310) of the world tree for every body at once: a brick of 4x4x4 Morton cells per
+//                      block, the 8x8x8 cells around it staged in LDS, 8 lanes per query; queries that do not fit, and
+//   k_pair_grid        the same by cell enumeration from global memory (the fallback, and what tiles with thin cells run);
 //                      k_lbvh_low / k_lbvh_top + k_pair_rows (implicit 4-ary tree over the cells, cooperative walk)
 //                      when one body spans too many cells; the hit SET is the reference's because acceptance is its own
 //                      predicate on the leaf boxes
@@ -23,6 +27,12 @@
 //                      k_setup_pairs<true> evaluates each one itself, so k_narrow_pairs is not launched
 //   k_chain_rows       order-preserving dependency links of the tick's constraint list (compact arrays, ConsLinks);
 //   k_adj_fill / k_chain  the same for a caller-supplied list in any order (mgf_world_set_constraints)
+//   k_flow6_blocks / k_flow6_links / k_flow6_chan
+//                      block tables of the default solver: slots, foreign bodies, rows; the links along every body's chain
+//                      written straight into the rows with their message channels; channel layout
+//   k_solve_flow6      ContactConstraint::solve (solver.rs:203-252) for a whole Solver::solve call: one workgroup per spatial
+//                      block, every body it touches, the arrival counters, the ready queue and the accumulated impulses in LDS,
+//                      edges across block faces as 48-byte messages polled by one wave (solver mode 6, the default)
 //   k_solve_flow5      ContactConstraint::solve (solver.rs:203-252) for a whole Solver::solve call: block-local persistent
 //                      dataflow launch (a spatial block's velocities, arrival counters and ready queues in LDS)
 //   k_solve_flow       the same graph with every hand-off through L2 (stand-by of k_solve_flow5, solver mode 1)
