@@ -353,6 +353,33 @@ __device__ __forceinline__ BodyPack load_pack(const Bodies& B, uint32_t i, bool 
   return P;
 }
 
+// The terrain side of the constraint setup (one thread per terrain candidate): runs as the first blocks of k_setup_pairs' launch.
+struct TerrainSetup {
+  TerrainDev M;
+  const uint32_t *t_owner, *t_nc, *t_pre;
+  const NContact* t_in;
+  uint32_t in_stride;
+  uint32_t blocks;  // blocks of the launch that work on terrain candidates (0: the world has no terrain)
+};
+__device__ __forceinline__ void setup_terrain_one(const Bodies& B, const TerrainSetup& T, const StepCounts* sc, uint32_t p, const uint32_t* base, float dt,
+                                                  float baumgarte, float slop, CRec* cons, uint2* ab) {
+  if (p >= sc->Mt) return;
+  uint32_t nc = T.t_nc[p];
+  if (nc == 0) return;
+  uint32_t i = T.t_owner[p];
+  BodyDyn A = load_dyn(B.srec, i), S = static_dyn();
+  const BodyPack Pa = load_pack(B, i, false);
+  float4 ea = Pa.ei;
+  V3 center = mk3(T.M.x[0], T.M.x[1], T.M.x[2]);  // Static{ center: terrain.center(), friction: 0.0 } world.rs:247
+  for (uint32_t k = 0; k < nc; ++k) {
+    NContact in = T.t_in[(size_t)T.in_stride * p + k];
+    CRec r = make_constraint(i, kNone, A, xyz(ea), ea.w, Pa.dl.w, S, center, 0.0f, 0.0f, xyz(in.n), xyz(in.la), xyz(in.lb), dt,
+                             baumgarte, slop);
+    store_crec(&cons[base[i] + T.t_pre[p] + k], r);
+    ab[base[i] + T.t_pre[p] + k] = make_uint2(i, kNone);
+  }
+}
+
 // SPHERES = true: a world of spheres whose broadphase ran the sphere-sphere test itself (k_pair_grid<true>): the list
 // holds contacts only, one per pair, and the contact is computed here from the colliders (no k_narrow_pairs pass, no
 // NContact round trip through memory).  `flag` is raised if the two evaluations of the same test ever disagreed.
@@ -361,8 +388,12 @@ __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCoun
                                                         const uint32_t* p_nc, const uint32_t* p_pre, const NContact* p_in,
                                                         const uint32_t* base, float dt, float baumgarte, float slop,
                                                         CRec* cons, uint2* ab, uint32_t* degb, uint32_t* rev, uint32_t rev_cap,
-                                                        uint32_t* rev_flag, uint32_t in_stride, uint32_t* flag) {
-  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+                                                        uint32_t* rev_flag, uint32_t in_stride, uint32_t* flag, TerrainSetup TS) {
+  if (blockIdx.x < TS.blocks) {  // the terrain candidates' constraints (k_setup_terrain's work, without a launch of its own)
+    setup_terrain_one(B, TS, sc, blockIdx.x * kBlock + threadIdx.x, base, dt, baumgarte, slop, cons, ab);
+    return;
+  }
+  uint32_t p = (blockIdx.x - TS.blocks) * kBlock + threadIdx.x;
   if (SPHERES) {
     // One contact per listed pair.  The 128-byte records leave through LDS: a lane storing its own record issues eight
     // 16-byte stores 128 bytes apart from its neighbours' (64 partial lines per instruction); handed round, consecutive lanes
@@ -428,28 +459,6 @@ __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCoun
     uint32_t pos = atomicAdd(&degb[j], 1u);
     if (pos < rev_cap) rev[(size_t)j * rev_cap + pos] = c;
     else *rev_flag = 1u;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_setup_terrain(Bodies B, TerrainDev M, const StepCounts* sc, const uint32_t* t_owner,
-                                                          const uint32_t* t_nc, const uint32_t* t_pre, const NContact* t_in,
-                                                          const uint32_t* base, float dt, float baumgarte, float slop, CRec* cons,
-                                                          uint2* ab, uint32_t in_stride) {
-  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-  if (p >= sc->Mt) return;
-  uint32_t nc = t_nc[p];
-  if (nc == 0) return;
-  uint32_t i = t_owner[p];
-  BodyDyn A = load_dyn(B.srec, i), S = static_dyn();
-  const BodyPack Pa = load_pack(B, i, false);
-  float4 ea = Pa.ei;
-  V3 center = mk3(M.x[0], M.x[1], M.x[2]);  // Static{ center: terrain.center(), friction: 0.0 } world.rs:247
-  for (uint32_t k = 0; k < nc; ++k) {
-    NContact in = t_in[(size_t)in_stride * p + k];
-    CRec r = make_constraint(i, kNone, A, xyz(ea), ea.w, Pa.dl.w, S, center, 0.0f, 0.0f, xyz(in.n), xyz(in.la), xyz(in.lb), dt,
-                             baumgarte, slop);
-    store_crec(&cons[base[i] + t_pre[p] + k], r);
-    ab[base[i] + t_pre[p] + k] = make_uint2(i, kNone);
   }
 }
 

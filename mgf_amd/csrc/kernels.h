@@ -21,7 +21,7 @@
 //   k_rows_to_csr      rows -> CSR, terrain faces in DFS order (partner contacts are ordered by k_count_contacts)
 //   k_narrow_pairs<A,B> / k_narrow_terrain<A>
 //                      one kernel per shape-pair type over the candidate lists
-//   k_count_contacts / k_setup_pairs<SPHERES> / k_setup_terrain
+//   k_count_contacts / k_setup_pairs<SPHERES> (its first blocks: the terrain candidates, setup_terrain_one)
 //                      Manifold::from + ContactConstraint::new (manifold.rs:120-148, solver.rs:101-191); in a world of
 //                      spheres only the broadphase lists contacts (k_pair_grid<true> runs the sphere test) and
 //                      k_setup_pairs<true> evaluates each one itself, so k_narrow_pairs is not launched
