@@ -102,10 +102,12 @@ __global__ __launch_bounds__(kBlock) void k_import_ghosts(Bodies B, uint32_t n_o
   if (sb_part) bounds_block_accumulate(blo, bhi, brm, sb_part);  // the scene bounds gathered by this tick's k_integrate take the ghosts in
 }
 // velocity record: 8 floats (v3, w3, 0, 0)
-__global__ __launch_bounds__(kBlock) void k_export_vel(const float4* srec, const uint32_t* ids, uint32_t m, float4* out) {
+// (ids_b / m_b: a second id list whose records follow the first's - both slab faces of a tile in one launch)
+__global__ __launch_bounds__(kBlock) void k_export_vel(const float4* srec, const uint32_t* ids, uint32_t m, float4* out, const uint32_t* ids_b = nullptr,
+                                                       uint32_t m_b = 0) {
   uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= m) return;
-  uint32_t i = ids[t];
+  if (t >= m + m_b) return;
+  uint32_t i = t < m ? ids[t] : ids_b[t - m];
   float4 s0 = srec[4 * i], s1 = srec[4 * i + 1];
   out[2 * t] = s0;
   out[2 * t + 1] = make_float4(s1.x, s1.y, 0.0f, 0.0f);
