@@ -25,13 +25,26 @@ __device__ __forceinline__ uint32_t morton_quant(float v, float lo, float hi) {
 // `min_frac` of the longest one.  Every axis gets the same number of cells, so a scene much shorter along one axis - an x-slab
 // tile of a wide pile - would otherwise get cells as thin along it, and a query's region many cells across (measured: 96
 // instead of 50 us for 131 072 bodies in a 19 x 130 x 66 tile).  0 = the bounds as they are (a terrain mesh: flat on purpose).
+constexpr int kMortonBits = 30;
 constexpr float kBodyGridMinFrac = 0.5f;
-__device__ __forceinline__ void grid_box(const SceneBounds* sb, float min_frac, float* lo, float* hi) {
+// ... and (bodies only, min_frac > 0) to at least one largest-fat-half-extent per cell, if that takes no more than half as
+// much again: a pile that has settled to two thirds of its height would otherwise get cells two thirds as high, every query's region
+// would reach three cells up and down instead of two, and the staged box of k_pair_brick (two cells around its brick) would not hold
+// it (measured: the settled pile fell back to k_pair_grid at 150 us).  `P` = prefix bits of the cells (2 x levels).
+__device__ __forceinline__ void grid_box(const SceneBounds* sb, float min_frac, uint32_t P, float* lo, float* hi) {
   float ext = 0.0f;
 #pragma unroll
   for (int k = 0; k < 3; ++k) { lo[k] = ord_f(sb->lo[k]); hi[k] = ord_f(sb->hi[k]); ext = fmaxf(ext, hi[k] - lo[k]); }
+  if (!(min_frac > 0.0f)) return;
+  const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};
 #pragma unroll
-  for (int k = 0; k < 3; ++k) if (hi[k] - lo[k] < min_frac * ext) hi[k] = lo[k] + min_frac * ext;
+  for (int k = 0; k < 3; ++k) {
+    float e = hi[k] - lo[k];
+    if (e < min_frac * ext) e = min_frac * ext;
+    const float want = ord_f(sb->rmax[k]) * (float)(1u << nb[k]) * 1.02f;
+    if (e < want && want <= 1.5f * e) e = want;
+    hi[k] = lo[k] + e;
+  }
 }
 // Counting sort of the bodies into Morton cells (a cell = one 2L-bit prefix of the 30-bit code): cell of every
 // body + its arrival rank inside the cell.  After a scan of the per-cell counts k_scatter_leaves places body i
@@ -43,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void k_morton_count(const float4* fb_c, uin
   if (i >= n) return;
   V3 c = xyz(fb_c[i]);
   float glo[3], ghi[3];
-  grid_box(sb, min_frac, glo, ghi);
+  grid_box(sb, min_frac, (uint32_t)(kMortonBits - shift), glo, ghi);
   uint32_t code = 0;
   for (int k = 0; k < 3; ++k) code |= expand10(morton_quant(at(c, k), glo[k], ghi[k])) << (2 - k);
   uint32_t cell = code >> shift;
@@ -258,7 +271,6 @@ struct Lbvh {
   unsigned long long* dbg;  // optional: [0] node fetches, [1] leaf records tested, [2] max fetches of one query
 };
 constexpr int kLdsQNodes = 341;  // levels 0..4 (1 + 4 + 16 + 64 + 256 nodes), 43 KB
-constexpr int kMortonBits = 30;
 __host__ __device__ __forceinline__ uint32_t qlevel_offset(uint32_t l) { return ((1u << (2 * l)) - 1u) / 3u; }
 
 __device__ __forceinline__ void box_min_max(V3& lo, V3& hi, V3 l, V3 h) {
@@ -275,7 +287,7 @@ __device__ __forceinline__ float pair_query_pad(const V3& c, const V3& r, float 
 __device__ __forceinline__ void pair_query_region(const V3& qc, const V3& qr, float pad, const SceneBounds* sb, const uint32_t* nb, uint32_t* ca, uint32_t* d,
                                                   float min_frac) {
   float glo[3], ghi[3];
-  grid_box(sb, min_frac, glo, ghi);
+  grid_box(sb, min_frac, nb[0] + nb[1] + nb[2], glo, ghi);
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     float lo = glo[k], hi = ghi[k], rm = ord_f(sb->rmax[k]);
@@ -889,7 +901,8 @@ __device__ __forceinline__ uint32_t compact10(uint32_t v) {  // inverse of expan
 }
 constexpr int kBrickLanes = 8;                                  // lanes per query
 constexpr int kBrickQueries = kCoopBlock / kBrickLanes;         // queries per pass of a block
-constexpr uint32_t kBrickCap = 672;                             // leaf records staged per brick (64 B each; 32 B when the sphere test is not fused)
+constexpr uint32_t kBrickCap = 672;                             // leaf records staged per brick (64 B each; 32 B when the sphere test is not fused):
+                                                                // three blocks per CU (the kernel takes the number as an argument)
 struct BrickSrcLds {   // the staged box: records in x-major cell order, start[] = first record of every cell (+ end)
   const float4 *rc, *rr, *cc, *cd;
   const uint16_t* start;
@@ -986,8 +999,8 @@ __device__ __forceinline__ void brick_query(const Src& S, const Box& q, const Co
 template <bool SPHERES>
 __global__ __launch_bounds__(kCoopBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_pair_brick(uint32_t n, uint32_t n_owned, Lbvh T,
                                                            uint32_t* rows_p, uint32_t* p_cnt, uint32_t* overflow, uint32_t* too_wide,
-                                                           uint32_t* pair_stat, uint32_t* slow_queries) {
-  extern __shared__ float4 s_dyn[];                      // records: rc | rr | (cc | cd), kBrickCap each
+                                                           uint32_t* pair_stat, uint32_t* slow_queries, uint32_t cap) {
+  extern __shared__ float4 s_dyn[];                      // records: rc | rr | (cc | cd), cap each
   __shared__ uint16_t s_start[516];
   __shared__ uint32_t s_wsum[kCoopBlock / 64];
   __shared__ uint16_t s_acc[SPHERES ? kBrickQueries : 1][SPHERES ? kRowCap : 1];
@@ -1000,7 +1013,7 @@ __global__ __launch_bounds__(kCoopBlock) __attribute__((amdgpu_waves_per_eu(6, 8
   const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};  // prefix bits per axis (x is the most significant)
   const int shift = kMortonBits - (int)P;
   BrickSrcLds L;
-  L.rc = s_dyn; L.rr = s_dyn + kBrickCap; L.cc = s_dyn + 2 * kBrickCap; L.cd = s_dyn + 3 * kBrickCap; L.start = s_start;
+  L.rc = s_dyn; L.rr = s_dyn + cap; L.cc = s_dyn + 2 * cap; L.cd = s_dyn + 3 * cap; L.start = s_start;
   {
     const uint32_t code = (brick * 64u) << shift;
     L.hb[0] = (int)(compact10(code >> 2) >> (10u - nb[0])) - 2;
@@ -1034,7 +1047,7 @@ __global__ __launch_bounds__(kCoopBlock) __attribute__((amdgpu_waves_per_eu(6, 8
 #pragma unroll
   for (int w = 0; w < kCoopBlock / 64; ++w) { const uint32_t u = s_wsum[w]; if (w < (int)(t >> 6)) base += u; total += u; }
   const uint32_t start = base + inc - cnt;
-  const bool staged = total <= kBrickCap;
+  const bool staged = total <= cap;
   s_start[t] = (uint16_t)min(start, 0xFFFFu);
   if (t == 0) { s_start[512] = (uint16_t)min(total, 0xFFFFu); s_start[513] = s_start[512]; }
   // round trip 2: the cell's records into the box copy, and the first pass's queries (cell-ordered copies: no look-up through
@@ -1046,7 +1059,7 @@ __global__ __launch_bounds__(kCoopBlock) __attribute__((amdgpu_waves_per_eu(6, 8
   uint2 qreg = make_uint2(0, 0);
   if (kq < q1) { qc = T.ltb[2 * kq]; qr = T.ltb[2 * kq + 1]; if (SPHERES) { qa = T.lcol[2 * kq]; qv = T.lcol[2 * kq + 1]; } qi = T.sidx[kq]; qreg = make_uint2(f2u(qc.w), f2u(qr.w)); }
   if (staged) {
-    float4* rc = s_dyn; float4* rr = s_dyn + kBrickCap; float4* cc = s_dyn + 2 * kBrickCap; float4* cd = s_dyn + 3 * kBrickCap;
+    float4* rc = s_dyn; float4* rr = s_dyn + cap; float4* cc = s_dyn + 2 * cap; float4* cd = s_dyn + 3 * cap;
     for (uint32_t r = 0; r < cnt; ++r) {
       LeafRec lr = T.leaves[g0 + r];
       rc[start + r] = lr.c; rr[start + r] = lr.r;
@@ -1103,7 +1116,7 @@ __global__ __launch_bounds__(kCoopBlock) __attribute__((amdgpu_waves_per_eu(6, 8
     if (t == 0 && s_slow) atomicAdd(slow_queries, s_slow);
   }
 }
-constexpr size_t brick_lds_bytes(bool spheres) { return (size_t)kBrickCap * 16u * (spheres ? 4u : 2u); }
+constexpr size_t brick_lds_bytes(bool spheres, uint32_t cap) { return (size_t)cap * 16u * (spheres ? 4u : 2u); }
 
 // Terrain faces per body without walking the reference tree.  A static mesh gets the same Morton-cell grid as the
 // bodies (cells over the face boxes, built once per set_terrain); a query enumerates the cells its box can reach,
