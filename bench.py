@@ -323,7 +323,20 @@ def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, w
         "solver_kernel_ms_per_tile_tick_rank0": kms / (args.steps * per_rank),
         "tile_tick_ms_rank0": elapsed * 1e3 / (args.steps * per_rank),
         "roofline": _roofline(units, launches, kms, mode, f"{refresh_every} iteration(s) of one tile between ghost refreshes", ("tiles", args.warmup, args.steps)),
+        "same_workload_on_one_gpu": _config4_one_gpu() if scene_kind == "config4" and world_size > 1 else None,
     }
+
+
+def _config4_one_gpu():
+    """The N = 1 bench line is BASELINE config 2 (the contract's single-GPU workload); the N > 1 lines are strong-scaling slices of
+    config 4.  For a scaling figure against the SAME workload: config 4's 8 tiles on ONE GPU, as measured and committed."""
+    p = os.path.join(ROOT, "profiles", "r02e_config4_8tiles_1gpu_bench.json")
+    try:
+        d = json.load(open(p))
+        return {"value": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
+                "source": "profiles/r02e_config4_8tiles_1gpu_bench.json (python bench.py --gpus 1 --scene config4; a committed measurement, not taken in this run)"}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def _keys(st):
