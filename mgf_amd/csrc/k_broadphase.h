@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter_leaves(Lbvh T, const float4*
     uint32_t ca[3], d[3];
     pair_query_region(xyz(c), xyz(r), pair_query_pad(xyz(c), xyz(r), pad_abs), sb, nb, ca, d, min_frac);
     T.ltb[2 * p] = mk4(xyz(c), u2f(ca[0] | (ca[1] << 10) | (ca[2] << 20)));  // (ca < 1024, d <= 1024 - ca)
-    T.ltb[2 * p + 1] = mk4(xyz(r), u2f(d[0] | (d[1] << 10) | (d[2] << 20)));
+    T.ltb[2 * p + 1] = mk4(xyz(r), u2f(min(d[0], 1023u) | (min(d[1], 1023u) << 10) | (min(d[2], 1023u) << 20)));  // (1023 cells across is "too wide" like 1024)
   }
   T.sidx[p] = body;
   brank[body] = p;  // position in cell order (the block-local solver groups bodies by it)
@@ -849,14 +849,24 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, 
   uint32_t i = live ? T.sidx[kq] : 0u;
   uint32_t np = 0, n_accepted = 0;
   if (live && i != 0 && T.n >= 2) {  // world.rs:256
-    Box q; q.c = xyz(B.tb_c[i]); q.r = xyz(B.tb_r[i]);
+    Box q;
     Comp A; V3 vA = mk3(0, 0, 0);
-    if (SPHERES) { A = load_comp(B, i); A.kind = KIND_SPHERE; vA = xyz(B.delta[i]); }
-    float pad = pad_abs + 1e-5f * (fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z);
+    uint32_t ca[3], d[3];
     const uint32_t P = 2u * T.levels;
     const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};  // prefix bits per axis (x is the most significant)
-    uint32_t ca[3], d[3];
-    pair_query_region(q.c, q.r, pad, sb, nb, ca, d, min_frac);
+    if (T.ltb) {  // the query in cell order, its cells worked out by k_scatter_leaves: no look-up through the body index, no divisions
+      const float4 qc = T.ltb[2 * kq], qr = T.ltb[2 * kq + 1];
+      q.c = xyz(qc); q.r = xyz(qr);
+      const uint32_t ra = f2u(qc.w), rd = f2u(qr.w);
+      ca[0] = ra & 1023u; ca[1] = (ra >> 10) & 1023u; ca[2] = ra >> 20;
+      d[0] = rd & 1023u; d[1] = (rd >> 10) & 1023u; d[2] = rd >> 20;
+      if (SPHERES) { const float4 c0 = T.lcol[2 * kq]; A.p = xyz(c0); A.r = c0.w; A.d = mk3(0, 0, 0); A.kind = KIND_SPHERE; vA = xyz(T.lcol[2 * kq + 1]); }
+    } else {
+      q.c = xyz(B.tb_c[i]); q.r = xyz(B.tb_r[i]);
+      if (SPHERES) { A = load_comp(B, i); A.kind = KIND_SPHERE; vA = xyz(B.delta[i]); }
+      float pad = pad_abs + 1e-5f * (fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z);
+      pair_query_region(q.c, q.r, pad, sb, nb, ca, d, min_frac);
+    }
     if (d[0] * d[1] * d[2] > kGridMaxCells) {
       if (sub == 0) *too_wide = 1u;
     } else {
