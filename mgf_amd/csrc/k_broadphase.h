@@ -753,13 +753,15 @@ __device__ __forceinline__ void pair_query_cells(const Src& S, const Box& q, con
                                                  const uint32_t* d, const uint32_t* nb, int shift, int sub, int gbase, uint32_t* row, AccT* acc,
                                                  uint32_t* overflow, uint32_t& np, uint32_t& n_accepted) {
   const uint32_t ncell = d[0] * d[1] * d[2];
+  // idx -> (cx, cy, cz) by two multiplications: ncell <= kGridMaxCells = 512, so idx * d < 2^18 and the 20-bit reciprocals are exact
+  const uint32_t m2 = ((1u << 20) + d[2] - 1u) / d[2], m1 = ((1u << 20) + d[1] - 1u) / d[1];
   np = 0;
   for (uint32_t cb = 0; cb < ncell; cb += kCoopLanes) {
     uint32_t idx = cb + (uint32_t)sub;
     uint32_t p0 = 0, p1 = 0;
     if (idx < ncell) {
-      uint32_t cz = idx % d[2], t = idx / d[2];
-      uint32_t cy = t % d[1], cx = t / d[1];
+      const uint32_t t = (idx * m2) >> 20, cz = idx - t * d[2];
+      const uint32_t cx = (t * m1) >> 20, cy = t - cx * d[1];
       const uint32_t cc3[3] = {ca[0] + cx, ca[1] + cy, ca[2] + cz};
       uint32_t code = (expand10(cc3[0] << (10u - nb[0])) << 2) | (expand10(cc3[1] << (10u - nb[1])) << 1) | expand10(cc3[2] << (10u - nb[2]));
       S.range(code >> shift, cc3, p0, p1);
