@@ -112,6 +112,8 @@ __global__ __launch_bounds__(kF6PrepThreads) void k_flow6_blocks(Flow6 F, ConsLi
   for (uint32_t e = t; e < kF6Hash; e += kBlock) { s_key[e] = 0u; s_val[e] = 0u; }
   if (t == 0) { s_cnt = 0u; s_run = 0u; }
   __syncthreads();
+  const bool single = p_hi - p_lo <= kBlock;  // one body per thread: what the first pass looked up serves the second
+  uint32_t keep_b[4] = {kNone, kNone, kNone, kNone}, keep_pb[4] = {0u, 0u, 0u, 0u};
   // (1) slots: a running prefix over the block's bodies in cell order, kBlock bodies per round (wave scan + the waves before)
   // (2) on the way, the foreign bodies among each body's partners go into the hash set
   for (uint32_t p0 = p_lo; p0 < p_hi; p0 += kBlock) {
@@ -126,13 +128,24 @@ __global__ __launch_bounds__(kF6PrepThreads) void k_flow6_blocks(Flow6 F, ConsLi
     uint32_t before = s_run, total = 0;
     for (uint32_t k = 0; k < kBlock / 64; ++k) { const uint32_t u = s_wave[k]; if (k < wv) before += u; total += u; }
     if (p < p_hi) F.binfo[x] = make_uint4(p, before + inc - cnt, b0, cnt);
-    for (uint32_t k = 0; k < cnt; ++k) {
-      const uint32_t b = K.ab[b0 + k].y;
-      if (b == kNone || F.brank[b] / F.nb == g) continue;
-      uint32_t i = (b * 2654435761u) >> 20;
-      for (uint32_t probe = 0; probe < kF6Hash; ++probe, i = (i + 1u) & (kF6Hash - 1u)) {
-        const uint32_t cur = atomicCAS(&s_key[i], 0u, b + 1u);
-        if (cur == 0u || cur == b + 1u) break;
+    for (uint32_t k0 = 0; k0 < cnt; k0 += 4u) {  // four partners' look-ups in flight; the first four are kept for the rows below
+      uint32_t b[4], pb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = k0 + (uint32_t)j < cnt ? K.ab[b0 + k0 + (uint32_t)j].y : kNone;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pb[j] = b[j] != kNone ? F.brank[b[j]] : 0u;
+      if (k0 == 0u) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { keep_b[j] = b[j]; keep_pb[j] = pb[j]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (b[j] == kNone || pb[j] / F.nb == g) continue;
+        uint32_t i = (b[j] * 2654435761u) >> 20;
+        for (uint32_t probe = 0; probe < kF6Hash; ++probe, i = (i + 1u) & (kF6Hash - 1u)) {
+          const uint32_t cur = atomicCAS(&s_key[i], 0u, b[j] + 1u);
+          if (cur == 0u || cur == b[j] + 1u) break;
+        }
       }
     }
     __syncthreads();
@@ -167,10 +180,15 @@ __global__ __launch_bounds__(kF6PrepThreads) void k_flow6_blocks(Flow6 F, ConsLi
     if (aref >= kF6NoBody) atomicOr(F.fail, 16u);
     for (uint32_t k0 = 0; k0 < ix.w; k0 += 4u) {  // four constraints' look-ups in flight
       uint32_t b[4], pb[4];
+      if (single && k0 == 0u) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = k0 + (uint32_t)j < ix.w ? K.ab[ix.z + k0 + (uint32_t)j].y : kNone;
+        for (int j = 0; j < 4; ++j) { b[j] = keep_b[j]; pb[j] = keep_pb[j]; }
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) pb[j] = b[j] != kNone ? F.brank[b[j]] : 0u;
+        for (int j = 0; j < 4; ++j) b[j] = k0 + (uint32_t)j < ix.w ? K.ab[ix.z + k0 + (uint32_t)j].y : kNone;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pb[j] = b[j] != kNone ? F.brank[b[j]] : 0u;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t k = k0 + (uint32_t)j;
