@@ -598,12 +598,15 @@ __device__ inline int comp_tri_local_at(const Comp& A, V3 vA, const Triangle& tr
   int n;
   if (A.kind == KIND_SPHERE) n = tri_msphere(tri, mks(A.p, A.r), vA, &raw[0]) ? 1 : 0;
   else n = tri_mcapsule(tri, mkcap(A.p, A.d, A.r), vA, raw);
-  for (int k = 0; k < n; ++k) {
-    Contact m = raw[k];  // Mesh::contacts callback value: a on the mesh, b on the body, n = face normal
-    V3 a_c = centre + vA * m.t;
-    out[k].la = m.b + -a_c;
-    out[k].lb = m.a + -mesh_center;
-    out[k].g = neg(m);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {  // (constant indices: the contacts stay in registers, not in scratch)
+    if (k < n) {
+      Contact m = raw[k];  // Mesh::contacts callback value: a on the mesh, b on the body, n = face normal
+      V3 a_c = centre + vA * m.t;
+      out[k].la = m.b + -a_c;
+      out[k].lb = m.a + -mesh_center;
+      out[k].g = neg(m);
+    }
   }
   return n;
 }

@@ -51,9 +51,12 @@ __global__ __launch_bounds__(kBlock) void k_narrow_terrain(Bodies B, TerrainDev 
   LocalContact lc[2];
   int nc = comp_tri_local(A, vA, tri, mx, lc);
   t_nc[p] = (uint32_t)nc;
-  for (int k = 0; k < nc; ++k) {
-    NContact o; o.la = mk4(lc[k].la, lc[k].g.t); o.lb = mk4(lc[k].lb, 0.0f); o.n = mk4(lc[k].g.n, 0.0f);  // Manifold::from(lc) manifold.rs:120-128
-    t_out[2 * p + k] = o;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {  // (constant indices: the two contacts stay in registers)
+    if (k < nc) {
+      NContact o; o.la = mk4(lc[k].la, lc[k].g.t); o.lb = mk4(lc[k].lb, 0.0f); o.n = mk4(lc[k].g.n, 0.0f);  // Manifold::from(lc) manifold.rs:120-128
+      t_out[2 * p + k] = o;
+    }
   }
 }
 
