@@ -1240,22 +1240,39 @@ __global__ __launch_bounds__(kBlock) void k_rows_to_csr(const StepCounts* sc, ui
                                                         const uint32_t* t_off, const uint32_t* p_off, uint32_t* t_cand, uint32_t* t_owner,
                                                         uint32_t* p_cand, uint32_t* p_owner) {
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n || sc->fail) return;
-  uint32_t tb = t_off[i], nt = t_off[i + 1] - tb, pb = p_off[i], np = p_off[i + 1] - pb;
-  if (nt > cap_row_t || np > (uint32_t)kRowCap) return;  // overflowed body: the host re-runs with wider rows or the two-pass path
-  const uint32_t* rt = rows_t + (size_t)i * cap_row_t;
-  const uint4* rp = reinterpret_cast<const uint4*>(rows_p + (size_t)i * kRowCap);  // rows are 16-byte aligned (kRowCap % 4 == 0)
-  if (face_of_rank) {  // the row holds DFS ranks in discovery order: sort, then name the faces
-    for (uint32_t a = 0; a < nt; ++a) {
-      uint32_t x = rt[a];
-      uint32_t b = a;
-      while (b > 0 && t_cand[tb + b - 1] > x) { t_cand[tb + b] = t_cand[tb + b - 1]; --b; }
-      t_cand[tb + b] = x;
+  if (sc->fail) return;
+  const bool live = i < n;
+  uint32_t tb = 0, nt = 0, pb = 0, np = 0;
+  if (live) { tb = t_off[i]; nt = t_off[i + 1] - tb; pb = p_off[i]; np = p_off[i + 1] - pb; }
+  const bool ok = live && nt <= cap_row_t && np <= (uint32_t)kRowCap;  // an overflowed body: the host re-runs with wider rows or the two-pass path
+  if (face_of_rank) {
+    // Terrain rows hold DFS ranks in discovery order: every entry goes straight to its place - the number of smaller ranks in the
+    // row (ranks are distinct) - and is named.  The wave takes its 64 bodies one after the other with a lane per ENTRY: the row is
+    // read, and the list written, by consecutive lanes (a thread walking its own row touched a 64-byte sector per entry and array:
+    // 105 us on 131 072 capsules over a heightfield).
+    const int lane = threadIdx.x & 63;
+    for (int sft = 0; sft < 64; ++sft) {
+      const uint32_t bi = __shfl(i, sft), bnt = __shfl(ok ? nt : 0u, sft), btb = __shfl(tb, sft);
+      if (bnt == 0u) continue;
+      const uint32_t* brow = rows_t + (size_t)bi * cap_row_t;
+      for (uint32_t e0 = 0; e0 < bnt; e0 += 64u) {
+        const uint32_t e = e0 + (uint32_t)lane;
+        const uint32_t x = e < bnt ? brow[e] : 0xFFFFFFFFu;
+        uint32_t before = 0;
+        for (uint32_t c0 = 0; c0 < bnt; c0 += 64u) {  // (rows longer than a wave: the other chunks are read again)
+          const uint32_t y = c0 == e0 ? x : (c0 + (uint32_t)lane < bnt ? brow[c0 + (uint32_t)lane] : 0xFFFFFFFFu);
+          const uint32_t m = min(bnt - c0, 64u);
+          for (uint32_t k = 0; k < m; ++k) before += __shfl(y, (int)k) < x ? 1u : 0u;
+        }
+        if (e < bnt) { t_cand[btb + before] = face_of_rank[x]; t_owner[btb + before] = bi; }
+      }
     }
-    for (uint32_t a = 0; a < nt; ++a) { t_cand[tb + a] = face_of_rank[t_cand[tb + a]]; t_owner[tb + a] = i; }
-  } else {
+  } else if (ok) {
+    const uint32_t* rt = rows_t + (size_t)i * cap_row_t;
     for (uint32_t a = 0; a < nt; ++a) { t_cand[tb + a] = rt[a]; t_owner[tb + a] = i; }
   }
+  if (!ok) return;
+  const uint4* rp = reinterpret_cast<const uint4*>(rows_p + (size_t)i * kRowCap);  // rows are 16-byte aligned (kRowCap % 4 == 0)
   // partners stay in discovery order: only the few that turn into contacts need the canonical (ascending) order, and
   // k_count_contacts numbers those by partner id
   for (uint32_t a = 0; a < np; a += 4) {
