@@ -188,3 +188,29 @@ def test_dataflow_solver_full_size_stress(ctx, mode):
             for k in ("v", "omega", "x"):
                 assert np.array_equal(s1[k].view(np.uint32), s2[k].view(np.uint32)), f"step {step}: {k} differs"
     print(f"solve phase: launches {ms_a / 40:.3f} ms/tick, dataflow mode {mode} {ms_b / 40:.3f} ms/tick")
+
+
+def test_dataflow_solver_settled_pile_at_full_size(ctx):
+    """The settled pile (tick 260 on: ~1 M constraints, long chains, the LDS plan of mode 6 at its narrow margins) - the regime
+    the 40-tick stress above never reaches.  Modes 1 (global dataflow) and 6 (block-local with channels, the default) carried
+    there by mgf_world_step_many and then stepped side by side: bit-identical, and mode 6 really ran its own kernel."""
+    import mgf_amd
+    from mgf_amd import scenes
+    scene = scenes.sphere_pile(64, 64, 64)
+    dt, iters = float(scene["dt"]), scene["iters"]
+    a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
+    a.set_option("solver_mode", 1)
+    b.set_option("solver_mode", 6)
+    a.step_many(dt, iters, 260)
+    b.step_many(dt, iters, 260)
+    fb0 = b.counter("flow6_fallbacks")
+    for step in range(24):
+        sa, sb = a.step(dt, iters), b.step(dt, iters)
+        assert sa.n_constraints == sb.n_constraints
+    assert sb.n_constraints > 900000
+    s1, s2 = a.state(), b.state()
+    for k in ("x", "q", "v", "omega", "delta"):
+        assert np.array_equal(s1[k].view(np.uint32), s2[k].view(np.uint32)), f"{k} differs"
+    assert b.counter("flow6_fallbacks") - fb0 <= 2, (fb0, b.counter("flow6_fallbacks"), b.counter("flow6_fail_reason"))
+    print(f"settled: {sb.n_constraints} constraints; mode 6 fallbacks {b.counter('flow6_fallbacks')} (reason {b.counter('flow6_fail_reason')}), "
+          f"nimp in LDS on {b.counter('flow6_nimp_lds')} ticks, max slots {b.counter('flow6_max_slots')}")
