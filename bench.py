@@ -333,10 +333,17 @@ def _config4_one_gpu():
     p = os.path.join(ROOT, "profiles", "r02e_config4_8tiles_1gpu_bench.json")
     try:
         d = json.load(open(p))
-        return {"value": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
-                "source": "profiles/r02e_config4_8tiles_1gpu_bench.json (python bench.py --gpus 1 --scene config4; a committed measurement, not taken in this run)"}
+        out = {"value": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
+               "source": "profiles/r02e_config4_8tiles_1gpu_bench.json (python bench.py --gpus 1 --scene config4; a committed measurement, not taken in this run)"}
     except (OSError, KeyError, ValueError):
         return None
+    try:  # and the same scene as ONE world (exact canonical order, no seams; tools/config4_undivided.py)
+        u = json.load(open(os.path.join(ROOT, "profiles", "r02f_config4_undivided_1gpu.json")))
+        out["undivided_world"] = {"value": u["value"], "ms_per_step": u["ms_per_step"], "steps": u["steps"], "warmup": u["warmup"],
+                                  "source": "profiles/r02f_config4_undivided_1gpu.json (tools/config4_undivided.py)"}
+    except (OSError, KeyError, ValueError):
+        pass
+    return out
 
 
 def _keys(st):
