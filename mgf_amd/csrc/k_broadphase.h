@@ -21,6 +21,9 @@ __device__ __forceinline__ uint32_t morton_quant(float v, float lo, float hi) {
   int qv = (int)(t * 1023.0f);
   return (uint32_t)(qv < 0 ? 0 : (qv > 1023 ? 1023 : qv));
 }
+__device__ __forceinline__ uint32_t face_cell(uint32_t cx, uint32_t cy, uint32_t cz, uint3 bits) {  // row-major cell of the face grid
+  return (((cx << bits.y) | cy) << bits.z) | cz;
+}
 // The box the Morton coordinates are quantised over: the scene bounds with every axis widened (upwards) to at least
 // `min_frac` of the longest one.  Every axis gets the same number of cells, so a scene much shorter along one axis - an x-slab
 // tile of a wide pile - would otherwise get cells as thin along it, and a query's region many cells across (measured: 96
@@ -50,16 +53,24 @@ __device__ __forceinline__ void grid_box(const SceneBounds* sb, float min_frac, 
 // body + its arrival rank inside the cell.  After a scan of the per-cell counts k_scatter_leaves places body i
 // at cell_lo[cell] + rank.  The order INSIDE a cell is arrival order (it varies from run to run); nothing
 // downstream depends on it - candidate rows are sorted by body index before they are used.
+// `axis_bits` (the static mesh's face grid): when not all zero the cells are ROW-MAJOR with that many bits per axis instead of
+// Morton prefixes - a flat mesh gives its thin axis no bits at all (see build_face_grid).
 __global__ __launch_bounds__(kBlock) void k_morton_count(const float4* fb_c, uint32_t n, const SceneBounds* sb, int shift, uint32_t* cell_of,
-                                                         uint32_t* rank, uint32_t* cell_cnt, float min_frac) {
+                                                         uint32_t* rank, uint32_t* cell_cnt, float min_frac, uint3 axis_bits) {
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   V3 c = xyz(fb_c[i]);
   float glo[3], ghi[3];
   grid_box(sb, min_frac, (uint32_t)(kMortonBits - shift), glo, ghi);
-  uint32_t code = 0;
-  for (int k = 0; k < 3; ++k) code |= expand10(morton_quant(at(c, k), glo[k], ghi[k])) << (2 - k);
-  uint32_t cell = code >> shift;
+  uint32_t cell;
+  if (axis_bits.x + axis_bits.y + axis_bits.z) {
+    cell = face_cell(morton_quant(c.x, glo[0], ghi[0]) >> (10u - axis_bits.x), morton_quant(c.y, glo[1], ghi[1]) >> (10u - axis_bits.y),
+                     morton_quant(c.z, glo[2], ghi[2]) >> (10u - axis_bits.z), axis_bits);
+  } else {
+    uint32_t code = 0;
+    for (int k = 0; k < 3; ++k) code |= expand10(morton_quant(at(c, k), glo[k], ghi[k])) << (2 - k);
+    cell = code >> shift;
+  }
   cell_of[i] = cell;
   rank[i] = atomicAdd(&cell_cnt[cell], 1u);
 }
@@ -1140,6 +1151,7 @@ constexpr size_t brick_lds_bytes(bool spheres, uint32_t cap) { return (size_t)ca
 // reference's callback order.  Meshes whose faces span many cells raise `too_wide`; the host then uses the tree walk.
 struct FaceGrid {
   Lbvh T;                      // cells over the face boxes: leaves[].c.w = face id
+  uint3 bits;                  // cells per axis = 2^bits, row-major (k_morton_count's axis_bits)
   const SceneBounds* sb;
   const uint32_t* rank_of_face;
   const uint32_t* leaf_of_face;  // node id of the face's leaf in the reference tree
@@ -1160,32 +1172,34 @@ __global__ __launch_bounds__(kCoopBlock) void k_terrain_grid(Bodies B, uint32_t 
   Box q; q.c = xyz(B.tb_c[i]) + -mk3(M.x[0], M.x[1], M.x[2]); q.r = xyz(B.tb_r[i]);
   float mag = fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z;
   float pad = pad_abs + 1e-5f * mag;
-  const uint32_t P = 2u * G.T.levels;
-  const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};
+  const uint32_t nb[3] = {G.bits.x, G.bits.y, G.bits.z};
   uint32_t ca[3], d[3];
+  bool away = false;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     float lo = ord_f(G.sb->lo[k]), hi = ord_f(G.sb->hi[k]), rm = ord_f(G.sb->rmax[k]);
     float a = at(q.c, k) - at(q.r, k) - rm - pad, b = at(q.c, k) + at(q.r, k) + rm + pad;
     uint32_t c0 = morton_quant(a, lo, hi) >> (10u - nb[k]), c1 = morton_quant(b, lo, hi) >> (10u - nb[k]);
     ca[k] = c0; d[k] = c1 - c0 + 1u;
+    // a query that ends before the first face box or starts behind the last one on any axis meets no face (the quantisation
+    // clamps, so without this test a body far above a flat mesh would still read the cells under it): Mesh::contacts returns
+    // at the root of its tree in that case (bvh.rs:283-297)
+    away = away || b < lo || a > hi;
   }
   const uint32_t ncell = d[0] * d[1] * d[2];
   uint32_t nt = 0;
-  if (ncell > kGridMaxCells) {
+  if (away) {
+  } else if (ncell > kGridMaxCells) {
     if (sub == 0) *too_wide = 1u;
   } else {
     uint32_t* row = rows_t + (size_t)i * cap_row;
-    const int shift = kMortonBits - (int)P;
     for (uint32_t cb = 0; cb < ncell; cb += kCoopLanes) {
       uint32_t idx = cb + (uint32_t)sub;
       uint32_t p0 = 0, p1 = 0;
       if (idx < ncell) {
         uint32_t cz = idx % d[2], t = idx / d[2];
         uint32_t cy = t % d[1], cx = t / d[1];
-        uint32_t code = (expand10((ca[0] + cx) << (10u - nb[0])) << 2) | (expand10((ca[1] + cy) << (10u - nb[1])) << 1) |
-                        expand10((ca[2] + cz) << (10u - nb[2]));
-        uint32_t cell = code >> shift;
+        uint32_t cell = face_cell(ca[0] + cx, ca[1] + cy, ca[2] + cz, G.bits);
         p0 = G.T.cell_lo[cell]; p1 = G.T.cell_lo[cell + 1];
       }
       for (;;) {
@@ -1211,6 +1225,13 @@ __global__ __launch_bounds__(kCoopBlock) void k_terrain_grid(Bodies B, uint32_t 
                 const float4* raw = reinterpret_cast<const float4*>(&M.nodes[node]);
                 Box nbx; nbx.c = xyz(raw[0]); nbx.r = xyz(raw[1]);
                 if (!box_overlaps(q, nbx)) { hit = false; break; }
+                // the same argument one level up: a CLEAR overlap with an ancestor implies an overlap with everything above it,
+                // and ancestors grow fast (a resting body's thin overlap with a face box is a deep one two or three unions up;
+                // without this every such hit climbed all ~17 levels: k_terrain_grid 80 -> see DESIGN.md section 4)
+                float ga = fmin_rs(fmin_rs(q.r.x + nbx.r.x - fabs_rs(q.c.x - nbx.c.x), q.r.y + nbx.r.y - fabs_rs(q.c.y - nbx.c.y)),
+                                   q.r.z + nbx.r.z - fabs_rs(q.c.z - nbx.c.z));
+                float ta = 1e-4f * (mag + fabs_rs(nbx.c.x) + fabs_rs(nbx.c.y) + fabs_rs(nbx.c.z) + nbx.r.x + nbx.r.y + nbx.r.z);
+                if (ga > ta) break;
               }
             }
             rank = G.rank_of_face[face];
