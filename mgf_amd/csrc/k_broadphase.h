@@ -732,6 +732,16 @@ __device__ __forceinline__ Comp load_comp(const Bodies& B, uint32_t i) {
   Comp k; k.p = xyz(c0); k.r = c0.w; k.d = xyz(c1); k.kind = (int)f2u(c1.w);
   return k;
 }
+// ... and the body's motion with it, from the packed copy when the host vouches for it: one 64-byte sector instead of three
+// look-ups in three arrays (the narrowphase kernels are bound by the rate of such look-ups, not by their arithmetic)
+__device__ __forceinline__ Comp load_comp_moving(const Bodies& B, uint32_t i, V3* v) {
+  float4 c0, c1, dl;
+  if (B.bpk) { c0 = B.bpk[4 * (size_t)i]; dl = B.bpk[4 * (size_t)i + 1]; c1 = B.bpk[4 * (size_t)i + 3]; }
+  else { c0 = B.col0[i]; c1 = B.col1[i]; dl = B.delta[i]; }
+  Comp k; k.p = xyz(c0); k.r = c0.w; k.d = xyz(c1); k.kind = (int)f2u(c1.w);
+  *v = xyz(dl);
+  return k;
+}
 
 // Partner bodies per body without a tree walk.  The leaf level of the Morton-cell tree IS a uniform grid: cell
 // (cx, cy, cz) is the 2L-bit Morton prefix of its interleaved coordinates, and cell_lo gives its bodies.

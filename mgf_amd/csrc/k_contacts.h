@@ -19,9 +19,9 @@ __global__ __launch_bounds__(kBlock) void k_narrow_pairs(Bodies B, const uint32_
   if (t >= *m_ptr) return;
   uint32_t p = work ? work[t] : t;
   uint32_t i = p_owner[p], j = p_cand[p];
-  Comp A = load_comp(B, i), Bc = load_comp(B, j);
+  V3 vA, vB;
+  Comp A = load_comp_moving(B, i, &vA), Bc = load_comp_moving(B, j, &vB);
   A.kind = KA; Bc.kind = KB;  // compile-time dispatch: the list holds only this pair type
-  V3 vA = xyz(B.delta[i]), vB = xyz(B.delta[j]);
   LocalContact lc;
   bool hit = comp_pair_local(A, vA, Bc, vB, &lc);
   p_nc[p] = hit ? 1u : 0u;
@@ -42,9 +42,9 @@ __global__ __launch_bounds__(kBlock) void k_narrow_terrain(Bodies B, TerrainDev 
   if (t >= *m_ptr) return;
   uint32_t p = work ? work[t] : t;
   uint32_t i = t_owner[p], f = t_cand[p];
-  Comp A = load_comp(B, i);
+  V3 vA;
+  Comp A = load_comp_moving(B, i, &vA);
   A.kind = KA;
-  V3 vA = xyz(B.delta[i]);
   uint4 fi = M.faces[f];
   V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
   Triangle tri = mkt(xyz(M.verts[fi.x]) + mx, xyz(M.verts[fi.y]) + mx, xyz(M.verts[fi.z]) + mx);  // mesh.rs:122-126
