@@ -564,19 +564,21 @@ __device__ __noinline__ bool capsule_mcapsule(const Capsule& self, const Capsule
 // Moving<Component>.contacts(&Moving<Component>) (compound.rs:180-190 twice, then
 // collision.rs:1387-1401): A's shape static, B sweeping at vB - vA, result shifted by vA*t;
 // the two negations of compound.rs:186-187 cancel.  At most one contact.
+// A cheap conservative reject before the reference's tests: every contact they report is a touching of the two shapes at some t
+// in [0, 1] of B's relative motion (t is clamped at 0 or rejected below it: collision.rs:249-359, 1089-1356), so the shapes'
+// bounding spheres come within reach of each other during the tick - with a margin of 1 % and a millimetre for rounding.  Nine
+// candidates in ten of a pile of capsules or two-part bodies end here.
+__device__ __forceinline__ bool comp_pair_far(const Comp& A, V3 vA, const Comp& B, V3 vB) {
+  const bool sa = A.kind == KIND_SPHERE, sb = B.kind == KIND_SPHERE;
+  const V3 ma = sa ? A.p : A.p + A.d * 0.5f, mb = sb ? B.p : B.p + B.d * 0.5f;
+  const float ra = sa ? A.r : A.r + 0.5f * mag(A.d), rb = sb ? B.r : B.r + 0.5f * mag(B.d);
+  const float lim = (ra + rb + mag(vB - vA)) * 1.01f + 1e-3f;
+  const V3 dd = mb - ma;
+  return dot(dd, dd) > lim * lim;
+}
 __device__ inline bool comp_pair_contact(const Comp& A, V3 vA, const Comp& B, V3 vB, Contact* out) {
   V3 vr = vB - vA;
-  {  // A cheap conservative reject before the reference's tests: every contact they report is a touching of the two shapes at
-     // some t in [0, 1] of B's relative motion (t is clamped at 0 or rejected below it: collision.rs:249-359, 1089-1356), so
-     // the shapes' bounding spheres come within reach of each other during the tick - with a margin of 1 % and a millimetre
-     // for rounding.  Nine candidates in ten of a pile of capsules or two-part bodies end here.
-    const bool sa = A.kind == KIND_SPHERE, sb = B.kind == KIND_SPHERE;
-    const V3 ma = sa ? A.p : A.p + A.d * 0.5f, mb = sb ? B.p : B.p + B.d * 0.5f;
-    const float ra = sa ? A.r : A.r + 0.5f * mag(A.d), rb = sb ? B.r : B.r + 0.5f * mag(B.d);
-    const float lim = (ra + rb + mag(vr)) * 1.01f + 1e-3f;
-    const V3 dd = mb - ma;
-    if (dot(dd, dd) > lim * lim) return false;
-  }
+  if (comp_pair_far(A, vA, B, vB)) return false;
   Contact k;
   bool hit;
   if (A.kind == KIND_SPHERE) {

@@ -15,9 +15,34 @@ struct NContact { float4 la, lb, n; };  // la.xyz + t, lb.xyz, n.xyz
 template <int KA, int KB>
 __global__ __launch_bounds__(kBlock) void k_narrow_pairs(Bodies B, const uint32_t* work, const uint32_t* m_ptr, const uint32_t* p_owner,
                                                          const uint32_t* p_cand, uint32_t* p_nc, NContact* p_out) {
-  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= *m_ptr) return;
-  uint32_t p = work ? work[t] : t;
+  // Candidates whose bounding spheres never come within reach (comp_pair_far: most of a pile's) leave first, and the block's
+  // survivors are packed into its first lanes: a lane that leaves early saves nothing while its wave runs the pair test.
+  __shared__ uint32_t s_list[kBlock];
+  __shared__ uint32_t s_n;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  {
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    bool live = false;
+    uint32_t p0 = 0;
+    if (t < *m_ptr) {
+      p0 = work ? work[t] : t;
+      V3 v0, v1;
+      Comp A0 = load_comp_moving(B, p_owner[p0], &v0), B0 = load_comp_moving(B, p_cand[p0], &v1);
+      A0.kind = KA; B0.kind = KB;
+      live = !comp_pair_far(A0, v0, B0, v1);
+      if (!live) p_nc[p0] = 0u;
+    }
+    const unsigned long long mask = __ballot(live);
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0 && mask) base = atomicAdd(&s_n, (uint32_t)__popcll(mask));
+    base = __shfl(base, 0);
+    if (live) s_list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = p0;
+  }
+  __syncthreads();
+  if (threadIdx.x >= s_n) return;
+  const uint32_t p = s_list[threadIdx.x];
   uint32_t i = p_owner[p], j = p_cand[p];
   V3 vA, vB;
   Comp A = load_comp_moving(B, i, &vA), Bc = load_comp_moving(B, j, &vB);
@@ -80,8 +105,35 @@ __device__ __forceinline__ int load_parts(const Bodies& B, uint32_t i, Comp out[
 }
 __global__ __launch_bounds__(kBlock) void k_narrow_pairs_parts(Bodies B, const uint32_t* m_ptr, const uint32_t* p_owner, const uint32_t* p_cand,
                                                                uint32_t* p_nc, NContact* p_out /* kPairContacts per candidate */) {
-  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-  if (p >= *m_ptr) return;
+  // The candidate was accepted on i's tight box against j's FAT box (bvh.rs:297), which is the larger by the margin and by every
+  // tick since j's last refit.  A contact is a touching of two parts somewhere inside both bodies' TIGHT swept boxes of this
+  // tick, so if those do not overlap (a millimetre and 1e-5 of the coordinates allowed for rounding) no part pair reports
+  // anything.  Three candidates in four leave here, before their parts are read - and the survivors of the block are packed
+  // into its first lanes (a lane that leaves early saves nothing while its wave goes on: whole waves have to leave).
+  __shared__ uint32_t s_list[kBlock];
+  __shared__ uint32_t s_n;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  {
+    const uint32_t p0 = blockIdx.x * kBlock + threadIdx.x;
+    bool live = false;
+    if (p0 < *m_ptr) {
+      const uint32_t i0 = p_owner[p0], j0 = p_cand[p0];
+      const float4 ca = B.tb_c[i0], ra = B.tb_r[i0], cb = B.tb_c[j0], rb = B.tb_r[j0];
+      const float slack = 1e-3f + 1e-5f * (fabs_rs(ca.x) + fabs_rs(ca.y) + fabs_rs(ca.z) + fabs_rs(cb.x) + fabs_rs(cb.y) + fabs_rs(cb.z));
+      live = !(fabs_rs(ca.x - cb.x) > ra.x + rb.x + slack || fabs_rs(ca.y - cb.y) > ra.y + rb.y + slack || fabs_rs(ca.z - cb.z) > ra.z + rb.z + slack);
+      if (!live) p_nc[p0] = 0u;
+    }
+    const unsigned long long mask = __ballot(live);
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0 && mask) base = atomicAdd(&s_n, (uint32_t)__popcll(mask));
+    base = __shfl(base, 0);
+    if (live) s_list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = p0;
+  }
+  __syncthreads();
+  if (threadIdx.x >= s_n) return;
+  const uint32_t p = s_list[threadIdx.x];
   const uint32_t i = p_owner[p], j = p_cand[p];
   Comp Pa[kMaxParts], Pb[kMaxParts];
   V3 ci, cj;
