@@ -165,3 +165,49 @@ def test_device_pointers_and_ghost_len(ctx):
     w.solve_enqueue(2)
     w.finish()
     torch.cuda.synchronize()
+
+
+def test_pair_contacts_at_the_edge_of_reach_survive_the_conservative_reject(ctx):
+    """The narrowphase rejects a pair whose bounding spheres never come within reach during the tick before it runs the
+    reference's tests (comp_pair_far, dev_geom.h).  That reject must never drop a contact: pairs built so that the shapes just
+    touch at the very end of the sweep (t close to 1), graze each other sideways, or sit exactly at the distance where the
+    bounding spheres meet - compared with the oracle, which has no such reject."""
+    rng = np.random.default_rng(77)
+    n_hit = n_late = 0
+    for k in range(600):
+        ta, tb = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        ra, rb = float(rng.uniform(0.2, 0.9)), float(rng.uniform(0.2, 0.9))
+        da = (rng.normal(size=3) * rng.uniform(0.1, 1.5)).astype(np.float32) if ta else np.zeros(3, np.float32)
+        db = (rng.normal(size=3) * rng.uniform(0.1, 1.5)).astype(np.float32) if tb else np.zeros(3, np.float32)
+        pa = rng.uniform(-50, 50, 3).astype(np.float32)
+        # the reach of the two bounding spheres, and a relative motion along the line of centres that closes a gap of about its own length
+        Ra, Rb = ra + 0.5 * float(np.linalg.norm(da)), rb + 0.5 * float(np.linalg.norm(db))
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        speed = float(rng.uniform(0.0, 3.0))
+        mode = k % 3
+        if mode == 0:    # head-on: centres start a little inside / outside Ra + Rb + speed
+            gap = (Ra + Rb + speed) * float(rng.uniform(0.9, 1.02))
+            side = np.zeros(3)
+        elif mode == 1:  # grazing: offset sideways by about the sum of the radii
+            w = np.cross(u, rng.normal(size=3)); w /= np.linalg.norm(w)
+            gap = speed * float(rng.uniform(0.2, 1.0))
+            side = w * (ra + rb) * float(rng.uniform(0.8, 1.05))
+        else:            # resting: no motion to speak of, surfaces a hair apart or overlapping
+            speed = float(rng.uniform(0.0, 1e-3))
+            gap = (ra + rb) * float(rng.uniform(0.7, 1.3))
+            side = np.zeros(3)
+        ma = pa + 0.5 * da                      # bounding-sphere centres
+        mb = ma + u * gap + side
+        pb = (mb - 0.5 * db).astype(np.float32)
+        vb = (-u * speed * rng.uniform(0.5, 1.0)).astype(np.float32)
+        va = (u * speed * rng.uniform(0.0, 0.5)).astype(np.float32)
+        got = mgf_amd.local_contacts_pair(ctx, (ta, pa, da, ra, va), (tb, pb, db, rb, vb))
+        want = O.local_contacts_pair(O.component(ta, pa, da, ra), va, O.component(tb, pb, db, rb), vb)
+        assert len(got) == len(want), (k, mode, ta, tb)
+        for g, w_ in zip(got, want):
+            for f in ("local_a", "local_b", "a", "b", "n"):
+                assert values_equal(g[f], w_[f]), (k, f)
+            assert values_equal([g["t"]], [w_["t"]])
+            n_late += 1 if w_["t"] > 0.8 else 0
+        n_hit += len(want)
+    assert n_hit > 100 and n_late > 10, (n_hit, n_late)
