@@ -380,6 +380,36 @@ def test_terrain_face_grid_and_tree_walk_agree(ctx):
         assert bits_equal(s1[k], s2[k]), k
 
 
+def test_terrain_face_grid_on_a_mesh_that_is_not_flat(ctx):
+    """The face grid's cells per axis follow the mesh (build_face_grid): the heightfield above is flat and gets one layer of cells; a
+    craggy one - heights of +-6 over 0.9-wide quads, faces as tall as they are wide - gets cells along all three axes, and a slab of it
+    offset far from the origin exercises the early return for bodies outside the mesh's bounds.  Grid and tree walk must agree, and
+    both with the oracle's first ticks."""
+    import mgf_amd
+    from mgf_amd import scenes
+    from tests.util import oracle_world
+    scene = scenes.capsule_field(20, 4, 20, quads=40, sphere_fraction=0.5)
+    scene = dict(scene, terrain=scenes.heightfield_terrain(40, 40, 36.0, 36.0, 6.0, pos=(0.0, -7.0, 0.0)))
+    a, b, o = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene), oracle_world(scene)
+    b.set_option("terrain_tree", 1)
+    assert a.counter("terrain_grid") == 1 and b.counter("terrain_grid") == 0
+    dt = float(scene["dt"])
+    for tick in range(70):
+        sa, sb = a.step(dt, 10), b.step(dt, 10)
+        assert (sa.n_constraints, sa.n_terrain_constraints, sa.n_terrain_candidates) == (sb.n_constraints, sb.n_terrain_constraints, sb.n_terrain_candidates), tick
+        if tick < 45:
+            so = o.step(dt, 10)
+            assert (sa.n_constraints, sa.n_terrain_constraints, sa.n_pair_candidates) == (so.n_constraints, so.n_terrain_constraints, so.n_pair_candidates), tick
+        if tick == 44:
+            g, w_ = a.state(), o.state()
+            for k in ("x", "q", "v", "omega"):
+                assert bits_equal(g[k], w_[k]), f"tick {tick}: {k} differs from the oracle"
+    assert sa.n_terrain_constraints > 100 and a.counter("terrain_grid") == 1
+    s1, s2 = a.state(), b.state()
+    for k in s1:
+        assert bits_equal(s1[k], s2[k]), k
+
+
 def test_two_pass_and_row_paths_agree(ctx):
     import mgf_amd
     from mgf_amd import scenes
