@@ -410,6 +410,39 @@ def test_terrain_face_grid_on_a_mesh_that_is_not_flat(ctx):
         assert bits_equal(s1[k], s2[k]), k
 
 
+def test_terrain_face_grid_with_cells_along_all_three_axes(ctx):
+    """Two floors: a small heightfield 12 above a large one.  The mesh is tall compared with its faces, so the face grid cuts the
+    vertical axis too (row-major cells, bits per axis from build_face_grid); bodies land on both floors.  Grid vs tree walk vs oracle."""
+    import mgf_amd
+    from mgf_amd import scenes
+    from tests.util import oracle_world
+    scene = scenes.capsule_field(16, 3, 16, quads=30, sphere_fraction=0.5)
+    lower = scenes.heightfield_terrain(30, 30, 32.0, 32.0, 0.2)
+    upper = scenes.heightfield_terrain(12, 12, 12.0, 12.0, 0.2, seed=5)
+    uv = upper["verts"].copy()
+    uv[:, 1] += 12.0
+    terrain = dict(verts=np.concatenate([lower["verts"], uv]).astype(np.float32),
+                   faces=np.concatenate([lower["faces"], upper["faces"] + np.uint32(len(lower["verts"]))]).astype(np.uint32),
+                   pos=np.float32([0.0, -14.0, 0.0]))
+    scene = dict(scene, terrain=terrain)
+    a, b, o = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene), oracle_world(scene)
+    b.set_option("terrain_tree", 1)
+    assert a.counter("terrain_grid") == 1 and b.counter("terrain_grid") == 0
+    dt = float(scene["dt"])
+    for tick in range(130):
+        sa, sb = a.step(dt, 10), b.step(dt, 10)
+        assert (sa.n_constraints, sa.n_terrain_constraints, sa.n_terrain_candidates) == (sb.n_constraints, sb.n_terrain_constraints, sb.n_terrain_candidates), tick
+        if tick < 100:
+            so = o.step(dt, 10)
+            assert (sa.n_constraints, sa.n_terrain_constraints) == (so.n_constraints, so.n_terrain_constraints), tick
+    y = a.state()["x"][:, 1]
+    assert (y > -4.0).sum() > 20 and (y < -10.0).sum() > 100, "bodies rest on both floors"
+    assert sa.n_terrain_constraints > 100
+    s1, s2 = a.state(), b.state()
+    for k in s1:
+        assert bits_equal(s1[k], s2[k]), k
+
+
 def test_two_pass_and_row_paths_agree(ctx):
     import mgf_amd
     from mgf_amd import scenes
