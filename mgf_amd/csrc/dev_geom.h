@@ -578,7 +578,8 @@ __device__ __forceinline__ bool comp_pair_far(const Comp& A, V3 vA, const Comp& 
 }
 __device__ inline bool comp_pair_contact(const Comp& A, V3 vA, const Comp& B, V3 vB, Contact* out) {
   V3 vr = vB - vA;
-  if (comp_pair_far(A, vA, B, vB)) return false;
+  // (not for two spheres: their own test is as cheap, and the kernels that fuse it into the pair search reject on their own)
+  if ((A.kind != KIND_SPHERE || B.kind != KIND_SPHERE) && comp_pair_far(A, vA, B, vB)) return false;
   Contact k;
   bool hit;
   if (A.kind == KIND_SPHERE) {

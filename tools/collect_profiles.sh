@@ -17,6 +17,7 @@ done
 cd $R
 for N in t s; do
   python tools/rocprof_summary.py gpurun_out/${TAG}${N}_trace/bench_results.db 60 > gpurun_out/${TAG}${N}_kernel_stats.txt
-  python tools/pmc_summary.py gpurun_out/${TAG}${N}_fetch/bench_results.db gpurun_out/${TAG}${N}_write/bench_results.db --timed k_solve_flow6 60 gpurun_out/${TAG}${N}_pmc_k_solve_flow6.json > gpurun_out/${TAG}${N}_pmc_hbm_traffic.txt
+  W=10; NAME=transient; [ $N = s ] && W=400 && NAME=settled
+  python tools/pmc_summary.py gpurun_out/${TAG}${N}_fetch/bench_results.db gpurun_out/${TAG}${N}_write/bench_results.db --timed k_solve_flow6 60 gpurun_out/${TAG}${N}_pmc_k_solve_flow6.json $NAME $W 60 > gpurun_out/${TAG}${N}_pmc_hbm_traffic.txt
 done
 ls gpurun_out | grep ${TAG}

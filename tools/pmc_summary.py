@@ -47,10 +47,20 @@ def main():
     if "--timed" in sys.argv:
         k = sys.argv.index("--timed")
         pattern, count, out = sys.argv[k + 1], int(sys.argv[k + 2]), sys.argv[k + 3]
+        # optional: the bench window the passes were taken on (name, warm-up ticks, timed ticks) - bench.py reports the traffic only
+        # beside a run of the same window
+        window = [sys.argv[k + 4], int(sys.argv[k + 5]), int(sys.argv[k + 6])] if len(sys.argv) > k + 6 else None
         f, n = last_launches(sys.argv[1], "FETCH_SIZE", pattern, count)
         w, _ = last_launches(sys.argv[2], "WRITE_SIZE", pattern, count)
-        json.dump(dict(kernel=pattern, launches=n, fetch_bytes_per_launch_raw=f, write_bytes_per_launch=w, hbm_bytes_per_launch_raw=f + w,
-                       hbm_bytes_per_launch=2 * f + w), open(out, "w"), indent=1)
+        d = dict(kernel=pattern, launches=n, fetch_bytes_per_launch_raw=f, write_bytes_per_launch=w, hbm_bytes_per_launch_raw=f + w,
+                 hbm_bytes_per_launch=2 * f + w)
+        if window:
+            d["window"] = window
+            d["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --no-cpu-baseline --no-settled "
+                         f"--no-order-check --min-seconds 0 --warmup {window[1]}` (262144 spheres, {window[2]} timed ticks, tools/collect_profiles.sh); "
+                         f"average over the LAST {count} launches of {pattern} = the timed window; counter unit KiB; hbm_bytes_per_launch = 2*FETCH + WRITE "
+                         "(gfx950 FETCH_SIZE reads 1/2 of 16-B/lane loads, MI355X_MICROARCH.md HBM section)")
+        json.dump(d, open(out, "w"), indent=1)
         print(f"# {pattern}: last {n} launches: fetch {f:.0f} B, write {w:.0f} B, raw {f + w:.0f} B, fetch x2 {2 * f + w:.0f} B per launch")
         sys.argv = sys.argv[:k]
     fetch, fc = load(sys.argv[1], "FETCH_SIZE")
