@@ -353,7 +353,7 @@ def _keys(st):
 def _pmc_traffic(mode, window):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_k_solve_flow*.json),
     only when they were collected on the window this run timed; else (None, why)."""
-    p = os.path.join(ROOT, "profiles", f"pmc_k_solve_flow{mode}.json")
+    p = os.path.join(ROOT, "profiles", f"pmc_k_solve_flow{mode}" + ("_settled" if window and window[0] == "settled" else "") + ".json")
     if not os.path.exists(p):
         return None, "no PMC pass committed for this kernel"
     try:
