@@ -15,12 +15,14 @@
 //                      k_lbvh_low / k_lbvh_top + k_pair_rows (implicit 4-ary tree over the cells, cooperative walk)
 //                      when one body spans too many cells; the hit SET is the reference's because acceptance is its own
 //                      predicate on the leaf boxes
-//   k_terrain_grid     Mesh::contacts' BVH::query by cell enumeration over the face boxes, hits stored as DFS ranks;
+//   k_terrain_grid     Mesh::contacts' BVH::query by cell enumeration over the face boxes (row-major cells, bits per axis chosen
+//                      from the mesh by build_face_grid: a heightfield's vertical axis gets none), hits stored as DFS ranks;
 //                      k_terrain_rows = the walk of the flattened reference tree in the reference's order
 //   k_candidates<FILL> the exact two-pass (count, fill) tree walk used when a candidate row overflows
 //   k_rows_to_csr      rows -> CSR, terrain faces in DFS order (partner contacts are ordered by k_count_contacts)
 //   k_narrow_pairs<A,B> / k_narrow_terrain<A>
-//                      one kernel per shape-pair type over the candidate lists
+//                      one kernel per shape-pair type over the candidate lists; pairs whose bounding spheres never come within
+//                      reach leave first (comp_pair_far) and a block's survivors are packed into its first lanes
 //   k_count_contacts / k_setup_pairs<SPHERES> (its first blocks: the terrain candidates, setup_terrain_one)
 //                      Manifold::from + ContactConstraint::new (manifold.rs:120-148, solver.rs:101-191); in a world of
 //                      spheres only the broadphase lists contacts (k_pair_grid<true> runs the sphere test) and
