@@ -267,7 +267,11 @@ __global__ __launch_bounds__(kScanBlock) void k_scan(ScanJob J) {
 // holds 4^l nodes at heap offset (4^l - 1) / 3; node k's children are 4k+1 .. 4k+4.  Built by plain
 // reductions (no atomics, no fences); traversed with a register-only bitmask trail; top levels in LDS.
 struct QNode { float4 lo[4], hi[4]; };     // child c: min = lo[c].xyz, max = hi[c].xyz; last level: lo.w = first body, hi.w = end
-struct LeafRec { float4 c, r; };           // fat box centre | body index, half extents (sorted order)
+// `order id`: what decides `j < i` (world.rs:266) and every other order the Gauss-Seidel sequence depends on.  The body store may be
+// kept in an internal (cell) order - slot s holds the caller's body ext[s], see host_perm.inc - and then the caller's index is the
+// order id; with the store in the caller's own order (ext = null) it is the slot itself.
+struct LeafRec { float4 c, r; };           // fat box centre | body slot, half extents | order id (sorted order)
+__device__ __forceinline__ uint32_t order_id(const uint32_t* ext, uint32_t slot) { return ext ? ext[slot] : slot; }
 struct Lbvh {
   QNode* nodes;        // (4^levels - 1) / 3 internal nodes
   LeafRec* leaves;     // n records in Morton order
@@ -276,6 +280,7 @@ struct Lbvh {
   float4* ltb;         // optional, 2 per leaf record: the body's tight box = its query, and in the .w words the cells that query has to
                        // look at: (centre, ca packed 10 bits per axis), (half extents, d packed likewise) (k_pair_brick)
   uint32_t* cell_lo;   // 4^levels + 1 entries: cell c holds the leaf records [cell_lo[c], cell_lo[c + 1])
+  const uint32_t* ext; // slot -> order id (the caller's body index), or null: the store is in the caller's order
   uint32_t n;          // live bodies
   uint32_t levels;     // internal levels L >= 4; 4^L leaf cells
   uint32_t* err;
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter_leaves(Lbvh T, const float4*
   uint32_t body = blockIdx.x * kBlock + threadIdx.x;
   if (body >= T.n) return;
   uint32_t p = T.cell_lo[cell_of[body]] + rank[body];
-  LeafRec lr; lr.c = mk4(xyz(fb_c[body]), u2f(body)); lr.r = mk4(xyz(fb_r[body]), 0.0f);
+  LeafRec lr; lr.c = mk4(xyz(fb_c[body]), u2f(body)); lr.r = mk4(xyz(fb_r[body]), u2f(order_id(T.ext, body)));
   T.leaves[p] = lr;
   if (T.lcol) { T.lcol[2 * p] = col0[body]; T.lcol[2 * p + 1] = delta[body]; }
   if (T.ltb) {
@@ -452,7 +457,7 @@ __device__ __forceinline__ void terrain_traverse(const TerrainDev& M, const Box&
 // Depth-first traversal of the implicit 4-ary tree with a bitmask trail (4 pending-child bits per level)
 // instead of a stack.  `top` = LDS copy of nodes [0, kLdsQNodes).
 template <class F>
-__device__ __forceinline__ void lbvh_traverse(const Lbvh& T, const QNode* top, uint32_t i, const Box& q, float pad_abs, F&& emit) {
+__device__ __forceinline__ void lbvh_traverse(const Lbvh& T, const QNode* top, uint32_t oi /* the query's order id */, const Box& q, float pad_abs, F&& emit) {
   if (T.n < 2) return;  // a single body has no partner
   // Inner nodes hold min/max unions: test them against a query padded well past f32 rounding so the
   // exact (centre, half-extent) acceptance test at the leaves is never pre-empted.
@@ -495,7 +500,7 @@ __device__ __forceinline__ void lbvh_traverse(const Lbvh& T, const QNode* top, u
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             uint32_t j = f2u(lr[e].c.w);
-            if (pb + e < p1 && j < i) {  // world.rs:266
+            if (pb + e < p1 && f2u(lr[e].r.w) < oi) {  // world.rs:266
               Box fb; fb.c = xyz(lr[e].c); fb.r = xyz(lr[e].r);
               if (box_overlaps(q, fb)) emit(j);  // the reference's own acceptance test (bvh.rs:297)
             }
@@ -564,8 +569,9 @@ __global__ __launch_bounds__(kBlock) void k_candidates(Bodies B, uint32_t n, uin
       ++nt;
     });
   }
-  if (i != 0) {  // world.rs:256
-    lbvh_traverse(T, s_top, i, q, pad, [&](uint32_t j) {
+  const uint32_t oi = order_id(T.ext, i);
+  if (oi != 0) {  // world.rs:256
+    lbvh_traverse(T, s_top, oi, q, pad, [&](uint32_t j) {
       if (j >= n_owned) return;  // ghost-ghost: the owners' business
       if (FILL) { p_cand[pb + np] = j; p_owner[pb + np] = i; }
       ++np;
@@ -575,8 +581,9 @@ __global__ __launch_bounds__(kBlock) void k_candidates(Bodies B, uint32_t n, uin
   // canonical partner order: ascending j (insertion sort, segments are ~10 long)
   for (uint32_t a = 1; a < np; ++a) {
     uint32_t v = p_cand[pb + a];
+    const uint32_t ov = order_id(T.ext, v);
     uint32_t b = a;
-    while (b > 0 && p_cand[pb + b - 1] > v) { p_cand[pb + b] = p_cand[pb + b - 1]; --b; }
+    while (b > 0 && order_id(T.ext, p_cand[pb + b - 1]) > ov) { p_cand[pb + b] = p_cand[pb + b - 1]; --b; }
     p_cand[pb + b] = v;
   }
 }
@@ -657,7 +664,8 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_rows(Bodies B, uint32_t n, 
   if (kq >= n) return;  // whole group leaves together
   uint32_t i = T.sidx[kq];  // Morton order: neighbouring groups walk neighbouring subtrees
   uint32_t np = 0;
-  if (i != 0 && T.n >= 2) {  // world.rs:256
+  const uint32_t oi = order_id(T.ext, i);
+  if (oi != 0 && T.n >= 2) {  // world.rs:256
     Box q; q.c = xyz(B.tb_c[i]); q.r = xyz(B.tb_r[i]);
     float pad = pad_abs + 1e-5f * (fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z);
     V3 qlo = q.c - q.r - mk3(pad, pad, pad), qhi = q.c + q.r + mk3(pad, pad, pad);
@@ -693,9 +701,10 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_rows(Bodies B, uint32_t n, 
             uint32_t rec = min(pb + (uint32_t)(sub >> 1), p1 - 1);
             float4 w = gleaves[(size_t)rec * 2 + (sub & 1)];  // even lane: centre | body, odd lane: half extents
             float rx = __shfl(w.x, lane | 1), ry = __shfl(w.y, lane | 1), rz = __shfl(w.z, lane | 1);
+            const uint32_t oj = f2u(__shfl(w.w, lane | 1));  // the record's order id rides with the half extents
             uint32_t j = f2u(w.w);
             bool hit = false;
-            if (!(sub & 1) && pb + (uint32_t)(sub >> 1) < p1 && j < i && j < n_owned) {  // world.rs:266; ghost-ghost skipped
+            if (!(sub & 1) && pb + (uint32_t)(sub >> 1) < p1 && oj < oi && j < n_owned) {  // world.rs:266; ghost-ghost skipped
               Box fb; fb.c = xyz(w); fb.r = mk3(rx, ry, rz);
               hit = box_overlaps(q, fb);  // the reference's own acceptance test (bvh.rs:297)
             }
@@ -770,7 +779,7 @@ struct PairSrcGlobal {
 // SPHERES - the sphere-sphere test on the accepted ones (staged in `acc`).  np = entries written to the row; n_accepted = fat-box
 // partners.  The lanes of a group stay together (ballots).
 template <bool SPHERES, class Src, class AccT>
-__device__ __forceinline__ void pair_query_cells(const Src& S, const Box& q, const Comp& A, V3 vA, uint32_t i, uint32_t n_owned, const uint32_t* ca,
+__device__ __forceinline__ void pair_query_cells(const Src& S, const Box& q, const Comp& A, V3 vA, uint32_t oi /* the query's order id */, uint32_t n_owned, const uint32_t* ca,
                                                  const uint32_t* d, const uint32_t* nb, int shift, int sub, int gbase, uint32_t* row, AccT* acc,
                                                  uint32_t* overflow, uint32_t& np, uint32_t& n_accepted) {
   const uint32_t ncell = d[0] * d[1] * d[2];
@@ -798,7 +807,7 @@ __device__ __forceinline__ void pair_query_cells(const Src& S, const Box& q, con
         float4 lc, lr;
         S.leaf(p0, lc, lr);
         j = f2u(lc.w);
-        if (j < i && j < n_owned) {  // world.rs:266; ghost-ghost skipped
+        if (f2u(lr.w) < oi && j < n_owned) {  // world.rs:266; ghost-ghost skipped
           Box fb; fb.c = xyz(lc); fb.r = xyz(lr);
           hit = box_overlaps(q, fb);  // the reference's own acceptance test (bvh.rs:297)
         }
@@ -871,7 +880,8 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, 
   const bool live = kq < n;  // whole groups are live or not
   uint32_t i = live ? T.sidx[kq] : 0u;
   uint32_t np = 0, n_accepted = 0;
-  if (live && i != 0 && T.n >= 2) {  // world.rs:256
+  const uint32_t oi = live ? order_id(T.ext, i) : 0u;
+  if (live && oi != 0 && T.n >= 2) {  // world.rs:256
     Box q;
     Comp A; V3 vA = mk3(0, 0, 0);
     uint32_t ca[3], d[3];
@@ -894,7 +904,7 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, 
       if (sub == 0) *too_wide = 1u;
     } else {
       PairSrcGlobal S; S.T = T;
-      pair_query_cells<SPHERES>(S, q, A, vA, i, n_owned, ca, d, nb, kMortonBits - (int)P, sub, gbase, rows_p + (size_t)i * kRowCap,
+      pair_query_cells<SPHERES>(S, q, A, vA, oi, n_owned, ca, d, nb, kMortonBits - (int)P, sub, gbase, rows_p + (size_t)i * kRowCap,
                                 s_acc[SPHERES ? threadIdx.x >> 3 : 0], overflow, np, n_accepted);
     }
   }
@@ -964,7 +974,7 @@ struct BrickSrcGlobal {  // the sorted arrays themselves, one cell at a time
 // Lane s of LQ over the cells [ca, ca + d) of one query.  cnt[0..2] (LDS, zero on entry): fat-box partners, partners that pass
 // the conservative distance test, contacts.  acc: staging row of record positions (kRowCap entries).
 template <bool SPHERES, class Src, class AccT>
-__device__ __forceinline__ void brick_query(const Src& S, const Box& q, const Comp& A, V3 vA, uint32_t i, uint32_t n_owned, const uint32_t* ca,
+__device__ __forceinline__ void brick_query(const Src& S, const Box& q, const Comp& A, V3 vA, uint32_t oi /* the query's order id */, uint32_t n_owned, const uint32_t* ca,
                                             const uint32_t* d, uint32_t s, uint32_t LQ, uint32_t* row, AccT* acc, uint32_t* cnt) {
   // lane s takes the z-columns s, s + LQ, ... of the d[0] x d[1] columns (division by the small d[1] through a multiplier)
   const uint32_t ncol = d[0] * d[1];
@@ -985,7 +995,7 @@ __device__ __forceinline__ void brick_query(const Src& S, const Box& q, const Co
             const uint32_t j = f2u(lc[u].w);
             Box fb; fb.c = xyz(lc[u]); fb.r = xyz(lr[u]);
             // world.rs:266 (ghost-ghost skipped) and the reference's own acceptance test (bvh.rs:297)
-            if (p + (uint32_t)u < p1 && j < i && j < n_owned && box_overlaps(q, fb)) hits |= 1u << u;
+            if (p + (uint32_t)u < p1 && f2u(lr[u].w) < oi && j < n_owned && box_overlaps(q, fb)) hits |= 1u << u;
           }
           if (hits) {
             uint32_t slot = atomicAdd(&cnt[0], (uint32_t)__popc(hits));
@@ -1088,9 +1098,9 @@ __global__ __launch_bounds__(kCoopBlock) __attribute__((amdgpu_waves_per_eu(6, 8
   uint32_t kq = q0 + t / (uint32_t)kBrickLanes;
   float4 qc, qr, qa, qv;
   qc = qr = qa = qv = make_float4(0, 0, 0, 0);
-  uint32_t qi = 0;
+  uint32_t qi = 0, qo = 0;  // the query's slot and order id (its own leaf record carries the latter)
   uint2 qreg = make_uint2(0, 0);
-  if (kq < q1) { qc = T.ltb[2 * kq]; qr = T.ltb[2 * kq + 1]; if (SPHERES) { qa = T.lcol[2 * kq]; qv = T.lcol[2 * kq + 1]; } qi = T.sidx[kq]; qreg = make_uint2(f2u(qc.w), f2u(qr.w)); }
+  if (kq < q1) { qc = T.ltb[2 * kq]; qr = T.ltb[2 * kq + 1]; if (SPHERES) { qa = T.lcol[2 * kq]; qv = T.lcol[2 * kq + 1]; } qi = T.sidx[kq]; qo = f2u(T.leaves[kq].r.w); qreg = make_uint2(f2u(qc.w), f2u(qr.w)); }
   if (staged) {
     float4* rc = s_dyn; float4* rr = s_dyn + cap; float4* cc = s_dyn + 2 * cap; float4* cd = s_dyn + 3 * cap;
     for (uint32_t r = 0; r < cnt; ++r) {
@@ -1104,11 +1114,11 @@ __global__ __launch_bounds__(kCoopBlock) __attribute__((amdgpu_waves_per_eu(6, 8
   uint32_t acc_total = 0, slow = 0;
   for (;;) {
     const bool live = kq < q1;  // whole groups are live or not
-    const uint32_t i = qi;
+    const uint32_t i = qi, oi = qo;
     uint32_t np = 0;
     if (sub == 0) { s_cnt[qg][0] = 0; s_cnt[qg][1] = 0; s_cnt[qg][2] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (live && i != 0 && T.n >= 2) {  // world.rs:256
+    if (live && oi != 0 && T.n >= 2) {  // world.rs:256
       Box q; q.c = xyz(qc); q.r = xyz(qr);
       Comp A; A.p = xyz(qa); A.r = qa.w; A.d = mk3(0, 0, 0); A.kind = KIND_SPHERE;
       const V3 vA = xyz(qv);
@@ -1118,10 +1128,10 @@ __global__ __launch_bounds__(kCoopBlock) __attribute__((amdgpu_waves_per_eu(6, 8
         if (sub == 0) *too_wide = 1u;
       } else if (staged && (int)ca[0] >= L.hb[0] && (int)ca[1] >= L.hb[1] && (int)ca[2] >= L.hb[2] && (int)(ca[0] + d[0]) <= L.hb[0] + 8 &&
                  (int)(ca[1] + d[1]) <= L.hb[1] + 8 && (int)(ca[2] + d[2]) <= L.hb[2] + 8) {
-        brick_query<SPHERES>(L, q, A, vA, i, n_owned, ca, d, sub, (uint32_t)kBrickLanes, row, s_acc[SPHERES ? qg : 0], s_cnt[qg]);
+        brick_query<SPHERES>(L, q, A, vA, oi, n_owned, ca, d, sub, (uint32_t)kBrickLanes, row, s_acc[SPHERES ? qg : 0], s_cnt[qg]);
       } else if (sub == 0) {
         BrickSrcGlobal S; S.T = T; S.nb[0] = nb[0]; S.nb[1] = nb[1]; S.nb[2] = nb[2]; S.shift = shift;
-        brick_query<SPHERES>(S, q, A, vA, i, n_owned, ca, d, 0u, 1u, row, row, s_cnt[qg]);  // (the row itself stages the accepted partners)
+        brick_query<SPHERES>(S, q, A, vA, oi, n_owned, ca, d, 0u, 1u, row, row, s_cnt[qg]);  // (the row itself stages the accepted partners)
         ++slow;
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1135,8 +1145,8 @@ __global__ __launch_bounds__(kCoopBlock) __attribute__((amdgpu_waves_per_eu(6, 8
     if (live && sub == 0) p_cnt[i] = np;
     kq += kBrickQueries;
     if (kq - qg >= q1) break;  // (the block's decision: every group sees the same pass base)
-    qi = 0;
-    if (kq < q1) { qc = T.ltb[2 * kq]; qr = T.ltb[2 * kq + 1]; if (SPHERES) { qa = T.lcol[2 * kq]; qv = T.lcol[2 * kq + 1]; } qi = T.sidx[kq]; qreg = make_uint2(f2u(qc.w), f2u(qr.w)); }
+    qi = 0; qo = 0;
+    if (kq < q1) { qc = T.ltb[2 * kq]; qr = T.ltb[2 * kq + 1]; if (SPHERES) { qa = T.lcol[2 * kq]; qv = T.lcol[2 * kq + 1]; } qi = T.sidx[kq]; qo = f2u(T.leaves[kq].r.w); qreg = make_uint2(f2u(qc.w), f2u(qr.w)); }
   }
   {  // accepted partners: one atomic per block, spread over many words
     uint32_t v = acc_total, u = slow;

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void k_bin_terrain(Bodies B, const uint32_t
 // running offset of each candidate inside the body's block.
 __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint32_t n, const uint32_t* t_off, const uint32_t* p_off,
                                                            const uint32_t* t_nc, const uint32_t* p_nc, const uint32_t* p_cand, uint32_t* t_pre,
-                                                           uint32_t* p_pre, uint32_t* cnt, int keep_order, uint32_t* tcn) {
+                                                           uint32_t* p_pre, uint32_t* cnt, int keep_order, uint32_t* tcn, const uint32_t* ext) {
   constexpr int kHitCap = 12;  // a sphere touches at most 12 equal ones
   __shared__ uint32_t s_j[kHitCap][kBlock], s_p[kHitCap][kBlock];
   const int tid = threadIdx.x;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint3
   uint32_t run = 0;
   for (uint32_t p = t_off[i]; p < t_off[i + 1]; ++p) { t_pre[p] = run; run += t_nc[p]; }
   if (run) atomicAdd(&s_ct, run);  // only the total is needed: one global atomic per block
-  // partner contacts are numbered in ascending partner order (the canonical insertion order); the candidate list itself
+  // partner contacts are numbered in ascending partner order - by the partners' order ids - (the canonical insertion order); the candidate list itself
   // is in discovery order, and only a few of its ~10 entries are contacts (at most one per partner): collect them, then
   // rank them among themselves
   const uint32_t lo = p_off[i], hi = p_off[i + 1];
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint3
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (nc[k]) {
-        if (h < (uint32_t)kHitCap) { s_j[h][tid] = p_cand[base + k]; s_p[h][tid] = (base + k) | (nc[k] << 28); }
+        if (h < (uint32_t)kHitCap) { s_j[h][tid] = order_id(ext, p_cand[base + k]); s_p[h][tid] = (base + k) | (nc[k] << 28); }
         ++h;
         total += nc[k];
       }
@@ -281,9 +281,9 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint3
   } else {  // a crowded body: the same by rescanning its list
     for (uint32_t p = lo; p < hi; ++p) {
       if (p_nc && p_nc[p] == 0) continue;
-      const uint32_t j = p_cand[p];
+      const uint32_t j = order_id(ext, p_cand[p]);
       uint32_t before = 0;
-      for (uint32_t q = lo; q < hi; ++q) before += (keep_order ? q < p : p_cand[q] < j) ? (p_nc ? p_nc[q] : 1u) : 0u;
+      for (uint32_t q = lo; q < hi; ++q) before += (keep_order ? q < p : order_id(ext, p_cand[q]) < j) ? (p_nc ? p_nc[q] : 1u) : 0u;
       p_pre[p] = run + before;
     }
   }

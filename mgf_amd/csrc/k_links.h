@@ -65,9 +65,15 @@ __device__ __forceinline__ uint32_t links_indeg0(const ConsLinks& K, uint32_t c)
 // in constraints of bodies i > x, whose ids are all larger: its chain is the own range followed by its row of `b`
 // occurrences (written by k_setup_pairs in arrival order, sorted here).  A row that overflowed raises kFailRevRow and
 // empties the tick (C = 0): the host widens the rows and re-runs the collide phase.
+// `ext` (the body store is kept in an internal order, host_perm.inc): a body's own range still comes first - the bodies it
+// meets as `b` are constraints of bodies with a LARGER order id, all inserted later - but ids no longer ascend with the
+// insertion order across bodies: the row is sorted by (order id of the constraint's body a, id).
+__device__ __forceinline__ unsigned long long rev_sort_key(const ConsLinks& K, const uint32_t* ext, uint32_t c) {
+  return ext ? (((unsigned long long)ext[K.ab[c].x] << 32) | c) : (unsigned long long)c;
+}
 __global__ __launch_bounds__(kBlock) void k_chain_rows(uint32_t n, ConsLinks K, const uint32_t* base, const uint32_t* degb, uint32_t* rev,
                                                        uint32_t rev_cap, const uint32_t* rev_flag, StepCounts* sc, const uint32_t* tcn, uint32_t n_owned,
-                                                       uint32_t* n_ghost_cons, const uint32_t* only_if) {
+                                                       uint32_t* n_ghost_cons, const uint32_t* only_if, const uint32_t* ext) {
   // (behind k_flow6_links, which has done the tick's bookkeeping: the links are only needed if the block-local solver declined)
   if (only_if && *only_if == 0u) return;
   uint32_t x = blockIdx.x * kBlock + threadIdx.x;
@@ -77,7 +83,9 @@ __global__ __launch_bounds__(kBlock) void k_chain_rows(uint32_t n, ConsLinks K, 
     if (x == 0) { sc->C = 0; sc->Ct = 0; sc->fail |= kFailRevRow; }
     return;
   }
-  if (x >= n || sc->fail) return;  // (a list-capacity miss: base[] counts constraints that were never written; the tick is re-run)
+  // (a list-capacity miss: base[] counts constraints that were never written; the tick is re-run.  kFailFlow6 alone is not
+  // such a miss: the list is whole, only the block-local solver's tables did not fit - and these links are what its stand-by walks)
+  if (x >= n || (sc->fail & ~kFailFlow6)) return;
   const uint32_t lo = base[x], na = base[x + 1] - lo, nb = degb[x];
   const uint32_t total = na + nb;
   if (total == 0) return;
@@ -85,7 +93,8 @@ __global__ __launch_bounds__(kBlock) void k_chain_rows(uint32_t n, ConsLinks K, 
   uint32_t* row = rev + (size_t)x * rev_cap;
   for (uint32_t a = 1; a < nb; ++a) {  // ascending constraint id = insertion order
     uint32_t v = row[a], b = a;
-    while (b > 0 && row[b - 1] > v) { row[b] = row[b - 1]; --b; }
+    const unsigned long long kv = rev_sort_key(K, ext, v);
+    while (b > 0 && rev_sort_key(K, ext, row[b - 1]) > kv) { row[b] = row[b - 1]; --b; }
     row[b] = v;
   }
   uint32_t* succ = reinterpret_cast<uint32_t*>(K.succ);

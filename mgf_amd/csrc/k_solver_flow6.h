@@ -233,7 +233,8 @@ __device__ __forceinline__ uint32_t f6_chan_slot(uint32_t* keys, uint32_t key1, 
 // this kernel with a guard - for the stand-by when a block did not fit).
 struct F6Ent { uint32_t home, slot, role, c, bref; };
 __global__ __launch_bounds__(kBlock) void k_flow6_links(Flow6 F, ConsLinks K, uint32_t n, const uint32_t* degb, uint32_t* rev, uint32_t rev_cap,
-                                                        const uint32_t* rev_flag, StepCounts* sc, uint32_t n_owned, uint32_t* n_ghost_cons) {
+                                                        const uint32_t* rev_flag, StepCounts* sc, uint32_t n_owned, uint32_t* n_ghost_cons,
+                                                        const uint32_t* ext) {
   const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   // constraints whose obj_a is a ghost (ids are ascending in obj_a): the copies of seam constraints (tiles count them once)
   if (t == 0) *n_ghost_cons = (sc->fail || *rev_flag) ? 0u : F.base[n] - F.base[n_owned];
@@ -249,17 +250,29 @@ __global__ __launch_bounds__(kBlock) void k_flow6_links(Flow6 F, ConsLinks K, ui
   uint32_t* row = rev + (size_t)x * rev_cap;
   // the row in ascending constraint id = insertion order: up to four entries (most bodies) sorted in registers from one
   // 16-byte load, longer rows in place
+  // (a store in internal order, `ext`: the insertion order across bodies is that of the order ids - rev_sort_key)
   const bool small = nbr <= 4u && (rev_cap & 3u) == 0u;
   uint32_t s4[4] = {kNone, kNone, kNone, kNone};
   if (small) {
     const uint4 r4 = *reinterpret_cast<const uint4*>(row);
     s4[0] = nbr > 0u ? r4.x : kNone; s4[1] = nbr > 1u ? r4.y : kNone; s4[2] = nbr > 2u ? r4.z : kNone; s4[3] = nbr > 3u ? r4.w : kNone;
-    auto cx = [&](int p, int q) { const uint32_t lo = min(s4[p], s4[q]), hi = max(s4[p], s4[q]); s4[p] = lo; s4[q] = hi; };
-    cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);  // (kNone = 0xFFFFFFFF sorts behind every id)
+    if (ext) {
+      unsigned long long k4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) k4[j] = s4[j] != kNone ? rev_sort_key(K, ext, s4[j]) : ~0ull;  // (the four look-ups go out together)
+      auto cx = [&](int p, int q) { const unsigned long long lo = min(k4[p], k4[q]), hi = max(k4[p], k4[q]); k4[p] = lo; k4[q] = hi; };
+      cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s4[j] = (uint32_t)k4[j];  // (the id is the key's low half; ~0 = kNone)
+    } else {
+      auto cx = [&](int p, int q) { const uint32_t lo = min(s4[p], s4[q]), hi = max(s4[p], s4[q]); s4[p] = lo; s4[q] = hi; };
+      cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);  // (kNone = 0xFFFFFFFF sorts behind every id)
+    }
   } else {
     for (uint32_t a = 1; a < nbr; ++a) {
       uint32_t v = row[a], b = a;
-      while (b > 0 && row[b - 1] > v) { row[b] = row[b - 1]; --b; }
+      const unsigned long long kv = rev_sort_key(K, ext, v);
+      while (b > 0 && rev_sort_key(K, ext, row[b - 1]) > kv) { row[b] = row[b - 1]; --b; }
       row[b] = v;
     }
   }

@@ -210,6 +210,29 @@ __global__ __launch_bounds__(kBlock) void k_compact_gather(Bodies B, uint32_t n,
   uint32_t i = t / kMigrantWords, e = t % kMigrantWords;
   if (keep[i]) tmp[(size_t)pos[i] * kMigrantWords + e] = migrant_get(B, e, i);
 }
+// ---- the body store in an internal order (host_perm.inc) ----------------------------------------------------------
+// Slot k of the new order takes the row of old slot order[k] - the body's row of every Bodies array, verbatim, like a
+// migrant's.  Word-major through the scratch copy (tmp[e * n + k]): consecutive lanes read one array at nearly consecutive
+// bodies (the store is re-sorted every few ticks: the old order is close to the new one) and write consecutive words.
+__global__ __launch_bounds__(kBlock) void k_permute_gather(Bodies B, uint32_t n, const uint32_t* order, float4* tmp) {
+  const uint32_t k = blockIdx.x * kBlock + threadIdx.x, e = blockIdx.y;
+  if (k >= n) return;
+  tmp[(size_t)e * n + k] = migrant_get(B, e, order[k]);
+}
+__global__ __launch_bounds__(kBlock) void k_permute_put(Bodies B, uint32_t n, const float4* tmp) {
+  const uint32_t k = blockIdx.x * kBlock + threadIdx.x, e = blockIdx.y;
+  if (k >= n) return;
+  migrant_put(B, e, k, tmp[(size_t)e * n + k]);
+}
+// the caller's index of every slot after the move (old_ext = null: the store was in the caller's order), and its inverse
+__global__ __launch_bounds__(kBlock) void k_permute_ids(uint32_t n, const uint32_t* order, const uint32_t* old_ext, uint32_t* new_ext, uint32_t* slot_of) {
+  const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t o = order[k], e = old_ext ? old_ext[o] : o;
+  new_ext[k] = e;
+  slot_of[e] = k;
+}
+
 __global__ __launch_bounds__(kBlock) void k_kind_mask(const float4* col1, const uint32_t* pcount, uint32_t base, uint32_t m, uint32_t* mask) {
   uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   if (t < m) atomicOr(mask, (pcount && pcount[base + t]) ? 4u : (f2u(col1[base + t].w) == (uint32_t)KIND_SPHERE ? 1u : 2u));

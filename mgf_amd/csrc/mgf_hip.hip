@@ -129,6 +129,7 @@ extern "C" mgf_status mgf_exclusive_scan_u32(mgf_ctx* ctx, const uint32_t* in, i
 #include "host_geom_io.inc"
 #include "host_single_shot.inc"
 #include "host_world.inc"
+#include "host_perm.inc"
 #include "host_tick.inc"
 #include "host_tiles.inc"
 #include "host_solver.inc"
