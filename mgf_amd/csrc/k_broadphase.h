@@ -992,10 +992,12 @@ __device__ __forceinline__ void brick_query(const Src& S, const Box& q, const Co
           uint32_t hits = 0;
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const uint32_t j = f2u(lc[u].w);
+            const uint32_t oj = f2u(lr[u].w);
             Box fb; fb.c = xyz(lc[u]); fb.r = xyz(lr[u]);
-            // world.rs:266 (ghost-ghost skipped) and the reference's own acceptance test (bvh.rs:297)
-            if (p + (uint32_t)u < p1 && f2u(lr[u].w) < oi && j < n_owned && box_overlaps(q, fb)) hits |= 1u << u;
+            // world.rs:266 (ghost-ghost skipped) and the reference's own acceptance test (bvh.rs:297).  (The ghost test on the order
+            // id: a world with ghosts is in the caller's order, where it is the slot; a re-sorted store has none.  The record's slot
+            // word is then only read for a hit: four registers less across the box test.)
+            if (p + (uint32_t)u < p1 && oj < oi && oj < n_owned && box_overlaps(q, fb)) hits |= 1u << u;
           }
           if (hits) {
             uint32_t slot = atomicAdd(&cnt[0], (uint32_t)__popc(hits));
@@ -1048,6 +1050,7 @@ __global__ __launch_bounds__(kCoopBlock) __attribute__((amdgpu_waves_per_eu(6, 8
   __shared__ uint32_t s_wsum[kCoopBlock / 64];
   __shared__ uint16_t s_acc[SPHERES ? kBrickQueries : 1][SPHERES ? kRowCap : 1];
   __shared__ uint32_t s_cnt[kBrickQueries][3];
+  __shared__ uint32_t s_qo[kBrickQueries];  // the order id of each group's query (fetched ahead with the query, parked here: a register less)
   __shared__ uint32_t s_sum, s_slow, s_q[2];
   const uint32_t P = 2u * T.levels;
   const uint32_t nbricks = (1u << P) >> 6;
@@ -1098,9 +1101,10 @@ __global__ __launch_bounds__(kCoopBlock) __attribute__((amdgpu_waves_per_eu(6, 8
   uint32_t kq = q0 + t / (uint32_t)kBrickLanes;
   float4 qc, qr, qa, qv;
   qc = qr = qa = qv = make_float4(0, 0, 0, 0);
-  uint32_t qi = 0, qo = 0;  // the query's slot and order id (its own leaf record carries the latter)
+  uint32_t qi = 0;  // the query's slot (its order id - its own leaf record carries it - waits in s_qo)
   uint2 qreg = make_uint2(0, 0);
-  if (kq < q1) { qc = T.ltb[2 * kq]; qr = T.ltb[2 * kq + 1]; if (SPHERES) { qa = T.lcol[2 * kq]; qv = T.lcol[2 * kq + 1]; } qi = T.sidx[kq]; qo = f2u(T.leaves[kq].r.w); qreg = make_uint2(f2u(qc.w), f2u(qr.w)); }
+  if (kq < q1) { qc = T.ltb[2 * kq]; qr = T.ltb[2 * kq + 1]; if (SPHERES) { qa = T.lcol[2 * kq]; qv = T.lcol[2 * kq + 1]; } qi = T.sidx[kq]; qreg = make_uint2(f2u(qc.w), f2u(qr.w)); }
+  if ((t & (uint32_t)(kBrickLanes - 1)) == 0u) s_qo[t / (uint32_t)kBrickLanes] = kq < q1 ? f2u(T.leaves[kq].r.w) : 0u;
   if (staged) {
     float4* rc = s_dyn; float4* rr = s_dyn + cap; float4* cc = s_dyn + 2 * cap; float4* cd = s_dyn + 3 * cap;
     for (uint32_t r = 0; r < cnt; ++r) {
@@ -1114,7 +1118,7 @@ __global__ __launch_bounds__(kCoopBlock) __attribute__((amdgpu_waves_per_eu(6, 8
   uint32_t acc_total = 0, slow = 0;
   for (;;) {
     const bool live = kq < q1;  // whole groups are live or not
-    const uint32_t i = qi, oi = qo;
+    const uint32_t i = qi, oi = s_qo[qg];
     uint32_t np = 0;
     if (sub == 0) { s_cnt[qg][0] = 0; s_cnt[qg][1] = 0; s_cnt[qg][2] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1145,8 +1149,9 @@ __global__ __launch_bounds__(kCoopBlock) __attribute__((amdgpu_waves_per_eu(6, 8
     if (live && sub == 0) p_cnt[i] = np;
     kq += kBrickQueries;
     if (kq - qg >= q1) break;  // (the block's decision: every group sees the same pass base)
-    qi = 0; qo = 0;
-    if (kq < q1) { qc = T.ltb[2 * kq]; qr = T.ltb[2 * kq + 1]; if (SPHERES) { qa = T.lcol[2 * kq]; qv = T.lcol[2 * kq + 1]; } qi = T.sidx[kq]; qo = f2u(T.leaves[kq].r.w); qreg = make_uint2(f2u(qc.w), f2u(qr.w)); }
+    qi = 0;
+    if (kq < q1) { qc = T.ltb[2 * kq]; qr = T.ltb[2 * kq + 1]; if (SPHERES) { qa = T.lcol[2 * kq]; qv = T.lcol[2 * kq + 1]; } qi = T.sidx[kq]; qreg = make_uint2(f2u(qc.w), f2u(qr.w)); }
+    if (sub == 0) s_qo[qg] = kq < q1 ? f2u(T.leaves[kq].r.w) : 0u;  // (this pass's value was read at its top: the lanes of a group move together)
   }
   {  // accepted partners: one atomic per block, spread over many words
     uint32_t v = acc_total, u = slow;

@@ -111,6 +111,22 @@ __global__ __launch_bounds__(kBlock) void k_chain_rows(uint32_t n, ConsLinks K, 
   }
 }
 
+// The insertion order of the tick's list when the body store is in an internal order (host_perm.inc): ids follow the slots, the
+// insertion order follows the caller's body indices.  cnt_e[e] = constraints body e inserts; after its scan (base_e),
+// canon[base_e[e] + k] = the k-th constraint of body e.  Needed by the executors that walk ids in order (k_solve_flow).
+__global__ __launch_bounds__(kBlock) void k_canon_counts(uint32_t n, const uint32_t* base, const uint32_t* ext, uint32_t* cnt_e) {
+  const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+  if (s < n) cnt_e[ext[s]] = base[s + 1] - base[s];
+  else if (s == n) cnt_e[n] = 0u;
+}
+__global__ __launch_bounds__(kBlock) void k_canon_fill(uint32_t n, const StepCounts* sc, const uint32_t* base, const uint32_t* ext, const uint32_t* base_e,
+                                                       uint32_t* canon) {
+  const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n || (sc->fail & ~kFailFlow6)) return;  // (a capacity miss: base[] counts constraints that were never written)
+  const uint32_t lo = base[s], m = base[s + 1] - lo, at = base_e[ext[s]];
+  for (uint32_t k = 0; k < m; ++k) canon[at + k] = lo + k;
+}
+
 // The solver walks the dependency graph of the WHOLE Solver::solve call (iters x constraints,
 // solver.rs:72-78) as one frontier process: a constraint's round k may run once the previous
 // constraint on each of its bodies has run (its round k, or round k-1 across the wrap).  Every

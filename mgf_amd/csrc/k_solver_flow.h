@@ -81,7 +81,10 @@ __global__ __launch_bounds__(kBlock) void k_flow_init(const uint32_t* C_ptr, Con
 template <bool TRACE>
 __global__ __launch_bounds__(kBlock) void k_solve_flow(float4* srec, CRec* cons, ConsLinks K, uint32_t* arr, const uint32_t* C_ptr, uint32_t iters,
                                                        uint32_t* abort_flag, uint32_t spin_limit, int sleep_mode, uint64_t* trace,
-                                                       const uint32_t* run_if, uint32_t* standby_bar) {
+                                                       const uint32_t* run_if, uint32_t* standby_bar, const uint32_t* canon) {
+  // `canon` (the body store is in an internal order, host_perm.inc: constraint ids follow the slots): canon[r] = id of the r-th
+  // constraint in insertion order.  A lane must walk ITS nodes in a topological order of the graph (see above) - the insertion
+  // order is one, the ids then are not.
   if (run_if && *run_if == 0u) return;  // stand-by launch behind the block-local solver: runs only if that one declined
   const uint32_t C = *C_ptr;
   const uint32_t L = gridDim.x * kBlock;
@@ -105,8 +108,8 @@ __global__ __launch_bounds__(kBlock) void k_solve_flow(float4* srec, CRec* cons,
     __syncthreads();
   }
   __amdgpu_buffer_rsrc_t rs = make_rsrc(srec);
-  uint32_t c = gl, round = 0;
-  bool done = (c >= C) || iters == 0;
+  uint32_t r = gl, c = 0, round = 0;
+  bool done = (r >= C) || iters == 0;
   bool have_rec = false;
   CRec rec;
   uint2 sw = make_uint2(0u, 0u);
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void k_solve_flow(float4* srec, CRec* cons,
     bool progressed = false;
     if (!done) {
       // the record is private to this lane: fetch it while the node is still waiting for its predecessors
-      if (!have_rec) { rec = load_crec(&cons[c]); sw = K.succ[c]; have_rec = true; }
+      if (!have_rec) { c = canon ? canon[r] : r; rec = load_crec(&cons[c]); sw = K.succ[c]; have_rec = true; }
       uint32_t a = __hip_atomic_load(&arr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (a >= 2u * (round + 1u)) {
         asm volatile("" ::: "memory");  // nothing below may be hoisted above the poll
@@ -138,8 +141,8 @@ __global__ __launch_bounds__(kBlock) void k_solve_flow(float4* srec, CRec* cons,
         if (TRACE) trace[2 * ((size_t)round * C + c) + 1] = wall_clock64();
         progressed = true;
         have_rec = false;
-        c += L;
-        if (c >= C) { c = gl; ++round; if (round >= iters) done = true; }
+        r += L;
+        if (r >= C) { r = gl; ++round; if (round >= iters) done = true; }
       }
     }
     if (__any(progressed)) { spins = 0; continue; }
