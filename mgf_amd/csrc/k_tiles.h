@@ -224,6 +224,63 @@ __global__ __launch_bounds__(kBlock) void k_permute_put(Bodies B, uint32_t n, co
   if (k >= n) return;
   migrant_put(B, e, k, tmp[(size_t)e * n + k]);
 }
+// ---- the order of a re-sort: compact blocks (host_perm.inc, partition_order) ------------------------------------------
+// Sort keys of one level of the three-level split (x slabs, y rows inside a slab, z inside a row): the unit the body fell into at
+// the level above - found from its position in that level's sorted order: units are runs of positions holding whole blocks, dealt
+// out evenly (the first B % f units one block more) - in the high bits, the 20-bit coordinate along this level's axis below.
+// vals[p] = the body (slot) at position p; null = p itself.
+constexpr uint32_t kPartCoordBits = 20;
+struct PartPlan { uint32_t nb, B, fx, fy; };  // bodies per block, blocks, x slabs, y rows per slab (at most)
+__host__ __device__ __forceinline__ void part_deal(uint32_t total, uint32_t f, uint32_t blk, uint32_t* unit, uint32_t* first, uint32_t* count) {
+  // `total` blocks over f units, the first total % f one more: which unit holds block `blk`, where that unit starts, how many it has
+  const uint32_t q = total / f, r = total % f, big = r * (q + 1u);
+  if (blk < big) { *unit = blk / (q + 1u); *first = *unit * (q + 1u); *count = q + 1u; }
+  else { const uint32_t k = q ? (blk - big) / q : 0u; *unit = r + k; *first = big + k * q; *count = q; }
+}
+__global__ __launch_bounds__(kBlock) void k_part_keys(uint32_t n, const uint32_t* vals, const float4* fb_c, const SceneBounds* sb, int axis,
+                                                      PartPlan P, uint32_t* keys, uint32_t* vals_out) {
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t b = vals ? vals[p] : p;
+  uint32_t unit = 0;
+  if (axis > 0) {
+    const uint32_t blk = p / P.nb;
+    uint32_t slab, first, cnt;
+    part_deal(P.B, P.fx, blk, &slab, &first, &cnt);
+    unit = slab;
+    if (axis == 2) {  // the row inside the slab
+      uint32_t row, rf, rc;
+      part_deal(cnt, min(P.fy, max(cnt, 1u)), blk - first, &row, &rf, &rc);
+      unit = slab * P.fy + row;
+    }
+  }
+  const float4 c = fb_c[b];
+  const float v = axis == 0 ? c.x : (axis == 1 ? c.y : c.z);
+  const float lo_f = ord_f(sb->lo[axis]), hi_f = ord_f(sb->hi[axis]);
+  const float ext = hi_f - lo_f;
+  float t = ext > 0.0f ? (v - lo_f) / ext : 0.0f;
+  t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+  const uint32_t q = (uint32_t)(t * (float)((1u << kPartCoordBits) - 1u));
+  keys[p] = (unit << kPartCoordBits) | q;
+  if (vals_out) vals_out[p] = b;
+}
+// ... and inside a block (a run of nb positions of the last level's order) the bodies in Morton order, 7 bits per axis over the
+// scene: the kernels of the tick walk the store beside the cell-sorted lists, which are in that order
+__global__ __launch_bounds__(kBlock) void k_part_keys_block(uint32_t n, const uint32_t* vals, const float4* fb_c, const SceneBounds* sb, uint32_t nb,
+                                                            uint32_t* keys) {
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  const float4 c = fb_c[vals[p]];
+  uint32_t code = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) code |= expand10(morton_quant(k == 0 ? c.x : (k == 1 ? c.y : c.z), ord_f(sb->lo[k]), ord_f(sb->hi[k])) >> 3) << (2 - k);
+  keys[p] = ((p / nb) << 21) | (code & 0x1FFFFFu);
+}
+
+__global__ __launch_bounds__(kBlock) void k_iota(uint32_t* a, uint32_t n) {
+  const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+  if (k < n) a[k] = k;
+}
 // the caller's index of every slot after the move (old_ext = null: the store was in the caller's order), and its inverse
 __global__ __launch_bounds__(kBlock) void k_permute_ids(uint32_t n, const uint32_t* order, const uint32_t* old_ext, uint32_t* new_ext, uint32_t* slot_of) {
   const uint32_t k = blockIdx.x * kBlock + threadIdx.x;

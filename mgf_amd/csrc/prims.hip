@@ -25,6 +25,17 @@ mgf_status prim_exclusive_scan_u32(mgf_ctx* ctx, const uint32_t* in, uint32_t* o
   return MGF_OK;
 }
 
+// (keys, values) sorted by the key bits [0, end_bit); stable
+mgf_status prim_sort_pairs_u32(mgf_ctx* ctx, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
+                               unsigned end_bit) {
+  if (n == 0) return MGF_OK;
+  size_t bytes = 0;
+  MGF_HIP_TRY(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, ctx->stream));
+  MGF_TRY(ensure_tmp(ctx, bytes));
+  MGF_HIP_TRY(rocprim::radix_sort_pairs(ctx->prim_tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, ctx->stream));
+  return MGF_OK;
+}
+
 // two independent scans of equal length in one pass (a tick's terrain and pair candidate counts become ready together)
 struct PlusPair {
   __host__ __device__ rocprim::tuple<uint32_t, uint32_t> operator()(const rocprim::tuple<uint32_t, uint32_t>& a,

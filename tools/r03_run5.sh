@@ -1,0 +1,11 @@
+set -u
+cd $GRAFT_REPO_ROOT
+(timeout 900 python -m pytest tests/test_gpu_cell_store.py tests/test_gpu_fullsize.py tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -5)
+B="python bench.py --no-cpu-baseline --no-order-check --min-seconds 0.5"
+for CFG in "resort_every=-1" "resort_every=64 --opt resort_partition=0"; do
+  echo "== $CFG"
+  $B --opt $CFG 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('ms/tick', round(d['ms_per_step'],4), 'solver frac', d['roofline']['frac'], 'settled ms', round(d['settled']['ms_per_step'],4), 'settled frac', d['settled']['roofline']['frac'])"
+done
