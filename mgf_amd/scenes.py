@@ -38,9 +38,33 @@ def uniform(seed, n, lo, hi, stream=0):
     return (np.float32(lo) + uniform01(seed, n, stream) * np.float32(hi - lo)).astype(np.float32)
 
 
-def seeded_permutation(seed, n, stream=0):
-    """Body index order: stable argsort of SplitMix64 keys (bounds the solver DAG depth)."""
+def fisher_yates(seed, n, stream=0):
+    """Body index order of SURVEY.md 8d: the seeded Fisher-Yates shuffle of 0..n-1 (Durstenfeld's form: for i = n-1 down to 1,
+    swap i with j = draw mod (i + 1)), draws = consecutive SplitMix64 outputs of the stream."""
+    if n <= 1:
+        return np.arange(n, dtype=np.int64)
+    draws = splitmix64(seed, n - 1, stream)
+    js = (draws % np.arange(n, 1, -1, dtype=np.uint64)).astype(np.int64)  # draw k serves i = n - 1 - k: modulus i + 1 = n - k
+    perm = list(range(n))
+    for k, j in enumerate(js.tolist()):
+        i = n - 1 - k
+        perm[i], perm[j] = perm[j], perm[i]
+    return np.asarray(perm, dtype=np.int64)
+
+
+def argsort_permutation(seed, n, stream=0):
+    """Rounds 1-2's body order, kept as a named variant (order="argsort"): stable argsort of SplitMix64 keys."""
     return np.argsort(splitmix64(seed, n, stream), kind="stable")
+
+
+def seeded_permutation(seed, n, stream=0, order="fisher_yates"):
+    """Body index order (it bounds the depth of the solver's dependency graph): SURVEY 8d's Fisher-Yates shuffle by
+    default; "argsort" = the variant of rounds 1-2."""
+    if order == "fisher_yates":
+        return fisher_yates(seed, n, stream)
+    if order == "argsort":
+        return argsort_permutation(seed, n, stream)
+    raise ValueError(f"unknown body order {order!r}")
 
 
 # mgf_demo/world.rs:118-150 — 8 vertices, 10 faces, open-top box; same winding.
@@ -92,7 +116,7 @@ def balls_demo(num=8, extra_ball=False, iters=10):
     return _scene(f"balls_demo_{len(c)}", _spheres(c, 0.5), box_terrain(10.0, 10.0, (0.0, -10.0, 0.0)), iters=iters)
 
 
-def sphere_pile(nx, ny, nz, seed=SEED, iters=10, shuffle=True, x_offset=0.0):
+def sphere_pile(nx, ny, nz, seed=SEED, iters=10, shuffle=True, x_offset=0.0, order="fisher_yates"):
     """BASELINE config 2 family: nx*ny*nz spheres r=0.5 on a pitch-1.0 lattice with jitter
     U(-0.05,0.05)^3 and v0 ~ U(-1,1)^3, resting on the floor of an open box; body index order
     is a seeded permutation.  sphere_pile(64,64,64) is the 262 144-sphere headline config."""
@@ -104,7 +128,7 @@ def sphere_pile(nx, ny, nz, seed=SEED, iters=10, shuffle=True, x_offset=0.0):
     c = (base + jit).astype(np.float32)
     c[:, 0] += np.float32(x_offset)
     if shuffle:
-        perm = seeded_permutation(seed, n, stream=7)
+        perm = seeded_permutation(seed, n, stream=7, order=order)
         c, v0 = c[perm], v0[perm]
     half = max(nx, nz) / 2.0 + 1.0
     terrain = box_terrain(half, ny + 2.0, (x_offset, 0.0, 0.0))
@@ -131,7 +155,7 @@ def sphere_pile_tile(nx, ny, nz, rank, world_size, seed=SEED, iters=10, drift=No
     jit = np.stack([uniform(seed, n, -0.05, 0.05, stream=st + s) for s in (1, 2, 3)], axis=1)
     v0 = np.stack([uniform(seed, n, -1.0, 1.0, stream=st + s) for s in (4, 5, 6)], axis=1)
     c = (base + jit).astype(np.float32)
-    perm = seeded_permutation(seed, n, stream=st + 7)
+    perm = seeded_permutation(seed, n, stream=st + 7)  # (SURVEY 8d's Fisher-Yates shuffle, per tile)
     c, v0 = c[perm], v0[perm]
     if drift is not None:
         v0 = (v0 + np.asarray(drift, np.float32)).astype(np.float32)
@@ -177,11 +201,12 @@ def _unit_vectors(seed, n, stream):
     return np.stack([s * np.cos(phi), z, s * np.sin(phi)], axis=1).astype(np.float32)
 
 
-def capsule_field(nx, ny, nz, quads=None, seed=SEED, iters=10, pitch=1.6, y0=1.2, sphere_fraction=0.0):
+def capsule_field(nx, ny, nz, quads=None, seed=SEED, iters=10, pitch=2.6, y0=1.2, sphere_fraction=0.0, order="fisher_yates"):
     """BASELINE config 3 family: nx*ny*nz capsules (r = 0.5, |d| = 0.5: the demo capsule of capsules.rs:67-75
-    at half scale) with seeded random orientations on a lattice above a heightfield of 2*quads^2 triangles
-    (Capsule-Triangle narrowphase).  capsule_field(128, 32, 32, quads=158) is the 131 072-capsule /
-    49 928-triangle configuration.  sphere_fraction > 0 mixes in spheres (r = 0.5)."""
+    at half scale) with seeded random orientations on a lattice of pitch 2.6 above a heightfield of
+    2*quads^2 triangles (Capsule-Triangle narrowphase).  capsule_field(128, 32, 32, quads=158) is the 131 072-capsule /
+    49 928-triangle configuration.  sphere_fraction > 0 mixes in spheres (r = 0.5).  capsule_field_dense = the same at
+    pitch 1.6 (rounds 1-2's default: neighbours touch from the first ticks on - what the small parity scenes want)."""
     n = nx * ny * nz
     i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
     base = np.stack([(i.ravel() - (nx - 1) / 2.0) * pitch, y0 + j.ravel() * pitch, (k.ravel() - (nz - 1) / 2.0) * pitch], axis=1)
@@ -195,13 +220,19 @@ def capsule_field(nx, ny, nz, quads=None, seed=SEED, iters=10, pitch=1.6, y0=1.2
         comps["p"][is_sphere] = c[is_sphere]
         comps["d"][is_sphere] = 0.0
     v0 = np.stack([uniform(seed, n, -0.5, 0.5, stream=s) for s in (37, 38, 39)], axis=1)
-    perm = seeded_permutation(seed, n, stream=40)
+    perm = seeded_permutation(seed, n, stream=40, order=order)
     comps, v0 = comps[perm], v0[perm]
     if quads is None:
         quads = max(4, int(round(max(nx, nz) * pitch / 1.3)))
     size_x, size_z = nx * pitch + 4.0, nz * pitch + 4.0
     terrain = heightfield_terrain(quads, quads, size_x, size_z, 0.2, seed=seed)
     return _scene(f"capsule_field_{nx}x{ny}x{nz}_q{quads}", comps, terrain, v0=v0, iters=iters)
+
+
+def capsule_field_dense(nx, ny, nz, **kw):
+    """capsule_field at pitch 1.6: a contact-rich field (the default of rounds 1-2, kept as a named variant)."""
+    kw.setdefault("pitch", 1.6)
+    return capsule_field(nx, ny, nz, **kw)
 
 
 def dumbbell_field(nx, ny, nz, n_plain=0, seed=SEED, iters=10, pitch=2.2, y0=1.5):

@@ -194,3 +194,42 @@ def test_scenes_are_deterministic():
     assert tuple(b["comps"]["p"][0]) == (-5.0, 20.0, -5.0) and tuple(b["comps"]["p"][1]) == (-5.0, 20.0, -3.75)
     full = scenes.balls_demo(11, extra_ball=True, iters=20)
     assert len(full["comps"]) == 1332 and tuple(full["comps"]["p"][-1]) == (0.0, 130.0, 0.0)
+
+
+def test_integration_md_declares_every_export():
+    """the Rust `extern "C"` block of INTEGRATION.md (what a maintainer of the reference would paste) against
+    include/mgf_hip.h - the same set of entry points, with the same number of parameters each."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r'^extern "C" \{\n(.*?)^\}', text, re.S | re.M)
+    assert m, 'INTEGRATION.md has no extern "C" block'
+    block = re.sub(r"//[^\n]*", "", m.group(1))
+    rust = {}
+    for fm in re.finditer(r"pub fn (mgf_\w+)\s*\((.*?)\)\s*(?:->\s*[^;]+)?;", block, re.S):
+        args = fm.group(2).strip()
+        depth, n = 0, 1 if args else 0   # top-level commas (a callback type `extern "C" fn(a, b)` holds commas of its own)
+        for ch in args:
+            depth += ch == "("
+            depth -= ch == ")"
+            n += ch == "," and depth == 0
+        rust[fm.group(1)] = n
+    header = open(os.path.join(ROOT, "include", "mgf_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    c = {}
+    for fm in re.finditer(r"MGF_API\s+[\w\s\*]+?\b(mgf_\w+)\s*\((.*?)\)\s*;", header, re.S):
+        args = fm.group(2).strip()
+        if args == "void":
+            c[fm.group(1)] = 0
+            continue
+        depth, n = 0, 1
+        for ch in args:
+            depth += ch == "("
+            depth -= ch == ")"
+            n += ch == "," and depth == 0
+        c[fm.group(1)] = n
+    assert set(c) == set(_declared_symbols()), "this test's header parser and _declared_symbols disagree"
+    missing = sorted(set(c) - set(rust))
+    extra = sorted(set(rust) - set(c))
+    assert not missing, f"exports not declared in INTEGRATION.md: {missing}"
+    assert not extra, f"INTEGRATION.md declares functions the header does not export: {extra}"
+    wrong = {k: (rust[k], c[k]) for k in c if rust[k] != c[k]}
+    assert not wrong, f"parameter counts differ (INTEGRATION.md, header): {wrong}"

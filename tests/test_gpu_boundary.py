@@ -43,7 +43,7 @@ def _info_equal(vel, info, want, what):
         assert bits_equal(np.atleast_1d(v), np.atleast_1d(np.asarray(want[k], np.float32))), f"{what}: {k}: {v} vs {want[k]}"
 
 
-@pytest.mark.parametrize("scene_fn", [lambda: scenes.sphere_pile(6, 6, 6), lambda: scenes.capsule_field(6, 2, 6)])
+@pytest.mark.parametrize("scene_fn", [lambda: scenes.sphere_pile(6, 6, 6), lambda: scenes.capsule_field_dense(6, 2, 6)])
 def test_constrained_set_get_and_set(ctx, scene_fn):
     """ConstrainedSet::get returns (v, omega) + (x + delta, e, mu, 1/m, world I^-1) (physics.rs:273-288); Static gives
     zeros at its centre (:289-302); set scatters (v, omega) and ignores Static (:306-314)."""
@@ -70,7 +70,7 @@ def test_constrained_set_get_and_set(ctx, scene_fn):
     _same_state(gw, ow, "tick after set")
 
 
-@pytest.mark.parametrize("scene_fn", [lambda: scenes.sphere_pile(6, 6, 6), lambda: scenes.capsule_field(6, 2, 6)])
+@pytest.mark.parametrize("scene_fn", [lambda: scenes.sphere_pile(6, 6, 6), lambda: scenes.capsule_field_dense(6, 2, 6)])
 def test_integrate_complete_motion_and_colliders_alone(ctx, scene_fn):
     """RigidBodyVec::integrate (physics.rs:222-253), ::complete_motion (:262-269) and ::colliders (:256) called one by one,
     the way a caller that owns its own tick would."""
@@ -189,7 +189,7 @@ def test_solver_handle_runs_a_callers_list_in_insertion_order(ctx, mode):
 
 
 def test_world_clone_is_independent_and_steps_identically(ctx):
-    for scene in (scenes.capsule_field(8, 2, 8), scenes.sphere_pile(8, 8, 8)):
+    for scene in (scenes.capsule_field_dense(8, 2, 8), scenes.sphere_pile(8, 8, 8)):
         dt, iters = float(scene["dt"]), scene["iters"]
         a = mgf_amd.World.from_scene(ctx, scene)
         for _ in range(8):

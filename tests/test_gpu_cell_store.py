@@ -40,8 +40,8 @@ def _scenes():
     from mgf_amd import scenes
     return {
         "spheres": scenes.sphere_pile(12, 10, 12),
-        "capsules_on_heightfield": scenes.capsule_field(10, 4, 10, quads=12, y0=0.9),
-        "mixed": scenes.capsule_field(8, 4, 8, quads=10, y0=0.9, sphere_fraction=0.5),
+        "capsules_on_heightfield": scenes.capsule_field_dense(10, 4, 10, quads=12, y0=0.9),
+        "mixed": scenes.capsule_field_dense(8, 4, 8, quads=10, y0=0.9, sphere_fraction=0.5),
         "two_part_bodies": scenes.dumbbell_field(6, 3, 6, n_plain=20),
     }
 
@@ -95,7 +95,7 @@ def test_step_many_with_a_stale_order(ctx):
 
 def test_boundary_maps_indices(ctx):
     from mgf_amd import scenes
-    scene = scenes.capsule_field(8, 3, 8, quads=10, y0=0.9, sphere_fraction=0.3)
+    scene = scenes.capsule_field_dense(8, 3, 8, quads=10, y0=0.9, sphere_fraction=0.3)
     dt, iters = float(scene["dt"]), scene["iters"]
     n = len(scene["comps"])
     ref = _world(ctx, scene, 0)

@@ -86,7 +86,7 @@ def test_single_shot_local_contacts_pair_and_mesh(ctx):
         n_hit += len(want)
     assert n_hit > 30
     # body against the terrain mesh: the oracle world's own terrain contacts for a few resting capsules
-    scene = scenes.capsule_field(6, 2, 6)
+    scene = scenes.capsule_field_dense(6, 2, 6)
     gw, ow = mgf_amd.World.from_scene(ctx, scene), oracle_world(scene)
     dt = float(scene["dt"])
     for _ in range(45):

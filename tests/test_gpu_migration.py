@@ -99,7 +99,7 @@ def test_migrant_round_trip_on_one_world(ctx):
     import mgf_amd
     from mgf_amd import scenes
     from mgf_amd.tiles import MIGRANT_FLOATS
-    sc = scenes.capsule_field(5, 2, 5, sphere_fraction=0.5)
+    sc = scenes.capsule_field_dense(5, 2, 5, sphere_fraction=0.5)
     dt, iters = float(sc["dt"]), sc["iters"]
     gw, ow = mgf_amd.World.from_scene(ctx, sc), oracle_world(sc)
     n = len(gw)

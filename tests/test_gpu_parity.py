@@ -107,8 +107,8 @@ def test_world_step_parity_teacher_forced(ctx, scene_name):
     from mgf_amd import scenes
     scene = {"balls8": lambda: scenes.balls_demo(8), "pile12": lambda: scenes.sphere_pile(12, 12, 12),
              "pile16_noshuffle": lambda: scenes.sphere_pile(16, 8, 16, shuffle=False),
-             "capsules": lambda: scenes.capsule_field(8, 3, 8),                       # Capsule-Capsule, Capsule-Triangle
-             "mixed": lambda: scenes.capsule_field(8, 3, 8, sphere_fraction=0.5),     # all four pair types + binning
+             "capsules": lambda: scenes.capsule_field_dense(8, 3, 8),                       # Capsule-Capsule, Capsule-Triangle
+             "mixed": lambda: scenes.capsule_field_dense(8, 3, 8, sphere_fraction=0.5),     # all four pair types + binning
              }[scene_name]()
     dt, iters = float(scene["dt"]), scene["iters"]
     ow = oracle_world(scene)
@@ -348,8 +348,8 @@ def test_grid_and_tree_broadphase_agree(ctx, scene_name):
     4-ary tree (k_pair_rows).  Same acceptance predicate, so the same candidates and the same tick."""
     import mgf_amd
     from mgf_amd import scenes
-    scene = {"pile16": lambda: scenes.sphere_pile(16, 16, 16), "capsules": lambda: scenes.capsule_field(10, 3, 10),
-             "mixed": lambda: scenes.capsule_field(8, 3, 8, sphere_fraction=0.5)}[scene_name]()
+    scene = {"pile16": lambda: scenes.sphere_pile(16, 16, 16), "capsules": lambda: scenes.capsule_field_dense(10, 3, 10),
+             "mixed": lambda: scenes.capsule_field_dense(8, 3, 8, sphere_fraction=0.5)}[scene_name]()
     a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
     b.set_option("broadphase_tree", 1)
     for _ in range(30):
@@ -366,7 +366,7 @@ def test_terrain_face_grid_and_tree_walk_agree(ctx):
     walk of the mesh BVH (k_terrain_rows): same faces in the same order, so the same tick."""
     import mgf_amd
     from mgf_amd import scenes
-    scene = scenes.capsule_field(24, 3, 24, quads=40)
+    scene = scenes.capsule_field_dense(24, 3, 24, quads=40)
     a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
     b.set_option("terrain_tree", 1)
     assert a.counter("terrain_grid") == 1 and b.counter("terrain_grid") == 0
@@ -388,7 +388,7 @@ def test_terrain_face_grid_on_a_mesh_that_is_not_flat(ctx):
     import mgf_amd
     from mgf_amd import scenes
     from tests.util import oracle_world
-    scene = scenes.capsule_field(20, 4, 20, quads=40, sphere_fraction=0.5)
+    scene = scenes.capsule_field_dense(20, 4, 20, quads=40, sphere_fraction=0.5)
     scene = dict(scene, terrain=scenes.heightfield_terrain(40, 40, 36.0, 36.0, 6.0, pos=(0.0, -7.0, 0.0)))
     a, b, o = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene), oracle_world(scene)
     b.set_option("terrain_tree", 1)
@@ -416,7 +416,7 @@ def test_terrain_face_grid_with_cells_along_all_three_axes(ctx):
     import mgf_amd
     from mgf_amd import scenes
     from tests.util import oracle_world
-    scene = scenes.capsule_field(16, 3, 16, quads=30, sphere_fraction=0.5)
+    scene = scenes.capsule_field_dense(16, 3, 16, quads=30, sphere_fraction=0.5)
     lower = scenes.heightfield_terrain(30, 30, 32.0, 32.0, 0.2)
     upper = scenes.heightfield_terrain(12, 12, 12.0, 12.0, 0.2, seed=5)
     uv = upper["verts"].copy()
@@ -446,7 +446,7 @@ def test_terrain_face_grid_with_cells_along_all_three_axes(ctx):
 def test_two_pass_and_row_paths_agree(ctx):
     import mgf_amd
     from mgf_amd import scenes
-    scene = scenes.capsule_field(8, 3, 8, sphere_fraction=0.5)
+    scene = scenes.capsule_field_dense(8, 3, 8, sphere_fraction=0.5)
     a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
     b.set_option("two_pass_candidates", 1)
     for _ in range(40):
@@ -478,7 +478,7 @@ def test_pipelined_step_many_with_capacity_misses(ctx, scene_name):
     bit, through forced misses (tiny list capacities before every batch) and with the pipeline switched off."""
     import mgf_amd
     from mgf_amd import scenes
-    scene = {"pile": lambda: scenes.sphere_pile(10, 10, 10), "mixed": lambda: scenes.capsule_field(8, 3, 8, sphere_fraction=0.5),
+    scene = {"pile": lambda: scenes.sphere_pile(10, 10, 10), "mixed": lambda: scenes.capsule_field_dense(8, 3, 8, sphere_fraction=0.5),
              "dumbbells": lambda: scenes.dumbbell_field(6, 4, 6, 60)}[scene_name]()
     dt, iters = float(scene["dt"]), scene["iters"]
     a, b, c = (mgf_amd.World.from_scene(ctx, scene) for _ in range(3))
@@ -631,7 +631,7 @@ def test_dataflow_solver_matches_oracle(ctx, scene_name, mode):
     """solver_mode=1 (one persistent dataflow launch) must give the sequential Gauss-Seidel result too."""
     import mgf_amd
     from mgf_amd import scenes
-    scene = {"pile12": lambda: scenes.sphere_pile(12, 12, 12), "mixed": lambda: scenes.capsule_field(8, 3, 8, sphere_fraction=0.5),
+    scene = {"pile12": lambda: scenes.sphere_pile(12, 12, 12), "mixed": lambda: scenes.capsule_field_dense(8, 3, 8, sphere_fraction=0.5),
              "balls8": lambda: scenes.balls_demo(8)}[scene_name]()
     dt, iters = float(scene["dt"]), scene["iters"]
     ow = oracle_world(scene)

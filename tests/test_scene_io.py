@@ -136,7 +136,7 @@ def test_mesh_json_round_trip_host_only():
 @pytest.mark.gpu
 def test_world_steps_identically_on_a_deserialised_terrain():
     ctx = mgf_amd.Context(0)
-    scene = scenes.capsule_field(8, 2, 8)
+    scene = scenes.capsule_field_dense(8, 2, 8)
     a = mgf_amd.World.from_scene(ctx, scene)
     b = mgf_amd.World(ctx)
     b.set_terrain(mgf_amd.Mesh.from_json(ctx, _terrain_mesh(ctx, scene["terrain"]).to_json()))

@@ -40,7 +40,7 @@ ok = True
 if len(sys.argv) < 2 or sys.argv[1] != "big":
     ok &= run(scenes.sphere_pile(12, 12, 12), 80, 0, block=64, label="pile 12^3, blocks of 64")
     ok &= run(scenes.sphere_pile(16, 16, 16), 60, 0, block=128, label="pile 16^3, blocks of 128")
-    ok &= run(scenes.capsule_field(16, 2, 16), 60, 0, block=64, label="capsules 16x2x16, blocks of 64")
+    ok &= run(scenes.capsule_field_dense(16, 2, 16), 60, 0, block=64, label="capsules 16x2x16, blocks of 64")
     ok &= run(scenes.sphere_pile(20, 20, 20), 40, 1, label="pile 20^3, default blocks")
 sc = scenes.sphere_pile(64, 64, 64)
 ok &= run(sc, 30, 5, label="pile 64^3")
