@@ -37,8 +37,7 @@ KERNEL_NAMES = {6: "k_solve_flow6 (ContactConstraint::solve, block-local persist
                 1: "k_solve_flow (ContactConstraint::solve, persistent dataflow launch",
                 4: "k_solve_flowk (ContactConstraint::solve, persistent dataflow launch",
                 0: "k_solve (ContactConstraint::solve, one launch per dependency frontier"}
-SCENE_NOTE = ("body order = argsort of SplitMix64 keys (SURVEY 8d names a Fisher-Yates shuffle of the same generator: another "
-              "fixed permutation, same statistics)")
+SCENE_NOTE = "body order = SURVEY 8d's seeded Fisher-Yates shuffle (SplitMix64, seed 0x6D6766)"
 
 
 def main():
@@ -46,12 +45,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--scene", default="auto", choices=["auto", "config2", "config4", "weak"])
+    ap.add_argument("--scene", default="auto", choices=["auto", "config2", "config3", "config5", "config4", "weak"],
+                    help="auto = config 2 at N = 1, config 4 at N > 1; config3 / config5 = those configurations alone on one GPU (their own line: profiles)")
     ap.add_argument("--tile", type=int, nargs=3, default=[64, 64, 64], help="spheres per tile (nx ny nz): config 2's world, or --scene weak's tile")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--min-seconds", type=float, default=1.0, help="N = 1: repeat the timed window from a snapshot until this much has been measured")
     ap.add_argument("--no-settled", action="store_true", help="N = 1: skip the second window after tick 400")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the nested one-window runs of BASELINE configs 3 and 5")
     ap.add_argument("--no-order-check", action="store_true", help="N = 1: skip the canonical-vs-world.rs-order deviation (a few seconds of host BVH replay)")
     ap.add_argument("--solver-mode", type=int, default=None, help="override the library's default solver mode (development)")
     ap.add_argument("--refresh-every", type=int, default=None, help="solver iterations between ghost velocity refreshes (tiles)")
@@ -75,8 +76,8 @@ def main():
     scene_kind = args.scene
     if scene_kind == "auto":
         scene_kind = "config2" if world_size == 1 else "config4"
-    if scene_kind == "config2" and world_size > 1:
-        raise SystemExit("config 2 is the single-GPU workload; use --scene config4 or --scene weak with --gpus N")
+    if scene_kind in ("config2", "config3", "config5") and world_size > 1:
+        raise SystemExit("configs 2, 3 and 5 are single-GPU workloads here; use --scene config4 or --scene weak with --gpus N")
     if scene_kind == "config4" and 8 % world_size:
         raise SystemExit("config 4 is cut into 8 tiles: --gpus must be 1, 2, 4 or 8")
 
@@ -115,6 +116,8 @@ def main():
     mode = args.solver_mode if args.solver_mode is not None else 6
     if scene_kind == "config2":
         out = bench_single_world(args, ctx, mgf_amd, scenes, configure, mode)
+    elif scene_kind in ("config3", "config5"):
+        out = bench_other_config(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, standalone=True)
     else:
         out = bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, world_size, dist, torch, red_dev, barrier, refresh_every)
     if rank == 0:
@@ -132,14 +135,15 @@ def _window_stats(per_tick, iters):
     launches = sum(int(st["solver_kernel_launches"]) for st in per_tick)
     kms = sum(float(st["ms_solver_kernels"]) for st in per_tick)
     phase = {k: sum(float(st[k]) for st in per_tick) / len(per_tick) for k in ("ms_integrate", "ms_broadphase", "ms_narrowphase", "ms_setup", "ms_solve")}
+    phase["ms_total"] = sum(float(st["ms_total"]) for st in per_tick) / len(per_tick)  # HIP events around the whole tick on its stream
     return units, cons, launches, kms, phase
 
 
-def _roofline(units, launches, kms, mode, what, window):
+def _roofline(units, launches, kms, mode, what, window, workload="config2"):
     if not (kms > 0 and launches > 0):
         return None
     achieved = units * SOLVE_BYTES_PER_UNIT / (kms * 1e-3) / 1e9
-    traffic, source = _pmc_traffic(mode, window)
+    traffic, source = _pmc_traffic(mode, window, workload)
     return {"bound": "hbm", "kernel": KERNEL_NAMES[mode] + ": " + what + ")", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": source, "bytes_per_unit": SOLVE_BYTES_PER_UNIT,
             "avg_launch_us": round(kms * 1e3 / launches, 3), "avg_units_per_launch": round(units / launches, 1), "launches_timed": int(launches)}
@@ -188,9 +192,15 @@ def bench_single_world(args, ctx, mgf_amd, scenes, configure, mode):
         "solver_launches_per_step": launches / args.steps, "phase_ms_per_step_rank0": phase,
         "solve_phase_constraint_iters_per_sec_rank0": units / (phase["ms_solve"] * args.steps * 1e-3) if phase["ms_solve"] > 0 else None,
         "roofline": _roofline(units, launches, kms, mode, "all iterations of a tick", ("transient", args.warmup, args.steps)),
+        # GPU activity as the stream itself saw it (HIP events around every tick; no sampler needed): the timed ticks of the reported
+        # window, and of all windows together
+        "gpu_event_ms": {"reported_window": round(phase["ms_total"] * args.steps, 3),
+                         "all_windows": round(sum(wd[1][4]["ms_total"] for wd in windows) * args.steps, 3),
+                         "solver_kernel_ms_reported_window": round(kms, 3)},
     }
     if not args.no_order_check:
         out["constraint_order_deviation"] = order_deviation(ctx, mgf_amd, scene, dt, args.iters)
+        out["constraint_order_demo_cost"] = demo_order_cost(ctx, mgf_amd, scenes, scene, args.iters)
     if not args.no_settled:
         # the settled pile (what the workload spends its life in): twice the constraints, deeper dependency graph
         while_ticks = max(0, 400 - args.warmup - args.steps)
@@ -208,7 +218,68 @@ def bench_single_world(args, ctx, mgf_amd, scenes, configure, mode):
         out["settled"] = {"window": f"ticks {args.warmup + args.steps + while_ticks}..{args.warmup + 2 * args.steps + while_ticks}", "value": u2 / el,
                           "ms_per_step": el * 1e3 / args.steps, "constraints_per_step": c2 / args.steps, "phase_ms_per_step": p2,
                           "roofline": _roofline(u2, l2, k2, mode, "all iterations of a tick", ("settled", 400, args.steps))}
+    if not args.no_other_configs:
+        # BASELINE configs 3 and 5 on the same GPU, one short window each (their own lines: python bench.py --scene config3 / config5)
+        del world, snap
+        for kind in ("config3", "config5"):
+            out[kind] = bench_other_config(args, ctx, mgf_amd, scenes, configure, mode, kind, standalone=False)
     return out
+
+
+OTHER_CONFIGS = {
+    # name, scene builder, warm-up ticks (the bodies have to arrive somewhere first), what it is
+    "config3": ("BASELINE config 3: 131 072 capsules (r = 0.5, |d| = 0.5, random orientations, 128x32x32 lattice of pitch 2.6) over a 49 928-triangle "
+                "heightfield (158 x 158 quads, heights U(-0.2, 0.2)), 10 solver iters", lambda sc: sc.capsule_field(128, 32, 32, quads=158), 150),
+    "config5": ("BASELINE config 5 (this build's own definition of a rigid body of two components - the reference has none, SURVEY H8): 65 536 bodies, "
+                "each a sphere (r = 0.5) + a capsule (|d| = 1, r = 0.3), 64x16x64 lattice of pitch 2.2 in an open box, 10 solver iters",
+                lambda sc: sc.dumbbell_field(64, 16, 64), 80),
+}
+
+
+def bench_other_config(args, ctx, mgf_amd, scenes, configure, mode, kind, standalone):
+    """One world of BASELINE config 3 / 5 on one GPU: W warm-up ticks, then the K timed ticks from a snapshot (repeated while
+    --min-seconds lasts when it is the run's own line)."""
+    import torch
+    what, build, warm_default = OTHER_CONFIGS[kind]
+    scene = build(scenes)
+    dt = float(scene["dt"])
+    warmup = args.warmup if standalone and args.warmup != 10 else warm_default
+    steps = args.steps
+    world = mgf_amd.World.from_scene(ctx, scene)
+    configure(world)
+    world.step_many(dt, args.iters, warmup)
+    snap = world.clone()
+    windows, total = [], 0.0
+    budget = args.min_seconds if standalone else 0.0
+    while not windows or (total < budget and len(windows) < 200):
+        w = snap.clone()
+        configure(w)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        per_tick = w.step_many(dt, args.iters, steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        windows.append((el, _window_stats(per_tick, args.iters), per_tick[len(per_tick) - 1]))
+        total += el
+        del w
+    windows.sort(key=lambda x: x[0])
+    elapsed, (units, cons, launches, kms, phase), last = windows[len(windows) // 2]
+    res = {
+        "value": units / elapsed, "unit": "constraint-iters/s", "ms_per_step": elapsed * 1e3 / steps, "steps": steps, "warmup": warmup,
+        "windows": len(windows), "bodies": len(world), "constraints_per_step": cons / steps, "terrain_constraints_last_tick": int(last["n_terrain_constraints"]),
+        "accepted_pairs_last_tick": int(last["n_pair_candidates"]), "phase_ms_per_step": phase,
+        "gpu_event_ms_reported_window": round(phase["ms_total"] * steps, 3),
+        "roofline": _roofline(units, launches, kms, mode, "all iterations of a tick", (kind, warmup, steps), workload=kind),
+        "store_resorts": world.counter("store_resorts"),
+    }
+    if not standalone:
+        res["workload"] = what
+        return res
+    res.update({"metric": "contact_constraint_iters_per_sec", "n_gpus": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic", "physics_steps_per_sec": steps / elapsed,
+                "config": {"workload": what + f"; ticks {warmup}..{warmup + steps}; {SCENE_NOTE}", "bodies_total": len(world), "iters": args.iters, "dt": dt,
+                           "constraint_order": "canonical (i asc; terrain DFS; partners j<i asc)", "parallelism": "1 GPU"}})
+    return res
 
 
 def order_deviation(ctx, mgf_amd, scene, dt, iters, ticks=(1,)):
@@ -226,6 +297,37 @@ def order_deviation(ctx, mgf_amd, scene, dt, iters, ticks=(1,)):
         dev = max(float(np.max(np.abs(x[f].astype(np.float64) - y[f].astype(np.float64)) / np.maximum(1.0, np.abs(y[f].astype(np.float64))))) for f in ("x", "q", "v", "omega"))
         out[f"after_tick_{target}"] = {"max_rel_deviation": dev, "constraints": int(sa.n_constraints), "same_constraint_count": int(sa.n_constraints) == int(sb.n_constraints)}
     out["note"] = "canonical order (the timed path) vs the reference's world.rs order (option constraint_order = demo); the contract bar is 1e-4"
+    return out
+
+
+def demo_order_cost(ctx, mgf_amd, scenes, scene2, iters):
+    """What choosing the reference's own insertion order costs (option constraint_order = demo: the world BVH of world.rs:233-291 is
+    replayed on the host every tick, single-threaded like the reference): wall ms per tick beside the canonical order's, at 512
+    bodies (BASELINE config 1), the unmodified demo's 1332, and config 2's 262 144."""
+    import torch
+    out = {}
+    cases = (("config1_balls_512", scenes.balls_demo(8), 120, 40), ("demo_balls_1332_iters20", scenes.balls_demo(11, extra_ball=True, iters=20), 120, 40),
+             ("config2_spheres_262144", scene2, 4, 3))
+    for name, sc, warm, ticks in cases:
+        dt, it = float(sc["dt"]), (sc["iters"] if name.startswith("demo") else iters)
+        row = {}
+        for order, key in ((0, "canonical_ms_per_tick"), (1, "demo_order_ms_per_tick")):
+            w = mgf_amd.World.from_scene(ctx, sc)
+            w.set_option("constraint_order", order)
+            for _ in range(warm):
+                w.step(dt, it)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(ticks):
+                st = w.step(dt, it)
+            torch.cuda.synchronize()
+            row[key] = (time.perf_counter() - t0) * 1e3 / ticks
+            row["constraints_last_tick"] = int(st.n_constraints)
+            del w
+        row["ticks_timed"] = ticks
+        out[name] = row
+    out["note"] = ("demo order = the reference's own insertion order, bit-identical to the oracle in world.rs order (tests/test_world_snapshots.py, "
+                   "tests/test_gpu_fullsize.py); its tree replay is serial host work, so its cost grows with the body count")
     return out
 
 
@@ -350,19 +452,22 @@ def _keys(st):
     return [f[0] for f in st._fields_] if hasattr(st, "_fields_") else list(st.keys())
 
 
-def _pmc_traffic(mode, window):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_k_solve_flow*.json),
-    only when they were collected on the window this run timed; else (None, why)."""
-    p = os.path.join(ROOT, "profiles", f"pmc_k_solve_flow{mode}" + ("_settled" if window and window[0] == "settled" else "") + ".json")
+def _pmc_traffic(mode, window, workload="config2"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_*k_solve_flow*.json: one
+    record, or a list of records - one per window the passes were taken on), only for the window this run timed; else (None, why)."""
+    prefix = "pmc_" if workload == "config2" else f"pmc_{workload}_"
+    p = os.path.join(ROOT, "profiles", f"{prefix}k_solve_flow{mode}" + ("_settled" if window and window[0] == "settled" else "") + ".json")
     if not os.path.exists(p):
         return None, "no PMC pass committed for this kernel"
     try:
         d = json.load(open(p))
     except Exception:
         return None, "unreadable PMC summary"
-    if d.get("window") != list(window):
-        return None, f"the committed PMC pass covers window {d.get('window')}, this run {list(window)}"
-    return d.get("hbm_bytes_per_launch"), f"{os.path.relpath(p, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same window)"
+    recs = d if isinstance(d, list) else [d]
+    for r in recs:
+        if r.get("window") == list(window):
+            return r.get("hbm_bytes_per_launch"), f"{os.path.relpath(p, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same window)"
+    return None, f"the committed PMC passes cover windows {[r.get('window') for r in recs]}, this run {list(window)}"
 
 
 def _cpu_model():
@@ -373,6 +478,40 @@ def _cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def run_config3_contact_rich(scenes, O, iters, gpu_ticks=150, cpu_ticks=3, budget_s=14.0):
+    """BASELINE config 3 on one host core from a contact-rich state: the capsules need a couple of hundred ticks to arrive on the
+    heightfield and on each other, which the CPU path cannot afford here - so the GPU carries the scene to tick `gpu_ticks` and the
+    oracle is started from that state (x, q, v, omega, delta: everything World::step reads) for `cpu_ticks` ticks."""
+    import mgf_amd
+    scene = scenes.capsule_field(128, 32, 32, quads=158)
+    dt = float(scene["dt"])
+    ctx = mgf_amd.Context(0)
+    g = mgf_amd.World.from_scene(ctx, scene)
+    g.step_many(dt, iters, gpu_ticks)
+    st = g.state()
+    del g
+    ctx.close()
+    w = O.World(O.ORDER_DEMO)
+    t = scene["terrain"]
+    w.set_terrain(t["verts"], t["faces"], t["pos"])
+    w.add_bodies(scene["comps"], scene["mass"], scene["restitution"], scene["friction"], scene["force"])
+    w.set_state(x=st["x"], q=st["q"], v=st["v"], omega=st["omega"], delta=st["delta"])
+    units, solve_s, done, cons = 0, 0.0, 0, 0
+    t0 = time.perf_counter()
+    for _ in range(cpu_ticks):
+        s1 = w.step(dt, iters)
+        units += s1.n_constraints * iters
+        cons = s1.n_constraints
+        solve_s += s1.t_solve
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    el = time.perf_counter() - t0
+    return {"constraint_iters_per_sec": units / el if el > 0 else None, "physics_steps_per_sec": done / el, "steps": done, "seconds": round(el, 2),
+            "solve_phase_constraint_iters_per_sec": units / solve_s if solve_s > 0 else None, "constraints_last_tick": int(cons),
+            "sample": f"ticks {gpu_ticks}..{gpu_ticks + done} of config 3, started from the GPU path's state at tick {gpu_ticks} (contact-rich), world.rs order"}
 
 
 def cpu_baseline(iters):
@@ -403,13 +542,13 @@ def cpu_baseline(iters):
 
     c2 = run(scenes.sphere_pile(64, 64, 64), 3, 12.0)
     c1 = run(scenes.balls_demo(8), 400, 6.0)
-    c3 = run(scenes.capsule_field(128, 32, 32, quads=158, y0=0.9), 2, 8.0)
+    c3 = run_config3_contact_rich(scenes, O, iters)
     return {"value": c2["constraint_iters_per_sec"], "unit": "constraint-iters/s", "cores": 1, "kind": "port",
             "sample": f"first {c2['steps']} ticks of config 2 (262144 spheres), world.rs order, {c2['seconds']} s of CPU work",
             "physics_steps_per_sec": c2["physics_steps_per_sec"], "solve_phase_constraint_iters_per_sec": c2["solve_phase_constraint_iters_per_sec"],
             "cpu_model": _cpu_model(), "nproc": os.cpu_count(),
             "config1_balls_512": c1, "config3_capsules_131072": c3,
-            "config3_note": "capsule_field(128, 32, 32) at pitch 1.6 over a 158 x 158-quad heightfield (SURVEY 8d names pitch 2.6: a sparser field, fewer contacts)",
+            "config3_note": "capsule_field(128, 32, 32): pitch 2.6 over a 158 x 158-quad heightfield, as SURVEY 8d names it",
             "note": "C++ restatement of mgf (g++ -O2 -ffp-contract=off), not rustc output; the reference is single-threaded"}
 
 

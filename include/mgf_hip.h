@@ -382,6 +382,9 @@ MGF_API mgf_status mgf_rccl_unique_id(void* id128);
 MGF_API mgf_status mgf_tiles_connect(mgf_tiles* t, const void* id128, int32_t rank, int32_t n_ranks);
 MGF_API mgf_status mgf_tiles_preflight(mgf_tiles* t, int32_t* n_ranks_seen);
 MGF_API mgf_status mgf_tiles_step(mgf_tiles* t, float dt, int32_t iters, mgf_step_stats* stats /* n_local, or NULL */);
+/* Options of a tile set.  "test_fail_tick" = the mgf_tiles_step call (0-based) in which this rank fails on purpose in its collide
+ * phase: the protocol's status agreement is then observable (no rank hangs, every rank reports the tick as lost); -1 = never. */
+MGF_API mgf_status mgf_tiles_set_option(mgf_tiles* t, const char* key, int64_t value);
 MGF_API int64_t mgf_tiles_migrated(const mgf_tiles* t, int32_t tile, int32_t direction_in); /* bodies handed over so far */
 /* Options (development and test knobs; defaults in brackets): "time_solver_kernels" [0] HIP events around the
  * solver kernels; "solver_mode" [6] 1 = persistent dataflow launch, 0 = one launch per dependency frontier,

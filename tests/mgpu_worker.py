@@ -1,0 +1,56 @@
+"""One rank of a multi-GPU tile run (tests/test_gpu_multi_device.py): its own process, its own device, its share of the tiles;
+the RCCL id travels from rank 0 through a multiprocessing queue - nothing but the C-ABI (mgf_rccl_unique_id, mgf_tiles_connect,
+mgf_tiles_step) touches the fabric."""
+import os
+import sys
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def run_rank(rank, n_ranks, total_tiles, dims, drift, ticks, fail_rank, fail_tick, uid_q, out_q):
+    try:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import numpy as np
+        import torch  # noqa: F401  (before libmgf_hip.so: see tests/conftest.py)
+        import mgf_amd
+        from mgf_amd import scenes
+        per = total_tiles // n_ranks
+        first = rank * per
+        ctx = mgf_amd.Context(rank)
+        nx, ny, nz = dims
+        tile_scenes = [scenes.sphere_pile_tile(nx, ny, nz, first + k, total_tiles, drift=drift) for k in range(per)]
+        worlds = []
+        for sc in tile_scenes:
+            w = mgf_amd.World.from_scene(ctx, sc)
+            w.set_tags(sc["tags"])
+            worlds.append(w)
+        T = mgf_amd.Tiles(ctx, worlds, [sc["x_range"] for sc in tile_scenes], first_tile=first, n_tiles_total=total_tiles)
+        if rank == 0:
+            uid = mgf_amd.rccl_unique_id()
+            for _ in range(n_ranks - 1):
+                uid_q.put(uid)
+        else:
+            uid = uid_q.get(timeout=120)
+        T.connect(uid, rank, n_ranks)
+        seen = T.preflight()
+        if rank == fail_rank:
+            T.set_option("test_fail_tick", fail_tick)
+        dt, iters = float(tile_scenes[0]["dt"]), tile_scenes[0]["iters"]
+        failed_at, err = None, None
+        for t in range(ticks):
+            try:
+                T.step(dt, iters)
+            except mgf_amd.MgfError as e:
+                failed_at, err = t, str(e)
+                break
+        tiles_out = []
+        if failed_at is None:
+            for k, w in enumerate(worlds):
+                st = w.state()
+                tiles_out.append(dict(tile=first + k, tags=w.tags(), migrated_in=T.migrated(k), **{f: st[f] for f in ("x", "q", "v", "omega", "delta")}))
+        out_q.put(dict(rank=rank, ranks_seen=seen, failed_at=failed_at, error=err, tiles=tiles_out))
+    except Exception:
+        out_q.put(dict(rank=rank, crash=traceback.format_exc()))

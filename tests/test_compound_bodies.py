@@ -144,7 +144,7 @@ def test_hip_dumbbell_field_equals_oracle(ctx, n_plain, mode):
     for tick in range(100):
         sg, so = gw.step(dt, iters), ow.step(dt, iters)
         assert (sg.n_constraints, sg.n_terrain_constraints, sg.n_pair_candidates) == (so.n_constraints, so.n_terrain_constraints, so.n_pair_candidates), f"tick {tick}"
-        if tick % 20 == 19:
+        if tick % 2 == 1:  # (manifolds of several contacts come and go within a few ticks in this small scene)
             got, want = gw.constraints(), ow.constraints()
             compare_constraints(got, want, check_impulse=True)
             ab = list(zip(want["a"].tolist(), want["b"].tolist()))

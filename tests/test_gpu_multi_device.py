@@ -1,0 +1,121 @@
+"""The tile protocol across GPUs: one process per device, ncclSend / ncclRecv over xGMI under the
+C-ABI.  These tests run when the box has at least two devices (the development box has one: they skip there, and the single-device
+half of the status agreement is tested below on any box) - so the first lease of a multi-GPU node proves the path by itself:
+a pile drifting through the tiles, ghost exchange, velocity refreshes and hand-overs, bit-identical to the oracle's tiles; and a
+rank that fails mid-tick takes the whole tick down on every rank instead of leaving its neighbours in a receive."""
+import multiprocessing as mp
+
+import numpy as np
+import pytest
+
+import mgf_amd
+from mgf_amd import scenes
+from tests.util import values_equal
+
+pytestmark = pytest.mark.gpu
+STATE_KEYS = ("x", "q", "v", "omega", "delta")
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _launch(n_ranks, total_tiles, dims, drift, ticks, fail_rank=-1, fail_tick=-1, timeout=600):
+    from tests.mgpu_worker import run_rank
+    mpc = mp.get_context("spawn")
+    uid_q, out_q = mpc.Queue(), mpc.Queue()
+    procs = [mpc.Process(target=run_rank, args=(r, n_ranks, total_tiles, dims, drift, ticks, fail_rank, fail_tick, uid_q, out_q)) for r in range(n_ranks)]
+    for p in procs:
+        p.start()
+    results = {}
+    try:
+        for _ in range(n_ranks):
+            res = out_q.get(timeout=timeout)   # a rank stuck in a receive shows up here as a timeout, not as a hung test run
+            results[res["rank"]] = res
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    for r in range(n_ranks):
+        assert "crash" not in results[r], results[r].get("crash")
+    return results
+
+
+@pytest.mark.parametrize("n_ranks", [2, 4, 8])
+def test_ranks_on_distinct_devices_match_the_oracle_tiles(n_ranks):
+    if _device_count() < n_ranks:
+        pytest.skip(f"needs {n_ranks} devices")
+    from mgf_amd.tiles import Tile, step_tiles_inprocess
+    from tests.oracle_engine import OracleEngine
+    P, dims, drift, ticks = 8, (4, 4, 5), (5.0, 0.0, 0.0), 40
+    res = _launch(n_ranks, P, dims, drift, ticks)
+    tile_scenes = [scenes.sphere_pile_tile(*dims, r, P, drift=drift) for r in range(P)]
+    ot = [Tile(OracleEngine(sc), sc["x_range"], r, P, sc["dt"], sc["iters"]) for r, sc in enumerate(tile_scenes)]
+    for _ in range(ticks):
+        step_tiles_inprocess(ot)
+    got = {}
+    for r in range(n_ranks):
+        assert res[r]["ranks_seen"] == n_ranks and res[r]["failed_at"] is None, res[r]
+        for t in res[r]["tiles"]:
+            got[t["tile"]] = t
+    assert sorted(got) == list(range(P))
+    moved = 0
+    for k in range(P):
+        assert np.array_equal(got[k]["tags"], ot[k].e.tags()), f"tile {k}: body order"
+        so = ot[k].e.state()
+        for f in STATE_KEYS:
+            assert values_equal(got[k][f], so[f]), f"tile {k}: {f}"
+        assert got[k]["migrated_in"] == ot[k].n_migrated_in
+        moved += got[k]["migrated_in"]
+    assert moved > 0  # bodies did change owner across ranks
+
+
+def test_a_failing_rank_takes_the_tick_down_on_every_rank():
+    if _device_count() < 2:
+        pytest.skip("needs 2 devices")
+    n_ranks = 4 if _device_count() >= 4 else 2
+    res = _launch(n_ranks, 8 if n_ranks == 4 else 4, (4, 4, 5), (5.0, 0.0, 0.0), 12, fail_rank=n_ranks - 1, fail_tick=5, timeout=300)
+    for r in range(n_ranks):
+        assert res[r]["failed_at"] == 5, f"rank {r}: {res[r]}"   # nobody hangs, nobody goes on alone
+    assert "halo" in res[n_ranks - 1]["error"]
+    assert all("rank failed" in res[r]["error"] for r in range(n_ranks - 1))
+
+
+# ---- the same agreement inside one process (any box) -------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ctx():
+    c = mgf_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("connected", [False, True])
+def test_a_failed_tick_is_reported_at_its_end_and_moves_nobody(ctx, connected):
+    """Three tiles in one process; the set fails in the collide phase of tick 4 (mgf_tiles_set_option "test_fail_tick"): the call
+    returns the failure after the tick's communication skeleton has run to its end - with a one-rank RCCL communicator too, whose
+    status all-reduce then runs - and no body has changed owner in that tick."""
+    P = 3
+    tile_scenes = [scenes.sphere_pile_tile(4, 4, 5, r, P, drift=(5.0, 0.0, 0.0)) for r in range(P)]
+    worlds = []
+    for sc in tile_scenes:
+        w = mgf_amd.World.from_scene(ctx, sc)
+        w.set_tags(sc["tags"])
+        worlds.append(w)
+    T = mgf_amd.Tiles(ctx, worlds, [sc["x_range"] for sc in tile_scenes])
+    if connected:
+        T.connect(mgf_amd.rccl_unique_id(), 0, 1)
+        assert T.preflight() == 1
+    T.set_option("test_fail_tick", 4)
+    dt, iters = float(tile_scenes[0]["dt"]), tile_scenes[0]["iters"]
+    for _ in range(4):
+        T.step(dt, iters)
+    owned = [len(w) for w in worlds]
+    moved = [T.migrated(r) for r in range(P)]
+    with pytest.raises(mgf_amd.MgfError) as e:
+        T.step(dt, iters)
+    assert "halo" in str(e.value)
+    assert [len(w) for w in worlds] == owned and [T.migrated(r) for r in range(P)] == moved
+    with pytest.raises(mgf_amd.MgfError):
+        T.set_option("no_such_option", 1)
