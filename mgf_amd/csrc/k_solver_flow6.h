@@ -354,6 +354,113 @@ __global__ __launch_bounds__(kBlock) void k_flow6_chan(Flow6 F, uint32_t iters) 
   }
 }
 
+// ---- the same tables for ANY insertion-ordered list (a caller's: mgf_world_set_constraints, mgf_solver_*) ----------------------
+// The tick's own list has structure the kernels above lean on (a body's own constraints are a contiguous id range, the rest of its
+// chain is its row of `b` occurrences).  A caller's list has none: its dependency links come from the generic adjacency build
+// (k_adj_fill + k_chain: successor words and predecessor flags per constraint), and the block tables are derived from those links:
+//   k_flow6g_assign  a constraint belongs to the block of its body a; its slot there is its arrival rank; the block's list of ids;
+//   k_flow6g_blocks  per block: the foreign bodies (LDS hash set, as above), every row's constraint id and body references;
+//   k_flow6g_links   per constraint: its two successor words translated - (block, slot) of the successor, and for a successor in
+//                    another block the channel and the LDS index the carried body has over there - and its predecessor flags.
+// k_flow6_chan and the solve kernel are the same.  Bodies are grouped by `brank` (cell order, or the slots of a re-sorted store).
+__global__ __launch_bounds__(kBlock) void k_flow6g_assign(Flow6 F, ConsLinks K, uint32_t* cslot, uint32_t* clist) {
+  const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= *F.C_ptr) return;
+  const uint32_t g = F.brank[K.ab[c].x] / F.nb;
+  const uint32_t slot = atomicAdd(&F.nslots[(size_t)g * kF6CntStride], 1u);
+  cslot[c] = slot;
+  if (slot < F.rows && slot < kF6MaxSlots) clist[(size_t)g * F.rows + slot] = c;
+  else atomicOr(F.fail, 2u);
+}
+__global__ __launch_bounds__(kF6PrepThreads) void k_flow6g_blocks(Flow6 F, ConsLinks K, const uint32_t* clist) {
+  constexpr uint32_t kBlock = kF6PrepThreads;
+  __shared__ uint32_t s_key[kF6Hash], s_val[kF6Hash];
+  __shared__ uint32_t s_cnt;
+  const uint32_t g = blockIdx.x, t = threadIdx.x;
+  if (*F.C_ptr == 0u) return;
+  for (uint32_t e = t; e < kF6Hash; e += kBlock) { s_key[e] = 0u; s_val[e] = 0u; }
+  if (t == 0) s_cnt = 0u;
+  __syncthreads();
+  const uint32_t total = F.nslots[(size_t)g * kF6CntStride], N = min(min(total, F.rows), kF6MaxSlots);
+  if (t == 0) { atomicMax(F.max_slots, total); if (total > F.slot_cap || total > kF6MaxSlots) atomicOr(F.fail, 2u); }
+  const uint32_t* list = clist + (size_t)g * F.rows;
+  for (uint32_t sl = t; sl < N; sl += kBlock) {  // the foreign bodies among the block's partners
+    const uint32_t b = K.ab[list[sl]].y;
+    if (b == kNone || F.brank[b] / F.nb == g) continue;
+    uint32_t i = (b * 2654435761u) >> 20;
+    for (uint32_t probe = 0; probe < kF6Hash; ++probe, i = (i + 1u) & (kF6Hash - 1u)) {
+      const uint32_t cur = atomicCAS(&s_key[i], 0u, b + 1u);
+      if (cur == 0u || cur == b + 1u) break;
+    }
+  }
+  __syncthreads();
+  for (uint32_t e = t; e < kF6Hash; e += kBlock) {
+    if (s_key[e]) {
+      const uint32_t k = atomicAdd(&s_cnt, 1u);
+      s_val[e] = k;
+      if (k < F.fcap) F.fbody[(size_t)g * F.fcap + k] = s_key[e] - 1u;
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    F.fcnt[(size_t)g * kF6CntStride] = s_cnt;
+    atomicMax(F.max_foreign, s_cnt);
+    if (s_cnt > F.fcap || s_cnt >= kF6Hash / 2u) atomicOr(F.fail, 1u);
+  }
+  for (uint32_t sl = t; sl < N; sl += kBlock) {
+    const uint32_t c = list[sl];
+    const uint2 e = K.ab[c];
+    const uint32_t aref = F.brank[e.x] - g * F.nb;
+    uint32_t bref = kF6NoBody;
+    if (e.y != kNone) {
+      const uint32_t pb = F.brank[e.y];
+      if (pb / F.nb == g) bref = pb - g * F.nb;
+      else {
+        uint32_t i = (e.y * 2654435761u) >> 20;
+        while (s_key[i] != e.y + 1u) i = (i + 1u) & (kF6Hash - 1u);
+        bref = F.nb + s_val[i];
+      }
+      F.bref[c] = bref;
+    }
+    if (aref >= kF6NoBody || (e.y != kNone && bref >= kF6NoBody)) atomicOr(F.fail, 16u);
+    uint4* dst = reinterpret_cast<uint4*>(&F.table[(size_t)g * F.rows + sl]);
+    dst[0] = make_uint4(c, aref | (min(bref, kF6NoBody) << kF6BodyBits), 0u, 0u);  // (the successor words: k_flow6g_links)
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_flow6g_links(Flow6 F, ConsLinks K, const uint32_t* cslot) {
+  const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= *F.C_ptr) return;
+  const uint2 e = K.ab[c];
+  const uint32_t g = F.brank[e.x] / F.nb, sl = cslot[c];
+  if (sl >= F.rows || sl >= kF6MaxSlots) return;  // (fail bit 2 is up)
+  const uint2 sw = K.succ[c];
+  uint32_t out[2] = {0u, 0u};
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    if (side == 1 && e.y == kNone) break;
+    const uint32_t w = side == 0 ? sw.x : sw.y, body = side == 0 ? e.x : e.y;
+    const uint32_t wid = w & kSuccId, wrap = (w & kSuccWrap) ? kF6Wrap : 0u;
+    const uint2 we = K.ab[wid];
+    const uint32_t hw = F.brank[we.x] / F.nb, ws = cslot[wid];
+    if (hw == g) { out[side] = wrap | ws; }
+    else {  // a message on the channel g -> hw, addressed to the body's LDS slot over there
+      const uint32_t dbody = we.x == body ? F.brank[body] - hw * F.nb : F.bref[wid];
+      uint32_t* ik = F.in_key + (size_t)hw * kF6Chan;
+      uint32_t* ok = F.out_key + (size_t)g * kF6Chan;
+      const uint32_t k_in = f6_chan_slot(ik, g + 1u, F.fail), k_out = f6_chan_slot(ok, hw + 1u, F.fail);
+      atomicAdd(&F.in_cnt[(size_t)hw * kF6Chan + k_in], 1u);
+      F.out_val[(size_t)g * kF6Chan + k_out] = k_in;
+      if (ws >= kF6MaxSlots || dbody >= kF6NoBody) atomicOr(F.fail, 16u);
+      out[side] = kF6Remote | wrap | (k_out << 24) | (dbody << kF6SlotBits) | ws;
+    }
+    // the body's chain ends here, in a block that is not its own: this block writes its result, its own does not
+    if (side == 1 && wrap && F.brank[body] / F.nb != g) F.skipwb[body] = 1;
+  }
+  uint32_t* row = reinterpret_cast<uint32_t*>(&F.table[(size_t)g * F.rows + sl]);
+  row[2] = out[0]; row[3] = out[1];
+  row[4] = K.pred[2 * c]; row[5] = e.y != kNone ? K.pred[2 * c + 1] : 0u; row[6] = 0u; row[7] = 0u;
+}
+
 // ---- the solve ------------------------------------------------------------------------------------------------------------
 struct F6Ring { uint16_t* ring; uint32_t* head; uint32_t* tail; uint32_t cap, magic; };
 __device__ __forceinline__ uint32_t f6_wrap(const F6Ring& q, uint32_t pos) {  // pos % cap for pos < cap * kF6MaxIters
