@@ -216,7 +216,7 @@ MGF_API mgf_status mgf_world_add_bodies(mgf_world* w, const mgf_component* comps
                                         uint64_t* first_id);
 /* Bodies of several components (BASELINE config 5).  NOT in the reference - physics.rs:200 takes one Component - so the
  * definition is this build's (oracle: RigidBodyVec::add_compound_body): body b is made of comps[offsets[b] ..
- * offsets[b + 1]) (1..2 components, world coordinates at creation) with masses comp_mass[..]; mass = sum, x = centre of
+ * offsets[b + 1]) (1..4 components, world coordinates at creation; bodies of more than two do not cross tiles: mgf_tiles_create refuses their worlds) with masses comp_mass[..]; mass = sum, x = centre of
  * mass, q = identity, inertia = sum of the components' tensors about the centre of mass (the reference's Inertia,
  * physics.rs:30-93); the parts are fixed in the body frame and rebuilt from (x, q) every tick like a single collider
  * (physics.rs:243-251).  Contacts: every pair of parts (Contacts, compound.rs:180-190), local points relative to the

@@ -1296,19 +1296,26 @@ __global__ __launch_bounds__(kBlock) void k_rows_to_csr(const StepCounts* sc, ui
     // row (ranks are distinct) - and is named.  The wave takes its 64 bodies one after the other with a lane per ENTRY: the row is
     // read, and the list written, by consecutive lanes (a thread walking its own row touched a 64-byte sector per entry and array:
     // 105 us on 131 072 capsules over a heightfield).
-    const int lane = threadIdx.x & 63;
-    for (int sft = 0; sft < 64; ++sft) {
-      const uint32_t bi = __shfl(i, sft), bnt = __shfl(ok ? nt : 0u, sft), btb = __shfl(tb, sft);
-      if (bnt == 0u) continue;
+    // (round 3: sixteen lanes per body, four bodies at a time - a wave whose 64 bodies all lie on the floor, which is what a store
+    // in cell order gives, used to walk them one after the other with a third of its lanes: 38 -> 73 us on config 3)
+    const int lane = threadIdx.x & 63, sl = lane & 15;
+    for (int sft = 0; sft < 16; ++sft) {
+      const int src = (lane >> 4) * 16 + sft;                 // this group's body of the step: lane src of the wave holds it
+      const uint32_t bi = __shfl(i, src), bnt = __shfl(ok ? nt : 0u, src), btb = __shfl(tb, src);
+      // (groups whose body has no row idle through the shuffles below with bnt = 0: the loops do not run)
       const uint32_t* brow = rows_t + (size_t)bi * cap_row_t;
-      for (uint32_t e0 = 0; e0 < bnt; e0 += 64u) {
-        const uint32_t e = e0 + (uint32_t)lane;
+      for (uint32_t e0 = 0; e0 < bnt; e0 += 16u) {
+        const uint32_t e = e0 + (uint32_t)sl;
         const uint32_t x = e < bnt ? brow[e] : 0xFFFFFFFFu;
         uint32_t before = 0;
-        for (uint32_t c0 = 0; c0 < bnt; c0 += 64u) {  // (rows longer than a wave: the other chunks are read again)
-          const uint32_t y = c0 == e0 ? x : (c0 + (uint32_t)lane < bnt ? brow[c0 + (uint32_t)lane] : 0xFFFFFFFFu);
-          const uint32_t m = min(bnt - c0, 64u);
-          for (uint32_t k = 0; k < m; ++k) before += __shfl(y, (int)k) < x ? 1u : 0u;
+        for (uint32_t c0 = 0; c0 < bnt; c0 += 16u) {  // (rows longer than a group: the other chunks are read again)
+          const uint32_t y = c0 == e0 ? x : (c0 + (uint32_t)sl < bnt ? brow[c0 + (uint32_t)sl] : 0xFFFFFFFFu);
+          const uint32_t m = min(bnt - c0, 16u);
+          // lane k of the group's row of sixteen, to all of them: a DPP row_share (no LDS round trip, unlike a shuffle by a lane-dependent index)
+#define MGF_ROW_SHARE(K) { const uint32_t yk = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0x150 + (K), 0xF, 0xF, false); before += ((K) < m && yk < x) ? 1u : 0u; }
+          MGF_ROW_SHARE(0) MGF_ROW_SHARE(1) MGF_ROW_SHARE(2) MGF_ROW_SHARE(3) MGF_ROW_SHARE(4) MGF_ROW_SHARE(5) MGF_ROW_SHARE(6) MGF_ROW_SHARE(7)
+          MGF_ROW_SHARE(8) MGF_ROW_SHARE(9) MGF_ROW_SHARE(10) MGF_ROW_SHARE(11) MGF_ROW_SHARE(12) MGF_ROW_SHARE(13) MGF_ROW_SHARE(14) MGF_ROW_SHARE(15)
+#undef MGF_ROW_SHARE
         }
         if (e < bnt) { t_cand[btb + before] = face_of_rank[x]; t_owner[btb + before] = bi; }
       }

@@ -91,20 +91,26 @@ __global__ __launch_bounds__(kBlock) void k_narrow_terrain(Bodies B, TerrainDev 
 // (manifold.rs:72-102), Manifold::from(pruner) (:131-148).  An ordinary body is a body of one part (its collider), so
 // these kernels serve mixed worlds too.  At most kMaxParts^2 = 4 contacts per pair (every part pair emits <= 1).
 constexpr float kPersistentThresholdSq = 0.5f;  // manifold.rs:38
-constexpr int kPairContacts = kMaxParts * kMaxParts;
-constexpr int kTerrainContacts = 2 * kMaxParts;  // per (body, face): a capsule part emits up to 2
-__device__ __forceinline__ int load_parts(const Bodies& B, uint32_t i, Comp out[kMaxParts], V3* centre) {
+// MP = the most parts any body of the world has (2 or 4: the kernels are instantiated for both, so that a world of two-part bodies
+// does not carry the registers of sixteen part pairs): a pair of bodies yields at most MP * MP contacts, a (body, face) 2 * MP.
+template <int MP>
+__device__ __forceinline__ int load_parts(const Bodies& B, uint32_t i, Comp out[MP], V3* centre) {
   const uint32_t pc = B.pcount ? B.pcount[i] : 0u;
   if (pc == 0) { out[0] = load_comp(B, i); *centre = comp_center(out[0]); return 1; }
-  for (uint32_t k = 0; k < pc; ++k) {
-    float4 a = B.wp0[kMaxParts * i + k], b = B.wp1[kMaxParts * i + k];
-    out[k].kind = (int)f2u(b.w); out[k].p = xyz(a); out[k].r = a.w; out[k].d = xyz(b);
+#pragma unroll
+  for (int k = 0; k < MP; ++k) {
+    if ((uint32_t)k < pc) {
+      float4 a = B.wp0[kMaxParts * i + k], b = B.wp1[kMaxParts * i + k];
+      out[k].kind = (int)f2u(b.w); out[k].p = xyz(a); out[k].r = a.w; out[k].d = xyz(b);
+    }
   }
   *centre = xyz(B.col0[i]);  // the carrier: the body's centre of mass
-  return (int)pc;
+  return (int)min(pc, (uint32_t)MP);
 }
+template <int MP>
 __global__ __launch_bounds__(kBlock) void k_narrow_pairs_parts(Bodies B, const uint32_t* m_ptr, const uint32_t* p_owner, const uint32_t* p_cand,
-                                                               uint32_t* p_nc, NContact* p_out /* kPairContacts per candidate */) {
+                                                               uint32_t* p_nc, NContact* p_out /* MP * MP per candidate */) {
+  constexpr int kPairContacts = MP * MP;
   // The candidate was accepted on i's tight box against j's FAT box (bvh.rs:297), which is the larger by the margin and by every
   // tick since j's last refit.  A contact is a touching of two parts somewhere inside both bodies' TIGHT swept boxes of this
   // tick, so if those do not overlap (a millimetre and 1e-5 of the coordinates allowed for rounding) no part pair reports
@@ -135,9 +141,9 @@ __global__ __launch_bounds__(kBlock) void k_narrow_pairs_parts(Bodies B, const u
   if (threadIdx.x >= s_n) return;
   const uint32_t p = s_list[threadIdx.x];
   const uint32_t i = p_owner[p], j = p_cand[p];
-  Comp Pa[kMaxParts], Pb[kMaxParts];
+  Comp Pa[MP], Pb[MP];
   V3 ci, cj;
-  const int na = load_parts(B, i, Pa, &ci), nb = load_parts(B, j, Pb, &cj);
+  const int na = load_parts<MP>(B, i, Pa, &ci), nb = load_parts<MP>(B, j, Pb, &cj);
   const V3 vA = xyz(B.delta[i]), vB = xyz(B.delta[j]);
   float min_t = kInf;
   int cnt = 0;
@@ -173,15 +179,17 @@ __global__ __launch_bounds__(kBlock) void k_narrow_pairs_parts(Bodies B, const u
 }
 // Terrain: per face (the candidate list is in the mesh's DFS order) the body's parts in order; every contact is its own
 // constraint (world.rs:243-251).
+template <int MP>
 __global__ __launch_bounds__(kBlock) void k_narrow_terrain_parts(Bodies B, TerrainDev M, const uint32_t* m_ptr, const uint32_t* t_owner,
                                                                  const uint32_t* t_cand, uint32_t* t_nc,
-                                                                 NContact* t_out /* kTerrainContacts per candidate */) {
+                                                                 NContact* t_out /* 2 * MP per candidate */) {
+  constexpr int kTerrainContacts = 2 * MP;  // per (body, face): a capsule part emits up to 2
   uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= *m_ptr) return;
   const uint32_t i = t_owner[p], f = t_cand[p];
-  Comp Pa[kMaxParts];
+  Comp Pa[MP];
   V3 ci;
-  const int na = load_parts(B, i, Pa, &ci);
+  const int na = load_parts<MP>(B, i, Pa, &ci);
   const V3 vA = xyz(B.delta[i]);
   uint4 fi = M.faces[f];
   V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint3
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (nc[k]) {
-        if (h < (uint32_t)kHitCap) { s_j[h][tid] = order_id(ext, p_cand[base + k]); s_p[h][tid] = (base + k) | (nc[k] << 28); }
+        if (h < (uint32_t)kHitCap) { s_j[h][tid] = order_id(ext, p_cand[base + k]); s_p[h][tid] = (base + k) | (nc[k] << 27); }
         ++h;
         total += nc[k];
       }
@@ -275,8 +283,8 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint3
       const uint32_t j = s_j[a][tid];
       uint32_t before = 0;
       // a partner's contacts (1, or up to 4 for bodies of several parts); keep_order: the list IS the insertion order (world.rs order)
-      for (uint32_t q = 0; q < h; ++q) before += (keep_order ? q < a : s_j[q][tid] < j) ? (s_p[q][tid] >> 28) : 0u;
-      p_pre[s_p[a][tid] & 0x0FFFFFFFu] = run + before;
+      for (uint32_t q = 0; q < h; ++q) before += (keep_order ? q < a : s_j[q][tid] < j) ? (s_p[q][tid] >> 27) : 0u;
+      p_pre[s_p[a][tid] & 0x07FFFFFFu] = run + before;  // (5 bits of contact count - up to 16 for bodies of four parts - above a 27-bit list position)
     }
   } else {  // a crowded body: the same by rescanning its list
     for (uint32_t p = lo; p < hi; ++p) {

@@ -88,6 +88,7 @@ struct Flow6 {
   uint32_t rows;             // table rows per block
   uint32_t fcap, slot_cap;   // LDS split of this launch: foreign body slots, constraint slots
   uint32_t poll_waves, poll_k;  // waves that poll the incoming channels; (unused)
+  uint32_t poll_prio;           // s_setprio of the polling waves (0..3): their few instructions issue ahead of the serving waves'
 };
 __host__ __device__ constexpr uint32_t f6_slot_bytes(bool nimp_lds) { return nimp_lds ? 22u : 18u; }  // successor words 8, id 4, state 4, ring 2 (+ impulse 4)
 __host__ __device__ constexpr uint32_t f6_lds_bytes(uint32_t nb, uint32_t fcap, uint32_t slot_cap, bool const_lds = false, bool nimp_lds = false) {
@@ -585,6 +586,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
     const unsigned long long* tail_ptr = F.tails + (size_t)g * kF6Chan + (owner ? s_in_slot[ch] : 0u);
     uint32_t* wl_cnt = s_wl_cnt + pw;
     uint16_t* wl = s_wl + pw * kF6WlLen;
+    if (F.poll_prio == 1u) __builtin_amdgcn_s_setprio(1); else if (F.poll_prio == 2u) __builtin_amdgcn_s_setprio(2); else if (F.poll_prio >= 3u) __builtin_amdgcn_s_setprio(3);
     uint32_t head = 0, mask = 0, known = 0;
     uint32_t st_sweeps = 0, st_hits = 0, st_lat_sum = 0, st_lat_max = 0, st_full = 0, st_wait = 0;  // TRACE: polling statistics
     if (lane == 0) __hip_atomic_store(wl_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

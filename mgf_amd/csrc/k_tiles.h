@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void k_export_bodies(Bodies B, const uint32
   o[34] = e.w; o[35] = d.w;
   const uint32_t pc = B.pcount ? B.pcount[i] : 0u;
   o[36] = u2f(pc); o[37] = o[38] = o[39] = 0.0f;
-  for (uint32_t k = 0; k < (uint32_t)kMaxParts; ++k) {
+  for (uint32_t k = 0; k < (uint32_t)kTileParts; ++k) {
     float4 a = make_float4(0, 0, 0, 0), b = a;
     if (k < pc) { a = B.wp0[kMaxParts * i + k]; b = B.wp1[kMaxParts * i + k]; }
     float* q8 = o + 40 + 8 * k;
@@ -71,12 +71,13 @@ __device__ __forceinline__ void import_ghost(Bodies B, uint32_t i, const float* 
   B.col1[i] = mk4(k.d, o[16]);
   if (B.bpk) { B.bpk[4 * i] = mk4(k.p, k.r); B.bpk[4 * i + 1] = mk4(d, o[35]); B.bpk[4 * i + 2] = mk4(x + d, o[34]); B.bpk[4 * i + 3] = mk4(k.d, o[16]); }
   Box tb = swept_bounds(k, d);
-  const uint32_t pc = min(f2u(o[36]), (uint32_t)kMaxParts);
+  const uint32_t pc = min(f2u(o[36]), (uint32_t)kTileParts);
   if (B.pcount) {
     B.pcount[i] = pc;
     for (uint32_t pk = 0; pk < (uint32_t)kMaxParts; ++pk) {  // a ghost is never integrated here: its world parts are all that matters
-      const float* q8 = o + 40 + 8 * pk;
-      float4 a = make_float4(q8[0], q8[1], q8[2], q8[3]), b = make_float4(q8[4], q8[5], q8[6], q8[7]);
+      const float* q8 = o + 40 + 8 * min(pk, (uint32_t)kTileParts - 1u);
+      float4 a = make_float4(0, 0, 0, 0), b = a;
+      if (pk < (uint32_t)kTileParts) { a = make_float4(q8[0], q8[1], q8[2], q8[3]); b = make_float4(q8[4], q8[5], q8[6], q8[7]); }
       B.wp0[kMaxParts * i + pk] = a; B.wp1[kMaxParts * i + pk] = b;
       B.lp0[kMaxParts * i + pk] = a; B.lp1[kMaxParts * i + pk] = b;
       if (pk < pc) {
@@ -124,8 +125,9 @@ __global__ __launch_bounds__(kBlock) void k_import_ghost_vel(float4* srec, uint3
 // ---- migration of owned bodies between tiles -----------------------------------------------------
 // A migrant record is the body's row of every Bodies array, verbatim (kMigrantWords float4 = 116 floats): the
 // receiving tile continues bit-identically, persistent fat box and constructor tag (ctor.w) included.
-constexpr int kMigrantWords = 29;  // 20 words of the ordinary arrays + part count + 2 slots of each of the four part arrays
-__device__ __forceinline__ float4* body_word(const Bodies& B, uint32_t e, uint32_t i) {
+constexpr int kMigrantWords = 21 + 4 * kTileParts;  // the tile protocol's record: 20 words of the ordinary arrays + part count + kTileParts slots of each of the four part arrays
+constexpr int kBodyWords = 21 + 4 * kMaxParts;      // a body's whole row (internal moves: re-sorting the store, compaction): every part slot
+__device__ __forceinline__ float4* body_word(const Bodies& B, uint32_t e, uint32_t i) {  // e < 20: the ordinary arrays
   switch (e) {
     case 0: return B.x + i;
     case 1: return B.q + i;
@@ -141,25 +143,31 @@ __device__ __forceinline__ float4* body_word(const Bodies& B, uint32_t e, uint32
     case 16: return B.tb_c + i;
     case 17: return B.tb_r + i;
     case 18: return B.fb_c + i;
-    case 19: return B.fb_r + i;
-    case 21: case 22: return B.lp0 + (size_t)kMaxParts * i + (e - 21);
-    case 23: case 24: return B.lp1 + (size_t)kMaxParts * i + (e - 23);
-    case 25: case 26: return B.wp0 + (size_t)kMaxParts * i + (e - 25);
-    default: return B.wp1 + (size_t)kMaxParts * i + (e - 27);
+    default: return B.fb_r + i;
   }
 }
-// words 20.. exist only in worlds that hold bodies of several parts (elsewhere they read as zeros and writes are dropped)
-__device__ __forceinline__ float4 migrant_get(const Bodies& B, uint32_t e, uint32_t i) {
+__device__ __forceinline__ float4* part_word(const Bodies& B, uint32_t arr, uint32_t slot, uint32_t i) {
+  float4* base = arr == 0 ? B.lp0 : (arr == 1 ? B.lp1 : (arr == 2 ? B.wp0 : B.wp1));
+  return base + (size_t)kMaxParts * i + slot;
+}
+// Word e of a record with `slots` part slots per array (kTileParts: a tile record; kMaxParts: a whole row): 0..19 ordinary, 20 the
+// part count, then `slots` words of lp0, lp1, wp0, wp1.  Words 20.. exist only in worlds that hold bodies of several parts
+// (elsewhere they read as zeros and writes are dropped); part slots a record does not carry are cleared on the way in.
+__device__ __forceinline__ float4 migrant_get(const Bodies& B, uint32_t e, uint32_t i, uint32_t slots) {
   if (e < 20u) return *body_word(B, e, i);
   if (!B.pcount) return make_float4(0, 0, 0, 0);
   if (e == 20u) return make_float4(u2f(B.pcount[i]), 0, 0, 0);
-  return *body_word(B, e, i);
+  const uint32_t k = e - 21u;
+  return *part_word(B, k / slots, k % slots, i);
 }
-__device__ __forceinline__ void migrant_put(const Bodies& B, uint32_t e, uint32_t i, float4 v) {
+__device__ __forceinline__ void migrant_put(const Bodies& B, uint32_t e, uint32_t i, float4 v, uint32_t slots) {
   if (e < 20u) { *body_word(B, e, i) = v; return; }
   if (!B.pcount) return;
   if (e == 20u) { B.pcount[i] = f2u(v.x); return; }
-  *body_word(B, e, i) = v;
+  const uint32_t k = e - 21u, arr = k / slots, slot = k % slots;
+  *part_word(B, arr, slot, i) = v;
+  if (slots < (uint32_t)kMaxParts && slot + 1u == slots)
+    for (uint32_t z = slots; z < (uint32_t)kMaxParts; ++z) *part_word(B, arr, z, i) = make_float4(0, 0, 0, 0);
 }
 // cnt[0] / cnt[1] += owned bodies whose centre lies below x_lo / at or above x_hi (the slab is [x_lo, x_hi))
 __global__ __launch_bounds__(kBlock) void k_migrant_count(Bodies B, uint32_t n_owned, float x_lo, float x_hi, uint32_t* cnt) {
@@ -180,17 +188,20 @@ __global__ __launch_bounds__(kBlock) void k_migrant_flags(Bodies B, uint32_t n_o
   }
   fl[i] = l; fr[i] = r;
 }
-__global__ __launch_bounds__(kBlock) void k_export_migrants(Bodies B, const uint32_t* ids, uint32_t m, float4* out) {
+// `slots` part slots per array in the records: kTileParts (words = kMigrantWords: the tile protocol) or kMaxParts (words = kBodyWords)
+__global__ __launch_bounds__(kBlock) void k_export_migrants(Bodies B, const uint32_t* ids, uint32_t m, float4* out, uint32_t slots) {
+  const uint32_t words = 21u + 4u * slots;
   uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= m * kMigrantWords) return;
-  uint32_t b = t / kMigrantWords, e = t % kMigrantWords;
-  out[t] = migrant_get(B, e, ids[b]);
+  if (t >= m * words) return;
+  uint32_t b = t / words, e = t % words;
+  out[t] = migrant_get(B, e, ids[b], slots);
 }
-__global__ __launch_bounds__(kBlock) void k_import_migrants(Bodies B, uint32_t base, uint32_t m, const float4* in) {
+__global__ __launch_bounds__(kBlock) void k_import_migrants(Bodies B, uint32_t base, uint32_t m, const float4* in, uint32_t slots) {
+  const uint32_t words = 21u + 4u * slots;
   uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= m * kMigrantWords) return;
-  uint32_t b = t / kMigrantWords, e = t % kMigrantWords;
-  migrant_put(B, e, base + b, in[t]);
+  if (t >= m * words) return;
+  uint32_t b = t / words, e = t % words;
+  migrant_put(B, e, base + b, in[t], slots);
 }
 // keep[i] = 1 for i < n, keep[n] = 0 (scan total); then the listed bodies are cleared
 __global__ __launch_bounds__(kBlock) void k_keep_fill(uint32_t* keep, uint32_t n) {
@@ -206,9 +217,9 @@ __global__ __launch_bounds__(kBlock) void k_keep_clear(uint32_t* keep, const uin
 // stable compaction through a scratch copy: tmp[pos[i]] = row i for kept bodies, then rows [0, n_new) = tmp
 __global__ __launch_bounds__(kBlock) void k_compact_gather(Bodies B, uint32_t n, const uint32_t* keep, const uint32_t* pos, float4* tmp) {
   uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= n * kMigrantWords) return;
-  uint32_t i = t / kMigrantWords, e = t % kMigrantWords;
-  if (keep[i]) tmp[(size_t)pos[i] * kMigrantWords + e] = migrant_get(B, e, i);
+  if (t >= n * kBodyWords) return;
+  uint32_t i = t / kBodyWords, e = t % kBodyWords;
+  if (keep[i]) tmp[(size_t)pos[i] * kBodyWords + e] = migrant_get(B, e, i, kMaxParts);
 }
 // ---- the body store in an internal order (host_perm.inc) ----------------------------------------------------------
 // Slot k of the new order takes the row of old slot order[k] - the body's row of every Bodies array, verbatim, like a
@@ -217,12 +228,12 @@ __global__ __launch_bounds__(kBlock) void k_compact_gather(Bodies B, uint32_t n,
 __global__ __launch_bounds__(kBlock) void k_permute_gather(Bodies B, uint32_t n, const uint32_t* order, float4* tmp) {
   const uint32_t k = blockIdx.x * kBlock + threadIdx.x, e = blockIdx.y;
   if (k >= n) return;
-  tmp[(size_t)e * n + k] = migrant_get(B, e, order[k]);
+  tmp[(size_t)e * n + k] = migrant_get(B, e, order[k], kMaxParts);
 }
 __global__ __launch_bounds__(kBlock) void k_permute_put(Bodies B, uint32_t n, const float4* tmp) {
   const uint32_t k = blockIdx.x * kBlock + threadIdx.x, e = blockIdx.y;
   if (k >= n) return;
-  migrant_put(B, e, k, tmp[(size_t)e * n + k]);
+  migrant_put(B, e, k, tmp[(size_t)e * n + k], kMaxParts);
 }
 // ---- the order of a re-sort: compact blocks (host_perm.inc, partition_order) ------------------------------------------
 // Sort keys of one level of the three-level split (x slabs, y rows inside a slab, z inside a row): the unit the body fell into at
