@@ -32,11 +32,16 @@ SCENES = {
 }
 
 
+KERNELS = [1]  # option pair_brick: 1 = k_pair_brick (the cell walk in LDS)
+
+
+@pytest.mark.parametrize("kern", KERNELS)
 @pytest.mark.parametrize("name", sorted(SCENES))
-def test_brick_and_grid_list_the_same_partners(ctx, name):
+def test_brick_and_grid_list_the_same_partners(ctx, name, kern):
     scene = SCENES[name]()
     dt, iters = float(scene["dt"]), scene["iters"]
     a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
+    a.set_option("pair_brick", kern)
     b.set_option("pair_brick", 0)
     ow = oracle_world(scene)
     for tick in range(30):
@@ -57,7 +62,8 @@ def _with_extra(scene, centres, radii):
     return scenes._scene(scene["name"] + "_extra", comps, scene["terrain"], v0=v0)
 
 
-def test_a_body_much_larger_than_a_cell_goes_through_global_memory(ctx):
+@pytest.mark.parametrize("kern", KERNELS)
+def test_a_body_much_larger_than_a_cell_goes_through_global_memory(ctx, kern):
     """One sphere of radius 2 in a pile of radius-0.5 spheres: the largest fat half extent grows every query's region to 5-7 cells
     per axis; those that no longer fit the staged box are answered by the one-lane global path - same partners, same result as the oracle -
     and the world switches back to k_pair_grid for the ticks that follow."""
@@ -65,6 +71,7 @@ def test_a_body_much_larger_than_a_cell_goes_through_global_memory(ctx):
     scene = _with_extra(base, [(0.0, 13.5, 0.0)], [2.0])
     dt, iters = float(scene["dt"]), scene["iters"]
     a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
+    a.set_option("pair_brick", kern)
     b.set_option("pair_brick", 0)
     ow = oracle_world(scene)
     sa, sb, so = a.step(dt, iters), b.step(dt, iters), ow.step(dt, iters)
@@ -81,7 +88,8 @@ def test_a_body_much_larger_than_a_cell_goes_through_global_memory(ctx):
         assert bits_equal(a.state()[k], so_state[k]), k
 
 
-def test_a_box_with_more_records_than_the_lds_copy_holds(ctx):
+@pytest.mark.parametrize("kern", KERNELS)
+def test_a_box_with_more_records_than_the_lds_copy_holds(ctx, kern):
     """A clump of 2500 small spheres and a few bodies far away (they stretch the scene bounds, so the cells are large and the
     clump sits in a handful of them): the bricks around the clump cannot stage their boxes and answer from global memory."""
     rng = np.random.default_rng(5)
@@ -95,6 +103,7 @@ def test_a_box_with_more_records_than_the_lds_copy_holds(ctx):
     scene = scenes._scene("clump", comps, scenes.box_terrain(70.0, 50.0, (0, 0, 0)), v0=np.zeros((len(centres), 3), np.float32))
     dt, iters = float(scene["dt"]), 4
     a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
+    a.set_option("pair_brick", kern)
     b.set_option("pair_brick", 0)
     ow = oracle_world(scene)
     for tick in range(3):
