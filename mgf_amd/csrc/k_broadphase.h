@@ -55,8 +55,24 @@ __device__ __forceinline__ void grid_box(const SceneBounds* sb, float min_frac, 
 // downstream depends on it - candidate rows are sorted by body index before they are used.
 // `axis_bits` (the static mesh's face grid): when not all zero the cells are ROW-MAJOR with that many bits per axis instead of
 // Morton prefixes - a flat mesh gives its thin axis no bits at all (see build_face_grid).
+// `sb_part` (the fused tick: this tick's k_integrate gathered the scene bounds into partial records and nothing has folded them
+// yet): every block folds them for itself - 64 x 9 words that sit in L2 - and block 0 also writes the result to *sb_out, where the
+// kernels behind the scan and the tick's read-back find it.  Null: *sb is final.
 __global__ __launch_bounds__(kBlock) void k_morton_count(const float4* fb_c, uint32_t n, const SceneBounds* sb, int shift, uint32_t* cell_of,
-                                                         uint32_t* rank, uint32_t* cell_cnt, float min_frac, uint3 axis_bits) {
+                                                         uint32_t* rank, uint32_t* cell_cnt, float min_frac, uint3 axis_bits,
+                                                         const int* sb_part = nullptr, SceneBounds* sb_out = nullptr) {
+  __shared__ SceneBounds s_sb;
+  if (sb_part) {
+    if (threadIdx.x < 9) {
+      const int k = threadIdx.x;
+      int v = sb_part[k];
+      for (int a = 1; a < kBoundSlots; ++a) { const int u = sb_part[(size_t)a * kBoundSlotInts + k]; v = k < 3 ? min(v, u) : max(v, u); }
+      if (k < 3) s_sb.lo[k] = v; else if (k < 6) s_sb.hi[k - 3] = v; else s_sb.rmax[k - 6] = v;
+      if (blockIdx.x == 0) { if (k < 3) sb_out->lo[k] = v; else if (k < 6) sb_out->hi[k - 3] = v; else sb_out->rmax[k - 6] = v; }
+    }
+    __syncthreads();
+    sb = &s_sb;
+  }
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   V3 c = xyz(fb_c[i]);
@@ -84,6 +100,35 @@ __global__ __launch_bounds__(kBlock) void k_zero_many(ZeroList z) {
     int v = z.sb_part[k];
     for (int a = 1; a < kBoundSlots; ++a) { int u = z.sb_part[(size_t)a * kBoundSlotInts + k]; v = k < 3 ? min(v, u) : max(v, u); }
     if (k < 3) z.sb->lo[k] = v; else if (k < 6) z.sb->hi[k - 3] = v; else z.sb->rmax[k - 6] = v;
+  }
+  for (int a = 0; a < kZeroSlots; ++a) {
+    uint32_t* p = z.p[a];
+    if (!p) continue;
+    for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < z.words[a]; e += gridDim.x * kBlock) p[e] = 0u;
+  }
+}
+
+// The fused tick's first launch: k_reset_step and k_zero_many in one, AHEAD of k_integrate (round 3: a launch less per tick).
+// Nothing it clears is read by k_integrate; what k_integrate's tail writes (the owned bodies' terrain counts, the row-overflow flag)
+// it writes afterwards.  The partial scene bounds are folded by k_morton_count instead.
+__global__ __launch_bounds__(kBlock) void k_tick_clear(ZeroList z, SceneBounds* sb, uint32_t* err, uint32_t* guard, const uint32_t* prev_fail, int spec,
+                                                       int* sb_part) {
+  // (see k_reset_step: a speculative tick behind a failed one raises the guard and resets nothing - but the counters are cleared all
+  // the same: the kernels of the cell sort run unguarded, on the unchanged bodies, and must start from zero)
+  const bool skip = spec && *prev_fail;
+  if (skip && blockIdx.x == 0 && threadIdx.x == 0) *guard = 1u;
+  if (blockIdx.x == 0 && !skip) {
+    if (sb_part && threadIdx.x < kBoundSlots) {
+      int* slot = sb_part + (size_t)threadIdx.x * kBoundSlotInts;
+      for (int k = 0; k < 3; ++k) { slot[k] = 0x7FFFFFFF; slot[3 + k] = (int)0x80000000; slot[6 + k] = 0; }
+    }
+    if (threadIdx.x == 0) {
+      *guard = 0u;
+      for (int k = 0; k < 3; ++k) { sb->lo[k] = 0x7FFFFFFF; sb->hi[k] = (int)0x80000000; }
+      sb->n_refits = 0; sb->pad = 0; sb->pad2 = 0;
+      for (int k = 0; k < 3; ++k) sb->rmax[k] = 0;
+      err[0] = 0; err[1] = 0; err[8] = 0;
+    }
   }
   for (int a = 0; a < kZeroSlots; ++a) {
     uint32_t* p = z.p[a];
