@@ -302,6 +302,87 @@ __global__ __launch_bounds__(kBlock) void k_count_contacts(StepCounts* sc, uint3
   if (tid == 0 && s_ct) atomicAdd(&sc->ct_sum, s_ct);
 }
 
+// A world of spheres over a small mesh (the headline workload; the fused broadphase has listed CONTACTS, the terrain rows hold face
+// ids in the mesh's DFS order): k_rows_to_csr, k_narrow_terrain<0> and k_count_contacts in one launch, a thread per body (round 3:
+// two launches less per tick).  The body's terrain row goes to the candidate list and through the sphere-triangle test on the way;
+// its partner row goes to the list and is ranked by the partners' order ids; the body's constraint count follows.
+__global__ __launch_bounds__(kBlock) void k_lists_spheres(Bodies B, TerrainDev M, StepCounts* sc, uint32_t n, uint32_t cap_row_t, const uint32_t* rows_t,
+                                                          const uint32_t* rows_p, const uint32_t* t_off, const uint32_t* p_off, uint32_t* t_cand,
+                                                          uint32_t* t_owner, uint32_t* t_nc, NContact* t_out /* 2 per candidate */, uint32_t* t_pre,
+                                                          uint32_t* p_cand, uint32_t* p_owner, uint32_t* p_pre, uint32_t* cnt, uint32_t* tcn,
+                                                          const uint32_t* ext) {
+  __shared__ uint32_t s_ct;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (threadIdx.x == 0) s_ct = 0;
+  __syncthreads();
+  bool active = i < n;
+  if (active && sc->fail) { cnt[i] = 0; tcn[i] = 0; active = false; }
+  if (active) {
+    const uint32_t tb = t_off[i], nt = t_off[i + 1] - tb, pb = p_off[i], np = p_off[i + 1] - pb;
+    if (nt > cap_row_t || np > (uint32_t)kRowCap) { cnt[i] = 0; tcn[i] = 0; }  // (an overflowed row: the flag is up, the host re-runs the phase)
+    else {
+      uint32_t run = 0;
+      if (nt) {  // Mesh::contacts' faces, in its order; every contact its own constraint (world.rs:243-251)
+        V3 vA;
+        Comp A = load_comp_moving(B, i, &vA);
+        A.kind = KIND_SPHERE;
+        const V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
+        const uint32_t* rt = rows_t + (size_t)i * cap_row_t;
+        for (uint32_t a = 0; a < nt; ++a) {
+          const uint32_t f = rt[a], p = tb + a;
+          t_cand[p] = f; t_owner[p] = i;
+          const uint4 fi = M.faces[f];
+          Triangle tri = mkt(xyz(M.verts[fi.x]) + mx, xyz(M.verts[fi.y]) + mx, xyz(M.verts[fi.z]) + mx);  // mesh.rs:122-126
+          LocalContact lc[2];
+          const int nc = comp_tri_local(A, vA, tri, mx, lc);
+          t_nc[p] = (uint32_t)nc;
+          t_pre[p] = run;
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            if (k < nc) { NContact o; o.la = mk4(lc[k].la, lc[k].g.t); o.lb = mk4(lc[k].lb, 0.0f); o.n = mk4(lc[k].g.n, 0.0f); t_out[2 * p + k] = o; }  // Manifold::from(lc) manifold.rs:120-128
+          run += (uint32_t)nc;
+        }
+        if (run) atomicAdd(&s_ct, run);
+      }
+      // the partners (all of them contacts, one each): to the list in discovery order, numbered in ascending order id - the canonical
+      // insertion order
+      const uint4* rp = reinterpret_cast<const uint4*>(rows_p + (size_t)i * kRowCap);
+      uint32_t o_id[12], slot[12];  // (a sphere touches at most 12 equal ones; more: the rescan below)
+      for (uint32_t a = 0; a < np; a += 4) {
+        const uint4 v = rp[a >> 2];
+        const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (a + k < np) { p_cand[pb + a + k] = e[k]; p_owner[pb + a + k] = i; }
+      }
+      if (np <= 12u) {
+#pragma unroll
+        for (int a = 0; a < 12; ++a) { slot[a] = (uint32_t)a < np ? rows_p[(size_t)i * kRowCap + a] : 0u; o_id[a] = (uint32_t)a < np ? order_id(ext, slot[a]) : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int a = 0; a < 12; ++a) {
+          if ((uint32_t)a < np) {
+            uint32_t before = 0;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) before += o_id[q] < o_id[a] ? 1u : 0u;
+            p_pre[pb + a] = run + before;
+          }
+        }
+      } else {
+        for (uint32_t a = 0; a < np; ++a) {
+          const uint32_t oa = order_id(ext, rows_p[(size_t)i * kRowCap + a]);
+          uint32_t before = 0;
+          for (uint32_t q = 0; q < np; ++q) before += order_id(ext, rows_p[(size_t)i * kRowCap + q]) < oa ? 1u : 0u;
+          p_pre[pb + a] = run + before;
+        }
+      }
+      cnt[i] = run + np;
+      tcn[i] = run;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_ct) atomicAdd(&sc->ct_sum, s_ct);
+}
+
 // ------------------------------------------------------------------------------------------
 // ContactConstraint (solver.rs:82-93, 256-262), single contact.  96-byte record.
 // ------------------------------------------------------------------------------------------
