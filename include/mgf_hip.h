@@ -210,6 +210,12 @@ MGF_API mgf_status mgf_intersections_batch(mgf_ctx* ctx, int64_t n, const mgf_pa
 MGF_API mgf_status mgf_world_new(mgf_ctx* ctx, const mgf_params* params, mgf_world** out);
 MGF_API void mgf_world_free(mgf_world* w);
 MGF_API mgf_status mgf_world_set_terrain(mgf_world* w, const mgf_mesh* mesh);         /* copies; World.terrain */
+/* A static Compound (compound.rs:230-352) as an obstacle of the world beside the Mesh (copied; its pose as set when it is added).
+ * Every tick each owned body's parts go through Compound::contacts (:334-352) after the body's terrain contacts - obstacles in the
+ * order they were added, the body's parts in order - and every contact becomes a constraint against
+ * Static{center: the compound's displacement (Shape::center, :289-291), friction: 0}: world.rs:243-251 with the compound in the Mesh's
+ * place (the reference's demo world holds a Mesh only; the oracle states the definition, World::obstacles).  At most 256 obstacles. */
+MGF_API mgf_status mgf_world_add_obstacle(mgf_world* w, const mgf_compound* c);
 /* World::add_body / RigidBodyVec::add_body (physics.rs:200-218), bulk; MGF_ERR_SINGULAR as the unwrap. */
 MGF_API mgf_status mgf_world_add_bodies(mgf_world* w, const mgf_component* comps, int64_t n, const float* mass,
                                         const float* restitution, const float* friction, const mgf_vec3* world_force,

@@ -131,7 +131,7 @@ SYMBOLS = [
     "mgf_solver_len", "mgf_solver_clear", "mgf_solver_read_constraints", "mgf_solver_solve", "mgf_world_clone",
     "mgf_geom_to_json", "mgf_geom_from_json",
     "mgf_tiles_create", "mgf_tiles_free", "mgf_rccl_unique_id", "mgf_tiles_connect", "mgf_tiles_preflight", "mgf_tiles_step",
-    "mgf_tiles_migrated", "mgf_tiles_set_option",
+    "mgf_tiles_migrated", "mgf_tiles_set_option", "mgf_world_add_obstacle",
 ]
 
 _lib = None
@@ -256,6 +256,7 @@ def load_library():
         "mgf_tiles_step": (i32, [vp, f32, i32, vp]),
         "mgf_tiles_migrated": (i64, [vp, i32, i32]),
         "mgf_tiles_set_option": (i32, [vp, C.c_char_p, i64]),
+        "mgf_world_add_obstacle": (i32, [vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -823,6 +824,10 @@ class World:
 
     def set_terrain(self, mesh):
         _check(load_library().mgf_world_set_terrain(self._h, mesh._h if mesh is not None else None))
+
+    def add_obstacle(self, compound):
+        """A static Compound as an obstacle of the world beside the Mesh (mgf_world_add_obstacle; the compound is copied)."""
+        _check(load_library().mgf_world_add_obstacle(self._h, compound._h))
 
     def add_bodies(self, comps, mass, restitution, friction, world_force):
         comps = np.ascontiguousarray(comps, dtype=COMPONENT_DTYPE)

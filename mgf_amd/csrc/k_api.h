@@ -271,6 +271,82 @@ __global__ __launch_bounds__(kBlock) void k_compound_intersections(CompoundDev D
   if (have) { st3(out[i].p, best_p); out[i].t = best_t; }
 }
 
+// ---- static Compounds as obstacles of the world (round 3; the oracle's World::obstacles) -------------------------------------
+// A candidate of the "terrain" lists is a mesh face or - flagged - a component of an obstacle met by one part of the body:
+// kObstacleFlag | obstacle << 23 | part << 20 | component.  Appended to a body's terrain row behind its faces: obstacles in insertion
+// order, the body's parts in order, the components in the order Compound::contacts visits them (compound.rs:334-352: its BVH
+// queried with the part's bounds turned into the obstacle's frame).
+constexpr uint32_t kObstacleFlag = 0x80000000u, kObstacleMax = 256u, kObstacleCompMax = 1u << 20;
+__device__ __forceinline__ int body_parts(const Bodies& B, uint32_t i, Comp* out /* kMaxParts */, V3* centre) {
+  const uint32_t pc = B.pcount ? B.pcount[i] : 0u;
+  if (pc == 0) { out[0] = load_comp(B, i); *centre = comp_center(out[0]); return 1; }
+  for (uint32_t k = 0; k < pc && k < (uint32_t)kMaxParts; ++k) {
+    const float4 a = B.wp0[kMaxParts * i + k], b = B.wp1[kMaxParts * i + k];
+    out[k].kind = (int)f2u(b.w); out[k].p = xyz(a); out[k].r = a.w; out[k].d = xyz(b);
+  }
+  *centre = xyz(B.col0[i]);
+  return (int)min(pc, (uint32_t)kMaxParts);
+}
+__global__ __launch_bounds__(kBlock) void k_obstacle_rows(Bodies B, uint32_t n_owned, const CompoundDev* obs, uint32_t n_obs, uint32_t cap_row, uint32_t* rows_t,
+                                                          uint32_t* t_cnt, uint32_t* overflow) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_owned) return;
+  Comp part[kMaxParts];
+  V3 ci;
+  const int np = body_parts(B, i, part, &ci);
+  const V3 vel = xyz(B.delta[i]);
+  uint32_t nt = t_cnt[i];
+  uint32_t* row = rows_t + (size_t)i * cap_row;
+  for (uint32_t k = 0; k < n_obs; ++k) {
+    const CompoundDev D = obs[k];
+    const V3 disp = ld3(D.disp);
+    const Quat rot = mkq(D.rot[0], mk3(D.rot[1], D.rot[2], D.rot[3])), conj = mkq(rot.s, -rot.v);
+    for (int pa = 0; pa < np; ++pa) {
+      Box rb = box_rotate(swept_bounds(part[pa], vel), conj);  // compound.rs:340-344
+      rb.c = rotate(conj, rb.c + -disp) + disp;
+      terrain_traverse(D.tree, rb, [&](uint32_t comp) {
+        if (nt < cap_row) row[nt] = kObstacleFlag | (k << 23) | ((uint32_t)pa << 20) | comp;
+        ++nt;
+      });
+    }
+  }
+  t_cnt[i] = nt;
+  if (nt > cap_row) atomicOr(overflow, 2u);
+}
+// The flagged candidates' contacts: Moving<part>.contacts(&component) through the :1368-1382 wrapper (what Compound::contacts calls, and
+// negates), then LocalContacts (collision.rs:1490-1506) with the obstacle in the Mesh's place: the record Manifold::from(lc) and
+// ContactConstraint::new consume.  k_narrow_terrain* leave these candidates alone.
+__global__ __launch_bounds__(kBlock) void k_narrow_obstacles(Bodies B, const CompoundDev* obs, const uint32_t* m_ptr, const uint32_t* t_owner, const uint32_t* t_cand,
+                                                             uint32_t* t_nc, NContact* t_out, uint32_t stride) {
+  const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= *m_ptr) return;
+  const uint32_t f = t_cand[p];
+  if (!(f & kObstacleFlag)) return;
+  const uint32_t i = t_owner[p], k = (f >> 23) & 0xFFu, pa = (f >> 20) & 7u, ci_ = f & (kObstacleCompMax - 1u);
+  Comp part[kMaxParts];
+  V3 centre;
+  body_parts(B, i, part, &centre);
+  const V3 vel = xyz(B.delta[i]);
+  const CompoundDev D = obs[k];
+  const Quat rot = mkq(D.rot[0], mk3(D.rot[1], D.rot[2], D.rot[3]));
+  Comp shape = comp_rotate_about(to_comp(D.comps[ci_]), rot, mk3(0.0f, 0.0f, 0.0f));
+  shape.p = shape.p + ld3(D.disp);
+  Contact c[2];
+  const int m = contacts_dispatch(comp_shape(part[pa]), true, vel, comp_shape(shape), false, mk3(0, 0, 0), c);
+  const V3 oc = ld3(D.disp);  // Shape::center for Compound compound.rs:289-291
+  uint32_t cnt = 0;
+  for (int e = 0; e < m && e < 2; ++e) {
+    // (Compound::contacts hands out -c: a on the obstacle; LocalContacts then takes b - the body side - relative to the body's
+    // centre at the contact time, a relative to the obstacle's, and negates back)
+    NContact o;
+    o.la = mk4(c[e].a + -(centre + vel * c[e].t), c[e].t);
+    o.lb = mk4(c[e].b + -oc, 0.0f);
+    o.n = mk4(c[e].n, 0.0f);
+    t_out[(size_t)stride * p + cnt++] = o;
+  }
+  t_nc[p] = cnt;
+}
+
 __device__ __forceinline__ Comp to_comp(const MovingIn& m) {
   Comp k; k.kind = m.tag; k.p = ld3(m.p); k.d = ld3(m.d); k.r = m.r; return k;
 }

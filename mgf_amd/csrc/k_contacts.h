@@ -67,6 +67,7 @@ __global__ __launch_bounds__(kBlock) void k_narrow_terrain(Bodies B, TerrainDev 
   if (t >= *m_ptr) return;
   uint32_t p = work ? work[t] : t;
   uint32_t i = t_owner[p], f = t_cand[p];
+  if (f & 0x80000000u) return;  // a component of a static obstacle, not a face: k_narrow_obstacles (k_api.h)
   V3 vA;
   Comp A = load_comp_moving(B, i, &vA);
   A.kind = KA;
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(kBlock) void k_narrow_terrain_parts(Bodies B, Terra
   uint32_t p = blockIdx.x * kBlock + threadIdx.x;
   if (p >= *m_ptr) return;
   const uint32_t i = t_owner[p], f = t_cand[p];
+  if (f & 0x80000000u) return;  // a component of a static obstacle: k_narrow_obstacles
   Comp Pa[MP];
   V3 ci;
   const int na = load_parts<MP>(B, i, Pa, &ci);
@@ -504,6 +506,8 @@ struct TerrainSetup {
   const NContact* t_in;
   uint32_t in_stride;
   uint32_t blocks;  // blocks of the launch that work on terrain candidates (0: the world has no terrain)
+  const uint32_t* t_cand;       // with obstacles: the candidates (a flagged one is a component of obstacle (f >> 23) & 255) ...
+  const float4* obs_center;     // ... and the obstacles' centres (their displacements): the Static body's centre of such a constraint
 };
 __device__ __forceinline__ void setup_terrain_one(const Bodies& B, const TerrainSetup& T, const StepCounts* sc, uint32_t p, const uint32_t* base, float dt,
                                                   float baumgarte, float slop, CRec* cons, uint2* ab) {
@@ -515,6 +519,7 @@ __device__ __forceinline__ void setup_terrain_one(const Bodies& B, const Terrain
   const BodyPack Pa = load_pack(B, i, false);
   float4 ea = Pa.ei;
   V3 center = mk3(T.M.x[0], T.M.x[1], T.M.x[2]);  // Static{ center: terrain.center(), friction: 0.0 } world.rs:247
+  if (T.obs_center) { const uint32_t f = T.t_cand[p]; if (f & 0x80000000u) center = xyz(T.obs_center[(f >> 23) & 0xFFu]); }
   for (uint32_t k = 0; k < nc; ++k) {
     NContact in = T.t_in[(size_t)T.in_stride * p + k];
     CRec r = make_constraint(i, kNone, A, xyz(ea), ea.w, Pa.dl.w, S, center, 0.0f, 0.0f, xyz(in.n), xyz(in.la), xyz(in.lb), dt,

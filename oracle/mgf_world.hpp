@@ -19,6 +19,7 @@
 #include <chrono>
 
 #include "mgf_bvh.hpp"
+#include "mgf_compound.hpp"
 #include "mgf_physics.hpp"
 
 namespace mgfo {
@@ -90,6 +91,12 @@ struct World {
   std::vector<size_t> bvh_ids;
   BVH<size_t> bvh;
   Mesh terrain;
+  // Static Compounds as obstacles of the world beside the Mesh (round 3).  world.rs holds one Mesh; a Compound
+  // (compound.rs:230-352) is the crate's other static aggregate and its Contacts<RHS> (:334-352) serves a moving Sphere or Capsule
+  // the way Mesh::contacts does - so the harness treats it the same way: after a body's terrain contacts, every obstacle in
+  // insertion order, the body's parts in order, `obstacle.contacts(&Moving(part, v))`; every contact its own constraint against
+  // Static{center: obstacle.center() (= its displacement, compound.rs:289-291), friction: 0} (world.rs:243-251 with the obstacle in the Mesh's place).
+  std::vector<Compound> obstacles;
   int order_mode = ORDER_DEMO;
   float fat_margin = 0.25f;  // world.rs:181,237
   ContactConstraintParams params;
@@ -352,6 +359,19 @@ struct World {
             });
           }
         });
+        for (const Compound& ob : obstacles) {
+          const V3 oc = ob.disp;  // Shape::center for Compound
+          for (size_t pa = 0; pa < np_i; ++pa) {
+            const Moving<Component> part = bodies.part(i, pa);
+            auto emit = [&](const Contact& c) {  // c: the obstacle-side view (a on the obstacle, b on the body), as Mesh::contacts hands it out
+              const LocalContact lc{c.b + -(ci + vi * c.t), c.a + -oc, neg(c)};
+              solver.add_constraint(ContactConstraint::make(bodies, dynamic_ref(i), static_ref(oc, 0.0f), manifold_from(lc), dt, params));
+              stats.n_terrain_constraints++;
+            };
+            if (part.shape.kind == COMP_SPHERE) ob.contacts(sweep(part.shape.s, part.vel), emit);
+            else ob.contacts(sweep(part.shape.c, part.vel), emit);
+          }
+        }
       }
       if (i == 0) continue;
       auto on_hit = [&](size_t j) {

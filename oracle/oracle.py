@@ -108,6 +108,7 @@ def lib():
         L.mgfo_compound_new.restype = C.c_void_p
         L.mgfo_compound_free.argtypes = [C.c_void_p]
         L.mgfo_compound_set_pose.argtypes = [C.c_void_p, P(Vec3), P(Quat)]
+        L.mgfo_world_add_obstacle.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, P(Vec3), P(Quat)]
         L.mgfo_compound_bounds.argtypes = [C.c_void_p, P(Aabb)]
         L.mgfo_compound_contacts.argtypes = [C.c_void_p, P(Shape), P(Vec3), P(Contact), C.c_int]
         L.mgfo_compound_contacts.restype = C.c_int
@@ -415,6 +416,11 @@ class World:
         faces = np.ascontiguousarray(faces, dtype=np.uint32).reshape(-1, 3)
         lib().mgfo_world_set_terrain(self.h, verts.ctypes.data, len(verts), faces.ctypes.data, len(faces),
                                      C.byref(vec3(pos)))
+
+    def add_obstacle(self, comps, disp=(0.0, 0.0, 0.0), rot=(1.0, 0.0, 0.0, 0.0)):
+        """A static Compound (compound.rs:230-352) as an obstacle of the world beside the Mesh (World::obstacles)."""
+        comps = np.ascontiguousarray(comps, dtype=COMPONENT_DTYPE)
+        lib().mgfo_world_add_obstacle(self.h, comps.ctypes.data, len(comps), C.byref(vec3(disp)), C.byref(Quat(*[float(v) for v in rot])))
 
     def add_bodies(self, comps, mass, rest, fric, force):
         comps = np.ascontiguousarray(comps, dtype=COMPONENT_DTYPE)

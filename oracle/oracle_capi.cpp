@@ -314,6 +314,16 @@ void mgfo_world_set_terrain(void* wp, const o_vec3* verts, int64_t nverts, const
   for (int64_t i = 0; i < nfaces; ++i) w->terrain.push_face(faces[3 * i], faces[3 * i + 1], faces[3 * i + 2]);
   w->terrain.set_pos(V(*pos));
 }
+// a static Compound as an obstacle of the world (World::obstacles)
+void mgfo_world_add_obstacle(void* wp, const o_component* comps, int64_t n, const o_vec3* disp, const o_quat* rot) {
+  World* w = (World*)wp;
+  std::vector<Component> cs;
+  for (int64_t k = 0; k < n; ++k) cs.push_back(as_component(comps[k]));
+  Compound c(cs);
+  c.disp = V(*disp);
+  c.rot = Quat{rot->s, v3(rot->x, rot->y, rot->z)};
+  w->obstacles.push_back(c);
+}
 int64_t mgfo_world_add_bodies(void* wp, const o_component* comps, int64_t n, const float* mass, const float* rest,
                               const float* fric, const o_vec3* force) {
   World* w = (World*)wp;
