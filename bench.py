@@ -372,11 +372,41 @@ def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, w
         step = lambda: tiles.step(dt, args.iters)  # noqa: E731
     for _ in range(args.warmup):
         step()
+    XKEYS = ("exchange_ns", "exchange_bytes_out", "exchange_bytes_in", "exchange_bytes_local", "exchange_calls", "host_waits")
+    x0 = {k: tiles.counter(k) for k in XKEYS} if transport == "native" else None
     barrier()
     t0 = time.perf_counter()
     ticks = [step() for _ in range(args.steps)]
     barrier()
     elapsed = time.perf_counter() - t0
+    # what the neighbour exchanges cost in the timed window, per rank (mgf_tiles_counter; stream time between the events around every
+    # exchange, the wait for the neighbouring rank included), and - outside the timed region - how deep bodies rest in each other
+    # across tile faces against inside the tiles (the price of block-Jacobi across faces: DESIGN.md, tests/test_gpu_tiles_native.py)
+    exchange = seam = None
+    if transport == "native":
+        mine = [float(tiles.counter(k) - x0[k]) / args.steps for k in XKEYS]
+        rows = torch.zeros((world_size, len(XKEYS)), dtype=torch.float64, device=red_dev)
+        rows[rank] = torch.tensor(mine, dtype=torch.float64, device=red_dev)
+        if dist is not None:
+            dist.all_reduce(rows, op=dist.ReduceOp.SUM)
+        rows = rows.cpu().numpy()
+        exchange = {"per_rank": [{"rank": r, "exchange_us_per_tick": round(rows[r][0] / 1e3, 2), "bytes_out_per_tick": int(rows[r][1]), "bytes_in_per_tick": int(rows[r][2]),
+                                  "bytes_between_own_tiles_per_tick": int(rows[r][3]), "exchange_calls_per_tick": round(rows[r][4], 2),
+                                  "host_waits_per_tick": round(rows[r][5], 2)} for r in range(world_size)],
+                    "note": "exchange_us = stream time between the HIP events around every exchange of the tick (ghost bodies, ghost velocity refreshes, hand-overs), "
+                            "the wait for the neighbouring rank included; bytes cross RANK faces (RCCL send/recv) unless said otherwise"}
+        try:
+            mine_x = [(first + k, np.asarray(w.state()["x"], dtype=np.float32)) for k, w in enumerate(worlds)]
+            if dist is not None:
+                gathered = [None] * world_size
+                dist.all_gather_object(gathered, mine_x)
+                all_x = [t for g in gathered for t in g]
+            else:
+                all_x = mine_x
+            if rank == 0:
+                seam = _seam_penetration(all_x)
+        except Exception as e:  # (a figure beside the measurement: never at the price of the line)
+            seam = {"error": repr(e)}
     units = cons = launches = 0
     kms = 0.0
     phase = dict(ms_integrate=0.0, ms_broadphase=0.0, ms_narrowphase=0.0, ms_setup=0.0, ms_solve=0.0)
@@ -426,24 +456,49 @@ def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, w
         "tile_tick_ms_rank0": elapsed * 1e3 / (args.steps * per_rank),
         "roofline": _roofline(units, launches, kms, mode, f"{refresh_every} iteration(s) of one tile between ghost refreshes", ("tiles", args.warmup, args.steps)),
         "same_workload_on_one_gpu": _config4_one_gpu() if scene_kind == "config4" and world_size > 1 else None,
+        "exchange": exchange, "seam_penetration": seam,
     }
+
+
+def _seam_penetration(tiles_x, radius=0.5):
+    """Resting depth of touching spheres at the end of the run: pairs whose bodies live on DIFFERENT tiles (their constraint is solved
+    block-Jacobi across the face, ghost velocities refreshed every R iterations) against pairs inside one tile (exact Gauss-Seidel)."""
+    from scipy.spatial import cKDTree
+    x = np.concatenate([t[1] for t in tiles_x]).astype(np.float64)
+    tile = np.concatenate([np.full(len(t[1]), t[0], np.int32) for t in tiles_x])
+    pairs = cKDTree(x).query_pairs(2.0 * radius, output_type="ndarray")
+    if len(pairs) == 0:
+        return {"pairs_touching": 0}
+    depth = 2.0 * radius - np.linalg.norm(x[pairs[:, 0]] - x[pairs[:, 1]], axis=1)
+    across = tile[pairs[:, 0]] != tile[pairs[:, 1]]
+
+    def stat(d):
+        return {"pairs": int(len(d)), "mean": float(d.mean()) if len(d) else None, "p99": float(np.percentile(d, 99)) if len(d) else None, "max": float(d.max()) if len(d) else None}
+    return {"unit": "sphere radii x 2 (depth = 2r - distance of centres, r = 0.5)", "across_tile_faces": stat(depth[across]), "inside_tiles": stat(depth[~across]),
+            "note": "state at the end of the timed window; a pile that has not come to rest yet shows little depth on either side"}
 
 
 def _config4_one_gpu():
     """The N = 1 bench line is BASELINE config 2 (the contract's single-GPU workload); the N > 1 lines are strong-scaling slices of
     config 4.  For a scaling figure against the SAME workload: config 4's 8 tiles on ONE GPU, as measured and committed."""
-    p = os.path.join(ROOT, "profiles", "r02e_config4_8tiles_1gpu_bench.json")
+    import glob
+
+    def newest(pattern):  # (profiles are named per round: the latest committed one)
+        found = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+        return found[-1] if found else None
+    p = newest("r*_config4_8tiles_1gpu_bench.json")
     try:
         d = json.load(open(p))
         out = {"value": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
-               "source": "profiles/r02e_config4_8tiles_1gpu_bench.json (python bench.py --gpus 1 --scene config4; a committed measurement, not taken in this run)"}
-    except (OSError, KeyError, ValueError):
+               "source": f"profiles/{os.path.basename(p)} (python bench.py --gpus 1 --scene config4; a committed measurement, not taken in this run)"}
+    except (OSError, KeyError, ValueError, TypeError):
         return None
     try:  # and the same scene as ONE world (exact canonical order, no seams; tools/config4_undivided.py)
-        u = json.load(open(os.path.join(ROOT, "profiles", "r02f_config4_undivided_1gpu.json")))
+        pu = newest("r*_config4_undivided_1gpu.json")
+        u = json.load(open(pu))
         out["undivided_world"] = {"value": u["value"], "ms_per_step": u["ms_per_step"], "steps": u["steps"], "warmup": u["warmup"],
-                                  "source": "profiles/r02f_config4_undivided_1gpu.json (tools/config4_undivided.py)"}
-    except (OSError, KeyError, ValueError):
+                                  "source": f"profiles/{os.path.basename(pu)} (tools/config4_undivided.py)"}
+    except (OSError, KeyError, ValueError, TypeError):
         pass
     return out
 

@@ -392,6 +392,11 @@ MGF_API mgf_status mgf_tiles_step(mgf_tiles* t, float dt, int32_t iters, mgf_ste
  * phase: the protocol's status agreement is then observable (no rank hangs, every rank reports the tick as lost); -1 = never. */
 MGF_API mgf_status mgf_tiles_set_option(mgf_tiles* t, const char* key, int64_t value);
 MGF_API int64_t mgf_tiles_migrated(const mgf_tiles* t, int32_t tile, int32_t direction_in); /* bodies handed over so far */
+/* What the neighbour exchanges of a tile set have cost since its creation (no reference counterpart: world.rs has one World): key =
+   "exchange_bytes_out" / "exchange_bytes_in" (rows that crossed a face between RANKS), "exchange_bytes_local" (rows copied between this
+   rank's own tiles), "exchange_calls", "exchange_ns" (stream time between the events around the exchanges, the wait for the neighbouring
+   rank included), "host_waits", "ticks"; -1 for an unknown key. */
+MGF_API int64_t mgf_tiles_counter(const mgf_tiles* t, const char* key);
 /* Options (development and test knobs; defaults in brackets): "time_solver_kernels" [0] HIP events around the
  * solver kernels; "solver_mode" [6] 1 = persistent dataflow launch, 0 = one launch per dependency frontier,
  * 4 = dataflow with out-of-order slots, 5 = block-local dataflow (velocities and counters of a spatial block in LDS),

@@ -131,7 +131,7 @@ SYMBOLS = [
     "mgf_solver_len", "mgf_solver_clear", "mgf_solver_read_constraints", "mgf_solver_solve", "mgf_world_clone",
     "mgf_geom_to_json", "mgf_geom_from_json",
     "mgf_tiles_create", "mgf_tiles_free", "mgf_rccl_unique_id", "mgf_tiles_connect", "mgf_tiles_preflight", "mgf_tiles_step",
-    "mgf_tiles_migrated", "mgf_tiles_set_option", "mgf_world_add_obstacle",
+    "mgf_tiles_migrated", "mgf_tiles_set_option", "mgf_world_add_obstacle", "mgf_tiles_counter",
 ]
 
 _lib = None
@@ -255,6 +255,7 @@ def load_library():
         "mgf_tiles_preflight": (i32, [vp, P(i32)]),
         "mgf_tiles_step": (i32, [vp, f32, i32, vp]),
         "mgf_tiles_migrated": (i64, [vp, i32, i32]),
+        "mgf_tiles_counter": (i64, [vp, C.c_char_p]),
         "mgf_tiles_set_option": (i32, [vp, C.c_char_p, i64]),
         "mgf_world_add_obstacle": (i32, [vp, vp]),
     }
@@ -1082,6 +1083,13 @@ class Tiles:
 
     def migrated(self, tile, incoming=True):
         return load_library().mgf_tiles_migrated(self._h, int(tile), 1 if incoming else 0)
+
+    def counter(self, key):
+        """exchange_bytes_out / _in / _local, exchange_calls, exchange_ns, host_waits, ticks (mgf_tiles_counter)."""
+        v = load_library().mgf_tiles_counter(self._h, key.encode())
+        if v < 0:
+            raise KeyError(key)
+        return int(v)
 
     def set_option(self, key, value):
         _check(load_library().mgf_tiles_set_option(self._h, key.encode(), int(value)))

@@ -87,7 +87,7 @@ struct Flow6 {
   uint32_t nb, nblocks, n;
   uint32_t rows;             // table rows per block
   uint32_t fcap, slot_cap;   // LDS split of this launch: foreign body slots, constraint slots
-  uint32_t poll_waves, poll_k;  // waves that poll the incoming channels; (unused)
+  uint32_t poll_waves, poll_k;  // waves that poll the incoming channels; 1: every sweep through the worklist, >= 2: quiet sweeps read straight
   uint32_t poll_prio;           // s_setprio of the polling waves (0..3): their few instructions issue ahead of the serving waves'
 };
 __host__ __device__ constexpr uint32_t f6_slot_bytes(bool nimp_lds) { return nimp_lds ? 22u : 18u; }  // successor words 8, id 4, state 4, ring 2 (+ impulse 4)
@@ -233,9 +233,8 @@ __device__ __forceinline__ uint32_t f6_chan_slot(uint32_t* keys, uint32_t key1, 
 // one: no (succ, pred) arrays in between (k_chain_rows still builds them for the other solver modes, and - launched behind
 // this kernel with a guard - for the stand-by when a block did not fit).
 struct F6Ent { uint32_t home, slot, role, c, bref; };
-__global__ __launch_bounds__(kBlock) void k_flow6_links(Flow6 F, ConsLinks K, uint32_t n, const uint32_t* degb, uint32_t* rev, uint32_t rev_cap,
-                                                        const uint32_t* rev_flag, StepCounts* sc, uint32_t n_owned, uint32_t* n_ghost_cons,
-                                                        const uint32_t* ext) {
+__device__ __forceinline__ void f6_links_body(const Flow6& F, const ConsLinks& K, uint32_t n, const uint32_t* degb, uint32_t* rev, uint32_t rev_cap,
+                                              const uint32_t* rev_flag, StepCounts* sc, uint32_t n_owned, uint32_t* n_ghost_cons, const uint32_t* ext) {
   const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   // constraints whose obj_a is a ghost (ids are ascending in obj_a): the copies of seam constraints (tiles count them once)
   if (t == 0) *n_ghost_cons = (sc->fail || *rev_flag) ? 0u : F.base[n] - F.base[n_owned];
@@ -333,6 +332,47 @@ __global__ __launch_bounds__(kBlock) void k_flow6_links(Flow6 F, ConsLinks K, ui
       if (last && u.role == 1u && u.home != g) F.skipwb[x] = 1;
       u = w;
     }
+  }
+}
+// The channel layout of one block (what k_flow6_chan does with a wave, here one thread): exclusive prefix of the block's incoming
+// edge counts, the totals, the capacity check.  The counts were built by device-scope atomics: read past L1 / a stale L2 line (sc1).
+__device__ __forceinline__ void f6_chan_one(const Flow6& F, uint32_t hs, uint32_t iters) {
+  __amdgpu_buffer_rsrc_t rc = make_rsrc(F.in_cnt);
+  v4f_t c[kF6Chan / 4];
+#pragma unroll
+  for (uint32_t k = 0; k < kF6Chan / 4; ++k) c[k] = __builtin_amdgcn_raw_buffer_load_b128(rc, (int)((hs * kF6Chan + 4u * k) * 4u), 0, kSc1);
+  uint32_t run = 0;
+  uint4* dst = reinterpret_cast<uint4*>(F.chan_prefix + (size_t)hs * kF6Chan);
+#pragma unroll
+  for (uint32_t k = 0; k < kF6Chan / 4; ++k) {
+    uint4 o;
+    o.x = run; run += f2u(c[k].x); o.y = run; run += f2u(c[k].y); o.z = run; run += f2u(c[k].z); o.w = run; run += f2u(c[k].w);
+    dst[k] = o;
+  }
+  atomicAdd(&F.fail[1], run);
+  atomicMax(&F.fail[2], run);
+  if ((uint64_t)run * iters > F.mbox_cap / F.nblocks) atomicOr(F.fail, 8u);
+}
+// The tick's launch: the links, and - by the block that finishes last (a ticket; the edge counts are complete when every block's
+// atomics have been acknowledged) - the channel layout, which used to be a launch of its own (k_flow6_chan: still there for a
+// caller's list and for a changed iteration count).
+__global__ __launch_bounds__(kBlock) void k_flow6_links(Flow6 F, ConsLinks K, uint32_t n, const uint32_t* degb, uint32_t* rev, uint32_t rev_cap,
+                                                        const uint32_t* rev_flag, StepCounts* sc, uint32_t n_owned, uint32_t* n_ghost_cons,
+                                                        const uint32_t* ext, uint32_t* ticket, uint32_t iters) {
+  f6_links_body(F, K, n, degb, rev, rev_cap, rev_flag, sc, n_owned, n_ghost_cons, ext);
+  if (!ticket) return;
+  __shared__ uint32_t s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's atomics on the edge counts are done ...
+  __syncthreads();                                   // ... and the block's
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  for (uint32_t hs = threadIdx.x; hs < F.nblocks; hs += kBlock) f6_chan_one(F, hs, iters);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *ticket = 0u;  // (re-armed for the next tick)
+    if (__hip_atomic_load(F.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicOr(F.tick_fail, kFailFlow6);
   }
 }
 // One wave per block (its kF6Chan hash slots = the wave's lanes): where each incoming channel's messages start inside the
@@ -582,7 +622,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
     const uint32_t n_loc = (n_in - pw + P - 1u) / P;
     const bool owner = lane < n_loc;
     const uint32_t ch = lane * P + pw;
-    const uint32_t lim = owner ? s_in_lim[ch] : 0u;
+    const uint32_t lim = owner ? s_in_lim[ch] : 0u, in_base = owner ? s_in_base[ch] : 0u;
     const unsigned long long* tail_ptr = F.tails + (size_t)g * kF6Chan + (owner ? s_in_slot[ch] : 0u);
     uint32_t* wl_cnt = s_wl_cnt + pw;
     uint16_t* wl = s_wl + pw * kF6WlLen;
@@ -594,11 +634,44 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
       if (__hip_atomic_load(s_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
       uint64_t tq0 = 0;
       if (TRACE) { ++st_sweeps; tq0 = wall_clock64(); }
-      // the owners list their positions
+      // what every owner wants to read in this sweep
+      uint32_t todo = 0;
       if (owner) {
         const uint32_t pend = known > head ? min(known - head, 32u) : 0u;
-        uint32_t todo = ~mask & (pend >= 32u ? 0xFFFFFFFFu : (1u << pend) - 1u);
+        todo = ~mask & (pend >= 32u ? 0xFFFFFFFFu : (1u << pend) - 1u);
         if (head < lim) todo |= 1u & ~mask;  // the head, on spec
+      }
+      unsigned long long hits = 0;
+      if (F.poll_k >= 2u && __ballot((todo & ~1u) != 0u) == 0ull) {
+        // the quiet sweep (no channel is known to hold more than its head position - the state a lone message on a critical path
+        // finds): every owner reads its own channel's head straight from its registers, no worklist, no shared words
+        const bool have = (todo & 1u) != 0u;
+        const uint32_t byte = have ? (in_base + head) * (16u * kF6MsgWords) : 0x80000000u;
+        const v4f_t g0 = __builtin_amdgcn_raw_buffer_load_b128(rmb, (int)byte, 0, kSc1);
+        const v4f_t g1 = __builtin_amdgcn_raw_buffer_load_b128(rmb, (int)(byte + 16u), 0, kSc1);
+        const v4f_t g2 = __builtin_amdgcn_raw_buffer_load_b128(rmb, (int)(byte + 32u), 0, kSc1);
+        if (owner) {
+          const unsigned long long tv = __hip_atomic_load(tail_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          known = (uint32_t)(tv >> 32) == epoch ? min((uint32_t)tv, lim) : 0u;
+        }
+        if (TRACE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st_wait += (uint32_t)(wall_clock64() - tq0); }
+        const bool hit = have && f2u(g0.w) == epoch && f2u(g1.w) == epoch && f2u(g2.w) == epoch;
+        if (hit) {
+          const uint32_t addr = f2u(g2.x);
+          const uint32_t slot = addr & ((1u << kF6SlotBits) - 1u), bi = addr >> kF6SlotBits;
+          s_body[2 * bi] = make_float4(g0.x, g0.y, g0.z, g1.x);
+          *reinterpret_cast<float2*>(&s_body[2 * bi + 1]) = make_float2(g1.y, g1.z);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the velocity is in LDS before the arrival counts
+          f6_arrive(q, s_state, slot);
+          if (TRACE) { const uint32_t lat = (uint32_t)wall_clock64() - f2u(g2.y); ++st_hits; st_lat_sum += lat; st_lat_max = max(st_lat_max, lat); }
+          mask |= 1u;
+          const uint32_t k = mask == 0xFFFFFFFFu ? 32u : (uint32_t)__builtin_ctz(~mask);
+          head += k; mask = k >= 32u ? 0u : mask >> k;
+        }
+        hits = __ballot(hit);
+      } else {
+      // the owners list their positions
+      if (owner) {
         const uint32_t need = (uint32_t)__popc(todo);
         if (need) {
           uint32_t at = __hip_atomic_fetch_add(wl_cnt, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -614,7 +687,6 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const uint32_t total = min(__hip_atomic_load(wl_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), kF6WlLen);
       if (TRACE && total >= 64u) ++st_full;
-      unsigned long long hits = 0;
       for (uint32_t b = 0; b < total || b == 0u; b += 64u) {
         const uint32_t j = b + lane;
         const bool have = j < total;
@@ -649,6 +721,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
         mask |= __hip_atomic_exchange(&s_in_mask[ch], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint32_t k = mask == 0xFFFFFFFFu ? 32u : (uint32_t)__builtin_ctz(~mask);
         head += k; mask = k >= 32u ? 0u : mask >> k;
+      }
       }
       if (hits) { spins = 0; continue; }
       __builtin_amdgcn_s_sleep(1);

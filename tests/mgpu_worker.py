@@ -1,4 +1,5 @@
-"""One rank of a multi-GPU tile run (tests/test_gpu_multi_device.py): its own process, its own device, its share of the tiles;
+"""One rank of a multi-rank tile run (tests/test_gpu_multi_device.py): its own process, its own device (or, with the stand-in transport
+of tests/fake_rccl, device 0 shared with the other ranks), its share of the tiles;
 the RCCL id travels from rank 0 through a multiprocessing queue - nothing but the C-ABI (mgf_rccl_unique_id, mgf_tiles_connect,
 mgf_tiles_step) touches the fabric."""
 import os
@@ -10,16 +11,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def run_rank(rank, n_ranks, total_tiles, dims, drift, ticks, fail_rank, fail_tick, uid_q, out_q):
+def run_rank(rank, n_ranks, total_tiles, dims, drift, ticks, fail_rank, fail_tick, uid_q, out_q, device=None, rccl_lib=None):
+    """device: the rank's device (default: its own, `rank`); rccl_lib: the library the C-ABI binds instead of librccl (MGF_RCCL_LIB -
+    the tests' stand-in that lets several ranks share one device, tests/fake_rccl)."""
     try:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if rccl_lib:
+            os.environ["MGF_RCCL_LIB"] = rccl_lib
+            os.environ.setdefault("MGF_FAKE_RCCL_TIMEOUT_S", "90")
         import numpy as np
         import torch  # noqa: F401  (before libmgf_hip.so: see tests/conftest.py)
         import mgf_amd
         from mgf_amd import scenes
         per = total_tiles // n_ranks
         first = rank * per
-        ctx = mgf_amd.Context(rank)
+        ctx = mgf_amd.Context(rank if device is None else device)
         nx, ny, nz = dims
         tile_scenes = [scenes.sphere_pile_tile(nx, ny, nz, first + k, total_tiles, drift=drift) for k in range(per)]
         worlds = []
@@ -51,6 +57,7 @@ def run_rank(rank, n_ranks, total_tiles, dims, drift, ticks, fail_rank, fail_tic
             for k, w in enumerate(worlds):
                 st = w.state()
                 tiles_out.append(dict(tile=first + k, tags=w.tags(), migrated_in=T.migrated(k), **{f: st[f] for f in ("x", "q", "v", "omega", "delta")}))
-        out_q.put(dict(rank=rank, ranks_seen=seen, failed_at=failed_at, error=err, tiles=tiles_out))
+        out_q.put(dict(rank=rank, ranks_seen=seen, failed_at=failed_at, error=err, tiles=tiles_out,
+                       bytes_out=T.counter("exchange_bytes_out"), bytes_in=T.counter("exchange_bytes_in")))
     except Exception:
         out_q.put(dict(rank=rank, crash=traceback.format_exc()))

@@ -21,11 +21,18 @@ def _device_count():
     return torch.cuda.device_count()
 
 
-def _launch(n_ranks, total_tiles, dims, drift, ticks, fail_rank=-1, fail_tick=-1, timeout=600):
+def _launch(n_ranks, total_tiles, dims, drift, ticks, fail_rank=-1, fail_tick=-1, timeout=600, shared_device=False):
+    """shared_device: every rank on device 0, the C-ABI bound to the stand-in transport of tests/fake_rccl (RCCL refuses two ranks on
+    one device) - every process still runs the whole of mgf_tiles_step's multi-rank path."""
     from tests.mgpu_worker import run_rank
+    lib = None
+    if shared_device:
+        from tests.fake_rccl.build import build
+        lib = build()
     mpc = mp.get_context("spawn")
     uid_q, out_q = mpc.Queue(), mpc.Queue()
-    procs = [mpc.Process(target=run_rank, args=(r, n_ranks, total_tiles, dims, drift, ticks, fail_rank, fail_tick, uid_q, out_q)) for r in range(n_ranks)]
+    procs = [mpc.Process(target=run_rank, args=(r, n_ranks, total_tiles, dims, drift, ticks, fail_rank, fail_tick, uid_q, out_q, 0 if shared_device else None, lib))
+             for r in range(n_ranks)]
     for p in procs:
         p.start()
     results = {}
@@ -43,23 +50,22 @@ def _launch(n_ranks, total_tiles, dims, drift, ticks, fail_rank=-1, fail_tick=-1
     return results
 
 
-@pytest.mark.parametrize("n_ranks", [2, 4, 8])
-def test_ranks_on_distinct_devices_match_the_oracle_tiles(n_ranks):
-    if _device_count() < n_ranks:
-        pytest.skip(f"needs {n_ranks} devices")
+def _check_against_oracle_tiles(res, n_ranks, P, dims, drift, ticks):
     from mgf_amd.tiles import Tile, step_tiles_inprocess
     from tests.oracle_engine import OracleEngine
-    P, dims, drift, ticks = 8, (4, 4, 5), (5.0, 0.0, 0.0), 40
-    res = _launch(n_ranks, P, dims, drift, ticks)
     tile_scenes = [scenes.sphere_pile_tile(*dims, r, P, drift=drift) for r in range(P)]
     ot = [Tile(OracleEngine(sc), sc["x_range"], r, P, sc["dt"], sc["iters"]) for r, sc in enumerate(tile_scenes)]
     for _ in range(ticks):
         step_tiles_inprocess(ot)
     got = {}
+    out_b = in_b = 0
     for r in range(n_ranks):
         assert res[r]["ranks_seen"] == n_ranks and res[r]["failed_at"] is None, res[r]
         for t in res[r]["tiles"]:
             got[t["tile"]] = t
+        out_b += res[r]["bytes_out"]; in_b += res[r]["bytes_in"]
+        assert res[r]["bytes_out"] > 0 and res[r]["bytes_in"] > 0   # every rank has a neighbouring rank
+    assert out_b == in_b   # what left one rank arrived on another
     assert sorted(got) == list(range(P))
     moved = 0
     for k in range(P):
@@ -70,6 +76,35 @@ def test_ranks_on_distinct_devices_match_the_oracle_tiles(n_ranks):
         assert got[k]["migrated_in"] == ot[k].n_migrated_in
         moved += got[k]["migrated_in"]
     assert moved > 0  # bodies did change owner across ranks
+
+
+@pytest.mark.parametrize("n_ranks", [2, 4, 8])
+def test_ranks_on_distinct_devices_match_the_oracle_tiles(n_ranks):
+    if _device_count() < n_ranks:
+        pytest.skip(f"needs {n_ranks} devices")
+    P, dims, drift, ticks = 8, (4, 4, 5), (5.0, 0.0, 0.0), 40
+    res = _launch(n_ranks, P, dims, drift, ticks)
+    _check_against_oracle_tiles(res, n_ranks, P, dims, drift, ticks)
+
+
+# ---- several ranks on ONE device (any box): the whole multi-rank path of mgf_tiles_step, processes and all, over the stand-in transport
+@pytest.mark.parametrize("n_ranks,P", [(2, 4), (2, 8), (4, 8)])
+def test_ranks_sharing_one_device_match_the_oracle_tiles(n_ranks, P):
+    """What the RCCL runs above would show on a multi-GPU box, minus the fabric: every send of the protocol is met by a receive of the
+    same size in the same order on the neighbouring rank (the stand-in fails a mismatch and reports a deadlock instead of hanging),
+    counts, ghosts, velocity refreshes and hand-overs cross RANK faces, and the result is the oracle tiles' bit for bit."""
+    dims, drift, ticks = (4, 4, 5), (5.0, 0.0, 0.0), 40
+    res = _launch(n_ranks, P, dims, drift, ticks, shared_device=True)
+    _check_against_oracle_tiles(res, n_ranks, P, dims, drift, ticks)
+
+
+def test_a_failing_rank_takes_the_tick_down_on_every_rank_sharing_one_device():
+    n_ranks = 3
+    res = _launch(n_ranks, 6, (4, 4, 5), (5.0, 0.0, 0.0), 12, fail_rank=n_ranks - 1, fail_tick=5, timeout=300, shared_device=True)
+    for r in range(n_ranks):
+        assert res[r]["failed_at"] == 5, f"rank {r}: {res[r]}"   # nobody hangs, nobody goes on alone
+    assert "halo" in res[n_ranks - 1]["error"]
+    assert all("rank failed" in res[r]["error"] for r in range(n_ranks - 1))
 
 
 def test_a_failing_rank_takes_the_tick_down_on_every_rank():
@@ -119,3 +154,9 @@ def test_a_failed_tick_is_reported_at_its_end_and_moves_nobody(ctx, connected):
     assert [len(w) for w in worlds] == owned and [T.migrated(r) for r in range(P)] == moved
     with pytest.raises(mgf_amd.MgfError):
         T.set_option("no_such_option", 1)
+    # the exchanges' counters: rows moved between this process's tiles only, five ticks, the events' time is there
+    assert T.counter("ticks") == 5 and T.counter("exchange_calls") >= 5 * 5 and T.counter("exchange_ns") > 0
+    assert T.counter("exchange_bytes_local") > 0 and T.counter("exchange_bytes_out") == 0 and T.counter("exchange_bytes_in") == 0
+    assert T.counter("host_waits") >= 5 * (2 + 2 * P)
+    with pytest.raises(KeyError):
+        T.counter("no_such_counter")

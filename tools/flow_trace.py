@@ -89,3 +89,24 @@ if mode == 6 and os.path.exists('/tmp/mgf_flow6_poll.bin'):
           f"message latency sent->consumed mean {st[:,2].sum() / max(st[:,1].sum(),1) * 0.01:.2f} us, max {st[:,3].max() * 0.01:.1f} us, "
           f"full windows/block {st[:,4].mean():.1f}, incoming channels mean {st[:,5].mean():.1f} max {st[:,5].max():.0f}; "
           f"time a sweep waits for its loads {st[:,6].sum() / max(st[:,0].sum(),1) * 0.01:.2f} us")
+
+# per block: constraints, when its last node was released - is the launch the slowest block's, and is that the fullest one?
+if rank is not None and nb_block:
+    blk = rank[A] // nb_block
+    nblk = int(blk.max()) + 1
+    Nb = np.bincount(blk, minlength=nblk)
+    fin = np.zeros(nblk)
+    np.maximum.at(fin, blk, done.max(axis=0))
+    first = np.full(nblk, 1e9)
+    np.minimum.at(first, blk, seen.min(axis=0))
+    span = done.max()
+    print(f"blocks {nblk}: constraints per block mean {Nb.mean():.0f} p10 {np.percentile(Nb,10):.0f} p50 {np.median(Nb):.0f} p90 {np.percentile(Nb,90):.0f} max {Nb.max()}")
+    print("block finish time (us): p10 %.0f p25 %.0f p50 %.0f p75 %.0f p90 %.0f max %.0f" % tuple(np.percentile(fin, [10, 25, 50, 75, 90, 100])))
+    cc = np.corrcoef(Nb, fin)[0, 1]
+    print(f"correlation(constraints of a block, its finish time) = {cc:.2f}; blocks still running at 50 % / 75 % / 90 % of the span: "
+          f"{int((fin > 0.5 * span).sum())} / {int((fin > 0.75 * span).sum())} / {int((fin > 0.9 * span).sum())}")
+    # node throughput over time, whole chip: nodes released per us in ten slices of the span
+    hist, _ = np.histogram(done.ravel(), bins=10, range=(0, span))
+    print("nodes released per us, by tenth of the span:", " ".join(f"{h / (span / 10):.0f}" for h in hist))
+    # per-iteration completion: when the last node of every iteration was released
+    print("iteration r complete at (us):", " ".join(f"{done[r].max():.0f}" for r in range(iters)))
