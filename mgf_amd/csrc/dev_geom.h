@@ -143,7 +143,7 @@ __device__ inline bool ray_sphere(V3 p, V3 d, const Sphere& s, V3* ip, float* to
   return true;
 }
 
-__device__ __noinline__ bool ray_capsule(V3 p, V3 d, const Capsule& cap, V3* ip, float* tout, float dt = kInf) {  // :275-359
+__device__ inline bool ray_capsule(V3 p, V3 d, const Capsule& cap, V3* ip, float* tout, float dt = kInf) {  // :275-359
   V3 m = p - cap.a;
   float md = dot(m, cap.d), nd = dot(d, cap.d), dd = dot(cap.d, cap.d);
   float nn = mag2(d), mn = dot(m, d);
@@ -262,7 +262,7 @@ __device__ inline bool plane_mcapsule(const Plane& pl, const Capsule& c, V3 v, C
 }
 
 // ---- triangle vs moving sphere :610-659 -----------------------------------------------
-__device__ __noinline__ bool tri_msphere(const Triangle& tri, const Sphere& s, V3 v, Contact* out) {
+__device__ inline bool tri_msphere(const Triangle& tri, const Sphere& s, V3 v, Contact* out) {
   Plane p = plane_from(tri.a, tri.b, tri.c);
   Contact contact;
   if (!plane_msphere(p, s, v, &contact)) return false;
@@ -295,7 +295,7 @@ HD bool seg2d(V2 a, V2 b, V2 c, V2 d, float* t) {
 }
 
 // ---- triangle vs moving capsule :693-1086; returns number of contacts (0..2) ------------
-__device__ __noinline__ int tri_mcapsule(const Triangle& tri, const Capsule& c, V3 v, Contact out[2]) {
+__device__ inline int tri_mcapsule(const Triangle& tri, const Capsule& c, V3 v, Contact out[2]) {
   const Plane p = plane_from(tri.a, tri.b, tri.c);
   // :698-719 capsule axis already crosses the face
   {
@@ -474,7 +474,7 @@ __device__ inline bool sphere_msphere(const Sphere& self, const Sphere& s, V3 v,
   return false;
 }
 
-__device__ __noinline__ bool capsule_msphere(const Capsule& self, const Sphere& s, V3 v, Contact* out) {  // :1145-1203
+__device__ inline bool capsule_msphere(const Capsule& self, const Sphere& s, V3 v, Contact* out) {  // :1145-1203
   float r = self.r + s.r;
   V3 cp = seg_closest(self.a, self.a + self.d, s.c);
   V3 d = s.c - cp;
@@ -510,7 +510,7 @@ __device__ inline bool sphere_mcapsule(const Sphere& self, const Capsule& c, V3 
   return true;
 }
 
-__device__ __noinline__ bool capsule_mcapsule(const Capsule& self, const Capsule& c, V3 v, Contact* out) {  // :1205-1356
+__device__ inline bool capsule_mcapsule(const Capsule& self, const Capsule& c, V3 v, Contact* out) {  // :1205-1356
   V3 sa = self.a, sb = self.a + self.d;
   V3 p1, p2;
   {

@@ -94,20 +94,24 @@ __global__ __launch_bounds__(kBlock) void k_narrow_terrain(Bodies B, TerrainDev 
 constexpr float kPersistentThresholdSq = 0.5f;  // manifold.rs:38
 // MP = the most parts any body of the world has (2 or 4: the kernels are instantiated for both, so that a world of two-part bodies
 // does not carry the registers of sixteen part pairs): a pair of bodies yields at most MP * MP contacts, a (body, face) 2 * MP.
-template <int MP>
-__device__ __forceinline__ int load_parts(const Bodies& B, uint32_t i, Comp out[MP], V3* centre) {
+// One part of a body: part k of a body of several components, or the body's own collider (k = 0 of an ordinary body); false when
+// the body has no such part.  *centre = the centre the local contact points are taken from (load_parts).
+__device__ __forceinline__ bool load_part(const Bodies& B, uint32_t i, uint32_t k, Comp* out, V3* centre) {
   const uint32_t pc = B.pcount ? B.pcount[i] : 0u;
-  if (pc == 0) { out[0] = load_comp(B, i); *centre = comp_center(out[0]); return 1; }
-#pragma unroll
-  for (int k = 0; k < MP; ++k) {
-    if ((uint32_t)k < pc) {
-      float4 a = B.wp0[kMaxParts * i + k], b = B.wp1[kMaxParts * i + k];
-      out[k].kind = (int)f2u(b.w); out[k].p = xyz(a); out[k].r = a.w; out[k].d = xyz(b);
-    }
-  }
-  *centre = xyz(B.col0[i]);  // the carrier: the body's centre of mass
-  return (int)min(pc, (uint32_t)MP);
+  if (pc == 0) { if (k) return false; *out = load_comp(B, i); *centre = comp_center(*out); return true; }
+  if (k >= pc) return false;
+  const float4 a = B.wp0[kMaxParts * i + k], b = B.wp1[kMaxParts * i + k];
+  out->kind = (int)f2u(b.w); out->p = xyz(a); out->r = a.w; out->d = xyz(b);
+  *centre = xyz(B.col0[i]);
+  return true;
 }
+// The block's 256 candidates in three steps (round 3; one thread used to walk its candidate's MP * MP part pairs by itself, the parts
+// in arrays it indexed at run time - scratch memory - and a block of mostly culled candidates kept one wave busy for all of them):
+//   1. cull + pack, as k_narrow_pairs: candidates whose tight boxes do not meet leave;
+//   2. one ITEM per (part pair, surviving candidate), part-pair-major - consecutive lanes run the same (a, b) of different
+//      candidates, which is the same pair of shapes in a world of equal bodies - through Contacts (compound.rs:180-190); the raw
+//      contact goes to the candidate's own output slot (a, b);
+//   3. a thread per surviving candidate: ContactPruner::push over its raw contacts in order (parts of i outer) and Manifold::from.
 template <int MP>
 __global__ __launch_bounds__(kBlock) void k_narrow_pairs_parts(Bodies B, const uint32_t* m_ptr, const uint32_t* p_owner, const uint32_t* p_cand,
                                                                uint32_t* p_nc, NContact* p_out /* MP * MP per candidate */) {
@@ -115,8 +119,7 @@ __global__ __launch_bounds__(kBlock) void k_narrow_pairs_parts(Bodies B, const u
   // The candidate was accepted on i's tight box against j's FAT box (bvh.rs:297), which is the larger by the margin and by every
   // tick since j's last refit.  A contact is a touching of two parts somewhere inside both bodies' TIGHT swept boxes of this
   // tick, so if those do not overlap (a millimetre and 1e-5 of the coordinates allowed for rounding) no part pair reports
-  // anything.  Three candidates in four leave here, before their parts are read - and the survivors of the block are packed
-  // into its first lanes (a lane that leaves early saves nothing while its wave goes on: whole waves have to leave).
+  // anything.  Three candidates in four leave here, before their parts are read.
   __shared__ uint32_t s_list[kBlock];
   __shared__ uint32_t s_n;
   if (threadIdx.x == 0) s_n = 0;
@@ -139,20 +142,71 @@ __global__ __launch_bounds__(kBlock) void k_narrow_pairs_parts(Bodies B, const u
     if (live) s_list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = p0;
   }
   __syncthreads();
-  if (threadIdx.x >= s_n) return;
+  const uint32_t live_n = s_n;
+  if (live_n == 0) return;
+  // 2. the part pairs (raw slot: a.xyz, t | b.xyz, hit | n.xyz).  First the cheap conservative test of k_narrow_pairs on every item
+  // (the parts' bounding spheres never come within reach during the tick: of a pair of bodies that touch, one part pair in MP * MP
+  // does), survivors packed again - whole waves have to leave for the leaving to save anything - then Contacts on those.
+  __shared__ uint16_t s_item[kBlock * kPairContacts];
+  __shared__ uint32_t s_items;
+  if (threadIdx.x == 0) s_items = 0;
+  __syncthreads();
+  auto item_parts = [&](uint32_t w, uint32_t& p, Comp& Pa, Comp& Pb, V3& vA, V3& vB) -> bool {
+    const uint32_t ab = w / live_n;
+    p = s_list[w - ab * live_n];
+    const uint32_t a = ab / (uint32_t)MP, b = ab - a * (uint32_t)MP;
+    const uint32_t i = p_owner[p], j = p_cand[p];
+    V3 ci, cj;
+    if (!load_part(B, i, a, &Pa, &ci) || !load_part(B, j, b, &Pb, &cj)) return false;
+    vA = xyz(B.delta[i]); vB = xyz(B.delta[j]);
+    return true;
+  };
+  const uint32_t n_items = live_n * (uint32_t)kPairContacts;
+  for (uint32_t w0 = 0; w0 < n_items; w0 += kBlock) {  // (whole waves walk the loop together: the ballots below see every lane)
+    const uint32_t w = w0 + threadIdx.x;
+    bool near = false;
+    if (w < n_items) {
+      uint32_t p; Comp Pa, Pb; V3 vA, vB;
+      const bool have = item_parts(w, p, Pa, Pb, vA, vB);
+      near = have && !comp_pair_far(Pa, vA, Pb, vB);
+      if (!near) { NContact z; z.la = z.lb = z.n = make_float4(0, 0, 0, 0); p_out[(size_t)kPairContacts * p + w / live_n] = z; }
+    }
+    const unsigned long long mask = __ballot(near);
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0 && mask) base = atomicAdd(&s_items, (uint32_t)__popcll(mask));
+    base = __shfl(base, 0);
+    if (near) s_item[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)w;
+  }
+  __syncthreads();
+  const uint32_t n_near = s_items;
+  for (uint32_t k = threadIdx.x; k < n_near; k += kBlock) {
+    const uint32_t w = s_item[k];
+    uint32_t p; Comp Pa, Pb; V3 vA, vB;
+    (void)item_parts(w, p, Pa, Pb, vA, vB);
+    Contact c;
+    NContact raw;
+    raw.la = raw.lb = raw.n = make_float4(0, 0, 0, 0);
+    if (comp_pair_contact(Pa, vA, Pb, vB, &c)) { raw.la = mk4(c.a, c.t); raw.lb = mk4(c.b, 1.0f); raw.n = mk4(c.n, 0.0f); }
+    p_out[(size_t)kPairContacts * p + w / live_n] = raw;
+  }
+  __syncthreads();  // (a block's stores are visible to the block behind its barrier)
+  // 3. the pruner, a thread per surviving candidate
+  if (threadIdx.x >= live_n) return;
   const uint32_t p = s_list[threadIdx.x];
   const uint32_t i = p_owner[p], j = p_cand[p];
-  Comp Pa[MP], Pb[MP];
-  V3 ci, cj;
-  const int na = load_parts<MP>(B, i, Pa, &ci), nb = load_parts<MP>(B, j, Pb, &cj);
+  const uint32_t pci = B.pcount ? B.pcount[i] : 0u, pcj = B.pcount ? B.pcount[j] : 0u;
+  const int na = pci ? (int)min(pci, (uint32_t)MP) : 1, nb = pcj ? (int)min(pcj, (uint32_t)MP) : 1;
+  const V3 ci = pci ? xyz(B.col0[i]) : comp_center(load_comp(B, i)), cj = pcj ? xyz(B.col0[j]) : comp_center(load_comp(B, j));
   const V3 vA = xyz(B.delta[i]), vB = xyz(B.delta[j]);
   float min_t = kInf;
   int cnt = 0;
   LocalContact keep[kPairContacts];
   for (int a = 0; a < na; ++a) {
     for (int b = 0; b < nb; ++b) {
-      Contact c;
-      if (!comp_pair_contact(Pa[a], vA, Pb[b], vB, &c)) continue;
+      const NContact raw = p_out[(size_t)kPairContacts * p + (uint32_t)(a * MP + b)];
+      if (raw.lb.w == 0.0f) continue;
+      Contact c; c.a = xyz(raw.la); c.b = xyz(raw.lb); c.n = xyz(raw.n); c.t = raw.la.w;
       LocalContact nc; nc.la = c.a + -(ci + vA * c.t); nc.lb = c.b + -(cj + vB * c.t); nc.g = c;
       if (nc.g.t < min_t - kCollisionEps) { cnt = 1; keep[0] = nc; min_t = nc.g.t; continue; }
       if (nc.g.t > min_t + kCollisionEps) continue;
@@ -179,30 +233,53 @@ __global__ __launch_bounds__(kBlock) void k_narrow_pairs_parts(Bodies B, const u
   }
 }
 // Terrain: per face (the candidate list is in the mesh's DFS order) the body's parts in order; every contact is its own
-// constraint (world.rs:243-251).
+// constraint (world.rs:243-251).  The same two steps: an item per (part, candidate of the block), part-major, writes the part's
+// up to two contacts to the candidate's slots (2 a, 2 a + 1) and their number to LDS; a thread per candidate packs them.
 template <int MP>
 __global__ __launch_bounds__(kBlock) void k_narrow_terrain_parts(Bodies B, TerrainDev M, const uint32_t* m_ptr, const uint32_t* t_owner,
                                                                  const uint32_t* t_cand, uint32_t* t_nc,
                                                                  NContact* t_out /* 2 * MP per candidate */) {
   constexpr int kTerrainContacts = 2 * MP;  // per (body, face): a capsule part emits up to 2
-  uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-  if (p >= *m_ptr) return;
-  const uint32_t i = t_owner[p], f = t_cand[p];
-  if (f & 0x80000000u) return;  // a component of a static obstacle: k_narrow_obstacles
-  Comp Pa[MP];
-  V3 ci;
-  const int na = load_parts<MP>(B, i, Pa, &ci);
-  const V3 vA = xyz(B.delta[i]);
-  uint4 fi = M.faces[f];
-  V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
-  Triangle tri = mkt(xyz(M.verts[fi.x]) + mx, xyz(M.verts[fi.y]) + mx, xyz(M.verts[fi.z]) + mx);  // mesh.rs:122-126
+  __shared__ uint8_t s_nc[MP][kBlock];
+  const uint32_t m = *m_ptr, p_lo = blockIdx.x * kBlock;
+  if (p_lo >= m) return;
+  const uint32_t here = min((uint32_t)kBlock, m - p_lo);
+  const V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
+  for (uint32_t w = threadIdx.x; w < here * (uint32_t)MP; w += kBlock) {
+    const uint32_t a = w / here, q = w - a * here, p = p_lo + q;
+    const uint32_t i = t_owner[p], f = t_cand[p];
+    int nc = 0;
+    Comp Pa;
+    V3 ci;
+    if (!(f & 0x80000000u) && load_part(B, i, a, &Pa, &ci)) {  // (a flagged candidate is a component of a static obstacle: k_narrow_obstacles)
+      const V3 vA = xyz(B.delta[i]);
+      const uint4 fi = M.faces[f];
+      const Triangle tri = mkt(xyz(M.verts[fi.x]) + mx, xyz(M.verts[fi.y]) + mx, xyz(M.verts[fi.z]) + mx);  // mesh.rs:122-126
+      LocalContact lc[2];
+      nc = comp_tri_local_at(Pa, vA, tri, mx, ci, lc);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (k < nc) {
+          NContact o; o.la = mk4(lc[k].la, lc[k].g.t); o.lb = mk4(lc[k].lb, 0.0f); o.n = mk4(lc[k].g.n, 0.0f);
+          t_out[(size_t)kTerrainContacts * p + 2u * a + (uint32_t)k] = o;
+        }
+      }
+    }
+    s_nc[a][q] = (uint8_t)nc;
+  }
+  __syncthreads();
+  const uint32_t q = threadIdx.x;
+  if (q >= here) return;
+  const uint32_t p = p_lo + q;
+  if (t_cand[p] & 0x80000000u) return;
   uint32_t cnt = 0;
-  for (int a = 0; a < na; ++a) {
-    LocalContact lc[2];
-    int nc = comp_tri_local_at(Pa[a], vA, tri, mx, ci, lc);
-    for (int k = 0; k < nc; ++k) {
-      NContact o; o.la = mk4(lc[k].la, lc[k].g.t); o.lb = mk4(lc[k].lb, 0.0f); o.n = mk4(lc[k].g.n, 0.0f);
-      t_out[(size_t)kTerrainContacts * p + cnt++] = o;
+#pragma unroll
+  for (int a = 0; a < MP; ++a) {
+    const uint32_t nc = s_nc[a][q];
+    for (uint32_t k = 0; k < nc; ++k) {  // (packing moves a contact to a slot at or before its own: read, then write)
+      const uint32_t src = 2u * (uint32_t)a + k;
+      if (src != cnt) { const NContact o = t_out[(size_t)kTerrainContacts * p + src]; t_out[(size_t)kTerrainContacts * p + cnt] = o; }
+      ++cnt;
     }
   }
   t_nc[p] = cnt;

@@ -335,8 +335,8 @@ __device__ __forceinline__ void f6_links_body(const Flow6& F, const ConsLinks& K
   }
 }
 // The channel layout of one block (what k_flow6_chan does with a wave, here one thread): exclusive prefix of the block's incoming
-// edge counts, the totals, the capacity check.  The counts were built by device-scope atomics: read past L1 / a stale L2 line (sc1).
-__device__ __forceinline__ void f6_chan_one(const Flow6& F, uint32_t hs, uint32_t iters) {
+// edge counts; returns their sum.  The counts were built by device-scope atomics: read past L1 / a stale L2 line (sc1).
+__device__ __forceinline__ uint32_t f6_chan_one(const Flow6& F, uint32_t hs) {
   __amdgpu_buffer_rsrc_t rc = make_rsrc(F.in_cnt);
   v4f_t c[kF6Chan / 4];
 #pragma unroll
@@ -349,9 +349,7 @@ __device__ __forceinline__ void f6_chan_one(const Flow6& F, uint32_t hs, uint32_
     o.x = run; run += f2u(c[k].x); o.y = run; run += f2u(c[k].y); o.z = run; run += f2u(c[k].z); o.w = run; run += f2u(c[k].w);
     dst[k] = o;
   }
-  atomicAdd(&F.fail[1], run);
-  atomicMax(&F.fail[2], run);
-  if ((uint64_t)run * iters > F.mbox_cap / F.nblocks) atomicOr(F.fail, 8u);
+  return run;
 }
 // The tick's launch: the links, and - by the block that finishes last (a ticket; the edge counts are complete when every block's
 // atomics have been acknowledged) - the channel layout, which used to be a launch of its own (k_flow6_chan: still there for a
@@ -367,10 +365,20 @@ __global__ __launch_bounds__(kBlock) void k_flow6_links(Flow6 F, ConsLinks K, ui
   if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
-  for (uint32_t hs = threadIdx.x; hs < F.nblocks; hs += kBlock) f6_chan_one(F, hs, iters);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (the totals through the block, not through 256 atomics on one word: those alone took 6 us)
+  __shared__ uint32_t s_sum[kBlock / 64], s_max[kBlock / 64];
+  uint32_t sum = 0, mx = 0;
+  for (uint32_t hs = threadIdx.x; hs < F.nblocks; hs += kBlock) { const uint32_t run = f6_chan_one(F, hs); sum += run; mx = max(mx, run); }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, (uint32_t)__shfl_xor(mx, o)); }
+  if ((threadIdx.x & 63u) == 0u) { s_sum[threadIdx.x >> 6] = sum; s_max[threadIdx.x >> 6] = mx; }
   __syncthreads();
   if (threadIdx.x == 0) {
+    sum = 0; mx = 0;
+    for (uint32_t k = 0; k < kBlock / 64; ++k) { sum += s_sum[k]; mx = max(mx, s_max[k]); }
+    atomicAdd(&F.fail[1], sum);  // edges that cross a block face, per iteration (the host sizes the channel buffer from it)
+    atomicMax(&F.fail[2], mx);   // ... the most any block receives
+    if ((uint64_t)mx * iters > F.mbox_cap / F.nblocks) atomicOr(F.fail, 8u);
     *ticket = 0u;  // (re-armed for the next tick)
     if (__hip_atomic_load(F.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicOr(F.tick_fail, kFailFlow6);
   }

@@ -9,10 +9,10 @@ import sys
 
 
 def window_start(path, steps):
-    """start time of the `steps`-th tick from the end (a tick begins with k_reset_step): bench.py's timed region - or None when
-    the trace holds fewer ticks (then everything is summarised)"""
+    """start time of the `steps`-th tick from the end (a tick begins with its clearing launch: k_tick_clear, k_reset_step before round
+    3's merge): bench.py's timed region - or None when the trace holds fewer ticks (then everything is summarised)"""
     db = sqlite3.connect(path)
-    rows = db.execute("select start from kernels where name like '%k_reset_step%' order by start desc limit ?", (steps,)).fetchall()
+    rows = db.execute("select start from kernels where name like '%k_tick_clear%' or name like '%k_reset_step%' order by start desc limit ?", (steps,)).fetchall()
     return rows[-1][0] if len(rows) == steps else None
 
 
