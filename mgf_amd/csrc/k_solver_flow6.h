@@ -248,26 +248,31 @@ __device__ __forceinline__ void f6_links_body(const Flow6& F, const ConsLinks& K
   const uint32_t g = t / F.nb, na = ix.w, nbr = degb[x];
   if (na + nbr == 0u) return;
   uint32_t* row = rev + (size_t)x * rev_cap;
-  // the row in ascending constraint id = insertion order: up to four entries (most bodies) sorted in registers from one
-  // 16-byte load, longer rows in place
+  // the row in ascending constraint id = insertion order: up to eight entries (a settled pile's bodies have four on average, and
+  // beyond the four of round 2's register path every key of the insertion sort was two dependent look-ups) sorted in registers from
+  // two 16-byte loads, longer rows in place
   // (a store in internal order, `ext`: the insertion order across bodies is that of the order ids - rev_sort_key)
-  const bool small = nbr <= 4u && (rev_cap & 3u) == 0u;
-  uint32_t s4[4] = {kNone, kNone, kNone, kNone};
+  const bool small = nbr <= 8u && (rev_cap & 7u) == 0u;
+  uint32_t s8[8] = {kNone, kNone, kNone, kNone, kNone, kNone, kNone, kNone};
   if (small) {
     const uint4 r4 = *reinterpret_cast<const uint4*>(row);
-    s4[0] = nbr > 0u ? r4.x : kNone; s4[1] = nbr > 1u ? r4.y : kNone; s4[2] = nbr > 2u ? r4.z : kNone; s4[3] = nbr > 3u ? r4.w : kNone;
-    if (ext) {
-      unsigned long long k4[4];
+    uint4 r5 = make_uint4(kNone, kNone, kNone, kNone);
+    if (nbr > 4u) r5 = *reinterpret_cast<const uint4*>(row + 4);
+    s8[0] = nbr > 0u ? r4.x : kNone; s8[1] = nbr > 1u ? r4.y : kNone; s8[2] = nbr > 2u ? r4.z : kNone; s8[3] = nbr > 3u ? r4.w : kNone;
+    s8[4] = nbr > 4u ? r5.x : kNone; s8[5] = nbr > 5u ? r5.y : kNone; s8[6] = nbr > 6u ? r5.z : kNone; s8[7] = nbr > 7u ? r5.w : kNone;
+    unsigned long long k8[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) k4[j] = s4[j] != kNone ? rev_sort_key(K, ext, s4[j]) : ~0ull;  // (the four look-ups go out together)
-      auto cx = [&](int p, int q) { const unsigned long long lo = min(k4[p], k4[q]), hi = max(k4[p], k4[q]); k4[p] = lo; k4[q] = hi; };
-      cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);
+    for (int j = 0; j < 8; ++j) k8[j] = s8[j] != kNone ? rev_sort_key(K, ext, s8[j]) : ~0ull;  // (the look-ups go out together; ~0 = kNone sorts last)
+    auto cx = [&](int p, int q) { const unsigned long long lo = min(k8[p], k8[q]), hi = max(k8[p], k8[q]); k8[p] = lo; k8[q] = hi; };
+    // Batcher's odd-even merge sort of eight (nineteen exchanges)
+    cx(0, 1); cx(2, 3); cx(4, 5); cx(6, 7);
+    cx(0, 2); cx(1, 3); cx(4, 6); cx(5, 7);
+    cx(1, 2); cx(5, 6);
+    cx(0, 4); cx(1, 5); cx(2, 6); cx(3, 7);
+    cx(2, 4); cx(3, 5);
+    cx(1, 2); cx(3, 4); cx(5, 6);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s4[j] = (uint32_t)k4[j];  // (the id is the key's low half; ~0 = kNone)
-    } else {
-      auto cx = [&](int p, int q) { const uint32_t lo = min(s4[p], s4[q]), hi = max(s4[p], s4[q]); s4[p] = lo; s4[q] = hi; };
-      cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);  // (kNone = 0xFFFFFFFF sorts behind every id)
-    }
+    for (int j = 0; j < 8; ++j) s8[j] = (uint32_t)k8[j];  // (the id is the key's low half; ~0 = kNone)
   } else {
     for (uint32_t a = 1; a < nbr; ++a) {
       uint32_t v = row[a], b = a;
@@ -284,12 +289,9 @@ __device__ __forceinline__ void f6_links_body(const Flow6& F, const ConsLinks& K
   bool have_u = na != 0u;
   // the `b` entries four at a time: their look-ups (constraint -> body a -> block, slot; LDS index of x over there) are
   // independent of each other and go out together; the links are then written in order
-  for (uint32_t k0 = 0; k0 <= nbr; k0 += 4u) {
-    uint32_t c[4];
+  auto four = [&](uint32_t k0, const uint32_t c[4]) {
     uint4 ii[4];
     uint32_t br[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) c[j] = small ? (k0 == 0u ? s4[j] : kNone) : (k0 + (uint32_t)j < nbr ? row[k0 + (uint32_t)j] : kNone);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       ii[j] = make_uint4(0, 0, 0, 0); br[j] = 0u;
@@ -331,6 +333,19 @@ __device__ __forceinline__ void f6_links_body(const Flow6& F, const ConsLinks& K
       // the chain ends in a constraint of another block: that block writes the body's result, its own does not
       if (last && u.role == 1u && u.home != g) F.skipwb[x] = 1;
       u = w;
+    }
+  };
+  if (small) {
+    const uint32_t lo4[4] = {s8[0], s8[1], s8[2], s8[3]}, hi4[4] = {s8[4], s8[5], s8[6], s8[7]}, none[4] = {kNone, kNone, kNone, kNone};
+    four(0u, lo4);
+    if (nbr >= 4u) four(4u, hi4);
+    if (nbr == 8u) four(8u, none);
+  } else {
+    for (uint32_t k0 = 0; k0 <= nbr; k0 += 4u) {
+      uint32_t c[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[j] = k0 + (uint32_t)j < nbr ? row[k0 + (uint32_t)j] : kNone;
+      four(k0, c);
     }
   }
 }
