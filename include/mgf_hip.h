@@ -99,7 +99,7 @@ typedef struct mgf_step_stats {
   uint64_t n_refits;               /* bodies whose swept AABB left their fat AABB (world.rs:235)    */
   uint32_t n_levels;               /* depth of the order-preserving dependency DAG                  */
   uint32_t iters;
-  float ms_integrate, ms_broadphase, ms_narrowphase, ms_setup, ms_solve, ms_total; /* HIP-event times */
+  float ms_integrate, ms_broadphase, ms_narrowphase, ms_setup, ms_solve, ms_total; /* HIP-event times of the phases: 0 unless option "phase_timing" is on (each event is a barrier packet: ~50 us of an idle GPU per tick together) */
   uint64_t solver_kernel_launches; /* number of solver kernel launches this tick     */
   float ms_solver_kernels;         /* sum of their HIP-event durations (0 if not timed) */
   uint64_t n_ghost_constraints;    /* of n_constraints: those whose obj_a is a ghost body of a neighbouring tile - a constraint across
@@ -407,7 +407,7 @@ MGF_API int64_t mgf_tiles_counter(const mgf_tiles* t, const char* key);
  * "grid_min_frac_pct" [50] (axes of the scene shorter than this percentage of the longest one are widened to it before
  * the Morton cells are laid over it: cells stay near-cubic in an x-slab tile);
  * "flow6_fcap", "flow6_const_lds", "flow6_poll_waves", "flow6_test_cap" (mode 6: foreign-body slots, constants in LDS,
- * polling waves, a test limit that forces the stand-by kernel); "two_pass_candidates" [0]; "broadphase_tree" [0]; "terrain_tree" [0]; "no_fused_narrowphase" [0] (a world of spheres only runs the sphere-sphere test inside the grid broadphase and lists contacts only; 1 = list every accepted partner); "stream_ordered" [0]; "spin_wait" [1] (the tick's one wait polls an event instead of blocking); "pipeline" [1] (mgf_world_step_many enqueues the next tick before it waits for this one); "cell_fill" [16] (bodies per Morton cell, in eighths, beyond which the broadphase grid gets another level); "no_fused_terrain_rows" [0], "no_fused_scene_bounds" [0] (mgf_world_step and mgf_world_begin_tick list the terrain faces of a body and gather the scene bounds inside the integration kernel; 1 = always the separate kernels); "list_capacity";
+ * polling waves, a test limit that forces the stand-by kernel); "two_pass_candidates" [0]; "broadphase_tree" [0]; "terrain_tree" [0]; "no_fused_narrowphase" [0] (a world of spheres only runs the sphere-sphere test inside the grid broadphase and lists contacts only; 1 = list every accepted partner); "stream_ordered" [0]; "phase_timing" [0] (HIP events at the tick's phase boundaries: mgf_step_stats::ms_*), "time_solver_kernels" [0] (events around the solver launches: ms_solver_kernels); "spin_wait" [1] (the tick's one wait polls an event instead of blocking); "pipeline" [1] (mgf_world_step_many enqueues the next tick before it waits for this one); "cell_fill" [16] (bodies per Morton cell, in eighths, beyond which the broadphase grid gets another level); "no_fused_terrain_rows" [0], "no_fused_scene_bounds" [0] (mgf_world_step and mgf_world_begin_tick list the terrain faces of a body and gather the scene bounds inside the integration kernel; 1 = always the separate kernels); "list_capacity";
  * "flow_blocks_per_cu"; "flow_sleep"; "flow_trace"; "debug_bvh"; "flow5_block", "flow5_slow_x2", "flow5_poller", "flow5_test_cap" (block-local solver: block size, wave split, polling wave, a test limit that forces the stand-by kernel); "body_kinds" (OR-in, bit0 sphere, bit1 capsule): the
  * kinds this world's ghosts may have - a tile whose own bodies are all of one kind must be told when a neighbour's are
  * not, because the narrowphase dispatch is chosen on the host (the tiles driver exchanges the masks with the counts). */

@@ -111,6 +111,15 @@ __global__ __launch_bounds__(kBlock) void k_zero_many(ZeroList z) {
 // The fused tick's first launch: k_reset_step and k_zero_many in one, AHEAD of k_integrate (round 3: a launch less per tick).
 // Nothing it clears is read by k_integrate; what k_integrate's tail writes (the owned bodies' terrain counts, the row-overflow flag)
 // it writes afterwards.  The partial scene bounds are folded by k_morton_count instead.
+// The tick's read-back without a copy engine and without an event (round 3): the block of counts, bounds and flags is written straight
+// into the world's pinned host memory, then - behind a system-scope fence - the slot's sequence word; the host polls that word.
+// (hipMemcpyAsync + hipEventRecord put a blit kernel and a barrier packet between two ticks: 11.6 us of an idle GPU per tick.)
+__global__ __launch_bounds__(kBlock) void k_publish(const uint32_t* rb, uint32_t* pin, uint32_t words, uint32_t seq_word, uint32_t seq) {
+  for (uint32_t i = threadIdx.x; i < words; i += kBlock) pin[i] = rb[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(pin + seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ __launch_bounds__(kBlock) void k_tick_clear(ZeroList z, SceneBounds* sb, uint32_t* err, uint32_t* guard, const uint32_t* prev_fail, int spec,
                                                        int* sb_part) {
   // (see k_reset_step: a speculative tick behind a failed one raises the guard and resets nothing - but the counters are cleared all

@@ -77,6 +77,7 @@ def test_solver_handle_at_full_size_is_as_fast_as_the_worlds_own_solve(ctx):
     snap = own.clone()
     for _ in range(3):   # the world's own solve of its list (a fresh clone each time: same velocities)
         w = snap.clone()
+        w.set_option("phase_timing", 1)   # (mgf_step_stats::ms_solve: HIP events around the solve phase)
         w.build_constraints(dt)
         ms_own.append(w.solve(iters).ms_solve)
     sv = mgf_amd.Solver()
@@ -84,6 +85,7 @@ def test_solver_handle_at_full_size_is_as_fast_as_the_worlds_own_solve(ctx):
     ms_list = []
     for _ in range(3):
         w = snap.clone()
+        w.set_option("phase_timing", 1)
         w.build_constraints(dt)      # (the spatial order of the bodies: the caller's list is cut into blocks by it)
         sv.clear()
         sv.add_constraints(lst)

@@ -177,6 +177,8 @@ def test_dataflow_solver_full_size_stress(ctx, mode):
     a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
     a.set_option("solver_mode", 0)
     b.set_option("solver_mode", mode)
+    for w in (a, b):
+        w.set_option("phase_timing", 1)  # (the solve phase's span, printed below)
     ms_a = ms_b = 0.0
     for step in range(40):
         sa, sb = a.step(dt, iters), b.step(dt, iters)

@@ -8,6 +8,7 @@ sc = scenes.capsule_field(128, 32, 32, quads=158) if which == 'config3' else sce
 dt = float(sc['dt'])
 for fill in [int(a) for a in sys.argv[2:]] or [0]:
     w = mgf_amd.World.from_scene(ctx, sc)
+    w.set_option('phase_timing', 1)
     if fill: w.set_option('cell_fill', fill)
     out = []
     for t in range(40):

@@ -13,6 +13,7 @@ for name, make in cases.items():
     if sc is None: continue
     for fill in (8, 16, 32):
         w = mgf_amd.World.from_scene(ctx, sc)
+        w.set_option('phase_timing', 1)
         w.set_option("cell_fill", fill)
         bp, tot = [], []
         for s in range(40):

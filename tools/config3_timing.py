@@ -6,6 +6,7 @@ from mgf_amd import scenes
 ctx = mgf_amd.Context(0)
 sc = scenes.capsule_field(128, 32, 32, quads=158)
 w = mgf_amd.World.from_scene(ctx, sc)
+w.set_option('phase_timing', 1)
 ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 80
 t = []; ph = None
 for s in range(ticks):

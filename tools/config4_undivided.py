@@ -10,6 +10,7 @@ warm, steps = 10, 60
 ctx = mgf_amd.Context(0)
 sc = scenes.sphere_pile(128, 128, 64)
 w = mgf_amd.World.from_scene(ctx, sc)
+w.set_option("phase_timing", 1)  # (ms_solve below)
 dt, it = float(sc["dt"]), sc["iters"]
 for _ in range(warm):
     w.step(dt, it)

@@ -22,6 +22,7 @@ def main():
     sc = scenes.dumbbell_field(*a.dims, n_plain=a.plain)
     ctx = mgf_amd.Context(0)
     w = mgf_amd.World.from_scene(ctx, sc)
+    w.set_option('phase_timing', 1)
     dt, iters = float(sc["dt"]), sc["iters"]
     for kv in a.opt:
         key, val = kv.split("=")

@@ -5,6 +5,7 @@ from mgf_amd import scenes
 ctx = mgf_amd.Context(0)
 sc = scenes.sphere_pile(64, 64, 64)
 w = mgf_amd.World.from_scene(ctx, sc)
+w.set_option('phase_timing', 1)
 w.set_option('debug_bvh', 1)
 for s in range(90):
     st = w.step(float(sc['dt']), 10)

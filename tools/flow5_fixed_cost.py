@@ -8,6 +8,7 @@ sc = scenes.sphere_pile(64, 64, 64)
 for mode in (5, 1):
     for iters in (1, 2, 5, 10, 20):
         w = mgf_amd.World.from_scene(ctx, sc)
+        w.set_option('phase_timing', 1)
         w.set_option('solver_mode', mode)
         w.set_option('time_solver_kernels', 1)
         ms = []; km = []

@@ -46,6 +46,7 @@ sc = scenes.sphere_pile(64, 64, 64)
 ok &= run(sc, 30, 5, label="pile 64^3")
 for mode in ((6,) if os.environ.get('MGF_F6_ONLY') else (5, 6)):
     w = mgf_amd.World.from_scene(ctx, sc)
+    w.set_option('phase_timing', 1)
     w.set_option("solver_mode", mode)
     for k, v in OPTS:
         w.set_option(k, int(v))

@@ -10,6 +10,7 @@ from mgf_amd.tiles import HipEngine, Tile, step_tiles_inprocess
 ctx = mgf_amd.Context(0)
 sc = scenes.sphere_pile_tile(64, 64, 64, 0, 2)
 w = mgf_amd.World.from_scene(ctx, sc)
+w.set_option('phase_timing', 1)
 bp = []
 for s in range(40):
     st = w.step(float(sc["dt"]), 10)

@@ -11,6 +11,7 @@ for spec in specs:
     f = [int(x) for x in spec.split(':')] + [0, 0, 0]
     mode, bpc, sl, k = f[0], f[1], f[2], f[3]
     w = mgf_amd.World.from_scene(ctx, sc)
+    w.set_option('phase_timing', 1)
     w.set_option('solver_mode', mode)
     if bpc: w.set_option('flow_blocks_per_cu', bpc)
     w.set_option('flow_sleep', sl)
