@@ -143,6 +143,7 @@ def test_a_failed_tick_is_reported_at_its_end_and_moves_nobody(ctx, connected):
         T.connect(mgf_amd.rccl_unique_id(), 0, 1)
         assert T.preflight() == 1
     T.set_option("test_fail_tick", 4)
+    T.set_option("exchange_timing", 1)
     dt, iters = float(tile_scenes[0]["dt"]), tile_scenes[0]["iters"]
     for _ in range(4):
         T.step(dt, iters)
