@@ -209,3 +209,31 @@ def test_world_clone_is_independent_and_steps_identically(ctx):
         b.set(0, (5, 5, 5), (0, 0, 0))  # writing to the clone leaves the original alone
         assert not bits_equal(a.state()["v"], b.state()["v"])
         assert bits_equal(a.state()["v"], sa["v"])
+
+
+def test_tick_without_events_and_the_two_read_back_paths(ctx):
+    """The tick records no HIP event unless asked (option phase_timing: mgf_step_stats::ms_* read 0 otherwise), and its read-back goes
+    by a kernel into pinned memory with a polled sequence word (readback_kernel, default) or by hipMemcpyAsync + an event: same bits,
+    through step, step_many (pipelined: two read-backs in flight) and build_constraints / solve."""
+    from mgf_amd import scenes
+    scene = scenes.sphere_pile(10, 9, 10)
+    dt, iters = float(scene["dt"]), scene["iters"]
+    a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
+    b.set_option("readback_kernel", 0)
+    b.set_option("phase_timing", 1)
+    for _ in range(5):
+        sa, sb = a.step(dt, iters), b.step(dt, iters)
+    assert sa.ms_total == 0.0 and sa.ms_solve == 0.0 and sa.ms_broadphase == 0.0
+    assert sb.ms_total > 0.0 and sb.ms_solve > 0.0 and sb.ms_broadphase > 0.0
+    pa, pb = a.step_many(dt, iters, 25), b.step_many(dt, iters, 25)
+    assert [int(s.n_constraints) for s in pa] == [int(s.n_constraints) for s in pb] and int(pa[24].n_constraints) > 0
+    assert all(float(s.ms_total) == 0.0 for s in pa) and all(float(s.ms_total) > 0.0 for s in pb)
+    for w in (a, b):
+        w.build_constraints(dt)
+        w.solve(iters)
+    sa, sb = a.state(), b.state()
+    for k in ("x", "q", "v", "omega", "delta"):
+        assert np.array_equal(sa[k].view(np.uint32), sb[k].view(np.uint32)), k
+    a.set_option("phase_timing", 1)   # switched on in mid-run: figures from the next tick on, nothing read from unrecorded events
+    s = a.step(dt, iters)
+    assert s.ms_total > 0.0
