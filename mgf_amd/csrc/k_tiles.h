@@ -96,10 +96,12 @@ __device__ __forceinline__ void import_ghost(Bodies B, uint32_t i, const float* 
   B.ctor[i] = make_float4(pc ? u2f(2u) : o[16], k.r, 0.0f, 0.0f);
   B.imb[3 * i] = make_float4(0, 0, 0, 0); B.imb[3 * i + 1] = make_float4(0, 0, 0, 0); B.imb[3 * i + 2] = make_float4(0, 0, 0, 0);
 }
-__global__ __launch_bounds__(kBlock) void k_import_ghosts(Bodies B, uint32_t n_owned, uint32_t m, const float* in, float fat_margin, int* sb_part) {
+// (in2 / m1: the rows from m1 on come from a second buffer - the two neighbours' send buffers read in place, no copy in between)
+__global__ __launch_bounds__(kBlock) void k_import_ghosts(Bodies B, uint32_t n_owned, uint32_t m, const float* in, float fat_margin, int* sb_part,
+                                                          const float* in2 = nullptr, uint32_t m1 = 0xFFFFFFFFu) {
   uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   int blo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, bhi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000}, brm[3] = {0, 0, 0};
-  if (t < m) import_ghost(B, n_owned + t, in + (size_t)t * kGhostFloats, fat_margin, blo, bhi, brm);
+  if (t < m) import_ghost(B, n_owned + t, t < m1 ? in + (size_t)t * kGhostFloats : in2 + (size_t)(t - m1) * kGhostFloats, fat_margin, blo, bhi, brm);
   if (sb_part) bounds_block_accumulate(blo, bhi, brm, sb_part);  // the scene bounds gathered by this tick's k_integrate take the ghosts in
 }
 // velocity record: 8 floats (v3, w3, 0, 0)
@@ -113,13 +115,15 @@ __global__ __launch_bounds__(kBlock) void k_export_vel(const float4* srec, const
   out[2 * t] = s0;
   out[2 * t + 1] = make_float4(s1.x, s1.y, 0.0f, 0.0f);
 }
-__global__ __launch_bounds__(kBlock) void k_import_ghost_vel(float4* srec, uint32_t n_owned, uint32_t m, const float4* in) {
+__global__ __launch_bounds__(kBlock) void k_import_ghost_vel(float4* srec, uint32_t n_owned, uint32_t m, const float4* in, const float4* in2 = nullptr,
+                                                             uint32_t m1 = 0xFFFFFFFFu) {
   uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= m) return;
   uint32_t i = n_owned + t;
-  srec[4 * i] = in[2 * t];
+  const float4* r = t < m1 ? in + 2 * (size_t)t : in2 + 2 * (size_t)(t - m1);
+  srec[4 * i] = r[0];
   float2* p = reinterpret_cast<float2*>(&srec[4 * i + 1]);
-  *p = make_float2(in[2 * t + 1].x, in[2 * t + 1].y);
+  *p = make_float2(r[1].x, r[1].y);
 }
 
 // ---- migration of owned bodies between tiles -----------------------------------------------------
