@@ -84,6 +84,7 @@ struct Flow6 {
   uint32_t* tick_fail;       // the tick's StepCounts::fail: gets kFailFlow6 when `fail` is up after the preparation (the host re-runs the tick)
   uint32_t* max_slots;       // largest block / most foreign bodies of this tick (the host sizes the next tick's LDS split)
   uint32_t* max_foreign;
+  uint32_t ident;            // 1: sidx and brank are the identity (blocks cut from the slots of a re-sorted store): their look-ups are skipped
   uint32_t nb, nblocks, n;
   uint32_t rows;             // table rows per block
   uint32_t fcap, slot_cap;   // LDS split of this launch: foreign body slots, constraint slots
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(kF6PrepThreads) void k_flow6_blocks(Flow6 F, ConsLi
   for (uint32_t p0 = p_lo; p0 < p_hi; p0 += kBlock) {
     const uint32_t p = p0 + t;
     uint32_t x = 0, b0 = 0, cnt = 0;
-    if (p < p_hi) { x = F.sidx[p]; b0 = F.base[x]; cnt = F.base[x + 1] - b0; }
+    if (p < p_hi) { x = F.ident ? p : F.sidx[p]; b0 = F.base[x]; cnt = F.base[x + 1] - b0; }
     uint32_t inc = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if ((int)lane >= o) inc += u; }
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(kF6PrepThreads) void k_flow6_blocks(Flow6 F, ConsLi
 #pragma unroll
       for (int j = 0; j < 4; ++j) b[j] = k0 + (uint32_t)j < cnt ? K.ab[b0 + k0 + (uint32_t)j].y : kNone;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) pb[j] = b[j] != kNone ? F.brank[b[j]] : 0u;
+      for (int j = 0; j < 4; ++j) pb[j] = b[j] != kNone ? (F.ident ? b[j] : F.brank[b[j]]) : 0u;
       if (k0 == 0u) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { keep_b[j] = b[j]; keep_pb[j] = pb[j]; }
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(kF6PrepThreads) void k_flow6_blocks(Flow6 F, ConsLi
   // every own constraint's row: id, LDS indices of its bodies, the link to the next constraint of body a's own range (the
   // last of the range is linked by k_flow6_links, which knows where the body's chain goes on)
   for (uint32_t p = p_lo + t; p < p_hi; p += kBlock) {
-    const uint32_t x = F.sidx[p];
+    const uint32_t x = F.ident ? p : F.sidx[p];
     const uint4 ix = F.binfo[x];
     const uint32_t aref = p - g * F.nb;
     if (aref >= kF6NoBody) atomicOr(F.fail, 16u);
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kF6PrepThreads) void k_flow6_blocks(Flow6 F, ConsLi
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[j] = k0 + (uint32_t)j < ix.w ? K.ab[ix.z + k0 + (uint32_t)j].y : kNone;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pb[j] = b[j] != kNone ? F.brank[b[j]] : 0u;
+        for (int j = 0; j < 4; ++j) pb[j] = b[j] != kNone ? (F.ident ? b[j] : F.brank[b[j]]) : 0u;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -243,7 +244,7 @@ __device__ __forceinline__ void f6_links_body(const Flow6& F, const ConsLinks& K
     return;
   }
   if (t >= n || sc->fail) return;
-  const uint32_t x = F.sidx[t];
+  const uint32_t x = F.ident ? t : F.sidx[t];
   const uint4 ix = F.binfo[x];  // (position = t, first slot, first constraint, constraints of its own)
   const uint32_t g = t / F.nb, na = ix.w, nbr = degb[x];
   if (na + nbr == 0u) return;
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
   __amdgpu_buffer_rsrc_t rmb = make_rsrc(F.mbox);
   // every body this block touches: its own, then the foreign ones
   for (uint32_t i = t; i < n_own + n_for; i += kF6Threads) {
-    const uint32_t x = i < n_own ? F.sidx[p_lo + i] : F.fbody[(size_t)g * F.fcap + (i - n_own)];
+    const uint32_t x = i < n_own ? (F.ident ? p_lo + i : F.sidx[p_lo + i]) : F.fbody[(size_t)g * F.fcap + (i - n_own)];
     const uint32_t idx = i < n_own ? i : F.nb + (i - n_own);
     const float4 r0 = srec[4 * (size_t)x], r1 = srec[4 * (size_t)x + 1];
     s_body[2 * idx] = r0;
@@ -877,7 +878,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
   if (NL) for (uint32_t idx = t; idx < N; idx += kF6Threads) cons[s_c[idx]].nimp = s_nimp[idx];
   // own bodies go back to the RigidBodyVec (a body whose chain ends in another block was written there)
   for (uint32_t i = t; i < n_own; i += kF6Threads) {
-    const uint32_t x = F.sidx[p_lo + i];
+    const uint32_t x = F.ident ? p_lo + i : F.sidx[p_lo + i];
     if (!F.skipwb[x]) {
       srec[4 * (size_t)x] = s_body[2 * i];
       const float4 s1 = s_body[2 * i + 1];
