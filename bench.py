@@ -122,7 +122,10 @@ def main():
         out = bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, world_size, dist, torch, red_dev, barrier, refresh_every)
     if rank == 0:
         if world_size == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.iters)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.iters)
+            except Exception as e:  # (the line with the GPU measurement is printed whatever happens to the CPU sample)
+                out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
@@ -225,8 +228,11 @@ def bench_single_world(args, ctx, mgf_amd, scenes, configure, mode):
         "instrumentation": INSTRUMENTATION_NOTE,
     }
     if not args.no_order_check:
-        out["constraint_order_deviation"] = order_deviation(ctx, mgf_amd, scene, dt, args.iters)
-        out["constraint_order_demo_cost"] = demo_order_cost(ctx, mgf_amd, scenes, scene, args.iters)
+        try:
+            out["constraint_order_deviation"] = order_deviation(ctx, mgf_amd, scene, dt, args.iters)
+            out["constraint_order_demo_cost"] = demo_order_cost(ctx, mgf_amd, scenes, scene, args.iters)
+        except Exception as e:
+            out["constraint_order_deviation"] = {"error": repr(e)}
     if not args.no_settled:
         # the settled pile (what the workload spends its life in): twice the constraints, deeper dependency graph
         while_ticks = max(0, 400 - args.warmup - args.steps)
@@ -251,7 +257,10 @@ def bench_single_world(args, ctx, mgf_amd, scenes, configure, mode):
         # BASELINE configs 3 and 5 on the same GPU, one short window each (their own lines: python bench.py --scene config3 / config5)
         del world, snap
         for kind in ("config3", "config5"):
-            out[kind] = bench_other_config(args, ctx, mgf_amd, scenes, configure, mode, kind, standalone=False)
+            try:
+                out[kind] = bench_other_config(args, ctx, mgf_amd, scenes, configure, mode, kind, standalone=False)
+            except Exception as e:  # (a nested figure: never at the price of the line)
+                out[kind] = {"error": repr(e)}
     return out
 
 
