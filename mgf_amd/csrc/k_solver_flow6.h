@@ -42,6 +42,8 @@ constexpr uint32_t kF6MaxIters = 64;                   // (ring positions are re
 constexpr uint32_t kF6WlLen = 128;                     // work items (channel, position) a polling wave lists per sweep
 constexpr uint32_t kF6MaxPollers = 4;
 constexpr uint32_t kF6CntStride = 32;                  // words between per-block counters (same-line atomics serialise)
+constexpr uint32_t kF6TraceWords = 16;                 // TRACE: 64-bit words of statistics per block behind the node stamps (polling: 0-6; clocks: 8 entry,
+                                                       // 9 bodies in LDS, 10 tables in LDS, 11 serving loop left, 12 written back)
 
 // One 32-byte row per slot, written once per tick - the constraint's own part and the links inside a body's own range by
 // k_flow6_blocks, the links that need the body's whole chain by k_flow6_links - and copied into LDS by the solve kernel.
@@ -550,6 +552,8 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
                                                             uint32_t spin_limit, uint64_t* trace, uint32_t C_trace) {
   if (*F.fail || *F.C_ptr == 0u) return;  // a limit was exceeded: the stand-by k_solve_flow launch behind this one does the work
   extern __shared__ float4 s_dyn[];
+  uint64_t* tstat = TRACE ? trace + 2 * (size_t)iters * C_trace + kF6TraceWords * (size_t)blockIdx.x : nullptr;
+  if (TRACE && threadIdx.x == 0) tstat[8] = wall_clock64();
   const uint32_t nbod = F.nb + F.fcap, cap = F.slot_cap;
   float4* s_body = s_dyn;                                              // [2 * nbod]: {v, w.x}, {w.y, w.z, body id, -}
   float2* s_const = reinterpret_cast<float2*>(s_dyn + 2 * (size_t)nbod);  // CL: [5 * nb] inverse mass and inertia of the own bodies
@@ -615,6 +619,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
     if (t == 0) s_ctl[3] = (uint32_t)__popcll(m);
   }
   __syncthreads();
+  if (TRACE && threadIdx.x == 0) tstat[9] = wall_clock64();
   // the block's slot table (built once per tick by k_flow6_blocks and k_flow6_links)
   const F6Row* rows = F.table + (size_t)g * F.rows;
   for (uint32_t idx = t; idx < N; idx += kF6Threads) {
@@ -627,6 +632,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
     if (st0 == 0u && iters > 0) f6_push(q, idx);  // iteration 0's frontier
   }
   __syncthreads();
+  if (TRACE && threadIdx.x == 0) tstat[10] = wall_clock64();
   const uint32_t wave = t >> 6, lane = t & 63u, nwaves = kF6Threads / 64u;
   const uint32_t n_in = s_ctl[3];
   // the last F.poll_waves waves poll the incoming channels (channel r belongs to poller r % P), the others serve the queue
@@ -756,7 +762,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
       }
     }
     if (TRACE) {  // per block: sweeps of the first polling lane, messages, latency sum / max (clock ticks), full batches
-      uint64_t* st = trace + 2 * (size_t)iters * C_trace + 8 * (size_t)g;
+      uint64_t* st = trace + 2 * (size_t)iters * C_trace + kF6TraceWords * (size_t)g;
       if (lane == 0 && pw == 0) st[0] = st_sweeps;
       atomicAdd(reinterpret_cast<unsigned long long*>(&st[1]), (unsigned long long)st_hits);
       atomicAdd(reinterpret_cast<unsigned long long*>(&st[2]), (unsigned long long)st_lat_sum);
@@ -874,6 +880,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
     }
   }
   __syncthreads();
+  if (TRACE && threadIdx.x == 0) tstat[11] = wall_clock64();
   // the accumulated normal impulses go back to the records (ContactState lives on: mgf_world_read_constraints, a later solve)
   if (NL) for (uint32_t idx = t; idx < N; idx += kF6Threads) cons[s_c[idx]].nimp = s_nimp[idx];
   // own bodies go back to the RigidBodyVec (a body whose chain ends in another block was written there)
@@ -885,6 +892,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
       *reinterpret_cast<float2*>(&srec[4 * (size_t)x + 1]) = make_float2(s1.x, s1.y);
     }
   }
+  if (TRACE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (threadIdx.x == 0) tstat[12] = wall_clock64(); }
 }
 
 }  // namespace mgf
