@@ -12,7 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmgf_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
+# -fno-slp-vectorize: the SLP pass packs the solver's scalar f32 arithmetic into v_pk_* pairs glued together with v_mov shuffles; the
+# serving loop of k_solve_flow6 is one lane's dependent chain, where the plain form is 2-5 % faster (profiles/r04_noslp.txt)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 UNITS = ["prims.hip", "mgf_hip.hip"]
 

@@ -42,7 +42,7 @@ constexpr uint32_t kF6MaxIters = 64;                   // (ring positions are re
 constexpr uint32_t kF6WlLen = 128;                     // work items (channel, position) a polling wave lists per sweep
 constexpr uint32_t kF6MaxPollers = 4;
 constexpr uint32_t kF6CntStride = 32;                  // words between per-block counters (same-line atomics serialise)
-constexpr uint32_t kF6TraceWords = 16;                 // TRACE: 64-bit words of statistics per block behind the node stamps (polling: 0-6; clocks: 8 entry,
+constexpr uint32_t kF6TraceWords = 24;                 // TRACE: 64-bit words of statistics per block behind the node stamps (polling: 0-6; clocks: 8 entry,
                                                        // 9 bodies in LDS, 10 tables in LDS, 11 serving loop left, 12 written back)
 
 // One 32-byte row per slot, written once per tick - the constraint's own part and the links inside a body's own range by
@@ -91,11 +91,14 @@ struct Flow6 {
   uint32_t rows;             // table rows per block
   uint32_t fcap, slot_cap;   // LDS split of this launch: foreign body slots, constraint slots
   uint32_t poll_waves, poll_k;  // waves that poll the incoming channels; 1: every sweep through the worklist, >= 2: quiet sweeps read straight
+  uint32_t chain_trips;         // CH: trips a serving wave may spend on its kept successors alone before it visits the queue again
   uint32_t poll_prio;           // s_setprio of the polling waves (0..3): their few instructions issue ahead of the serving waves'
 };
-__host__ __device__ constexpr uint32_t f6_slot_bytes(bool nimp_lds) { return nimp_lds ? 22u : 18u; }  // successor words 8, id 4, state 4, ring 2 (+ impulse 4)
-__host__ __device__ constexpr uint32_t f6_lds_bytes(uint32_t nb, uint32_t fcap, uint32_t slot_cap, bool const_lds = false, bool nimp_lds = false) {
-  return 32u * (nb + fcap) + (const_lds ? 40u * nb : 0u) + f6_slot_bytes(nimp_lds) * slot_cap + 4u * (16u + 8u * kF6Chan) + 4u * (2u * kF6WlLen + 16u) + 32u;
+constexpr uint32_t kF6RecWords = 5;  // RL: float4 words of a constraint's solver half in LDS (80 bytes: CRec words 2..20 and the accumulated impulse)
+// successor words 8, id 4, state 4, ring 2 (+ impulse 4; or + the record's solver half 80, which holds the impulse)
+__host__ __device__ constexpr uint32_t f6_slot_bytes(bool nimp_lds, bool rec_lds = false) { return rec_lds ? 18u + 16u * kF6RecWords : (nimp_lds ? 22u : 18u); }
+__host__ __device__ constexpr uint32_t f6_lds_bytes(uint32_t nb, uint32_t fcap, uint32_t slot_cap, int const_lds = 0, bool nimp_lds = false, bool rec_lds = false) {
+  return 32u * (nb + fcap) + (const_lds == 2 ? 40u * (nb + fcap) : const_lds == 1 ? 40u * nb : 0u) + f6_slot_bytes(nimp_lds, rec_lds) * slot_cap + 4u * (16u + 8u * kF6Chan) + 4u * (2u * kF6WlLen + 16u) + 32u;
 }
 
 // ---- preparation, once per constraint list ------------------------------------------------------------------------------
@@ -547,7 +550,16 @@ __device__ __forceinline__ void f6_arrive(const F6Ring& q, uint32_t* s_state, ui
 // chosen by the host when the block's constraints leave room for it (the first ~100 ticks of the bench pile); otherwise the
 // lanes read it from the RigidBodyVec beside the constraint record.
 // NL: ContactState::normal_impulse of every slot's constraint lives in LDS for the launch as well (4 bytes per slot, when there is room).
-template <bool TRACE, bool CL, bool NL>
+// RL: the solver half of EVERY constraint record of the block (normal, tangents, arms, bias, effective masses: 76 bytes) and its
+// accumulated impulse live in LDS for the launch as well, read once in the prologue by coalesced loads - chosen by the host when
+// the block's slots leave room for 80 more bytes each (worlds of few constraints per block: BASELINE configs 3 and 5, tiles).  A
+// node then touches no global memory at all (with CL; messages apart): its service is LDS reads + arithmetic.  Implies NL's effect.
+#ifdef MGF_F6_PROFILE  // (the profile build measures the trips themselves: no per-node clock reads, whose latency would be most of a trip)
+#define F6_NODE_CLOCK() 0ull
+#else
+#define F6_NODE_CLOCK() wall_clock64()
+#endif
+template <bool TRACE, int CL, bool NL, bool RL, bool CH>
 __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* cons, Flow6 F, uint32_t iters, uint32_t epoch, uint32_t* abort_flag,
                                                             uint32_t spin_limit, uint64_t* trace, uint32_t C_trace) {
   if (*F.fail || *F.C_ptr == 0u) return;  // a limit was exceeded: the stand-by k_solve_flow launch behind this one does the work
@@ -555,15 +567,17 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
   uint64_t* tstat = TRACE ? trace + 2 * (size_t)iters * C_trace + kF6TraceWords * (size_t)blockIdx.x : nullptr;
   if (TRACE && threadIdx.x == 0) tstat[8] = wall_clock64();
   const uint32_t nbod = F.nb + F.fcap, cap = F.slot_cap;
+  constexpr bool NLS = NL && !RL;                                      // the impulses in an array of their own
   float4* s_body = s_dyn;                                              // [2 * nbod]: {v, w.x}, {w.y, w.z, body id, -}
-  float2* s_const = reinterpret_cast<float2*>(s_dyn + 2 * (size_t)nbod);  // CL: [5 * nb] inverse mass and inertia of the own bodies
-  uint2* s_succ = reinterpret_cast<uint2*>(s_const + (CL ? 5 * (size_t)F.nb : 0));  // [cap]
+  float4* s_rec = s_dyn + 2 * (size_t)nbod;                            // RL: [kF6RecWords * cap] CRec words 4..19, then {n.x, n.y, tmass1, nimp}
+  float2* s_const = reinterpret_cast<float2*>(s_rec + (RL ? kF6RecWords * (size_t)cap : 0u));  // CL: [5 * nb] inverse mass and inertia of the own bodies
+  uint2* s_succ = reinterpret_cast<uint2*>(s_const + (CL == 2 ? 5 * (size_t)nbod : CL == 1 ? 5 * (size_t)F.nb : 0));  // [cap]
   uint32_t* s_c = reinterpret_cast<uint32_t*>(s_succ + cap);           // [cap]
   uint32_t* s_state = s_c + cap;                                       // [cap] arrivals missing | iterations done | body references (kF6St*)
   float* s_nimp = reinterpret_cast<float*>(s_state + cap);            // [cap] ContactState::normal_impulse of the slot's constraint: read and written
                                                                        // once per solve - in LDS (NL), not in the record (a 4-byte store per solve
                                                                        // costs the launch 8 %: it queues in front of the next records' loads)
-  uint32_t* s_ctl = reinterpret_cast<uint32_t*>(s_nimp + (NL ? cap : 0u));  // [16]: 0 head, 1 tail, 2 nodes left, 3 incoming channels
+  uint32_t* s_ctl = reinterpret_cast<uint32_t*>(s_nimp + (NLS ? cap : 0u));  // [16]: 0 head, 1 tail, 2 nodes left, 3 incoming channels
   uint32_t* s_out_base = s_ctl + 16;                                   // [kF6Chan] first message of the outgoing channel
   uint32_t* s_out_tail = s_out_base + kF6Chan;                         // [kF6Chan] messages sent
   uint32_t* s_out_tidx = s_out_tail + kF6Chan;                         // [kF6Chan] the channel's word of F.tails
@@ -590,7 +604,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
     const float4 r0 = srec[4 * (size_t)x], r1 = srec[4 * (size_t)x + 1];
     s_body[2 * idx] = r0;
     s_body[2 * idx + 1] = make_float4(r1.x, r1.y, u2f(x), 0.0f);
-    if (CL && i < n_own) {
+    if (CL == 2 || (CL == 1 && i < n_own)) {
       const float4 r2 = srec[4 * (size_t)x + 2], r3 = srec[4 * (size_t)x + 3];
       s_const[5 * idx] = make_float2(r1.z, r1.w); s_const[5 * idx + 1] = make_float2(r2.x, r2.y); s_const[5 * idx + 2] = make_float2(r2.z, r2.w);
       s_const[5 * idx + 3] = make_float2(r3.x, r3.y); s_const[5 * idx + 4] = make_float2(r3.z, r3.w);
@@ -628,7 +642,13 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
     const uint4 r1 = src[1];
     const uint32_t st0 = r1.x + r1.y;
     s_c[idx] = r0.x; s_succ[idx] = make_uint2(r0.z, r0.w); s_state[idx] = st0 | (r0.y << kF6StRefShift);
-    if (NL) s_nimp[idx] = cons[r0.x].nimp;  // (0 in a tick's first Solver::solve; what the last one left in a later one)
+    if (RL) {
+      const float4* g = reinterpret_cast<const float4*>(&cons[r0.x]);
+      const float4 g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], g4 = g[4], g5 = g[5];
+      float4* d = s_rec + kF6RecWords * (size_t)idx;
+      d[0] = g1; d[1] = g2; d[2] = g3; d[3] = g4; d[4] = make_float4(g0.z, g0.w, g5.x, g5.z);
+    }
+    if (NLS) s_nimp[idx] = cons[r0.x].nimp;  // (0 in a tick's first Solver::solve; what the last one left in a later one)
     if (st0 == 0u && iters > 0) f6_push(q, idx);  // iteration 0's frontier
   }
   __syncthreads();
@@ -771,48 +791,82 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
       if (lane == 0 && pw == 0) { st[5] = n_in; st[6] = st_wait; }
     }
   } else {
+    // The serving loop, written for few LDS round trips (r04: a trip's time is its dependent LDS accesses - ~150 clocks each - and, until
+    // CL == 2, a global fetch of a foreign body's constants; the solve's arithmetic is a tenth of it: tools/r04_trip_profile.py).
+    // CH: a lane KEEPS a local successor that its own release made ready and runs it in the wave's next trip - no push, no pop, no
+    // wait for a wave to come by (the state word comes back with the release's own atomic) - and while the wave has such lanes it
+    // skips the queue for up to F.chain_trips trips, so that a chain inside a block advances by operand loads + arithmetic + one release.
+    constexpr uint32_t kNoSlot = 0xFFFFFFFFu, kSlotMask = (1u << kF6SlotBits) - 1u;
+    uint32_t my_slot = kNoSlot, my_stw = 0u, since_pop = 0u;
+    uint32_t* s_dummy = s_ctl + 8;  // [2] words nobody reads: the target of a release that has no local successor on a side
+#ifdef MGF_F6_PROFILE  // (variant build: where a trip's time goes, shader clocks summed over wave 0's trips -> the block's trace words 13..21)
+    uint64_t pf_t0 = 0, pf_t1 = 0, pf_t2 = 0, pf_t2a = 0, pf_t3 = 0, pf_acc6 = 0, pf_acc[5] = {0, 0, 0, 0, 0}, pf_trips = 0, pf_nodes = 0, pf_idle_t = 0;
+#define PF_STAMP(x) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); x = clock64(); } while (0)
+#define PF_STAMP_V(x) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); x = clock64(); } while (0)
+#else
+#define PF_STAMP(x) do { } while (0)
+#define PF_STAMP_V(x) do { } while (0)
+#endif
     for (;;) {
-      if (__hip_atomic_load(s_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
-      // take up to 64 ready nodes
-      uint32_t h = 0, take = 0;
-      if (lane == 0) {
-        h = __hip_atomic_load(q.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        uint32_t tl = __hip_atomic_load(q.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        take = min(tl - h, 64u);
+      PF_STAMP(pf_t0);
+      const bool chained = CH && __ballot(my_slot != kNoSlot) != 0ull;
+      if (!chained || since_pop >= F.chain_trips) {
+        since_pop = 0u;
+        // the queue (every lane reads the same three words: broadcast reads, no shuffles afterwards)
+        const uint32_t left = __builtin_amdgcn_readfirstlane(__hip_atomic_load(s_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        const uint32_t h0 = __builtin_amdgcn_readfirstlane(__hip_atomic_load(q.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        const uint32_t tl = __builtin_amdgcn_readfirstlane(__hip_atomic_load(q.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (left == 0u) break;
+        const unsigned long long fm = __ballot(my_slot == kNoSlot);
+        uint32_t take = min(tl - h0, (uint32_t)__popcll(fm));  // up to 64 ready nodes (CH: as many as the wave has free lanes)
         if (take) {
-          uint32_t expect = h;
-          if (!__hip_atomic_compare_exchange_strong(q.head, &expect, h + take, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) take = 0;
+          uint32_t got = 0u;
+          if (lane == 0) {
+            uint32_t expect = h0;
+            if (__hip_atomic_compare_exchange_strong(q.head, &expect, h0 + take, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) got = take;
+          }
+          take = __builtin_amdgcn_readfirstlane(got);
+          const uint32_t r = (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
+          if (my_slot == kNoSlot && r < take) {
+            uint16_t* cell = &q.ring[f6_wrap(q, h0 + r)];
+            uint32_t e;
+            do { e = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (!(e & 0x8000u));  // the pusher is between its two writes
+            *cell = 0;
+            my_slot = e & 0x7FFFu;
+            my_stw = __hip_atomic_load(&s_state[my_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
         }
-      }
-      h = __shfl(h, 0); take = __shfl(take, 0);
-      if (take) {
+      } else ++since_pop;
+      const bool act = my_slot != kNoSlot;
+      const unsigned long long am = __ballot(act);
+      PF_STAMP(pf_t1);
+      if (am) {
         spins = 0;
-        if (lane < take) {
-          uint16_t* cell = &q.ring[f6_wrap(q, h + lane)];
-          uint32_t e;
-          do { e = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (!(e & 0x8000u));  // the pusher is between its two writes
-          *cell = 0;
-          const uint32_t slot = e & 0x7FFFu;
-          const uint32_t stw = __hip_atomic_load(&s_state[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t nx_slot = kNoSlot, nx_stw = 0u;
+        if (act) {
+          const uint32_t slot = my_slot, stw = my_stw;
           const uint32_t round = (stw >> kF6StIterShift) & kF6StIterMask;
           uint64_t t_seen = 0;
-          if (TRACE) t_seen = wall_clock64();
+          if (TRACE) t_seen = F6_NODE_CLOCK();
           const uint32_t c = s_c[slot], ref = stw >> kF6StRefShift;
           const uint2 sw = s_succ[slot];
           const uint32_t ai = ref & kF6NoBody, bi_raw = (ref >> kF6BodyBits) & kF6NoBody;
           const bool has_b = bi_raw != kF6NoBody;
           const uint32_t bi = has_b ? bi_raw : ai;
-          CRec rec = load_crec_solve(&cons[c]);  // only the lane running the constraint touches its record
-          if (NL) rec.nimp = s_nimp[slot];
+          CRec rec;
+          float4 q0, q1, q2, q3, q4;
+          if (RL) { const float4* d = s_rec + kF6RecWords * (size_t)slot; q0 = d[0]; q1 = d[1]; q2 = d[2]; q3 = d[3]; q4 = d[4]; }
+          else rec = load_crec_solve(&cons[c]);  // only the lane running the constraint touches its record
+          if (NLS) rec.nimp = s_nimp[slot];
           const float4 a0 = s_body[2 * ai], a1 = s_body[2 * ai + 1], b0 = s_body[2 * bi], b1 = s_body[2 * bi + 1];
           const uint32_t ga = f2u(a1.z), gb = f2u(b1.z);
-          // the constant half of ConstrainedSet::get (inverse mass, world inverse inertia): from LDS for own bodies (CL), else plain
-          // loads beside the record's
+          // the constant half of ConstrainedSet::get (inverse mass, world inverse inertia): from LDS for own bodies (CL >= 1) and
+          // foreign ones (CL == 2), else plain loads beside the record's
           float4 ca1, ca2, ca3, cb1, cb2, cb3;
           if (CL) {
             const float2 k0 = s_const[5 * ai], k1 = s_const[5 * ai + 1], k2 = s_const[5 * ai + 2], k3 = s_const[5 * ai + 3], k4 = s_const[5 * ai + 4];
             ca1 = make_float4(0, 0, k0.x, k0.y); ca2 = make_float4(k1.x, k1.y, k2.x, k2.y); ca3 = make_float4(k3.x, k3.y, k4.x, k4.y);
-            if (bi < F.nb) {
+            if (CL == 2 || bi < F.nb) {
               const float2 j0 = s_const[5 * bi], j1 = s_const[5 * bi + 1], j2 = s_const[5 * bi + 2], j3 = s_const[5 * bi + 3], j4 = s_const[5 * bi + 4];
               cb1 = make_float4(0, 0, j0.x, j0.y); cb2 = make_float4(j1.x, j1.y, j2.x, j2.y); cb3 = make_float4(j3.x, j3.y, j4.x, j4.y);
             } else {
@@ -828,14 +882,21 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
           Bd.v = mk3(b0.x, b0.y, b0.z); Bd.w = mk3(b0.w, b1.x, b1.y); Bd.im = cb1.z;
           Bd.I = m3_cols(mk3(cb1.w, cb2.x, cb2.y), mk3(cb2.z, cb2.w, cb3.x), mk3(cb3.y, cb3.z, cb3.w));
           if (!has_b) Bd = static_dyn();
-          solve_one(rec, A, Bd);
+          PF_STAMP(pf_t2a);
+          PF_STAMP_V(pf_t2);
+          if (RL) {
+            float nimp = q4.w;
+            solve_core(mk3(q4.x, q4.y, q0.x), mk3(q0.y, q0.z, q0.w), mk3(q1.x, q1.y, q1.z), mk3(q1.w, q2.x, q2.y), mk3(q2.z, q2.w, q3.x), q3.y, q3.z, q3.w, q4.z,
+                       nimp, A, Bd);
+            s_rec[kF6RecWords * (size_t)slot + 4].w = nimp;
+          } else solve_one(rec, A, Bd);
           s_body[2 * ai] = make_float4(A.v.x, A.v.y, A.v.z, A.w.x);
           *reinterpret_cast<float2*>(&s_body[2 * ai + 1]) = make_float2(A.w.y, A.w.z);
           if (has_b) {
             s_body[2 * bi] = make_float4(Bd.v.x, Bd.v.y, Bd.v.z, Bd.w.x);
             *reinterpret_cast<float2*>(&s_body[2 * bi + 1]) = make_float2(Bd.w.y, Bd.w.z);
           }
-          if (NL) s_nimp[slot] = rec.nimp; else cons[c].nimp = rec.nimp;
+          if (NLS) s_nimp[slot] = rec.nimp; else if (!RL) cons[c].nimp = rec.nimp;
           // re-arm: one arrival per dynamic body and iteration from now on (no arrival of the next iteration can come before
           // this node's own releases), and one more iteration done
           __hip_atomic_fetch_add(&s_state[slot], (1u << kF6StIterShift) + (has_b ? 2u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -843,34 +904,63 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
             if (has_b && (sw.y & kF6Wrap) && bi >= F.nb) store_vel(srec, gb, Bd);  // (a is always the block's own)
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // velocities are in LDS before any local successor hears of it
+          PF_STAMP(pf_t3);
+#ifndef MGF_F6_PROFILE
           if (TRACE) {
             trace[2 * ((size_t)round * C_trace + c)] = t_seen & ~3ull;
-            trace[2 * ((size_t)round * C_trace + c) + 1] = wall_clock64();
+            trace[2 * ((size_t)round * C_trace + c) + 1] = F6_NODE_CLOCK();
           }
+#endif
+          // The release, both sides at once: the arrivals at local successors are two LDS atomics in flight together (a side without a
+          // local successor decrements a dummy word: no branch between them), then whatever became ready is kept (CH) or queued,
+          // then the messages of the sides whose successor lives in another block.
+          const uint32_t w0 = sw.x, w1 = sw.y;
+          const bool live0 = round + ((w0 & kF6Wrap) ? 1u : 0u) < iters, live1 = has_b && round + ((w1 & kF6Wrap) ? 1u : 0u) < iters;
+          const bool loc0 = live0 && !(w0 & kF6Remote), loc1 = live1 && !(w1 & kF6Remote);
+          const uint32_t ws0 = w0 & kSlotMask, ws1 = w1 & kSlotMask;
+          const uint32_t was0 = __hip_atomic_fetch_sub(loc0 ? &s_state[ws0] : &s_dummy[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          const uint32_t was1 = __hip_atomic_fetch_sub(loc1 ? &s_state[ws1] : &s_dummy[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          bool rdy0 = loc0 && (was0 & kF6StArrMask) == 1u, rdy1 = loc1 && (was1 & kF6StArrMask) == 1u;
+          if (CH) {  // the lane's next node: the successor this release completed (its state word came back with the atomic)
+            if (rdy0) { nx_slot = ws0; nx_stw = was0 - 1u; rdy0 = false; }
+            else if (rdy1) { nx_slot = ws1; nx_stw = was1 - 1u; rdy1 = false; }
+          }
+          if (rdy0) f6_push(q, ws0);
+          if (rdy1) f6_push(q, ws1);
 #pragma unroll
           for (int side = 0; side < 2; ++side) {
-            if (side == 1 && !has_b) break;
-            const uint32_t w = side == 0 ? sw.x : sw.y;
-            if (round + ((w & kF6Wrap) ? 1u : 0u) >= iters) continue;
-            if (!(w & kF6Remote)) {
-              f6_arrive(q, s_state, w & ((1u << kF6SlotBits) - 1u));
-            } else {  // a message: the body's velocity, where it goes, the launch's tag in every granule - and on we go
-              const uint32_t chn = (w >> 24) & (kF6Chan - 1u);  // (6 bits)
-              const uint32_t pos = __hip_atomic_fetch_add(&s_out_tail[chn], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              const uint32_t byte = (s_out_base[chn] + pos) * (16u * kF6MsgWords);
-              const BodyDyn& X = side == 0 ? A : Bd;
-              const float tg = u2f(epoch);
-              v4f_t m0 = {X.v.x, X.v.y, X.v.z, tg}, m1 = {X.w.x, X.w.y, X.w.z, tg}, m2 = {u2f(w & 0x00FFFFFFu), TRACE ? u2f((uint32_t)wall_clock64()) : 0.0f, 0.0f, tg};
-              __builtin_amdgcn_raw_buffer_store_b128(m0, rmb, (int)byte, 0, kSc1);
-              __builtin_amdgcn_raw_buffer_store_b128(m1, rmb, (int)(byte + 16u), 0, kSc1);
-              __builtin_amdgcn_raw_buffer_store_b128(m2, rmb, (int)(byte + 32u), 0, kSc1);
-              __hip_atomic_fetch_max(F.tails + s_out_tidx[chn], ((unsigned long long)epoch << 32) | (pos + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            const uint32_t w = side == 0 ? w0 : w1;
+            if (!((side == 0 ? live0 : live1) && (w & kF6Remote))) continue;
+            // a message: the body's velocity, where it goes, the launch's tag in every granule - and on we go
+            const uint32_t chn = (w >> 24) & (kF6Chan - 1u);  // (6 bits)
+            const uint32_t pos = __hip_atomic_fetch_add(&s_out_tail[chn], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t byte = (s_out_base[chn] + pos) * (16u * kF6MsgWords);
+            const BodyDyn& X = side == 0 ? A : Bd;
+            const float tg = u2f(epoch);
+            v4f_t m0 = {X.v.x, X.v.y, X.v.z, tg}, m1 = {X.w.x, X.w.y, X.w.z, tg}, m2 = {u2f(w & 0x00FFFFFFu), TRACE ? u2f((uint32_t)F6_NODE_CLOCK()) : 0.0f, 0.0f, tg};
+            __builtin_amdgcn_raw_buffer_store_b128(m0, rmb, (int)byte, 0, kSc1);
+            __builtin_amdgcn_raw_buffer_store_b128(m1, rmb, (int)(byte + 16u), 0, kSc1);
+            __builtin_amdgcn_raw_buffer_store_b128(m2, rmb, (int)(byte + 32u), 0, kSc1);
+            __hip_atomic_fetch_max(F.tails + s_out_tidx[chn], ((unsigned long long)epoch << 32) | (pos + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
-        if (lane == 0) __hip_atomic_fetch_sub(s_left, take, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        my_slot = nx_slot; my_stw = nx_stw;
+        if (lane == 0) __hip_atomic_fetch_sub(s_left, (uint32_t)__popcll(am), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef MGF_F6_PROFILE
+        {
+          uint64_t pf_t4; PF_STAMP(pf_t4);
+          // (stamps taken by inactive lanes are stale: the first active lane's are the trip's)
+          const int fl = (int)__builtin_ctzll(am);
+          const uint64_t a2 = __shfl(pf_t2, fl), a3 = __shfl(pf_t3, fl), a2a = __shfl(pf_t2a, fl);
+          pf_acc6 += a2a - pf_t1;
+          pf_acc[0] += pf_t1 - pf_t0; pf_acc[1] += a2 - pf_t1; pf_acc[2] += a3 - a2; pf_acc[3] += pf_t4 - a3; ++pf_trips; pf_nodes += (uint64_t)__popcll(am);
+        }
+#endif
         continue;
       }
+#ifdef MGF_F6_PROFILE
+      pf_idle_t += pf_t1 - pf_t0; pf_acc[4] += 1;
+#endif
       __builtin_amdgcn_s_sleep(2);
       if ((++spins & 255u) == 0u) {
         bool give_up = spins > spin_limit;
@@ -878,11 +968,19 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
         if (give_up || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
       }
     }
+#ifdef MGF_F6_PROFILE
+    if (TRACE && wave == 0 && lane == 0) {
+      tstat[13] = pf_acc[0]; tstat[14] = pf_acc[1]; tstat[15] = pf_acc[2]; tstat[16] = pf_acc[3]; tstat[17] = pf_trips; tstat[18] = pf_nodes; tstat[19] = pf_idle_t; tstat[20] = pf_acc[4]; tstat[21] = pf_acc6;
+    }
+#endif
   }
+#undef PF_STAMP
+#undef PF_STAMP_V
   __syncthreads();
   if (TRACE && threadIdx.x == 0) tstat[11] = wall_clock64();
   // the accumulated normal impulses go back to the records (ContactState lives on: mgf_world_read_constraints, a later solve)
-  if (NL) for (uint32_t idx = t; idx < N; idx += kF6Threads) cons[s_c[idx]].nimp = s_nimp[idx];
+  if (NLS) for (uint32_t idx = t; idx < N; idx += kF6Threads) cons[s_c[idx]].nimp = s_nimp[idx];
+  if (RL) for (uint32_t idx = t; idx < N; idx += kF6Threads) cons[s_c[idx]].nimp = s_rec[kF6RecWords * (size_t)idx + 4].w;
   // own bodies go back to the RigidBodyVec (a body whose chain ends in another block was written there)
   for (uint32_t i = t; i < n_own; i += kF6Threads) {
     const uint32_t x = F.ident ? p_lo + i : F.sidx[p_lo + i];

@@ -8,7 +8,7 @@ import numpy as np
 
 TRACE = "/tmp/mgf_flow_trace.bin"
 POLL = "/tmp/mgf_flow6_poll.bin"
-WORDS = 16  # kF6TraceWords
+WORDS = 24  # kF6TraceWords
 
 
 def load(cons):
@@ -141,6 +141,13 @@ def analyse(T):
             "serving_max_end": round(float(us(ph[:, 3].max())), 2),
             "write_back_mean": round(float(np.mean(ph[:, 4] - ph[:, 3]) * 0.01), 2),
             "last_block_done": round(float(us(ph[:, 4].max())), 2)}
+    if poll.shape[1] >= 21 and poll[:nblk, 17].sum() > 0:  # MGF_F6_PROFILE build: shader clocks of wave 0's trips, by section
+        trips = float(poll[:nblk, 17].sum())
+        out["trip_profile_clocks"] = {"trips_wave0_per_block": round(trips / nblk, 1), "nodes_per_trip": round(float(poll[:nblk, 18].sum()) / trips, 2),
+                                      "pop": round(float(poll[:nblk, 13].sum()) / trips, 1), "loads": round(float(poll[:nblk, 14].sum()) / trips, 1),
+                                      "solve_and_store": round(float(poll[:nblk, 15].sum()) / trips, 1), "release": round(float(poll[:nblk, 16].sum()) / trips, 1),
+                                      "idle_polls_per_block": round(float(poll[:nblk, 20].sum()) / nblk, 1),
+                                      "idle_poll_clocks": round(float(poll[:nblk, 19].sum()) / max(float(poll[:nblk, 20].sum()), 1.0), 1)}
     Nb = np.bincount(blk, minlength=nblk)
     out["constraints_per_block"] = {"mean": round(float(Nb.mean()), 1), "max": int(Nb.max())}
     sweeps = poll[:nblk, 0].astype(np.float64)

@@ -109,7 +109,7 @@ def main():
                 row.update({"constraints_per_tick": round(cons / steps, 1), "solver_us_per_tick": round(kms * 1e3 / steps, 2),
                             "solver_us_per_launch": round(kms * 1e3 / max(nl, 1), 2),
                             "frac_of_hbm_roofline": round(cons * iters * launches * 288 / (kms * 1e-3) / 8e12, 4) if kms > 0 else None,
-                            "flow6_const_lds": x.counter("flow6_const_lds"), "flow6_nimp_lds": x.counter("flow6_nimp_lds"),
+                            "flow6_const_lds": x.counter("flow6_const_lds"), "flow6_rec_lds": x.counter("flow6_rec_lds"), "flow6_nimp_lds": x.counter("flow6_nimp_lds"),
                             "flow6_max_slots": x.counter("flow6_max_slots"), "flow6_max_foreign": x.counter("flow6_max_foreign")})
                 del x
                 if not a.no_trace and row["flow6_fallbacks"] == 0:
@@ -135,7 +135,7 @@ def main():
                 h = t.get("hops", {})
                 print(f"{name:16s} nb {eff:5d} ({row['blocks']:3d} blocks): tick {row['tick_ms_wall']:.3f} ms, solver {row['solver_us_per_tick']:7.1f} us/tick "
                       f"({row['solver_us_per_launch']:.1f}/launch), cons {row['constraints_per_tick']:.0f}, frac {row['frac_of_hbm_roofline']}, "
-                      f"fallbacks {row['flow6_fallbacks']}; hops in {h.get('in_block', {}).get('n')} x ({h.get('in_block', {}).get('handoff_us')}+{h.get('in_block', {}).get('service_us')}) "
+                      f"fallbacks {row['flow6_fallbacks']} CL{row['flow6_const_lds']}NL{row['flow6_nimp_lds']}RL{row['flow6_rec_lds']}; hops in {h.get('in_block', {}).get('n')} x ({h.get('in_block', {}).get('handoff_us')}+{h.get('in_block', {}).get('service_us')}) "
                       f"cross {h.get('cross_block', {}).get('n')} x ({h.get('cross_block', {}).get('handoff_us')}+{h.get('cross_block', {}).get('service_us')}) "
                       f"span {t.get('span_us')} iter0 {t.get('iteration_complete_us', [None])[0]}", flush=True)
 
