@@ -903,7 +903,11 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
           if (round + 1u == iters) {  // the end of a foreign body's chain: its home block does not write it back
             if (has_b && (sw.y & kF6Wrap) && bi >= F.nb) store_vel(srec, gb, Bd);  // (a is always the block's own)
           }
+#ifndef MGF_F6_NO_STORE_WAIT
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // velocities are in LDS before any local successor hears of it
+#else
+          asm volatile("" ::: "memory");  // (experiment: a wave's DS instructions execute in issue order)
+#endif
           PF_STAMP(pf_t3);
 #ifndef MGF_F6_PROFILE
           if (TRACE) {
@@ -961,7 +965,10 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
 #ifdef MGF_F6_PROFILE
       pf_idle_t += pf_t1 - pf_t0; pf_acc[4] += 1;
 #endif
-      __builtin_amdgcn_s_sleep(2);
+#ifndef MGF_F6_IDLE_SLEEP
+#define MGF_F6_IDLE_SLEEP 2
+#endif
+      if (MGF_F6_IDLE_SLEEP > 0) __builtin_amdgcn_s_sleep(MGF_F6_IDLE_SLEEP);
       if ((++spins & 255u) == 0u) {
         bool give_up = spins > spin_limit;
         if (give_up) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
