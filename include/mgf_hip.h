@@ -419,8 +419,12 @@ MGF_API mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_t v
  * "max_fat_half_extent_x_milli"}. */
 MGF_API mgf_status mgf_world_counter(const mgf_world* w, const char* name, int64_t* out);
 /* Raw device pointers of resident state for zero-copy exchange (multi-GPU halo): name in
- * {"x","q","solver_rec","delta"}; pointer valid until the next add_bodies. */
+ * {"x","q","solver_rec","delta"} (the pub fields `x`, `q` of RigidBodyVec physics.rs:142-154 and what ConstrainedSet::get returns,
+ * :273-288), rows indexed by the caller's body index.  Valid until the next add_bodies / remove_bodies.  While pointers are out the
+ * world keeps its store in the caller's order (the fused tick does not re-sort it into cell order: slower ticks, same results);
+ * mgf_world_release_device_ptrs gives them back - after it the pointers must not be used. */
 MGF_API mgf_status mgf_world_device_ptr(mgf_world* w, const char* name, void** ptr, int64_t* bytes);
+MGF_API mgf_status mgf_world_release_device_ptrs(mgf_world* w);
 
 #ifdef __cplusplus
 }

@@ -122,6 +122,7 @@ SYMBOLS = [
     "mgf_world_integrate", "mgf_world_get", "mgf_world_set", "mgf_world_read_state", "mgf_world_write_state",
     "mgf_world_read_colliders", "mgf_world_read_constraints", "mgf_world_set_constraints", "mgf_world_set_option",
     "mgf_world_device_ptr",
+    "mgf_world_release_device_ptrs",
     "mgf_world_begin_tick", "mgf_world_collide", "mgf_world_select_boundary", "mgf_world_export_bodies",
     "mgf_world_import_ghosts", "mgf_world_export_velocities", "mgf_world_import_ghost_velocities", "mgf_world_ghost_len",
     "mgf_world_select_tile", "mgf_world_export_migrants", "mgf_world_remove_bodies", "mgf_world_import_migrants",
@@ -219,6 +220,7 @@ def load_library():
         "mgf_world_set_constraints": (i32, [vp, vp, i64]),
         "mgf_world_set_option": (i32, [vp, C.c_char_p, i64]),
         "mgf_world_device_ptr": (i32, [vp, C.c_char_p, P(vp), P(i64)]),
+        "mgf_world_release_device_ptrs": (i32, [vp]),
         "mgf_world_begin_tick": (i32, [vp, f32]),
         "mgf_world_collide": (i32, [vp, f32, P(StepStats)]),
         "mgf_world_select_boundary": (i32, [vp, f32, f32, vp, vp, i64, P(i64), P(i64)]),
@@ -1036,6 +1038,9 @@ class World:
         nb = C.c_int64()
         _check(load_library().mgf_world_device_ptr(self._h, name.encode(), C.byref(p), C.byref(nb)))
         return p.value, nb.value
+
+    def release_device_ptrs(self):
+        _check(load_library().mgf_world_release_device_ptrs(self._h))
 
 
 def rccl_unique_id():

@@ -313,6 +313,37 @@ __global__ __launch_bounds__(kBlock) void k_obstacle_rows(Bodies B, uint32_t n_o
   t_cnt[i] = nt;
   if (nt > cap_row) atomicOr(overflow, 2u);
 }
+// The same candidates on the exact count / fill path of the candidate search (k_candidates: the tick that follows a row overflow).
+// FILL = false: adds a body's obstacle hits to its count, behind k_candidates<false>; FILL = true: writes them behind the body's
+// faces, in the order k_obstacle_rows lists them (t_cnt[i] = faces + hits from the counting pass), behind k_candidates<true>.
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void k_obstacle_candidates(Bodies B, uint32_t n_owned, const CompoundDev* obs, uint32_t n_obs, uint32_t* t_cnt,
+                                                                const uint32_t* t_off, uint32_t* t_cand, uint32_t* t_owner, const StepCounts* sc) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_owned) return;
+  if (FILL && sc->fail) return;
+  Comp part[kMaxParts];
+  V3 ci;
+  const int np = body_parts(B, i, part, &ci);
+  const V3 vel = xyz(B.delta[i]);
+  auto walk = [&](auto&& hit) {
+    for (uint32_t k = 0; k < n_obs; ++k) {
+      const CompoundDev D = obs[k];
+      const V3 disp = ld3(D.disp);
+      const Quat rot = mkq(D.rot[0], mk3(D.rot[1], D.rot[2], D.rot[3])), conj = mkq(rot.s, -rot.v);
+      for (int pa = 0; pa < np; ++pa) {
+        Box rb = box_rotate(swept_bounds(part[pa], vel), conj);  // compound.rs:340-344
+        rb.c = rotate(conj, rb.c + -disp) + disp;
+        terrain_traverse(D.tree, rb, [&](uint32_t comp) { hit(kObstacleFlag | (k << 23) | ((uint32_t)pa << 20) | comp); });
+      }
+    }
+  };
+  uint32_t no = 0;
+  walk([&](uint32_t) { ++no; });
+  if (!FILL) { t_cnt[i] += no; return; }
+  uint32_t at = t_off[i] + (t_cnt[i] - no);
+  walk([&](uint32_t f) { t_cand[at] = f; t_owner[at] = i; ++at; });
+}
 // The flagged candidates' contacts: Moving<part>.contacts(&component) through the :1368-1382 wrapper (what Compound::contacts calls, and
 // negates), then LocalContacts (collision.rs:1490-1506) with the obstacle in the Mesh's place: the record Manifold::from(lc) and
 // ContactConstraint::new consume.  k_narrow_terrain* leave these candidates alone.

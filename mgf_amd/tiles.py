@@ -321,8 +321,11 @@ def step_tile(tile, transport):
             out = tile.phase_migrate_out()
             got, _ = transport.exchange(out, tile.mig_split, MIGRANT_FLOATS, e.alloc, recv_counts=arriving)
             tile.phase_migrate_in(got)
-    for k in ("solver_kernel_launches", "ms_solve", "ms_solver_kernels", "n_levels", "ms_total", "iters"):
+    for k in ("solver_kernel_launches", "n_levels", "iters"):
         if k in fin:
+            stats[k] = fin[k]
+    for k in ("ms_solve", "ms_solver_kernels", "ms_total"):  # measured only with the options phase_timing / time_solver_kernels: 0 = not measured
+        if fin.get(k):
             stats[k] = fin[k]
     return stats
 

@@ -125,6 +125,41 @@ def test_mesh_pushed_vertex_by_vertex_equals_the_bulk_build(ctx):
     assert a.to_json() == b.to_json()
 
 
+def test_device_pointers_keep_their_meaning_across_ticks_of_a_large_world(ctx):
+    """A world of >= 16 384 bodies keeps its store in an internal order that the fused tick re-sorts.  Raw pointers
+    handed out by mgf_world_device_ptr are indexed by the CALLER's body index: while they are out the store stays in the caller's
+    order, so a zero-copy consumer that steps the world and reads through a pointer it already holds sees body i in row i; the
+    results are those of a world that never handed pointers out (bit for bit); releasing them lets the world re-sort again."""
+    scene = scenes.sphere_pile(26, 26, 26)  # 17 576 bodies
+    dt = float(scene["dt"])
+    a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
+    for _ in range(3):
+        a.step(dt, 10); b.step(dt, 10)
+    assert a.counter("store_permuted") == 1
+    n = len(a)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    px, nbytes = a.device_ptr("x")
+    psr, _ = a.device_ptr("solver_rec")
+    assert a.counter("store_permuted") == 0
+    for k in range(4):  # (resort_every = 1 would re-sort at every one of these ticks)
+        a.set_option("resort_every", 1)
+        a.step(dt, 10); b.step(dt, 10)
+        assert a.counter("store_permuted") == 0
+        hx, hs = np.zeros((n, 4), np.float32), np.zeros((n, 16), np.float32)
+        assert hip.hipMemcpy(hx.ctypes.data, C.c_void_p(px), nbytes, 2) == 0
+        assert hip.hipMemcpy(hs.ctypes.data, C.c_void_p(psr), 64 * n, 2) == 0
+        sb = b.state()
+        assert bits_equal(hx[:, :3], sb["x"]) and bits_equal(hs[:, :3], sb["v"]) and bits_equal(hs[:, 3:6], sb["omega"])
+    a.release_device_ptrs()
+    a.step(dt, 10); b.step(dt, 10)
+    a.step(dt, 10); b.step(dt, 10)
+    assert a.counter("store_permuted") == 1
+    sa, sb = a.state(), b.state()
+    for f in ("x", "q", "v", "omega"):
+        assert bits_equal(sa[f], sb[f])
+
+
 def test_device_pointers_and_ghost_len(ctx):
     """mgf_world_device_ptr hands out the resident arrays (x, q, solver records, delta) for zero-copy exchange; what is read
     through them is the state the ordinary read-back returns.  mgf_world_ghost_len counts the tick's imported ghosts."""

@@ -100,3 +100,24 @@ def test_obstacles_without_a_mesh_and_through_a_clone(ctx):
     g, o = gw.state(), ow.state()
     for k in ("x", "q", "v", "omega"):
         assert values_equal(g[k], o[k]), k
+
+
+@pytest.mark.parametrize("name", ["spheres", "bodies_of_several_parts"])
+def test_obstacles_on_the_exact_two_pass_candidate_path(ctx, name):
+    """A tick whose partner row overflows is re-run on the exact count / fill path (k_candidates); a world with obstacles used to
+    fail there with MGF_ERR_INVALID after the bodies had been integrated.  The obstacles' components are now counted and
+    written on that path too (k_obstacle_candidates): option two_pass_candidates = 1 takes it every tick - same lists, same state."""
+    sc = SCENES[name]()
+    dt, iters = float(sc["dt"]), sc["iters"]
+    gw, ow = mgf_amd.World.from_scene(ctx, sc), oracle_world(sc)
+    _add(ctx, gw, ow)
+    gw.set_option("two_pass_candidates", 1)
+    for tick in range(60):
+        sg, so = gw.step(dt, iters), ow.step(dt, iters)
+        assert (sg.n_constraints, sg.n_terrain_constraints) == (so.n_constraints, so.n_terrain_constraints), f"tick {tick}"
+        if tick % 20 == 19:
+            compare_constraints(gw.constraints(), ow.constraints(), check_impulse=True)
+    g, o = gw.state(), ow.state()
+    for k in ("x", "q", "v", "omega"):
+        assert values_equal(g[k], o[k]), k
+    assert int((gw.constraints()["b"] < 0).sum()) > 10
