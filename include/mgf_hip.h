@@ -331,8 +331,8 @@ MGF_API mgf_status mgf_compound_intersections(mgf_compound* c, const mgf_particl
  * Ghost bodies are local copies of a neighbour tile's boundary bodies; they collide with owned
  * bodies only (their terrain contacts and ghost-ghost pairs belong to their owner).  All buffers
  * below are DEVICE pointers owned by the caller (e.g. the exchange buffers handed to RCCL).
- * Ghost record: 56 floats  x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction | n_parts, 3 pad |
- * 2 x (p3 r d3 kind) world parts of a body of several components (zeros otherwise);
+ * Ghost record: MGF_GHOST_FLOATS = 72 floats  x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction | n_parts, 3 pad |
+ * 4 x (p3 r d3 kind) world parts of a body of several components (zeros otherwise);
  * velocity record: 8 floats v3 w3 0 0. */
 MGF_API mgf_status mgf_world_begin_tick(mgf_world* w, float dt);     /* complete_motion + integrate (world.rs:230-231) */
 MGF_API mgf_status mgf_world_collide(mgf_world* w, float dt, mgf_step_stats* stats); /* world.rs:233-291 */
@@ -352,7 +352,8 @@ MGF_API int64_t mgf_world_ghost_len(const mgf_world* w);
  * export_migrants (MGF_MIGRANT_FLOATS floats per body: the body's row of every device array, fat AABB and tag
  * included) -> neighbour -> remove_bodies on the old owner, import_migrants (append) on the new one.  Ids of the
  * remaining bodies shift down on removal; mgf_world_set_tags / read_tags give bodies an identity that survives. */
-#define MGF_MIGRANT_FLOATS 116
+#define MGF_GHOST_FLOATS 72
+#define MGF_MIGRANT_FLOATS 148
 MGF_API mgf_status mgf_world_select_tile(mgf_world* w, float x_left, float x_right, float x_lo, float x_hi,
                                          uint32_t* ids_left, uint32_t* ids_right, uint32_t* ids_migrants, int64_t cap,
                                          int64_t* counts /* [4] */);
@@ -385,6 +386,10 @@ MGF_API mgf_status mgf_tiles_create(mgf_ctx* ctx, int32_t n_local, mgf_world* co
                                     mgf_tiles** out);
 MGF_API void mgf_tiles_free(mgf_tiles* t);
 MGF_API mgf_status mgf_rccl_unique_id(void* id128);
+/* Which library provides ncclSend / ncclRecv: librccl.so by default, whatever the environment says.  After
+ * mgf_rccl_allow_override(1) - called by the host program before any other mgf_rccl_* / mgf_tiles_connect call - the environment
+ * variable MGF_RCCL_LIB may name another one (a site's own RCCL build; the test-suite's stand-in transport). */
+MGF_API mgf_status mgf_rccl_allow_override(int32_t allow);
 MGF_API mgf_status mgf_tiles_connect(mgf_tiles* t, const void* id128, int32_t rank, int32_t n_ranks);
 MGF_API mgf_status mgf_tiles_preflight(mgf_tiles* t, int32_t* n_ranks_seen);
 MGF_API mgf_status mgf_tiles_step(mgf_tiles* t, float dt, int32_t iters, mgf_step_stats* stats /* n_local, or NULL */);

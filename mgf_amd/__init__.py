@@ -7,6 +7,6 @@ There is no CPU fallback: importing works anywhere, but creating a Context witho
 library or without a GPU raises MgfError.
 """
 from . import scenes  # noqa: F401
-from ._capi import (MgfError, Context, Mesh, Bvh, World, Solver, Tiles, rccl_unique_id, Compound, contacts, contacts_batch, local_contacts_pair,  # noqa: F401
+from ._capi import (MgfError, Context, Mesh, Bvh, World, Solver, Tiles, rccl_unique_id, rccl_allow_override, Compound, contacts, contacts_batch, local_contacts_pair,  # noqa: F401
                     local_contacts_mesh, ray_capsule, intersections, particles, manifolds_from_contacts, inertia_tensor, geom_to_json, geom_from_json, default_params, lib_path, load_library,
                     COMPONENT_DTYPE, CONSTRAINT_DTYPE, MOVING_DTYPE, PARTICLE_DTYPE, INTERSECTION_DTYPE, CONTACT_DTYPE, LOCAL_CONTACT_DTYPE, MANIFOLD_DTYPE)

@@ -131,7 +131,7 @@ SYMBOLS = [
     "mgf_constraints_new", "mgf_solver_new", "mgf_solver_free", "mgf_solver_add_constraint", "mgf_solver_add_constraints",
     "mgf_solver_len", "mgf_solver_clear", "mgf_solver_read_constraints", "mgf_solver_solve", "mgf_world_clone",
     "mgf_geom_to_json", "mgf_geom_from_json",
-    "mgf_tiles_create", "mgf_tiles_free", "mgf_rccl_unique_id", "mgf_tiles_connect", "mgf_tiles_preflight", "mgf_tiles_step",
+    "mgf_tiles_create", "mgf_tiles_free", "mgf_rccl_unique_id", "mgf_rccl_allow_override", "mgf_tiles_connect", "mgf_tiles_preflight", "mgf_tiles_step",
     "mgf_tiles_migrated", "mgf_tiles_set_option", "mgf_world_add_obstacle", "mgf_tiles_counter",
 ]
 
@@ -253,6 +253,7 @@ def load_library():
         "mgf_tiles_create": (i32, [vp, i32, vp, vp, vp, i32, i32, f32, i32, i32, P(vp)]),
         "mgf_tiles_free": (None, [vp]),
         "mgf_rccl_unique_id": (i32, [vp]),
+        "mgf_rccl_allow_override": (i32, [C.c_int32]),
         "mgf_tiles_connect": (i32, [vp, vp, i32, i32]),
         "mgf_tiles_preflight": (i32, [vp, P(i32)]),
         "mgf_tiles_step": (i32, [vp, f32, i32, vp]),
@@ -1041,6 +1042,11 @@ class World:
 
     def release_device_ptrs(self):
         _check(load_library().mgf_world_release_device_ptrs(self._h))
+
+
+def rccl_allow_override(allow=True):
+    """Let the environment variable MGF_RCCL_LIB name the collectives library (before the first RCCL call of the process)."""
+    _check(load_library().mgf_rccl_allow_override(1 if allow else 0))
 
 
 def rccl_unique_id():

@@ -51,8 +51,8 @@ struct Bodies {
   float4* wp1;
 };
 constexpr int kMaxParts = 4;   // part slots per body in the part arrays (round 3: 2 -> 4)
-constexpr int kTileParts = 2;  // part slots of a ghost / migrant record of the tile protocol (its record sizes are part of the ABI: bodies of more
-                               // than two parts do not cross tiles yet - the tiling entry points refuse such worlds)
+constexpr int kTileParts = 4;  // part slots of a ghost / migrant record of the tile protocol (its record sizes are part of the ABI; r04: 2 -> 4 =
+                               // kMaxParts, every body the store can hold crosses tiles)
 
 constexpr int kBoundSlots = 64, kBoundSlotInts = 32;  // partial scene bounds: lo[3], hi[3], rmax[3] per slot, one 128-byte line each
 struct SceneBounds { int lo[3]; int hi[3]; uint32_t n_refits; uint32_t pad; int rmax[3]; uint32_t pad2; };  // ordered-int encoded floats; rmax = largest fat half extent

@@ -6,10 +6,10 @@ namespace mgf {
 
 // ------------------------------------------------------------------------------------------
 // Spatial tiling (one process per GPU): boundary selection, ghost export / import.
-// Ghost record, 56 floats: x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction | n_parts, 3 pad |
-// 2 x (p3 r d3 kind) world parts of a body of several components (zeros for an ordinary body).
+// Ghost record, 72 floats: x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction | n_parts, 3 pad |
+// kTileParts x (p3 r d3 kind) world parts of a body of several components (zeros for an ordinary body).
 // ------------------------------------------------------------------------------------------
-constexpr int kGhostFloats = 56;
+constexpr int kGhostFloats = 40 + 8 * kTileParts;
 
 // flags[i] bit0: owned body i's fat box reaches below x_left; bit1: above x_right.
 __global__ __launch_bounds__(kBlock) void k_boundary_flags(Bodies B, uint32_t n_owned, float x_left, float x_right, uint32_t* fl,

@@ -4,11 +4,11 @@ data path).  The tick on every tile:
 
     begin_tick                      complete_motion + integrate the owned bodies
     select_boundary / export        owned bodies whose fat AABB reaches into the halo of a slab face
-    <-> neighbours                  body records (56 floats each)
+    <-> neighbours                  body records (72 floats each)
     import_ghosts, collide          broadphase / narrowphase / ContactConstraint::new on owned + ghost
     iters/R x { solve(R); <-> neighbours: velocities of the exported bodies (8 floats each) }
     finish                          the one place the host waits for the solver (status, timings)
-    migrate (only when needed)      owned bodies whose centre left the slab: full records (116 floats) to the
+    migrate (only when needed)      owned bodies whose centre left the slab: full records (148 floats) to the
                                     neighbour, removed here, appended there - selected at the start of the tick
                                     (the counts ride on the ghost count message), moved at its end
 
@@ -32,9 +32,9 @@ import numpy as np
 
 from . import scenes
 
-GHOST_FLOATS = 56
+GHOST_FLOATS = 72
 VEL_FLOATS = 8
-MIGRANT_FLOATS = 116
+MIGRANT_FLOATS = 148
 # Solver iterations between two ghost velocity refreshes (1 = refresh after every iteration).  Measured on a
 # two-tile 6x6x6 pile after 60 ticks (tests/test_tiles_cpu.py::test_seam_quality_vs_refresh_interval): mean
 # resting penetration of the sphere pairs straddling the slab face 0.043 (R=1), 0.046 (R=2), 0.055 (R=10)

@@ -150,9 +150,9 @@ struct World {
     b.sync_parts();
     tags.resize(n_owned, 0u);
   }
-  // record (kGhostFloats = 56): x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction | n_parts, 3 pad |
-  // 2 x (p3 r d3 kind) world parts of a body of several components (zeros for an ordinary body)
-  static constexpr int kGhostFloats = 56;
+  // record (kGhostFloats = 72): x3 q4 v3 w3 delta3 | tag p3 d3 r | inv_mass I9 restitution friction | n_parts, 3 pad |
+  // 4 x (p3 r d3 kind) world parts of a body of several components (zeros for an ordinary body)
+  static constexpr int kGhostFloats = 72;
   static void put_part(float* o, const Component& c) {
     uint32_t kind = (uint32_t)c.kind;
     if (c.kind == COMP_SPHERE) { o[0] = c.s.c.x; o[1] = c.s.c.y; o[2] = c.s.c.z; o[3] = c.s.r; o[4] = o[5] = o[6] = 0.0f; }
@@ -226,7 +226,7 @@ struct World {
 
   // ---- migration between tiles (not in the reference): an owned body whose centre leaves the slab
   // [x_lo, x_hi) is handed to the neighbouring tile with its whole state, persistent fat box included.
-  static constexpr int kMigrantFloats = 116;  // the ghost record (56) | force3 inv_moment_body9 constructor3 fat box6 tag, 2 pad | 2 local parts | padding (the HIP path's record is 116 floats)
+  static constexpr int kMigrantFloats = 148;  // the ghost record (72) | force3 inv_moment_body9 constructor3 fat box6 tag, 2 pad | 4 local parts | padding (the HIP path's record is 148 floats)
   void select_migrants(float x_lo, float x_hi, std::vector<uint32_t>* left, std::vector<uint32_t>* right) const {
     left->clear(); right->clear();
     for (size_t i = 0; i < n_owned; ++i) {

@@ -396,7 +396,7 @@ class Bvh:
         return nodes[:n], bounds[:n]
 
 
-GHOST_FLOATS = 56  # World::kGhostFloats
+GHOST_FLOATS = 72  # World::kGhostFloats
 
 
 class World:
@@ -497,7 +497,7 @@ class World:
         lib().mgfo_world_import_ghosts(self.h, recs.ctypes.data, len(recs))
 
     # ---- migration of owned bodies between tiles ----
-    MIGRANT_FLOATS = 116
+    MIGRANT_FLOATS = 148
 
     def select_migrants(self, x_lo, x_hi):
         n = len(self)

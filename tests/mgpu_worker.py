@@ -23,6 +23,8 @@ def run_rank(rank, n_ranks, total_tiles, dims, drift, ticks, fail_rank, fail_tic
         import torch  # noqa: F401  (before libmgf_hip.so: see tests/conftest.py)
         import mgf_amd
         from mgf_amd import scenes
+        if rccl_lib:
+            mgf_amd.rccl_allow_override(True)
         per = total_tiles // n_ranks
         first = rank * per
         ctx = mgf_amd.Context(rank if device is None else device)

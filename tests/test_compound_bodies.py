@@ -94,12 +94,12 @@ def test_config5_scene_runs_and_settles():
     assert np.isfinite(s["x"]).all() and s["x"][:, 1].min() > 0.2 and st.n_constraints > 30
 
 
-def _tiled_setup(engine_factory, P, drift=0.0):
+def _tiled_setup(engine_factory, P, drift=0.0, jacks=False):
     from mgf_amd.tiles import Tile
-    sc = scenes.dumbbell_field(6, 2, 4, n_plain=8)
+    sc = scenes.jack_field(6, 2, 4) if jacks else scenes.dumbbell_field(6, 2, 4, n_plain=8)
     if drift:
         sc["v0"] = (sc["v0"] + np.float32([drift, 0.0, 0.0])).astype(np.float32)
-    half = 6 * 2.2 / 2.0 + 2.0
+    half = 6 * (2.6 if jacks else 2.2) / 2.0 + 2.0
     # (halo 2: a dumbbell's fat half extent along x reaches ~1.5 - the drivers refuse a halo smaller than that)
     return sc, [Tile(engine_factory(t), t["x_range"], r, P, t["dt"], t["iters"], halo=2.0) for r, t in enumerate(scenes.split_by_slabs(sc, P, half))]
 
@@ -171,14 +171,15 @@ def test_hip_larger_config5_scene(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("P,drift", [(2, 0.0), (3, 3.0)])
-def test_hip_two_part_bodies_across_tiles_equal_oracle_tiles(ctx, P, drift):
+@pytest.mark.parametrize("P,drift,jacks", [(2, 0.0, False), (3, 3.0, False), (2, 0.0, True), (3, 3.0, True)])
+def test_hip_two_part_bodies_across_tiles_equal_oracle_tiles(ctx, P, drift, jacks):
     """The tile protocol with bodies of several parts (ghost records with parts, hand-overs with the part arrays, kind
-    masks telling a tile that its neighbours hold such bodies): every tile bit-identical to the oracle's."""
+    masks telling a tile that its neighbours hold such bodies): every tile bit-identical to the oracle's.  jacks: bodies of FOUR
+    parts (r04: the tile records carry four part slots)."""
     from mgf_amd.tiles import HipEngine, step_tiles_inprocess
     from tests.oracle_engine import OracleEngine
-    _, gt = _tiled_setup(lambda t: HipEngine(ctx, t, 0), P, drift)
-    _, ot = _tiled_setup(OracleEngine, P, drift)
+    _, gt = _tiled_setup(lambda t: HipEngine(ctx, t, 0), P, drift, jacks)
+    _, ot = _tiled_setup(OracleEngine, P, drift, jacks)
     for tick in range(40):
         sg, so = step_tiles_inprocess(gt), step_tiles_inprocess(ot)
         for r in range(P):
@@ -248,7 +249,7 @@ def test_hip_four_part_bodies_equal_oracle(ctx, mode):
 @pytest.mark.gpu
 def test_hip_worlds_mixing_one_two_and_four_parts(ctx):
     """Ordinary spheres, two-part and four-part bodies in one world (the four-part kernels then serve every pair), through a re-sorted
-    store and a clone; the tile protocol refuses a world with bodies of more than two parts."""
+    store and a clone; the tile protocol takes such a world too (r04: four part slots in its records)."""
     import mgf_amd
     a, b = scenes.jack_field(3, 2, 3), scenes.dumbbell_field(3, 1, 3, n_plain=8)
     b["compound"]["comps"]["p"][:, 1] += 7.0
@@ -268,8 +269,12 @@ def test_hip_worlds_mixing_one_two_and_four_parts(ctx):
     g, o = gw.state(), ow.state()
     for k in ("x", "q", "v", "omega"):
         assert values_equal(g[k], o[k]), k
-    with pytest.raises(mgf_amd.MgfError):
-        mgf_amd.Tiles(ctx, [gw], [(-1e30, 1e30)])
+    T = mgf_amd.Tiles(ctx, [gw], [(-1e30, 1e30)], halo=2.5)  # one tile: steps like the world itself
+    sg, so = T.step(dt, iters), ow.step(dt, iters)
+    assert int(sg[0].n_constraints) == so.n_constraints
+    g, o = gw.state(), ow.state()
+    for k in ("x", "q", "v", "omega"):
+        assert values_equal(g[k], o[k]), k
 
 
 @pytest.mark.gpu

@@ -133,6 +133,50 @@ def test_config4_one_million_spheres_as_eight_tiles(ctx):
     print("config 4, 8 tiles: constraints per tile", [int(s.n_constraints) for s in sg])
 
 
+def test_config5_65536_two_part_bodies_as_eight_tiles(ctx):
+    """BASELINE config 5 as BASELINE.json states it - 65 536 bodies of a sphere and a capsule each, cut into 8 x-slab tiles - on one
+    GPU (the exchange between a rank's own tiles is a device copy, between ranks RCCL: same code): the first tick, and a later
+    contact-rich one (the oracle's tiles teacher-forced from the GPU's state), bit-identical to the oracle's 8 tiles; ghost records
+    carry the bodies' parts across every face.  (This build's own definition of such a body: SURVEY 8f row 1.)"""
+    from mgf_amd.tiles import step_tiles_inprocess
+    P = 8
+    sc = scenes.dumbbell_field(64, 16, 64)
+    tile_scenes = scenes.split_by_slabs(sc, P, 64 * 2.2 / 2.0)
+    assert sum(len(t["compound"]["offsets"]) - 1 for t in tile_scenes) == 65536
+    T, worlds = _native(ctx, tile_scenes, halo=2.0)
+    ot = _oracle_tiles(tile_scenes, halo=2.0)
+    dt, iters = float(sc["dt"]), sc["iters"]
+    sg, so = T.step(dt, iters), step_tiles_inprocess(ot)
+    assert [int(s.n_constraints) for s in sg] == [int(s["n_constraints"]) for s in so]
+    _assert_equal(worlds, ot, "first tick")
+    for _ in range(62):
+        sg = T.step(dt, iters)
+    assert sum(int(s.n_constraints) for s in sg) > 10000 and sum(int(s.n_ghost_constraints) for s in sg) > 100
+    # a few bodies have changed tile by now: the oracle's tiles are rebuilt from the GPU's - each tile's bodies in the GPU tile's order
+    # (tags = indices into the undivided scene) - and take its state
+    cb, off = sc["compound"], sc["compound"]["offsets"]
+    rebuilt = []
+    for w, t in zip(worlds, tile_scenes):
+        tags = w.tags().astype(np.int64)
+        parts = np.concatenate([np.arange(off[b], off[b + 1]) for b in tags])
+        sub = dict(t)
+        sub["compound"] = dict(comps=cb["comps"][parts], comp_mass=np.asarray(cb["comp_mass"], np.float32)[parts],
+                               offsets=np.arange(0, 2 * len(tags) + 1, 2, dtype=np.int64), restitution=cb["restitution"][tags],
+                               friction=cb["friction"][tags], force=cb["force"][tags])
+        sub["v0"] = sc["v0"][tags]
+        sub["tags"] = tags.astype(np.uint32)
+        rebuilt.append(sub)
+    ot = _oracle_tiles(rebuilt, halo=2.0)
+    for w, o in zip(worlds, ot):
+        assert np.array_equal(w.tags(), o.e.tags())
+        s = w.state()
+        o.e.w.set_state(x=s["x"], q=s["q"], v=s["v"], omega=s["omega"], delta=s["delta"])
+    sg, so = T.step(dt, iters), step_tiles_inprocess(ot)
+    assert [int(s.n_constraints) for s in sg] == [int(s["n_constraints"]) for s in so]
+    _assert_equal(worlds, ot, "later tick")
+    print("config 5, 8 tiles: constraints per tile", [int(s.n_constraints) for s in sg], "hand-overs", sum(T.migrated(r) for r in range(P)))
+
+
 def test_halo_smaller_than_a_body_is_refused(ctx):
     """a body whose fat half extent exceeds the halo could touch a neighbour's body that was never exported.  Both
     drivers fail loudly instead of dropping the contact."""
