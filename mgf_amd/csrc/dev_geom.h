@@ -295,7 +295,9 @@ HD bool seg2d(V2 a, V2 b, V2 c, V2 d, float* t) {
 }
 
 // ---- triangle vs moving capsule :693-1086; returns number of contacts (0..2) ------------
-__device__ inline int tri_mcapsule(const Triangle& tri, const Capsule& c, V3 v, Contact out[2]) {
+// (the two contacts leave through references to two separate objects, not through an array: with `Contact out[2]` the compiler kept the
+// pair in scratch memory - stored at every exit, loaded again by the caller: 96 bytes per lane in k_narrow_terrain<1>)
+__device__ inline int tri_mcapsule(const Triangle& tri, const Capsule& c, V3 v, Contact& out0, Contact& out1) {
   const Plane p = plane_from(tri.a, tri.b, tri.c);
   // :698-719 capsule axis already crosses the face
   {
@@ -306,7 +308,7 @@ __device__ inline int tri_mcapsule(const Triangle& tri, const Capsule& c, V3 v, 
         V3 q = c.a + c.d * t;
         if (tri_contains(tri, q)) {
           V3 base = (dot(p.n, c.a) - p.d < 0.0f) ? c.a : (c.a + c.d);
-          out[0] = mkc(q, base + -p.n * c.r, p.n, 0.0f);
+          out0 = mkc(q, base + -p.n * c.r, p.n, 0.0f);
           return 1;
         }
       }
@@ -325,7 +327,7 @@ __device__ inline int tri_mcapsule(const Triangle& tri, const Capsule& c, V3 v, 
         if (c2.t < c1.t) { found = true; fc = c2; dir = -c.d; }
         else if (c2.t == 0.0f) {
           bool in1 = tri_contains(tri, c1.a), in2 = tri_contains(tri, c2.a);
-          if (in1 && in2) { out[0] = c2; out[1] = c1; return 2; }
+          if (in1 && in2) { out0 = c2; out1 = c1; return 2; }
           else if (in1) { found = true; fc = c1; dir = c.d; checked = true; }
           else if (in2) { found = true; fc = c2; dir = -c.d; checked = true; }
         } else { found = true; fc = c1; dir = c.d; }
@@ -343,7 +345,7 @@ __device__ inline int tri_mcapsule(const Triangle& tri, const Capsule& c, V3 v, 
     bool inside = checked || tri_contains(tri, fc.a);
     bool parallel = fabs_rs(dot(dir, p.n)) < kCollisionEps;
     if (inside) {
-      out[0] = fc;
+      out0 = fc;
       if (!parallel) return 1;
     }
     if (inside || (fc.t > 0.0f && parallel)) {
@@ -363,14 +365,14 @@ __device__ inline int tri_mcapsule(const Triangle& tri, const Capsule& c, V3 v, 
       float t_max2 = (t_max == 0.0f) ? 1.0f : t_max;
       if (inside) {  // :808-839 second contact for a face-parallel capsule
         V3 q = fc.a + sil_v * t_max2;
-        out[1] = mkc(q, q, p.n, fc.t);
+        out1 = mkc(q, q, p.n, fc.t);
         return 2;
       }
       if (hit) {  // :847-888
         V3 q0 = fc.a + sil_v * t_min;
         V3 q1 = fc.a + sil_v * t_max2;
-        out[0] = mkc(q0, q0, p.n, fc.t);
-        out[1] = mkc(q1, q1, p.n, fc.t);
+        out0 = mkc(q0, q0, p.n, fc.t);
+        out1 = mkc(q1, q1, p.n, fc.t);
         return 2;
       }
     }
@@ -439,10 +441,10 @@ __device__ inline int tri_mcapsule(const Triangle& tri, const Capsule& c, V3 v, 
     }
   }
   // :1061-1085
-  if (best_sum_t < best_par_t) { out[0] = mkc(best_sum_p, best_sum_p, p.n, best_sum_t); return 1; }
+  if (best_sum_t < best_par_t) { out0 = mkc(best_sum_p, best_sum_p, p.n, best_sum_t); return 1; }
   if (best_par_t != kInf) {
-    out[0] = mkc(best_par_a, best_par_a, p.n, best_par_t);
-    out[1] = mkc(best_par_b, best_par_b, p.n, best_par_t);
+    out0 = mkc(best_par_a, best_par_a, p.n, best_par_t);
+    out1 = mkc(best_par_b, best_par_b, p.n, best_par_t);
     return 2;
   }
   return 0;
@@ -608,20 +610,14 @@ __device__ inline bool comp_pair_local(const Comp& A, V3 vA, const Comp& B, V3 v
 // `centre`: the body's centre the local point is taken from (the component's own for an ordinary body; the centre of
 // mass for a part of a body of several components).
 __device__ inline int comp_tri_local_at(const Comp& A, V3 vA, const Triangle& tri, V3 mesh_center, V3 centre, LocalContact out[2]) {
-  Contact raw[2];
+  Contact raw0, raw1;
+  raw0 = raw1 = mkc(mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), 0.0f);
   int n;
-  if (A.kind == KIND_SPHERE) n = tri_msphere(tri, mks(A.p, A.r), vA, &raw[0]) ? 1 : 0;
-  else n = tri_mcapsule(tri, mkcap(A.p, A.d, A.r), vA, raw);
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {  // (constant indices: the contacts stay in registers, not in scratch)
-    if (k < n) {
-      Contact m = raw[k];  // Mesh::contacts callback value: a on the mesh, b on the body, n = face normal
-      V3 a_c = centre + vA * m.t;
-      out[k].la = m.b + -a_c;
-      out[k].lb = m.a + -mesh_center;
-      out[k].g = neg(m);
-    }
-  }
+  if (A.kind == KIND_SPHERE) n = tri_msphere(tri, mks(A.p, A.r), vA, &raw0) ? 1 : 0;
+  else n = tri_mcapsule(tri, mkcap(A.p, A.d, A.r), vA, raw0, raw1);
+  // Mesh::contacts callback value: a on the mesh, b on the body, n = face normal
+  if (n > 0) { const V3 a_c = centre + vA * raw0.t; out[0].la = raw0.b + -a_c; out[0].lb = raw0.a + -mesh_center; out[0].g = neg(raw0); }
+  if (n > 1) { const V3 a_c = centre + vA * raw1.t; out[1].la = raw1.b + -a_c; out[1].lb = raw1.a + -mesh_center; out[1].g = neg(raw1); }
   return n;
 }
 __device__ inline int comp_tri_local(const Comp& A, V3 vA, const Triangle& tri, V3 mesh_center, LocalContact out[2]) {

@@ -29,7 +29,7 @@ __device__ inline int contacts_dispatch(const ShapeIn& a, bool ma, V3 va, const 
     } else if (kb == MGF_CAPSULE) {
       if (ka == MGF_SPHERE) return sphere_mcapsule(S(a), Cp(b), vb, out) ? 1 : 0;
       if (ka == MGF_CAPSULE) return capsule_mcapsule(Cp(a), Cp(b), vb, out) ? 1 : 0;
-      if (ka == MGF_TRIANGLE) return tri_mcapsule(Tr(a), Cp(b), vb, out);
+      if (ka == MGF_TRIANGLE) return tri_mcapsule(Tr(a), Cp(b), vb, out[0], out[1]);
       if (ka == MGF_PLANE) return plane_mcapsule(Pl(a), Cp(b), vb, out) ? 1 : 0;
     }
     return -1;

@@ -199,42 +199,55 @@ __global__ __launch_bounds__(kBlock) void k_narrow_pairs_parts(Bodies B, const u
   const int na = pci ? (int)min(pci, (uint32_t)MP) : 1, nb = pcj ? (int)min(pcj, (uint32_t)MP) : 1;
   const V3 ci = pci ? xyz(B.col0[i]) : comp_center(load_comp(B, i)), cj = pcj ? xyz(B.col0[j]) : comp_center(load_comp(B, j));
   const V3 vA = xyz(B.delta[i]), vB = xyz(B.delta[j]);
+  // ContactPruner::push manifold.rs:72-102 over the raw contacts in the candidate's own output slots.  What the pruner keeps is a list
+  // of SLOT NUMBERS (four bits each in one register pair) - a kept contact is read again from its slot when a later one is compared
+  // with it - instead of up to MP * MP LocalContacts of 64 bytes in scratch memory (r04: 288 -> 0 bytes per lane for MP = 2).
+  static_assert(kPairContacts <= 16, "four bits per kept slot");
+  const NContact* mine = p_out + (size_t)kPairContacts * p;
+  auto local_of = [&](const NContact& raw) -> LocalContact {
+    Contact c; c.a = xyz(raw.la); c.b = xyz(raw.lb); c.n = xyz(raw.n); c.t = raw.la.w;
+    LocalContact nc; nc.la = c.a + -(ci + vA * c.t); nc.lb = c.b + -(cj + vB * c.t); nc.g = c;
+    return nc;
+  };
   float min_t = kInf;
   int cnt = 0;
-  LocalContact keep[kPairContacts];
+  unsigned long long keep = 0ull;  // keep[k] = (keep >> 4k) & 15: the slot of the k-th kept contact
+  auto kept = [&](int k) -> uint32_t { return (uint32_t)(keep >> (4 * k)) & 15u; };
+  auto set_kept = [&](int k, uint32_t slot) { keep = (keep & ~(15ull << (4 * k))) | ((unsigned long long)slot << (4 * k)); };
   for (int a = 0; a < na; ++a) {
     for (int b = 0; b < nb; ++b) {
-      const NContact raw = p_out[(size_t)kPairContacts * p + (uint32_t)(a * MP + b)];
+      const uint32_t slot = (uint32_t)(a * MP + b);
+      const NContact raw = mine[slot];
       if (raw.lb.w == 0.0f) continue;
-      Contact c; c.a = xyz(raw.la); c.b = xyz(raw.lb); c.n = xyz(raw.n); c.t = raw.la.w;
-      LocalContact nc; nc.la = c.a + -(ci + vA * c.t); nc.lb = c.b + -(cj + vB * c.t); nc.g = c;
-      if (nc.g.t < min_t - kCollisionEps) { cnt = 1; keep[0] = nc; min_t = nc.g.t; continue; }
+      const LocalContact nc = local_of(raw);
+      if (nc.g.t < min_t - kCollisionEps) { cnt = 1; set_kept(0, slot); min_t = nc.g.t; continue; }
       if (nc.g.t > min_t + kCollisionEps) continue;
       bool merged = false;
       for (int k = 0; k < cnt && !merged; ++k) {
-        V3 ra = nc.g.a - keep[k].g.a, rb = nc.g.b - keep[k].g.b;
+        const LocalContact kc = local_of(mine[kept(k)]);
+        V3 ra = nc.g.a - kc.g.a, rb = nc.g.b - kc.g.b;
         if (mag2(ra) <= kPersistentThresholdSq || mag2(rb) <= kPersistentThresholdSq) {
-          float prev = mag2(keep[k].la) + mag2(keep[k].lb), cur = mag2(nc.la) + mag2(nc.lb);
-          if (prev < cur) keep[k] = nc;
+          float prev = mag2(kc.la) + mag2(kc.lb), cur = mag2(nc.la) + mag2(nc.lb);
+          if (prev < cur) set_kept(k, slot);
           merged = true;
         }
       }
-      if (!merged) keep[cnt++] = nc;  // cnt <= na * nb <= kPairContacts
+      if (!merged) set_kept(cnt++, slot);  // cnt <= na * nb <= kPairContacts
     }
   }
   p_nc[p] = (uint32_t)cnt;
   if (cnt == 0) return;
   V3 sum = mk3(0.0f, 0.0f, 0.0f);
-  for (int k = 0; k < cnt; ++k) sum = sum + keep[k].g.n;
+  for (int k = 0; k < cnt; ++k) sum = sum + xyz(mine[kept(k)].n);
   const V3 avg = sum / (float)cnt;
+  // (the k-th kept contact sits in a slot >= k - it was found at or after the k-th raw contact - and the kept slots are distinct: writing
+  // output slot k never overwrites a raw contact that a later k still has to read)
   for (int k = 0; k < cnt; ++k) {
-    NContact o; o.la = mk4(keep[k].la, min_t); o.lb = mk4(keep[k].lb, 0.0f); o.n = mk4(avg, 0.0f);
+    const LocalContact kc = local_of(mine[kept(k)]);
+    NContact o; o.la = mk4(kc.la, min_t); o.lb = mk4(kc.lb, 0.0f); o.n = mk4(avg, 0.0f);
     p_out[(size_t)kPairContacts * p + k] = o;
   }
 }
-// Terrain: per face (the candidate list is in the mesh's DFS order) the body's parts in order; every contact is its own
-// constraint (world.rs:243-251).  The same two steps: an item per (part, candidate of the block), part-major, writes the part's
-// up to two contacts to the candidate's slots (2 a, 2 a + 1) and their number to LDS; a thread per candidate packs them.
 template <int MP>
 __global__ __launch_bounds__(kBlock) void k_narrow_terrain_parts(Bodies B, TerrainDev M, const uint32_t* m_ptr, const uint32_t* t_owner,
                                                                  const uint32_t* t_cand, uint32_t* t_nc,

@@ -91,7 +91,7 @@ struct Flow6 {
   uint32_t rows;             // table rows per block
   uint32_t fcap, slot_cap;   // LDS split of this launch: foreign body slots, constraint slots
   uint32_t poll_waves, poll_k;  // waves that poll the incoming channels; 1: every sweep through the worklist, >= 2: quiet sweeps read straight
-  uint32_t chain_trips;         // CH: trips a serving wave may spend on its kept successors alone before it visits the queue again
+  uint32_t quad_max;            // QD: a wave takes a four-lanes-per-node trip while the ready queue holds at most this many nodes
   uint32_t poll_prio;           // s_setprio of the polling waves (0..3): their few instructions issue ahead of the serving waves'
 };
 constexpr uint32_t kF6RecWords = 5;  // RL: float4 words of a constraint's solver half in LDS (80 bytes: CRec words 2..20 and the accumulated impulse)
@@ -554,12 +554,15 @@ __device__ __forceinline__ void f6_arrive(const F6Ring& q, uint32_t* s_state, ui
 // accumulated impulse live in LDS for the launch as well, read once in the prologue by coalesced loads - chosen by the host when
 // the block's slots leave room for 80 more bytes each (worlds of few constraints per block: BASELINE configs 3 and 5, tiles).  A
 // node then touches no global memory at all (with CL; messages apart): its service is LDS reads + arithmetic.  Implies NL's effect.
+#ifndef MGF_F6_IDLE_SLEEP
+#define MGF_F6_IDLE_SLEEP 2  // s_sleep argument of a serving wave that found the ready queue empty (0, 1, 2: within 1.5 % of each other, r04)
+#endif
 #ifdef MGF_F6_PROFILE  // (the profile build measures the trips themselves: no per-node clock reads, whose latency would be most of a trip)
 #define F6_NODE_CLOCK() 0ull
 #else
 #define F6_NODE_CLOCK() wall_clock64()
 #endif
-template <bool TRACE, int CL, bool NL, bool RL, bool CH>
+template <bool TRACE, int CL, bool NL, bool RL, bool QD>
 __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* cons, Flow6 F, uint32_t iters, uint32_t epoch, uint32_t* abort_flag,
                                                             uint32_t spin_limit, uint64_t* trace, uint32_t C_trace) {
   if (*F.fail || *F.C_ptr == 0u) return;  // a limit was exceeded: the stand-by k_solve_flow launch behind this one does the work
@@ -791,15 +794,12 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
       if (lane == 0 && pw == 0) { st[5] = n_in; st[6] = st_wait; }
     }
   } else {
-    // The serving loop, written for few LDS round trips (r04: a trip's time is its dependent LDS accesses - ~150 clocks each - and, until
-    // CL == 2, a global fetch of a foreign body's constants; the solve's arithmetic is a tenth of it: tools/r04_trip_profile.py).
-    // CH: a lane KEEPS a local successor that its own release made ready and runs it in the wave's next trip - no push, no pop, no
-    // wait for a wave to come by (the state word comes back with the release's own atomic) - and while the wave has such lanes it
-    // skips the queue for up to F.chain_trips trips, so that a chain inside a block advances by operand loads + arithmetic + one release.
-    constexpr uint32_t kNoSlot = 0xFFFFFFFFu, kSlotMask = (1u << kF6SlotBits) - 1u;
-    uint32_t my_slot = kNoSlot, my_stw = 0u, since_pop = 0u;
+    // ---- the serving waves ---------------------------------------------------------------------------------------------------
+    // Written for few LDS round trips (r04: a trip's time is its dependent LDS accesses - ~150 clocks each - plus one lane's chain of
+    // arithmetic, tools/r04_trip_profile.py): the queue's three words are broadcast reads, both releases of a node are in flight together.
+    constexpr uint32_t kSlotMask = (1u << kF6SlotBits) - 1u;
     uint32_t* s_dummy = s_ctl + 8;  // [2] words nobody reads: the target of a release that has no local successor on a side
-#ifdef MGF_F6_PROFILE  // (variant build: where a trip's time goes, shader clocks summed over wave 0's trips -> the block's trace words 13..21)
+#ifdef MGF_F6_PROFILE  // (variant build: where a trip's time goes, shader clocks summed over wave 0's trips -> the block's trace words 13..21; QD = 0)
     uint64_t pf_t0 = 0, pf_t1 = 0, pf_t2 = 0, pf_t2a = 0, pf_t3 = 0, pf_acc6 = 0, pf_acc[5] = {0, 0, 0, 0, 0}, pf_trips = 0, pf_nodes = 0, pf_idle_t = 0;
 #define PF_STAMP(x) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); x = clock64(); } while (0)
 #define PF_STAMP_V(x) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); x = clock64(); } while (0)
@@ -807,43 +807,29 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
 #define PF_STAMP(x) do { } while (0)
 #define PF_STAMP_V(x) do { } while (0)
 #endif
-    for (;;) {
-      PF_STAMP(pf_t0);
-      const bool chained = CH && __ballot(my_slot != kNoSlot) != 0ull;
-      if (!chained || since_pop >= F.chain_trips) {
-        since_pop = 0u;
-        // the queue (every lane reads the same three words: broadcast reads, no shuffles afterwards)
-        const uint32_t left = __builtin_amdgcn_readfirstlane(__hip_atomic_load(s_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        const uint32_t h0 = __builtin_amdgcn_readfirstlane(__hip_atomic_load(q.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        const uint32_t tl = __builtin_amdgcn_readfirstlane(__hip_atomic_load(q.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if (left == 0u) break;
-        const unsigned long long fm = __ballot(my_slot == kNoSlot);
-        uint32_t take = min(tl - h0, (uint32_t)__popcll(fm));  // up to 64 ready nodes (CH: as many as the wave has free lanes)
-        if (take) {
-          uint32_t got = 0u;
-          if (lane == 0) {
-            uint32_t expect = h0;
-            if (__hip_atomic_compare_exchange_strong(q.head, &expect, h0 + take, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) got = take;
-          }
-          take = __builtin_amdgcn_readfirstlane(got);
-          const uint32_t r = (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
-          if (my_slot == kNoSlot && r < take) {
-            uint16_t* cell = &q.ring[f6_wrap(q, h0 + r)];
-            uint32_t e;
-            do { e = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (!(e & 0x8000u));  // the pusher is between its two writes
-            *cell = 0;
-            my_slot = e & 0x7FFFu;
-            my_stw = __hip_atomic_load(&s_state[my_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
+    // One trip with ONE LANE PER NODE: up to 64 ready nodes taken from the queue (head h0, tail tl as just read), run, released.
+    // Returns false when another wave took them first.
+    auto scalar_trip = [&](uint32_t h0, uint32_t tl) -> bool {
+      uint32_t take = min(tl - h0, 64u);
+      if (take) {
+        uint32_t got = 0u;
+        if (lane == 0) {
+          uint32_t expect = h0;
+          if (__hip_atomic_compare_exchange_strong(q.head, &expect, h0 + take, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) got = take;
         }
-      } else ++since_pop;
-      const bool act = my_slot != kNoSlot;
-      const unsigned long long am = __ballot(act);
+        take = __builtin_amdgcn_readfirstlane(got);
+      }
       PF_STAMP(pf_t1);
-      if (am) {
-        spins = 0;
-        uint32_t nx_slot = kNoSlot, nx_stw = 0u;
-        if (act) {
+      if (!take) return false;
+      const bool act = lane < take;
+      if (act) {
+        uint16_t* cell = &q.ring[f6_wrap(q, h0 + lane)];
+        uint32_t e;
+        do { e = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (!(e & 0x8000u));  // the pusher is between its two writes
+        *cell = 0;
+        const uint32_t my_slot = e & 0x7FFFu;
+        const uint32_t my_stw = __hip_atomic_load(&s_state[my_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        {
           const uint32_t slot = my_slot, stw = my_stw;
           const uint32_t round = (stw >> kF6StIterShift) & kF6StIterMask;
           uint64_t t_seen = 0;
@@ -916,7 +902,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
           }
 #endif
           // The release, both sides at once: the arrivals at local successors are two LDS atomics in flight together (a side without a
-          // local successor decrements a dummy word: no branch between them), then whatever became ready is kept (CH) or queued,
+          // local successor decrements a dummy word: no branch between them), then whatever became ready is queued,
           // then the messages of the sides whose successor lives in another block.
           const uint32_t w0 = sw.x, w1 = sw.y;
           const bool live0 = round + ((w0 & kF6Wrap) ? 1u : 0u) < iters, live1 = has_b && round + ((w1 & kF6Wrap) ? 1u : 0u) < iters;
@@ -924,11 +910,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
           const uint32_t ws0 = w0 & kSlotMask, ws1 = w1 & kSlotMask;
           const uint32_t was0 = __hip_atomic_fetch_sub(loc0 ? &s_state[ws0] : &s_dummy[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           const uint32_t was1 = __hip_atomic_fetch_sub(loc1 ? &s_state[ws1] : &s_dummy[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          bool rdy0 = loc0 && (was0 & kF6StArrMask) == 1u, rdy1 = loc1 && (was1 & kF6StArrMask) == 1u;
-          if (CH) {  // the lane's next node: the successor this release completed (its state word came back with the atomic)
-            if (rdy0) { nx_slot = ws0; nx_stw = was0 - 1u; rdy0 = false; }
-            else if (rdy1) { nx_slot = ws1; nx_stw = was1 - 1u; rdy1 = false; }
-          }
+          const bool rdy0 = loc0 && (was0 & kF6StArrMask) == 1u, rdy1 = loc1 && (was1 & kF6StArrMask) == 1u;
           if (rdy0) f6_push(q, ws0);
           if (rdy1) f6_push(q, ws1);
 #pragma unroll
@@ -948,25 +930,193 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
             __hip_atomic_fetch_max(F.tails + s_out_tidx[chn], ((unsigned long long)epoch << 32) | (pos + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
-        my_slot = nx_slot; my_stw = nx_stw;
-        if (lane == 0) __hip_atomic_fetch_sub(s_left, (uint32_t)__popcll(am), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (lane == 0) __hip_atomic_fetch_sub(s_left, take, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef MGF_F6_PROFILE
+      {
+        uint64_t pf_t4; PF_STAMP(pf_t4);
+        const uint64_t a2 = __shfl(pf_t2, 0), a3 = __shfl(pf_t3, 0), a2a = __shfl(pf_t2a, 0);
+        pf_acc6 += a2a - pf_t1;
+        pf_acc[0] += pf_t1 - pf_t0; pf_acc[1] += a2 - pf_t1; pf_acc[2] += a3 - a2; pf_acc[3] += pf_t4 - a3; ++pf_trips; pf_nodes += (uint64_t)take;
+      }
+#endif
+      return true;
+    };
+    // QD: FOUR LANES PER NODE.  Lane c of a quad (lane 3 mirrors lane 2) holds component c of every vector of the solve and runs
+    // ContactConstraint::solve (solver.rs:203-252) in the reference's operation order with the other components fetched through DPP
+    // quad permutes: a cross product is 2 multiplies and a subtraction per lane (its rotated operands are DPP sources or were loaded
+    // rotated), a matrix-vector product 3 multiplies and 2 adds, a dot product a multiply, a move and two adds.  ~105 float
+    // instructions per lane where the one-lane form needs ~330 on one dependent chain - and that chain is what a trip's time is made
+    // of - at 16 nodes per wave trip.  Bit-identical: same operations, same order, no contraction.  A wave takes a quad trip while the
+    // queue holds at most F.quad_max nodes (the latency-bound stretches of a launch: few nodes ready, every one on somebody's critical
+    // path) and a one-lane-per-node trip of up to 64 when it holds more (the throughput-bound stretches).
+    const uint32_t k4 = lane & 3u, quad = lane >> 2;
+    const uint32_t cc = k4 == 3u ? 2u : k4, c1 = cc == 2u ? 0u : cc + 1u, c2 = cc == 0u ? 2u : cc - 1u;  // this lane's component, the next, the one after
+    // quad permutes (dpp_ctrl = sel0 | sel1 << 2 | sel2 << 4 | sel3 << 6): the value of the lane holding the NEXT component, the one after, component j
+#define QP(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (float)(x)), (ctrl), 0xF, 0xF, true))
+#define Q_NEXT(x) QP(x, 0x09)   /* [1, 2, 0, 0] */
+#define Q_PREV(x) QP(x, 0x52)   /* [2, 0, 1, 1] */
+#define Q_X(x) QP(x, 0x00)
+#define Q_Y(x) QP(x, 0x55)
+#define Q_Z(x) QP(x, 0xAA)
+    auto quad_trip = [&](uint32_t h0, uint32_t tl) -> bool {
+      uint32_t take = min(tl - h0, 16u);  // up to 16 ready nodes: one per quad
+      if (take) {
+        uint32_t got = 0u;
+        if (lane == 0) {
+          uint32_t expect = h0;
+          if (__hip_atomic_compare_exchange_strong(q.head, &expect, h0 + take, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) got = take;
+        }
+        take = __builtin_amdgcn_readfirstlane(got);
+      }
+      if (!take) return false;
+      const bool act = quad < take;
+      if (act) {
+        uint16_t* cell = &q.ring[f6_wrap(q, h0 + quad)];
+        uint32_t e;
+        do { e = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (!(e & 0x8000u));  // the pusher is between its two writes
+        if (k4 == 0u) *cell = 0;  // (the quad's four lanes read the cell together, above)
+        const uint32_t slot = e & 0x7FFFu;
+        const uint32_t stw = __hip_atomic_load(&s_state[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t round = (stw >> kF6StIterShift) & kF6StIterMask;
+        uint64_t t_seen = 0;
+        if (TRACE) t_seen = F6_NODE_CLOCK();
+        const uint32_t c = s_c[slot], ref = stw >> kF6StRefShift;
+        const uint2 sw = s_succ[slot];
+        const uint32_t ai = ref & kF6NoBody, bi_raw = (ref >> kF6BodyBits) & kF6NoBody;
+        const bool has_b = bi_raw != kF6NoBody;
+        const uint32_t bi = has_b ? bi_raw : ai;
+        // ---- operands: this lane's component of every vector
+        float* fa = reinterpret_cast<float*>(s_body + 2 * (size_t)ai);
+        float* fb = reinterpret_cast<float*>(s_body + 2 * (size_t)bi);
+        float va = fa[cc], oa = fa[3u + cc], vb = fb[cc], ob = fb[3u + cc];
+        const uint32_t ga = f2u(fa[6]), gb = f2u(fb[6]);
+        // constants of a body as a flat row: [0] inverse mass, [1 + 3 j + i] = column j, row i of the world inverse inertia
+        float im_a, ia0, ia1, ia2, im_b, ib0, ib1, ib2;
         {
-          uint64_t pf_t4; PF_STAMP(pf_t4);
-          // (stamps taken by inactive lanes are stale: the first active lane's are the trip's)
-          const int fl = (int)__builtin_ctzll(am);
-          const uint64_t a2 = __shfl(pf_t2, fl), a3 = __shfl(pf_t3, fl), a2a = __shfl(pf_t2a, fl);
-          pf_acc6 += a2a - pf_t1;
-          pf_acc[0] += pf_t1 - pf_t0; pf_acc[1] += a2 - pf_t1; pf_acc[2] += a3 - a2; pf_acc[3] += pf_t4 - a3; ++pf_trips; pf_nodes += (uint64_t)__popcll(am);
+          const float* ka;
+          if (CL) ka = reinterpret_cast<const float*>(s_const + 5 * (size_t)ai);
+          else ka = reinterpret_cast<const float*>(srec + 4 * (size_t)ga) + 6;
+          im_a = ka[0]; ia0 = ka[1u + cc]; ia1 = ka[4u + cc]; ia2 = ka[7u + cc];
+          if (CL == 2 || (CL == 1 && bi < F.nb)) {
+            const float* kb = reinterpret_cast<const float*>(s_const + 5 * (size_t)bi);
+            im_b = kb[0]; ib0 = kb[1u + cc]; ib1 = kb[4u + cc]; ib2 = kb[7u + cc];
+          } else {
+            const float* kb = reinterpret_cast<const float*>(srec + 4 * (size_t)gb) + 6;
+            im_b = kb[0]; ib0 = kb[1u + cc]; ib1 = kb[4u + cc]; ib2 = kb[7u + cc];
+          }
+        }
+        float n, t0, t1, ra1, ra2, rb1, rb2, bias, nmass, tm0, tm1, nimp;  // (the arms only ever enter cross products: their rotated components)
+        if (RL) {  // the staged half: words 0..15 = CRec words 4..19, then {n.x, n.y, tmass1, nimp}
+          const float* R = reinterpret_cast<const float*>(s_rec + kF6RecWords * (size_t)slot);
+          n = R[cc == 2u ? 0u : 16u + cc]; t0 = R[1u + cc]; t1 = R[4u + cc];
+          ra1 = R[7u + c1]; ra2 = R[7u + c2]; rb1 = R[10u + c1]; rb2 = R[10u + c2];
+          bias = R[13]; nmass = R[14]; tm0 = R[15]; tm1 = R[18]; nimp = R[19];
+        } else {  // CRec words: 2 n, 5 t0, 8 t1, 11 ra, 14 rb, 17 bias, 18 nmass, 19 20 tmass, 22 nimp - one 128-byte line
+          const float* G = reinterpret_cast<const float*>(&cons[c]);
+          n = G[2u + cc]; t0 = G[5u + cc]; t1 = G[8u + cc];
+          ra1 = G[11u + c1]; ra2 = G[11u + c2]; rb1 = G[14u + c1]; rb2 = G[14u + c2];
+          bias = G[17]; nmass = G[18]; tm0 = G[19]; tm1 = G[20];
+          nimp = NLS ? s_nimp[slot] : G[22];
+        }
+        if (!has_b) { vb = 0.0f; ob = 0.0f; im_b = 0.0f; ib0 = 0.0f; ib1 = 0.0f; ib2 = 0.0f; }  // static_dyn(): physics.rs:289-302
+        // ---- the solve, component-parallel (solve_core in k_links.h is the one-lane statement of the same operations)
+        // cross(w, r)[c] = w[c+1] r[c+2] - w[c+2] r[c+1];  dot = (p.x + p.y) + p.z;  (M v)[c] = (M[c][0] v.x + M[c][1] v.y) + M[c][2] v.z
+        auto cross_wr = [&](float w, float r1_, float r2_) -> float { return Q_NEXT(w) * r2_ - Q_PREV(w) * r1_; };  // dynamic w, rotated constant r
+        auto cross_rw = [&](float r1_, float r2_, float w) -> float { return r1_ * Q_PREV(w) - r2_ * Q_NEXT(w); };  // constant r, dynamic w
+        auto dot3 = [&](float p) -> float { return (Q_X(p) + Q_Y(p)) + Q_Z(p); };
+        auto mat3 = [&](float m0, float m1, float m2, float v) -> float { return (m0 * Q_X(v) + m1 * Q_Y(v)) + m2 * Q_Z(v); };
+        const float dv = ((vb + cross_wr(ob, rb1, rb2)) - va) - cross_wr(oa, ra1, ra2);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const float t = k == 0 ? t0 : t1, tm = k == 0 ? tm0 : tm1;
+          const float lambda = -dot3(dv * t) * tm;
+          const float imp = t * lambda;
+          va = va - imp * im_a;
+          oa = oa - mat3(ia0, ia1, ia2, cross_rw(ra1, ra2, imp));
+          vb = vb + imp * im_b;
+          ob = ob + mat3(ib0, ib1, ib2, cross_rw(rb1, rb2, imp));
+        }
+        {
+          const float dv2 = ((vb + cross_wr(ob, rb1, rb2)) - va) - cross_wr(oa, ra1, ra2);
+          const float vn = dot3(dv2 * n);
+          float lambda = nmass * (-vn + bias);
+          const float prev = nimp;
+          nimp = fmax_rs(prev + lambda, 0.0f);
+          lambda = nimp - prev;
+          const float imp = n * lambda;
+          va = va - imp * im_a;
+          oa = oa - mat3(ia0, ia1, ia2, cross_rw(ra1, ra2, imp));
+          vb = vb + imp * im_b;
+          ob = ob + mat3(ib0, ib1, ib2, cross_rw(rb1, rb2, imp));
+        }
+        // ---- ConstrainedSet::set: every lane its component (lane 3 holds lane 2's: it writes nothing)
+        if (k4 < 3u) {
+          fa[cc] = va; fa[3u + cc] = oa;
+          if (has_b) { fb[cc] = vb; fb[3u + cc] = ob; }
+        }
+        if (k4 == 0u) {
+          if (RL) reinterpret_cast<float*>(s_rec + kF6RecWords * (size_t)slot)[19] = nimp;
+          else if (NLS) s_nimp[slot] = nimp;
+          else cons[c].nimp = nimp;
+          // re-arm: one arrival per dynamic body and iteration from now on, and one more iteration done
+          __hip_atomic_fetch_add(&s_state[slot], (1u << kF6StIterShift) + (has_b ? 2u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // the body's whole velocity in lanes 0 (a) and 1 (b) of the quad: what a message or the final write-back of a foreign body carries
+        const float a_vx = Q_X(va), a_vy = Q_Y(va), a_vz = Q_Z(va), a_wx = Q_X(oa), a_wy = Q_Y(oa), a_wz = Q_Z(oa);
+        const float b_vx = Q_X(vb), b_vy = Q_Y(vb), b_vz = Q_Z(vb), b_wx = Q_X(ob), b_wy = Q_Y(ob), b_wz = Q_Z(ob);
+        if (round + 1u == iters && k4 == 1u) {  // the end of a foreign body's chain: its home block does not write it back
+          if (has_b && (sw.y & kF6Wrap) && bi >= F.nb) {
+            srec[4 * (size_t)gb] = make_float4(b_vx, b_vy, b_vz, b_wx);
+            *reinterpret_cast<float2*>(&srec[4 * (size_t)gb + 1]) = make_float2(b_wy, b_wz);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // velocities are in LDS before any local successor hears of it
+#ifndef MGF_F6_PROFILE
+        if (TRACE && k4 == 0u) {
+          trace[2 * ((size_t)round * C_trace + c)] = t_seen & ~3ull;
+          trace[2 * ((size_t)round * C_trace + c) + 1] = F6_NODE_CLOCK();
         }
 #endif
-        continue;
+        // ---- the release: lane 0 of the quad releases body a's successor, lane 1 body b's - both in the same instructions
+        if (k4 < 2u) {
+          const uint32_t w = k4 == 0u ? sw.x : sw.y;
+          const bool live = (k4 == 0u || has_b) && round + ((w & kF6Wrap) ? 1u : 0u) < iters;
+          const bool loc = live && !(w & kF6Remote);
+          const uint32_t ws = w & kSlotMask;
+          const uint32_t was = __hip_atomic_fetch_sub(loc ? &s_state[ws] : &s_dummy[k4], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (loc && (was & kF6StArrMask) == 1u) f6_push(q, ws);
+          if (live && (w & kF6Remote)) {  // a message: the body's velocity, where it goes, the launch's tag in every granule - and on we go
+            const uint32_t chn = (w >> 24) & (kF6Chan - 1u);  // (6 bits)
+            const uint32_t pos = __hip_atomic_fetch_add(&s_out_tail[chn], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t byte = (s_out_base[chn] + pos) * (16u * kF6MsgWords);
+            const float tg = u2f(epoch);
+            v4f_t m0, m1;
+            if (k4 == 0u) { m0 = v4f_t{a_vx, a_vy, a_vz, tg}; m1 = v4f_t{a_wx, a_wy, a_wz, tg}; }
+            else { m0 = v4f_t{b_vx, b_vy, b_vz, tg}; m1 = v4f_t{b_wx, b_wy, b_wz, tg}; }
+            v4f_t m2 = {u2f(w & 0x00FFFFFFu), TRACE ? u2f((uint32_t)F6_NODE_CLOCK()) : 0.0f, 0.0f, tg};
+            __builtin_amdgcn_raw_buffer_store_b128(m0, rmb, (int)byte, 0, kSc1);
+            __builtin_amdgcn_raw_buffer_store_b128(m1, rmb, (int)(byte + 16u), 0, kSc1);
+            __builtin_amdgcn_raw_buffer_store_b128(m2, rmb, (int)(byte + 32u), 0, kSc1);
+            __hip_atomic_fetch_max(F.tails + s_out_tidx[chn], ((unsigned long long)epoch << 32) | (pos + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+      if (lane == 0) __hip_atomic_fetch_sub(s_left, take, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      return true;
+    };
+    for (;;) {
+      PF_STAMP(pf_t0);
+      const uint32_t left = __builtin_amdgcn_readfirstlane(__hip_atomic_load(s_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      const uint32_t h0 = __builtin_amdgcn_readfirstlane(__hip_atomic_load(q.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      const uint32_t tl = __builtin_amdgcn_readfirstlane(__hip_atomic_load(q.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      if (left == 0u) break;
+      if (tl != h0) {
+        const bool did = (QD && tl - h0 <= F.quad_max) ? quad_trip(h0, tl) : scalar_trip(h0, tl);
+        if (did) { spins = 0; continue; }
       }
 #ifdef MGF_F6_PROFILE
-      pf_idle_t += pf_t1 - pf_t0; pf_acc[4] += 1;
-#endif
-#ifndef MGF_F6_IDLE_SLEEP
-#define MGF_F6_IDLE_SLEEP 2
+      { uint64_t pf_now; PF_STAMP(pf_now); pf_idle_t += pf_now - pf_t0; pf_acc[4] += 1; }
 #endif
       if (MGF_F6_IDLE_SLEEP > 0) __builtin_amdgcn_s_sleep(MGF_F6_IDLE_SLEEP);
       if ((++spins & 255u) == 0u) {
@@ -980,6 +1130,12 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
       tstat[13] = pf_acc[0]; tstat[14] = pf_acc[1]; tstat[15] = pf_acc[2]; tstat[16] = pf_acc[3]; tstat[17] = pf_trips; tstat[18] = pf_nodes; tstat[19] = pf_idle_t; tstat[20] = pf_acc[4]; tstat[21] = pf_acc6;
     }
 #endif
+#undef QP
+#undef Q_NEXT
+#undef Q_PREV
+#undef Q_X
+#undef Q_Y
+#undef Q_Z
   }
 #undef PF_STAMP
 #undef PF_STAMP_V

@@ -1,23 +1,40 @@
 #!/bin/bash
-# rocprofv3 evidence for bench.py's default window and for the settled pile: kernel trace, then the two PMC passes (separate
-# runs, counters only - MI355X_MICROARCH.md).  Usage on the GPU box: bash tools/collect_profiles.sh <tag>   (writes gpurun_out/<tag>_*)
+# The round's rocprofv3 evidence (run on the GPU box through gpurun): for every window bench.py reports - the falling pile (default:
+# --warmup 10 --steps 60), the driver's own command (--warmup 5 --steps 20), the settled pile (--warmup 400), BASELINE configs 3 and 5,
+# each with 60 and with 20 timed ticks (the driver's nested windows) - a kernel trace and the two PMC passes (FETCH_SIZE, WRITE_SIZE:
+# separate runs, counters only - MI355X_MICROARCH.md), all on the exact bench command.
+#   Usage: bash tools/collect_profiles.sh <tag>   -> gpurun_out/<tag>_*      then: python tools/publish_profiles.py <tag>
 set -u
-TAG=${1:-r02}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
-B="python $R/bench.py --no-cpu-baseline --no-settled --no-order-check --min-seconds 0"
+O=$R/gpurun_out
+B="python $R/bench.py --no-cpu-baseline --no-settled --no-order-check --no-other-configs --min-seconds 0"
 cd /tmp && export TMPDIR=/tmp
-for W in 10 400; do
-  N=t; [ $W = 400 ] && N=s
-  rocprofv3 --kernel-trace -d $R/gpurun_out/${TAG}${N}_trace -o bench -- $B --warmup $W > $R/gpurun_out/${TAG}${N}_trace.log 2>&1
-  grep -a '"metric"' $R/gpurun_out/${TAG}${N}_trace.log | tail -1 > $R/gpurun_out/${TAG}${N}_bench_under_trace.json
-  rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}${N}_fetch -o bench -- $B --warmup $W > $R/gpurun_out/${TAG}${N}_fetch.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${TAG}${N}_write -o bench -- $B --warmup $W > $R/gpurun_out/${TAG}${N}_write.log 2>&1
-  $B --warmup $W > $R/gpurun_out/${TAG}${N}_bench.json 2> /dev/null
-done
+run() {  # name, timed ticks, dominant kernel, window label for bench.py, its warm-up, bench args...
+  local N=$1 K=$2 KER=$3 WIN=$4 W=$5; shift 5
+  rocprofv3 --kernel-trace -d $O/${TAG}_${N}_trace -o bench -- $B "$@" > $O/${TAG}_${N}_trace.log 2>&1
+  grep -a '"metric"' $O/${TAG}_${N}_trace.log | tail -1 > $O/${TAG}_${N}_bench_under_trace.json
+  rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_${N}_fetch -o bench -- $B "$@" > $O/${TAG}_${N}_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_${N}_write -o bench -- $B "$@" > $O/${TAG}_${N}_write.log 2>&1
+  $B "$@" > $O/${TAG}_${N}_bench.json 2> /dev/null
+  ( cd $R
+    python tools/rocprof_summary.py gpurun_out/${TAG}_${N}_trace/bench_results.db $K --timed $KER $K > gpurun_out/${TAG}_${N}_kernel_stats.txt
+    python tools/pmc_summary.py gpurun_out/${TAG}_${N}_fetch/bench_results.db gpurun_out/${TAG}_${N}_write/bench_results.db --timed $KER $K gpurun_out/${TAG}_${N}_pmc.json $WIN $W $K > gpurun_out/${TAG}_${N}_pmc_hbm_traffic.txt
+    rm -rf gpurun_out/${TAG}_${N}_trace gpurun_out/${TAG}_${N}_fetch gpurun_out/${TAG}_${N}_write )
+}
+run transient  60 k_solve_flow6 transient 10 --warmup 10 --steps 60
+run driver     20 k_solve_flow6 transient 5  --warmup 5 --steps 20
+run settled    60 k_solve_flow6 settled 400 --warmup 400 --steps 60
+run settled20  20 k_solve_flow6 settled 400 --warmup 400 --steps 20
+run config3    60 k_solve_flow6 config3 150 --scene config3
+run config3_20 20 k_solve_flow6 config3 150 --scene config3 --steps 20
+run config5    60 k_solve_flow6 config5 80  --scene config5
+run config5_20 20 k_solve_flow6 config5 80  --scene config5 --steps 20
 cd $R
-for N in t s; do
-  python tools/rocprof_summary.py gpurun_out/${TAG}${N}_trace/bench_results.db 60 > gpurun_out/${TAG}${N}_kernel_stats.txt
-  W=10; NAME=transient; [ $N = s ] && W=400 && NAME=settled
-  python tools/pmc_summary.py gpurun_out/${TAG}${N}_fetch/bench_results.db gpurun_out/${TAG}${N}_write/bench_results.db --timed k_solve_flow6 60 gpurun_out/${TAG}${N}_pmc_k_solve_flow6.json $NAME $W 60 > gpurun_out/${TAG}${N}_pmc_hbm_traffic.txt
-done
-ls gpurun_out | grep ${TAG}
+python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
+python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_driver_command.json 2> /dev/null
+python bench.py --gpus 1 --scene config4 --no-cpu-baseline > $O/${TAG}_config4_8tiles_1gpu_bench.json 2> /dev/null
+python bench.py --gpus 1 --scene config5_tiles --no-cpu-baseline > $O/${TAG}_config5_8tiles_1gpu_bench.json 2> /dev/null
+python bench.py --scene config5 --no-cpu-baseline > $O/${TAG}_config5_undivided_1gpu.json 2> /dev/null
+python tools/config4_undivided.py > /dev/null 2>&1; cp $O/config4_undivided_1gpu.json $O/${TAG}_config4_undivided_1gpu.json
+ls $O | grep ${TAG}_

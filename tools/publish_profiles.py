@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copies one collection of tools/collect_profiles_r03.sh (gpurun_out/<tag>_*) into profiles/ (tracked) and assembles the PMC records
+"""Copies one collection of tools/collect_profiles.sh (gpurun_out/<tag>_*) into profiles/ (tracked) and assembles the PMC records
 bench.py's `roofline.traffic` reads: profiles/pmc_k_solve_flow6.json = the LIST of the falling-pile windows that were profiled
 (bench.py's default window and the driver's own --warmup 5 --steps 20), _settled, and one file per other BASELINE config.
 Usage: python tools/publish_profiles.py <tag>"""
@@ -14,7 +14,7 @@ tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out")
 dst = os.path.join(ROOT, "profiles")
 keep = ("_bench.json", "_bench_under_trace.json", "_kernel_stats.txt", "_pmc_hbm_traffic.txt", "_bench_default.json", "_bench_driver_command.json",
-        "_config4_8tiles_1gpu_bench.json", "_config4_undivided_1gpu.json")
+        "_config4_8tiles_1gpu_bench.json", "_config4_undivided_1gpu.json", "_config5_8tiles_1gpu_bench.json", "_config5_undivided_1gpu.json")
 n = 0
 for p in sorted(glob.glob(os.path.join(src, tag + "_*"))):
     if os.path.isfile(p) and p.endswith(keep) and os.path.getsize(p) > 0:
@@ -34,7 +34,7 @@ def put(name, obj):
 
 
 put("pmc_k_solve_flow6.json", [r for r in (rec("transient"), rec("driver")) if r])
-put("pmc_k_solve_flow6_settled.json", rec("settled"))
-put("pmc_config3_k_solve_flow6.json", rec("config3"))
-put("pmc_config5_k_solve_flow6.json", rec("config5"))
+put("pmc_k_solve_flow6_settled.json", [r for r in (rec("settled"), rec("settled20")) if r])
+put("pmc_config3_k_solve_flow6.json", [r for r in (rec("config3"), rec("config3_20")) if r])
+put("pmc_config5_k_solve_flow6.json", [r for r in (rec("config5"), rec("config5_20")) if r])
 print(n, "files copied under profiles/ with tag", tag)
