@@ -889,10 +889,10 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
           if (round + 1u == iters) {  // the end of a foreign body's chain: its home block does not write it back
             if (has_b && (sw.y & kF6Wrap) && bi >= F.nb) store_vel(srec, gb, Bd);  // (a is always the block's own)
           }
-#ifndef MGF_F6_NO_STORE_WAIT
+#ifdef MGF_F6_STORE_WAIT  // (r04: not needed - a wave's DS instructions execute in issue order, so the release's atomic cannot overtake the stores; 1-2.5 % faster without)
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // velocities are in LDS before any local successor hears of it
 #else
-          asm volatile("" ::: "memory");  // (experiment: a wave's DS instructions execute in issue order)
+          asm volatile("" ::: "memory");
 #endif
           PF_STAMP(pf_t3);
 #ifndef MGF_F6_PROFILE
@@ -1062,16 +1062,20 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
           // re-arm: one arrival per dynamic body and iteration from now on, and one more iteration done
           __hip_atomic_fetch_add(&s_state[slot], (1u << kF6StIterShift) + (has_b ? 2u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        // the body's whole velocity in lanes 0 (a) and 1 (b) of the quad: what a message or the final write-back of a foreign body carries
-        const float a_vx = Q_X(va), a_vy = Q_Y(va), a_vz = Q_Z(va), a_wx = Q_X(oa), a_wy = Q_Y(oa), a_wz = Q_Z(oa);
-        const float b_vx = Q_X(vb), b_vy = Q_Y(vb), b_vz = Q_Z(vb), b_wx = Q_X(ob), b_wy = Q_Y(ob), b_wz = Q_Z(ob);
+#ifdef MGF_F6_STORE_WAIT  // (r04: not needed - a wave's DS instructions execute in issue order, so the release's atomic cannot overtake the stores; 1-2.5 % faster without)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // velocities are in LDS before any local successor hears of it
+#else
+        asm volatile("" ::: "memory");
+#endif
+        // (a body's whole velocity - what a message or the final write-back of a foreign body carries - is read back from its LDS slot by
+        // the one lane that needs it: no gathering across the quad on the path of the nodes that need neither)
         if (round + 1u == iters && k4 == 1u) {  // the end of a foreign body's chain: its home block does not write it back
           if (has_b && (sw.y & kF6Wrap) && bi >= F.nb) {
-            srec[4 * (size_t)gb] = make_float4(b_vx, b_vy, b_vz, b_wx);
-            *reinterpret_cast<float2*>(&srec[4 * (size_t)gb + 1]) = make_float2(b_wy, b_wz);
+            const float4 p0 = s_body[2 * (size_t)bi], p1 = s_body[2 * (size_t)bi + 1];
+            srec[4 * (size_t)gb] = p0;
+            *reinterpret_cast<float2*>(&srec[4 * (size_t)gb + 1]) = make_float2(p1.x, p1.y);
           }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // velocities are in LDS before any local successor hears of it
 #ifndef MGF_F6_PROFILE
         if (TRACE && k4 == 0u) {
           trace[2 * ((size_t)round * C_trace + c)] = t_seen & ~3ull;
@@ -1091,9 +1095,9 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
             const uint32_t pos = __hip_atomic_fetch_add(&s_out_tail[chn], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const uint32_t byte = (s_out_base[chn] + pos) * (16u * kF6MsgWords);
             const float tg = u2f(epoch);
-            v4f_t m0, m1;
-            if (k4 == 0u) { m0 = v4f_t{a_vx, a_vy, a_vz, tg}; m1 = v4f_t{a_wx, a_wy, a_wz, tg}; }
-            else { m0 = v4f_t{b_vx, b_vy, b_vz, tg}; m1 = v4f_t{b_wx, b_wy, b_wz, tg}; }
+            const uint32_t xi = k4 == 0u ? ai : bi;
+            const float4 p0 = s_body[2 * (size_t)xi], p1 = s_body[2 * (size_t)xi + 1];
+            const v4f_t m0 = {p0.x, p0.y, p0.z, tg}, m1 = {p0.w, p1.x, p1.y, tg};
             v4f_t m2 = {u2f(w & 0x00FFFFFFu), TRACE ? u2f((uint32_t)F6_NODE_CLOCK()) : 0.0f, 0.0f, tg};
             __builtin_amdgcn_raw_buffer_store_b128(m0, rmb, (int)byte, 0, kSc1);
             __builtin_amdgcn_raw_buffer_store_b128(m1, rmb, (int)(byte + 16u), 0, kSc1);
