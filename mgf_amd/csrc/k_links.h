@@ -173,11 +173,8 @@ __device__ __forceinline__ void solve_core(V3 n, V3 t0, V3 t1, V3 ra, V3 rb, flo
                                            float& nimp, BodyDyn& A, BodyDyn& Bd) {
   V3 va = A.v, oa = A.w, vb = Bd.v, ob = Bd.w;
   V3 dv = vb + cross(ob, rb) - va - cross(oa, ra);
-#ifndef MGF_ABLATE_FRICTION_ROWS  // (timing experiments only: the results are wrong without the rows)
-#define MGF_ABLATE_FRICTION_ROWS 0
-#endif
 #pragma unroll
-  for (int k = 0; k < (MGF_ABLATE_FRICTION_ROWS ? 0 : 2); ++k) {
+  for (int k = 0; k < 2; ++k) {
     V3 t = k == 0 ? t0 : t1;
     float tm = k == 0 ? tmass0 : tmass1;
     float lambda = -dot(dv, t) * tm;
