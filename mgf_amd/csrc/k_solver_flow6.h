@@ -969,6 +969,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
         }
         take = __builtin_amdgcn_readfirstlane(got);
       }
+      PF_STAMP(pf_t1);
       if (!take) return false;
       const bool act = quad < take;
       if (act) {
@@ -1020,6 +1021,8 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
           nimp = NLS ? s_nimp[slot] : G[22];
         }
         if (!has_b) { vb = 0.0f; ob = 0.0f; im_b = 0.0f; ib0 = 0.0f; ib1 = 0.0f; ib2 = 0.0f; }  // static_dyn(): physics.rs:289-302
+        PF_STAMP(pf_t2a);
+        PF_STAMP_V(pf_t2);
         // ---- the solve, component-parallel (solve_core in k_links.h is the one-lane statement of the same operations)
         // cross(w, r)[c] = w[c+1] r[c+2] - w[c+2] r[c+1];  dot = (p.x + p.y) + p.z;  (M v)[c] = (M[c][0] v.x + M[c][1] v.y) + M[c][2] v.z
         auto cross_wr = [&](float w, float r1_, float r2_) -> float { return Q_NEXT(w) * r2_ - Q_PREV(w) * r1_; };  // dynamic w, rotated constant r
@@ -1076,6 +1079,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
             *reinterpret_cast<float2*>(&srec[4 * (size_t)gb + 1]) = make_float2(p1.x, p1.y);
           }
         }
+        PF_STAMP(pf_t3);
 #ifndef MGF_F6_PROFILE
         if (TRACE && k4 == 0u) {
           trace[2 * ((size_t)round * C_trace + c)] = t_seen & ~3ull;
@@ -1107,6 +1111,14 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
         }
       }
       if (lane == 0) __hip_atomic_fetch_sub(s_left, take, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef MGF_F6_PROFILE
+      {
+        uint64_t pf_t4; PF_STAMP(pf_t4);
+        const uint64_t a2 = __shfl(pf_t2, 0), a3 = __shfl(pf_t3, 0), a2a = __shfl(pf_t2a, 0);
+        pf_acc6 += a2a - pf_t1;
+        pf_acc[0] += pf_t1 - pf_t0; pf_acc[1] += a2 - pf_t1; pf_acc[2] += a3 - a2; pf_acc[3] += pf_t4 - a3; ++pf_trips; pf_nodes += (uint64_t)take;
+      }
+#endif
       return true;
     };
     for (;;) {
