@@ -200,7 +200,7 @@ def bench_single_world(args, ctx, mgf_amd, scenes, configure, mode):
     snap = world.clone()
     windows = []
     total = 0.0
-    while not windows or (total < args.min_seconds and len(windows) < 200):
+    while not windows or (total < args.min_seconds and len(windows) < 1000):
         w = snap.clone()
         configure(w)
         import torch
@@ -255,7 +255,7 @@ def bench_single_world(args, ctx, mgf_amd, scenes, configure, mode):
         import torch
         snap2 = w.clone()
         wins2, total2 = [], 0.0
-        while not wins2 or (total2 < args.min_seconds and len(wins2) < 200):
+        while not wins2 or (total2 < args.min_seconds and len(wins2) < 1000):
             x = snap2.clone()
             configure(x)
             torch.cuda.synchronize()
@@ -309,7 +309,7 @@ def bench_other_config(args, ctx, mgf_amd, scenes, configure, mode, kind, standa
     windows, total = [], 0.0
     budget = args.min_seconds if standalone else args.min_seconds / 3.0
     # (nested in the config-2 line: three windows, the median's reported - a clone's first window pays for its buffers)
-    while len(windows) < 3 or (total < budget and len(windows) < 200):
+    while len(windows) < 3 or (total < budget and len(windows) < 1000):
         w = snap.clone()
         configure(w)
         torch.cuda.synchronize()
