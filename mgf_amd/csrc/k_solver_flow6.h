@@ -25,7 +25,7 @@ namespace mgf {
 // eventually seen.  Bit-identical to the sequential order: any topological order of the graph is.
 // ------------------------------------------------------------------------------------------
 #ifndef MGF_F6_THREADS
-#define MGF_F6_THREADS 512
+#define MGF_F6_THREADS 768  // 12 waves: 11 serving + 1 polling (r04: with quad trips - 16 nodes per wave trip - the settled pile gains 4 % over 8 waves, the other scenes are within 1 %; 6 waves lose; a run-time size costs 2 %)
 #endif
 constexpr int kF6Threads = MGF_F6_THREADS;
 constexpr uint32_t kF6Chan = 64;                       // neighbour blocks per block, each direction (hash slots)
