@@ -407,6 +407,10 @@ MGF_API int64_t mgf_tiles_counter(const mgf_tiles* t, const char* key);
  * solver kernels; "solver_mode" [6] 1 = persistent dataflow launch, 0 = one launch per dependency frontier,
  * 4 = dataflow with out-of-order slots, 5 = block-local dataflow (velocities and counters of a spatial block in LDS),
  * 6 = block-local dataflow with message channels between the blocks (every body a block touches in LDS);
+ * (modes 1, 4, 5, 6 are persistent launches whose workgroups wait for one another: they need the device's compute units to
+ * themselves - one process per GPU, one context's stream at a time.  Where two processes' launches overlap on one device each
+ * may hold part of the compute units; a launch then gives up after about half a second and the call returns MGF_ERR_HIP
+ * "dataflow solver gave up waiting" instead of hanging - the world's velocities are then undefined);
  * "constraint_order" [0] 1 = the reference's own insertion order, replayed on the host (world.rs:233-291);
  * "pair_brick" [1] (grid broadphase with an 8x8x8-cell box staged in LDS; 0 = every look-up from global memory);
  * "body_pack" [1] (the constraint setup reads collider, motion and info from the packed per-tick copy);
