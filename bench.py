@@ -572,7 +572,7 @@ def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, w
         "tile_tick_ms_rank0": elapsed * 1e3 / (args.steps * per_rank),
         "tile_tick_ms_per_rank": [round(float(v), 4) for v in rank_ms.cpu().numpy()],
         "roofline": _roofline(r_units, r_launches, kms, mode, f"{refresh_every} iteration(s) of one tile between ghost refreshes; the {args.steps} ticks behind the "
-                              "timed region, HIP events around every launch", ("tiles", args.warmup, args.steps)),
+                              "timed region, HIP events around every launch", ("tiles", warmup, args.steps), workload=("config4" if scene_kind != "config5_tiles" else "config5") + "_tiles"),
         "instrumentation": "the timed ticks carry no HIP events; the roofline's launches are those of the same number of ticks run right behind them with the events on",
         "same_workload_on_one_gpu": one_gpu, "efficiency_vs_same_workload_on_one_gpu": eff,
         "exchange": exchange, "seam_penetration": seam,
@@ -644,7 +644,8 @@ def _pmc_traffic(mode, window, workload="config2"):
             continue
         for r in (d if isinstance(d, list) else [d]):
             recs.append(r.get("window"))
-            if r.get("window") and list(r["window"][1:]) == list(window[1:]):
+            same_scene = r.get("window") and {r["window"][0], window[0]} <= {"transient", "settled"}
+            if r.get("window") and (list(r["window"]) == list(window) or (same_scene and list(r["window"][1:]) == list(window[1:]))):
                 return r.get("hbm_bytes_per_launch"), f"{os.path.relpath(p, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same window)"
     if not found:
         return None, "no PMC pass committed for this kernel"

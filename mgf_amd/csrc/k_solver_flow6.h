@@ -42,8 +42,8 @@ constexpr uint32_t kF6MaxIters = 64;                   // (ring positions are re
 constexpr uint32_t kF6WlLen = 128;                     // work items (channel, position) a polling wave lists per sweep
 constexpr uint32_t kF6MaxPollers = 4;
 constexpr uint32_t kF6CntStride = 32;                  // words between per-block counters (same-line atomics serialise)
-constexpr uint32_t kF6TraceWords = 24;                 // TRACE: 64-bit words of statistics per block behind the node stamps (polling: 0-6; clocks: 8 entry,
-                                                       // 9 bodies in LDS, 10 tables in LDS, 11 serving loop left, 12 written back)
+constexpr uint32_t kF6TraceWords = 32;                 // TRACE: 64-bit words of statistics per block behind the node stamps (polling: 0-6; clocks: 8 entry,
+                                                       // 9 bodies in LDS, 10 tables in LDS, 11 serving loop left, 12 written back; 24-29 messages by latency, 30 seen by quiet sweeps)
 
 // One 32-byte row per slot, written once per tick - the constraint's own part and the links inside a body's own range by
 // k_flow6_blocks, the links that need the body's whole chain by k_flow6_links - and copied into LDS by the solve kernel.
@@ -93,6 +93,7 @@ struct Flow6 {
   uint32_t poll_waves, poll_k;  // waves that poll the incoming channels; 1: every sweep through the worklist, >= 2: quiet sweeps read straight
   uint32_t quad_max;            // QD: a wave takes a four-lanes-per-node trip while the ready queue holds at most this many nodes
   uint32_t poll_prio;           // s_setprio of the polling waves (0..3): their few instructions issue ahead of the serving waves'
+  uint32_t poll_spec;           // positions behind a channel's head a quiet sweep reads on spec (1..8; the wave's idle lanes take them)
 };
 constexpr uint32_t kF6RecWords = 5;  // RL: float4 words of a constraint's solver half in LDS (80 bytes: CRec words 2..20 and the accumulated impulse)
 // successor words 8, id 4, state 4, ring 2 (+ impulse 4; or + the record's solver half 80, which holds the impulse)
@@ -681,7 +682,14 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
     uint16_t* wl = s_wl + pw * kF6WlLen;
     if (F.poll_prio == 1u) __builtin_amdgcn_s_setprio(1); else if (F.poll_prio == 2u) __builtin_amdgcn_s_setprio(2); else if (F.poll_prio >= 3u) __builtin_amdgcn_s_setprio(3);
     uint32_t head = 0, mask = 0, known = 0;
+    // the quiet sweep's lanes: position my_j behind the head of owner my_o's channel
+    const uint32_t kq = max(1u, min(min(F.poll_spec, 8u), 64u / max(n_loc, 1u)));
+    const uint32_t my_o = lane % max(n_loc, 1u), my_j = lane / max(n_loc, 1u);
+    const bool my_act = my_j < kq;
+    const uint32_t lim_o = (uint32_t)__shfl((int)lim, (int)my_o), base_o = (uint32_t)__shfl((int)in_base, (int)my_o);
     uint32_t st_sweeps = 0, st_hits = 0, st_lat_sum = 0, st_lat_max = 0, st_full = 0, st_wait = 0;  // TRACE: polling statistics
+    uint32_t st_h0 = 0, st_h1 = 0, st_h2 = 0, st_h3 = 0, st_h4 = 0, st_h5 = 0, st_quiet = 0;  // messages by latency (< 1, 2, 3, 4, 6 us, more); seen by a quiet sweep
+#define F6_LAT_HIST(lat) { if ((lat) < 100u) ++st_h0; else if ((lat) < 200u) ++st_h1; else if ((lat) < 300u) ++st_h2; else if ((lat) < 400u) ++st_h3; else if ((lat) < 600u) ++st_h4; else ++st_h5; }
     if (lane == 0) __hip_atomic_store(wl_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     for (;;) {
       if (__hip_atomic_load(s_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) break;
@@ -695,11 +703,15 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
         if (head < lim) todo |= 1u & ~mask;  // the head, on spec
       }
       unsigned long long hits = 0;
-      if (F.poll_k >= 2u && __ballot((todo & ~1u) != 0u) == 0ull) {
-        // the quiet sweep (no channel is known to hold more than its head position - the state a lone message on a critical path
-        // finds): every owner reads its own channel's head straight from its registers, no worklist, no shared words
-        const bool have = (todo & 1u) != 0u;
-        const uint32_t byte = have ? (in_base + head) * (16u * kF6MsgWords) : 0x80000000u;
+      if (F.poll_k >= 2u && __ballot((todo >> kq) != 0u) == 0ull) {
+        // the quiet sweep (no channel is known to hold more than the `kq` positions behind its head - the state a message on a critical
+        // path finds): lane l reads position head + l / n_loc of channel l % n_loc straight, no worklist, no shared words.  Positions
+        // behind the head are read ON SPEC (nothing says they were sent): a message that is not the first of its channel is seen by
+        // the sweep it arrives in instead of the one after the producers' hint was read - the load instructions are the same three.
+        const uint32_t h_o = (uint32_t)__shfl((int)head, (int)my_o), m_o = (uint32_t)__shfl((int)mask, (int)my_o);
+        const uint32_t pos = h_o + my_j;
+        const bool have = my_act && pos < lim_o && ((m_o >> my_j) & 1u) == 0u;
+        const uint32_t byte = have ? (base_o + pos) * (16u * kF6MsgWords) : 0x80000000u;
         const v4f_t g0 = __builtin_amdgcn_raw_buffer_load_b128(rmb, (int)byte, 0, kSc1);
         const v4f_t g1 = __builtin_amdgcn_raw_buffer_load_b128(rmb, (int)(byte + 16u), 0, kSc1);
         const v4f_t g2 = __builtin_amdgcn_raw_buffer_load_b128(rmb, (int)(byte + 32u), 0, kSc1);
@@ -716,12 +728,14 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
           *reinterpret_cast<float2*>(&s_body[2 * bi + 1]) = make_float2(g1.y, g1.z);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the velocity is in LDS before the arrival counts
           f6_arrive(q, s_state, slot);
-          if (TRACE) { const uint32_t lat = (uint32_t)wall_clock64() - f2u(g2.y); ++st_hits; st_lat_sum += lat; st_lat_max = max(st_lat_max, lat); }
-          mask |= 1u;
+          if (TRACE) { const uint32_t lat = (uint32_t)wall_clock64() - f2u(g2.y); ++st_hits; st_lat_sum += lat; st_lat_max = max(st_lat_max, lat); F6_LAT_HIST(lat); ++st_quiet; }
+        }
+        hits = __ballot(hit);
+        if (owner && hits) {  // lane j * n_loc + o read position head + j of owner o's channel
+          for (uint32_t j = 0; j < kq; ++j) mask |= (uint32_t)((hits >> (j * n_loc + lane)) & 1ull) << j;
           const uint32_t k = mask == 0xFFFFFFFFu ? 32u : (uint32_t)__builtin_ctz(~mask);
           head += k; mask = k >= 32u ? 0u : mask >> k;
         }
-        hits = __ballot(hit);
       } else {
       // the owners list their positions
       if (owner) {
@@ -764,7 +778,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the velocity is in LDS before the arrival counts
           f6_arrive(q, s_state, slot);
           __hip_atomic_fetch_or(&s_in_mask[chn], 1u << bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (TRACE) { const uint32_t lat = (uint32_t)wall_clock64() - f2u(g2.y); ++st_hits; st_lat_sum += lat; st_lat_max = max(st_lat_max, lat); }
+          if (TRACE) { const uint32_t lat = (uint32_t)wall_clock64() - f2u(g2.y); ++st_hits; st_lat_sum += lat; st_lat_max = max(st_lat_max, lat); F6_LAT_HIST(lat); }
         }
         hits |= __ballot(hit);
       }
@@ -792,6 +806,10 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
       atomicMax(reinterpret_cast<unsigned long long*>(&st[3]), (unsigned long long)st_lat_max);
       if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&st[4]), (unsigned long long)st_full);
       if (lane == 0 && pw == 0) { st[5] = n_in; st[6] = st_wait; }
+      atomicAdd(reinterpret_cast<unsigned long long*>(&st[24]), (unsigned long long)st_h0); atomicAdd(reinterpret_cast<unsigned long long*>(&st[25]), (unsigned long long)st_h1);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&st[26]), (unsigned long long)st_h2); atomicAdd(reinterpret_cast<unsigned long long*>(&st[27]), (unsigned long long)st_h3);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&st[28]), (unsigned long long)st_h4); atomicAdd(reinterpret_cast<unsigned long long*>(&st[29]), (unsigned long long)st_h5);
+      atomicAdd(reinterpret_cast<unsigned long long*>(&st[30]), (unsigned long long)st_quiet);
     }
   } else {
     // ---- the serving waves ---------------------------------------------------------------------------------------------------

@@ -27,6 +27,8 @@ VARIANTS = {
     "no constants in LDS": {"flow6_const_lds": 0},
     "records without constants": {"flow6_rec_lds": 2, "flow6_const_lds": 0},
     "no impulses in LDS": {"flow6_nimp_lds": 0, "flow6_rec_lds": 0},
+    "quiet sweeps read 4 positions per channel on spec": {"flow6_spec": 4},
+    "quiet sweeps read 8 positions on spec, one lane per node": {"flow6_spec": 8, "flow6_quad": 0},
     "quad, nothing optional in LDS": {"flow6_quad_max": 1000000, "flow6_nimp_lds": 0, "flow6_rec_lds": 0, "flow6_const_lds": 0},
 }
 SCENES = {

@@ -16,12 +16,14 @@ run() {  # name, timed ticks, dominant kernel, window label for bench.py, its wa
   grep -a '"metric"' $O/${TAG}_${N}_trace.log | tail -1 > $O/${TAG}_${N}_bench_under_trace.json
   rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_${N}_fetch -o bench -- $B "$@" > $O/${TAG}_${N}_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_${N}_write -o bench -- $B "$@" > $O/${TAG}_${N}_write.log 2>&1
-  $B "$@" > $O/${TAG}_${N}_bench.json 2> /dev/null
   ( cd $R
     python tools/rocprof_summary.py gpurun_out/${TAG}_${N}_trace/bench_results.db $K --timed $KER $K > gpurun_out/${TAG}_${N}_kernel_stats.txt
     python tools/pmc_summary.py gpurun_out/${TAG}_${N}_fetch/bench_results.db gpurun_out/${TAG}_${N}_write/bench_results.db --timed $KER $K gpurun_out/${TAG}_${N}_pmc.json $WIN $W $K > gpurun_out/${TAG}_${N}_pmc_hbm_traffic.txt
-    rm -rf gpurun_out/${TAG}_${N}_trace gpurun_out/${TAG}_${N}_fetch gpurun_out/${TAG}_${N}_write )
+    rm -rf gpurun_out/${TAG}_${N}_trace gpurun_out/${TAG}_${N}_fetch gpurun_out/${TAG}_${N}_write
+    python tools/publish_profiles.py $TAG > /dev/null )  # (the box's copy of profiles/: the run below reports this pass's traffic)
+  $B "$@" > $O/${TAG}_${N}_bench.json 2> /dev/null
 }
+if [ -z "${ONLY_TILES:-}" ]; then
 run transient  60 k_solve_flow6 transient 10 --warmup 10 --steps 60
 run driver     20 k_solve_flow6 transient 5  --warmup 5 --steps 20
 run settled    60 k_solve_flow6 settled 400 --warmup 400 --steps 60
@@ -30,11 +32,32 @@ run config3    60 k_solve_flow6 config3 150 --scene config3
 run config3_20 20 k_solve_flow6 config3 150 --scene config3 --steps 20
 run config5    60 k_solve_flow6 config5 80  --scene config5
 run config5_20 20 k_solve_flow6 config5 80  --scene config5 --steps 20
+fi
+# the tile launches (2 iterations of one 131 072-body tile between ghost refreshes; 8 tiles on this GPU): the instrumented ticks'
+# 60 x 8 x 5 launches are the last 2400 of the run
+run_tiles() {  # name, scene, warm-up
+  local N=$1 SC=$2 W=$3
+  local BT="python $R/bench.py --gpus 1 --scene $SC --no-cpu-baseline"
+  rocprofv3 --kernel-trace -d $O/${TAG}_${N}_trace -o bench -- $BT > $O/${TAG}_${N}_trace.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_${N}_fetch -o bench -- $BT > $O/${TAG}_${N}_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_${N}_write -o bench -- $BT > $O/${TAG}_${N}_write.log 2>&1
+  ( cd $R
+    python tools/rocprof_summary.py gpurun_out/${TAG}_${N}_trace/bench_results.db 480 --timed k_solve_flow6 2400 > gpurun_out/${TAG}_${N}_kernel_stats.txt
+    python tools/pmc_summary.py gpurun_out/${TAG}_${N}_fetch/bench_results.db gpurun_out/${TAG}_${N}_write/bench_results.db --timed k_solve_flow6 2400 gpurun_out/${TAG}_${N}_pmc.json tiles $W 60 > gpurun_out/${TAG}_${N}_pmc_hbm_traffic.txt
+    rm -rf gpurun_out/${TAG}_${N}_trace gpurun_out/${TAG}_${N}_fetch gpurun_out/${TAG}_${N}_write
+    python tools/publish_profiles.py $TAG > /dev/null )
+}
+if [ -z "${NO_TILES:-}" ]; then
+run_tiles config4_tiles config4 10
+run_tiles config5_tiles config5_tiles 80
+fi
 cd $R
+if [ -z "${ONLY_TILES:-}" ]; then
 python bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_driver_command.json 2> /dev/null
-python bench.py --gpus 1 --scene config4 --no-cpu-baseline > $O/${TAG}_config4_8tiles_1gpu_bench.json 2> /dev/null
-python bench.py --gpus 1 --scene config5_tiles --no-cpu-baseline > $O/${TAG}_config5_8tiles_1gpu_bench.json 2> /dev/null
 python bench.py --scene config5 --no-cpu-baseline > $O/${TAG}_config5_undivided_1gpu.json 2> /dev/null
 python tools/config4_undivided.py > /dev/null 2>&1; cp $O/config4_undivided_1gpu.json $O/${TAG}_config4_undivided_1gpu.json
+fi
+python bench.py --gpus 1 --scene config4 --no-cpu-baseline > $O/${TAG}_config4_8tiles_1gpu_bench.json 2> /dev/null
+python bench.py --gpus 1 --scene config5_tiles --no-cpu-baseline > $O/${TAG}_config5_8tiles_1gpu_bench.json 2> /dev/null
 ls $O | grep ${TAG}_

@@ -8,7 +8,7 @@ import numpy as np
 
 TRACE = "/tmp/mgf_flow_trace.bin"
 POLL = "/tmp/mgf_flow6_poll.bin"
-WORDS = 24  # kF6TraceWords
+WORDS = 32  # kF6TraceWords
 
 
 def load(cons):
@@ -155,5 +155,7 @@ def analyse(T):
         out["polling"] = {"sweep_period_us": round(float(out["span_us"] / max(sweeps.mean(), 1)), 2),
                           "messages_per_block": round(float(poll[:nblk, 1].mean()), 1),
                           "message_latency_us": round(float(poll[:nblk, 2].sum() / max(poll[:nblk, 1].sum(), 1) * 0.01), 2),
-                          "incoming_channels_mean": round(float(poll[:nblk, 5].mean()), 1)}
+                          "incoming_channels_mean": round(float(poll[:nblk, 5].mean()), 1),
+                          "latency_hist_lt_1_2_3_4_6_more_us": [round(float(poll[:nblk, 24 + k].sum() / max(poll[:nblk, 1].sum(), 1)), 3) for k in range(6)],
+                          "seen_by_quiet_sweeps_frac": round(float(poll[:nblk, 30].sum() / max(poll[:nblk, 1].sum(), 1)), 3)}
     return out
