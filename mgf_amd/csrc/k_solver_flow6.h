@@ -93,6 +93,7 @@ struct Flow6 {
   uint32_t poll_waves, poll_k;  // waves that poll the incoming channels; 1: every sweep through the worklist, >= 2: quiet sweeps read straight
   uint32_t quad_max;            // QD: a wave takes a four-lanes-per-node trip while the ready queue holds at most this many nodes
   uint32_t poll_prio;           // s_setprio of the polling waves (0..3): their few instructions issue ahead of the serving waves'
+  uint32_t poll_spec_wl;        // worklist sweeps: positions behind the producers' hint read on spec (0: the head only)
   uint32_t poll_spec;           // positions behind a channel's head a quiet sweep reads on spec (1..8; the wave's idle lanes take them)
 };
 constexpr uint32_t kF6RecWords = 5;  // RL: float4 words of a constraint's solver half in LDS (80 bytes: CRec words 2..20 and the accumulated impulse)
@@ -700,7 +701,11 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
       if (owner) {
         const uint32_t pend = known > head ? min(known - head, 32u) : 0u;
         todo = ~mask & (pend >= 32u ? 0xFFFFFFFFu : (1u << pend) - 1u);
-        if (head < lim) todo |= 1u & ~mask;  // the head, on spec
+        if (F.poll_spec_wl == 0u) { if (head < lim) todo |= 1u & ~mask; }  // the head, on spec
+        else if (head + pend < lim && pend < 32u) {  // the positions behind what the producers' hint covers - where the next messages land
+          const uint32_t ns = min(F.poll_spec_wl, min(32u - pend, lim - head - pend));
+          todo |= (((1u << ns) - 1u) << pend) & ~mask;
+        }
       }
       unsigned long long hits = 0;
       if (F.poll_k >= 2u && __ballot((todo >> kq) != 0u) == 0ull) {

@@ -29,6 +29,8 @@ VARIANTS = {
     "no impulses in LDS": {"flow6_nimp_lds": 0, "flow6_rec_lds": 0},
     "quiet sweeps read 4 positions per channel on spec": {"flow6_spec": 4},
     "quiet sweeps read 8 positions on spec, one lane per node": {"flow6_spec": 8, "flow6_quad": 0},
+    "one polling wave, the head only on spec": {"flow6_poll_waves": 1, "flow6_spec_wl": 0, "flow6_spec": 1},
+    "three polling waves, 8 positions behind the hint": {"flow6_poll_waves": 3, "flow6_spec_wl": 8},
     "quad, nothing optional in LDS": {"flow6_quad_max": 1000000, "flow6_nimp_lds": 0, "flow6_rec_lds": 0, "flow6_const_lds": 0},
 }
 SCENES = {
