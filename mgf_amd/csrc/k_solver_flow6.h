@@ -570,7 +570,8 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
   if (*F.fail || *F.C_ptr == 0u) return;  // a limit was exceeded: the stand-by k_solve_flow launch behind this one does the work
   extern __shared__ float4 s_dyn[];
   uint64_t* tstat = TRACE ? trace + 2 * (size_t)iters * C_trace + kF6TraceWords * (size_t)blockIdx.x : nullptr;
-  if (TRACE && threadIdx.x == 0) tstat[8] = wall_clock64();
+  uint64_t trace_c0 = 0;
+  if (TRACE && threadIdx.x == 0) { tstat[8] = wall_clock64(); trace_c0 = clock64(); }
   const uint32_t nbod = F.nb + F.fcap, cap = F.slot_cap;
   constexpr bool NLS = NL && !RL;                                      // the impulses in an array of their own
   float4* s_body = s_dyn;                                              // [2 * nbod]: {v, w.x}, {w.y, w.z, body id, -}
@@ -1182,7 +1183,7 @@ __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* 
 #undef PF_STAMP
 #undef PF_STAMP_V
   __syncthreads();
-  if (TRACE && threadIdx.x == 0) tstat[11] = wall_clock64();
+  if (TRACE && threadIdx.x == 0) { tstat[11] = wall_clock64(); tstat[23] = clock64() - trace_c0; }  // (23: shader clocks between stamps 8 and 11)
   // the accumulated normal impulses go back to the records (ContactState lives on: mgf_world_read_constraints, a later solve)
   if (NLS) for (uint32_t idx = t; idx < N; idx += kF6Threads) cons[s_c[idx]].nimp = s_nimp[idx];
   if (RL) for (uint32_t idx = t; idx < N; idx += kF6Threads) cons[s_c[idx]].nimp = s_rec[kF6RecWords * (size_t)idx + 4].w;

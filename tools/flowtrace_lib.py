@@ -148,11 +148,15 @@ def analyse(T):
                                       "solve_and_store": round(float(poll[:nblk, 15].sum()) / trips, 1), "release": round(float(poll[:nblk, 16].sum()) / trips, 1),
                                       "idle_polls_per_block": round(float(poll[:nblk, 20].sum()) / nblk, 1),
                                       "idle_poll_clocks": round(float(poll[:nblk, 19].sum()) / max(float(poll[:nblk, 20].sum()), 1.0), 1)}
+    if (poll[:nblk, 23] > 0).any():
+        dt = (poll[:nblk, 11] - poll[:nblk, 8]).astype(np.float64)
+        out["shader_clock_mhz"] = round(float(np.mean(poll[:nblk, 23] / np.maximum(dt, 1.0)) * 100.0), 1)
     Nb = np.bincount(blk, minlength=nblk)
     out["constraints_per_block"] = {"mean": round(float(Nb.mean()), 1), "max": int(Nb.max())}
     sweeps = poll[:nblk, 0].astype(np.float64)
     if sweeps.sum() > 0:
-        out["polling"] = {"sweep_period_us": round(float(out["span_us"] / max(sweeps.mean(), 1)), 2),
+        serving = (poll[:nblk, 11] - poll[:nblk, 10]).astype(np.float64) * 0.01  # (a block's polling wave sweeps while the block serves)
+        out["polling"] = {"sweep_period_us": round(float(np.mean(serving / np.maximum(sweeps, 1.0))), 2),
                           "messages_per_block": round(float(poll[:nblk, 1].mean()), 1),
                           "message_latency_us": round(float(poll[:nblk, 2].sum() / max(poll[:nblk, 1].sum(), 1) * 0.01), 2),
                           "incoming_channels_mean": round(float(poll[:nblk, 5].mean()), 1),
