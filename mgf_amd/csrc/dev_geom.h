@@ -309,6 +309,8 @@ __device__ inline int tri_mcapsule(const Triangle& tri, const Capsule& c, V3 v, 
         if (tri_contains(tri, q)) {
           V3 base = (dot(p.n, c.a) - p.d < 0.0f) ? c.a : (c.a + c.d);
           out0 = mkc(q, base + -p.n * c.r, p.n, 0.0f);
+          out1 = out0;  // (every exit writes BOTH results - the second is not looked at when one contact is returned: with exits that wrote
+                        // one or the other the compiler merged their stores through a selected pointer and kept the pair in scratch memory)
           return 1;
         }
       }
@@ -344,10 +346,7 @@ __device__ inline int tri_mcapsule(const Triangle& tri, const Capsule& c, V3 v, 
     V2 sb = xy(rotate(rot, fc.a + sil_v - p.n * p.d));
     bool inside = checked || tri_contains(tri, fc.a);
     bool parallel = fabs_rs(dot(dir, p.n)) < kCollisionEps;
-    if (inside) {
-      out0 = fc;
-      if (!parallel) return 1;
-    }
+    if (inside && !parallel) { out0 = fc; out1 = fc; return 1; }
     if (inside || (fc.t > 0.0f && parallel)) {
       float t_min = kInf, t_max = 0.0f;
       bool hit = false;
@@ -365,6 +364,7 @@ __device__ inline int tri_mcapsule(const Triangle& tri, const Capsule& c, V3 v, 
       float t_max2 = (t_max == 0.0f) ? 1.0f : t_max;
       if (inside) {  // :808-839 second contact for a face-parallel capsule
         V3 q = fc.a + sil_v * t_max2;
+        out0 = fc;
         out1 = mkc(q, q, p.n, fc.t);
         return 2;
       }
@@ -441,12 +441,13 @@ __device__ inline int tri_mcapsule(const Triangle& tri, const Capsule& c, V3 v, 
     }
   }
   // :1061-1085
-  if (best_sum_t < best_par_t) { out0 = mkc(best_sum_p, best_sum_p, p.n, best_sum_t); return 1; }
+  if (best_sum_t < best_par_t) { out0 = mkc(best_sum_p, best_sum_p, p.n, best_sum_t); out1 = out0; return 1; }
   if (best_par_t != kInf) {
     out0 = mkc(best_par_a, best_par_a, p.n, best_par_t);
     out1 = mkc(best_par_b, best_par_b, p.n, best_par_t);
     return 2;
   }
+  out0 = out1 = mkc(mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), 0.0f);
   return 0;
 }
 

@@ -151,13 +151,28 @@ __global__ __launch_bounds__(kBlock) void k_narrow_pairs_parts(Bodies B, const u
   __shared__ uint32_t s_items;
   if (threadIdx.x == 0) s_items = 0;
   __syncthreads();
+  // (the two parts as VALUES: with `load_part(.., &Pa, ..)` and `load_part(.., &Pb, ..)` the compiler ran both through one piece of code that
+  // stored through a selected pointer - the parts' 16 bytes of (d, r) in scratch memory)
+  auto part_of = [&](uint32_t i, uint32_t k, bool& ok) -> Comp {
+    Comp c; c.kind = KIND_SPHERE; c.p = mk3(0, 0, 0); c.r = 0.0f; c.d = mk3(0, 0, 0);
+    const uint32_t pc = B.pcount ? B.pcount[i] : 0u;
+    ok = pc == 0u ? k == 0u : k < pc;
+    if (ok) {
+      float4 a, b;
+      if (pc == 0u) { a = B.col0[i]; b = B.col1[i]; }
+      else { a = B.wp0[kMaxParts * i + k]; b = B.wp1[kMaxParts * i + k]; }
+      c.kind = (int)f2u(b.w); c.p = xyz(a); c.r = a.w; c.d = xyz(b);
+    }
+    return c;
+  };
   auto item_parts = [&](uint32_t w, uint32_t& p, Comp& Pa, Comp& Pb, V3& vA, V3& vB) -> bool {
     const uint32_t ab = w / live_n;
     p = s_list[w - ab * live_n];
     const uint32_t a = ab / (uint32_t)MP, b = ab - a * (uint32_t)MP;
     const uint32_t i = p_owner[p], j = p_cand[p];
-    V3 ci, cj;
-    if (!load_part(B, i, a, &Pa, &ci) || !load_part(B, j, b, &Pb, &cj)) return false;
+    bool oka, okb;
+    Pa = part_of(i, a, oka); Pb = part_of(j, b, okb);
+    if (!oka || !okb) return false;
     vA = xyz(B.delta[i]); vB = xyz(B.delta[j]);
     return true;
   };

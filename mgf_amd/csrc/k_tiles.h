@@ -223,7 +223,15 @@ __global__ __launch_bounds__(kBlock) void k_compact_gather(Bodies B, uint32_t n,
   uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= n * kBodyWords) return;
   uint32_t i = t / kBodyWords, e = t % kBodyWords;
-  if (keep[i]) tmp[(size_t)pos[i] * kBodyWords + e] = migrant_get(B, e, i, kMaxParts);
+  if (keep[i] && pos[i] != i) tmp[(size_t)pos[i] * kBodyWords + e] = migrant_get(B, e, i, kMaxParts);  // (a body in front of the first removed one stays where it is)
+}
+// ... rows [0, n_new) = tmp, except the rows that did not move: row k kept its place iff every body up to it was kept (pos[k] == k, keep[k])
+__global__ __launch_bounds__(kBlock) void k_compact_put(Bodies B, uint32_t n_new, const uint32_t* keep, const uint32_t* pos, const float4* tmp) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n_new * kBodyWords) return;
+  uint32_t k = t / kBodyWords, e = t % kBodyWords;
+  if (keep[k] && pos[k] == k) return;
+  migrant_put(B, e, k, tmp[t], kMaxParts);
 }
 // ---- the body store in an internal order (host_perm.inc) ----------------------------------------------------------
 // Slot k of the new order takes the row of old slot order[k] - the body's row of every Bodies array, verbatim, like a
