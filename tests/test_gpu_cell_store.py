@@ -120,11 +120,15 @@ def test_boundary_maps_indices(ctx):
         ref.step(dt, iters)
         w.step(dt, iters)
     _same_state(ref.state(), w.state(), "after set")
-    # an entry point that names bodies by index puts the caller's order back (and the next fused tick re-sorts again)
+    # write_state names bodies by the caller's indices and leaves the store in its internal order: rows go through slot_of
     s = w.state()
-    w.write_state(v=s["v"])
-    ref.write_state(v=ref.state()["v"])
-    assert w.counter("store_permuted") == 0
+    v2 = s["v"].copy(); v2[::7] += np.float32(0.25)
+    x2 = s["x"].copy(); x2[::11, 1] += np.float32(0.01)
+    om2 = s["omega"].copy(); om2[::5, 2] -= np.float32(0.125)
+    w.write_state(x=x2, v=v2, omega=om2)
+    ref.write_state(x=x2, v=v2, omega=om2)
+    assert w.counter("store_permuted") == 1
+    _same_state(ref.state(), w.state(), "right after write_state")
     for _ in range(3):
         ref.step(dt, iters)
         w.step(dt, iters)
