@@ -4,6 +4,7 @@
 # each with 60 and with 20 timed ticks (the driver's nested windows) - a kernel trace and the two PMC passes (FETCH_SIZE, WRITE_SIZE:
 # separate runs, counters only - MI355X_MICROARCH.md), all on the exact bench command.
 #   Usage: bash tools/collect_profiles.sh <tag>   -> gpurun_out/<tag>_*      then: python tools/publish_profiles.py <tag>
+#   (WINDOWS="driver transient" NO_TILES=1 ONLY_BENCH_LINES= ... : a subset of the windows; the final bench lines are always taken)
 set -u
 TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
@@ -12,6 +13,7 @@ B="python $R/bench.py --no-cpu-baseline --no-settled --no-order-check --no-other
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, timed ticks, dominant kernel, window label for bench.py, its warm-up, bench args...
   local N=$1 K=$2 KER=$3 WIN=$4 W=$5; shift 5
+  if [ -n "${WINDOWS:-}" ] && ! echo " $WINDOWS " | grep -q " $N "; then return; fi  # (WINDOWS="driver transient": only those)
   rocprofv3 --kernel-trace -d $O/${TAG}_${N}_trace -o bench -- $B "$@" > $O/${TAG}_${N}_trace.log 2>&1
   grep -a '"metric"' $O/${TAG}_${N}_trace.log | tail -1 > $O/${TAG}_${N}_bench_under_trace.json
   rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_${N}_fetch -o bench -- $B "$@" > $O/${TAG}_${N}_fetch.log 2>&1
