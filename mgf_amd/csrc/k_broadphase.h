@@ -120,22 +120,11 @@ __global__ __launch_bounds__(kBlock) void k_publish(const uint32_t* rb, uint32_t
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(pin + seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// `pub` (r04: mgf_world_step_many, the tick BEFORE this one left its read-back to this launch - one launch less per tick): block 0
-// first writes that tick's block of counts to its pinned slot, exactly as k_publish would have, and only then resets anything; the
-// words of the read-back block that this launch clears (z.in_rb: bit a = entry a lies inside it) are cleared by block 0 alone, after
-// the copy.
-struct DeferredPublish { const uint32_t* rb; uint32_t* pin; uint32_t words, seq_word, seq; };
 __global__ __launch_bounds__(kBlock) void k_tick_clear(ZeroList z, SceneBounds* sb, uint32_t* err, uint32_t* guard, const uint32_t* prev_fail, int spec,
-                                                       int* sb_part, DeferredPublish pub, uint32_t in_rb) {
+                                                       int* sb_part) {
   // (see k_reset_step: a speculative tick behind a failed one raises the guard and resets nothing - but the counters are cleared all
   // the same: the kernels of the cell sort run unguarded, on the unchanged bodies, and must start from zero)
   const bool skip = spec && *prev_fail;
-  if (pub.pin && blockIdx.x == 0) {
-    for (uint32_t i = threadIdx.x; i < pub.words; i += kBlock) pub.pin[i] = pub.rb[i];
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(pub.pin + pub.seq_word, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
   if (skip && blockIdx.x == 0 && threadIdx.x == 0) *guard = 1u;
   if (blockIdx.x == 0 && !skip) {
     if (sb_part && threadIdx.x < kBoundSlots) {
@@ -153,10 +142,6 @@ __global__ __launch_bounds__(kBlock) void k_tick_clear(ZeroList z, SceneBounds* 
   for (int a = 0; a < kZeroSlots; ++a) {
     uint32_t* p = z.p[a];
     if (!p) continue;
-    if (pub.pin && ((in_rb >> a) & 1u)) {  // a piece of the read-back block: block 0, behind its copy
-      if (blockIdx.x == 0) for (uint32_t e = threadIdx.x; e < z.words[a]; e += kBlock) p[e] = 0u;
-      continue;
-    }
     for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < z.words[a]; e += gridDim.x * kBlock) p[e] = 0u;
   }
 }

@@ -93,24 +93,6 @@ def test_step_many_with_a_stale_order(ctx):
     assert 3 <= w.counter("store_resorts") <= 5
 
 
-@pytest.mark.parametrize("name", ["spheres", "two_part_bodies"])
-def test_step_many_with_the_read_back_left_to_the_next_tick(ctx, name):
-    """mgf_world_step_many: a tick that is followed by another leaves its read-back block to the next tick's clearing launch
-    (option defer_publish, default on).  Same states, same per-tick statistics as with a k_publish launch per tick - also across a
-    capacity re-run (the first ticks of a fresh world grow their buffers) and for windows of one and two ticks."""
-    scene = _scenes()[name]
-    dt, iters = float(scene["dt"]), scene["iters"]
-    a = _world(ctx, scene, 4, defer_publish=1)
-    b = _world(ctx, scene, 4, defer_publish=0)
-    for n in (1, 2, 7, 30):
-        sa, sb = a.step_many(dt, iters, n), b.step_many(dt, iters, n)
-        assert [(int(x["n_constraints"]), int(x["n_terrain_constraints"]), int(x["n_pair_candidates"]), int(x["n_refits"])) for x in sa] == \
-               [(int(x["n_constraints"]), int(x["n_terrain_constraints"]), int(x["n_pair_candidates"]), int(x["n_refits"])) for x in sb], n
-        _same_state(a.state(), b.state(), f"step_many({n})")
-    a.step(dt, iters); b.step(dt, iters)  # (a single step behind a window: nothing is left pending)
-    _same_state(a.state(), b.state(), "step after step_many")
-
-
 def test_boundary_maps_indices(ctx):
     from mgf_amd import scenes
     scene = scenes.capsule_field_dense(8, 3, 8, quads=10, y0=0.9, sphere_fraction=0.3)
