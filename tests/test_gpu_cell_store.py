@@ -129,6 +129,9 @@ def test_boundary_maps_indices(ctx):
     ref.write_state(x=x2, v=v2, omega=om2)
     assert w.counter("store_permuted") == 1
     _same_state(ref.state(), w.state(), "right after write_state")
+    tags2 = (np.arange(n, dtype=np.uint32)[::-1] * 5 + 1).astype(np.uint32)   # ... and so does set_tags
+    w.set_tags(tags2)
+    assert w.counter("store_permuted") == 1 and np.array_equal(w.tags(), tags2)
     for _ in range(3):
         ref.step(dt, iters)
         w.step(dt, iters)
