@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--no-migrate", action="store_true", help="tiles: keep every body on its initial tile (development)")
     ap.add_argument("--transport", default="native", choices=["native", "torch"],
                     help="native = mgf_tiles_* (RCCL under the C-ABI); torch = the Python driver over torch.distributed (--scene weak only)")
+    ap.add_argument("--rccl-lib", default=None, metavar="PATH",
+                    help="development: bind this library instead of librccl under the C-ABI (tests/fake_rccl: several ranks on ONE GPU); the line "
+                         "says so - such a run validates the multi-rank flow, it measures no fabric")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the rendezvous / barrier (and of --transport torch): nccl = RCCL; gloo = host-staged, "
                          "for validating the multi-rank flow on one GPU")
@@ -71,10 +74,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` exactly as the N = 1 command is issued: this process becomes the launcher of its own N ranks
+        # (one per GPU, the contract's torch.distributed.run form); rank 0's JSON line is the only thing on stdout
+        raise SystemExit(_spawn_ranks(args))
     if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
     scene_kind = args.scene
     if scene_kind == "auto":
@@ -103,8 +107,11 @@ def main():
     from mgf_amd import scenes
     from mgf_amd.tiles import DEFAULT_REFRESH_EVERY
     refresh_every = args.refresh_every or DEFAULT_REFRESH_EVERY
-    if os.environ.get("MGF_RCCL_LIB") and os.environ.get("MGF_BENCH_ALLOW_RCCL_OVERRIDE") == "1":
+    args.standin = _standin_lib(args)
+    if args.standin:
         # development: the multi-rank flow validated on ONE GPU over the test-suite's stand-in transport (tests/fake_rccl) - never a measurement of xGMI
+        os.environ["MGF_RCCL_LIB"] = args.standin
+        os.environ.setdefault("MGF_FAKE_RCCL_TIMEOUT_S", "120")
         mgf_amd.rccl_allow_override(True)
     ctx = mgf_amd.Context(dev_index)
 
@@ -184,6 +191,38 @@ def _roofline(units, launches, kms, mode, what, window, workload="config2"):
     return {"bound": "hbm", "kernel": KERNEL_NAMES[mode] + ": " + what + ")", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": source, "bytes_per_unit": SOLVE_BYTES_PER_UNIT,
             "avg_launch_us": round(kms * 1e3 / launches, 3), "avg_units_per_launch": round(units / launches, 1), "launches_timed": int(launches)}
+
+
+def _standin_lib(args):
+    """The library named to stand in for librccl (several ranks on ONE GPU over tests/fake_rccl: the multi-rank flow, never a
+    measurement of xGMI), or None: --rccl-lib, or MGF_RCCL_LIB together with MGF_BENCH_ALLOW_RCCL_OVERRIDE=1."""
+    if args.rccl_lib:
+        return os.path.abspath(args.rccl_lib)
+    if os.environ.get("MGF_RCCL_LIB") and os.environ.get("MGF_BENCH_ALLOW_RCCL_OVERRIDE") == "1":
+        return os.environ["MGF_RCCL_LIB"]
+    return None
+
+
+def _spawn_ranks(args):
+    """Re-run this command line as N ranks under torch.distributed.run on 127.0.0.1 (a free port) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    extra = []
+    if _standin_lib(args):
+        import torch
+        if torch.cuda.device_count() < args.gpus:
+            # the stand-in transport's reason to exist: every rank on device 0, the rendezvous host-staged (RCCL refuses two ranks on a device)
+            env.setdefault("MGF_BENCH_DEVICE", "0")
+            if "--backend" not in sys.argv:
+                extra = ["--backend", "gloo"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
+    return subprocess.call(cmd, env=env)
 
 
 def bench_single_world(args, ctx, mgf_amd, scenes, configure, mode):
@@ -441,6 +480,8 @@ def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, w
     warmup = OTHER_CONFIGS["config5"][2] if scene_kind == "config5_tiles" and args.warmup == 10 else args.warmup
     for _ in range(warmup):
         step()
+    # the state the timed window starts from (mgf_world_clone of every tile): the instrumented replay below steps THE SAME ticks again
+    snaps = [w.clone() for w in worlds] if transport == "native" else None
     XKEYS = ("exchange_bytes_out", "exchange_bytes_in", "exchange_bytes_local", "exchange_calls", "host_waits")
     x0 = {k: tiles.counter(k) for k in XKEYS} if transport == "native" else None
     barrier()
@@ -464,7 +505,7 @@ def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, w
                                   "host_waits_per_tick": round(rows[r][4], 2)} for r in range(world_size)],
                     "note": "bytes cross RANK faces (RCCL send/recv) unless said otherwise; exchange_us_per_tick = stream time between the HIP events around every "
                             "exchange (ghost bodies, ghost velocity refreshes, hand-overs), the wait for the neighbouring rank included - taken, like the "
-                            "roofline's launches, in the ticks behind the timed region (option exchange_timing)"}
+                            "roofline's launches, in a replay of the timed ticks (option exchange_timing)"}
         try:
             if whole5 is not None:  # the bodies' sphere parts: centre = x + R(q) (p_sphere - x) of the initial pose
                 cb5 = whole5["compound"]
@@ -505,14 +546,34 @@ def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, w
                 kms += float(st["ms_solver_kernels"])
         return units, cons, launches, kms
     units, cons, launches, _kms = tally(ticks)
-    # the dominant kernel's launches, timed with HIP events in the K ticks BEHIND the timed region (ten events per tile-tick in the
-    # timed ticks themselves would cost them 5-10 %): `roofline` describes those launches
-    for w in (worlds if transport == "native" else [tw.world]):
-        w.set_option("time_solver_kernels", 1)
+    # the dominant kernel's launches and the exchanges, timed with HIP events (ten events per tile-tick in the timed ticks themselves would
+    # cost them 5-10 %): a REPLAY of the timed ticks - a second tile set over clones taken where the timed window started, its own
+    # communicator - so that `roofline`, solver_kernel_ms_per_tile_tick and exchange_us_per_tick describe the window `value` was timed on
+    replayed = "the timed ticks, replayed from clones of the tile worlds taken where the window starts"
     if transport == "native":
+        del step
+        del tiles
+        rworlds = snaps
+        for w in rworlds:
+            configure(w)
+            w.set_option("time_solver_kernels", 1)
+        tiles = mgf_amd.Tiles(ctx, rworlds, [sc["x_range"] for sc in tile_scenes], first_tile=first, n_tiles_total=total_tiles, halo=halo,
+                              refresh_every=refresh_every, migrate=not args.no_migrate)
+        if world_size > 1:
+            uid = torch.zeros(128, dtype=torch.uint8, device=red_dev)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(mgf_amd.rccl_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            tiles.connect(bytes(uid.cpu().numpy().tobytes()), rank, world_size)
         tiles.set_option("exchange_timing", 1)
         ns0 = tiles.counter("exchange_ns")
+        step = lambda: tiles.step(dt, args.iters)  # noqa: E731
+    else:
+        replayed = "the ticks behind the timed region (--transport torch: development driver)"
+        tw.world.set_option("time_solver_kernels", 1)
+    barrier()
     r_units, _rc, r_launches, kms = tally([step() for _ in range(args.steps)])
+    replay_same = bool(abs(r_units - units) < 0.5)
     if transport == "native" and exchange is not None:
         xus = torch.zeros(world_size, dtype=torch.float64, device=red_dev)
         xus[rank] = (tiles.counter("exchange_ns") - ns0) / 1e3 / args.steps
@@ -554,7 +615,9 @@ def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, w
     return {
         "metric": "contact_constraint_iters_per_sec", "value": units_all / elapsed, "unit": "constraint-iters/s", "n_gpus": world_size,
         "steps": args.steps, "warmup": warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
-        "scaling": "strong" if scene_kind in ("config4", "config5_tiles") else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong" if scene_kind in ("config4", "config5_tiles") else "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic" if not args.standin else "synthetic; NOT A MEASUREMENT OF xGMI: the ranks exchanged over a stand-in transport bound in place of librccl "
+                                                     f"({args.standin}), sharing GPUs as MGF_BENCH_DEVICE says - the multi-rank flow on one box, nothing else",
         "config": {"workload": f"{name}, dt=1/60, {args.iters} solver iters; {per_rank} tile(s) per GPU; ghost bodies once per tick, ghost velocities every "
                                f"{refresh_every} solver iterations, bodies handed to the tile that holds their centre"
                                + (" - DISABLED" if args.no_migrate else "") + f"; {SCENE_NOTE}",
@@ -563,17 +626,19 @@ def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, w
                    "parallelism": f"{world_size} GPU(s) x {per_rank} tile(s); exchange between a rank's tiles by device copies"
                                   + ("" if world_size == 1 else (", between ranks by RCCL send/recv over xGMI under the C-ABI (mgf_tiles_*)" if transport == "native"
                                                                  else f", between ranks by torch.distributed ({args.backend})"))},
-        "transport": transport, "rccl_ranks_seen": ranks_seen,
+        "transport": transport, "rccl_ranks_seen": ranks_seen, "rccl_lib": args.standin or ("librccl (dlopen under the C-ABI)" if world_size > 1 else None),
         "physics_steps_per_sec": args.steps / elapsed, "constraints_per_step": cons_all / args.steps,
         "solver_launches_per_step_rank0": launches / args.steps,
         # (a rank's tiles share one stream and their phases are enqueued interleaved: per-phase event spans of one tile include
         # the other tiles' work, so only the solver kernels' own event time is reported)
-        "solver_kernel_ms_per_tile_tick_rank0": kms / (args.steps * per_rank),  # (of the instrumented ticks behind the timed region)
+        "solver_kernel_ms_per_tile_tick_rank0": kms / (args.steps * per_rank),  # (of the instrumented replay of the timed ticks)
         "tile_tick_ms_rank0": elapsed * 1e3 / (args.steps * per_rank),
         "tile_tick_ms_per_rank": [round(float(v), 4) for v in rank_ms.cpu().numpy()],
-        "roofline": _roofline(r_units, r_launches, kms, mode, f"{refresh_every} iteration(s) of one tile between ghost refreshes; the {args.steps} ticks behind the "
-                              "timed region, HIP events around every launch", ("tiles", warmup, args.steps), workload=("config4" if scene_kind != "config5_tiles" else "config5") + "_tiles"),
-        "instrumentation": "the timed ticks carry no HIP events; the roofline's launches are those of the same number of ticks run right behind them with the events on",
+        "roofline": _roofline(r_units, r_launches, kms, mode, f"{refresh_every} iteration(s) of one tile between ghost refreshes; a replay of the {args.steps} "
+                              "timed ticks, HIP events around every launch", ("tiles", warmup, args.steps), workload=("config4" if scene_kind != "config5_tiles" else "config5") + "_tiles"),
+        "instrumentation": "the timed ticks carry no HIP events; roofline, solver_kernel_ms_per_tile_tick and exchange_us_per_tick come from " + replayed
+                           + " with the events on",
+        "replay_did_the_timed_windows_work_rank0": replay_same,
         "same_workload_on_one_gpu": one_gpu, "efficiency_vs_same_workload_on_one_gpu": eff,
         "exchange": exchange, "seam_penetration": seam,
     }

@@ -161,3 +161,33 @@ def test_a_failed_tick_is_reported_at_its_end_and_moves_nobody(ctx, connected):
     assert T.counter("host_waits") >= 5 * (2 + 2 * P)
     with pytest.raises(KeyError):
         T.counter("no_such_counter")
+
+
+# ---- `python bench.py --gpus N` as the driver issues it: no torchrun around it, the command spawns its own ranks ----------------
+def test_bench_gpus_2_spawns_its_own_ranks_and_prints_one_line():
+    """the scaling bench is launched like the N = 1 bench (plain `python bench.py --gpus N ...`); on a one-GPU box the
+    two ranks share device 0 over the stand-in transport, and the line says that it is no fabric measurement.  The roofline comes from a
+    replay of the timed ticks (clones of the tile worlds), which must have done the timed window's work."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.fake_rccl.build import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--scene", "config5", "--steps", "4", "--warmup", "12"]
+    if _device_count() < 2:
+        cmd += ["--rccl-lib", build()]
+    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["rccl_ranks_seen"] == 2 and len(d["tile_tick_ms_per_rank"]) == 2
+    assert d["replay_did_the_timed_windows_work_rank0"] is True
+    assert d["roofline"] and d["roofline"]["avg_launch_us"] > 0 and d["roofline"]["launches_timed"] == 4 * 4 * 5  # 4 ticks x 4 tiles x 5 launches
+    if _device_count() < 2:
+        assert "NOT A MEASUREMENT" in d["data"] and d["rccl_lib"].endswith(".so")
+    else:
+        assert d["data"] == "synthetic"
