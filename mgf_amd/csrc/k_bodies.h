@@ -237,7 +237,8 @@ __global__ __launch_bounds__(kBlock) void k_refresh_einfo(Bodies B, uint32_t n) 
 // `spec`: the tick is being enqueued before the previous one has been read back (mgf_world_step_many).  If that one
 // turns out to have failed a capacity check (its StepCounts still sit in `sc`), this tick must not touch the state: the
 // guard word makes k_integrate and the whole collide phase no-ops, and the host re-runs both ticks.
-__global__ void k_reset_step(SceneBounds* sb, uint32_t* err, uint32_t* guard, const uint32_t* prev_fail, int spec, int* sb_part) {
+__global__ void k_reset_step(SceneBounds* sb, uint32_t* err, uint32_t* guard, const uint32_t* prev_fail, int spec, int* sb_part, uint32_t* near_cnt = nullptr) {
+  if (near_cnt && threadIdx.x == 0) *near_cnt = 0u;  // (the length of the list k_integrate's tail is about to build)
   if (spec && *prev_fail) { if (threadIdx.x == 0) *guard = 1u; return; }
   if (sb_part && threadIdx.x < kBoundSlots) {  // launched with 64 threads: one partial record each
     int* slot = sb_part + (size_t)threadIdx.x * kBoundSlotInts;

@@ -161,10 +161,11 @@ constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u, 
 // The list sizes of the tick, checked against the capacities the lists were allocated with, at the end of the scans that
 // produce them (the thread of k_scan that writes the last prefix runs these: no launch of their own).
 struct ScanEpilogue {
-  int kind;                       // 0 none, 1 candidate lists (after the scan of the terrain / partner rows), 2 constraint list
-  uint32_t cap_a, cap_b;          // kind 1: cap_t, cap_p; kind 2: cap_c
-  const uint32_t *row_overflow, *grid_wide, *terrain_wide, *guard;  // kind 1 (each may be null but guard)
+  int kind;                       // 0 none, 1 candidate lists (after the scan of the terrain / partner rows), 2 constraint list, 3 both at once (k_contacts_spheres' tick: no candidate lists)
+  uint32_t cap_a, cap_b;          // kind 1: cap_t, cap_p; kind 2: cap_c; kind 3: cap_t, cap_c
+  const uint32_t *row_overflow, *grid_wide, *terrain_wide, *guard;  // kinds 1, 3 (each may be null but guard)
   StepCounts* sc;
+  const uint32_t *sum_t, *sum_ct; // kind 3: terrain candidates and terrain contacts (k_terrain_contacts' counters)
 };
 __device__ __forceinline__ void caps_candidates(const ScanEpilogue& E, uint32_t mt, uint32_t mp) {
   StepCounts r;
@@ -181,6 +182,24 @@ __device__ __forceinline__ void caps_candidates(const ScanEpilogue& E, uint32_t 
   r.ct_sum = 0;
   *E.sc = r;
 }
+// kind 3: the scanned counts were the bodies' constraint counts themselves (contacts only in the partner rows, terrain contacts counted by
+// k_terrain_contacts): the tick's counts in one go
+__device__ __forceinline__ void caps_contacts(const ScanEpilogue& E, uint32_t c) {
+  StepCounts r;
+  const uint32_t mt = *E.sum_t, ct = *E.sum_ct;
+  r.need_Mt = mt; r.need_Mp = c - ct; r.need_C = c; r.need_Ct = ct;
+  r.fail = 0;
+  if (E.row_overflow && (*E.row_overflow & 1u)) r.fail |= kFailRowOverflow;
+  if (E.row_overflow && (*E.row_overflow & 2u)) r.fail |= kFailTerrainRow;
+  if (E.grid_wide && *E.grid_wide) r.fail |= kFailGridWide;
+  if (*E.guard) r.fail |= kFailSkipped;
+  if (!r.fail && mt > E.cap_a) r.fail |= kFailCandCap;
+  if (!r.fail && c > E.cap_b) r.fail |= kFailConsCap;
+  r.Mt = r.fail ? 0u : mt; r.Mp = r.fail ? 0u : r.need_Mp; r.C = r.fail ? 0u : c; r.Ct = r.fail ? 0u : ct;
+  for (int k = 0; k < 6; ++k) r.bins[k] = 0;
+  r.ct_sum = ct;
+  *E.sc = r;
+}
 __device__ __forceinline__ void caps_constraints(const ScanEpilogue& E, uint32_t c) {
   StepCounts* sc = E.sc;
   if (sc->fail) return;
@@ -195,9 +214,13 @@ __device__ __forceinline__ void caps_constraints(const ScanEpilogue& E, uint32_t
 // until it meets a tile whose inclusive prefix is known (decoupled look-back).  The status words and the ticket are
 // zeroed by the tick's clearing launch (k_zero_many).  W = 2 scans two arrays of equal length together (both totals share a
 // status word: 31 bits each).
-constexpr int kScanBlock = 256, kScanRounds = 4, kScanTile = kScanBlock * 4 * kScanRounds;  // 4096 items per tile
+#ifndef MGF_SCAN_ROUNDS
+#define MGF_SCAN_ROUNDS 4
+#endif
+constexpr int kScanBlock = 256, kScanRounds = MGF_SCAN_ROUNDS, kScanTile = kScanBlock * 4 * kScanRounds;  // 4096 items per tile
 constexpr unsigned long long kScanAgg = 1ull << 62, kScanInc = 2ull << 62, kScanFlag = 3ull << 62;
-struct ScanJob { const uint32_t* in[2]; uint32_t* out[2]; uint32_t n; unsigned long long* status; uint32_t* ticket; ScanEpilogue epi; };
+struct ScanJob { const uint32_t* in[2]; uint32_t* out[2]; uint32_t n; unsigned long long* status; uint32_t* ticket; ScanEpilogue epi;
+                 const uint32_t* add; };  // add (W = 1, or null): a second array of the same length, summed into the first item by item
 template <int W>
 __global__ __launch_bounds__(kScanBlock) void k_scan(ScanJob J) {
   __shared__ uint32_t s_tile;
@@ -220,6 +243,12 @@ __global__ __launch_bounds__(kScanBlock) void k_scan(ScanJob J) {
       uint4 x = make_uint4(0, 0, 0, 0);
       if (i + 3u < J.n) x = *reinterpret_cast<const uint4*>(J.in[a] + i);
       else { if (i < J.n) x.x = J.in[a][i]; if (i + 1u < J.n) x.y = J.in[a][i + 1]; if (i + 2u < J.n) x.z = J.in[a][i + 2]; }
+      if (W == 1 && J.add) {
+        uint4 y = make_uint4(0, 0, 0, 0);
+        if (i + 3u < J.n) y = *reinterpret_cast<const uint4*>(J.add + i);
+        else { if (i < J.n) y.x = J.add[i]; if (i + 1u < J.n) y.y = J.add[i + 1]; if (i + 2u < J.n) y.z = J.add[i + 2]; }
+        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+      }
       v[a][r] = x;
       tot[a] += x.x + x.y + x.z + x.w;
     }
@@ -310,6 +339,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan(ScanJob J) {
   // the thread that wrote the last prefix (= the sum of everything before the closing element) checks the list sizes
   if (is_last && J.epi.kind == 1) caps_candidates(J.epi, last[0], last[W - 1]);
   if (is_last && J.epi.kind == 2) caps_constraints(J.epi, last[0]);
+  if (is_last && J.epi.kind == 3) caps_contacts(J.epi, last[0]);
 }
 
 // Linear BVH as an implicit complete 4-ary tree over MORTON CELLS.  A leaf is the cell of one 2L-bit
@@ -668,6 +698,7 @@ __global__ __launch_bounds__(kBlock) void k_terrain_rows(Bodies B, uint32_t n_ow
 struct TerrainRowsTail {
   static constexpr int kLdsWords = 2 * 64;  // a mesh of up to 64 tree nodes (the demo's 10-face box: 19) is walked in LDS
   TerrainDev M; uint32_t cap_row; uint32_t* rows_t; uint32_t* t_cnt; uint32_t* overflow;
+  uint32_t* near_list; uint32_t* near_cnt;  // optional: the bodies that list a face, compacted (k_terrain_contacts works on those alone)
   __device__ __forceinline__ void stage(float4* s) const {
     if (2u * M.n_nodes > (uint32_t)kLdsWords) return;
     const float4* src = reinterpret_cast<const float4*>(M.nodes);
@@ -686,6 +717,16 @@ struct TerrainRowsTail {
     else terrain_traverse(M, q, emit);
     t_cnt[i] = nt;
     if (nt > cap) atomicOr(overflow, 2u);
+    if (near_list) {  // (one atomic per wave that has such a body)
+      const unsigned long long m = __ballot(nt != 0u);
+      if (nt) {
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+        uint32_t at = 0;
+        if (lane == leader) at = atomicAdd(near_cnt, (uint32_t)__popcll(m));
+        at = __shfl(at, leader);
+        near_list[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+      }
+    }
   }
 };
 

@@ -716,6 +716,229 @@ __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCoun
   }
 }
 
+// A world of spheres over a small mesh (round 5): from the rows to the constraint records without candidate lists.
+//   k_terrain_contacts   a thread per body with terrain faces: the sphere-triangle test on its row (Mesh::contacts' faces, in its
+//                        order), the contacts parked in the terrain list's slots (handed out by an atomic counter), tcn = their number;
+//   k_scan<1> (+ add)    base = exclusive prefix of p_cnt + tcn: the partner rows hold contacts only, so that IS the body's constraint
+//                        count; its last thread writes the tick's StepCounts (caps_contacts);
+//   k_contacts_spheres   a block per 256 consecutive bodies: ContactConstraint::new for the terrain contacts by their bodies' threads
+//                        and for the partner contacts as a list in LDS in canonical order (ascending order id inside a body), dealt
+//                        evenly to the threads.
+// What this replaces - k_scan<2> (row offsets), k_lists_spheres, k_scan<1>, k_setup_pairs<true> - built t_cand / p_cand / ..._pre /
+// ..._owner lists that nobody downstream reads.
+constexpr uint32_t kCsEntCap = 1024;  // partner contacts of a block staged per pass (a settled pile's block has ~900)
+constexpr uint32_t kCsSumStride = 32; // words between the two global counters (their own cache lines)
+#ifndef MGF_TC_LANES
+#define MGF_TC_LANES 4
+#endif
+constexpr int kTcLanes = MGF_TC_LANES;  // lanes per body in k_terrain_contacts: a face each (a body near the box's floor or walls lists 1-4)
+constexpr uint32_t kTcMesh = 64;        // faces / vertices of a mesh staged in LDS
+// The bodies that list a face (near_list, compacted by k_integrate's tail), kTcLanes lanes each: a scan over all bodies - most of them
+// nowhere near the mesh - took 21 us for what is 4 dependent round trips and a few hundred instructions per body.  tcn / tpos of the
+// other bodies are zero (the tick's clearing launch).
+__global__ __launch_bounds__(kBlock) void k_terrain_contacts(Bodies B, TerrainDev M, const uint32_t* near_list, const uint32_t* near_cnt, uint32_t n_faces, uint32_t n_verts,
+                                                             uint32_t cap_row_t, const uint32_t* rows_t, const uint32_t* t_cnt,
+                                                             uint32_t* sums /* [0] candidates = slot allocator, [kCsSumStride] contacts */, uint32_t cap_t,
+                                                             NContact* t_out /* 2 per slot; .lb.w of the first = the face's contact count */, uint32_t* tcn,
+                                                             uint32_t* tpos, const uint32_t* guard) {
+  __shared__ uint4 s_face[kTcMesh];
+  __shared__ float4 s_vert[kTcMesh];
+  const uint32_t L = *guard ? 0u : *near_cnt;
+  const uint32_t per_pass = gridDim.x * (uint32_t)(kBlock / kTcLanes);
+  if (blockIdx.x * (uint32_t)(kBlock / kTcLanes) >= L) return;
+  const bool staged = n_faces <= kTcMesh && n_verts <= kTcMesh;
+  if (staged) {
+    for (uint32_t e = threadIdx.x; e < n_faces; e += kBlock) s_face[e] = M.faces[e];
+    for (uint32_t e = threadIdx.x; e < n_verts; e += kBlock) s_vert[e] = M.verts[e];
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  const uint32_t sub = threadIdx.x % (uint32_t)kTcLanes;
+  const V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
+  // (the loop's trips are the same for every lane of a wave: the shuffles below need the whole wave)
+  for (uint32_t e0 = blockIdx.x * (uint32_t)(kBlock / kTcLanes) + ((uint32_t)threadIdx.x & ~63u) / (uint32_t)kTcLanes; e0 < L; e0 += per_pass) {
+    const uint32_t e = e0 + (uint32_t)lane / (uint32_t)kTcLanes;
+    uint32_t i = 0, nt = 0;
+    if (e < L) { i = near_list[e]; nt = t_cnt[i]; }
+    if (nt > cap_row_t) nt = 0;  // (an overflowed row: the flag is up, the host re-runs the phase)
+    // the wave's slots with ONE atomic
+    uint32_t run = 0, tp = 0;
+    {
+      const uint32_t mine = sub == 0u ? nt : 0u;
+      uint32_t inc = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+      uint32_t wave_base = 0;
+      if (lane == 63 && inc) wave_base = atomicAdd(&sums[0], inc);
+      wave_base = __shfl(wave_base, 63);
+      tp = __shfl(wave_base + inc - mine, lane & ~(kTcLanes - 1));
+    }
+    if (nt) {
+      V3 vA;
+      Comp Ca = load_comp_moving(B, i, &vA);
+      Ca.kind = KIND_SPHERE;
+      const uint32_t* rt = rows_t + (size_t)i * cap_row_t;
+      for (uint32_t a = sub; a < nt; a += (uint32_t)kTcLanes) {
+        const uint32_t f = rt[a];
+        const uint4 fi = staged ? s_face[f] : M.faces[f];
+        Triangle tri = staged ? mkt(xyz(s_vert[fi.x]) + mx, xyz(s_vert[fi.y]) + mx, xyz(s_vert[fi.z]) + mx)
+                              : mkt(xyz(M.verts[fi.x]) + mx, xyz(M.verts[fi.y]) + mx, xyz(M.verts[fi.z]) + mx);  // mesh.rs:122-126
+        LocalContact lc[2];
+        const int nc = comp_tri_local(Ca, vA, tri, mx, lc);
+        if (tp + a < cap_t) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            NContact o; o.la = mk4(lc[k].la, lc[k].g.t); o.lb = mk4(lc[k].lb, k == 0 ? u2f((uint32_t)nc) : 0.0f); o.n = mk4(lc[k].g.n, 0.0f);  // Manifold::from(lc) manifold.rs:120-128
+            if (k < nc || k == 0) t_out[2 * (size_t)(tp + a) + k] = o;
+          }
+        }
+        run += (uint32_t)nc;
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < kTcLanes; o <<= 1) run += __shfl_xor(run, o);
+    if (e < L && sub == 0u) {
+      tcn[i] = run;  // the body's terrain constraints come first in its range (k_chain_rows)
+      tpos[i] = tp;
+    }
+    uint32_t wrun = sub == 0u ? run : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wrun += __shfl_xor(wrun, o);
+    if (lane == 0 && wrun) atomicAdd(&sums[kCsSumStride], wrun);
+  }
+}
+struct ContactsSpheres {
+  const StepCounts* sc;
+  uint32_t n, cap_row_t, cap_c, cap_t;
+  const uint32_t *rows_p, *t_cnt, *p_cnt, *base, *tcn, *tpos;
+  const NContact* t_out;
+  float dt, baumgarte, slop;
+  CRec* cons; uint2* ab; uint32_t* degb; uint32_t* rev; uint32_t rev_cap; uint32_t* rev_flag; uint32_t* flag;
+  const uint32_t* ext;
+};
+// a body's partner row -> the block's list in LDS, canonical order (entries of the window [w0, w0 + kCsEntCap))
+__device__ __forceinline__ void cs_list_row(const uint32_t* rp, uint32_t np, const uint32_t* ext, uint32_t first, uint32_t w0, uint32_t owner, uint32_t* s_j, uint16_t* s_b) {
+  if (np <= 12u) {  // (a sphere touches at most 12 equal ones)
+    uint32_t pj[12], o_id[12];
+#pragma unroll
+    for (int a = 0; a < 12; a += 4) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if ((uint32_t)a < np) v = *reinterpret_cast<const uint4*>(rp + a);
+      pj[a] = v.x; pj[a + 1] = v.y; pj[a + 2] = v.z; pj[a + 3] = v.w;
+    }
+#pragma unroll
+    for (int a = 0; a < 12; ++a) o_id[a] = (uint32_t)a < np ? order_id(ext, pj[a]) : 0xFFFFFFFFu;
+#pragma unroll
+    for (int a = 0; a < 12; ++a) {
+      uint32_t before = 0;
+#pragma unroll
+      for (int q = 0; q < 12; ++q) before += o_id[q] < o_id[a] ? 1u : 0u;
+      const uint32_t pos = first + before - w0;
+      if ((uint32_t)a < np && pos < kCsEntCap) { s_j[pos] = pj[a]; s_b[pos] = (uint16_t)owner; }
+    }
+  } else {
+    for (uint32_t a = 0; a < np; ++a) {
+      const uint32_t j = rp[a], oa = order_id(ext, j);
+      uint32_t before = 0;
+      for (uint32_t q = 0; q < np; ++q) before += order_id(ext, rp[q]) < oa ? 1u : 0u;
+      const uint32_t pos = first + before - w0;
+      if (pos < kCsEntCap) { s_j[pos] = j; s_b[pos] = (uint16_t)owner; }
+    }
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_contacts_spheres(Bodies B, TerrainDev M, ContactsSpheres A) {
+  __shared__ float4 s_w[kBlock / 64][7 * 65];  // a wave's records on their way out (see k_setup_pairs)
+  __shared__ uint32_t s_c[kBlock / 64][64];
+  __shared__ uint32_t s_j[kCsEntCap];           // the pass's partner contacts in canonical order: partner ...
+  __shared__ uint16_t s_b[kCsEntCap];           // ... and owner (the block's body)
+  __shared__ uint32_t s_cbase[kBlock];          // body -> id of its first partner constraint minus its first entry's position
+  __shared__ uint32_t s_wave[kBlock / 64];
+  if (A.sc->fail) return;  // (the scan's closing thread found a flag up or a capacity exceeded: the host re-runs the phase)
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const uint32_t i0 = blockIdx.x * (uint32_t)kBlock, i = i0 + (uint32_t)t;
+  uint32_t np = 0, run = 0, base_i = 0;
+  if (i < A.n) { np = A.p_cnt[i]; run = A.tcn[i]; base_i = A.base[i]; }
+  // ---- where the body's partner contacts start in the block's list
+  uint32_t inc_p = np;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc_p, o); if (lane >= o) inc_p += v; }
+  if (lane == 63) s_wave[wv] = inc_p;
+  __syncthreads();
+  uint32_t before_p = 0, totalp = 0;
+  for (int k = 0; k < kBlock / 64; ++k) { const uint32_t v = s_wave[k]; if (k < wv) before_p += v; totalp += v; }
+  const uint32_t excl_p = before_p + inc_p - np;
+  const uint32_t* rp = A.rows_p + (size_t)i * kRowCap;
+  if (np) cs_list_row(rp, np, A.ext, excl_p, 0u, (uint32_t)t, s_j, s_b);
+  s_cbase[t] = base_i + run - excl_p;
+  // ---- ContactConstraint::new for the terrain contacts (world.rs:243-251): the body's own thread (setup_terrain_one's work)
+  if (run) {
+    const uint32_t nt = A.t_cnt[i], tp = A.tpos[i];
+    const V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
+    const BodyDyn Ad = load_dyn(B.srec, i), S = static_dyn();
+    const BodyPack Pa = load_pack(B, i, false);
+    uint32_t c = base_i;
+    for (uint32_t a = 0; a < nt; ++a) {
+      const NContact in0 = A.t_out[2 * (size_t)(tp + a)];
+      const uint32_t nc = f2u(in0.lb.w);
+      for (uint32_t k = 0; k < nc; ++k, ++c) {
+        const NContact in = k == 0 ? in0 : A.t_out[2 * (size_t)(tp + a) + k];
+        // Static{ center: terrain.center(), friction: 0.0 } world.rs:247
+        const CRec r = make_constraint(i, kNone, Ad, xyz(Pa.ei), Pa.ei.w, Pa.dl.w, S, mx, 0.0f, 0.0f, xyz(in.n), xyz(in.la), xyz(in.lb), A.dt, A.baumgarte, A.slop);
+        store_crec(&A.cons[c], r);
+        A.ab[c] = make_uint2(i, kNone);
+      }
+    }
+  }
+  // ---- ... and for the partner contacts: the block's list, kCsEntCap entries per pass, an entry per thread
+  float4* out = reinterpret_cast<float4*>(A.cons);
+  __syncthreads();  // (the list's first pass, s_cbase)
+  for (uint32_t w0 = 0; w0 < totalp; w0 += kCsEntCap) {
+    if (w0) {  // (rare: a block with more contacts than a pass holds lists the next window)
+      __syncthreads();
+      if (np) cs_list_row(rp, np, A.ext, excl_p, w0, (uint32_t)t, s_j, s_b);
+      __syncthreads();
+    }
+    const uint32_t m = min(totalp - w0, kCsEntCap);
+    for (uint32_t e0 = 0; e0 < m; e0 += (uint32_t)kBlock) {  // (the same trips for every wave of the block)
+      const uint32_t e = e0 + (uint32_t)t;
+      uint32_t c = kNone;
+      if (e < m) {
+        const uint32_t b = s_b[e], j = s_j[e], ia = i0 + b;
+        const BodyPack Pa = load_pack(B, ia, true), Pb = load_pack(B, j, true);
+        Comp Xa, Xb;  // as k_narrow_pairs<0, 0>
+        Xa.p = xyz(Pa.c0); Xa.r = Pa.c0.w; Xa.d = mk3(0.0f, 0.0f, 0.0f); Xa.kind = KIND_SPHERE;
+        Xb.p = xyz(Pb.c0); Xb.r = Pb.c0.w; Xb.d = mk3(0.0f, 0.0f, 0.0f); Xb.kind = KIND_SPHERE;
+        LocalContact lc;
+        if (!comp_pair_local(Xa, xyz(Pa.dl), Xb, xyz(Pb.dl), &lc)) {
+          *A.flag = 1u;  // the broadphase's sphere test and this one disagree about a contact
+        } else {
+          const V3 nrm = (mk3(0.0f, 0.0f, 0.0f) + lc.g.n) / 1.0f;  // Manifold::from(pruner) of one contact (manifold.rs:135-140)
+          const BodyDyn Ad = load_dyn(B.srec, ia), Bd = load_dyn(B.srec, j);
+          c = s_cbase[b] + w0 + e;
+          const CRec r = make_constraint(ia, j, Ad, xyz(Pa.ei), Pa.ei.w, Pa.dl.w, Bd, xyz(Pb.ei), Pb.ei.w, Pb.dl.w, nrm, lc.la, lc.lb, A.dt, A.baumgarte, A.slop);
+          const float4* rw = reinterpret_cast<const float4*>(&r);
+#pragma unroll
+          for (int k = 0; k < 7; ++k) s_w[wv][k * 65 + lane] = rw[k];
+          A.ab[c] = make_uint2(ia, j);
+          // body j's row of the constraints it takes part in as `b` (k_chain_rows); as `a` a body owns a contiguous id range
+          const uint32_t pos = atomicAdd(&A.degb[j], 1u);
+          if (pos < A.rev_cap) A.rev[(size_t)j * A.rev_cap + pos] = c;
+          else *A.rev_flag = 1u;
+        }
+      }
+      s_c[wv][lane] = c;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (a wave's LDS accesses are served in order; the wave reads only what it wrote)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int rec = it * 8 + (lane >> 3), k = lane & 7;
+        const uint32_t cr = s_c[wv][rec];
+        if (cr != kNone && k < 7) out[(size_t)cr * 8 + k] = s_w[wv][k * 65 + rec];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+}
+
 // ContactConstraint::new (solver.rs:101-191) for caller-built manifolds on the resident RigidBodyVec (mgf_constraints_new):
 // one thread per (manifold, contact) row.  obj_a is Dynamic; obj_b Dynamic or Static{center, friction} (b == kNone).
 struct ManifoldRow { uint32_t a, b; float cb[3], fric_b; float n[3], t0[3], t1[3], la[3], lb[3]; };

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Same-box A/B of several builds of libmgf_hip.so on one bench window: kernel-trace summaries.
+#   bash tools/scratch/ab_libs.sh "<bench args>" <ticks> tree <variant name> ...     (variant NAME = mgf_amd/variants/libmgf_hip_NAME.so)
+ARGS=$1; K=$2; shift 2
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+for L in "$@"; do
+  if [ $L = tree ]; then unset MGF_AMD_LIB; else export MGF_AMD_LIB=$R/mgf_amd/variants/libmgf_hip_$L.so; fi
+  rocprofv3 --kernel-trace -d $O/abl_${L}_trace -o bench -- python $R/bench.py --no-cpu-baseline --no-settled --no-order-check --no-other-configs --min-seconds 0 $ARGS > $O/abl_${L}.log 2>&1
+  ( cd $R; python tools/rocprof_summary.py gpurun_out/abl_${L}_trace/bench_results.db $K --timed k_solve_flow6 $K > gpurun_out/abl_${L}_kernel_stats.txt; rm -rf gpurun_out/abl_${L}_trace )
+  echo "== $L"; cut -c1-60,75-140 $O/abl_${L}_kernel_stats.txt | head -${HEAD:-8}
+done
