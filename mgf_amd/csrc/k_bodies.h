@@ -94,7 +94,7 @@ __device__ __forceinline__ void bounds_block_accumulate(const int blo[3], const 
 struct NoTail {
   static constexpr int kLdsWords = 1;
   __device__ __forceinline__ void stage(float4*) const {}
-  __device__ __forceinline__ void operator()(uint32_t, const Box&, const float4*) const {}
+  __device__ __forceinline__ void operator()(uint32_t, const Box&, const float4*, const Comp&, const V3&) const {}
 };
 template <class Tail>
 __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, float dt, float fat_margin, int do_complete,
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
       }
       blo[0] = bhi[0] = f_ord(fb.c.x); blo[1] = bhi[1] = f_ord(fb.c.y); blo[2] = bhi[2] = f_ord(fb.c.z);
       brm[0] = f_ord(fb.r.x); brm[1] = f_ord(fb.r.y); brm[2] = f_ord(fb.r.z);
-      tail(i, tb, s_tail);
+      tail(i, tb, s_tail, col, d);
     } else if (do_complete) {
       B.einfo[i] = mk4(x + xyz(dl), B.einfo[i].w);
     }
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void k_refresh_einfo(Bodies B, uint32_t n) 
 // guard word makes k_integrate and the whole collide phase no-ops, and the host re-runs both ticks.
 __global__ void k_reset_step(SceneBounds* sb, uint32_t* err, uint32_t* guard, const uint32_t* prev_fail, int spec, int* sb_part, uint32_t* near_cnt = nullptr) {
   if (near_cnt && threadIdx.x == 0) *near_cnt = 0u;  // (the length of the list k_integrate's tail is about to build)
-  if (spec && *prev_fail) { if (threadIdx.x == 0) *guard = 1u; return; }
+  if (spec && (*prev_fail || err[2])) { if (threadIdx.x == 0) *guard = 1u; return; }  // (err[2]: the solvers' abort flag, see k_tick_clear)
   if (sb_part && threadIdx.x < kBoundSlots) {  // launched with 64 threads: one partial record each
     int* slot = sb_part + (size_t)threadIdx.x * kBoundSlotInts;
     for (int k = 0; k < 3; ++k) { slot[k] = 0x7FFFFFFF; slot[3 + k] = (int)0x80000000; slot[6 + k] = 0; }

@@ -124,7 +124,9 @@ __global__ __launch_bounds__(kBlock) void k_tick_clear(ZeroList z, SceneBounds* 
                                                        int* sb_part) {
   // (see k_reset_step: a speculative tick behind a failed one raises the guard and resets nothing - but the counters are cleared all
   // the same: the kernels of the cell sort run unguarded, on the unchanged bodies, and must start from zero)
-  const bool skip = spec && *prev_fail;
+  // (err[2]: the solvers' abort flag - a tick whose persistent launch gave up is solved again by the host, solver_abort_fallback; this
+  // launch clears the flag below, its first wave has read it here)
+  const bool skip = spec && (*prev_fail || err[2]);
   if (skip && blockIdx.x == 0 && threadIdx.x == 0) *guard = 1u;
   if (blockIdx.x == 0 && !skip) {
     if (sb_part && threadIdx.x < kBoundSlots) {
@@ -398,10 +400,9 @@ __device__ __forceinline__ void pair_query_region(const V3& qc, const V3& qr, fl
 }
 
 // Bodies -> leaf records in cell order (counting sort, second half).
-__global__ __launch_bounds__(kBlock) void k_scatter_leaves(Lbvh T, const float4* fb_c, const float4* fb_r, const uint32_t* cell_of,
-                                                           const uint32_t* rank, uint32_t* brank, const float4* col0, const float4* delta, const float4* tb_c,
-                                                           const float4* tb_r, const SceneBounds* sb, float pad_abs, float min_frac) {
-  uint32_t body = blockIdx.x * kBlock + threadIdx.x;
+__device__ __forceinline__ void scatter_leaf(uint32_t body, const Lbvh& T, const float4* fb_c, const float4* fb_r, const uint32_t* cell_of,
+                                             const uint32_t* rank, uint32_t* brank, const float4* col0, const float4* delta, const float4* tb_c,
+                                             const float4* tb_r, const SceneBounds* sb, float pad_abs, float min_frac) {
   if (body >= T.n) return;
   uint32_t p = T.cell_lo[cell_of[body]] + rank[body];
   LeafRec lr; lr.c = mk4(xyz(fb_c[body]), u2f(body)); lr.r = mk4(xyz(fb_r[body]), u2f(order_id(T.ext, body)));
@@ -418,6 +419,11 @@ __global__ __launch_bounds__(kBlock) void k_scatter_leaves(Lbvh T, const float4*
   }
   T.sidx[p] = body;
   brank[body] = p;  // position in cell order (the block-local solver groups bodies by it)
+}
+__global__ __launch_bounds__(kBlock) void k_scatter_leaves(Lbvh T, const float4* fb_c, const float4* fb_r, const uint32_t* cell_of,
+                                                           const uint32_t* rank, uint32_t* brank, const float4* col0, const float4* delta, const float4* tb_c,
+                                                           const float4* tb_r, const SceneBounds* sb, float pad_abs, float min_frac) {
+  scatter_leaf(blockIdx.x * kBlock + threadIdx.x, T, fb_c, fb_r, cell_of, rank, brank, col0, delta, tb_c, tb_r, sb, pad_abs, min_frac);
 }
 
 // One block per 256 consecutive cells: the 4 internal levels above them.
@@ -698,19 +704,25 @@ __global__ __launch_bounds__(kBlock) void k_terrain_rows(Bodies B, uint32_t n_ow
 struct TerrainRowsTail {
   static constexpr int kLdsWords = 2 * 64;  // a mesh of up to 64 tree nodes (the demo's 10-face box: 19) is walked in LDS
   TerrainDev M; uint32_t cap_row; uint32_t* rows_t; uint32_t* t_cnt; uint32_t* overflow;
-  uint32_t* near_list; uint32_t* near_cnt;  // optional: the bodies that list a face, compacted (k_terrain_contacts works on those alone)
+  // optional: the bodies that list a face, compacted, each with what the sphere-triangle test needs of it - k_terrain_contacts works on
+  // these records alone.  3 words per body: (collider p, r), (motion, body), (faces listed, the first eight of them as bytes - or
+  // 0xFFFFFFFF: read the row -, -)
+  float4* near_list; uint32_t* near_cnt;
   __device__ __forceinline__ void stage(float4* s) const {
     if (2u * M.n_nodes > (uint32_t)kLdsWords) return;
     const float4* src = reinterpret_cast<const float4*>(M.nodes);
     for (uint32_t e = threadIdx.x; e < 2u * M.n_nodes; e += blockDim.x) s[e] = src[e];
   }
-  __device__ __forceinline__ void operator()(uint32_t i, const Box& tb, const float4* s) const {
+  __device__ __forceinline__ void operator()(uint32_t i, const Box& tb, const float4* s, const Comp& col, const V3& d) const {
     Box q; q.c = tb.c + -mk3(M.x[0], M.x[1], M.x[2]); q.r = tb.r;
     uint32_t* row = rows_t + (size_t)i * cap_row;
-    uint32_t nt = 0;
+    uint32_t nt = 0, big = 0;
+    unsigned long long pk = 0ull;
     const uint32_t cap = cap_row;
     auto emit = [&](uint32_t face) {
       if (nt < cap) row[nt] = face;
+      big |= face;
+      pk |= nt < 8u ? (unsigned long long)face << (8u * nt) : 0ull;
       ++nt;
     };
     if (2u * M.n_nodes <= (uint32_t)kLdsWords) terrain_traverse_at(M, s, q, emit);  // (two calls: a selected pointer would make the loads flat)
@@ -723,8 +735,11 @@ struct TerrainRowsTail {
         const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
         uint32_t at = 0;
         if (lane == leader) at = atomicAdd(near_cnt, (uint32_t)__popcll(m));
-        at = __shfl(at, leader);
-        near_list[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+        at = __shfl(at, leader) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (big > 255u || nt > 8u) pk = ~0ull;
+        near_list[3 * (size_t)at] = mk4(col.p, col.r);
+        near_list[3 * (size_t)at + 1] = mk4(d, u2f(i));
+        near_list[3 * (size_t)at + 2] = make_float4(u2f(nt), u2f((uint32_t)pk), u2f((uint32_t)(pk >> 32)), 0.0f);
       }
     }
   }

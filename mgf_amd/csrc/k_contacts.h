@@ -736,16 +736,25 @@ constexpr uint32_t kTcMesh = 64;        // faces / vertices of a mesh staged in 
 // The bodies that list a face (near_list, compacted by k_integrate's tail), kTcLanes lanes each: a scan over all bodies - most of them
 // nowhere near the mesh - took 21 us for what is 4 dependent round trips and a few hundred instructions per body.  tcn / tpos of the
 // other bodies are zero (the tick's clearing launch).
-__global__ __launch_bounds__(kBlock) void k_terrain_contacts(Bodies B, TerrainDev M, const uint32_t* near_list, const uint32_t* near_cnt, uint32_t n_faces, uint32_t n_verts,
-                                                             uint32_t cap_row_t, const uint32_t* rows_t, const uint32_t* t_cnt,
-                                                             uint32_t* sums /* [0] candidates = slot allocator, [kCsSumStride] contacts */, uint32_t cap_t,
-                                                             NContact* t_out /* 2 per slot; .lb.w of the first = the face's contact count */, uint32_t* tcn,
-                                                             uint32_t* tpos, const uint32_t* guard) {
+struct TerrainContacts {
+  TerrainDev M;
+  const float4* near_list; const uint32_t* near_cnt;
+  uint32_t n_faces, n_verts, cap_row_t, cap_t;
+  const uint32_t* rows_t;
+  uint32_t* sums;      // [0] candidates = slot allocator, [kCsSumStride] contacts
+  NContact* t_out;     // 2 per slot; .lb.w of the first = the face's contact count
+  uint32_t *tcn, *tpos;
+  const uint32_t* guard;
+};
+__device__ __forceinline__ void terrain_contacts_job(const TerrainContacts& A, uint32_t job_block, uint32_t job_blocks) {
+  const TerrainDev& M = A.M;
+  const float4* near_list = A.near_list; const uint32_t n_faces = A.n_faces, n_verts = A.n_verts, cap_row_t = A.cap_row_t, cap_t = A.cap_t;
+  const uint32_t* rows_t = A.rows_t; uint32_t* sums = A.sums; NContact* t_out = A.t_out; uint32_t* tcn = A.tcn; uint32_t* tpos = A.tpos;
   __shared__ uint4 s_face[kTcMesh];
   __shared__ float4 s_vert[kTcMesh];
-  const uint32_t L = *guard ? 0u : *near_cnt;
-  const uint32_t per_pass = gridDim.x * (uint32_t)(kBlock / kTcLanes);
-  if (blockIdx.x * (uint32_t)(kBlock / kTcLanes) >= L) return;
+  const uint32_t L = *A.guard ? 0u : *A.near_cnt;
+  const uint32_t per_pass = job_blocks * (uint32_t)(kBlock / kTcLanes);
+  if (job_block * (uint32_t)(kBlock / kTcLanes) >= L) return;
   const bool staged = n_faces <= kTcMesh && n_verts <= kTcMesh;
   if (staged) {
     for (uint32_t e = threadIdx.x; e < n_faces; e += kBlock) s_face[e] = M.faces[e];
@@ -756,10 +765,15 @@ __global__ __launch_bounds__(kBlock) void k_terrain_contacts(Bodies B, TerrainDe
   const uint32_t sub = threadIdx.x % (uint32_t)kTcLanes;
   const V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
   // (the loop's trips are the same for every lane of a wave: the shuffles below need the whole wave)
-  for (uint32_t e0 = blockIdx.x * (uint32_t)(kBlock / kTcLanes) + ((uint32_t)threadIdx.x & ~63u) / (uint32_t)kTcLanes; e0 < L; e0 += per_pass) {
+  for (uint32_t e0 = job_block * (uint32_t)(kBlock / kTcLanes) + ((uint32_t)threadIdx.x & ~63u) / (uint32_t)kTcLanes; e0 < L; e0 += per_pass) {
     const uint32_t e = e0 + (uint32_t)lane / (uint32_t)kTcLanes;
-    uint32_t i = 0, nt = 0;
-    if (e < L) { i = near_list[e]; nt = t_cnt[i]; }
+    uint32_t i = 0, nt = 0, pk0 = 0, pk1 = 0;
+    float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
+    if (e < L) {
+      r0 = near_list[3 * (size_t)e]; r1 = near_list[3 * (size_t)e + 1];
+      const float4 r2 = near_list[3 * (size_t)e + 2];
+      i = f2u(r1.w); nt = f2u(r2.x); pk0 = f2u(r2.y); pk1 = f2u(r2.z);
+    }
     if (nt > cap_row_t) nt = 0;  // (an overflowed row: the flag is up, the host re-runs the phase)
     // the wave's slots with ONE atomic
     uint32_t run = 0, tp = 0;
@@ -774,12 +788,12 @@ __global__ __launch_bounds__(kBlock) void k_terrain_contacts(Bodies B, TerrainDe
       tp = __shfl(wave_base + inc - mine, lane & ~(kTcLanes - 1));
     }
     if (nt) {
-      V3 vA;
-      Comp Ca = load_comp_moving(B, i, &vA);
-      Ca.kind = KIND_SPHERE;
+      const V3 vA = xyz(r1);
+      Comp Ca; Ca.p = xyz(r0); Ca.r = r0.w; Ca.d = mk3(0.0f, 0.0f, 0.0f); Ca.kind = KIND_SPHERE;
       const uint32_t* rt = rows_t + (size_t)i * cap_row_t;
+      const bool bytes = pk0 != 0xFFFFFFFFu || pk1 != 0xFFFFFFFFu;  // (both all-ones: faces above 255 or more than eight - read the row)
       for (uint32_t a = sub; a < nt; a += (uint32_t)kTcLanes) {
-        const uint32_t f = rt[a];
+        const uint32_t f = bytes ? ((a < 4u ? pk0 >> (8u * a) : pk1 >> (8u * (a - 4u))) & 255u) : rt[a];
         const uint4 fi = staged ? s_face[f] : M.faces[f];
         Triangle tri = staged ? mkt(xyz(s_vert[fi.x]) + mx, xyz(s_vert[fi.y]) + mx, xyz(s_vert[fi.z]) + mx)
                               : mkt(xyz(M.verts[fi.x]) + mx, xyz(M.verts[fi.y]) + mx, xyz(M.verts[fi.z]) + mx);  // mesh.rs:122-126
@@ -806,6 +820,16 @@ __global__ __launch_bounds__(kBlock) void k_terrain_contacts(Bodies B, TerrainDe
     for (int o = 32; o >= 1; o >>= 1) wrun += __shfl_xor(wrun, o);
     if (lane == 0 && wrun) atomicAdd(&sums[kCsSumStride], wrun);
   }
+}
+__global__ __launch_bounds__(kBlock) void k_terrain_contacts(TerrainContacts A) { terrain_contacts_job(A, blockIdx.x, gridDim.x); }
+// ... as the last `tc_blocks` blocks of the leaf scatter's launch (both follow k_integrate, neither needs the other: the few waves of the
+// sphere-triangle tests - a resting sphere against the floor's other triangle runs three ray-capsule tests, ~15 us of one lane's
+// arithmetic - hide behind the streaming kernel instead of taking a launch of their own)
+__global__ __launch_bounds__(kBlock) void k_scatter_leaves_tc(Lbvh T, const float4* fb_c, const float4* fb_r, const uint32_t* cell_of,
+                                                              const uint32_t* rank, uint32_t* brank, const float4* col0, const float4* delta, const float4* tb_c,
+                                                              const float4* tb_r, const SceneBounds* sb, float pad_abs, float min_frac, TerrainContacts A, uint32_t tc_blocks) {
+  if (blockIdx.x < tc_blocks) { terrain_contacts_job(A, blockIdx.x, tc_blocks); return; }  // (first: they take longest)
+  scatter_leaf((blockIdx.x - tc_blocks) * kBlock + threadIdx.x, T, fb_c, fb_r, cell_of, rank, brank, col0, delta, tb_c, tb_r, sb, pad_abs, min_frac);
 }
 struct ContactsSpheres {
   const StepCounts* sc;

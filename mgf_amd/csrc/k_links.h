@@ -140,6 +140,21 @@ struct Frontier {
                        // clears cnt[(r+2)%3] (nobody touches it during launch r) - no fences, no last-block logic
 };
 
+// Solver::solve cannot fail (solver.rs:72-78), a persistent launch can (it needs all its workgroups resident at once: a device shared
+// with another process, a CU mask): the velocities and accumulated impulses as they were before the launch, and back - the host then
+// runs the list with the launch-per-frontier executor, which needs no residency (solver_abort_fallback).
+__global__ __launch_bounds__(kBlock) void k_solver_snapshot(const float4* srec, uint32_t n, float4* vsnap, const CRec* cons, uint32_t C, float* nsnap) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t < n) { vsnap[2 * (size_t)t] = srec[4 * (size_t)t]; vsnap[2 * (size_t)t + 1] = srec[4 * (size_t)t + 1]; }
+  if (nsnap && t < C) nsnap[t] = cons[t].nimp;
+}
+__global__ __launch_bounds__(kBlock) void k_solver_restore(float4* srec, uint32_t n, const float4* vsnap, CRec* cons, uint32_t C, const float* nsnap, uint32_t* abort_flag) {
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t < n) { srec[4 * (size_t)t] = vsnap[2 * (size_t)t]; srec[4 * (size_t)t + 1] = vsnap[2 * (size_t)t + 1]; }  // (v, w; inv_mass and I00 are constants)
+  if (t < C) cons[t].nimp = nsnap ? nsnap[t] : 0.0f;  // (no snapshot: the list is fresh from ContactConstraint::new)
+  if (t == 0) *abort_flag = 0u;
+}
+
 // Start of a Solver::solve call: reset round / in-degree of every record; launch 0's list =
 // constraints without predecessors in iteration 0.  Block-aggregated append.
 __global__ __launch_bounds__(kBlock) void k_frontier0(uint32_t C, CRec* cons, ConsLinks K, Frontier F) {

@@ -379,7 +379,11 @@ __device__ __forceinline__ uint32_t f6_chan_one(const Flow6& F, uint32_t hs) {
 // caller's list and for a changed iteration count).
 __global__ __launch_bounds__(kBlock) void k_flow6_links(Flow6 F, ConsLinks K, uint32_t n, const uint32_t* degb, uint32_t* rev, uint32_t rev_cap,
                                                         const uint32_t* rev_flag, StepCounts* sc, uint32_t n_owned, uint32_t* n_ghost_cons,
-                                                        const uint32_t* ext, uint32_t* ticket, uint32_t iters) {
+                                                        const uint32_t* ext, uint32_t* ticket, uint32_t iters, const float4* srec, float4* vsnap) {
+  {  // the velocities as Solver::solve is about to find them (k_solver_snapshot's work on the way: the solve follows this launch in the fused tick)
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    if (vsnap && t < n) { vsnap[2 * (size_t)t] = srec[4 * (size_t)t]; vsnap[2 * (size_t)t + 1] = srec[4 * (size_t)t + 1]; }
+  }
   f6_links_body(F, K, n, degb, rev, rev_cap, rev_flag, sc, n_owned, n_ghost_cons, ext);
   if (!ticket) return;
   __shared__ uint32_t s_last;
