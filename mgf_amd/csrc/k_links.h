@@ -143,7 +143,8 @@ struct Frontier {
 // Solver::solve cannot fail (solver.rs:72-78), a persistent launch can (it needs all its workgroups resident at once: a device shared
 // with another process, a CU mask): the velocities and accumulated impulses as they were before the launch, and back - the host then
 // runs the list with the launch-per-frontier executor, which needs no residency (solver_abort_fallback).
-__global__ __launch_bounds__(kBlock) void k_solver_snapshot(const float4* srec, uint32_t n, float4* vsnap, const CRec* cons, uint32_t C, float* nsnap) {
+__global__ __launch_bounds__(kBlock) void k_solver_snapshot(const float4* srec, uint32_t n, float4* vsnap, const CRec* cons, uint32_t C, float* nsnap, const uint32_t* guard) {
+  if (*guard) return;  // (a speculative tick behind one that failed or gave up: the copy in place is that tick's)
   const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   if (t < n) { vsnap[2 * (size_t)t] = srec[4 * (size_t)t]; vsnap[2 * (size_t)t + 1] = srec[4 * (size_t)t + 1]; }
   if (nsnap && t < C) nsnap[t] = cons[t].nimp;

@@ -382,7 +382,8 @@ __global__ __launch_bounds__(kBlock) void k_flow6_links(Flow6 F, ConsLinks K, ui
                                                         const uint32_t* ext, uint32_t* ticket, uint32_t iters, const float4* srec, float4* vsnap) {
   {  // the velocities as Solver::solve is about to find them (k_solver_snapshot's work on the way: the solve follows this launch in the fused tick)
     const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-    if (vsnap && t < n) { vsnap[2 * (size_t)t] = srec[4 * (size_t)t]; vsnap[2 * (size_t)t + 1] = srec[4 * (size_t)t + 1]; }
+    // (not in a tick that is being skipped - a speculative one behind a tick that failed or gave up: the copy in place is that tick's)
+    if (vsnap && t < n && !sc->fail) { vsnap[2 * (size_t)t] = srec[4 * (size_t)t]; vsnap[2 * (size_t)t + 1] = srec[4 * (size_t)t + 1]; }
   }
   f6_links_body(F, K, n, degb, rev, rev_cap, rev_flag, sc, n_owned, n_ghost_cons, ext);
   if (!ticket) return;
@@ -572,6 +573,9 @@ template <bool TRACE, int CL, bool NL, bool RL, bool QD>
 __global__ __launch_bounds__(kF6Threads) void k_solve_flow6(float4* srec, CRec* cons, Flow6 F, uint32_t iters, uint32_t epoch, uint32_t* abort_flag,
                                                             uint32_t spin_limit, uint64_t* trace, uint32_t C_trace) {
   if (*F.fail || *F.C_ptr == 0u) return;  // a limit was exceeded: the stand-by k_solve_flow launch behind this one does the work
+  // tests (option flow_spin_limit = 1): every other workgroup behaves as one that never became resident - the others wait for its messages,
+  // give up at their first look at the limit, and the world is left half-solved for solver_abort_fallback to put right
+  if (spin_limit == 1u && (blockIdx.x & 1u)) { if (threadIdx.x == 0) __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
   extern __shared__ float4 s_dyn[];
   uint64_t* tstat = TRACE ? trace + 2 * (size_t)iters * C_trace + kF6TraceWords * (size_t)blockIdx.x : nullptr;
   uint64_t trace_c0 = 0;

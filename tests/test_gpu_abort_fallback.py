@@ -1,6 +1,6 @@
 """Solver::solve has no failure mode (solver.rs:72-78): a persistent solver launch that gives up - not all of its workgroups resident: a
 device shared with another process, a CU mask - must not leave the world half-solved.  The launches are made to give
-up here by a tiny wait limit (option flow_spin_limit); the world restores the pre-launch velocities and impulses, solves the list with the
+up here (option flow_spin_limit = 1: every other workgroup returns at once, the others wait for it in vain); the world restores the pre-launch velocities and impulses, solves the list with the
 launch-per-frontier executor, counts it, and steps on bit-identical to a world that never gave up."""
 import numpy as np
 import pytest
@@ -31,7 +31,7 @@ def test_a_launch_that_gives_up_is_solved_again_bit_identically(ctx, driver):
     scene = scenes.sphere_pile(24, 12, 24)
     dt, iters = float(scene["dt"]), scene["iters"]
     ref, w = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
-    w.set_option("flow_spin_limit", 256)  # the first look at the wait limit gives up: any block that waits for a neighbour does
+    w.set_option("flow_spin_limit", 1)  # every other workgroup of a persistent launch plays "never became resident"; the others give up waiting for it
     ticks = 40
     if driver == "step_many":
         ref.step_many(dt, iters, ticks)
@@ -67,3 +67,21 @@ def test_a_world_told_to_share_the_device_uses_fewer_workgroups_and_steps_identi
     _same(w, ref, "flow_max_blocks")
     with pytest.raises(mgf_amd.MgfError):
         w.set_option("flow_max_blocks", -1)
+
+
+def test_a_tick_rerun_behind_a_speculative_one_keeps_its_terrain_contacts(ctx):
+    """mgf_world_step_many enqueues tick k + 1 before it has read tick k's counts; when tick k then fails a capacity check, tick k + 1 -
+    a no-op by its guard - has still cleared the per-tick counters, the terrain rows' counts of tick k's k_integrate among them.  The
+    re-run of tick k must list those rows again (it used to take them as still there: the pile lost its floor contacts for a tick)."""
+    scene = scenes.sphere_pile(24, 12, 24)
+    dt, iters = float(scene["dt"]), scene["iters"]
+    ref, w = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
+    ref.step_many(dt, iters, 10); w.step_many(dt, iters, 10)
+    for _ in range(3):
+        w.set_option("list_capacity", 1024)  # the next tick's lists do not fit: it is re-run, with a speculative tick behind it
+        r0 = w.counter("capacity_retries")
+        sa, sb = ref.step_many(dt, iters, 6), w.step_many(dt, iters, 6)
+        assert w.counter("capacity_retries") > r0
+        assert [int(x["n_terrain_constraints"]) for x in sa] == [int(x["n_terrain_constraints"]) for x in sb]
+        assert int(sa[0]["n_terrain_constraints"]) > 0
+    _same(w, ref, "re-run behind a speculative tick")
