@@ -323,7 +323,15 @@ __global__ __launch_bounds__(kBlock) void k_permute_ids(uint32_t n, const uint32
 
 __global__ __launch_bounds__(kBlock) void k_kind_mask(const float4* col1, const uint32_t* pcount, uint32_t base, uint32_t m, uint32_t* mask) {
   uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t < m) atomicOr(mask, (pcount && pcount[base + t]) ? 4u : (f2u(col1[base + t].w) == (uint32_t)KIND_SPHERE ? 1u : 2u));
+  if (t >= m) return;
+  const uint32_t pc = pcount ? pcount[base + t] : 0u;
+  atomicOr(mask, pc ? (pc > 2u ? 12u : 4u) : (f2u(col1[base + t].w) == (uint32_t)KIND_SPHERE ? 1u : 2u));
+}
+// the most parts any of m incoming records carries (a ghost record keeps the count in float 36, a migrant record in word 20): the
+// receiving world needs part arrays - and the *_parts kernels for that many slots - BEFORE the records are unpacked
+__global__ __launch_bounds__(kBlock) void k_record_max_parts(const float* rec, uint32_t m, uint32_t stride_floats, uint32_t at, uint32_t* out) {
+  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t < m) { const uint32_t pc = f2u(rec[(size_t)t * stride_floats + at]); if (pc) atomicMax(out, pc); }
 }
 __global__ __launch_bounds__(kBlock) void k_tags_set(float4* ctor, const uint32_t* tags, uint32_t n) {
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;

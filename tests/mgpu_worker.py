@@ -11,7 +11,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def run_rank(rank, n_ranks, total_tiles, dims, drift, ticks, fail_rank, fail_tick, uid_q, out_q, device=None, rccl_lib=None):
+def run_rank(rank, n_ranks, total_tiles, dims, drift, ticks, fail_rank, fail_tick, uid_q, out_q, device=None, rccl_lib=None, world_opts=None):
     """device: the rank's device (default: its own, `rank`); rccl_lib: the library the C-ABI binds instead of librccl (MGF_RCCL_LIB -
     the tests' stand-in that lets several ranks share one device, tests/fake_rccl)."""
     try:
@@ -34,6 +34,8 @@ def run_rank(rank, n_ranks, total_tiles, dims, drift, ticks, fail_rank, fail_tic
         for sc in tile_scenes:
             w = mgf_amd.World.from_scene(ctx, sc)
             w.set_tags(sc["tags"])
+            for key, val in (world_opts or {}).items():
+                w.set_option(key, val)
             worlds.append(w)
         T = mgf_amd.Tiles(ctx, worlds, [sc["x_range"] for sc in tile_scenes], first_tile=first, n_tiles_total=total_tiles)
         if rank == 0:
@@ -60,6 +62,7 @@ def run_rank(rank, n_ranks, total_tiles, dims, drift, ticks, fail_rank, fail_tic
                 st = w.state()
                 tiles_out.append(dict(tile=first + k, tags=w.tags(), migrated_in=T.migrated(k), **{f: st[f] for f in ("x", "q", "v", "omega", "delta")}))
         out_q.put(dict(rank=rank, ranks_seen=seen, failed_at=failed_at, error=err, tiles=tiles_out,
-                       bytes_out=T.counter("exchange_bytes_out"), bytes_in=T.counter("exchange_bytes_in")))
+                       bytes_out=T.counter("exchange_bytes_out"), bytes_in=T.counter("exchange_bytes_in"),
+                       flow6_runs=sum(w.counter("flow6_runs") for w in worlds), flow_blocks=[w.counter("flow5_blocks") for w in worlds]))
     except Exception:
         out_q.put(dict(rank=rank, crash=traceback.format_exc()))

@@ -179,3 +179,42 @@ def test_remove_bodies_rejects_bad_ids(ctx):
             gw.remove_bodies(d.data_ptr(), len(bad))
     assert len(gw) == 27
     gw.step(1.0 / 60.0, 4)
+
+
+@pytest.mark.parametrize("target", ["two_part_bodies", "ordinary_bodies"])
+def test_arrivals_of_more_parts_than_the_world_has_slots_for_raise_them(ctx, target):
+    """through the plain C API (no tile set announcing its neighbours' kinds, no option body_kinds) bodies of three and four
+    parts arrive in a world that holds two-part bodies - or ordinary ones only, with no part arrays at all.  Nothing may be dropped on
+    the way in: the world reads the records' part counts first and raises its slots."""
+    import torch
+    import mgf_amd
+    from mgf_amd import scenes
+    from mgf_amd.tiles import GHOST_FLOATS, MIGRANT_FLOATS
+    jacks = scenes.jack_field(3, 2, 3)
+    src = mgf_amd.World.from_scene(ctx, jacks)
+    dst = mgf_amd.World.from_scene(ctx, scenes.dumbbell_field(3, 2, 3) if target == "two_part_bodies" else scenes.sphere_pile(4, 3, 4))
+    dt, iters = float(jacks["dt"]), jacks["iters"]
+    src.step(dt, iters); dst.step(dt, iters)
+    assert src.counter("body_kinds") & 8 and not dst.counter("body_kinds") & 8
+    ids = np.array([0, 5, len(src) - 1], np.uint32)
+    d_ids = torch.from_numpy(ids.astype(np.int32)).cuda()
+    rec = torch.empty((len(ids), MIGRANT_FLOATS), dtype=torch.float32, device="cuda")
+    src.export_migrants(d_ids.data_ptr(), len(ids), rec.data_ptr())
+    n0 = len(dst)
+    dst.import_migrants(rec.data_ptr(), len(ids))
+    torch.cuda.synchronize()
+    assert len(dst) == n0 + len(ids) and dst.counter("body_kinds") & 12 == 12
+    back = torch.empty_like(rec)
+    d_new = torch.arange(n0, n0 + len(ids), dtype=torch.int32, device="cuda")
+    dst.export_migrants(d_new.data_ptr(), len(ids), back.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(rec.view(torch.int32), back.view(torch.int32))  # every part slot arrived
+    # ... and as ghosts: a fresh world of the same kind takes the jacks' ghost records
+    dst2 = mgf_amd.World.from_scene(ctx, scenes.dumbbell_field(3, 2, 3) if target == "two_part_bodies" else scenes.sphere_pile(4, 3, 4))
+    grec = torch.empty((len(ids), GHOST_FLOATS), dtype=torch.float32, device="cuda")
+    src.export_bodies(d_ids.data_ptr(), len(ids), grec.data_ptr())
+    dst2.begin_tick(dt)
+    dst2.import_ghosts(grec.data_ptr(), len(ids))
+    assert dst2.ghost_len() == len(ids) and dst2.counter("body_kinds") & 12 == 12
+    dst2.collide(dt)
+    dst.step(dt, iters)
