@@ -183,6 +183,23 @@ def _window_stats(per_tick, iters):
     return units, cons, launches, kms, phase
 
 
+def _roofline_tick(per_tick, iters, elapsed_s):
+    """The whole tick against the HBM roofline: SURVEY.md 8(d)'s algorithmic bytes of every phase, summed over the timed ticks, over the
+    wall time of the window - complete_motion + integrate 284 B per body; pair search 32 B per leaf record a query accepts by its fat
+    box (+ the query's own); sphere pair narrowphase 2 x 44 B in + 64 B out per emitted contact; ContactConstraint::new 332 B per
+    constraint; ContactConstraint::solve 288 B per call."""
+    n = sum(int(st["n_bodies"]) for st in per_tick)
+    c = sum(int(st["n_constraints"]) for st in per_tick)
+    ct = sum(int(st["n_terrain_constraints"]) for st in per_tick)
+    acc = sum(int(st["n_pair_candidates"]) for st in per_tick)
+    terms = {"integrate": 284 * n, "broadphase": 32 * (acc + n), "narrowphase": 152 * (c - ct), "setup": 332 * c, "solve": SOLVE_BYTES_PER_UNIT * c * iters}
+    total = sum(terms.values())
+    gbs = total / elapsed_s / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+            "bytes_per_tick": round(total / len(per_tick)), "bytes_per_tick_by_phase": {k: round(v / len(per_tick)) for k, v in terms.items()},
+            "note": "sum over the phases of SURVEY 8(d)'s algorithmic bytes / wall time of the timed window (the whole tick, not its best kernel)"}
+
+
 def _roofline(units, launches, kms, mode, what, window, workload="config2"):
     if not (kms > 0 and launches > 0):
         return None
@@ -248,11 +265,11 @@ def bench_single_world(args, ctx, mgf_amd, scenes, configure, mode):
         per_tick = w.step_many(dt, args.iters, args.steps)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        windows.append((el, _window_stats(per_tick, args.iters)))
+        windows.append((el, _window_stats(per_tick, args.iters), _roofline_tick(per_tick, args.iters, el)))
         total += el
         del w
     windows.sort(key=lambda x: x[0])
-    elapsed, (units, cons, _l, _k, _p) = windows[len(windows) // 2]
+    elapsed, (units, cons, _l, _k, _p), tick_roof = windows[len(windows) // 2]
     ru, rc, launches, kms, phase = _instrumented_replays(snap, configure, dt, args.iters, args.steps)
     assert (ru, rc) == (units, cons), "a replay of the window did other work than the window"
     window_name = f"ticks {args.warmup}..{args.warmup + args.steps} of the falling pile"
@@ -270,10 +287,12 @@ def bench_single_world(args, ctx, mgf_amd, scenes, configure, mode):
                                    "efficiency_vs_same_workload_on_one_gpu (`scaling` here follows the contract's default for a single-GPU line)"},
         "timed_region": {"windows": len(windows), "seconds": round(total, 3), "reported": "median window",
                          "ms_per_step_min": windows[0][0] * 1e3 / args.steps, "ms_per_step_max": windows[-1][0] * 1e3 / args.steps},
+        "lib_sha256": _lib_sha256(),
         "physics_steps_per_sec": args.steps / elapsed, "constraints_per_step": cons / args.steps,
         "solver_launches_per_step": launches / args.steps, "phase_ms_per_step_rank0": phase,
         "solve_phase_constraint_iters_per_sec_rank0": units / (phase["ms_solve"] * args.steps * 1e-3) if phase["ms_solve"] > 0 else None,
         "roofline": _roofline(units, launches, kms, mode, "all iterations of a tick", ("transient", args.warmup, args.steps)),
+        "roofline_tick": tick_roof,
         # GPU activity as the stream itself saw it (HIP events around every tick of the instrumented replay; no sampler needed)
         "gpu_event_ms": {"replayed_window": round(phase["ms_total"] * args.steps, 3), "solver_kernel_ms_replayed_window": round(kms, 3)},
         "instrumentation": INSTRUMENTATION_NOTE,
@@ -301,16 +320,17 @@ def bench_single_world(args, ctx, mgf_amd, scenes, configure, mode):
             t0 = time.perf_counter()
             per_tick = x.step_many(dt, args.iters, args.steps)
             torch.cuda.synchronize()
-            wins2.append((time.perf_counter() - t0, _window_stats(per_tick, args.iters)))
+            el2 = time.perf_counter() - t0
+            wins2.append((el2, _window_stats(per_tick, args.iters), _roofline_tick(per_tick, args.iters, el2)))
             total2 += wins2[-1][0]
             del x
         wins2.sort(key=lambda q: q[0])
-        el, (u2, c2, _l2, _k2, _p2) = wins2[len(wins2) // 2]
+        el, (u2, c2, _l2, _k2, _p2), tick_roof2 = wins2[len(wins2) // 2]
         _u, _c, l2, k2, p2 = _instrumented_replays(snap2, configure, dt, args.iters, args.steps)
         del snap2
         out["settled"] = {"window": f"ticks {args.warmup + args.steps + while_ticks}..{args.warmup + 2 * args.steps + while_ticks}", "value": u2 / el, "windows": len(wins2),
                           "ms_per_step": el * 1e3 / args.steps, "constraints_per_step": c2 / args.steps, "phase_ms_per_step": p2,
-                          "roofline": _roofline(u2, l2, k2, mode, "all iterations of a tick", ("settled", 400, args.steps))}
+                          "roofline": _roofline(u2, l2, k2, mode, "all iterations of a tick", ("settled", 400, args.steps)), "roofline_tick": tick_roof2}
     if not args.no_other_configs:
         # BASELINE configs 3 and 5 on the same GPU, one short window each (their own lines: python bench.py --scene config3 / config5)
         del world, snap
@@ -356,11 +376,11 @@ def bench_other_config(args, ctx, mgf_amd, scenes, configure, mode, kind, standa
         per_tick = w.step_many(dt, args.iters, steps)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        windows.append((el, _window_stats(per_tick, args.iters), per_tick[len(per_tick) - 1]))
+        windows.append((el, _window_stats(per_tick, args.iters), per_tick[len(per_tick) - 1], _roofline_tick(per_tick, args.iters, el)))
         total += el
         del w
     windows.sort(key=lambda x: x[0])
-    elapsed, (units, cons, _l, _k, _p), last = windows[len(windows) // 2]
+    elapsed, (units, cons, _l, _k, _p), last, tick_roof = windows[len(windows) // 2]
     _u, _c, launches, kms, phase = _instrumented_replays(snap, configure, dt, args.iters, steps)
     res = {
         "value": units / elapsed, "unit": "constraint-iters/s", "ms_per_step": elapsed * 1e3 / steps, "steps": steps, "warmup": warmup,
@@ -368,6 +388,7 @@ def bench_other_config(args, ctx, mgf_amd, scenes, configure, mode, kind, standa
         "accepted_pairs_last_tick": int(last["n_pair_candidates"]), "phase_ms_per_step": phase,
         "gpu_event_ms_replayed_window": round(phase["ms_total"] * steps, 3),
         "roofline": _roofline(units, launches, kms, mode, "all iterations of a tick", (kind, warmup, steps), workload=kind),
+        "roofline_tick": tick_roof,
         "store_resorts": world.counter("store_resorts"),
     }
     if not standalone:
@@ -691,9 +712,25 @@ def _keys(st):
     return [f[0] for f in st._fields_] if hasattr(st, "_fields_") else list(st.keys())
 
 
+_LIB_SHA = []
+
+
+def _lib_sha256():
+    """sha256 of the libmgf_hip.so this process loaded"""
+    if not _LIB_SHA:
+        import hashlib
+        from mgf_amd import _capi
+        try:
+            _LIB_SHA.append(hashlib.sha256(open(_capi.lib_path(), "rb").read()).hexdigest())
+        except OSError:
+            _LIB_SHA.append(None)
+    return _LIB_SHA[0]
+
+
 def _pmc_traffic(mode, window, workload="config2"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_*k_solve_flow*.json: one
-    record, or a list of records - one per window the passes were taken on), only for the window this run timed; else (None, why)."""
+    record, or a list of records - one per window the passes were taken on), only for the window this run timed AND only when the
+    passes ran the library this run loaded (the record's lib_sha256); else (None, why)."""
     prefix = "pmc_" if workload == "config2" else f"pmc_{workload}_"
     base = os.path.join(ROOT, "profiles", f"{prefix}k_solve_flow{mode}")
     recs, found = [], False
@@ -711,7 +748,11 @@ def _pmc_traffic(mode, window, workload="config2"):
             recs.append(r.get("window"))
             same_scene = r.get("window") and {r["window"][0], window[0]} <= {"transient", "settled"}
             if r.get("window") and (list(r["window"]) == list(window) or (same_scene and list(r["window"][1:]) == list(window[1:]))):
-                return r.get("hbm_bytes_per_launch"), f"{os.path.relpath(p, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same window)"
+                if r.get("lib_sha256") != _lib_sha256():
+                    return None, (f"{os.path.relpath(p, ROOT)} covers this window, but its passes ran another build of libmgf_hip.so "
+                                  f"(sha256 {str(r.get('lib_sha256'))[:12]}... there, {str(_lib_sha256())[:12]}... here): no traffic figure for this build")
+                return r.get("hbm_bytes_per_launch"), (f"{os.path.relpath(p, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same window, "
+                                                       f"same libmgf_hip.so: sha256 {_lib_sha256()[:12]}...)")
     if not found:
         return None, "no PMC pass committed for this kernel"
     return None, f"the committed PMC passes cover windows {recs}, this run {list(window)}"

@@ -43,6 +43,19 @@ def last_launches(path, counter, pattern, count):
     return sum(vals) * 1024.0 / len(vals), len(vals)
 
 
+def lib_sha256():
+    """sha256 of the libmgf_hip.so the passes ran (MGF_AMD_LIB, or the tree's): bench.py reports a record's traffic only while it is
+    running that very library - a kernel change without fresh passes must not keep printing the old bytes"""
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.environ.get("MGF_AMD_LIB") or os.path.join(root, "mgf_amd", "libmgf_hip.so")
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
 def main():
     if "--timed" in sys.argv:
         k = sys.argv.index("--timed")
@@ -53,7 +66,7 @@ def main():
         f, n = last_launches(sys.argv[1], "FETCH_SIZE", pattern, count)
         w, _ = last_launches(sys.argv[2], "WRITE_SIZE", pattern, count)
         d = dict(kernel=pattern, launches=n, fetch_bytes_per_launch_raw=f, write_bytes_per_launch=w, hbm_bytes_per_launch_raw=f + w,
-                 hbm_bytes_per_launch=2 * f + w)
+                 hbm_bytes_per_launch=2 * f + w, lib_sha256=lib_sha256())
         if window:
             d["window"] = window
             d["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --no-cpu-baseline --no-settled "
