@@ -96,9 +96,14 @@ struct NoTail {
   __device__ __forceinline__ void stage(float4*) const {}
   __device__ __forceinline__ void operator()(uint32_t, const Box&, const float4*, const Comp&, const V3&) const {}
 };
+// The counting sort's first half (k_morton_count's work) while the body's fat box is in registers: its Morton cell over the box of
+// the PREVIOUS tick's scene bounds (`grid`: the scene moves a fraction of a cell per tick; the quantisation clamps, and the pair search
+// finds every body whatever the box is - only how evenly the cells fill depends on it) and its arrival rank inside the cell.
+struct CellSort { const SceneBounds* grid; int shift; float min_frac; uint32_t* cell_of; uint32_t* rank; uint32_t* cell_cnt; };
+__device__ __forceinline__ uint32_t morton_cell_of(V3 c, const SceneBounds* sb, float min_frac, int shift);  // k_broadphase.h
 template <class Tail>
 __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, float dt, float fat_margin, int do_complete,
-                                                      int do_integrate, SceneBounds* sb, const uint32_t* guard, Tail tail, int* sb_part) {
+                                                      int do_integrate, SceneBounds* sb, const uint32_t* guard, Tail tail, int* sb_part, CellSort cs) {
   if (guard && *guard) return;  // a speculative tick behind a failed one (see k_reset_step)
   __shared__ float4 s_tail[Tail::kLdsWords];
   tail.stage(s_tail);
@@ -176,6 +181,11 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
       }
       blo[0] = bhi[0] = f_ord(fb.c.x); blo[1] = bhi[1] = f_ord(fb.c.y); blo[2] = bhi[2] = f_ord(fb.c.z);
       brm[0] = f_ord(fb.r.x); brm[1] = f_ord(fb.r.y); brm[2] = f_ord(fb.r.z);
+      if (cs.grid) {
+        const uint32_t cell = morton_cell_of(fb.c, cs.grid, cs.min_frac, cs.shift);
+        cs.cell_of[i] = cell;
+        cs.rank[i] = atomicAdd(&cs.cell_cnt[cell], 1u);
+      }
       tail(i, tb, s_tail, col, d);
     } else if (do_complete) {
       B.einfo[i] = mk4(x + xyz(dl), B.einfo[i].w);

@@ -49,6 +49,13 @@ __device__ __forceinline__ void grid_box(const SceneBounds* sb, float min_frac, 
     hi[k] = lo[k] + e;
   }
 }
+__device__ __forceinline__ uint32_t morton_cell_of(V3 c, const SceneBounds* sb, float min_frac, int shift) {
+  float glo[3], ghi[3];
+  grid_box(sb, min_frac, (uint32_t)(kMortonBits - shift), glo, ghi);
+  uint32_t code = 0;
+  for (int k = 0; k < 3; ++k) code |= expand10(morton_quant(at(c, k), glo[k], ghi[k])) << (2 - k);
+  return code >> shift;
+}
 // Counting sort of the bodies into Morton cells (a cell = one 2L-bit prefix of the 30-bit code): cell of every
 // body + its arrival rank inside the cell.  After a scan of the per-cell counts k_scatter_leaves places body i
 // at cell_lo[cell] + rank.  The order INSIDE a cell is arrival order (it varies from run to run); nothing
@@ -114,7 +121,10 @@ __global__ __launch_bounds__(kBlock) void k_zero_many(ZeroList z) {
 // The tick's read-back without a copy engine and without an event (round 3): the block of counts, bounds and flags is written straight
 // into the world's pinned host memory, then - behind a system-scope fence - the slot's sequence word; the host polls that word.
 // (hipMemcpyAsync + hipEventRecord put a blit kernel and a barrier packet between two ticks: 11.6 us of an idle GPU per tick.)
-__global__ __launch_bounds__(kBlock) void k_publish(const uint32_t* rb, uint32_t* pin, uint32_t words, uint32_t seq_word, uint32_t seq) {
+__global__ __launch_bounds__(kBlock) void k_publish(const uint32_t* rb, uint32_t* pin, uint32_t words, uint32_t seq_word, uint32_t seq, const uint32_t* sb_words = nullptr,
+                                                    uint32_t* grid_words = nullptr) {
+  // (the tick's scene bounds: the box the NEXT tick's k_integrate quantises its Morton cells over - CellSort)
+  if (grid_words && threadIdx.x < sizeof(SceneBounds) / 4) grid_words[threadIdx.x] = sb_words[threadIdx.x];
   for (uint32_t i = threadIdx.x; i < words; i += kBlock) pin[i] = rb[i];
   __threadfence_system();
   __syncthreads();
@@ -222,7 +232,8 @@ __device__ __forceinline__ void caps_constraints(const ScanEpilogue& E, uint32_t
 constexpr int kScanBlock = 256, kScanRounds = MGF_SCAN_ROUNDS, kScanTile = kScanBlock * 4 * kScanRounds;  // 4096 items per tile
 constexpr unsigned long long kScanAgg = 1ull << 62, kScanInc = 2ull << 62, kScanFlag = 3ull << 62;
 struct ScanJob { const uint32_t* in[2]; uint32_t* out[2]; uint32_t n; unsigned long long* status; uint32_t* ticket; ScanEpilogue epi;
-                 const uint32_t* add; };  // add (W = 1, or null): a second array of the same length, summed into the first item by item
+                 const uint32_t* add;   // add (W = 1, or null): a second array of the same length, summed into the first item by item
+                 const int* sb_part; SceneBounds* sb_out; };  // optional side job of the last workgroup's idle fourth wave: fold k_integrate's partial scene bounds (k_morton_count did)
 template <int W>
 __global__ __launch_bounds__(kScanBlock) void k_scan(ScanJob J) {
   __shared__ uint32_t s_tile;
@@ -230,6 +241,21 @@ __global__ __launch_bounds__(kScanBlock) void k_scan(ScanJob J) {
   __shared__ uint32_t s_prev[W];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   if (t == 0) s_tile = atomicAdd(J.ticket, 1u);
+  if (J.sb_part && blockIdx.x == gridDim.x - 1 && wv == kScanBlock / 64 - 1) {  // (one wave of the launch, beside its first loads: a partial record per lane)
+    static_assert(kBoundSlots == 64, "a lane per partial record");
+    int v[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] = J.sb_part[(size_t)lane * kBoundSlotInts + k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) { const int u = __shfl_xor(v[k], o); v[k] = k < 3 ? min(v[k], u) : max(v[k], u); }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { J.sb_out->lo[k] = v[k]; J.sb_out->hi[k] = v[3 + k]; J.sb_out->rmax[k] = v[6 + k]; }
+    }
+  }
   __syncthreads();
   const uint32_t tile = s_tile;
   const uint32_t i0 = tile * (uint32_t)kScanTile;
@@ -386,10 +412,12 @@ __device__ __forceinline__ void box_min_max(V3& lo, V3& hi, V3 l, V3 h) {
 __device__ __forceinline__ float pair_query_pad(const V3& c, const V3& r, float pad_abs) {
   return pad_abs + 1e-5f * (fabs_rs(c.x) + fabs_rs(c.y) + fabs_rs(c.z) + r.x + r.y + r.z);
 }
+// (`box`: the bounds the cells were quantised over - this tick's, or the previous tick's when k_integrate did the counting sort's first
+// half; the half width rmax is always this tick's)
 __device__ __forceinline__ void pair_query_region(const V3& qc, const V3& qr, float pad, const SceneBounds* sb, const uint32_t* nb, uint32_t* ca, uint32_t* d,
-                                                  float min_frac) {
+                                                  float min_frac, const SceneBounds* box = nullptr) {
   float glo[3], ghi[3];
-  grid_box(sb, min_frac, nb[0] + nb[1] + nb[2], glo, ghi);
+  grid_box(box ? box : sb, min_frac, nb[0] + nb[1] + nb[2], glo, ghi);
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     float lo = glo[k], hi = ghi[k], rm = ord_f(sb->rmax[k]);
@@ -402,7 +430,7 @@ __device__ __forceinline__ void pair_query_region(const V3& qc, const V3& qr, fl
 // Bodies -> leaf records in cell order (counting sort, second half).
 __device__ __forceinline__ void scatter_leaf(uint32_t body, const Lbvh& T, const float4* fb_c, const float4* fb_r, const uint32_t* cell_of,
                                              const uint32_t* rank, uint32_t* brank, const float4* col0, const float4* delta, const float4* tb_c,
-                                             const float4* tb_r, const SceneBounds* sb, float pad_abs, float min_frac) {
+                                             const float4* tb_r, const SceneBounds* sb, float pad_abs, float min_frac, const SceneBounds* box = nullptr) {
   if (body >= T.n) return;
   uint32_t p = T.cell_lo[cell_of[body]] + rank[body];
   LeafRec lr; lr.c = mk4(xyz(fb_c[body]), u2f(body)); lr.r = mk4(xyz(fb_r[body]), u2f(order_id(T.ext, body)));
@@ -413,7 +441,7 @@ __device__ __forceinline__ void scatter_leaf(uint32_t body, const Lbvh& T, const
     const uint32_t P = 2u * T.levels;
     const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};
     uint32_t ca[3], d[3];
-    pair_query_region(xyz(c), xyz(r), pair_query_pad(xyz(c), xyz(r), pad_abs), sb, nb, ca, d, min_frac);
+    pair_query_region(xyz(c), xyz(r), pair_query_pad(xyz(c), xyz(r), pad_abs), sb, nb, ca, d, min_frac, box);
     T.ltb[2 * p] = mk4(xyz(c), u2f(ca[0] | (ca[1] << 10) | (ca[2] << 20)));  // (ca < 1024, d <= 1024 - ca)
     T.ltb[2 * p + 1] = mk4(xyz(r), u2f(min(d[0], 1023u) | (min(d[1], 1023u) << 10) | (min(d[2], 1023u) << 20)));  // (1023 cells across is "too wide" like 1024)
   }
@@ -422,8 +450,8 @@ __device__ __forceinline__ void scatter_leaf(uint32_t body, const Lbvh& T, const
 }
 __global__ __launch_bounds__(kBlock) void k_scatter_leaves(Lbvh T, const float4* fb_c, const float4* fb_r, const uint32_t* cell_of,
                                                            const uint32_t* rank, uint32_t* brank, const float4* col0, const float4* delta, const float4* tb_c,
-                                                           const float4* tb_r, const SceneBounds* sb, float pad_abs, float min_frac) {
-  scatter_leaf(blockIdx.x * kBlock + threadIdx.x, T, fb_c, fb_r, cell_of, rank, brank, col0, delta, tb_c, tb_r, sb, pad_abs, min_frac);
+                                                           const float4* tb_r, const SceneBounds* sb, float pad_abs, float min_frac, const SceneBounds* box = nullptr) {
+  scatter_leaf(blockIdx.x * kBlock + threadIdx.x, T, fb_c, fb_r, cell_of, rank, brank, col0, delta, tb_c, tb_r, sb, pad_abs, min_frac, box);
 }
 
 // One block per 256 consecutive cells: the 4 internal levels above them.
