@@ -282,6 +282,39 @@ __device__ inline bool tri_msphere(const Triangle& tri, const Sphere& s, V3 v, C
   return false;
 }
 
+// The same test by FOUR LANES that hold the same triangle, sphere and motion (k_terrain_contacts): the plane contact and the containment
+// test by all of them, then lanes 0..2 an edge's ray-capsule test each instead of one lane running the three in a row (a sphere
+// resting on the floor's other triangle goes all the way through them: ~5 us of one lane's arithmetic); the loop's choice - the
+// smallest t <= 1, the earliest edge among equals - is replayed from the lanes' results.  Same operations on the same values: same bits.
+// `e` = the lane's index in its group of four, `base` = the wave lane of the group's lane 0.
+__device__ inline bool tri_msphere_x4(const Triangle& tri, const Sphere& s, V3 v, Contact* out, int e, int base) {
+  Plane p = plane_from(tri.a, tri.b, tri.c);
+  Contact contact;
+  if (!plane_msphere(p, s, v, &contact)) return false;
+  if (tri_contains(tri, contact.a)) { *out = contact; return true; }
+  if (mag2(v) == 0.0f) return false;
+  // (every lane of the group is here or none: the branches above depend on what the four share)
+  bool ok = false;
+  float it = kInf;
+  V3 cp = mk3(0.0f, 0.0f, 0.0f);
+  if (e < 3) {
+    const V3 v1 = e == 0 ? tri.a : (e == 1 ? tri.b : tri.c), v2 = e == 0 ? tri.b : (e == 1 ? tri.c : tri.a);
+    V3 ip;
+    if (ray_capsule(s.c, v, mkcap(v1, v2 - v1, s.r), &ip, &it)) { ok = it <= 1.0f; if (ok) cp = seg_closest(v1, v2, ip); }
+  }
+  float first_t = kInf;
+  V3 tri_p = mk3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const bool ok_k = __shfl(ok ? 1 : 0, base + k) != 0;
+    const float it_k = __shfl(it, base + k);
+    const V3 cp_k = mk3(__shfl(cp.x, base + k), __shfl(cp.y, base + k), __shfl(cp.z, base + k));
+    if (ok_k && it_k < first_t) { first_t = it_k; tri_p = cp_k; }
+  }
+  if (first_t != kInf) { *out = mkc(tri_p, tri_p, p.n, first_t); return true; }
+  return false;
+}
+
 // seg_2d_intersect :667-688 (only t is used by the callers)
 HD float area2d(V2 a, V2 b, V2 c) { return (a.x - c.x) * (b.y - c.y) - (a.y - c.y) * (b.x - c.x); }
 HD bool seg2d(V2 a, V2 b, V2 c, V2 d, float* t) {

@@ -94,7 +94,9 @@ __device__ __forceinline__ void bounds_block_accumulate(const int blo[3], const 
 struct NoTail {
   static constexpr int kLdsWords = 1;
   __device__ __forceinline__ void stage(float4*) const {}
-  __device__ __forceinline__ void operator()(uint32_t, const Box&, const float4*, const Comp&, const V3&) const {}
+  static constexpr bool kNear = false;
+  float4* near_list = nullptr; uint32_t* near_cnt = nullptr;
+  __device__ __forceinline__ void operator()(uint32_t, const Box&, const float4*, uint32_t&, unsigned long long&) const {}
 };
 // The counting sort's first half (k_morton_count's work) while the body's fat box is in registers: its Morton cell over the box of
 // the PREVIOUS tick's scene bounds (`grid`: the scene moves a fraction of a cell per tick; the quantisation clamps, and the pair search
@@ -106,8 +108,13 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
                                                       int do_integrate, SceneBounds* sb, const uint32_t* guard, Tail tail, int* sb_part, CellSort cs) {
   if (guard && *guard) return;  // a speculative tick behind a failed one (see k_reset_step)
   __shared__ float4 s_tail[Tail::kLdsWords];
+  __shared__ uint32_t s_near[2];  // bodies of this block that list a terrain face, where their records start in the tick's list
   tail.stage(s_tail);
+  if (Tail::kNear && threadIdx.x == 0) s_near[0] = 0u;
   if (Tail::kLdsWords > 1) __syncthreads();
+  float4 near0 = make_float4(0, 0, 0, 0), near1 = near0;
+  uint32_t near_nt = 0;
+  unsigned long long near_pk = 0ull;
   __shared__ float4 s_rec[kBlock / 64][8 * 65];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -186,7 +193,8 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
         cs.cell_of[i] = cell;
         cs.rank[i] = atomicAdd(&cs.cell_cnt[cell], 1u);
       }
-      tail(i, tb, s_tail, col, d);
+      tail(i, tb, s_tail, near_nt, near_pk);
+      if (Tail::kNear && near_nt) { near0 = mk4(col.p, col.r); near1 = mk4(d, u2f(i)); }
     } else if (do_complete) {
       B.einfo[i] = mk4(x + xyz(dl), B.einfo[i].w);
     }
@@ -205,9 +213,23 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
     }
   }
   if (!do_integrate || sb == nullptr) return;
+  // the block's records for k_terrain_contacts (TerrainRowsTail): ranks through LDS, ONE atomic per block on the list's length (a wave
+  // each - thousands of them on one word once the pile touches the walls - cost this kernel 9 us)
+  uint32_t near_rank = 0;
+  if (Tail::kNear && near_nt) near_rank = atomicAdd(&s_near[0], 1u);
   // refit count: one atomic per block
   int nref = __syncthreads_count(refit ? 1 : 0);
   if (threadIdx.x == 0 && nref) atomicAdd(&sb->n_refits, (uint32_t)nref);
+  if (Tail::kNear && tail.near_list) {
+    if (threadIdx.x == 0 && s_near[0]) s_near[1] = atomicAdd(tail.near_cnt, s_near[0]);
+    __syncthreads();
+    if (near_nt) {
+      const size_t at = (size_t)s_near[1] + near_rank;
+      tail.near_list[3 * at] = near0;
+      tail.near_list[3 * at + 1] = near1;
+      tail.near_list[3 * at + 2] = make_float4(u2f(near_nt), u2f((uint32_t)near_pk), u2f((uint32_t)(near_pk >> 32)), 0.0f);
+    }
+  }
   if (!sb_part) return;
   bounds_block_accumulate(blo, bhi, brm, sb_part);
 }

@@ -741,7 +741,9 @@ struct TerrainRowsTail {
     const float4* src = reinterpret_cast<const float4*>(M.nodes);
     for (uint32_t e = threadIdx.x; e < 2u * M.n_nodes; e += blockDim.x) s[e] = src[e];
   }
-  __device__ __forceinline__ void operator()(uint32_t i, const Box& tb, const float4* s, const Comp& col, const V3& d) const {
+  static constexpr bool kNear = true;
+  // -> near_nt = the faces listed (0: none), near_pk = the first eight of them as bytes (~0: read the row); k_integrate appends the record
+  __device__ __forceinline__ void operator()(uint32_t i, const Box& tb, const float4* s, uint32_t& near_nt, unsigned long long& near_pk) const {
     Box q; q.c = tb.c + -mk3(M.x[0], M.x[1], M.x[2]); q.r = tb.r;
     uint32_t* row = rows_t + (size_t)i * cap_row;
     uint32_t nt = 0, big = 0;
@@ -757,19 +759,8 @@ struct TerrainRowsTail {
     else terrain_traverse(M, q, emit);
     t_cnt[i] = nt;
     if (nt > cap) atomicOr(overflow, 2u);
-    if (near_list) {  // (one atomic per wave that has such a body)
-      const unsigned long long m = __ballot(nt != 0u);
-      if (nt) {
-        const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
-        uint32_t at = 0;
-        if (lane == leader) at = atomicAdd(near_cnt, (uint32_t)__popcll(m));
-        at = __shfl(at, leader) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (big > 255u || nt > 8u) pk = ~0ull;
-        near_list[3 * (size_t)at] = mk4(col.p, col.r);
-        near_list[3 * (size_t)at + 1] = mk4(d, u2f(i));
-        near_list[3 * (size_t)at + 2] = make_float4(u2f(nt), u2f((uint32_t)pk), u2f((uint32_t)(pk >> 32)), 0.0f);
-      }
-    }
+    if (big > 255u || nt > 8u) pk = ~0ull;
+    near_nt = near_list ? nt : 0u; near_pk = pk;
   }
 };
 

@@ -792,25 +792,28 @@ __device__ __forceinline__ void terrain_contacts_job(const TerrainContacts& A, u
       Comp Ca; Ca.p = xyz(r0); Ca.r = r0.w; Ca.d = mk3(0.0f, 0.0f, 0.0f); Ca.kind = KIND_SPHERE;
       const uint32_t* rt = rows_t + (size_t)i * cap_row_t;
       const bool bytes = pk0 != 0xFFFFFFFFu || pk1 != 0xFFFFFFFFu;  // (both all-ones: faces above 255 or more than eight - read the row)
-      for (uint32_t a = sub; a < nt; a += (uint32_t)kTcLanes) {
+      static_assert(kTcLanes == 4, "tri_msphere_x4: a face by four lanes");
+      for (uint32_t a = 0; a < nt; ++a) {  // the body's faces one after the other, each by the group's four lanes together
         const uint32_t f = bytes ? ((a < 4u ? pk0 >> (8u * a) : pk1 >> (8u * (a - 4u))) & 255u) : rt[a];
         const uint4 fi = staged ? s_face[f] : M.faces[f];
         Triangle tri = staged ? mkt(xyz(s_vert[fi.x]) + mx, xyz(s_vert[fi.y]) + mx, xyz(s_vert[fi.z]) + mx)
                               : mkt(xyz(M.verts[fi.x]) + mx, xyz(M.verts[fi.y]) + mx, xyz(M.verts[fi.z]) + mx);  // mesh.rs:122-126
-        LocalContact lc[2];
-        const int nc = comp_tri_local(Ca, vA, tri, mx, lc);
-        if (tp + a < cap_t) {
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            NContact o; o.la = mk4(lc[k].la, lc[k].g.t); o.lb = mk4(lc[k].lb, k == 0 ? u2f((uint32_t)nc) : 0.0f); o.n = mk4(lc[k].g.n, 0.0f);  // Manifold::from(lc) manifold.rs:120-128
-            if (k < nc || k == 0) t_out[2 * (size_t)(tp + a) + k] = o;
+        // comp_tri_local for a sphere, the triangle test by the four lanes (tri_msphere_x4)
+        Contact raw = mkc(mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), 0.0f);
+        const uint32_t nc = tri_msphere_x4(tri, mks(Ca.p, Ca.r), vA, &raw, (int)sub, lane & ~(kTcLanes - 1)) ? 1u : 0u;
+        if (sub == 0u && tp + a < cap_t) {
+          NContact o;
+          o.la = make_float4(0, 0, 0, 0); o.lb = make_float4(0, 0, 0, u2f(0u)); o.n = make_float4(0, 0, 0, 0);
+          if (nc) {  // Mesh::contacts callback value: a on the mesh, b on the body, n = face normal; Manifold::from(lc) manifold.rs:120-128
+            const V3 a_c = comp_center(Ca) + vA * raw.t;
+            const Contact g = neg(raw);
+            o.la = mk4(raw.b + -a_c, g.t); o.lb = mk4(raw.a + -mx, u2f(1u)); o.n = mk4(g.n, 0.0f);
           }
+          t_out[2 * (size_t)(tp + a)] = o;
         }
-        run += (uint32_t)nc;
+        run += nc;
       }
     }
-#pragma unroll
-    for (int o = 1; o < kTcLanes; o <<= 1) run += __shfl_xor(run, o);
     if (e < L && sub == 0u) {
       tcn[i] = run;  // the body's terrain constraints come first in its range (k_chain_rows)
       tpos[i] = tp;
