@@ -418,6 +418,12 @@ MGF_API int64_t mgf_tiles_counter(const mgf_tiles* t, const char* key);
  * the Morton cells are laid over it: cells stay near-cubic in an x-slab tile);
  * "flow6_fcap", "flow6_const_lds", "flow6_poll_waves", "flow6_test_cap" (mode 6: foreign-body slots, constants in LDS,
  * polling waves, a test limit that forces the stand-by kernel); "two_pass_candidates" [0]; "broadphase_tree" [0]; "terrain_tree" [0]; "no_fused_narrowphase" [0] (a world of spheres only runs the sphere-sphere test inside the grid broadphase and lists contacts only; 1 = list every accepted partner); "stream_ordered" [0]; "phase_timing" [0] (HIP events at the tick's phase boundaries: mgf_step_stats::ms_*), "time_solver_kernels" [0] (events around the solver launches: ms_solver_kernels); "spin_wait" [1] (the tick's one wait polls an event instead of blocking); "pipeline" [1] (mgf_world_step_many enqueues the next tick before it waits for this one); "cell_fill" [16] (bodies per Morton cell, in eighths, beyond which the broadphase grid gets another level); "no_fused_terrain_rows" [0], "no_fused_scene_bounds" [0] (mgf_world_step and mgf_world_begin_tick list the terrain faces of a body and gather the scene bounds inside the integration kernel; 1 = always the separate kernels); "list_capacity";
+ * "fused_contacts" [1] (a world of spheres over a small mesh: rows -> constraint records without candidate lists; 0 = the candidate-list kernels);
+ * "cells_in_integrate" [1] (the fused tick's k_integrate works out the bodies' Morton cells over the previous tick's scene bounds);
+ * "flow_max_blocks" [0] (the persistent solver launches of this world take at most this many workgroups - one per CU; 0 = all CUs.  Processes that
+ * share a device each take a part, so that their launches are resident together); "flow_spin_limit" [0] (tests: 1 = every other workgroup of a
+ * persistent launch returns at once and the launch gives up - the world then restores its pre-launch velocities and solves the list with the
+ * launch-per-frontier executor, counter "solver_abort_fallbacks");
  * "flow_blocks_per_cu"; "flow_sleep"; "flow_trace"; "debug_bvh"; "flow5_block", "flow5_slow_x2", "flow5_poller", "flow5_test_cap" (block-local solver: block size, wave split, polling wave, a test limit that forces the stand-by kernel); "body_kinds" (OR-in, bit0 sphere, bit1 capsule): the
  * kinds this world's ghosts may have - a tile whose own bodies are all of one kind must be told when a neighbour's are
  * not, because the narrowphase dispatch is chosen on the host (the tiles driver exchanges the masks with the counts). */
@@ -425,7 +431,9 @@ MGF_API mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_t v
 /* Diagnostics: how often a slow path was taken.  name in {"row_overflows", "capacity_retries", "flow5_fallbacks",
  * "grid_too_wide", "flow5_blocks", "flow5_class0|1|2", "terrain_grid", "terrain_row_capacity", "rev_row_capacity", "body_kinds",
  * "flow6_fallbacks", "flow6_fail_reason", "flow6_max_slots", "flow6_max_foreign", "pair_brick_slow_queries", "pair_brick_off_ticks",
- * "max_fat_half_extent_x_milli"}. */
+ * "max_fat_half_extent_x_milli", "solver_abort_fallbacks" (Solver::solve calls whose persistent launch gave up and that were solved again from
+ * the pre-launch state: Solver::solve has no failure mode, solver.rs:72-78), "device_ptrs_out" (1 while mgf_world_device_ptr's pointers pin
+ * the store to the caller's order)}. */
 MGF_API mgf_status mgf_world_counter(const mgf_world* w, const char* name, int64_t* out);
 /* Raw device pointers of resident state for zero-copy exchange (multi-GPU halo): name in
  * {"x","q","solver_rec","delta"} (the pub fields `x`, `q` of RigidBodyVec physics.rs:142-154 and what ConstrainedSet::get returns,

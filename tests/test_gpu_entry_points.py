@@ -151,13 +151,25 @@ def test_device_pointers_keep_their_meaning_across_ticks_of_a_large_world(ctx):
         assert hip.hipMemcpy(hs.ctypes.data, C.c_void_p(psr), 64 * n, 2) == 0
         sb = b.state()
         assert bits_equal(hx[:, :3], sb["x"]) and bits_equal(hs[:, :3], sb["v"]) and bits_equal(hs[:, 3:6], sb["omega"])
+    assert a.counter("device_ptrs_out") == 1
     a.release_device_ptrs()
+    assert a.counter("device_ptrs_out") == 0
     a.step(dt, 10); b.step(dt, 10)
     a.step(dt, 10); b.step(dt, 10)
     assert a.counter("store_permuted") == 1
     sa, sb = a.state(), b.state()
     for f in ("x", "q", "v", "omega"):
         assert bits_equal(sa[f], sb[f])
+    # a failed look-up pins nothing; pointers die with the arrays - adding bodies gives the re-sort back without a release
+    with pytest.raises(mgf_amd.MgfError):
+        a.device_ptr("no_such_array")
+    assert a.counter("device_ptrs_out") == 0
+    a.device_ptr("q")
+    assert a.counter("device_ptrs_out") == 1
+    extra = scenes.sphere_pile(2, 1, 2)
+    extra["comps"]["p"][:, 1] += 40.0
+    a.add_bodies(extra["comps"], extra["mass"], extra["restitution"], extra["friction"], extra["force"])
+    assert a.counter("device_ptrs_out") == 0
 
 
 def test_device_pointers_and_ghost_len(ctx):
