@@ -6,7 +6,7 @@
 #   Usage: bash tools/collect_profiles.sh <tag>   -> gpurun_out/<tag>_*      then: python tools/publish_profiles.py <tag>
 #   (WINDOWS="driver transient" NO_TILES=1 ONLY_BENCH_LINES= ... : a subset of the windows; the final bench lines are always taken)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 B="python $R/bench.py --no-cpu-baseline --no-settled --no-order-check --no-other-configs --min-seconds 0"
