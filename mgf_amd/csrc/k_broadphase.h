@@ -101,6 +101,18 @@ __global__ __launch_bounds__(kBlock) void k_morton_count(const float4* fb_c, uin
 // Zero several small arrays with one launch (instead of one fill kernel each).
 constexpr int kZeroSlots = 20;
 struct ZeroList { uint32_t* p[kZeroSlots]; uint32_t words[kZeroSlots]; SceneBounds* sb; const int* sb_part; };
+// one array of the list, by the whole grid: 16 bytes per lane where the array allows (the per-body arrays are a megabyte each)
+__device__ __forceinline__ void zero_words(uint32_t* p, uint32_t words) {
+  if (!p || !words) return;
+  const uint32_t head = min(words, (uint32_t)((16u - ((uintptr_t)p & 15u)) & 15u) / 4u);  // words in front of the first 16-byte boundary
+  const uint32_t quads = (words - head) / 4u;
+  uint4* q = reinterpret_cast<uint4*>(p + head);
+  for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < quads; e += gridDim.x * kBlock) q[e] = make_uint4(0u, 0u, 0u, 0u);
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t < head) p[t] = 0u;
+  const uint32_t tail0 = head + 4u * quads;
+  if (t < words - tail0) p[tail0 + t] = 0u;
+}
 __global__ __launch_bounds__(kBlock) void k_zero_many(ZeroList z) {
   if (z.sb_part && blockIdx.x == 0 && threadIdx.x < 9) {  // fold k_integrate's partial scene bounds (see there)
     const int k = threadIdx.x;
@@ -108,11 +120,7 @@ __global__ __launch_bounds__(kBlock) void k_zero_many(ZeroList z) {
     for (int a = 1; a < kBoundSlots; ++a) { int u = z.sb_part[(size_t)a * kBoundSlotInts + k]; v = k < 3 ? min(v, u) : max(v, u); }
     if (k < 3) z.sb->lo[k] = v; else if (k < 6) z.sb->hi[k - 3] = v; else z.sb->rmax[k - 6] = v;
   }
-  for (int a = 0; a < kZeroSlots; ++a) {
-    uint32_t* p = z.p[a];
-    if (!p) continue;
-    for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < z.words[a]; e += gridDim.x * kBlock) p[e] = 0u;
-  }
+  for (int a = 0; a < kZeroSlots; ++a) zero_words(z.p[a], z.words[a]);
 }
 
 // The fused tick's first launch: k_reset_step and k_zero_many in one, AHEAD of k_integrate (round 3: a launch less per tick).
@@ -151,11 +159,7 @@ __global__ __launch_bounds__(kBlock) void k_tick_clear(ZeroList z, SceneBounds* 
       err[0] = 0; err[1] = 0; err[8] = 0;
     }
   }
-  for (int a = 0; a < kZeroSlots; ++a) {
-    uint32_t* p = z.p[a];
-    if (!p) continue;
-    for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < z.words[a]; e += gridDim.x * kBlock) p[e] = 0u;
-  }
+  for (int a = 0; a < kZeroSlots; ++a) zero_words(z.p[a], z.words[a]);
 }
 
 struct StepCounts {
@@ -240,7 +244,9 @@ __global__ __launch_bounds__(kScanBlock) void k_scan(ScanJob J) {
   __shared__ uint32_t s_wave[W][kScanBlock / 64];
   __shared__ uint32_t s_prev[W];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  if (t == 0) s_tile = atomicAdd(J.ticket, 1u);
+  // (few tiles - all of the launch's workgroups resident at once, whatever the order they start in: the block's own index; a launch of more
+  // than a thousand takes tickets, so that a tile's predecessors are always running)
+  if (t == 0) s_tile = gridDim.x <= 1024u ? blockIdx.x : atomicAdd(J.ticket, 1u);
   if (J.sb_part && blockIdx.x == gridDim.x - 1 && wv == kScanBlock / 64 - 1) {  // (one wave of the launch, beside its first loads: a partial record per lane)
     static_assert(kBoundSlots == 64, "a lane per partial record");
     int v[9];
@@ -1073,8 +1079,13 @@ __device__ __forceinline__ uint32_t compact10(uint32_t v) {  // inverse of expan
 }
 constexpr int kBrickLanes = 8;                                  // lanes per query
 constexpr int kBrickQueries = kCoopBlock / kBrickLanes;         // queries per pass of a block
-constexpr uint32_t kBrickCap = 672;                             // leaf records staged per brick (64 B each; 32 B when the sphere test is not fused):
-                                                                // three blocks per CU (the kernel takes the number as an argument)
+// Records in the LDS copy are PADDED by one in sixteen (r05): the eight lanes of a query read the heads of eight neighbouring z-columns -
+// ~4 records, 64 bytes, apart - so lanes k and k + 4 met in the same banks; with the pad the second four are a record further on.
+// k_pair_brick 72.9 -> 65.4 us on the falling pile (one in eight: 64.4 with fewer records staged; one in 32: 67.0).  The physical length
+// stays 672 (three blocks per CU: a record more per block and the CU holds two - 83 us), so a brick stages 632 records.
+constexpr uint32_t kBrickCap = 632;                             // leaf records staged per brick (64 B each; 32 B when the sphere test is not fused)
+__host__ __device__ constexpr uint32_t brick_phys(uint32_t p) { return p + (p >> 4); }
+__host__ __device__ constexpr uint32_t brick_phys_cap(uint32_t cap) { return brick_phys(cap) + 1u; }
 struct BrickSrcLds {   // the staged box: records in x-major cell order, start[] = first record of every cell (+ end)
   const float4 *rc, *rr, *cc, *cd;
   const uint16_t* start;
@@ -1084,8 +1095,8 @@ struct BrickSrcLds {   // the staged box: records in x-major cell order, start[]
     const uint32_t c = ((uint32_t)((int)cx - hb[0]) << 6) | ((uint32_t)((int)cy - hb[1]) << 3) | (uint32_t)((int)cz - hb[2]);
     p0 = start[c]; p1 = start[c + dz];
   }
-  __device__ __forceinline__ void leaf(uint32_t p, float4& c, float4& r) const { c = rc[p]; r = rr[p]; }
-  __device__ __forceinline__ void col(uint32_t p, float4& c0, float4& d0, uint32_t& j) const { c0 = cc[p]; d0 = cd[p]; j = f2u(rc[p].w); }
+  __device__ __forceinline__ void leaf(uint32_t p, float4& c, float4& r) const { c = rc[brick_phys(p)]; r = rr[brick_phys(p)]; }
+  __device__ __forceinline__ void col(uint32_t p, float4& c0, float4& d0, uint32_t& j) const { c0 = cc[brick_phys(p)]; d0 = cd[brick_phys(p)]; j = f2u(rc[brick_phys(p)].w); }
 };
 struct BrickSrcGlobal {  // the sorted arrays themselves, one cell at a time
   Lbvh T;
@@ -1188,7 +1199,8 @@ __global__ __launch_bounds__(kCoopBlock) __attribute__((amdgpu_waves_per_eu(6, 8
   const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};  // prefix bits per axis (x is the most significant)
   const int shift = kMortonBits - (int)P;
   BrickSrcLds L;
-  L.rc = s_dyn; L.rr = s_dyn + cap; L.cc = s_dyn + 2 * cap; L.cd = s_dyn + 3 * cap; L.start = s_start;
+  const uint32_t capp = brick_phys_cap(cap);  // (the arrays' physical length)
+  L.rc = s_dyn; L.rr = s_dyn + capp; L.cc = s_dyn + 2 * capp; L.cd = s_dyn + 3 * capp; L.start = s_start;
   {
     const uint32_t code = (brick * 64u) << shift;
     L.hb[0] = (int)(compact10(code >> 2) >> (10u - nb[0])) - 2;
@@ -1235,11 +1247,12 @@ __global__ __launch_bounds__(kCoopBlock) __attribute__((amdgpu_waves_per_eu(6, 8
   if (kq < q1) { qc = T.ltb[2 * kq]; qr = T.ltb[2 * kq + 1]; if (SPHERES) { qa = T.lcol[2 * kq]; qv = T.lcol[2 * kq + 1]; } qi = T.sidx[kq]; qreg = make_uint2(f2u(qc.w), f2u(qr.w)); }
   if ((t & (uint32_t)(kBrickLanes - 1)) == 0u) s_qo[t / (uint32_t)kBrickLanes] = kq < q1 ? f2u(T.leaves[kq].r.w) : 0u;
   if (staged) {
-    float4* rc = s_dyn; float4* rr = s_dyn + cap; float4* cc = s_dyn + 2 * cap; float4* cd = s_dyn + 3 * cap;
+    float4* rc = s_dyn; float4* rr = s_dyn + capp; float4* cc = s_dyn + 2 * capp; float4* cd = s_dyn + 3 * capp;
     for (uint32_t r = 0; r < cnt; ++r) {
       LeafRec lr = T.leaves[g0 + r];
-      rc[start + r] = lr.c; rr[start + r] = lr.r;
-      if (SPHERES) { cc[start + r] = T.lcol[2 * (g0 + r)]; cd[start + r] = T.lcol[2 * (g0 + r) + 1]; }
+      const uint32_t pp = brick_phys(start + r);
+      rc[pp] = lr.c; rr[pp] = lr.r;
+      if (SPHERES) { cc[pp] = T.lcol[2 * (g0 + r)]; cd[pp] = T.lcol[2 * (g0 + r) + 1]; }
     }
   }
   __syncthreads();
@@ -1293,7 +1306,7 @@ __global__ __launch_bounds__(kCoopBlock) __attribute__((amdgpu_waves_per_eu(6, 8
     if (t == 0 && s_slow) atomicAdd(slow_queries, s_slow);
   }
 }
-constexpr size_t brick_lds_bytes(bool spheres, uint32_t cap) { return (size_t)cap * 16u * (spheres ? 4u : 2u); }
+constexpr size_t brick_lds_bytes(bool spheres, uint32_t cap) { return (size_t)brick_phys_cap(cap) * 16u * (spheres ? 4u : 2u); }
 
 // Terrain faces per body without walking the reference tree.  A static mesh gets the same Morton-cell grid as the
 // bodies (cells over the face boxes, built once per set_terrain); a query enumerates the cells its box can reach,
