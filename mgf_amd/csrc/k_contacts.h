@@ -9,6 +9,10 @@ namespace mgf {
 // LocalContact reduced to what Manifold/ContactConstraint::new consume (local_a, local_b, n).
 // ------------------------------------------------------------------------------------------
 struct NContact { float4 la, lb, n; };  // la.xyz + t, lb.xyz, n.xyz
+// an entry of a body's row of the constraints it takes part in as `b` (k_chain_rows / k_flow6_links, k_links.h): the constraint's id,
+// body a's slot and body a's order id
+struct RevEnt { uint32_t c, a, oid, pad; };
+static_assert(sizeof(RevEnt) == 16, "a row entry is one 16-byte word");
 
 
 // work = nullptr: dense over [0, m); else the m candidate ids of this pair type.
@@ -641,8 +645,8 @@ template <bool SPHERES>
 __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCounts* sc, const uint32_t* p_owner, const uint32_t* p_cand,
                                                         const uint32_t* p_nc, const uint32_t* p_pre, const NContact* p_in,
                                                         const uint32_t* base, float dt, float baumgarte, float slop,
-                                                        CRec* cons, uint2* ab, uint32_t* degb, uint32_t* rev, uint32_t rev_cap,
-                                                        uint32_t* rev_flag, uint32_t in_stride, uint32_t* flag, TerrainSetup TS) {
+                                                        CRec* cons, uint2* ab, uint32_t* degb, RevEnt* rev, uint32_t rev_cap,
+                                                        uint32_t* rev_flag, uint32_t in_stride, uint32_t* flag, TerrainSetup TS, const uint32_t* ext) {
   if (blockIdx.x < TS.blocks) {  // the terrain candidates' constraints (k_setup_terrain's work, without a launch of its own)
     setup_terrain_one(B, TS, sc, blockIdx.x * kBlock + threadIdx.x, base, dt, baumgarte, slop, cons, ab);
     return;
@@ -677,7 +681,7 @@ __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCoun
         ab[c] = make_uint2(i, j);
         // body j's row of the constraints it takes part in as `b` (k_chain_rows); as `a` a body owns a contiguous id range
         const uint32_t pos = atomicAdd(&degb[j], 1u);
-        if (pos < rev_cap) rev[(size_t)j * rev_cap + pos] = c;
+        if (pos < rev_cap) rev[(size_t)j * rev_cap + pos] = RevEnt{c, i, order_id(ext, i), 0u};
         else *rev_flag = 1u;
       }
     }
@@ -711,7 +715,7 @@ __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCoun
     ab[c] = make_uint2(i, j);
     // body j's row of the constraints it takes part in as `b` (k_chain_rows); as `a` a body owns a contiguous id range
     uint32_t pos = atomicAdd(&degb[j], 1u);
-    if (pos < rev_cap) rev[(size_t)j * rev_cap + pos] = c;
+    if (pos < rev_cap) rev[(size_t)j * rev_cap + pos] = RevEnt{c, i, order_id(ext, i), 0u};
     else *rev_flag = 1u;
   }
 }
@@ -841,7 +845,7 @@ struct ContactsSpheres {
   const uint32_t *rows_p, *t_cnt, *p_cnt, *base, *tcn, *tpos;
   const NContact* t_out;
   float dt, baumgarte, slop;
-  CRec* cons; uint2* ab; uint32_t* degb; uint32_t* rev; uint32_t rev_cap; uint32_t* rev_flag; uint32_t* flag;
+  CRec* cons; uint2* ab; uint32_t* degb; RevEnt* rev; uint32_t rev_cap; uint32_t* rev_flag; uint32_t* flag;
   const uint32_t* ext;
 };
 // a body's partner row -> the block's list in LDS, canonical order (entries of the window [w0, w0 + kCsEntCap))
@@ -950,7 +954,7 @@ __global__ __launch_bounds__(kBlock) void k_contacts_spheres(Bodies B, TerrainDe
           A.ab[c] = make_uint2(ia, j);
           // body j's row of the constraints it takes part in as `b` (k_chain_rows); as `a` a body owns a contiguous id range
           const uint32_t pos = atomicAdd(&A.degb[j], 1u);
-          if (pos < A.rev_cap) A.rev[(size_t)j * A.rev_cap + pos] = c;
+          if (pos < A.rev_cap) A.rev[(size_t)j * A.rev_cap + pos] = RevEnt{c, ia, order_id(A.ext, ia), 0u};
           else *A.rev_flag = 1u;
         }
       }

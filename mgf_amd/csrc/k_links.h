@@ -68,10 +68,19 @@ __device__ __forceinline__ uint32_t links_indeg0(const ConsLinks& K, uint32_t c)
 // `ext` (the body store is kept in an internal order, host_perm.inc): a body's own range still comes first - the bodies it
 // meets as `b` are constraints of bodies with a LARGER order id, all inserted later - but ids no longer ascend with the
 // insertion order across bodies: the row is sorted by (order id of the constraint's body a, id).
-__device__ __forceinline__ unsigned long long rev_sort_key(const ConsLinks& K, const uint32_t* ext, uint32_t c) {
-  return ext ? (((unsigned long long)ext[K.ab[c].x] << 32) | c) : (unsigned long long)c;
+// (r05: a row entry carries what the sort and the links need of its constraint - its id, body a's slot and body a's order id - so
+// that nothing has to be looked up through the id: the key used to be two dependent gathers, K.ab[c].x and ext[..], per comparison)
+__device__ __forceinline__ unsigned long long rev_key(const RevEnt& e) { return ((unsigned long long)e.oid << 32) | e.c; }
+__device__ __forceinline__ void rev_sort_in_place(RevEnt* row, uint32_t nb) {  // (rows longer than the register path: insertion sort where they lie)
+  for (uint32_t a = 1; a < nb; ++a) {
+    const RevEnt v = row[a];
+    const unsigned long long kv = rev_key(v);
+    uint32_t b = a;
+    while (b > 0 && rev_key(row[b - 1]) > kv) { row[b] = row[b - 1]; --b; }
+    row[b] = v;
+  }
 }
-__global__ __launch_bounds__(kBlock) void k_chain_rows(uint32_t n, ConsLinks K, const uint32_t* base, const uint32_t* degb, uint32_t* rev,
+__global__ __launch_bounds__(kBlock) void k_chain_rows(uint32_t n, ConsLinks K, const uint32_t* base, const uint32_t* degb, RevEnt* rev,
                                                        uint32_t rev_cap, const uint32_t* rev_flag, StepCounts* sc, const uint32_t* tcn, uint32_t n_owned,
                                                        uint32_t* n_ghost_cons, const uint32_t* only_if, const uint32_t* ext) {
   // (behind k_flow6_links, which has done the tick's bookkeeping: the links are only needed if the block-local solver declined)
@@ -90,19 +99,14 @@ __global__ __launch_bounds__(kBlock) void k_chain_rows(uint32_t n, ConsLinks K, 
   const uint32_t total = na + nb;
   if (total == 0) return;
   const uint32_t nt = tcn[x];
-  uint32_t* row = rev + (size_t)x * rev_cap;
-  for (uint32_t a = 1; a < nb; ++a) {  // ascending constraint id = insertion order
-    uint32_t v = row[a], b = a;
-    const unsigned long long kv = rev_sort_key(K, ext, v);
-    while (b > 0 && rev_sort_key(K, ext, row[b - 1]) > kv) { row[b] = row[b - 1]; --b; }
-    row[b] = v;
-  }
+  RevEnt* row = rev + (size_t)x * rev_cap;
+  rev_sort_in_place(row, nb);  // ascending (order id of body a, constraint id) = insertion order
   uint32_t* succ = reinterpret_cast<uint32_t*>(K.succ);
-  const uint32_t first = na ? lo : row[0];
+  const uint32_t first = na ? lo : row[0].c;
   for (uint32_t k = 0; k < total; ++k) {
     const bool last = k + 1 == total;
-    const uint32_t u = k < na ? lo + k : row[k - na], role = k < na ? 0u : 1u;
-    const uint32_t wid = last ? first : (k + 1 < na ? lo + k + 1 : row[k + 1 - na]);
+    const uint32_t u = k < na ? lo + k : row[k - na].c, role = k < na ? 0u : 1u;
+    const uint32_t wid = last ? first : (k + 1 < na ? lo + k + 1 : row[k + 1 - na].c);
     // the successor has two dynamic bodies unless it is one of this body's own terrain constraints - the first tcn[x] of its
     // range (no look-up of the successor's (a, b): that was a dependent gather per link)
     const bool two = !(wid >= lo && wid - lo < nt);

@@ -241,7 +241,7 @@ __device__ __forceinline__ uint32_t f6_chan_slot(uint32_t* keys, uint32_t key1, 
 // one: no (succ, pred) arrays in between (k_chain_rows still builds them for the other solver modes, and - launched behind
 // this kernel with a guard - for the stand-by when a block did not fit).
 struct F6Ent { uint32_t home, slot, role, c, bref; };
-__device__ __forceinline__ void f6_links_body(const Flow6& F, const ConsLinks& K, uint32_t n, const uint32_t* degb, uint32_t* rev, uint32_t rev_cap,
+__device__ __forceinline__ void f6_links_body(const Flow6& F, const ConsLinks& K, uint32_t n, const uint32_t* degb, RevEnt* rev, uint32_t rev_cap,
                                               const uint32_t* rev_flag, StepCounts* sc, uint32_t n_owned, uint32_t* n_ghost_cons, const uint32_t* ext) {
   const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   // constraints whose obj_a is a ghost (ids are ascending in obj_a): the copies of seam constraints (tiles count them once)
@@ -255,23 +255,26 @@ __device__ __forceinline__ void f6_links_body(const Flow6& F, const ConsLinks& K
   const uint4 ix = F.binfo[x];  // (position = t, first slot, first constraint, constraints of its own)
   const uint32_t g = t / F.nb, na = ix.w, nbr = degb[x];
   if (na + nbr == 0u) return;
-  uint32_t* row = rev + (size_t)x * rev_cap;
-  // the row in ascending constraint id = insertion order: up to eight entries (a settled pile's bodies have four on average, and
-  // beyond the four of round 2's register path every key of the insertion sort was two dependent look-ups) sorted in registers from
-  // two 16-byte loads, longer rows in place
-  // (a store in internal order, `ext`: the insertion order across bodies is that of the order ids - rev_sort_key)
-  const bool small = nbr <= 8u && (rev_cap & 7u) == 0u;
-  uint32_t s8[8] = {kNone, kNone, kNone, kNone, kNone, kNone, kNone, kNone};
+  RevEnt* row = rev + (size_t)x * rev_cap;
+  // the row in insertion order - ascending (order id of the constraint's body a, constraint id): up to eight entries (a settled pile's bodies
+  // have four on average) sorted in registers, longer rows where they lie.  The entries carry their keys and body a's slot (r05): no
+  // look-up through the constraint id, neither for the sort nor for the links below
+  const bool small = nbr <= 8u;
+  uint32_t s8[8] = {kNone, kNone, kNone, kNone, kNone, kNone, kNone, kNone}, a8[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
   if (small) {
-    const uint4 r4 = *reinterpret_cast<const uint4*>(row);
-    uint4 r5 = make_uint4(kNone, kNone, kNone, kNone);
-    if (nbr > 4u) r5 = *reinterpret_cast<const uint4*>(row + 4);
-    s8[0] = nbr > 0u ? r4.x : kNone; s8[1] = nbr > 1u ? r4.y : kNone; s8[2] = nbr > 2u ? r4.z : kNone; s8[3] = nbr > 3u ? r4.w : kNone;
-    s8[4] = nbr > 4u ? r5.x : kNone; s8[5] = nbr > 5u ? r5.y : kNone; s8[6] = nbr > 6u ? r5.z : kNone; s8[7] = nbr > 7u ? r5.w : kNone;
     unsigned long long k8[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) k8[j] = s8[j] != kNone ? rev_sort_key(K, ext, s8[j]) : ~0ull;  // (the look-ups go out together; ~0 = kNone sorts last)
-    auto cx = [&](int p, int q) { const unsigned long long lo = min(k8[p], k8[q]), hi = max(k8[p], k8[q]); k8[p] = lo; k8[q] = hi; };
+    for (int j = 0; j < 8; ++j) {
+      RevEnt e{kNone, 0u, 0xFFFFFFFFu, 0u};
+      if ((uint32_t)j < nbr) e = row[j];
+      k8[j] = rev_key(e); a8[j] = e.a;  // (kNone's key - all ones - sorts last)
+    }
+    auto cx = [&](int p, int q) {
+      const bool sw = k8[p] > k8[q];
+      const unsigned long long lo = sw ? k8[q] : k8[p], hi = sw ? k8[p] : k8[q];
+      const uint32_t al = sw ? a8[q] : a8[p], ah = sw ? a8[p] : a8[q];
+      k8[p] = lo; k8[q] = hi; a8[p] = al; a8[q] = ah;
+    };
     // Batcher's odd-even merge sort of eight (nineteen exchanges)
     cx(0, 1); cx(2, 3); cx(4, 5); cx(6, 7);
     cx(0, 2); cx(1, 3); cx(4, 6); cx(5, 7);
@@ -284,12 +287,7 @@ __device__ __forceinline__ void f6_links_body(const Flow6& F, const ConsLinks& K
     for (int j = 0; j < 8; ++j) s8[j] = (uint32_t)k8[j];  // (the id is the key's low half; ~0 = kNone)
 #endif
   } else {
-    for (uint32_t a = 1; a < nbr; ++a) {
-      uint32_t v = row[a], b = a;
-      const unsigned long long kv = rev_sort_key(K, ext, v);
-      while (b > 0 && rev_sort_key(K, ext, row[b - 1]) > kv) { row[b] = row[b - 1]; --b; }
-      row[b] = v;
-    }
+    rev_sort_in_place(row, nbr);
   }
   // the chain: [last own constraint,] b_0 .. b_{nbr-1}, and back to its FIRST constraint (first own, else b_0)
   F6Ent first;
@@ -299,18 +297,16 @@ __device__ __forceinline__ void f6_links_body(const Flow6& F, const ConsLinks& K
   bool have_u = na != 0u;
   // the `b` entries four at a time: their look-ups (constraint -> body a -> block, slot; LDS index of x over there) are
   // independent of each other and go out together; the links are then written in order
-  auto four = [&](uint32_t k0, const uint32_t c[4]) {
-    uint4 ii[4];
-    uint32_t br[4];
+  // the `b` entries' look-ups (constraint -> body a's block and slot there; LDS index of x over there) go out together - all eight of a
+  // short row before the first link is written (r05) - the links are then written in order
+  auto look4 = [&](const uint32_t c[4], const uint32_t ca[4], uint4 ii[4], uint32_t br[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       ii[j] = make_uint4(0, 0, 0, 0); br[j] = 0u;
-#ifdef MGF_L_NOLOOKUP
-      if (c[j] != kNone) { ii[j] = make_uint4(c[j] & 0xFFFFu, c[j] >> 3, c[j] >> 4, 1u); br[j] = c[j] & 255u; }
-#else
-      if (c[j] != kNone) { ii[j] = F.binfo[K.ab[c[j]].x]; br[j] = F.bref[c[j]]; }  // the constraint lives in its body a's block
-#endif
+      if (c[j] != kNone) { ii[j] = F.binfo[ca[j]]; br[j] = F.bref[c[j]]; }  // the constraint lives in its body a's block
     }
+  };
+  auto link4 = [&](uint32_t k0, const uint32_t c[4], const uint4 ii[4], const uint32_t br[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint32_t kb = k0 + (uint32_t)j;
@@ -359,15 +355,26 @@ __device__ __forceinline__ void f6_links_body(const Flow6& F, const ConsLinks& K
   };
   if (small) {
     const uint32_t lo4[4] = {s8[0], s8[1], s8[2], s8[3]}, hi4[4] = {s8[4], s8[5], s8[6], s8[7]}, none[4] = {kNone, kNone, kNone, kNone};
-    four(0u, lo4);
-    if (nbr >= 4u) four(4u, hi4);
-    if (nbr == 8u) four(8u, none);
+    const uint32_t la4[4] = {a8[0], a8[1], a8[2], a8[3]}, ha4[4] = {a8[4], a8[5], a8[6], a8[7]};
+    uint4 il[4], ih[4];
+    uint32_t bl[4], bh[4];
+    look4(lo4, la4, il, bl);
+    look4(hi4, ha4, ih, bh);
+    link4(0u, lo4, il, bl);
+    if (nbr >= 4u) link4(4u, hi4, ih, bh);
+    if (nbr == 8u) link4(8u, none, il, bl);
   } else {
     for (uint32_t k0 = 0; k0 <= nbr; k0 += 4u) {
-      uint32_t c[4];
+      uint32_t c[4], ca[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) c[j] = k0 + (uint32_t)j < nbr ? row[k0 + (uint32_t)j] : kNone;
-      four(k0, c);
+      for (int j = 0; j < 4; ++j) {
+        c[j] = kNone; ca[j] = 0u;
+        if (k0 + (uint32_t)j < nbr) { const RevEnt e = row[k0 + (uint32_t)j]; c[j] = e.c; ca[j] = e.a; }
+      }
+      uint4 ii[4];
+      uint32_t br[4];
+      look4(c, ca, ii, br);
+      link4(k0, c, ii, br);
     }
   }
 }
@@ -391,7 +398,7 @@ __device__ __forceinline__ uint32_t f6_chan_one(const Flow6& F, uint32_t hs) {
 // The tick's launch: the links, and - by the block that finishes last (a ticket; the edge counts are complete when every block's
 // atomics have been acknowledged) - the channel layout, which used to be a launch of its own (k_flow6_chan: still there for a
 // caller's list and for a changed iteration count).
-__global__ __launch_bounds__(kBlock) void k_flow6_links(Flow6 F, ConsLinks K, uint32_t n, const uint32_t* degb, uint32_t* rev, uint32_t rev_cap,
+__global__ __launch_bounds__(kBlock) void k_flow6_links(Flow6 F, ConsLinks K, uint32_t n, const uint32_t* degb, RevEnt* rev, uint32_t rev_cap,
                                                         const uint32_t* rev_flag, StepCounts* sc, uint32_t n_owned, uint32_t* n_ghost_cons,
                                                         const uint32_t* ext, uint32_t* ticket, uint32_t iters, const float4* srec, float4* vsnap) {
   {  // the velocities as Solver::solve is about to find them (k_solver_snapshot's work on the way: the solve follows this launch in the fused tick)
