@@ -216,3 +216,27 @@ def test_dataflow_solver_settled_pile_at_full_size(ctx):
     assert b.counter("flow6_fallbacks") - fb0 <= 2, (fb0, b.counter("flow6_fallbacks"), b.counter("flow6_fail_reason"))
     print(f"settled: {sb.n_constraints} constraints; mode 6 fallbacks {b.counter('flow6_fallbacks')} (reason {b.counter('flow6_fail_reason')}), "
           f"nimp in LDS on {b.counter('flow6_nimp_lds')} ticks, max slots {b.counter('flow6_max_slots')}")
+
+
+def test_config2_front_ends_agree_over_a_hundred_ticks(ctx):
+    """Round 5's front end of a world of spheres - Morton cells inside k_integrate over the previous tick's bounds, near-mesh records and
+    the sphere-triangle tests by four lanes in the scatter's launch, constraint records straight from the rows (no candidate lists) - against
+    the candidate-list path it replaced (options fused_contacts = 0, cells_in_integrate = 0), 262 144 spheres, ticks 0..100 and 400..420
+    of the same pile: every count and every bit of the state."""
+    import mgf_amd
+    from mgf_amd import scenes
+    scene = scenes.sphere_pile(64, 64, 64)
+    dt, iters = float(scene["dt"]), scene["iters"]
+    a, b = mgf_amd.World.from_scene(ctx, scene), mgf_amd.World.from_scene(ctx, scene)
+    b.set_option("fused_contacts", 0)
+    b.set_option("cells_in_integrate", 0)
+    done = 0
+    for ticks in (100, 300, 20):
+        sa, sb = a.step_many(dt, iters, ticks), b.step_many(dt, iters, ticks)
+        done += ticks
+        for key in ("n_constraints", "n_terrain_constraints", "n_terrain_candidates", "n_pair_candidates", "n_refits"):
+            assert [int(s[key]) for s in sa] == [int(s[key]) for s in sb], (done, key)
+        xa, xb = a.state(), b.state()
+        for k in ("x", "q", "v", "omega", "delta"):
+            assert np.array_equal(xa[k].view(np.uint32), xb[k].view(np.uint32)), (done, k)
+    assert int(sa[-1]["n_terrain_constraints"]) > 4000 and int(sa[-1]["n_constraints"]) > 900000
