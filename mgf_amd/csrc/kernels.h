@@ -3,7 +3,9 @@
 //   k_integrate<Tail>  RigidBodyVec::complete_motion + integrate (physics.rs:222-269), swept AABB
 //                      (bounds.rs:60-68), fat-AABB refit test (world.rs:234-238).  In mgf_world_step (collide follows at
 //                      once on the same bodies) its tail also lists each body's terrain faces (what k_terrain_rows does)
-//                      and the blocks gather the scene bounds (what k_scene_bounds does; folded by k_zero_many)
+//                      and the blocks gather the scene bounds (what k_scene_bounds does; folded by k_zero_many); in the fused tick
+//                      (r05) it also works out the body's Morton cell and rank over the previous tick's bounds (CellSort: no
+//                      k_morton_count launch) and appends a 48-byte record of every body that lists a terrain face
 //   k_scene_bounds / k_morton_count / k_scatter_leaves
 //                      bodies counting-sorted into Morton cells (cell = 2L-bit prefix of the 30-bit code of the fat-box
 //                      centre); the same kernels build the static grid over a terrain mesh's face boxes
@@ -27,6 +29,14 @@
 //                      Manifold::from + ContactConstraint::new (manifold.rs:120-148, solver.rs:101-191); in a world of
 //                      spheres only the broadphase lists contacts (k_pair_grid<true> runs the sphere test) and
 //                      k_setup_pairs<true> evaluates each one itself, so k_narrow_pairs is not launched
+//   k_terrain_contacts / k_contacts_spheres (r05)
+//                      a world of spheres over a small mesh, no candidate lists: the sphere-triangle tests of the bodies near the
+//                      mesh (records from k_integrate's tail; a face by four lanes, tri_msphere_x4; as the last blocks of
+//                      k_scatter_leaves_tc's launch), k_scan over p_cnt + tcn with the tick's counts in its epilogue
+//                      (caps_contacts), then a block per 256 bodies: its partner contacts as an LDS list in canonical order,
+//                      ContactConstraint::new for each
+//   k_solver_snapshot / k_solver_restore (r05)
+//                      the velocities / impulses a persistent solver launch finds, and back, if it gives up (solver_abort_fallback)
 //   k_chain_rows       order-preserving dependency links of the tick's constraint list (compact arrays, ConsLinks);
 //   k_adj_fill / k_chain  the same for a caller-supplied list in any order (mgf_world_set_constraints)
 //   k_flow6_blocks / k_flow6_links / k_flow6_chan
