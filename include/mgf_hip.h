@@ -395,13 +395,16 @@ MGF_API mgf_status mgf_tiles_preflight(mgf_tiles* t, int32_t* n_ranks_seen);
 MGF_API mgf_status mgf_tiles_step(mgf_tiles* t, float dt, int32_t iters, mgf_step_stats* stats /* n_local, or NULL */);
 /* Options of a tile set.  "exchange_timing" [0]: HIP events around every neighbour exchange feed the counter "exchange_ns" (an event is
  * a barrier packet in the stream: off unless asked for).  "test_fail_tick" = the mgf_tiles_step call (0-based) in which this rank fails on purpose in its collide
- * phase: the protocol's status agreement is then observable (no rank hangs, every rank reports the tick as lost); -1 = never. */
+ * phase: the protocol's status agreement is then observable (no rank hangs, every rank reports the tick as lost); -1 = never.
+ * "retry_lost_ticks" [1]: a tick in which a persistent solver launch gave up on any rank (a device shared with another process) is repeated
+ * on every rank - the tiles' owned bodies put back to where the tick found them, the launch-per-frontier executor for the next solves;
+ * Solver::solve has no failure mode, solver.rs:72-78 - instead of being reported as lost (counter "ticks_retried"). */
 MGF_API mgf_status mgf_tiles_set_option(mgf_tiles* t, const char* key, int64_t value);
 MGF_API int64_t mgf_tiles_migrated(const mgf_tiles* t, int32_t tile, int32_t direction_in); /* bodies handed over so far */
 /* What the neighbour exchanges of a tile set have cost since its creation (no reference counterpart: world.rs has one World): key =
    "exchange_bytes_out" / "exchange_bytes_in" (rows that crossed a face between RANKS), "exchange_bytes_local" (rows copied between this
    rank's own tiles), "exchange_calls", "exchange_ns" (stream time between the events around the exchanges, the wait for the neighbouring
-   rank included; counted while mgf_tiles_set_option "exchange_timing" is 1), "host_waits", "ticks"; -1 for an unknown key. */
+   rank included; counted while mgf_tiles_set_option "exchange_timing" is 1), "host_waits", "ticks", "ticks_retried"; -1 for an unknown key. */
 MGF_API int64_t mgf_tiles_counter(const mgf_tiles* t, const char* key);
 /* Options (development and test knobs; defaults in brackets): "time_solver_kernels" [0] HIP events around the
  * solver kernels; "solver_mode" [6] 1 = persistent dataflow launch, 0 = one launch per dependency frontier,

@@ -126,6 +126,19 @@ __global__ __launch_bounds__(kBlock) void k_import_ghost_vel(float4* srec, uint3
   *p = make_float2(r[1].x, r[1].y);
 }
 
+// What a tile's tick changes of its owned bodies that cannot be worked out again - position, orientation, velocities, motion, the
+// persistent fat box (7 words per body) - and back: a tick lost to a solver launch that gave up is repeated from here (mgf_tiles_step).
+constexpr int kTickSnapWords = 7;
+__global__ __launch_bounds__(kBlock) void k_tick_snapshot(Bodies B, uint32_t n, float4* snap, int restore) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  float4* s = snap + (size_t)kTickSnapWords * i;
+  if (!restore) {
+    s[0] = B.x[i]; s[1] = B.q[i]; s[2] = B.srec[4 * (size_t)i]; s[3] = B.srec[4 * (size_t)i + 1]; s[4] = B.delta[i]; s[5] = B.fb_c[i]; s[6] = B.fb_r[i];
+  } else {
+    B.x[i] = s[0]; B.q[i] = s[1]; B.srec[4 * (size_t)i] = s[2]; B.srec[4 * (size_t)i + 1] = s[3]; B.delta[i] = s[4]; B.fb_c[i] = s[5]; B.fb_r[i] = s[6];
+  }
+}
 // ---- migration of owned bodies between tiles -----------------------------------------------------
 // A migrant record is the body's row of every Bodies array, verbatim (kMigrantWords float4 = 116 floats): the
 // receiving tile continues bit-identically, persistent fat box and constructor tag (ctor.w) included.

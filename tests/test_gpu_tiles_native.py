@@ -236,3 +236,32 @@ def test_seam_quality_at_scale_against_the_undivided_world(ctx):
     assert ref_n > 500 and rows[2][2] > 500
     assert rows[2][0] < 1.25 * rows[2][1] and rows[1][0] < 1.25 * rows[1][1]   # the default keeps the seam at the interior's level
     assert rows[2][1] < 1.1 * ref_in                                          # ... and the interior at the undivided world's
+
+
+def test_a_tick_lost_to_a_solver_launch_that_gave_up_is_repeated(ctx):
+    """Solver::solve has no failure mode (solver.rs:72-78), and a tile set's tick has none either when a persistent solver launch gives up
+    under it (a device shared with another process): every tile's bodies go back to where the tick found them, the tiles back off to the
+    launch-per-frontier executor and the tick - exchanges, ghost refreshes and all - is repeated; the set stays bit-identical to the
+    oracle's tiles.  (The middle tile's launches are made to give up: option flow_spin_limit = 1, small blocks so that it has several.)"""
+    from mgf_amd.tiles import step_tiles_inprocess
+    P, nx, ny, nz = 3, 5, 4, 5
+    tile_scenes = [scenes.sphere_pile_tile(nx, ny, nz, r, P, drift=(4.0, 0.0, 0.0)) for r in range(P)]
+    T, worlds = _native(ctx, tile_scenes)
+    for w in worlds:
+        w.set_option("flow5_block", 16)
+    worlds[1].set_option("flow_spin_limit", 1)
+    ot = _oracle_tiles(tile_scenes)
+    dt, iters = float(tile_scenes[0]["dt"]), tile_scenes[0]["iters"]
+    for tick in range(40):
+        sg, so = T.step(dt, iters), step_tiles_inprocess(ot)
+        assert [int(s.n_constraints) for s in sg] == [int(s["n_constraints"]) for s in so], tick
+        if tick % 10 == 9:
+            _assert_equal(worlds, ot, f"tick {tick}")
+    assert T.counter("ticks_retried") >= 1 and worlds[1].counter("solver_abort_fallbacks") >= 1
+    assert T.counter("ticks") == 40 and sum(T.migrated(r) for r in range(P)) > 0
+    # ... and with the repetition switched off such a tick is reported as lost, as before
+    worlds[1].set_option("flow_spin_limit", 1)
+    T.set_option("retry_lost_ticks", 0)
+    with pytest.raises(mgf_amd.MgfError):
+        for _ in range(80):
+            T.step(dt, iters)
