@@ -63,6 +63,7 @@ def run_rank(rank, n_ranks, total_tiles, dims, drift, ticks, fail_rank, fail_tic
                 tiles_out.append(dict(tile=first + k, tags=w.tags(), migrated_in=T.migrated(k), **{f: st[f] for f in ("x", "q", "v", "omega", "delta")}))
         out_q.put(dict(rank=rank, ranks_seen=seen, failed_at=failed_at, error=err, tiles=tiles_out,
                        bytes_out=T.counter("exchange_bytes_out"), bytes_in=T.counter("exchange_bytes_in"),
-                       flow6_runs=sum(w.counter("flow6_runs") for w in worlds), flow_blocks=[w.counter("flow5_blocks") for w in worlds]))
+                       flow6_runs=sum(w.counter("flow6_runs") for w in worlds), flow_blocks=[w.counter("flow5_blocks") for w in worlds],
+                       ticks_retried=T.counter("ticks_retried")))
     except Exception:
         out_q.put(dict(rank=rank, crash=traceback.format_exc()))

@@ -98,6 +98,17 @@ def test_ranks_sharing_one_device_match_the_oracle_tiles(n_ranks, P):
     _check_against_oracle_tiles(res, n_ranks, P, dims, drift, ticks)
 
 
+def test_two_processes_sharing_one_device_unannounced_still_finish_every_tick():
+    """... and when nobody told them: each process launches 256 workgroups as if the device were its own.  Whenever the two launches take
+    part of the CUs each and wait for the rest, they give up after ~0.5 s; the ranks agree on it, put their bodies back and repeat the tick
+    with the launch-per-frontier executor (mgf_tiles_step, option retry_lost_ticks) - slower, never an error, the same bits."""
+    P, dims, drift, ticks = 2, (16, 128, 64), None, 4
+    res = _launch(2, P, dims, drift, ticks, shared_device=True, timeout=900)
+    for r in range(2):
+        assert res[r]["failed_at"] is None, res[r]["error"]
+    _check_against_oracle_tiles(res, 2, P, dims, drift, ticks, expect_moves=False)
+
+
 def test_two_processes_sharing_one_device_at_config4_tile_size():
     """two processes on device 0, a 131 072-sphere tile of BASELINE config 4's shape each.  A persistent solver launch
     needs all its workgroups resident at once; two such launches of 256 workgroups from two processes can take half the CUs each and
