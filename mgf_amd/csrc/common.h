@@ -82,6 +82,5 @@ struct DBuf {
 mgf_status prim_exclusive_scan_u32(mgf_ctx* ctx, const uint32_t* in, uint32_t* out, size_t n_plus_1);
 mgf_status prim_sort_pairs_u32(mgf_ctx* ctx, const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out, size_t n,
                                unsigned end_bit);
-mgf_status prim_exclusive_scan_u32x2(mgf_ctx* ctx, const uint32_t* in_a, const uint32_t* in_b, uint32_t* out_a, uint32_t* out_b, size_t n_plus_1);
 
 }  // namespace mgf

@@ -11,31 +11,110 @@ namespace mgf {
 // ------------------------------------------------------------------------------------------
 constexpr int kGhostFloats = 40 + 8 * kTileParts;
 
-// flags[i] bit0: owned body i's fat box reaches below x_left; bit1: above x_right.
-__global__ __launch_bounds__(kBlock) void k_boundary_flags(Bodies B, uint32_t n_owned, float x_left, float x_right, uint32_t* fl,
-                                                           uint32_t* fr) {
-  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i > n_owned) return;
-  uint32_t l = 0, r = 0;
-  if (i < n_owned) {
-    float c = B.fb_c[i].x, h = B.fb_r[i].x;
-    l = (c - h < x_left) ? 1u : 0u;
-    r = (c + h > x_right) ? 1u : 0u;
+// ---- what a tile sends: selection ------------------------------------------------------------------------------------------------
+// Every launch of the tile protocol's own kernels takes up to kTileBatch tiles (blockIdx.y = the tile): a rank that holds several tiles
+// - the whole scene on one GPU, two tiles per GPU - pays one launch where it paid one per tile (r05: these kernels move a few KB each and
+// cost ~4.5 us apiece: 158 of them per tick of 8 tiles, now 14).
+constexpr int kTileBatch = 8;
+// The four ascending lists of a tile: owned bodies whose fat box reaches below x_left (ghosts of the left neighbour) / above x_right,
+// and bodies whose centre left the slab [x_lo, x_hi) (migrants: left-goers first) - per-block counts, their offsets, the scatter.
+struct SelTile {
+  const float4 *fb_c, *fb_r, *x;
+  uint32_t n;
+  float x_left, x_right, x_lo, x_hi;
+  uint32_t* blk;   // [4 * blocks]: per block (nl, nr, ml, mr) - counts (k_tile_select_count), then exclusive offsets (k_tile_select_offsets)
+  uint32_t* tot;   // [4] the totals
+  uint32_t *ids_l, *ids_r, *ids_m;  // (null: not wanted - the count kernels run without them)
+};
+struct SelBatch { SelTile t[kTileBatch]; };
+__device__ __forceinline__ uint32_t sel_flags(const SelTile& S, uint32_t i) {
+  const float c = S.fb_c[i].x, h = S.fb_r[i].x, cx = S.x[i].x;
+  uint32_t f = 0;
+  if (c - h < S.x_left) f |= 1u;
+  if (c + h > S.x_right) f |= 2u;
+  if (cx < S.x_lo) f |= 4u; else if (cx >= S.x_hi) f |= 8u;
+  return f;
+}
+__global__ __launch_bounds__(kBlock) void k_tile_select_count(SelBatch A) {
+  const SelTile& S = A.t[blockIdx.y];
+  if (blockIdx.x * kBlock >= S.n) return;
+  __shared__ uint32_t s_c[4];
+  if (threadIdx.x < 4) s_c[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t f = i < S.n ? sel_flags(S, i) : 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t c = (uint32_t)__popcll(__ballot((f >> k) & 1u));
+    if ((threadIdx.x & 63u) == 0u && c) atomicAdd(&s_c[k], c);
   }
-  fl[i] = l; fr[i] = r;  // slot n_owned = 0 so the exclusive scan yields the total there
+  __syncthreads();
+  if (threadIdx.x < 4) S.blk[4 * (size_t)blockIdx.x + threadIdx.x] = s_c[threadIdx.x];
 }
-__global__ __launch_bounds__(kBlock) void k_boundary_scatter(uint32_t n_owned, const uint32_t* fl, const uint32_t* sl, const uint32_t* fr,
-                                                             const uint32_t* sr, uint32_t* ids_l, uint32_t* ids_r) {
-  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n_owned) return;
-  if (fl[i]) ids_l[sl[i]] = i;
-  if (fr[i]) ids_r[sr[i]] = i;
+// one workgroup per tile: the per-block counts become exclusive offsets, the totals go to `tot`
+constexpr uint32_t kSelScanThreads = 1024;
+__global__ __launch_bounds__(kSelScanThreads) void k_tile_select_offsets(SelBatch A) {
+  const SelTile& S = A.t[blockIdx.x];
+  __shared__ uint32_t s_w[kSelScanThreads / 64][4];
+  __shared__ uint32_t s_run[4];
+  const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+  const uint32_t nb = (S.n + kBlock - 1) / kBlock;
+  if (t < 4) s_run[t] = 0u;
+  __syncthreads();
+  uint4* blk = reinterpret_cast<uint4*>(S.blk);
+  for (uint32_t b0 = 0; b0 < nb; b0 += kSelScanThreads) {
+    const uint32_t b = b0 + t;
+    const uint4 c = b < nb ? blk[b] : make_uint4(0, 0, 0, 0);
+    uint32_t v[4] = {c.x, c.y, c.z, c.w}, inc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      inc[k] = v[k];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc[k], o); if ((int)lane >= o) inc[k] += u; }
+      if (lane == 63u) s_w[wv][k] = inc[k];
+    }
+    __syncthreads();
+    uint32_t before[4], total[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      before[k] = s_run[k]; total[k] = 0u;
+      for (uint32_t w = 0; w < kSelScanThreads / 64; ++w) { const uint32_t u = s_w[w][k]; if (w < wv) before[k] += u; total[k] += u; }
+    }
+    if (b < nb) blk[b] = make_uint4(before[0] + inc[0] - v[0], before[1] + inc[1] - v[1], before[2] + inc[2] - v[2], before[3] + inc[3] - v[3]);
+    __syncthreads();
+    if (t < 4) s_run[t] += total[t];
+    __syncthreads();
+  }
+  if (t < 4) S.tot[t] = s_run[t];
 }
-__global__ __launch_bounds__(kBlock) void k_export_bodies(Bodies B, const uint32_t* ids, uint32_t m, float* out) {
-  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= m) return;
-  uint32_t i = ids[t];
-  float* o = out + (size_t)t * kGhostFloats;
+__global__ __launch_bounds__(kBlock) void k_tile_select_scatter(SelBatch A) {
+  const SelTile& S = A.t[blockIdx.y];
+  if (blockIdx.x * kBlock >= S.n) return;
+  __shared__ uint32_t s_w[kBlock / 64][4];
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t f = i < S.n ? sel_flags(S, i) : 0u;
+  uint32_t rank[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned long long m = __ballot((f >> k) & 1u);
+    rank[k] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0u) s_w[wv][k] = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  if (!f) return;
+  const uint4 off = reinterpret_cast<const uint4*>(S.blk)[blockIdx.x];
+  const uint32_t o4[4] = {off.x, off.y, off.z, off.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!((f >> k) & 1u)) continue;
+    uint32_t r = o4[k] + rank[k];
+    for (uint32_t w = 0; w < wv; ++w) r += s_w[w][k];
+    if (k == 0) { if (S.ids_l) S.ids_l[r] = i; }
+    else if (k == 1) { if (S.ids_r) S.ids_r[r] = i; }
+    else if (S.ids_m) S.ids_m[(k == 3 ? S.tot[2] : 0u) + r] = i;
+  }
+}
+__device__ __forceinline__ void export_body(const Bodies& B, uint32_t i, float* o) {
   float4 x = B.x[i], q = B.q[i], s0 = B.srec[4 * i], s1 = B.srec[4 * i + 1], s2 = B.srec[4 * i + 2], s3 = B.srec[4 * i + 3];
   float4 d = B.delta[i], e = B.einfo[i], c0 = B.col0[i], c1 = B.col1[i];
   o[0] = x.x; o[1] = x.y; o[2] = x.z;
@@ -55,6 +134,15 @@ __global__ __launch_bounds__(kBlock) void k_export_bodies(Bodies B, const uint32
     float* q8 = o + 40 + 8 * k;
     q8[0] = a.x; q8[1] = a.y; q8[2] = a.z; q8[3] = a.w; q8[4] = b.x; q8[5] = b.y; q8[6] = b.z; q8[7] = b.w;
   }
+}
+// both faces' records of every tile of the batch: the left face's first (ids_r == null: one list)
+struct ExpTile { Bodies B; const uint32_t *ids_l, *ids_r; uint32_t nl, nr; float* out; };
+struct ExpBatch { ExpTile t[kTileBatch]; };
+__global__ __launch_bounds__(kBlock) void k_export_bodies(ExpBatch A) {
+  const ExpTile& E = A.t[blockIdx.y];
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= E.nl + E.nr) return;
+  export_body(E.B, t < E.nl ? E.ids_l[t] : E.ids_r[t - E.nl], E.out + (size_t)t * kGhostFloats);
 }
 __device__ __forceinline__ void import_ghost(Bodies B, uint32_t i, const float* o, float fat_margin, int blo[3], int bhi[3], int brm[3]) {
   V3 x = mk3(o[0], o[1], o[2]), d = mk3(o[13], o[14], o[15]);
@@ -97,46 +185,61 @@ __device__ __forceinline__ void import_ghost(Bodies B, uint32_t i, const float* 
   B.imb[3 * i] = make_float4(0, 0, 0, 0); B.imb[3 * i + 1] = make_float4(0, 0, 0, 0); B.imb[3 * i + 2] = make_float4(0, 0, 0, 0);
 }
 // (in2 / m1: the rows from m1 on come from a second buffer - the two neighbours' send buffers read in place, no copy in between)
-__global__ __launch_bounds__(kBlock) void k_import_ghosts(Bodies B, uint32_t n_owned, uint32_t m, const float* in, float fat_margin, int* sb_part,
-                                                          const float* in2 = nullptr, uint32_t m1 = 0xFFFFFFFFu) {
-  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+struct ImpTile { Bodies B; uint32_t n_owned, m, m1; float fat_margin; const float *in, *in2; int* sb_part; };
+struct ImpBatch { ImpTile t[kTileBatch]; };
+__global__ __launch_bounds__(kBlock) void k_import_ghosts(ImpBatch A) {
+  const ImpTile& I = A.t[blockIdx.y];
+  if (blockIdx.x * kBlock >= I.m) return;
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   int blo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, bhi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000}, brm[3] = {0, 0, 0};
-  if (t < m) import_ghost(B, n_owned + t, t < m1 ? in + (size_t)t * kGhostFloats : in2 + (size_t)(t - m1) * kGhostFloats, fat_margin, blo, bhi, brm);
-  if (sb_part) bounds_block_accumulate(blo, bhi, brm, sb_part);  // the scene bounds gathered by this tick's k_integrate take the ghosts in
+  if (t < I.m) import_ghost(I.B, I.n_owned + t, t < I.m1 ? I.in + (size_t)t * kGhostFloats : I.in2 + (size_t)(t - I.m1) * kGhostFloats, I.fat_margin, blo, bhi, brm);
+  if (I.sb_part) bounds_block_accumulate(blo, bhi, brm, I.sb_part);  // the scene bounds gathered by this tick's k_integrate take the ghosts in
 }
-// velocity record: 8 floats (v3, w3, 0, 0)
-// (ids_b / m_b: a second id list whose records follow the first's - both slab faces of a tile in one launch)
-__global__ __launch_bounds__(kBlock) void k_export_vel(const float4* srec, const uint32_t* ids, uint32_t m, float4* out, const uint32_t* ids_b = nullptr,
-                                                       uint32_t m_b = 0) {
-  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= m + m_b) return;
-  uint32_t i = t < m ? ids[t] : ids_b[t - m];
-  float4 s0 = srec[4 * i], s1 = srec[4 * i + 1];
-  out[2 * t] = s0;
-  out[2 * t + 1] = make_float4(s1.x, s1.y, 0.0f, 0.0f);
+// velocity record: 8 floats (v3, w3, 0, 0); both slab faces of a tile in one list of records, the left face's first
+struct VelTile { float4* srec; const uint32_t *ids_l, *ids_r; uint32_t nl, nr; float4* out; };   // export: srec -> out
+struct VelBatch { VelTile t[kTileBatch]; };
+__global__ __launch_bounds__(kBlock) void k_export_vel(VelBatch A) {
+  const VelTile& V = A.t[blockIdx.y];
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= V.nl + V.nr) return;
+  const uint32_t i = t < V.nl ? V.ids_l[t] : V.ids_r[t - V.nl];
+  const float4 s0 = V.srec[4 * (size_t)i], s1 = V.srec[4 * (size_t)i + 1];
+  V.out[2 * (size_t)t] = s0;
+  V.out[2 * (size_t)t + 1] = make_float4(s1.x, s1.y, 0.0f, 0.0f);
 }
-__global__ __launch_bounds__(kBlock) void k_import_ghost_vel(float4* srec, uint32_t n_owned, uint32_t m, const float4* in, const float4* in2 = nullptr,
-                                                             uint32_t m1 = 0xFFFFFFFFu) {
-  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= m) return;
-  uint32_t i = n_owned + t;
-  const float4* r = t < m1 ? in + 2 * (size_t)t : in2 + 2 * (size_t)(t - m1);
-  srec[4 * i] = r[0];
-  float2* p = reinterpret_cast<float2*>(&srec[4 * i + 1]);
-  *p = make_float2(r[1].x, r[1].y);
+struct GVelTile { float4* srec; uint32_t n_owned, m, m1; const float4 *in, *in2; };  // import: the rows from m1 on come from in2
+struct GVelBatch { GVelTile t[kTileBatch]; };
+__global__ __launch_bounds__(kBlock) void k_import_ghost_vel(GVelBatch A) {
+  const GVelTile& G = A.t[blockIdx.y];
+  const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= G.m) return;
+  const size_t i = (size_t)G.n_owned + t;
+  const float4* r = t < G.m1 ? G.in + 2 * (size_t)t : G.in2 + 2 * (size_t)(t - G.m1);
+  G.srec[4 * i] = r[0];
+  *reinterpret_cast<float2*>(&G.srec[4 * i + 1]) = make_float2(r[1].x, r[1].y);
 }
 
+// the solver flags of every tile of the batch (16 words each: abort, fail bits, block sizes) straight into the tiles' pinned read-back blocks:
+// one launch where eight device-to-host copies - each a blit kernel with ~18 us of queue handling around it - stood
+struct FlagTile { const uint32_t* src; uint32_t* dst; };
+struct FlagBatch { FlagTile t[kTileBatch]; };
+__global__ __launch_bounds__(16 * kTileBatch) void k_fetch_flags(FlagBatch A) {
+  const FlagTile& F = A.t[threadIdx.x >> 4];
+  if (F.src) F.dst[threadIdx.x & 15u] = F.src[threadIdx.x & 15u];
+}
 // What a tile's tick changes of its owned bodies that cannot be worked out again - position, orientation, velocities, motion, the
 // persistent fat box (7 words per body) - and back: a tick lost to a solver launch that gave up is repeated from here (mgf_tiles_step).
 constexpr int kTickSnapWords = 7;
 __global__ __launch_bounds__(kBlock) void k_tick_snapshot(Bodies B, uint32_t n, float4* snap, int restore) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  float4* s = snap + (size_t)kTickSnapWords * i;
+  // word-major (snap[e * n + i]): consecutive lanes, consecutive addresses on both sides (body-major, 112 bytes apart: 16.7 us per 131 072 bodies; so: see EXPERIMENTS.md)
+  float4* s = snap + i;
+  const size_t n_ = n;
   if (!restore) {
-    s[0] = B.x[i]; s[1] = B.q[i]; s[2] = B.srec[4 * (size_t)i]; s[3] = B.srec[4 * (size_t)i + 1]; s[4] = B.delta[i]; s[5] = B.fb_c[i]; s[6] = B.fb_r[i];
+    s[0] = B.x[i]; s[n_] = B.q[i]; s[2 * n_] = B.srec[4 * (size_t)i]; s[3 * n_] = B.srec[4 * (size_t)i + 1]; s[4 * n_] = B.delta[i]; s[5 * n_] = B.fb_c[i]; s[6 * n_] = B.fb_r[i];
   } else {
-    B.x[i] = s[0]; B.q[i] = s[1]; B.srec[4 * (size_t)i] = s[2]; B.srec[4 * (size_t)i + 1] = s[3]; B.delta[i] = s[4]; B.fb_c[i] = s[5]; B.fb_r[i] = s[6];
+    B.x[i] = s[0]; B.q[i] = s[n_]; B.srec[4 * (size_t)i] = s[2 * n_]; B.srec[4 * (size_t)i + 1] = s[3 * n_]; B.delta[i] = s[4 * n_]; B.fb_c[i] = s[5 * n_]; B.fb_r[i] = s[6 * n_];
   }
 }
 // ---- migration of owned bodies between tiles -----------------------------------------------------
@@ -186,25 +289,6 @@ __device__ __forceinline__ void migrant_put(const Bodies& B, uint32_t e, uint32_
   if (slots < (uint32_t)kMaxParts && slot + 1u == slots)
     for (uint32_t z = slots; z < (uint32_t)kMaxParts; ++z) *part_word(B, arr, z, i) = make_float4(0, 0, 0, 0);
 }
-// cnt[0] / cnt[1] += owned bodies whose centre lies below x_lo / at or above x_hi (the slab is [x_lo, x_hi))
-__global__ __launch_bounds__(kBlock) void k_migrant_count(Bodies B, uint32_t n_owned, float x_lo, float x_hi, uint32_t* cnt) {
-  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n_owned) return;
-  float cx = B.x[i].x;
-  if (cx < x_lo) atomicAdd(cnt, 1u);
-  else if (cx >= x_hi) atomicAdd(cnt + 1, 1u);
-}
-__global__ __launch_bounds__(kBlock) void k_migrant_flags(Bodies B, uint32_t n_owned, float x_lo, float x_hi, uint32_t* fl, uint32_t* fr) {
-  uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i > n_owned) return;
-  uint32_t l = 0, r = 0;
-  if (i < n_owned) {
-    float cx = B.x[i].x;
-    l = (cx < x_lo) ? 1u : 0u;
-    r = (!l && cx >= x_hi) ? 1u : 0u;
-  }
-  fl[i] = l; fr[i] = r;
-}
 // `slots` part slots per array in the records: kTileParts (words = kMigrantWords: the tile protocol) or kMaxParts (words = kBodyWords)
 __global__ __launch_bounds__(kBlock) void k_export_migrants(Bodies B, const uint32_t* ids, uint32_t m, float4* out, uint32_t slots) {
   const uint32_t words = 21u + 4u * slots;
@@ -230,6 +314,50 @@ __global__ __launch_bounds__(kBlock) void k_keep_clear(uint32_t* keep, const uin
   if (t >= m) return;
   uint32_t i = ids[t];
   if (i >= n || atomicExch(&keep[i], 0u) == 0u) atomicOr(err, 1u);  // out of range or listed twice
+}
+// pos = exclusive scan of the 0 / 1 flags `keep` (m entries) in three small launches: per-block counts, their offsets (one workgroup), the
+// positions.  (rocPRIM's scan did this in two - behind ~175 us of host time per call, device queries, during which the stream ran dry.)
+__global__ __launch_bounds__(kBlock) void k_flag_count(const uint32_t* keep, uint32_t m, uint32_t* blk) {
+  __shared__ uint32_t s_c;
+  if (threadIdx.x == 0) s_c = 0u;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t c = (uint32_t)__popcll(__ballot(i < m && keep[i] != 0u));
+  if ((threadIdx.x & 63u) == 0u && c) atomicAdd(&s_c, c);
+  __syncthreads();
+  if (threadIdx.x == 0) blk[blockIdx.x] = s_c;
+}
+__global__ __launch_bounds__(kSelScanThreads) void k_flag_offsets(uint32_t* blk, uint32_t nb) {
+  __shared__ uint32_t s_w[kSelScanThreads / 64];
+  __shared__ uint32_t s_run;
+  const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+  if (t == 0) s_run = 0u;
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < nb; b0 += kSelScanThreads) {
+    const uint32_t b = b0 + t, v = b < nb ? blk[b] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o); if ((int)lane >= o) inc += u; }
+    if (lane == 63u) s_w[wv] = inc;
+    __syncthreads();
+    uint32_t before = s_run, total = 0u;
+    for (uint32_t w = 0; w < kSelScanThreads / 64; ++w) { const uint32_t u = s_w[w]; if (w < wv) before += u; total += u; }
+    if (b < nb) blk[b] = before + inc - v;
+    __syncthreads();
+    if (t == 0) s_run += total;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_flag_positions(const uint32_t* keep, uint32_t m, const uint32_t* blk, uint32_t* pos) {
+  __shared__ uint32_t s_w[kBlock / 64];
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const unsigned long long mk = __ballot(i < m && keep[i] != 0u);
+  if (lane == 0u) s_w[wv] = (uint32_t)__popcll(mk);
+  __syncthreads();
+  if (i >= m) return;
+  uint32_t r = blk[blockIdx.x] + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+  for (uint32_t w = 0; w < wv; ++w) r += s_w[w];
+  pos[i] = r;
 }
 // stable compaction through a scratch copy: tmp[pos[i]] = row i for kept bodies, then rows [0, n_new) = tmp
 __global__ __launch_bounds__(kBlock) void k_compact_gather(Bodies B, uint32_t n, const uint32_t* keep, const uint32_t* pos, float4* tmp) {

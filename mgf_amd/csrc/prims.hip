@@ -36,23 +36,4 @@ mgf_status prim_sort_pairs_u32(mgf_ctx* ctx, const uint32_t* keys_in, uint32_t* 
   return MGF_OK;
 }
 
-// two independent scans of equal length in one pass (a tick's terrain and pair candidate counts become ready together)
-struct PlusPair {
-  __host__ __device__ rocprim::tuple<uint32_t, uint32_t> operator()(const rocprim::tuple<uint32_t, uint32_t>& a,
-                                                                     const rocprim::tuple<uint32_t, uint32_t>& b) const {
-    return rocprim::make_tuple(rocprim::get<0>(a) + rocprim::get<0>(b), rocprim::get<1>(a) + rocprim::get<1>(b));
-  }
-};
-mgf_status prim_exclusive_scan_u32x2(mgf_ctx* ctx, const uint32_t* in_a, const uint32_t* in_b, uint32_t* out_a, uint32_t* out_b, size_t n_plus_1) {
-  if (n_plus_1 == 0) return MGF_OK;
-  auto in = rocprim::make_zip_iterator(rocprim::make_tuple(in_a, in_b));
-  auto out = rocprim::make_zip_iterator(rocprim::make_tuple(out_a, out_b));
-  const auto zero = rocprim::make_tuple(0u, 0u);
-  size_t bytes = 0;
-  MGF_HIP_TRY(rocprim::exclusive_scan(nullptr, bytes, in, out, zero, n_plus_1, PlusPair(), ctx->stream));
-  MGF_TRY(ensure_tmp(ctx, bytes));
-  MGF_HIP_TRY(rocprim::exclusive_scan(ctx->prim_tmp, bytes, in, out, zero, n_plus_1, PlusPair(), ctx->stream));
-  return MGF_OK;
-}
-
 }  // namespace mgf

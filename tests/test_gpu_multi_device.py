@@ -183,7 +183,8 @@ def test_a_failed_tick_is_reported_at_its_end_and_moves_nobody(ctx, connected):
     # the exchanges' counters: rows moved between this process's tiles only, five ticks, the events' time is there
     assert T.counter("ticks") == 5 and T.counter("exchange_calls") >= 5 * 5 and T.counter("exchange_ns") > 0
     assert T.counter("exchange_bytes_local") > 0 and T.counter("exchange_bytes_out") == 0 and T.counter("exchange_bytes_in") == 0
-    assert T.counter("host_waits") >= 5 * (2 + 2 * P)
+    # (r05: one wait per phase whatever the number of tiles - counts, read-backs, solver flags - plus the status agreement between ranks)
+    assert 5 * 3 <= T.counter("host_waits") <= 5 * 5
     with pytest.raises(KeyError):
         T.counter("no_such_counter")
 
