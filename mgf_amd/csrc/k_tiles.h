@@ -24,6 +24,7 @@ struct SelTile {
   float x_left, x_right, x_lo, x_hi;
   uint32_t* blk;   // [4 * blocks]: per block (nl, nr, ml, mr) - counts (k_tile_select_count), then exclusive offsets (k_tile_select_offsets)
   uint32_t* tot;   // [4] the totals
+  uint32_t* tot_host;  // null, or where the host reads them (pinned memory as the device sees it: no copy command behind the kernels)
   uint32_t *ids_l, *ids_r, *ids_m;  // (null: not wanted - the count kernels run without them)
 };
 struct SelBatch { SelTile t[kTileBatch]; };
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(kSelScanThreads) void k_tile_select_offsets(SelBatc
     if (t < 4) s_run[t] += total[t];
     __syncthreads();
   }
-  if (t < 4) S.tot[t] = s_run[t];
+  if (t < 4) { S.tot[t] = s_run[t]; if (S.tot_host) S.tot_host[t] = s_run[t]; }
 }
 __global__ __launch_bounds__(kBlock) void k_tile_select_scatter(SelBatch A) {
   const SelTile& S = A.t[blockIdx.y];
@@ -221,11 +222,11 @@ __global__ __launch_bounds__(kBlock) void k_import_ghost_vel(GVelBatch A) {
 
 // the solver flags of every tile of the batch (16 words each: abort, fail bits, block sizes) straight into the tiles' pinned read-back blocks:
 // one launch where eight device-to-host copies - each a blit kernel with ~18 us of queue handling around it - stood
-struct FlagTile { const uint32_t* src; uint32_t* dst; };
+struct FlagTile { const uint32_t* src; uint32_t* dst; uint32_t words; uint32_t pad; };  // words <= 16
 struct FlagBatch { FlagTile t[kTileBatch]; };
 __global__ __launch_bounds__(16 * kTileBatch) void k_fetch_flags(FlagBatch A) {
   const FlagTile& F = A.t[threadIdx.x >> 4];
-  if (F.src) F.dst[threadIdx.x & 15u] = F.src[threadIdx.x & 15u];
+  if ((threadIdx.x & 15u) < F.words) F.dst[threadIdx.x & 15u] = F.src[threadIdx.x & 15u];
 }
 // What a tile's tick changes of its owned bodies that cannot be worked out again - position, orientation, velocities, motion, the
 // persistent fat box (7 words per body) - and back: a tick lost to a solver launch that gave up is repeated from here (mgf_tiles_step).
@@ -297,12 +298,14 @@ __global__ __launch_bounds__(kBlock) void k_export_migrants(Bodies B, const uint
   uint32_t b = t / words, e = t % words;
   out[t] = migrant_get(B, e, ids[b], slots);
 }
-__global__ __launch_bounds__(kBlock) void k_import_migrants(Bodies B, uint32_t base, uint32_t m, const float4* in, uint32_t slots) {
+// (in2 / m1: the records from m1 on come from a second buffer - the two neighbours' send buffers read in place)
+__global__ __launch_bounds__(kBlock) void k_import_migrants(Bodies B, uint32_t base, uint32_t m, const float4* in, uint32_t slots, const float4* in2 = nullptr,
+                                                            uint32_t m1 = 0xFFFFFFFFu) {
   const uint32_t words = 21u + 4u * slots;
   uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= m * words) return;
   uint32_t b = t / words, e = t % words;
-  migrant_put(B, e, base + b, in[t], slots);
+  migrant_put(B, e, base + b, b < m1 ? in[t] : in2[t - m1 * words], slots);
 }
 // keep[i] = 1 for i < n, keep[n] = 0 (scan total); then the listed bodies are cleared
 __global__ __launch_bounds__(kBlock) void k_keep_fill(uint32_t* keep, uint32_t n) {
