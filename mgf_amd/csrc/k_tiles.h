@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void k_keep_clear(uint32_t* keep, const uin
   uint32_t i = ids[t];
   if (i >= n || atomicExch(&keep[i], 0u) == 0u) atomicOr(err, 1u);  // out of range or listed twice
 }
-// pos = exclusive scan of the 0 / 1 flags `keep` (m entries) in three small launches: per-block counts, their offsets (one workgroup), the
+// pos = exclusive scan of the 0 / 1 flags `keep` (m entries; kNone where the flag is 0, the total in the last entry) in three small launches: per-block counts, their offsets (one workgroup), the
 // positions.  (rocPRIM's scan did this in two - behind ~175 us of host time per call, device queries, during which the stream ran dry.)
 __global__ __launch_bounds__(kBlock) void k_flag_count(const uint32_t* keep, uint32_t m, uint32_t* blk) {
   __shared__ uint32_t s_c;
@@ -360,22 +360,43 @@ __global__ __launch_bounds__(kBlock) void k_flag_positions(const uint32_t* keep,
   if (i >= m) return;
   uint32_t r = blk[blockIdx.x] + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
   for (uint32_t w = 0; w < wv; ++w) r += s_w[w];
-  pos[i] = r;
+  pos[i] = (keep[i] != 0u || i + 1u == m) ? r : kNone;  // (the last entry - the list's own zero - carries the total)
 }
-// stable compaction through a scratch copy: tmp[pos[i]] = row i for kept bodies, then rows [0, n_new) = tmp
-__global__ __launch_bounds__(kBlock) void k_compact_gather(Bodies B, uint32_t n, const uint32_t* keep, const uint32_t* pos, float4* tmp) {
-  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= n * kBodyWords) return;
-  uint32_t i = t / kBodyWords, e = t % kBodyWords;
-  if (keep[i] && pos[i] != i) tmp[(size_t)pos[i] * kBodyWords + e] = migrant_get(B, e, i, kMaxParts);  // (a body in front of the first removed one stays where it is)
+// The same positions for a SHORT list of removed bodies (a tile's hand-over: a handful per tick) in one launch: pos[i] = i - (ids below i),
+// kNone for a listed body; err |= 1 for an id out of range or listed twice.  (The list in any order.)
+constexpr uint32_t kRemoveShort = 64;
+__global__ __launch_bounds__(kBlock) void k_remove_positions_short(const uint32_t* ids, uint32_t m, uint32_t n, uint32_t* pos, uint32_t* err) {
+  __shared__ uint32_t s_ids[kRemoveShort];
+  if (threadIdx.x < m) s_ids[threadIdx.x] = ids[threadIdx.x];
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x < m) {
+    const uint32_t id = s_ids[threadIdx.x];
+    bool bad = id >= n;
+    for (uint32_t j = 0; j < threadIdx.x; ++j) bad = bad || s_ids[j] == id;
+    if (bad) atomicOr(err, 1u);
+  }
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i > n) return;  // (pos[n] = the new length, as the scan's total)
+  uint32_t below = 0;
+  bool listed = false;
+  for (uint32_t k = 0; k < m; ++k) { const uint32_t id = s_ids[k]; below += id < i ? 1u : 0u; listed = listed || id == i; }
+  pos[i] = listed ? kNone : i - below;
 }
-// ... rows [0, n_new) = tmp, except the rows that did not move: row k kept its place iff every body up to it was kept (pos[k] == k, keep[k])
-__global__ __launch_bounds__(kBlock) void k_compact_put(Bodies B, uint32_t n_new, const uint32_t* keep, const uint32_t* pos, const float4* tmp) {
-  uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= n_new * kBodyWords) return;
-  uint32_t k = t / kBodyWords, e = t % kBodyWords;
-  if (keep[k] && pos[k] == k) return;
-  migrant_put(B, e, k, tmp[t], kMaxParts);
+// stable compaction through a scratch copy: tmp[pos[i]] = row i for kept bodies, then rows [0, n_new) = tmp.  Word-major like the
+// re-sort's copy (blockIdx.y = the word, tmp[e * n + k]): consecutive lanes read one array at consecutive bodies and write consecutive
+// words (r05; body-major - 37 arrays per wave load - took 29 + 21 us per removal on a 131 072-body tile).
+__global__ __launch_bounds__(kBlock) void k_compact_gather(Bodies B, uint32_t n, const uint32_t* pos /* kNone: removed */, float4* tmp) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x, e = blockIdx.y;
+  if (i >= n) return;
+  const uint32_t p = pos[i];
+  if (p != kNone && p != i) tmp[(size_t)e * n + p] = migrant_get(B, e, i, kMaxParts);  // (a body in front of the first removed one stays where it is)
+}
+// ... rows [0, n_new) = tmp, except the rows that did not move: row k kept its place iff every body up to it was kept (pos[k] == k)
+__global__ __launch_bounds__(kBlock) void k_compact_put(Bodies B, uint32_t n, uint32_t n_new, const uint32_t* pos, const float4* tmp) {
+  const uint32_t k = blockIdx.x * kBlock + threadIdx.x, e = blockIdx.y;
+  if (k >= n_new) return;
+  if (pos[k] == k) return;
+  migrant_put(B, e, k, tmp[(size_t)e * n + k], kMaxParts);
 }
 // ---- the body store in an internal order (host_perm.inc) ----------------------------------------------------------
 // Slot k of the new order takes the row of old slot order[k] - the body's row of every Bodies array, verbatim, like a

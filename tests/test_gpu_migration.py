@@ -168,16 +168,41 @@ def test_three_ranks_on_one_gpu_match_oracle_tiles(tmp_path):
             assert values_equal(got[k], want[k]), f"rank {rank} {k}"
 
 
+@pytest.mark.parametrize("n_gone", [3, 64, 65, 700])
+def test_remove_bodies_short_and_long_lists_keep_the_others_in_order(ctx, n_gone):
+    """The compaction behind a removal has two ways to the kept bodies' new slots - one launch for a handful of ids (a tile's hand-over),
+    count / offsets / positions for a long list: both must leave exactly the kept bodies, in their old order, every array verbatim."""
+    import torch
+    import mgf_amd
+    from mgf_amd import scenes
+    gw = mgf_amd.World.from_scene(ctx, scenes.sphere_pile(10, 10, 10))
+    n = len(gw)
+    tags = np.arange(n, dtype=np.uint32) + 7
+    gw.set_tags(tags)
+    gw.step(1.0 / 60.0, 4)
+    before = gw.state()
+    rng = np.random.default_rng(n_gone)
+    ids = rng.permutation(n)[:n_gone].astype(np.uint32)  # (any order)
+    d = torch.from_numpy(ids.astype(np.int32)).cuda()
+    gw.remove_bodies(d.data_ptr(), len(ids))
+    keep = np.setdiff1d(np.arange(n), ids)
+    assert len(gw) == len(keep) and np.array_equal(gw.tags(), tags[keep])
+    after = gw.state()
+    for k in STATE_KEYS:
+        assert np.array_equal(after[k], before[k][keep]), k
+    gw.step(1.0 / 60.0, 4)
+
+
 def test_remove_bodies_rejects_bad_ids(ctx):
     import torch
     import mgf_amd
     from mgf_amd import scenes
-    gw = mgf_amd.World.from_scene(ctx, scenes.sphere_pile(3, 3, 3))
-    for bad in ([1, 1], [5, 400]):
+    gw = mgf_amd.World.from_scene(ctx, scenes.sphere_pile(5, 5, 5))
+    for bad in ([1, 1], [5, 400], list(range(70)) + [3], list(range(70)) + [400]):  # (short lists and long ones: two ways to the new slots)
         d = torch.tensor(bad, dtype=torch.int32, device="cuda")
         with pytest.raises(mgf_amd.MgfError):
             gw.remove_bodies(d.data_ptr(), len(bad))
-    assert len(gw) == 27
+    assert len(gw) == 125
     gw.step(1.0 / 60.0, 4)
 
 
