@@ -115,25 +115,34 @@ __global__ __launch_bounds__(kBlock) void k_tile_select_scatter(SelBatch A) {
     else if (S.ids_m) S.ids_m[(k == 3 ? S.tot[2] : 0u) + r] = i;
   }
 }
+// (written word by word: 16-byte stores - 288 bytes apart between lanes - were TWICE as slow as the 72 scalar ones, 95 against 49 us for
+// the 64 000 records of eight tiles; the import's 16-byte loads are the faster ones, 31 against 75 us)
 __device__ __forceinline__ void export_body(const Bodies& B, uint32_t i, float* o) {
+  constexpr bool vec = false;
   float4 x = B.x[i], q = B.q[i], s0 = B.srec[4 * i], s1 = B.srec[4 * i + 1], s2 = B.srec[4 * i + 2], s3 = B.srec[4 * i + 3];
   float4 d = B.delta[i], e = B.einfo[i], c0 = B.col0[i], c1 = B.col1[i];
-  o[0] = x.x; o[1] = x.y; o[2] = x.z;
-  o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
-  o[7] = s0.x; o[8] = s0.y; o[9] = s0.z;
-  o[10] = s0.w; o[11] = s1.x; o[12] = s1.y;
-  o[13] = d.x; o[14] = d.y; o[15] = d.z;
-  o[16] = c1.w; o[17] = c0.x; o[18] = c0.y; o[19] = c0.z; o[20] = c1.x; o[21] = c1.y; o[22] = c1.z; o[23] = c0.w;
-  o[24] = s1.z;
-  o[25] = s1.w; o[26] = s2.x; o[27] = s2.y; o[28] = s2.z; o[29] = s2.w; o[30] = s3.x; o[31] = s3.y; o[32] = s3.z; o[33] = s3.w;
-  o[34] = e.w; o[35] = d.w;
   const uint32_t pc = B.pcount ? B.pcount[i] : 0u;
-  o[36] = u2f(pc); o[37] = o[38] = o[39] = 0.0f;
+  float4 r[10];
+  r[0] = make_float4(x.x, x.y, x.z, q.x);
+  r[1] = make_float4(q.y, q.z, q.w, s0.x);
+  r[2] = make_float4(s0.y, s0.z, s0.w, s1.x);
+  r[3] = make_float4(s1.y, d.x, d.y, d.z);
+  r[4] = make_float4(c1.w, c0.x, c0.y, c0.z);
+  r[5] = make_float4(c1.x, c1.y, c1.z, c0.w);
+  r[6] = make_float4(s1.z, s1.w, s2.x, s2.y);
+  r[7] = make_float4(s2.z, s2.w, s3.x, s3.y);
+  r[8] = make_float4(s3.z, s3.w, e.w, d.w);
+  r[9] = make_float4(u2f(pc), 0.0f, 0.0f, 0.0f);
+  auto put = [&](uint32_t k, const float4& v) {
+    if (vec) reinterpret_cast<float4*>(o)[k] = v;
+    else { o[4 * k] = v.x; o[4 * k + 1] = v.y; o[4 * k + 2] = v.z; o[4 * k + 3] = v.w; }
+  };
+#pragma unroll
+  for (uint32_t k = 0; k < 10; ++k) put(k, r[k]);
   for (uint32_t k = 0; k < (uint32_t)kTileParts; ++k) {
     float4 a = make_float4(0, 0, 0, 0), b = a;
     if (k < pc) { a = B.wp0[kMaxParts * i + k]; b = B.wp1[kMaxParts * i + k]; }
-    float* q8 = o + 40 + 8 * k;
-    q8[0] = a.x; q8[1] = a.y; q8[2] = a.z; q8[3] = a.w; q8[4] = b.x; q8[5] = b.y; q8[6] = b.z; q8[7] = b.w;
+    put(10 + 2 * k, a); put(11 + 2 * k, b);
   }
 }
 // both faces' records of every tile of the batch: the left face's first (ids_r == null: one list)
@@ -145,7 +154,16 @@ __global__ __launch_bounds__(kBlock) void k_export_bodies(ExpBatch A) {
   if (t >= E.nl + E.nr) return;
   export_body(E.B, t < E.nl ? E.ids_l[t] : E.ids_r[t - E.nl], E.out + (size_t)t * kGhostFloats);
 }
-__device__ __forceinline__ void import_ghost(Bodies B, uint32_t i, const float* o, float fat_margin, int blo[3], int bhi[3], int brm[3]) {
+__device__ __forceinline__ void import_ghost(Bodies B, uint32_t i, const float* src, float fat_margin, int blo[3], int bhi[3], int brm[3]) {
+  // the record's first 40 floats, as ten 16-byte words when the buffer is 16-byte aligned (the tile set's own buffers are)
+  const bool vec = (reinterpret_cast<uintptr_t>(src) & 15u) == 0u;
+  auto get = [&](uint32_t k) -> float4 {
+    if (vec) return reinterpret_cast<const float4*>(src)[k];
+    return make_float4(src[4 * k], src[4 * k + 1], src[4 * k + 2], src[4 * k + 3]);
+  };
+  float o[40];
+#pragma unroll
+  for (uint32_t k = 0; k < 10; ++k) { const float4 v = get(k); o[4 * k] = v.x; o[4 * k + 1] = v.y; o[4 * k + 2] = v.z; o[4 * k + 3] = v.w; }
   V3 x = mk3(o[0], o[1], o[2]), d = mk3(o[13], o[14], o[15]);
   B.x[i] = mk4(x, 0.0f);
   B.q[i] = make_float4(o[3], o[4], o[5], o[6]);
@@ -164,9 +182,8 @@ __device__ __forceinline__ void import_ghost(Bodies B, uint32_t i, const float* 
   if (B.pcount) {
     B.pcount[i] = pc;
     for (uint32_t pk = 0; pk < (uint32_t)kMaxParts; ++pk) {  // a ghost is never integrated here: its world parts are all that matters
-      const float* q8 = o + 40 + 8 * min(pk, (uint32_t)kTileParts - 1u);
       float4 a = make_float4(0, 0, 0, 0), b = a;
-      if (pk < (uint32_t)kTileParts) { a = make_float4(q8[0], q8[1], q8[2], q8[3]); b = make_float4(q8[4], q8[5], q8[6], q8[7]); }
+      if (pk < (uint32_t)kTileParts) { a = get(10 + 2 * pk); b = get(11 + 2 * pk); }
       B.wp0[kMaxParts * i + pk] = a; B.wp1[kMaxParts * i + pk] = b;
       B.lp0[kMaxParts * i + pk] = a; B.lp1[kMaxParts * i + pk] = b;
       if (pk < pc) {
