@@ -50,6 +50,12 @@
 //   k_solve_flow       the same graph with every hand-off through L2 (stand-by of k_solve_flow5, solver mode 1)
 //   k_frontier0 / k_solve
 //                      one launch per frontier of the unrolled (iterations x constraints) graph (solver mode 0, cross-check)
+//   k_tile_select_* / k_export_bodies / k_import_ghosts / k_export_vel / k_import_ghost_vel / k_fetch_flags (k_tiles.h; batched in r05)
+//                      the tile protocol: the boundary bodies and migrants of up to eight tiles per launch (per-block counts,
+//                      offsets by one workgroup per tile, ordered scatter), 72-float ghost records out and in, the velocity refreshes
+//                      between solver launches, every tile's solver flags into its pinned block; k_remove_positions_short /
+//                      k_flag_* + k_compact_gather / _put: the stable compaction behind a hand-over; k_tick_snapshot: what a
+//                      tile's tick changes, kept for the retry of a tick in which a persistent launch gave up
 //   k_compound_* / k_bvh_raytrace / k_intersections_batch
 //                      Compound (compound.rs:230-352), BVH::raytrace and Intersects (bvh.rs:345-369, collision.rs:169-373)
 //
