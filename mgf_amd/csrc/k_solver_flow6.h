@@ -282,10 +282,8 @@ __device__ __forceinline__ void f6_links_body(const Flow6& F, const ConsLinks& K
     cx(0, 4); cx(1, 5); cx(2, 6); cx(3, 7);
     cx(2, 4); cx(3, 5);
     cx(1, 2); cx(3, 4); cx(5, 6);
-#ifndef MGF_L_NOSORT
 #pragma unroll
     for (int j = 0; j < 8; ++j) s8[j] = (uint32_t)k8[j];  // (the id is the key's low half; ~0 = kNone)
-#endif
   } else {
     rev_sort_in_place(row, nbr);
   }
@@ -322,11 +320,7 @@ __device__ __forceinline__ void f6_links_body(const Flow6& F, const ConsLinks& K
       }
       const uint32_t wrap = last ? kF6Wrap : 0u;
       uint32_t word;
-#ifdef MGF_L_NOCHAN
-      if (true) {
-#else
       if (u.home == w.home) {
-#endif
         word = wrap | w.slot;
       } else {  // the link crosses a block face: a message on the channel u.home -> w.home
         const uint32_t dbody = w.role == 0u ? t - w.home * F.nb : w.bref;  // as a: own there; as b: what k_flow6_blocks gave it
@@ -343,11 +337,7 @@ __device__ __forceinline__ void f6_links_body(const Flow6& F, const ConsLinks& K
         if (w.slot >= kF6MaxSlots || dbody >= kF6NoBody) atomicOr(F.fail, 16u);
         word = kF6Remote | wrap | (k_out << 24) | (dbody << kF6SlotBits) | w.slot;
       }
-#ifndef MGF_L_NOWRITE
       if (u.slot < F.rows) reinterpret_cast<uint32_t*>(&F.table[(size_t)u.home * F.rows + u.slot])[2 + u.role] = word;
-#else
-      if (word == 0x12345u) F.fail[3] = word;
-#endif
       // the chain ends in a constraint of another block: that block writes the body's result, its own does not
       if (last && u.role == 1u && u.home != g) F.skipwb[x] = 1;
       u = w;
