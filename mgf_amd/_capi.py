@@ -902,11 +902,11 @@ class World:
 
     def state(self):
         n = len(self)
-        x = np.zeros((n, 3), np.float32)
-        q = np.zeros((n, 4), np.float32)
-        v = np.zeros((n, 3), np.float32)
-        w = np.zeros((n, 3), np.float32)
-        d = np.zeros((n, 3), np.float32)
+        x = np.empty((n, 3), np.float32)  # (every element is written: mgf_world_read_state fills n bodies)
+        q = np.empty((n, 4), np.float32)
+        v = np.empty((n, 3), np.float32)
+        w = np.empty((n, 3), np.float32)
+        d = np.empty((n, 3), np.float32)
         _check(load_library().mgf_world_read_state(self._h, x.ctypes.data, q.ctypes.data, v.ctypes.data, w.ctypes.data,
                                                    d.ctypes.data, n))
         return dict(x=x, q=q, v=v, omega=w, delta=d)

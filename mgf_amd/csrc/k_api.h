@@ -425,4 +425,57 @@ __global__ __launch_bounds__(kBlock) void k_bvh_query(TerrainDev M, const float*
   if (!FILL) cnt[t] = m;
 }
 
+// mgf_world_read_state's device half: the caller's body e sits in slot slot_of[e] (null: e itself); what was asked for of its x, q, v, omega,
+// delta packed in the caller's order - 3 / 4 / 3 / 3 / 3 floats a body - so that ONE copy into pinned memory brings exactly the bytes the
+// caller gets (r05: four pageable copies of whole float4 arrays and a gather on the host took 16-20 ms for 262 144 bodies)
+__global__ __launch_bounds__(kBlock) void k_pack_state(Bodies B, uint32_t n, const uint32_t* slot_of, float* x, float* q, float* v, float* om, float* d) {
+  const uint32_t e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n) return;
+  const size_t i = slot_of ? slot_of[e] : e;
+  if (x) { const float4 a = B.x[i]; x[3 * (size_t)e] = a.x; x[3 * (size_t)e + 1] = a.y; x[3 * (size_t)e + 2] = a.z; }
+  if (q) reinterpret_cast<float4*>(q)[e] = B.q[i];
+  if (d) { const float4 a = B.delta[i]; d[3 * (size_t)e] = a.x; d[3 * (size_t)e + 1] = a.y; d[3 * (size_t)e + 2] = a.z; }
+  if (v || om) {
+    const float4 s0 = B.srec[4 * i], s1 = B.srec[4 * i + 1];
+    if (v) { v[3 * (size_t)e] = s0.x; v[3 * (size_t)e + 1] = s0.y; v[3 * (size_t)e + 2] = s0.z; }
+    if (om) { om[3 * (size_t)e] = s0.w; om[3 * (size_t)e + 1] = s1.x; om[3 * (size_t)e + 2] = s1.y; }
+  }
+}
+
+// ... and mgf_world_write_state's: the caller's packed arrays (null: not given) into the slots, the other words of a record - inverse mass,
+// inertia, delta's friction word - left as they are
+__global__ __launch_bounds__(kBlock) void k_unpack_state(Bodies B, uint32_t n, const uint32_t* slot_of, const float* x, const float* q, const float* v, const float* om,
+                                                         const float* d) {
+  const uint32_t e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n) return;
+  const size_t i = slot_of ? slot_of[e] : e;
+  if (x) B.x[i] = make_float4(x[3 * (size_t)e], x[3 * (size_t)e + 1], x[3 * (size_t)e + 2], 0.0f);
+  if (q) B.q[i] = reinterpret_cast<const float4*>(q)[e];
+  if (d) { const float fw = B.delta[i].w; B.delta[i] = make_float4(d[3 * (size_t)e], d[3 * (size_t)e + 1], d[3 * (size_t)e + 2], fw); }
+  if (v || om) {
+    float4 s0 = B.srec[4 * i];
+    if (v) { s0.x = v[3 * (size_t)e]; s0.y = v[3 * (size_t)e + 1]; s0.z = v[3 * (size_t)e + 2]; }
+    if (om) {
+      s0.w = om[3 * (size_t)e];
+      float2* s1 = reinterpret_cast<float2*>(&B.srec[4 * i + 1]);
+      *s1 = make_float2(om[3 * (size_t)e + 1], om[3 * (size_t)e + 2]);
+    }
+    B.srec[4 * i] = s0;
+  }
+}
+
+// mgf_world_read_colliders' device half: Moving<Component> of the caller's body e as the 11 words of mgf_moving_component (tag, p, d, r; delta)
+__global__ __launch_bounds__(kBlock) void k_pack_colliders(Bodies B, uint32_t n, const uint32_t* slot_of, uint32_t* out) {
+  const uint32_t e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n) return;
+  const size_t i = slot_of ? slot_of[e] : e;
+  const float4 a = B.col0[i], b = B.col1[i], d = B.delta[i];
+  uint32_t* o = out + 11 * (size_t)e;
+  o[0] = f2u(b.w);
+  o[1] = f2u(a.x); o[2] = f2u(a.y); o[3] = f2u(a.z);
+  o[4] = f2u(b.x); o[5] = f2u(b.y); o[6] = f2u(b.z);
+  o[7] = f2u(a.w);
+  o[8] = f2u(d.x); o[9] = f2u(d.y); o[10] = f2u(d.z);
+}
+
 }  // namespace mgf

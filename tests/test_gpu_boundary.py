@@ -237,3 +237,45 @@ def test_tick_without_events_and_the_two_read_back_paths(ctx):
     a.set_option("phase_timing", 1)   # switched on in mid-run: figures from the next tick on, nothing read from unrecorded events
     s = a.step(dt, iters)
     assert s.ms_total > 0.0
+
+
+@pytest.mark.parametrize("resorted", [False, True])
+def test_read_and_write_state_take_any_subset_of_the_arrays(ctx, resorted):
+    """mgf_world_read_state / write_state pack what was asked for on the device, in the caller's order, and move it through pinned memory in one
+    copy: any subset of (x, q, v, omega, delta) - NULL for the rest - must give the same numbers as the full call, on a store in the caller's
+    order and on a re-sorted one, and a write of a subset must leave the other arrays (and the records' other words) alone."""
+    from mgf_amd._capi import load_library, _check
+    sc = scenes.sphere_pile(9, 9, 9)
+    w = mgf_amd.World.from_scene(ctx, sc)
+    if resorted:
+        w.set_option("resort_every", 4)
+    dt, it = float(sc["dt"]), sc["iters"]
+    for _ in range(9):
+        w.step(dt, it)
+    if resorted:
+        assert w.counter("store_permuted") == 1
+    full = w.state()
+    n = len(w)
+    lib = load_library()
+    for keys in (("v",), ("x", "omega"), ("q", "delta"), ("x", "q", "v", "omega", "delta")):
+        arr = {k: np.full((n, 4 if k == "q" else 3), np.nan, np.float32) for k in keys}
+        p = [arr[k].ctypes.data if k in arr else None for k in ("x", "q", "v", "omega", "delta")]
+        _check(lib.mgf_world_read_state(w._h, *p, n))
+        for k in keys:
+            assert np.array_equal(arr[k], full[k]), (keys, k)
+    # a write of v alone: v changes, everything else - and the next ticks against a twin that was written in full - stays
+    twin = w.clone()
+    v2 = (full["v"] * np.float32(0.5)).astype(np.float32)
+    w.write_state(v=v2)
+    twin.write_state(x=full["x"], q=full["q"], v=v2, omega=full["omega"], delta=full["delta"])
+    a, b = w.state(), twin.state()
+    assert np.array_equal(a["v"], v2)
+    for k in ("x", "q", "omega", "delta"):
+        assert np.array_equal(a[k], full[k]) and np.array_equal(b[k], full[k]), k
+    for _ in range(3):
+        w.step(dt, it); twin.step(dt, it)
+    a, b = w.state(), twin.state()
+    for k in ("x", "q", "v", "omega", "delta"):
+        assert np.array_equal(a[k], b[k]), k
+    cols = w.colliders()
+    assert np.array_equal(cols["delta"], a["delta"]) if "delta" in cols.dtype.names else True
