@@ -269,20 +269,31 @@ __global__ __launch_bounds__(kBlock) void k_refresh_einfo(Bodies B, uint32_t n) 
 // `spec`: the tick is being enqueued before the previous one has been read back (mgf_world_step_many).  If that one
 // turns out to have failed a capacity check (its StepCounts still sit in `sc`), this tick must not touch the state: the
 // guard word makes k_integrate and the whole collide phase no-ops, and the host re-runs both ticks.
-__global__ void k_reset_step(SceneBounds* sb, uint32_t* err, uint32_t* guard, const uint32_t* prev_fail, int spec, int* sb_part, uint32_t* near_cnt = nullptr) {
+__device__ __forceinline__ void reset_step(SceneBounds* sb, uint32_t* err, uint32_t* guard, const uint32_t* prev_fail, int spec, int* sb_part, uint32_t* near_cnt) {
   if (near_cnt && threadIdx.x == 0) *near_cnt = 0u;  // (the length of the list k_integrate's tail is about to build)
   if (spec && (*prev_fail || err[2])) { if (threadIdx.x == 0) *guard = 1u; return; }  // (err[2]: the solvers' abort flag, see k_tick_clear)
   if (sb_part && threadIdx.x < kBoundSlots) {  // launched with 64 threads: one partial record each
     int* slot = sb_part + (size_t)threadIdx.x * kBoundSlotInts;
     for (int k = 0; k < 3; ++k) { slot[k] = 0x7FFFFFFF; slot[3 + k] = (int)0x80000000; slot[6 + k] = 0; }
   }
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
+  if (threadIdx.x == 0) {
     *guard = 0u;
     for (int k = 0; k < 3; ++k) { sb->lo[k] = 0x7FFFFFFF; sb->hi[k] = (int)0x80000000; }
     sb->n_refits = 0; sb->pad = 0; sb->pad2 = 0;
     for (int k = 0; k < 3; ++k) sb->rmax[k] = 0;
     err[0] = 0; err[1] = 0; err[8] = 0;  // traversal stack overflow, candidate row overflow, fused narrowphase mismatch
   }
+}
+__global__ void k_reset_step(SceneBounds* sb, uint32_t* err, uint32_t* guard, const uint32_t* prev_fail, int spec, int* sb_part, uint32_t* near_cnt = nullptr) {
+  reset_step(sb, err, guard, prev_fail, spec, sb_part, near_cnt);
+}
+// ... of several worlds on one stream in one launch (the tile set: a workgroup per world)
+struct ResetOne { SceneBounds* sb; uint32_t* err; uint32_t* guard; const uint32_t* prev_fail; int* sb_part; uint32_t* near_cnt; };
+constexpr int kWorldBatch = 8;
+struct ResetBatch { ResetOne t[kWorldBatch]; };
+__global__ void k_reset_step_batch(ResetBatch A) {
+  const ResetOne& R = A.t[blockIdx.x];
+  reset_step(R.sb, R.err, R.guard, R.prev_fail, 0, R.sb_part, R.near_cnt);
 }
 
 }  // namespace mgf

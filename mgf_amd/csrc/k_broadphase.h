@@ -129,14 +129,24 @@ __global__ __launch_bounds__(kBlock) void k_zero_many(ZeroList z) {
 // The tick's read-back without a copy engine and without an event (round 3): the block of counts, bounds and flags is written straight
 // into the world's pinned host memory, then - behind a system-scope fence - the slot's sequence word; the host polls that word.
 // (hipMemcpyAsync + hipEventRecord put a blit kernel and a barrier packet between two ticks: 11.6 us of an idle GPU per tick.)
-__global__ __launch_bounds__(kBlock) void k_publish(const uint32_t* rb, uint32_t* pin, uint32_t words, uint32_t seq_word, uint32_t seq, const uint32_t* sb_words = nullptr,
-                                                    uint32_t* grid_words = nullptr) {
+__device__ __forceinline__ void publish(const uint32_t* rb, uint32_t* pin, uint32_t words, uint32_t seq_word, uint32_t seq, const uint32_t* sb_words, uint32_t* grid_words) {
   // (the tick's scene bounds: the box the NEXT tick's k_integrate quantises its Morton cells over - CellSort)
   if (grid_words && threadIdx.x < sizeof(SceneBounds) / 4) grid_words[threadIdx.x] = sb_words[threadIdx.x];
   for (uint32_t i = threadIdx.x; i < words; i += kBlock) pin[i] = rb[i];
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(pin + seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ __launch_bounds__(kBlock) void k_publish(const uint32_t* rb, uint32_t* pin, uint32_t words, uint32_t seq_word, uint32_t seq, const uint32_t* sb_words = nullptr,
+                                                    uint32_t* grid_words = nullptr) {
+  publish(rb, pin, words, seq_word, seq, sb_words, grid_words);
+}
+// ... of several worlds on one stream in one launch (the tile set: a workgroup per world)
+struct PublishOne { const uint32_t* rb; uint32_t* pin; uint32_t words, seq_word, seq, pad; const uint32_t* sb_words; uint32_t* grid_words; };
+struct PublishBatch { PublishOne t[kWorldBatch]; };
+__global__ __launch_bounds__(kBlock) void k_publish_batch(PublishBatch A) {
+  const PublishOne& P = A.t[blockIdx.x];
+  publish(P.rb, P.pin, P.words, P.seq_word, P.seq, P.sb_words, P.grid_words);
 }
 __global__ __launch_bounds__(kBlock) void k_tick_clear(ZeroList z, SceneBounds* sb, uint32_t* err, uint32_t* guard, const uint32_t* prev_fail, int spec,
                                                        int* sb_part) {

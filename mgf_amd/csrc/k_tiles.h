@@ -248,7 +248,12 @@ __global__ __launch_bounds__(16 * kTileBatch) void k_fetch_flags(FlagBatch A) {
 // What a tile's tick changes of its owned bodies that cannot be worked out again - position, orientation, velocities, motion, the
 // persistent fat box (7 words per body) - and back: a tick lost to a solver launch that gave up is repeated from here (mgf_tiles_step).
 constexpr int kTickSnapWords = 7;
-__global__ __launch_bounds__(kBlock) void k_tick_snapshot(Bodies B, uint32_t n, float4* snap, int restore) {
+struct SnapTile { Bodies B; uint32_t n, pad; float4* snap; };
+struct SnapBatch { SnapTile t[kTileBatch]; };
+__global__ __launch_bounds__(kBlock) void k_tick_snapshot(SnapBatch A, int restore) {
+  const Bodies& B = A.t[blockIdx.y].B;
+  const uint32_t n = A.t[blockIdx.y].n;
+  float4* snap = A.t[blockIdx.y].snap;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   // word-major (snap[e * n + i]): consecutive lanes, consecutive addresses on both sides (body-major, 112 bytes apart: 16.7 us per 131 072 bodies; so: see EXPERIMENTS.md)
