@@ -44,7 +44,7 @@ run_tiles() {  # name, scene, warm-up
   rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_${N}_fetch -o bench -- $BT > $O/${TAG}_${N}_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_${N}_write -o bench -- $BT > $O/${TAG}_${N}_write.log 2>&1
   ( cd $R
-    python tools/rocprof_summary.py gpurun_out/${TAG}_${N}_trace/bench_results.db 480 --timed k_solve_flow6 2400 > gpurun_out/${TAG}_${N}_kernel_stats.txt
+    python tools/rocprof_summary.py gpurun_out/${TAG}_${N}_trace/bench_results.db 480 --tick-start k_integrate --timed k_solve_flow6 2400 > gpurun_out/${TAG}_${N}_kernel_stats.txt
     python tools/pmc_summary.py gpurun_out/${TAG}_${N}_fetch/bench_results.db gpurun_out/${TAG}_${N}_write/bench_results.db --timed k_solve_flow6 2400 gpurun_out/${TAG}_${N}_pmc.json tiles $W 60 > gpurun_out/${TAG}_${N}_pmc_hbm_traffic.txt
     rm -rf gpurun_out/${TAG}_${N}_trace gpurun_out/${TAG}_${N}_fetch gpurun_out/${TAG}_${N}_write
     python tools/publish_profiles.py $TAG > /dev/null )

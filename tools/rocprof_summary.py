@@ -8,11 +8,15 @@ import sqlite3
 import sys
 
 
-def window_start(path, steps):
+def window_start(path, steps, tick_start=None):
     """start time of the `steps`-th tick from the end (a tick begins with its clearing launch: k_tick_clear, k_reset_step before round
-    3's merge): bench.py's timed region - or None when the trace holds fewer ticks (then everything is summarised)"""
+    3's merge; `tick_start`: another kernel that runs once per tick - the tile set resets all its tiles in one launch, so its tile-ticks
+    are counted by their k_integrate): bench.py's timed region - or None when the trace holds fewer ticks (then everything is summarised)"""
     db = sqlite3.connect(path)
-    rows = db.execute("select start from kernels where name like '%k_tick_clear%' or name like '%k_reset_step%' order by start desc limit ?", (steps,)).fetchall()
+    if tick_start:
+        rows = db.execute("select start from kernels where name like ? order by start desc limit ?", (f"%{tick_start}%", steps)).fetchall()
+    else:
+        rows = db.execute("select start from kernels where name like '%k_tick_clear%' or name like '%k_reset_step%' order by start desc limit ?", (steps,)).fetchall()
     return rows[-1][0] if len(rows) == steps else None
 
 
@@ -35,7 +39,8 @@ def last_launches(path, pattern, count):
 def main():
     path = sys.argv[1]
     steps = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else None
-    t0 = window_start(path, steps) if steps else None
+    tick_start = sys.argv[sys.argv.index("--tick-start") + 1] if "--tick-start" in sys.argv else None
+    t0 = window_start(path, steps, tick_start) if steps else None
     rows = summarise(path, t0)
     tot = sum(r["total_us"] for r in rows)
     print(f"# rocprofv3 --kernel-trace summary of {path}" + (f": the last {steps} ticks (bench.py's timed region; warm-up launches left out)" if t0 else ""))
