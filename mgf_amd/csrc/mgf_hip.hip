@@ -40,7 +40,11 @@ extern "C" mgf_params mgf_default_params(void) {
 
 static inline unsigned nblk(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 static mgf_status fail(mgf_status s, const char* msg) { set_error("%s", msg); return s; }
+#ifdef MGF_DEBUG_LAUNCH  // (development build, tools/build_variant.sh: every launch waited for and named - the last line printed before a device fault is the launch in front of the faulting one)
+#define LAUNCH_CHECK() do { MGF_HIP_TRY(hipGetLastError()); MGF_HIP_TRY(hipDeviceSynchronize()); fprintf(stderr, "[mgf] ok %s:%d\n", __FILE__, __LINE__); } while (0)
+#else
 #define LAUNCH_CHECK() MGF_HIP_TRY(hipGetLastError())
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // context
