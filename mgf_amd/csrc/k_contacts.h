@@ -879,19 +879,13 @@ __device__ __forceinline__ void cs_list_row(const uint32_t* rp, uint32_t np, con
   }
 }
 // ... for the windows behind the first (a block with more than kCsEntCap partner contacts: bodies pressed into each other - a collapsing
-// pile): the plain loops whatever the row's length, and NOT inlined.  (r05: with the twelve-entry network inlined a second time inside the
+// pile): the same listing, NOT inlined.  (r05: with the twelve-entry network inlined a second time inside the
 // window loop, the kernel faulted on a null-based address the first time a tile of the collapsing million-sphere pile reached a second
 // window - tools/soak_tiles.py, tick 156 - while small worlds in the same state passed; out of line it does not: tests/test_gpu_contacts_dense.py,
 // the 600-tick tile soak.)
-__device__ __forceinline__ void cs_list_row_again(const uint32_t* rp, uint32_t np, const uint32_t* ext, uint32_t first, uint32_t w0, uint32_t owner,
+__device__ __attribute__((noinline)) void cs_list_row_again(const uint32_t* rp, uint32_t np, const uint32_t* ext, uint32_t first, uint32_t w0, uint32_t owner,
                                                             uint32_t* s_j, uint16_t* s_b) {
-  for (uint32_t a = 0; a < np; ++a) {
-    const uint32_t j = rp[a], oa = order_id(ext, j);
-    uint32_t before = 0;
-    for (uint32_t q = 0; q < np; ++q) before += order_id(ext, rp[q]) < oa ? 1u : 0u;
-    const uint32_t pos = first + before - w0;
-    if (pos < kCsEntCap) { s_j[pos] = j; s_b[pos] = (uint16_t)owner; }
-  }
+  cs_list_row(rp, np, ext, first, w0, owner, s_j, s_b);
 }
 __global__ __launch_bounds__(kBlock) void k_contacts_spheres(Bodies B, TerrainDev M, ContactsSpheres A) {
   __shared__ float4 s_w[kBlock / 64][7 * 65];  // a wave's records on their way out (see k_setup_pairs)
