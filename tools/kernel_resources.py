@@ -19,8 +19,8 @@ for blk in txt.split("  - .agpr_count")[1:]:
         return m.group(1) if m else "?"
     name = subprocess.run(["c++filt", g("name")], capture_output=True, text=True).stdout.strip()
     name = re.sub(r"\(.*", "", name).replace("void ", "").replace("mgf::", "")
-    rows.add((name, g("vgpr_count"), g("sgpr_count"), g("private_segment_fixed_size"), g("group_segment_fixed_size")))
-print(f"{'kernel':80s} vgpr sgpr scratch    lds")
+    rows.add((name, g("vgpr_count"), g("sgpr_count"), g("private_segment_fixed_size"), g("group_segment_fixed_size"), g("sgpr_spill_count"), g("vgpr_spill_count")))
+print(f"{'kernel':80s} vgpr sgpr scratch    lds sgpr-spills vgpr-spills")
 for r in sorted(rows):
     if pat in r[0] and (not only_scratch or r[3] not in ("0", "?")):
-        print(f"{r[0][:80]:80s} {r[1]:>4s} {r[2]:>4s} {r[3]:>7s} {r[4]:>6s}")
+        print(f"{r[0][:80]:80s} {r[1]:>4s} {r[2]:>4s} {r[3]:>7s} {r[4]:>6s} {r[5]:>11s} {r[6]:>11s}")

@@ -1,15 +1,15 @@
-"""Long run of the tile set on one GPU: BASELINE config 4 as 8 x-slab tiles and, again, as 4 tiles of twice the width - two different cuts of
+"""Long run of the tile set on one GPU: BASELINE config 4 as 8 x-slab tiles, as 4 tiles of twice the width and undivided - three cuts of
 the SAME scene.  No oracle at this size for this long (tests/test_gpu_fullsize.py pins the first ticks bit for bit): what must hold over
 hundreds of ticks is that no body is lost or doubled when it changes owner (the tags stay a permutation of the scene's), every state stays
-finite, no tick is lost or repeated, and the two cuts - block-Jacobi across different faces, so not bit-identical - settle to the same pile
-(height of the centre of mass, kinetic energy) within a few per cent."""
+finite, no tick is lost or repeated, and the tiled cuts - block-Jacobi across different faces, so not bit-identical - settle to the same pile
+(height of the centre of mass) within a few per cent."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, mgf_amd
 from mgf_amd import scenes
 ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 every = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-only = [int(a) for a in sys.argv[3].split(",")] if len(sys.argv) > 3 else [8, 4]
+only = [int(a) for a in sys.argv[3].split(",")] if len(sys.argv) > 3 else [8, 4, 1]  # (1: the same scene undivided - exact Gauss-Seidel, the global solver)
 ctx = mgf_amd.Context(0)
 summ = {}
 for P in only:
@@ -38,9 +38,11 @@ for P in only:
             print(f"{P} tiles tick {s}: {n_total} bodies accounted for, {moved} hand-overs so far, mean height {summ[(P, s)][0]:.4f}, kinetic energy {summ[(P, s)][1]:.1f}, "
                   f"{(time.time() - t0) * 1e3 / s:.2f} ms per tick [{time.time() - t0:.0f} s]", flush=True)
     del T, worlds
-if 8 in only and 4 in only:
+cuts = [P for P in only if P > 1]  # (the undivided world is exact Gauss-Seidel - another algorithm than block-Jacobi across faces: ten iterations
+                                    # compress a 128-layer pile differently; it is here for the invariants, not for the comparison)
+if len(cuts) > 1:
     for s in range(every, ticks + 1, every):
-        h8, h4 = summ[(8, s)][0], summ[(4, s)][0]
-        assert abs(h8 - h4) <= 0.03 * abs(h4), f"tick {s}: the two cuts disagree on the pile's height ({h8} vs {h4})"
-    print("the 8-tile and the 4-tile cut agree on the pile's mean height within 3 % at every mark")
+        hs = [summ[(P, s)][0] for P in cuts]
+        assert max(hs) - min(hs) <= 0.03 * abs(min(hs)), f"tick {s}: the cuts disagree on the pile's height ({hs})"
+    print(f"the cuts into {cuts} tiles agree on the pile's mean height within 3 % at every mark")
 print("soak OK")
