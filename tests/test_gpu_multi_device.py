@@ -217,3 +217,37 @@ def test_bench_gpus_2_spawns_its_own_ranks_and_prints_one_line():
         assert "NOT A MEASUREMENT" in d["data"] and d["rccl_lib"].endswith(".so")
     else:
         assert d["data"] == "synthetic"
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_through_the_piles_collapse_equal_one_process():
+    """BASELINE config 4 at full size for 170 ticks - through the collapse of the million-sphere pile, the state no bench window reaches
+    (tools/soak_tiles.py found a device fault there): 2 ranks x 4 tiles on one device over the stand-in transport against the same 8 tiles
+    in one process.  Thousands of bodies change owner per tick, many of them across the RANK face; the result must be the same bit for bit."""
+    import mgf_amd
+    P, dims, ticks = 8, (16, 128, 64), 170
+    res = _launch(2, P, dims, None, ticks, shared_device=True, timeout=800, world_opts={"flow_max_blocks": 128})
+    got = {}
+    for r in (0, 1):
+        assert res[r]["failed_at"] is None and res[r]["ticks_retried"] == 0, res[r]
+        for t in res[r]["tiles"]:
+            got[t["tile"]] = t
+    ctx = mgf_amd.Context(0)
+    scs = [scenes.sphere_pile_tile(*dims, r, P) for r in range(P)]
+    worlds = []
+    for sc in scs:
+        w = mgf_amd.World.from_scene(ctx, sc)
+        w.set_tags(sc["tags"])
+        worlds.append(w)
+    T = mgf_amd.Tiles(ctx, worlds, [sc["x_range"] for sc in scs])
+    dt, it = float(scs[0]["dt"]), scs[0]["iters"]
+    for _ in range(ticks):
+        T.step(dt, it)
+    assert sum(T.migrated(k) for k in range(P)) > 10000  # (the collapse is under way)
+    for k, w in enumerate(worlds):
+        assert np.array_equal(w.tags(), got[k]["tags"]), f"tile {k}: bodies / order differ"
+        st = w.state()
+        for f in STATE_KEYS:
+            assert np.array_equal(st[f].view(np.uint32), got[k][f].view(np.uint32)), f"tile {k}: {f} differs"
+    del T, worlds
+    ctx.close()
