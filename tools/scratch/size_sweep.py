@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np, mgf_amd
 from mgf_amd import scenes
 ctx = mgf_amd.Context(0)
-for dims in ((17, 9, 13), (50, 50, 40), (70, 70, 70), (80, 80, 80), (90, 100, 64), (128, 100, 64)):
+for dims in [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]] or ((17, 9, 13), (50, 50, 40), (70, 70, 70), (80, 80, 80), (90, 100, 64), (128, 100, 64)):
     sc = scenes.sphere_pile(*dims)
     a, b = mgf_amd.World.from_scene(ctx, sc), mgf_amd.World.from_scene(ctx, sc)
     for k, v in (("solver_mode", 1), ("fused_contacts", 0), ("resort_every", 0), ("cells_in_integrate", 0)):
