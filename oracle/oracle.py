@@ -407,7 +407,7 @@ class World:
         self.stats = Stats()
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and callable(lib):  # (at interpreter exit the module's globals may be gone already)
             lib().mgfo_world_free(self.h)
             self.h = None
 
