@@ -749,7 +749,11 @@ struct TerrainContacts {
   NContact* t_out;     // 2 per slot; .lb.w of the first = the face's contact count
   uint32_t *tcn, *tpos;
   const uint32_t* guard;
+  const float4* col1;  // GEN: the bodies' collider word 1 (d.xyz, kind) - the records of k_integrate's tail carry word 0 and the motion
 };
+// GEN (r06): bodies of any single-component kind - a lane per FACE through the body-triangle test (collision.rs:610-1086) instead of a face by
+// the group's four lanes (tri_msphere_x4 is the sphere's); the parked slots are the same.
+template <bool GEN>
 __device__ __forceinline__ void terrain_contacts_job(const TerrainContacts& A, uint32_t job_block, uint32_t job_blocks) {
   const TerrainDev& M = A.M;
   const float4* near_list = A.near_list; const uint32_t n_faces = A.n_faces, n_verts = A.n_verts, cap_row_t = A.cap_row_t, cap_t = A.cap_t;
@@ -791,7 +795,33 @@ __device__ __forceinline__ void terrain_contacts_job(const TerrainContacts& A, u
       wave_base = __shfl(wave_base, 63);
       tp = __shfl(wave_base + inc - mine, lane & ~(kTcLanes - 1));
     }
-    if (nt) {
+    if (GEN) {
+      if (nt) {
+        const V3 vA = xyz(r1);
+        const float4 c1 = A.col1[i];
+        Comp Ca; Ca.p = xyz(r0); Ca.r = r0.w; Ca.d = xyz(c1); Ca.kind = (int)f2u(c1.w);
+        const uint32_t* rt = rows_t + (size_t)i * cap_row_t;
+        const bool bytes = pk0 != 0xFFFFFFFFu || pk1 != 0xFFFFFFFFu;
+        for (uint32_t a = sub; a < nt; a += (uint32_t)kTcLanes) {  // the body's faces dealt to the group's lanes
+          const uint32_t f = bytes ? ((a < 4u ? pk0 >> (8u * a) : pk1 >> (8u * (a - 4u))) & 255u) : rt[a];
+          const uint4 fi = staged ? s_face[f] : M.faces[f];
+          const Triangle tri = staged ? mkt(xyz(s_vert[fi.x]) + mx, xyz(s_vert[fi.y]) + mx, xyz(s_vert[fi.z]) + mx)
+                                      : mkt(xyz(M.verts[fi.x]) + mx, xyz(M.verts[fi.y]) + mx, xyz(M.verts[fi.z]) + mx);  // mesh.rs:122-126
+          LocalContact lc[2];
+          const int nc = comp_tri_local(Ca, vA, tri, mx, lc);
+          if (tp + a < cap_t) {
+            NContact o;
+            o.la = make_float4(0, 0, 0, 0); o.lb = make_float4(0, 0, 0, u2f(0u)); o.n = make_float4(0, 0, 0, 0);
+            if (nc > 0) { o.la = mk4(lc[0].la, lc[0].g.t); o.lb = mk4(lc[0].lb, u2f((uint32_t)nc)); o.n = mk4(lc[0].g.n, 0.0f); }  // Manifold::from(lc) manifold.rs:120-128
+            t_out[2 * (size_t)(tp + a)] = o;
+            if (nc > 1) { o.la = mk4(lc[1].la, lc[1].g.t); o.lb = mk4(lc[1].lb, 0.0f); o.n = mk4(lc[1].g.n, 0.0f); t_out[2 * (size_t)(tp + a) + 1] = o; }
+          }
+          run += (uint32_t)nc;
+        }
+      }
+      // (the group's total: every lane of the wave is here)
+      run += (uint32_t)__shfl_xor((int)run, 1); run += (uint32_t)__shfl_xor((int)run, 2);
+    } else if (nt) {
       const V3 vA = xyz(r1);
       Comp Ca; Ca.p = xyz(r0); Ca.r = r0.w; Ca.d = mk3(0.0f, 0.0f, 0.0f); Ca.kind = KIND_SPHERE;
       const uint32_t* rt = rows_t + (size_t)i * cap_row_t;
@@ -828,15 +858,17 @@ __device__ __forceinline__ void terrain_contacts_job(const TerrainContacts& A, u
     if (lane == 0 && wrun) atomicAdd(&sums[kCsSumStride], wrun);
   }
 }
-__global__ __launch_bounds__(kBlock) void k_terrain_contacts(TerrainContacts A) { terrain_contacts_job(A, blockIdx.x, gridDim.x); }
+template <bool GEN>
+__global__ __launch_bounds__(kBlock) void k_terrain_contacts(TerrainContacts A) { terrain_contacts_job<GEN>(A, blockIdx.x, gridDim.x); }
 // ... as the last `tc_blocks` blocks of the leaf scatter's launch (both follow k_integrate, neither needs the other: the few waves of the
 // sphere-triangle tests - a resting sphere against the floor's other triangle runs three ray-capsule tests, ~15 us of one lane's
 // arithmetic - hide behind the streaming kernel instead of taking a launch of their own)
+template <bool GEN>
 __global__ __launch_bounds__(kBlock) void k_scatter_leaves_tc(Lbvh T, const float4* fb_c, const float4* fb_r, const uint32_t* cell_of,
                                                               const uint32_t* rank, uint32_t* brank, const float4* col0, const float4* delta, const float4* tb_c,
                                                               const float4* tb_r, const SceneBounds* sb, float pad_abs, float min_frac, TerrainContacts A, uint32_t tc_blocks,
                                                               const SceneBounds* box) {
-  if (blockIdx.x < tc_blocks) { terrain_contacts_job(A, blockIdx.x, tc_blocks); return; }  // (first: they take longest)
+  if (blockIdx.x < tc_blocks) { terrain_contacts_job<GEN>(A, blockIdx.x, tc_blocks); return; }  // (first: they take longest)
   scatter_leaf((blockIdx.x - tc_blocks) * kBlock + threadIdx.x, T, fb_c, fb_r, cell_of, rank, brank, col0, delta, tb_c, tb_r, sb, pad_abs, min_frac, box);
 }
 struct ContactsSpheres {
@@ -887,7 +919,17 @@ __device__ __attribute__((noinline)) void cs_list_row_again(const uint32_t* rp, 
                                                             uint32_t* s_j, uint16_t* s_b) {
   cs_list_row(rp, np, ext, first, w0, owner, s_j, s_b);
 }
-__global__ __launch_bounds__(kBlock) void k_contacts_spheres(Bodies B, TerrainDev M, ContactsSpheres A) {
+// the collider of a body of the rows from its packed copy: SPH = a world of spheres only (word 1 is not read)
+template <bool SPH>
+__device__ __forceinline__ Comp pack_comp(const Bodies& B, uint32_t i, const BodyPack& P) {
+  Comp X; X.p = xyz(P.c0); X.r = P.c0.w; X.d = mk3(0.0f, 0.0f, 0.0f); X.kind = KIND_SPHERE;
+  if (!SPH) { const float4 c1 = B.bpk ? B.bpk[4 * (size_t)i + 3] : B.col1[i]; X.d = xyz(c1); X.kind = (int)f2u(c1.w); }
+  return X;
+}
+// SPH = false (r06): the rows of a world of any single-component kinds (k_pair_grid_n lists contacts only, k_terrain_near / k_terrain_contacts<true>
+// park the terrain contacts): the same kernel with the colliders' kinds read from the bodies.
+template <bool SPH>
+__global__ __launch_bounds__(kBlock) void k_contacts_rows(Bodies B, TerrainDev M, ContactsSpheres A) {
   __shared__ float4 s_w[kBlock / 64][7 * 65];  // a wave's records on their way out (see k_setup_pairs)
   __shared__ uint32_t s_c[kBlock / 64][64];
   __shared__ uint32_t s_j[kCsEntCap];           // the pass's partner contacts in canonical order: partner ...
@@ -946,12 +988,10 @@ __global__ __launch_bounds__(kBlock) void k_contacts_spheres(Bodies B, TerrainDe
       if (e < m) {
         const uint32_t b = s_b[e], j = s_j[e], ia = i0 + b;
         const BodyPack Pa = load_pack(B, ia, true), Pb = load_pack(B, j, true);
-        Comp Xa, Xb;  // as k_narrow_pairs<0, 0>
-        Xa.p = xyz(Pa.c0); Xa.r = Pa.c0.w; Xa.d = mk3(0.0f, 0.0f, 0.0f); Xa.kind = KIND_SPHERE;
-        Xb.p = xyz(Pb.c0); Xb.r = Pb.c0.w; Xb.d = mk3(0.0f, 0.0f, 0.0f); Xb.kind = KIND_SPHERE;
+        const Comp Xa = pack_comp<SPH>(B, ia, Pa), Xb = pack_comp<SPH>(B, j, Pb);  // as k_narrow_pairs<KA, KB>
         LocalContact lc;
         if (!comp_pair_local(Xa, xyz(Pa.dl), Xb, xyz(Pb.dl), &lc)) {
-          *A.flag = 1u;  // the broadphase's sphere test and this one disagree about a contact
+          *A.flag = 1u;  // the broadphase's pair test and this one disagree about a contact
         } else {
           const V3 nrm = (mk3(0.0f, 0.0f, 0.0f) + lc.g.n) / 1.0f;  // Manifold::from(pruner) of one contact (manifold.rs:135-140)
           const BodyDyn Ad = load_dyn(B.srec, ia), Bd = load_dyn(B.srec, j);

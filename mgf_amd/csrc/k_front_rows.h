@@ -1,0 +1,357 @@
+// The list-free front end for worlds that are NOT spheres only (r06): capsules, mixed worlds of single-component bodies.
+// (Part of the kernel set described in kernels.h.)
+//
+// What the spheres got in round 5 - rows that hold CONTACTS, a scan of the bodies' constraint counts, records written straight from the
+// rows (k_contacts_rows) - for every single-component kind.  The tick of such a world used to build candidate lists in CSR form
+// (k_scan<2>, k_rows_to_csr), run one narrowphase launch per shape-pair type over them, count (k_count_contacts), scan and set up
+// (k_setup_pairs): on BASELINE config 3 (131 072 capsules over a 49 928-triangle heightfield) 165 us of list plumbing that nothing
+// downstream reads.  Here:
+//   k_near_list        the bodies whose tight box can reach a face of the static mesh at all (Mesh::contacts returns at the root of its
+//                      tree for the others, bvh.rs:283-297): a compact list - one body in sixteen of a pile lies on the floor;
+//   k_terrain_near<L>  L lanes per listed body: the face grid's cells (k_terrain_grid's search, the work dealt by FACE RECORD, not by
+//                      cell), the hits sorted into the reference's DFS order in LDS, then a lane per hit through the body-triangle test
+//                      (collision.rs:610-1086); the contacts are parked in the terrain list's slots exactly as k_terrain_contacts parks
+//                      the spheres' (tcn / tpos / t_cnt per body);
+//   k_pair_grid_n      k_pair_grid's search; the accepted partners pass the conservative bounding-sphere test by the query's own eight
+//                      lanes, the survivors of the block's 64 queries are POOLED and go through the pair test (collision.rs:1089-1356)
+//                      a lane each - the branchy capsule code runs in one or two full waves per block instead of in every wave with a
+//                      lane or two active; the rows hold contacts only;
+//   k_scan<1> (+ tcn)  base = exclusive prefix of p_cnt + tcn, the tick's counts in its epilogue (caps_contacts);
+//   k_contacts_rows<false>  (k_contacts.h) ContactConstraint::new from the rows, the pair test evaluated once more for the contacts.
+// Results are those of the list-based kernels bit for bit: the same device functions on the same inputs, the same insertion order
+// (terrain contacts in Mesh::contacts' order, then partners by ascending order id).
+#pragma once
+#include "k_contacts.h"
+
+namespace mgf {
+
+// ---- bodies near the static mesh -------------------------------------------------------------------------------------------------
+// (the test k_terrain_grid opens with: a query that ends before the first face box or starts behind the last one on any axis)
+__global__ __launch_bounds__(kBlock) void k_near_list(const float4* tb_c, const float4* tb_r, uint32_t n_owned, TerrainDev M, const SceneBounds* gsb,
+                                                      float pad_abs, uint32_t* near_ids, uint32_t* near_cnt, const uint32_t* guard) {
+  __shared__ uint32_t s_n, s_base;
+  if (*guard) return;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  bool near = false;
+  if (i < n_owned) {
+    const V3 qc = xyz(tb_c[i]) + -mk3(M.x[0], M.x[1], M.x[2]), qr = xyz(tb_r[i]);
+    const float pad = pad_abs + 1e-5f * (fabs_rs(qc.x) + fabs_rs(qc.y) + fabs_rs(qc.z) + qr.x + qr.y + qr.z);
+    near = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float lo = ord_f(gsb->lo[k]), hi = ord_f(gsb->hi[k]), rm = ord_f(gsb->rmax[k]);
+      const float a = at(qc, k) - at(qr, k) - rm - pad, b = at(qc, k) + at(qr, k) + rm + pad;
+      near = near && !(b < lo || a > hi);
+    }
+  }
+  const unsigned long long mask = __ballot(near);
+  const int lane = threadIdx.x & 63;
+  uint32_t wbase = 0;
+  if (lane == 0 && mask) wbase = atomicAdd(&s_n, (uint32_t)__popcll(mask));
+  wbase = __shfl(wbase, 0);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_n) s_base = atomicAdd(near_cnt, s_n);
+  __syncthreads();
+  if (near) near_ids[s_base + wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = i;
+}
+
+// ---- terrain search + body-triangle narrowphase of the listed bodies ----------------------------------------------------------------
+constexpr uint32_t kTnHitCap = 128;  // faces a body's query may accept (more: the flag goes up and the host takes the list-based kernels)
+struct TerrainNear {
+  TerrainDev M; FaceGrid G;
+  const uint32_t* near_ids; const uint32_t* near_cnt;
+  const uint32_t* face_of_rank;
+  float pad_abs; uint32_t cap_t;
+  uint32_t* sums;      // [0] accepted faces = slot allocator (World::step's terrain candidates), [kCsSumStride] contacts
+  NContact* t_out;     // 2 per slot; .lb.w of the first = the face's contact count
+  uint32_t *tcn, *tpos, *t_cnt;
+  uint32_t *overflow, *too_wide;
+  const uint32_t* guard;
+};
+template <int L>
+__global__ __launch_bounds__(kBlock) void k_terrain_near(Bodies B, TerrainNear A) {
+  static_assert(L == 16 || L == 32 || L == 64, "a group is a power-of-two part of a wave");
+  constexpr int NG = kBlock / L;
+  constexpr int kPer = (int)kTnHitCap / L;  // hits per lane when a group's list is full
+  __shared__ uint32_t s_hits[NG][kTnHitCap];
+  __shared__ uint32_t s_p0[NG][L], s_pre[NG][L + 1];
+  __shared__ uint32_t s_cnt[NG], s_tp[NG];
+  __shared__ uint32_t s_con;
+  const uint32_t Ltot = *A.guard ? 0u : *A.near_cnt;
+  const int t = threadIdx.x, g = t / L, s = t % L, lane = t & 63;
+  const int gshift = lane & ~(L - 1);
+  const unsigned long long gmask = L == 64 ? ~0ull : ((1ull << (L & 63)) - 1ull);
+  const V3 mx = mk3(A.M.x[0], A.M.x[1], A.M.x[2]);
+  const uint32_t nb[3] = {A.G.bits.x, A.G.bits.y, A.G.bits.z};
+  for (uint32_t e0 = blockIdx.x * (uint32_t)NG; e0 < Ltot; e0 += gridDim.x * (uint32_t)NG) {  // (the same trips for every thread of the block)
+    if (t < NG) s_cnt[t] = 0u;
+    if (t == 0) s_con = 0u;
+    __syncthreads();
+    const uint32_t e = e0 + (uint32_t)g;
+    const bool live = e < Ltot;
+    const uint32_t i = live ? A.near_ids[e] : 0u;
+    V3 vA = mk3(0, 0, 0);
+    Comp Ac; Ac.kind = KIND_SPHERE; Ac.p = mk3(0, 0, 0); Ac.d = mk3(0, 0, 0); Ac.r = 0.0f;
+    if (live) {
+      Ac = load_comp_moving(B, i, &vA);
+      // ---- Mesh::contacts' BVH::query by cell enumeration (k_terrain_grid), a lane per face record
+      Box q; q.c = xyz(B.tb_c[i]) + -mx; q.r = xyz(B.tb_r[i]);
+      const float mag = fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z;
+      const float pad = A.pad_abs + 1e-5f * mag;
+      uint32_t ca[3], d[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float lo = ord_f(A.G.sb->lo[k]), hi = ord_f(A.G.sb->hi[k]), rm = ord_f(A.G.sb->rmax[k]);
+        const float a = at(q.c, k) - at(q.r, k) - rm - pad, b = at(q.c, k) + at(q.r, k) + rm + pad;
+        const uint32_t c0 = morton_quant(a, lo, hi) >> (10u - nb[k]), c1 = morton_quant(b, lo, hi) >> (10u - nb[k]);
+        ca[k] = c0; d[k] = c1 - c0 + 1u;
+      }
+      const uint32_t ncell = d[0] * d[1] * d[2];
+      if (ncell > kGridMaxCells) {
+        if (s == 0) *A.too_wide = 1u;
+      } else {
+        for (uint32_t cb = 0; cb < ncell; cb += (uint32_t)L) {  // (the group's lanes move together)
+          const uint32_t idx = cb + (uint32_t)s;
+          uint32_t p0 = 0, cnt = 0;
+          if (idx < ncell) {
+            const uint32_t cz = idx % d[2], tt = idx / d[2];
+            const uint32_t cy = tt % d[1], cx = tt / d[1];
+            const uint32_t cell = face_cell(ca[0] + cx, ca[1] + cy, ca[2] + cz, A.G.bits);
+            p0 = A.G.T.cell_lo[cell]; cnt = A.G.T.cell_lo[cell + 1] - p0;
+          }
+          uint32_t inc = cnt;
+#pragma unroll
+          for (int o = 1; o < L; o <<= 1) { const uint32_t u = __shfl_up(inc, o, L); if (s >= o) inc += u; }
+          const uint32_t total = __shfl(inc, L - 1, L);
+          s_p0[g][s] = p0; s_pre[g][s + 1] = inc;
+          if (s == 0) s_pre[g][0] = 0u;
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (a wave's LDS accesses are served in order; the group reads what it wrote)
+          for (uint32_t m = (uint32_t)s; m < total; m += (uint32_t)L) {
+            int c = 0;  // the cell of record m: the last c with s_pre[c] <= m
+#pragma unroll
+            for (int step = L / 2; step >= 1; step >>= 1) if (c + step < L && s_pre[g][c + step] <= m) c += step;
+            const uint32_t p = s_p0[g][c] + (m - s_pre[g][c]);
+            const LeafRec lr = A.G.T.leaves[p];
+            const uint32_t face = f2u(lr.c.w);
+            Box fb; fb.c = xyz(lr.c); fb.r = xyz(lr.r);
+            if (!box_overlaps(q, fb)) continue;  // the reference's acceptance test at the leaf (bvh.rs:297)
+            bool hit = true;
+            // a hit within rounding distance of not overlapping: the reference only reaches a leaf through its ancestors (see k_terrain_grid)
+            const float gap = fmin_rs(fmin_rs(q.r.x + fb.r.x - fabs_rs(q.c.x - fb.c.x), q.r.y + fb.r.y - fabs_rs(q.c.y - fb.c.y)),
+                                      q.r.z + fb.r.z - fabs_rs(q.c.z - fb.c.z));
+            const float tol = 1e-4f * (mag + fabs_rs(fb.c.x) + fabs_rs(fb.c.y) + fabs_rs(fb.c.z) + fb.r.x + fb.r.y + fb.r.z);
+            if (!(gap > tol)) {
+              uint32_t node = A.G.leaf_of_face[face];
+              while (node != A.M.root) {
+                node = A.G.parent[node];
+                const float4* raw = reinterpret_cast<const float4*>(&A.M.nodes[node]);
+                Box nbx; nbx.c = xyz(raw[0]); nbx.r = xyz(raw[1]);
+                if (!box_overlaps(q, nbx)) { hit = false; break; }
+                const float ga = fmin_rs(fmin_rs(q.r.x + nbx.r.x - fabs_rs(q.c.x - nbx.c.x), q.r.y + nbx.r.y - fabs_rs(q.c.y - nbx.c.y)),
+                                         q.r.z + nbx.r.z - fabs_rs(q.c.z - nbx.c.z));
+                const float ta = 1e-4f * (mag + fabs_rs(nbx.c.x) + fabs_rs(nbx.c.y) + fabs_rs(nbx.c.z) + nbx.r.x + nbx.r.y + nbx.r.z);
+                if (ga > ta) break;
+              }
+            }
+            if (hit) {
+              const uint32_t pos = atomicAdd(&s_cnt[g], 1u);
+              if (pos < kTnHitCap) s_hits[g][pos] = A.G.rank_of_face[face];
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next chunk overwrites the tables)
+        }
+      }
+    }
+    __syncthreads();
+    // ---- the hits into the reference's callback order (DFS ranks are distinct: a hit's place = the smaller ranks of its list)
+    uint32_t H = s_cnt[g];
+    if (H > kTnHitCap) { if (s == 0) atomicOr(A.overflow, 2u); H = 0u; }
+    uint32_t rk[kPer], at_[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const uint32_t a = (uint32_t)(u * L + s);
+      rk[u] = 0u; at_[u] = 0u;
+      if (a < H) {
+        rk[u] = s_hits[g][a];
+        uint32_t before = 0;
+        for (uint32_t b = 0; b < H; ++b) before += s_hits[g][b] < rk[u] ? 1u : 0u;
+        at_[u] = before;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) if ((uint32_t)(u * L + s) < H) s_hits[g][at_[u]] = rk[u];
+    if (t == 0) {  // the block's slots with ONE atomic
+      uint32_t total = 0;
+      for (int k = 0; k < NG; ++k) { const uint32_t h = s_cnt[k] > kTnHitCap ? 0u : s_cnt[k]; s_tp[k] = total; total += h; }
+      const uint32_t base = total ? atomicAdd(&A.sums[0], total) : 0u;
+      for (int k = 0; k < NG; ++k) s_tp[k] += base;
+    }
+    __syncthreads();
+    // ---- a lane per hit through the body-triangle test; the faces that report contacts parked in the body's slots, in order
+    const uint32_t tp = s_tp[g];
+    uint32_t Hw = H;
+#pragma unroll
+    for (int o = L; o < 64; o <<= 1) Hw = max(Hw, (uint32_t)__shfl_xor((int)Hw, o));  // (the wave's groups walk the loop together: ballots)
+    uint32_t kf = 0, ncon = 0;
+    for (uint32_t a0 = 0; a0 < Hw; a0 += (uint32_t)L) {
+      const uint32_t a = a0 + (uint32_t)s;
+      int nc = 0;
+      LocalContact lc[2];
+      if (a < H) {
+        const uint32_t f = A.face_of_rank[s_hits[g][a]];
+        const uint4 fi = A.M.faces[f];
+        const Triangle tri = mkt(xyz(A.M.verts[fi.x]) + mx, xyz(A.M.verts[fi.y]) + mx, xyz(A.M.verts[fi.z]) + mx);  // mesh.rs:122-126
+        nc = comp_tri_local(Ac, vA, tri, mx, lc);
+      }
+      const unsigned long long m1 = (__ballot(nc >= 1) >> gshift) & gmask, m2 = (__ballot(nc == 2) >> gshift) & gmask;
+      if (nc) {
+        const uint32_t slot = tp + kf + (uint32_t)__popcll(m1 & ((1ull << s) - 1ull));
+        if (slot < A.cap_t) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            if (k < nc) {  // Manifold::from(lc) manifold.rs:120-128
+              NContact o; o.la = mk4(lc[k].la, lc[k].g.t); o.lb = mk4(lc[k].lb, k == 0 ? u2f((uint32_t)nc) : 0.0f); o.n = mk4(lc[k].g.n, 0.0f);
+              A.t_out[2 * (size_t)slot + k] = o;
+            }
+          }
+        }
+      }
+      kf += (uint32_t)__popcll(m1); ncon += (uint32_t)(__popcll(m1) + __popcll(m2));
+    }
+    if (live && s == 0) {
+      A.tcn[i] = ncon;  // the body's terrain constraints come first in its range (k_chain_rows)
+      A.tpos[i] = tp;
+      A.t_cnt[i] = kf;  // the faces parked
+      if (ncon) atomicAdd(&s_con, ncon);
+    }
+    __syncthreads();
+    if (t == 0 && s_con) atomicAdd(&A.sums[kCsSumStride], s_con);
+  }
+}
+
+// ---- pair search with the narrowphase of any single-component pair in it ---------------------------------------------------------------
+// (pair_query_cells<false>'s first phase with the accepted partners staged in LDS)
+template <class Src>
+__device__ __forceinline__ uint32_t pair_query_accept(const Src& S, const Box& q, uint32_t oi, uint32_t n_owned, const uint32_t* ca, const uint32_t* d,
+                                                      const uint32_t* nb, int shift, int sub, int gbase, uint32_t* acc) {
+  const uint32_t ncell = d[0] * d[1] * d[2];
+  const uint32_t m2 = ((1u << 20) + d[2] - 1u) / d[2], m1 = ((1u << 20) + d[1] - 1u) / d[1];
+  uint32_t np = 0;
+  for (uint32_t cb = 0; cb < ncell; cb += kCoopLanes) {
+    const uint32_t idx = cb + (uint32_t)sub;
+    uint32_t p0 = 0, p1 = 0;
+    if (idx < ncell) {
+      const uint32_t t = (idx * m2) >> 20, cz = idx - t * d[2];
+      const uint32_t cx = (t * m1) >> 20, cy = t - cx * d[1];
+      const uint32_t cc3[3] = {ca[0] + cx, ca[1] + cy, ca[2] + cz};
+      const uint32_t code = (expand10(cc3[0] << (10u - nb[0])) << 2) | (expand10(cc3[1] << (10u - nb[1])) << 1) | expand10(cc3[2] << (10u - nb[2]));
+      S.range(code >> shift, cc3, p0, p1);
+    }
+    for (;;) {
+      const bool more = p0 < p1;
+      const unsigned long long mb = __ballot(more);
+      if (((uint32_t)(mb >> gbase) & 255u) == 0u) break;
+      bool hit = false;
+      uint32_t j = 0;
+      if (more) {
+        float4 lc, lr;
+        S.leaf(p0, lc, lr);
+        j = f2u(lc.w);
+        if (f2u(lr.w) < oi && j < n_owned) {  // world.rs:266; ghost-ghost skipped
+          Box fb; fb.c = xyz(lc); fb.r = xyz(lr);
+          hit = box_overlaps(q, fb);  // the reference's own acceptance test (bvh.rs:297)
+        }
+        ++p0;
+      }
+      const uint32_t gm = (uint32_t)(__ballot(hit) >> gbase) & 255u;
+      if (hit) {
+        const uint32_t slot = np + __popc(gm & ((1u << sub) - 1u));
+        if (slot < (uint32_t)kRowCap) acc[slot] = j;
+      }
+      np += __popc(gm);
+    }
+  }
+  return np;
+}
+constexpr uint32_t kPnQueries = kCoopBlock / kCoopLanes;  // 64 queries per block
+__global__ __launch_bounds__(kCoopBlock) void k_pair_grid_n(Bodies B, uint32_t n, uint32_t n_owned, Lbvh T, const SceneBounds* sb, float pad_abs, uint32_t* rows_p,
+                                                            uint32_t* p_cnt, uint32_t* overflow, uint32_t* too_wide, uint32_t* pair_stat, float min_frac) {
+  __shared__ uint32_t s_acc[kPnQueries][kRowCap];   // accepted partners of a query (body slots)
+  __shared__ uint32_t s_pool[kPnQueries * kRowCap]; // the block's partners that may touch: partner slot | query << 26
+  __shared__ uint32_t s_qi[kPnQueries], s_np[kPnQueries];
+  __shared__ uint32_t s_pool_n, s_sum;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7;
+  const int gbase = lane & ~7;
+  const uint32_t qg = threadIdx.x >> 3;
+  const uint32_t kq = xcd_logical_block_coop() * kPnQueries + qg;
+  const bool live = kq < n;  // whole groups are live or not
+  const uint32_t i = live ? T.sidx[kq] : 0u;
+  if (threadIdx.x == 0) { s_pool_n = 0u; s_sum = 0u; }
+  if (sub == 0) { s_qi[qg] = i; s_np[qg] = 0u; }
+  __syncthreads();
+  uint32_t n_accepted = 0;
+  const uint32_t oi = live ? order_id(T.ext, i) : 0u;
+  if (live && oi != 0 && T.n >= 2) {  // world.rs:256
+    Box q;
+    uint32_t ca[3], d[3];
+    const uint32_t P = 2u * T.levels;
+    const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};  // prefix bits per axis (x is the most significant)
+    if (T.ltb) {  // the query in cell order, its cells worked out by k_scatter_leaves
+      const float4 qc = T.ltb[2 * kq], qr = T.ltb[2 * kq + 1];
+      q.c = xyz(qc); q.r = xyz(qr);
+      const uint32_t ra = f2u(qc.w), rd = f2u(qr.w);
+      ca[0] = ra & 1023u; ca[1] = (ra >> 10) & 1023u; ca[2] = ra >> 20;
+      d[0] = rd & 1023u; d[1] = (rd >> 10) & 1023u; d[2] = rd >> 20;
+    } else {
+      q.c = xyz(B.tb_c[i]); q.r = xyz(B.tb_r[i]);
+      const float pad = pad_abs + 1e-5f * (fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z);
+      pair_query_region(q.c, q.r, pad, sb, nb, ca, d, min_frac);
+    }
+    if (d[0] * d[1] * d[2] > kGridMaxCells) {
+      if (sub == 0) *too_wide = 1u;
+    } else {
+      PairSrcGlobal S; S.T = T;
+      n_accepted = pair_query_accept(S, q, oi, n_owned, ca, d, nb, kMortonBits - (int)P, sub, gbase, s_acc[qg]);
+      if (n_accepted > (uint32_t)kRowCap && sub == 0) atomicOr(overflow, 1u);
+      // the accepted partners whose bounding spheres come within reach during the tick (comp_pair_far: nine in ten of a pile do not)
+      // join the block's pool
+      const uint32_t na = min(n_accepted, (uint32_t)kRowCap);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the group reads the staging row its lanes wrote)
+      if (na) {
+        V3 vA;
+        const Comp A = load_comp_moving(B, i, &vA);
+        for (uint32_t a = (uint32_t)sub; a < na; a += kCoopLanes) {
+          const uint32_t j = s_acc[qg][a];
+          V3 vB;
+          const Comp Bc = load_comp_moving(B, j, &vB);
+          if (!comp_pair_far(A, vA, Bc, vB)) s_pool[atomicAdd(&s_pool_n, 1u)] = j | (qg << 26);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- the pool through the pair test, a lane each: contacts go to their query's row
+  const uint32_t pool_n = s_pool_n;
+  for (uint32_t e = threadIdx.x; e < pool_n; e += kCoopBlock) {
+    const uint32_t w = s_pool[e], j = w & 0x03FFFFFFu, g2 = w >> 26, ia = s_qi[g2];
+    V3 vA, vB;
+    const Comp A = load_comp_moving(B, ia, &vA), Bc = load_comp_moving(B, j, &vB);
+    LocalContact lc;
+    if (comp_pair_local(A, vA, Bc, vB, &lc)) rows_p[(size_t)ia * kRowCap + atomicAdd(&s_np[g2], 1u)] = j;
+  }
+  {  // accepted partners (World::step's candidate statistic): one atomic per block, spread over many words
+    uint32_t v = (live && sub == 0) ? n_accepted : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0 && v) atomicAdd(&s_sum, v);
+  }
+  __syncthreads();
+  if (live && sub == 0) p_cnt[i] = s_np[qg];
+  if (threadIdx.x == 0 && s_sum) atomicAdd(&pair_stat[blockIdx.x & (kPairStatWords - 1u)], s_sum);
+}
+
+}  // namespace mgf

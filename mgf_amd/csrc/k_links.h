@@ -1,6 +1,6 @@
 // Order-preserving dependency links of a constraint list and the launch-per-frontier solver (mode 0).  (Part of the kernel set described in kernels.h.)
 #pragma once
-#include "k_contacts.h"
+#include "k_front_rows.h"
 
 namespace mgf {
 
