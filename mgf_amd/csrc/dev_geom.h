@@ -658,6 +658,35 @@ __device__ inline int comp_tri_local(const Comp& A, V3 vA, const Triangle& tri, 
   return comp_tri_local_at(A, vA, tri, mesh_center, comp_center(A), out);
 }
 
+// A cheap conservative reject before the reference's body-triangle tests (collision.rs:610-1086), as comp_pair_far is for pairs.  Every
+// contact those tests report - the axis crossing the face (:698-719), the end spheres' plane contacts inside the face (:723-764), the
+// silhouette clipped against the edges (:767-890), the Minkowski faces, edge and vertex capsules (:901-1060), the sphere's plane contact
+// and edge capsules (:610-659) - is a touching, at some t in [0, 1] of the body's motion, of the body's axis (a sphere: its centre)
+// inflated by r with a point OF THE TRIANGLE.  The triangle lies on the inner side of the plane through each of its edges perpendicular
+// to the face, and in the face's plane: a body whose axis end points are both further than r + |v| (1 % and a millimetre for rounding)
+// beyond one of those four planes, on the same side, never touches it.  The candidates that fail here are the ones that would have
+// walked through every branch of tri_mcapsule to report nothing.
+__device__ __forceinline__ bool comp_tri_far(const Comp& A, V3 vA, const Triangle& tri) {
+  const V3 p0 = A.p, p1 = A.kind == KIND_SPHERE ? A.p : A.p + A.d;
+  const float lim = (A.r + mag(vA)) * 1.01f + 1e-3f;
+  const V3 e0 = tri.b - tri.a, e1 = tri.c - tri.b, e2 = tri.a - tri.c;
+  const V3 n = cross(e0, tri.c - tri.a);
+  const float nn = dot(n, n);
+  if (!(nn > 0.0f)) return false;  // (a degenerate face: the reference's tests decide)
+  {
+    const float l = lim * __builtin_sqrtf(nn);
+    const float d0 = dot(p0 - tri.a, n), d1 = dot(p1 - tri.a, n);
+    if ((d0 > l && d1 > l) || (d0 < -l && d1 < -l)) return true;
+  }
+  // cross(edge, n) points away from the triangle whatever its winding (n turns with it)
+  const V3 m0 = cross(e0, n), m1 = cross(e1, n), m2 = cross(e2, n);
+  const float l0 = lim * __builtin_sqrtf(dot(m0, m0)), l1 = lim * __builtin_sqrtf(dot(m1, m1)), l2 = lim * __builtin_sqrtf(dot(m2, m2));
+  if (dot(p0 - tri.a, m0) > l0 && dot(p1 - tri.a, m0) > l0) return true;
+  if (dot(p0 - tri.b, m1) > l1 && dot(p1 - tri.b, m1) > l1) return true;
+  if (dot(p0 - tri.c, m2) > l2 && dot(p1 - tri.c, m2) > l2) return true;
+  return false;
+}
+
 // compute_basis geom.rs:1138-1145
 HD void compute_basis(V3 n, V3* t0, V3* t1) {
   V3 b = (fabs_rs(n.x) >= 0.57735f) ? mk3(n.y, -n.x, 0.0f) : mk3(0.0f, n.z, -n.y);

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void k_morton_count(const float4* fb_c, uin
 }
 
 // Zero several small arrays with one launch (instead of one fill kernel each).
-constexpr int kZeroSlots = 20;
+constexpr int kZeroSlots = 22;
 struct ZeroList { uint32_t* p[kZeroSlots]; uint32_t words[kZeroSlots]; SceneBounds* sb; const int* sb_part; };
 // one array of the list, by the whole grid: 16 bytes per lane where the array allows (the per-body arrays are a megabyte each)
 __device__ __forceinline__ void zero_words(uint32_t* p, uint32_t words) {
@@ -192,6 +192,7 @@ struct ScanEpilogue {
   const uint32_t *row_overflow, *grid_wide, *terrain_wide, *guard;  // kinds 1, 3 (each may be null but guard)
   StepCounts* sc;
   const uint32_t *sum_t, *sum_ct; // kind 3: terrain candidates and terrain contacts (k_terrain_contacts' counters)
+  uint32_t sum_t_parts, sum_t_stride;  // kind 3: the terrain candidates are the sum of this many partial counts, that many words apart (0: the one word)
 };
 __device__ __forceinline__ void caps_candidates(const ScanEpilogue& E, uint32_t mt, uint32_t mp) {
   StepCounts r;
@@ -212,12 +213,16 @@ __device__ __forceinline__ void caps_candidates(const ScanEpilogue& E, uint32_t 
 // k_terrain_contacts): the tick's counts in one go
 __device__ __forceinline__ void caps_contacts(const ScanEpilogue& E, uint32_t c) {
   StepCounts r;
-  const uint32_t mt = *E.sum_t, ct = *E.sum_ct;
+  uint32_t mt = *E.sum_t;
+  for (uint32_t k = 1; k < E.sum_t_parts; ++k) mt += E.sum_t[(size_t)k * E.sum_t_stride];
+  const uint32_t ct = *E.sum_ct;
   r.need_Mt = mt; r.need_Mp = c - ct; r.need_C = c; r.need_Ct = ct;
   r.fail = 0;
+  if (E.row_overflow && (*E.row_overflow & 4u)) { r.fail |= kFailCandCap; r.need_Mt = max(mt, 2u * E.cap_a); }  // (k_terrain_near: a region of the slots ran full)
   if (E.row_overflow && (*E.row_overflow & 1u)) r.fail |= kFailRowOverflow;
   if (E.row_overflow && (*E.row_overflow & 2u)) r.fail |= kFailTerrainRow;
   if (E.grid_wide && *E.grid_wide) r.fail |= kFailGridWide;
+  if (E.terrain_wide && *E.terrain_wide) r.fail |= kFailTerrainWide;
   if (*E.guard) r.fail |= kFailSkipped;
   if (!r.fail && mt > E.cap_a) r.fail |= kFailCandCap;
   if (!r.fail && c > E.cap_b) r.fail |= kFailConsCap;

@@ -808,7 +808,7 @@ __device__ __forceinline__ void terrain_contacts_job(const TerrainContacts& A, u
           const Triangle tri = staged ? mkt(xyz(s_vert[fi.x]) + mx, xyz(s_vert[fi.y]) + mx, xyz(s_vert[fi.z]) + mx)
                                       : mkt(xyz(M.verts[fi.x]) + mx, xyz(M.verts[fi.y]) + mx, xyz(M.verts[fi.z]) + mx);  // mesh.rs:122-126
           LocalContact lc[2];
-          const int nc = comp_tri_local(Ca, vA, tri, mx, lc);
+          const int nc = comp_tri_far(Ca, vA, tri) ? 0 : comp_tri_local(Ca, vA, tri, mx, lc);
           if (tp + a < cap_t) {
             NContact o;
             o.la = make_float4(0, 0, 0, 0); o.lb = make_float4(0, 0, 0, u2f(0u)); o.n = make_float4(0, 0, 0, 0);

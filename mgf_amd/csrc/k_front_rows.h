@@ -59,35 +59,38 @@ __global__ __launch_bounds__(kBlock) void k_near_list(const float4* tb_c, const 
 
 // ---- terrain search + body-triangle narrowphase of the listed bodies ----------------------------------------------------------------
 constexpr uint32_t kTnHitCap = 128;  // faces a body's query may accept (more: the flag goes up and the host takes the list-based kernels)
+// The slots of the tick are handed out from kTnRegions counters, a block uses the one of its XCD (blockIdx & 7): one counter for all
+// cost the launch 13 ns per workgroup (returning atomics on one word serialise) - 2 500 of them - however short the blocks' own work.
+constexpr uint32_t kTnRegions = 8, kTnCntStride = 32;  // (words between counters: a cache line)
+constexpr uint32_t kTnFarBit = 0x40000000u;  // a hit that comp_tri_far rejects (DFS ranks are below 2^30)
 struct TerrainNear {
   TerrainDev M; FaceGrid G;
   const uint32_t* near_ids; const uint32_t* near_cnt;
   const uint32_t* face_of_rank;
   float pad_abs; uint32_t cap_t;
-  uint32_t* sums;      // [0] accepted faces = slot allocator (World::step's terrain candidates), [kCsSumStride] contacts
-  NContact* t_out;     // 2 per slot; .lb.w of the first = the face's contact count
-  uint32_t *tcn, *tpos, *t_cnt;
+  uint32_t* cnt;       // kTnRegions slot counters and as many partial counts of the accepted faces (World::step's terrain candidates), a cache line each
+  uint32_t region_cap; // slots per region
+  uint32_t *slot_body, *slot_rank;  // per slot: the body and the face's DFS rank (k_terrain_tests)
+  uint32_t *tpos, *t_cnt;
   uint32_t *overflow, *too_wide;
   const uint32_t* guard;
+  uint32_t check;      // tests: 1 = the rejected hits get slots too, marked kTnFarBit: k_terrain_tests raises a flag if one of them reports a contact
 };
 template <int L>
 __global__ __launch_bounds__(kBlock) void k_terrain_near(Bodies B, TerrainNear A) {
   static_assert(L == 16 || L == 32 || L == 64, "a group is a power-of-two part of a wave");
   constexpr int NG = kBlock / L;
   constexpr int kPer = (int)kTnHitCap / L;  // hits per lane when a group's list is full
-  __shared__ uint32_t s_hits[NG][kTnHitCap];
+  __shared__ uint32_t s_hits[NG][kTnHitCap], s_surv[NG][kTnHitCap];
   __shared__ uint32_t s_p0[NG][L], s_pre[NG][L + 1];
-  __shared__ uint32_t s_cnt[NG], s_tp[NG];
-  __shared__ uint32_t s_con;
+  __shared__ uint32_t s_cnt[NG], s_scnt[NG], s_tp[NG];
   const uint32_t Ltot = *A.guard ? 0u : *A.near_cnt;
-  const int t = threadIdx.x, g = t / L, s = t % L, lane = t & 63;
-  const int gshift = lane & ~(L - 1);
-  const unsigned long long gmask = L == 64 ? ~0ull : ((1ull << (L & 63)) - 1ull);
+  const int t = threadIdx.x, g = t / L, s = t % L;
   const V3 mx = mk3(A.M.x[0], A.M.x[1], A.M.x[2]);
   const uint32_t nb[3] = {A.G.bits.x, A.G.bits.y, A.G.bits.z};
+  // (blockIdx & 7 - the block's XCD - picks its region: the stride keeps a block in its region over its trips)
   for (uint32_t e0 = blockIdx.x * (uint32_t)NG; e0 < Ltot; e0 += gridDim.x * (uint32_t)NG) {  // (the same trips for every thread of the block)
-    if (t < NG) s_cnt[t] = 0u;
-    if (t == 0) s_con = 0u;
+    if (t < NG) { s_cnt[t] = 0u; s_scnt[t] = 0u; }
     __syncthreads();
     const uint32_t e = e0 + (uint32_t)g;
     const bool live = e < Ltot;
@@ -98,8 +101,8 @@ __global__ __launch_bounds__(kBlock) void k_terrain_near(Bodies B, TerrainNear A
       Ac = load_comp_moving(B, i, &vA);
       // ---- Mesh::contacts' BVH::query by cell enumeration (k_terrain_grid), a lane per face record
       Box q; q.c = xyz(B.tb_c[i]) + -mx; q.r = xyz(B.tb_r[i]);
-      const float mag = fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z;
-      const float pad = A.pad_abs + 1e-5f * mag;
+      const float mag_q = fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z;
+      const float pad = A.pad_abs + 1e-5f * mag_q;
       uint32_t ca[3], d[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -141,8 +144,12 @@ __global__ __launch_bounds__(kBlock) void k_terrain_near(Bodies B, TerrainNear A
             // a hit within rounding distance of not overlapping: the reference only reaches a leaf through its ancestors (see k_terrain_grid)
             const float gap = fmin_rs(fmin_rs(q.r.x + fb.r.x - fabs_rs(q.c.x - fb.c.x), q.r.y + fb.r.y - fabs_rs(q.c.y - fb.c.y)),
                                       q.r.z + fb.r.z - fabs_rs(q.c.z - fb.c.z));
-            const float tol = 1e-4f * (mag + fabs_rs(fb.c.x) + fabs_rs(fb.c.y) + fabs_rs(fb.c.z) + fb.r.x + fb.r.y + fb.r.z);
+            const float tol = 1e-4f * (mag_q + fabs_rs(fb.c.x) + fabs_rs(fb.c.y) + fabs_rs(fb.c.z) + fb.r.x + fb.r.y + fb.r.z);
+#if defined(MGF_TN_ABL) && MGF_TN_ABL == 1
+            if (false) {
+#else
             if (!(gap > tol)) {
+#endif
               uint32_t node = A.G.leaf_of_face[face];
               while (node != A.M.root) {
                 node = A.G.parent[node];
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void k_terrain_near(Bodies B, TerrainNear A
                 if (!box_overlaps(q, nbx)) { hit = false; break; }
                 const float ga = fmin_rs(fmin_rs(q.r.x + nbx.r.x - fabs_rs(q.c.x - nbx.c.x), q.r.y + nbx.r.y - fabs_rs(q.c.y - nbx.c.y)),
                                          q.r.z + nbx.r.z - fabs_rs(q.c.z - nbx.c.z));
-                const float ta = 1e-4f * (mag + fabs_rs(nbx.c.x) + fabs_rs(nbx.c.y) + fabs_rs(nbx.c.z) + nbx.r.x + nbx.r.y + nbx.r.z);
+                const float ta = 1e-4f * (mag_q + fabs_rs(nbx.c.x) + fabs_rs(nbx.c.y) + fabs_rs(nbx.c.z) + nbx.r.x + nbx.r.y + nbx.r.z);
                 if (ga > ta) break;
               }
             }
@@ -165,71 +172,115 @@ __global__ __launch_bounds__(kBlock) void k_terrain_near(Bodies B, TerrainNear A
       }
     }
     __syncthreads();
-    // ---- the hits into the reference's callback order (DFS ranks are distinct: a hit's place = the smaller ranks of its list)
+    // ---- the cheap reject on every hit (comp_tri_far), by the group's own lanes
     uint32_t H = s_cnt[g];
+#if defined(MGF_TN_ABL) && MGF_TN_ABL == 3
+    H = 0;
+#endif
     if (H > kTnHitCap) { if (s == 0) atomicOr(A.overflow, 2u); H = 0u; }
-    uint32_t rk[kPer], at_[kPer];
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
       const uint32_t a = (uint32_t)(u * L + s);
-      rk[u] = 0u; at_[u] = 0u;
       if (a < H) {
-        rk[u] = s_hits[g][a];
-        uint32_t before = 0;
-        for (uint32_t b = 0; b < H; ++b) before += s_hits[g][b] < rk[u] ? 1u : 0u;
-        at_[u] = before;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < kPer; ++u) if ((uint32_t)(u * L + s) < H) s_hits[g][at_[u]] = rk[u];
-    if (t == 0) {  // the block's slots with ONE atomic
-      uint32_t total = 0;
-      for (int k = 0; k < NG; ++k) { const uint32_t h = s_cnt[k] > kTnHitCap ? 0u : s_cnt[k]; s_tp[k] = total; total += h; }
-      const uint32_t base = total ? atomicAdd(&A.sums[0], total) : 0u;
-      for (int k = 0; k < NG; ++k) s_tp[k] += base;
-    }
-    __syncthreads();
-    // ---- a lane per hit through the body-triangle test; the faces that report contacts parked in the body's slots, in order
-    const uint32_t tp = s_tp[g];
-    uint32_t Hw = H;
-#pragma unroll
-    for (int o = L; o < 64; o <<= 1) Hw = max(Hw, (uint32_t)__shfl_xor((int)Hw, o));  // (the wave's groups walk the loop together: ballots)
-    uint32_t kf = 0, ncon = 0;
-    for (uint32_t a0 = 0; a0 < Hw; a0 += (uint32_t)L) {
-      const uint32_t a = a0 + (uint32_t)s;
-      int nc = 0;
-      LocalContact lc[2];
-      if (a < H) {
-        const uint32_t f = A.face_of_rank[s_hits[g][a]];
-        const uint4 fi = A.M.faces[f];
+        const uint32_t rank = s_hits[g][a];
+        const uint4 fi = A.M.faces[A.face_of_rank[rank]];
         const Triangle tri = mkt(xyz(A.M.verts[fi.x]) + mx, xyz(A.M.verts[fi.y]) + mx, xyz(A.M.verts[fi.z]) + mx);  // mesh.rs:122-126
-        nc = comp_tri_local(Ac, vA, tri, mx, lc);
+#if defined(MGF_TN_ABL) && MGF_TN_ABL == 2
+        if (false) s_hits[g][a] = rank | kTnFarBit;
+#else
+        if (comp_tri_far(Ac, vA, tri)) s_hits[g][a] = rank | kTnFarBit;
+#endif
       }
-      const unsigned long long m1 = (__ballot(nc >= 1) >> gshift) & gmask, m2 = (__ballot(nc == 2) >> gshift) & gmask;
-      if (nc) {
-        const uint32_t slot = tp + kf + (uint32_t)__popcll(m1 & ((1ull << s) - 1ull));
-        if (slot < A.cap_t) {
+    }
+    __syncthreads();
+    // ---- the survivors into the reference's callback order (DFS ranks are distinct: a hit's place = the smaller ranks among them)
+    const uint32_t keep_mask = A.check ? 0u : kTnFarBit;  // (check: the rejected hits stay in the list, marked)
 #pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            if (k < nc) {  // Manifold::from(lc) manifold.rs:120-128
-              NContact o; o.la = mk4(lc[k].la, lc[k].g.t); o.lb = mk4(lc[k].lb, k == 0 ? u2f((uint32_t)nc) : 0.0f); o.n = mk4(lc[k].g.n, 0.0f);
-              A.t_out[2 * (size_t)slot + k] = o;
-            }
-          }
+    for (int u = 0; u < kPer; ++u) {
+      const uint32_t a = (uint32_t)(u * L + s);
+      if (a < H) {
+        const uint32_t w = s_hits[g][a];
+        if (!(w & keep_mask)) {
+          const uint32_t r = w & ~kTnFarBit;
+          uint32_t before = 0;
+          for (uint32_t b = 0; b < H; ++b) { const uint32_t o = s_hits[g][b]; before += (!(o & keep_mask) && (o & ~kTnFarBit) < r) ? 1u : 0u; }
+          s_surv[g][before] = w;
+          atomicAdd(&s_scnt[g], 1u);
         }
       }
-      kf += (uint32_t)__popcll(m1); ncon += (uint32_t)(__popcll(m1) + __popcll(m2));
-    }
-    if (live && s == 0) {
-      A.tcn[i] = ncon;  // the body's terrain constraints come first in its range (k_chain_rows)
-      A.tpos[i] = tp;
-      A.t_cnt[i] = kf;  // the faces parked
-      if (ncon) atomicAdd(&s_con, ncon);
     }
     __syncthreads();
-    if (t == 0 && s_con) atomicAdd(&A.sums[kCsSumStride], s_con);
+    if (t == 0) {  // the block's slots with ONE atomic (and the accepted faces counted with another)
+      uint32_t total = 0, cand = 0;
+      for (int k = 0; k < NG; ++k) { s_tp[k] = total; total += s_scnt[k]; cand += s_cnt[k] > kTnHitCap ? 0u : s_cnt[k]; }
+      const uint32_t region = blockIdx.x & (kTnRegions - 1u);
+      uint32_t base = total ? atomicAdd(&A.cnt[region * kTnCntStride], total) : 0u;
+      if (base + total > A.region_cap) { atomicOr(A.overflow, 4u); base = A.region_cap; }  // (the tick is run again with more room: nothing of this block is written)
+      if (cand) atomicAdd(&A.cnt[(kTnRegions + region) * kTnCntStride], cand);
+      for (int k = 0; k < NG; ++k) s_tp[k] += region * A.region_cap + base;
+    }
+    __syncthreads();
+    // ---- every survivor has its slot - in its body's run, in the reference's order - whether it will report a contact or not
+    const uint32_t S = s_scnt[g], tp = s_tp[g];
+    const uint32_t region_end = ((blockIdx.x & (kTnRegions - 1u)) + 1u) * A.region_cap;
+    for (uint32_t a = (uint32_t)s; a < S; a += (uint32_t)L) {
+      if (tp + a < region_end) { A.slot_body[tp + a] = i; A.slot_rank[tp + a] = s_surv[g][a]; }
+    }
+    if (live && s == 0) { A.tpos[i] = tp; A.t_cnt[i] = S; }  // (tcn: k_terrain_tests adds the contacts up; the tick's clearing launch zeroed it)
   }
+}
+// ... and the body-triangle test (collision.rs:610-1086), a lane per slot: whole waves of it, as many as there are slots - nothing else
+// in the launch, so that it is as short as ONE walk through tri_mcapsule's branches.
+struct TerrainTests {
+  TerrainDev M;
+  const uint32_t* face_of_rank;
+  const uint32_t *slot_body, *slot_rank, *cnt;  // cnt: the regions' slot counters (k_terrain_near)
+  uint32_t region_cap;
+  NContact* t_out;     // 2 per slot; .lb.w of the first = the face's contact count
+  uint32_t* tcn;       // += the body's terrain contacts
+  uint32_t* sum_ct;    // += the tick's
+  uint32_t* flag;      // check mode: a slot marked kTnFarBit reported a contact
+  const uint32_t* overflow;  // bit 2: a region ran full - slots were reserved and not written; the host runs the tick again with more room
+};
+__global__ __launch_bounds__(kBlock) void k_terrain_tests(Bodies B, TerrainTests A) {
+  __shared__ uint32_t s_con;
+  if (*A.overflow & 4u) return;
+  // (a region's slots are its first ones: the blocks behind them leave at once)
+  const uint32_t p = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+  const uint32_t r_first = (blockIdx.x * (uint32_t)kBlock) / A.region_cap, r_last = min((blockIdx.x * (uint32_t)kBlock + (uint32_t)kBlock - 1u) / A.region_cap, kTnRegions - 1u);
+  bool any = false;
+  for (uint32_t r = r_first; r <= r_last && r < kTnRegions; ++r) {
+    const uint32_t lo = max(r * A.region_cap, blockIdx.x * (uint32_t)kBlock);
+    any = any || lo - r * A.region_cap < min(A.cnt[r * kTnCntStride], A.region_cap);
+  }
+  if (!any) return;
+  if (threadIdx.x == 0) s_con = 0u;
+  __syncthreads();
+  const uint32_t region = p / A.region_cap;
+  int nc = 0;
+  if (region < kTnRegions && p - region * A.region_cap < min(A.cnt[region * kTnCntStride], A.region_cap)) {
+    const uint32_t i = A.slot_body[p], w = A.slot_rank[p];
+    const V3 mx = mk3(A.M.x[0], A.M.x[1], A.M.x[2]);
+    V3 vA;
+    const Comp Ac = load_comp_moving(B, i, &vA);
+    const uint4 fi = A.M.faces[A.face_of_rank[w & ~kTnFarBit]];
+    const Triangle tri = mkt(xyz(A.M.verts[fi.x]) + mx, xyz(A.M.verts[fi.y]) + mx, xyz(A.M.verts[fi.z]) + mx);  // mesh.rs:122-126
+    LocalContact lc[2];
+    nc = comp_tri_local(Ac, vA, tri, mx, lc);
+    if ((w & kTnFarBit) && nc) *A.flag = 1u;  // (check mode only: the reject was wrong)
+    NContact o;
+    o.la = make_float4(0, 0, 0, 0); o.lb = make_float4(0, 0, 0, u2f(0u)); o.n = make_float4(0, 0, 0, 0);
+    if (nc > 0) { o.la = mk4(lc[0].la, lc[0].g.t); o.lb = mk4(lc[0].lb, u2f((uint32_t)nc)); o.n = mk4(lc[0].g.n, 0.0f); }  // Manifold::from(lc) manifold.rs:120-128
+    A.t_out[2 * (size_t)p] = o;
+    if (nc > 1) { o.la = mk4(lc[1].la, lc[1].g.t); o.lb = mk4(lc[1].lb, 0.0f); o.n = mk4(lc[1].g.n, 0.0f); A.t_out[2 * (size_t)p + 1] = o; }
+    if (nc) atomicAdd(&A.tcn[i], (uint32_t)nc);  // the body's terrain constraints come first in its range (k_chain_rows)
+  }
+  uint32_t v = (uint32_t)nc;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_con, v);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_con) atomicAdd(A.sum_ct, s_con);
 }
 
 // ---- pair search with the narrowphase of any single-component pair in it ---------------------------------------------------------------
@@ -321,7 +372,11 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid_n(Bodies B, uint32_t n
       // join the block's pool
       const uint32_t na = min(n_accepted, (uint32_t)kRowCap);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the group reads the staging row its lanes wrote)
+#if defined(MGF_PN_ABL) && MGF_PN_ABL >= 2
+      if (false) {
+#else
       if (na) {
+#endif
         V3 vA;
         const Comp A = load_comp_moving(B, i, &vA);
         for (uint32_t a = (uint32_t)sub; a < na; a += kCoopLanes) {
@@ -335,7 +390,11 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid_n(Bodies B, uint32_t n
   }
   __syncthreads();
   // ---- the pool through the pair test, a lane each: contacts go to their query's row
+#if defined(MGF_PN_ABL) && MGF_PN_ABL >= 1
+  const uint32_t pool_n = 0;
+#else
   const uint32_t pool_n = s_pool_n;
+#endif
   for (uint32_t e = threadIdx.x; e < pool_n; e += kCoopBlock) {
     const uint32_t w = s_pool[e], j = w & 0x03FFFFFFu, g2 = w >> 26, ia = s_qi[g2];
     V3 vA, vB;

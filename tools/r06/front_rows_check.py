@@ -22,6 +22,7 @@ for name, sc, ticks in cases:
     dt, it = float(sc["dt"]), sc["iters"]
     a, b = mgf_amd.World.from_scene(ctx, sc), mgf_amd.World.from_scene(ctx, sc)
     b.set_option("front_rows", 0)
+    a.set_option("front_rows_check", 1)  # (the faces the cheap reject drops are tested all the same: a contact among them is an error)
     ow = oracle_world(sc)
     for s in range(ticks):
         if s % 40 == 0:  # against the oracle from the same state: the constraint list and the state after the solve
@@ -46,10 +47,12 @@ if not quick:
     dt, it = float(sc["dt"]), sc["iters"]
     a, b = mgf_amd.World.from_scene(ctx, sc), mgf_amd.World.from_scene(ctx, sc)
     b.set_option("front_rows", 0)
+    if "--check" in sys.argv: a.set_option("front_rows_check", 1)
     for s in range(50, 401, 50):
         t0 = time.perf_counter(); sa = a.step_many(dt, it, 50); ta = (time.perf_counter() - t0) / 50
         t0 = time.perf_counter(); sb = b.step_many(dt, it, 50); tb = (time.perf_counter() - t0) / 50
         assert same_state(a.state(), b.state()), s
         assert int(sa[49]["n_constraints"]) == int(sb[49]["n_constraints"]) and int(sa[49]["n_pair_candidates"]) == int(sb[49]["n_pair_candidates"]) and int(sa[49]["n_terrain_candidates"]) == int(sb[49]["n_terrain_candidates"]), s
+        print(f"   near bodies {a.counter('front_near')}, faces accepted {a.counter('front_faces')}, after the cheap reject {a.counter('front_slots')}")
         print(f"config 3 tick {s}: bit-identical, {int(sa[49]['n_constraints'])} constraints, {int(sa[49]['n_terrain_candidates'])} terrain candidates, {int(sa[49]['n_pair_candidates'])} accepted partners; ms/tick front_rows {ta*1e3:.3f} vs lists {tb*1e3:.3f}", flush=True)
 print("OK")
