@@ -879,6 +879,10 @@ struct ContactsSpheres {
   float dt, baumgarte, slop;
   CRec* cons; uint2* ab; uint32_t* degb; RevEnt* rev; uint32_t rev_cap; uint32_t* rev_flag; uint32_t* flag;
   const uint32_t* ext;
+  // (r06, k_terrain_near's slots) the terrain contacts' constraints by the first `t_blocks` workgroups of the launch, a lane per SLOT, instead of
+  // by their bodies' threads one after the other (a block of bodies on the floor held the launch up: 256 threads with six slots each, the rest idle)
+  uint32_t t_blocks, region_cap, regions, cnt_stride;
+  const uint32_t *slot_body, *slot_cnt;
 };
 // a body's partner row -> the block's list in LDS, canonical order (entries of the window [w0, w0 + kCsEntCap))
 __device__ __forceinline__ void cs_list_row(const uint32_t* rp, uint32_t np, const uint32_t* ext, uint32_t first, uint32_t w0, uint32_t owner, uint32_t* s_j, uint16_t* s_b) {
@@ -937,8 +941,29 @@ __global__ __launch_bounds__(kBlock) void k_contacts_rows(Bodies B, TerrainDev M
   __shared__ uint32_t s_cbase[kBlock];          // body -> id of its first partner constraint minus its first entry's position
   __shared__ uint32_t s_wave[kBlock / 64];
   if (A.sc->fail) return;  // (the scan's closing thread found a flag up or a capacity exceeded: the host re-runs the phase)
+  if (blockIdx.x < A.t_blocks) {  // ---- ContactConstraint::new for the terrain contacts (world.rs:243-251), a lane per slot
+    const uint32_t p = blockIdx.x * (uint32_t)kBlock + threadIdx.x, region = p / A.region_cap;
+    if (region >= A.regions || p - region * A.region_cap >= min(A.slot_cnt[region * A.cnt_stride], A.region_cap)) return;
+    const NContact in0 = A.t_out[2 * (size_t)p];
+    const uint32_t nc = f2u(in0.lb.w);
+    if (nc == 0) return;
+    const uint32_t i = A.slot_body[p], tp = A.tpos[i];
+    uint32_t c = A.base[i];
+    for (uint32_t q = tp; q < p; ++q) c += f2u(A.t_out[2 * (size_t)q].lb.w);  // the contacts of the body's earlier faces (its slots are a run, in Mesh::contacts' order)
+    const V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
+    const BodyDyn Ad = load_dyn(B.srec, i), S = static_dyn();
+    const BodyPack Pa = load_pack(B, i, false);
+    for (uint32_t k = 0; k < nc; ++k, ++c) {
+      const NContact in = k == 0 ? in0 : A.t_out[2 * (size_t)p + k];
+      // Static{ center: terrain.center(), friction: 0.0 } world.rs:247
+      const CRec r = make_constraint(i, kNone, Ad, xyz(Pa.ei), Pa.ei.w, Pa.dl.w, S, mx, 0.0f, 0.0f, xyz(in.n), xyz(in.la), xyz(in.lb), A.dt, A.baumgarte, A.slop);
+      store_crec(&A.cons[c], r);
+      A.ab[c] = make_uint2(i, kNone);
+    }
+    return;
+  }
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const uint32_t i0 = blockIdx.x * (uint32_t)kBlock, i = i0 + (uint32_t)t;
+  const uint32_t i0 = (blockIdx.x - A.t_blocks) * (uint32_t)kBlock, i = i0 + (uint32_t)t;
   uint32_t np = 0, run = 0, base_i = 0;
   if (i < A.n) { np = A.p_cnt[i]; run = A.tcn[i]; base_i = A.base[i]; }
   // ---- where the body's partner contacts start in the block's list
@@ -954,7 +979,7 @@ __global__ __launch_bounds__(kBlock) void k_contacts_rows(Bodies B, TerrainDev M
   if (np) cs_list_row(rp, np, A.ext, excl_p, 0u, (uint32_t)t, s_j, s_b);
   s_cbase[t] = base_i + run - excl_p;
   // ---- ContactConstraint::new for the terrain contacts (world.rs:243-251): the body's own thread (setup_terrain_one's work)
-  if (run) {
+  if (run && A.t_blocks == 0u) {
     const uint32_t nt = A.t_cnt[i], tp = A.tpos[i];
     const V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
     const BodyDyn Ad = load_dyn(B.srec, i), S = static_dyn();

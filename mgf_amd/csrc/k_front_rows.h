@@ -365,8 +365,20 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid_n(Bodies B, uint32_t n
     if (d[0] * d[1] * d[2] > kGridMaxCells) {
       if (sub == 0) *too_wide = 1u;
     } else {
+#if defined(MGF_PN_ACCEPT) && MGF_PN_ACCEPT == 0
       PairSrcGlobal S; S.T = T;
       n_accepted = pair_query_accept(S, q, oi, n_owned, ca, d, nb, kMortonBits - (int)P, sub, gbase, s_acc[qg]);
+#else
+      // (the search of k_pair_brick's slow path: a lane walks its z-columns of cells on its own, four leaf records in flight, hits appended
+      // through an LDS counter - no ballot per record: in the dense part of a scene a cell holds ten bodies)
+      BrickSrcGlobal S; S.T = T; S.nb[0] = nb[0]; S.nb[1] = nb[1]; S.nb[2] = nb[2]; S.shift = kMortonBits - (int)P;
+      Comp A0; A0.kind = KIND_SPHERE; A0.p = mk3(0, 0, 0); A0.d = mk3(0, 0, 0); A0.r = 0.0f;
+      brick_query<false>(S, q, A0, mk3(0, 0, 0), oi, n_owned, ca, d, (uint32_t)sub, (uint32_t)kCoopLanes, s_acc[qg], s_acc[qg], &s_np[qg]);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      n_accepted = *(volatile uint32_t*)&s_np[qg];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (sub == 0) s_np[qg] = 0u;  // (the contacts' counter from here on: the group's lanes have read it)
+#endif
       if (n_accepted > (uint32_t)kRowCap && sub == 0) atomicOr(overflow, 1u);
       // the accepted partners whose bounding spheres come within reach during the tick (comp_pair_far: nine in ten of a pile do not)
       // join the block's pool
