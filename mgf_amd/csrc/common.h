@@ -41,6 +41,7 @@ struct mgf_ctx {
   void* pinned = nullptr;    // small pinned staging area for read-backs
   size_t pinned_bytes = 0;
   int num_cus = 256;
+  hipStream_t aux = nullptr; // a second stream for work that runs BESIDE the tick's main chain of launches (r06: the terrain kernels of a capsule world beside its pair search), created on first use
 };
 
 namespace mgf {

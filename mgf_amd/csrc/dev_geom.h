@@ -684,7 +684,43 @@ __device__ __forceinline__ bool comp_tri_far(const Comp& A, V3 vA, const Triangl
   if (dot(p0 - tri.a, m0) > l0 && dot(p1 - tri.a, m0) > l0) return true;
   if (dot(p0 - tri.b, m1) > l1 && dot(p1 - tri.b, m1) > l1) return true;
   if (dot(p0 - tri.c, m2) > l2 && dot(p1 - tri.c, m2) > l2) return true;
-  return false;
+  // ... and the distance itself, where the axis stays on one side of the face: the closest pair of a segment and a triangle it does not
+  // cross is an end point over the face's inside or a pair of points of the segment and an edge.  (A body that lies on the NEXT face, half a
+  // radius from this one's edge, passes the four planes above and touches nothing here: two candidates in three of a capsule field at rest.)
+  {
+    const float d0 = dot(p0 - tri.a, n), d1 = dot(p1 - tri.a, n);
+    if (!((d0 > 0.0f && d1 > 0.0f) || (d0 < 0.0f && d1 < 0.0f))) return false;  // (the axis meets the plane: the reference's tests decide)
+    const float lim2 = lim * lim;
+    // an end point whose projection lies inside the face (or on its rim: then an edge is as near) is |d| / |n| from it
+    const bool in0 = dot(p0 - tri.a, m0) <= 0.0f && dot(p0 - tri.b, m1) <= 0.0f && dot(p0 - tri.c, m2) <= 0.0f;
+    const bool in1 = dot(p1 - tri.a, m0) <= 0.0f && dot(p1 - tri.b, m1) <= 0.0f && dot(p1 - tri.c, m2) <= 0.0f;
+    if (in0 && d0 * d0 <= lim2 * nn) return false;
+    if (in1 && d1 * d1 <= lim2 * nn) return false;
+    const V3 ax = p1 - p0;
+    float best = kInf;
+    bool sure = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // segment - segment (Ericson, Real-Time Collision Detection 5.1.9), the edges one after the other
+      const V3 q = k == 0 ? tri.a : (k == 1 ? tri.b : tri.c), e = k == 0 ? e0 : (k == 1 ? e1 : e2);
+      const V3 r = p0 - q;
+      const float a = dot(ax, ax), ee = dot(e, e), f = dot(e, r);
+      float sa = 0.0f, tb = 0.0f;
+      if (!(ee > 0.0f)) { sure = false; continue; }
+      if (a > 0.0f) {
+        const float c = dot(ax, r), b = dot(ax, e), den = a * ee - b * b;
+        if (!(den > 1e-3f * a * ee)) { sure = false; continue; }  // (all but parallel: the closest pair is ill-conditioned - no verdict from here)
+        sa = clampf((b * f - c * ee) / den, 0.0f, 1.0f);
+        tb = (b * sa + f) / ee;
+        if (tb < 0.0f) { tb = 0.0f; sa = clampf(-c / a, 0.0f, 1.0f); }
+        else if (tb > 1.0f) { tb = 1.0f; sa = clampf((b - c) / a, 0.0f, 1.0f); }
+      } else {
+        tb = clampf(f / ee, 0.0f, 1.0f);
+      }
+      const V3 dd = (p0 + ax * sa) - (q + e * tb);
+      best = fmin_rs(best, dot(dd, dd));
+    }
+    return sure && best > lim2;
+  }
 }
 
 // compute_basis geom.rs:1138-1145

@@ -43,7 +43,12 @@ __device__ __forceinline__ void grid_box(const SceneBounds* sb, float min_frac, 
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     float e = hi[k] - lo[k];
-    if (e < min_frac * ext) e = min_frac * ext;
+    // (r06) ... but not beyond cells of 0.4 of a query's reach along the axis (a query is about 3.4 largest fat half extents across: its own
+    // tight box and the partners' fat ones): wider cells only hold more bodies - config 3's 337 x 60 x 87 capsule field widened to half its
+    // length had 5.2 x 2.6 x 2.6 cells with twenty capsules each in the pile (k_pair_grid_n 117 us; 88 with cells of 1.4).  An x-slab
+    // tile's thin axis and config 5's flat field end up where the plain half-of-the-longest rule put them.
+    const float cell_cap = 1.36f * ord_f(sb->rmax[k]) * (float)(1u << nb[k]);
+    if (e < min_frac * ext) e = fmaxf(e, fminf(min_frac * ext, cell_cap));
     const float want = ord_f(sb->rmax[k]) * (float)(1u << nb[k]) * 1.02f;
     if (e < want && want <= 1.5f * e) e = want;
     hi[k] = lo[k] + e;
@@ -1018,63 +1023,6 @@ __device__ __forceinline__ void pair_query_cells(const Src& S, const Box& q, con
   }
 }
 
-template <bool SPHERES>
-__global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, uint32_t n_owned, Lbvh T, const SceneBounds* sb, float pad_abs,
-                                                          uint32_t* rows_p, uint32_t* p_cnt, uint32_t* overflow, uint32_t* too_wide,
-                                                          uint32_t* pair_stat, float min_frac) {
-  __shared__ uint32_t s_acc[SPHERES ? kCoopBlock / kCoopLanes : 1][SPHERES ? kRowCap : 1];  // accepted partners of a query (leaf positions)
-  const int lane = threadIdx.x & 63;
-  const int sub = lane & 7;
-  const int gbase = lane & ~7;
-  uint32_t kq = xcd_logical_block_coop() * (kCoopBlock / kCoopLanes) + (threadIdx.x >> 3);
-  const bool live = kq < n;  // whole groups are live or not
-  uint32_t i = live ? T.sidx[kq] : 0u;
-  uint32_t np = 0, n_accepted = 0;
-  const uint32_t oi = live ? order_id(T.ext, i) : 0u;
-  if (live && oi != 0 && T.n >= 2) {  // world.rs:256
-    Box q;
-    Comp A; V3 vA = mk3(0, 0, 0);
-    uint32_t ca[3], d[3];
-    const uint32_t P = 2u * T.levels;
-    const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};  // prefix bits per axis (x is the most significant)
-    if (T.ltb) {  // the query in cell order, its cells worked out by k_scatter_leaves: no look-up through the body index, no divisions
-      const float4 qc = T.ltb[2 * kq], qr = T.ltb[2 * kq + 1];
-      q.c = xyz(qc); q.r = xyz(qr);
-      const uint32_t ra = f2u(qc.w), rd = f2u(qr.w);
-      ca[0] = ra & 1023u; ca[1] = (ra >> 10) & 1023u; ca[2] = ra >> 20;
-      d[0] = rd & 1023u; d[1] = (rd >> 10) & 1023u; d[2] = rd >> 20;
-      if (SPHERES) { const float4 c0 = T.lcol[2 * kq]; A.p = xyz(c0); A.r = c0.w; A.d = mk3(0, 0, 0); A.kind = KIND_SPHERE; vA = xyz(T.lcol[2 * kq + 1]); }
-    } else {
-      q.c = xyz(B.tb_c[i]); q.r = xyz(B.tb_r[i]);
-      if (SPHERES) { A = load_comp(B, i); A.kind = KIND_SPHERE; vA = xyz(B.delta[i]); }
-      float pad = pad_abs + 1e-5f * (fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z);
-      pair_query_region(q.c, q.r, pad, sb, nb, ca, d, min_frac);
-    }
-    if (d[0] * d[1] * d[2] > kGridMaxCells) {
-      if (sub == 0) *too_wide = 1u;
-    } else {
-      PairSrcGlobal S; S.T = T;
-      pair_query_cells<SPHERES>(S, q, A, vA, oi, n_owned, ca, d, nb, kMortonBits - (int)P, sub, gbase, rows_p + (size_t)i * kRowCap,
-                                s_acc[SPHERES ? threadIdx.x >> 3 : 0], overflow, np, n_accepted);
-    }
-  }
-  if (live && sub == 0) {
-    p_cnt[i] = np;
-    if (!SPHERES && np > (uint32_t)kRowCap) atomicOr(overflow, 1u);
-  }
-  if (SPHERES) {  // accepted partners: one atomic per block, spread over many words
-    __shared__ uint32_t s_sum;
-    if (threadIdx.x == 0) s_sum = 0;
-    __syncthreads();
-    uint32_t v = (live && sub == 0) ? n_accepted : 0u;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    if (lane == 0 && v) atomicAdd(&s_sum, v);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_sum) atomicAdd(&pair_stat[blockIdx.x & (kPairStatWords - 1u)], s_sum);
-  }
-}
-
 // k_pair_grid with the cells in LDS.  k_pair_grid is bound by instruction issue, not by memory: 8 lanes share a query and
 // spend ~1900 wave instructions per 8 queries on cell arithmetic (divisions, Morton interleaves), ballots and lanes that
 // wait for each other.  Here a block takes a BRICK of 4 x 4 x 4 cells (64 consecutive Morton cells: its queries are one
@@ -1193,6 +1141,82 @@ __device__ __forceinline__ void brick_query(const Src& S, const Box& q, const Co
     Comp Bc; Bc.kind = KIND_SPHERE; Bc.p = xyz(c0); Bc.r = c0.w; Bc.d = mk3(0, 0, 0);
     LocalContact lc;
     if (comp_pair_local(A, vA, Bc, xyz(d0), &lc)) row[atomicAdd(&cnt[2], 1u)] = jj;
+  }
+}
+
+// (k_pair_grid itself: behind brick_query, whose walk it may use)
+template <bool SPHERES>
+__global__ __launch_bounds__(kCoopBlock) void k_pair_grid(Bodies B, uint32_t n, uint32_t n_owned, Lbvh T, const SceneBounds* sb, float pad_abs,
+                                                          uint32_t* rows_p, uint32_t* p_cnt, uint32_t* overflow, uint32_t* too_wide,
+                                                          uint32_t* pair_stat, float min_frac) {
+  __shared__ uint32_t s_acc[SPHERES ? kCoopBlock / kCoopLanes : 1][SPHERES ? kRowCap : 1];  // accepted partners of a query (leaf positions)
+#if defined(MGF_PG_WALK) && MGF_PG_WALK == 1
+  __shared__ uint32_t s_cnt3[kCoopBlock / kCoopLanes][4];
+#endif
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & 7;
+  const int gbase = lane & ~7;
+  uint32_t kq = xcd_logical_block_coop() * (kCoopBlock / kCoopLanes) + (threadIdx.x >> 3);
+  const bool live = kq < n;  // whole groups are live or not
+  uint32_t i = live ? T.sidx[kq] : 0u;
+  uint32_t np = 0, n_accepted = 0;
+  const uint32_t oi = live ? order_id(T.ext, i) : 0u;
+  if (live && oi != 0 && T.n >= 2) {  // world.rs:256
+    Box q;
+    Comp A; V3 vA = mk3(0, 0, 0);
+    uint32_t ca[3], d[3];
+    const uint32_t P = 2u * T.levels;
+    const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};  // prefix bits per axis (x is the most significant)
+    if (T.ltb) {  // the query in cell order, its cells worked out by k_scatter_leaves: no look-up through the body index, no divisions
+      const float4 qc = T.ltb[2 * kq], qr = T.ltb[2 * kq + 1];
+      q.c = xyz(qc); q.r = xyz(qr);
+      const uint32_t ra = f2u(qc.w), rd = f2u(qr.w);
+      ca[0] = ra & 1023u; ca[1] = (ra >> 10) & 1023u; ca[2] = ra >> 20;
+      d[0] = rd & 1023u; d[1] = (rd >> 10) & 1023u; d[2] = rd >> 20;
+      if (SPHERES) { const float4 c0 = T.lcol[2 * kq]; A.p = xyz(c0); A.r = c0.w; A.d = mk3(0, 0, 0); A.kind = KIND_SPHERE; vA = xyz(T.lcol[2 * kq + 1]); }
+    } else {
+      q.c = xyz(B.tb_c[i]); q.r = xyz(B.tb_r[i]);
+      if (SPHERES) { A = load_comp(B, i); A.kind = KIND_SPHERE; vA = xyz(B.delta[i]); }
+      float pad = pad_abs + 1e-5f * (fabs_rs(q.c.x) + fabs_rs(q.c.y) + fabs_rs(q.c.z) + q.r.x + q.r.y + q.r.z);
+      pair_query_region(q.c, q.r, pad, sb, nb, ca, d, min_frac);
+    }
+    if (d[0] * d[1] * d[2] > kGridMaxCells) {
+      if (sub == 0) *too_wide = 1u;
+    } else {
+#if defined(MGF_PG_WALK) && MGF_PG_WALK == 1
+      // (r06) the walk of k_pair_brick's slow path: every lane its own z-columns of cells, four leaf records in flight, hits through an LDS counter
+      BrickSrcGlobal S; S.T = T; S.nb[0] = nb[0]; S.nb[1] = nb[1]; S.nb[2] = nb[2]; S.shift = kMortonBits - (int)P;
+      uint32_t* cnt3 = s_cnt3[threadIdx.x >> 3];
+      if (sub < 3) cnt3[sub] = 0u;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      uint32_t* row = rows_p + (size_t)i * kRowCap;
+      if (SPHERES) brick_query<SPHERES>(S, q, A, vA, oi, n_owned, ca, d, (uint32_t)sub, (uint32_t)kCoopLanes, row, s_acc[SPHERES ? threadIdx.x >> 3 : 0], cnt3);
+      else brick_query<SPHERES>(S, q, A, vA, oi, n_owned, ca, d, (uint32_t)sub, (uint32_t)kCoopLanes, row, row, cnt3);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      n_accepted = *(volatile uint32_t*)&cnt3[0];
+      np = SPHERES ? *(volatile uint32_t*)&cnt3[2] : n_accepted;
+      if (SPHERES && n_accepted > (uint32_t)kRowCap && sub == 0) atomicOr(overflow, 1u);
+#else
+      PairSrcGlobal S; S.T = T;
+      pair_query_cells<SPHERES>(S, q, A, vA, oi, n_owned, ca, d, nb, kMortonBits - (int)P, sub, gbase, rows_p + (size_t)i * kRowCap,
+                                s_acc[SPHERES ? threadIdx.x >> 3 : 0], overflow, np, n_accepted);
+#endif
+    }
+  }
+  if (live && sub == 0) {
+    p_cnt[i] = np;
+    if (!SPHERES && np > (uint32_t)kRowCap) atomicOr(overflow, 1u);
+  }
+  if (SPHERES) {  // accepted partners: one atomic per block, spread over many words
+    __shared__ uint32_t s_sum;
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    uint32_t v = (live && sub == 0) ? n_accepted : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0 && v) atomicAdd(&s_sum, v);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_sum) atomicAdd(&pair_stat[blockIdx.x & (kPairStatWords - 1u)], s_sum);
   }
 }
 

@@ -86,6 +86,7 @@ extern "C" void mgf_ctx_destroy(mgf_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   ctx->stream = nullptr;
+  if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); ctx->aux = nullptr; }
   if (ctx->prim_tmp) (void)hipFree(ctx->prim_tmp);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   delete ctx;
