@@ -668,7 +668,13 @@ __device__ inline int comp_tri_local(const Comp& A, V3 vA, const Triangle& tri, 
 // walked through every branch of tri_mcapsule to report nothing.
 __device__ __forceinline__ bool comp_tri_far(const Comp& A, V3 vA, const Triangle& tri) {
   const V3 p0 = A.p, p1 = A.kind == KIND_SPHERE ? A.p : A.p + A.d;
-  const float lim = (A.r + mag(vA)) * 1.01f + 1e-3f;
+  // (... of the reference's ARITHMETIC, which is f32 relative to the far end of an edge: ray_capsule forms |m|^2 |D|^2 - (m.D)^2 with m from
+  // the edge's start - 200 m away on the floor of config 5's box - and whether a capsule 0.31 from the floor's diagonal touches it comes out
+  // of the last bits (it did: tools/r06/dbg_c5.py).  The reach below grows with the square of the distance to the face's farthest vertex:
+  // nothing beside a 2 m triangle, 0.7 instead of 0.3 beside a 200 m one.)
+  const float far2 = fmax_rs(fmax_rs(mag2(p0 - tri.a), mag2(p0 - tri.b)), mag2(p0 - tri.c)) + mag2(p1 - p0);
+  const float lim0 = (A.r + mag(vA)) * 1.01f + 1e-3f;
+  const float lim = __builtin_sqrtf(lim0 * lim0 + 1e-5f * far2);
   const V3 e0 = tri.b - tri.a, e1 = tri.c - tri.b, e2 = tri.a - tri.c;
   const V3 n = cross(e0, tri.c - tri.a);
   const float nn = dot(n, n);

@@ -750,10 +750,13 @@ struct TerrainContacts {
   uint32_t *tcn, *tpos;
   const uint32_t* guard;
   const float4* col1;  // GEN: the bodies' collider word 1 (d.xyz, kind) - the records of k_integrate's tail carry word 0 and the motion
+  const uint32_t* pcount; const float4 *wp0, *wp1;  // GEN = 2: the parts of bodies of several components (Bodies)
+  uint32_t check; uint32_t* flag;  // tests (option front_rows_check): the faces comp_tri_far drops are tested all the same; a contact among them raises *flag
 };
 // GEN (r06): bodies of any single-component kind - a lane per FACE through the body-triangle test (collision.rs:610-1086) instead of a face by
 // the group's four lanes (tri_msphere_x4 is the sphere's); the parked slots are the same.
-template <bool GEN>
+// GEN = 2: bodies of up to two components - every part against the face (k_narrow_terrain_parts<2>), up to four contacts per slot (t_out: 4 per slot).
+template <int GEN>
 __device__ __forceinline__ void terrain_contacts_job(const TerrainContacts& A, uint32_t job_block, uint32_t job_blocks) {
   const TerrainDev& M = A.M;
   const float4* near_list = A.near_list; const uint32_t n_faces = A.n_faces, n_verts = A.n_verts, cap_row_t = A.cap_row_t, cap_t = A.cap_t;
@@ -795,7 +798,56 @@ __device__ __forceinline__ void terrain_contacts_job(const TerrainContacts& A, u
       wave_base = __shfl(wave_base, 63);
       tp = __shfl(wave_base + inc - mine, lane & ~(kTcLanes - 1));
     }
-    if (GEN) {
+    if (GEN == 2) {
+      if (nt) {
+        const V3 vA = xyz(r1);
+        const uint32_t pc = A.pcount ? A.pcount[i] : 0u;
+        Comp P0, P1;
+        V3 centre;
+        int np = 1;
+        P1.kind = KIND_SPHERE; P1.p = mk3(0, 0, 0); P1.d = mk3(0, 0, 0); P1.r = 0.0f;
+        if (pc == 0u) { const float4 c1 = A.col1[i]; P0.p = xyz(r0); P0.r = r0.w; P0.d = xyz(c1); P0.kind = (int)f2u(c1.w); centre = comp_center(P0); }
+        else {
+          centre = xyz(r0); np = (int)min(pc, 2u);
+          const float4 a0 = A.wp0[kMaxParts * (size_t)i], b0 = A.wp1[kMaxParts * (size_t)i];
+          P0.kind = (int)f2u(b0.w); P0.p = xyz(a0); P0.r = a0.w; P0.d = xyz(b0);
+          if (pc > 1u) { const float4 a1 = A.wp0[kMaxParts * (size_t)i + 1], b1 = A.wp1[kMaxParts * (size_t)i + 1]; P1.kind = (int)f2u(b1.w); P1.p = xyz(a1); P1.r = a1.w; P1.d = xyz(b1); }
+        }
+        const uint32_t* rt = rows_t + (size_t)i * cap_row_t;
+        const bool bytes = pk0 != 0xFFFFFFFFu || pk1 != 0xFFFFFFFFu;
+        for (uint32_t a = sub; a < nt; a += (uint32_t)kTcLanes) {  // the body's faces dealt to the group's lanes
+          const uint32_t f = bytes ? ((a < 4u ? pk0 >> (8u * a) : pk1 >> (8u * (a - 4u))) & 255u) : rt[a];
+          const uint4 fi = staged ? s_face[f] : M.faces[f];
+          const Triangle tri = staged ? mkt(xyz(s_vert[fi.x]) + mx, xyz(s_vert[fi.y]) + mx, xyz(s_vert[fi.z]) + mx)
+                                      : mkt(xyz(M.verts[fi.x]) + mx, xyz(M.verts[fi.y]) + mx, xyz(M.verts[fi.z]) + mx);  // mesh.rs:122-126
+          LocalContact l0[2], l1[2];
+          const bool f0 = comp_tri_far(P0, vA, tri), f1 = np >= 2 && comp_tri_far(P1, vA, tri);
+          const int n0 = (f0 && !A.check) ? 0 : comp_tri_local_at(P0, vA, tri, mx, centre, l0);
+          const int n1 = (np < 2 || (f1 && !A.check)) ? 0 : comp_tri_local_at(P1, vA, tri, mx, centre, l1);
+          if (A.check && ((f0 && n0) || (f1 && n1))) *A.flag = 1u;  // (tests: the cheap reject dropped a face that reports a contact)
+          const int nc = n0 + n1;
+          if (tp + a < cap_t) {
+            // the contacts packed in order, the parts one after the other (k_narrow_terrain_parts); the first record carries the count
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              if (k == 0 || k < nc) {
+                NContact o;
+                o.la = make_float4(0, 0, 0, 0); o.lb = make_float4(0, 0, 0, 0.0f); o.n = make_float4(0, 0, 0, 0);
+                if (k < nc) {
+                  const int q = k - n0;  // (k >= n0: contact q of the second part)
+                  const LocalContact c = k < n0 ? (k == 0 ? l0[0] : l0[1]) : (q == 0 ? l1[0] : l1[1]);
+                  o.la = mk4(c.la, c.g.t); o.lb = mk4(c.lb, 0.0f); o.n = mk4(c.g.n, 0.0f);  // Manifold::from(lc) manifold.rs:120-128
+                }
+                if (k == 0) o.lb.w = u2f((uint32_t)nc);
+                t_out[4 * (size_t)(tp + a) + k] = o;
+              }
+            }
+          }
+          run += (uint32_t)nc;
+        }
+      }
+      run += (uint32_t)__shfl_xor((int)run, 1); run += (uint32_t)__shfl_xor((int)run, 2);
+    } else if (GEN == 1) {
       if (nt) {
         const V3 vA = xyz(r1);
         const float4 c1 = A.col1[i];
@@ -808,7 +860,9 @@ __device__ __forceinline__ void terrain_contacts_job(const TerrainContacts& A, u
           const Triangle tri = staged ? mkt(xyz(s_vert[fi.x]) + mx, xyz(s_vert[fi.y]) + mx, xyz(s_vert[fi.z]) + mx)
                                       : mkt(xyz(M.verts[fi.x]) + mx, xyz(M.verts[fi.y]) + mx, xyz(M.verts[fi.z]) + mx);  // mesh.rs:122-126
           LocalContact lc[2];
-          const int nc = comp_tri_far(Ca, vA, tri) ? 0 : comp_tri_local(Ca, vA, tri, mx, lc);
+          const bool ff = comp_tri_far(Ca, vA, tri);
+          const int nc = (ff && !A.check) ? 0 : comp_tri_local(Ca, vA, tri, mx, lc);
+          if (A.check && ff && nc) *A.flag = 1u;  // (tests: the cheap reject dropped a face that reports a contact)
           if (tp + a < cap_t) {
             NContact o;
             o.la = make_float4(0, 0, 0, 0); o.lb = make_float4(0, 0, 0, u2f(0u)); o.n = make_float4(0, 0, 0, 0);
@@ -858,12 +912,12 @@ __device__ __forceinline__ void terrain_contacts_job(const TerrainContacts& A, u
     if (lane == 0 && wrun) atomicAdd(&sums[kCsSumStride], wrun);
   }
 }
-template <bool GEN>
+template <int GEN>
 __global__ __launch_bounds__(kBlock) void k_terrain_contacts(TerrainContacts A) { terrain_contacts_job<GEN>(A, blockIdx.x, gridDim.x); }
 // ... as the last `tc_blocks` blocks of the leaf scatter's launch (both follow k_integrate, neither needs the other: the few waves of the
 // sphere-triangle tests - a resting sphere against the floor's other triangle runs three ray-capsule tests, ~15 us of one lane's
 // arithmetic - hide behind the streaming kernel instead of taking a launch of their own)
-template <bool GEN>
+template <int GEN>
 __global__ __launch_bounds__(kBlock) void k_scatter_leaves_tc(Lbvh T, const float4* fb_c, const float4* fb_r, const uint32_t* cell_of,
                                                               const uint32_t* rank, uint32_t* brank, const float4* col0, const float4* delta, const float4* tb_c,
                                                               const float4* tb_r, const SceneBounds* sb, float pad_abs, float min_frac, TerrainContacts A, uint32_t tc_blocks,

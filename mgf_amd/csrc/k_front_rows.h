@@ -328,9 +328,89 @@ __device__ __forceinline__ uint32_t pair_query_accept(const Src& S, const Box& q
   return np;
 }
 constexpr uint32_t kPnQueries = kCoopBlock / kCoopLanes;  // 64 queries per block
+
+// ---- bodies of up to two components (BASELINE config 5; not in the reference: DESIGN.md) ---------------------------------------------
+// The manifold of a pair of bodies, all in registers: k_narrow_pairs_parts' three steps for ONE candidate - Contacts (compound.rs:180-190)
+// per part pair in order (parts of i outer), local points relative to the bodies' centres (LocalContacts, compound.rs:192-207),
+// ContactPruner::push (manifold.rs:72-102), Manifold::from(pruner) (:131-148) - the same operations on the same values.  An ordinary
+// body is a body of one part (its collider).  Returns the contacts kept (0..4); la / lb = their local points, *normal = the manifold's.
+struct PartsOf { Comp part[2]; int n; V3 centre, v; };
+__device__ __forceinline__ PartsOf load_parts2(const Bodies& B, uint32_t i) {
+  PartsOf P;
+  const uint32_t pc = B.pcount ? B.pcount[i] : 0u;
+  const float4 c0 = B.col0[i];
+  P.v = xyz(B.delta[i]);
+  P.part[1].kind = KIND_SPHERE; P.part[1].p = mk3(0, 0, 0); P.part[1].d = mk3(0, 0, 0); P.part[1].r = 0.0f;
+  if (pc == 0u) {
+    const float4 c1 = B.col1[i];
+    P.part[0].kind = (int)f2u(c1.w); P.part[0].p = xyz(c0); P.part[0].r = c0.w; P.part[0].d = xyz(c1);
+    P.n = 1; P.centre = comp_center(P.part[0]);
+  } else {
+    P.n = (int)min(pc, 2u); P.centre = xyz(c0);
+    const float4 a0 = B.wp0[kMaxParts * (size_t)i], b0 = B.wp1[kMaxParts * (size_t)i];
+    P.part[0].kind = (int)f2u(b0.w); P.part[0].p = xyz(a0); P.part[0].r = a0.w; P.part[0].d = xyz(b0);
+    if (pc > 1u) {
+      const float4 a1 = B.wp0[kMaxParts * (size_t)i + 1], b1 = B.wp1[kMaxParts * (size_t)i + 1];
+      P.part[1].kind = (int)f2u(b1.w); P.part[1].p = xyz(a1); P.part[1].r = a1.w; P.part[1].d = xyz(b1);
+    }
+  }
+  return P;
+}
+__device__ __forceinline__ Contact pick4(const Contact* raw, uint32_t k) { return k == 0u ? raw[0] : (k == 1u ? raw[1] : (k == 2u ? raw[2] : raw[3])); }
+__device__ inline int pair_manifold2(const PartsOf& Pi, const PartsOf& Pj, V3* la, V3* lb, V3* normal) {
+  Contact raw[4];
+  bool have[4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int slot = a * 2 + b;
+      have[slot] = false;
+      raw[slot] = mkc(mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), 0.0f);
+      if (a < Pi.n && b < Pj.n && !comp_pair_far(Pi.part[a], Pi.v, Pj.part[b], Pj.v)) have[slot] = comp_pair_contact(Pi.part[a], Pi.v, Pj.part[b], Pj.v, &raw[slot]);
+    }
+  }
+  auto local_a = [&](const Contact& c) -> V3 { return c.a + -(Pi.centre + Pi.v * c.t); };
+  auto local_b = [&](const Contact& c) -> V3 { return c.b + -(Pj.centre + Pj.v * c.t); };
+  float min_t = kInf;
+  int cnt = 0;
+  uint32_t keep = 0u;  // (keep >> 2k) & 3: the slot of the k-th kept contact
+#pragma unroll
+  for (int slot = 0; slot < 4; ++slot) {
+    if (!have[slot]) continue;
+    const Contact nc = raw[slot];
+    if (nc.t < min_t - kCollisionEps) { cnt = 1; keep = (uint32_t)slot; min_t = nc.t; continue; }
+    if (nc.t > min_t + kCollisionEps) continue;
+    bool merged = false;
+    for (int k = 0; k < cnt && !merged; ++k) {
+      const Contact kc = pick4(raw, (keep >> (2 * k)) & 3u);
+      const V3 ra = nc.a - kc.a, rb = nc.b - kc.b;
+      if (mag2(ra) <= kPersistentThresholdSq || mag2(rb) <= kPersistentThresholdSq) {
+        const float prev = mag2(local_a(kc)) + mag2(local_b(kc)), cur = mag2(local_a(nc)) + mag2(local_b(nc));
+        if (prev < cur) keep = (keep & ~(3u << (2 * k))) | ((uint32_t)slot << (2 * k));
+        merged = true;
+      }
+    }
+    if (!merged) { keep = (keep & ~(3u << (2 * cnt))) | ((uint32_t)slot << (2 * cnt)); ++cnt; }
+  }
+  if (cnt == 0) return 0;
+  V3 sum = mk3(0.0f, 0.0f, 0.0f);
+  for (int k = 0; k < cnt; ++k) sum = sum + pick4(raw, (keep >> (2 * k)) & 3u).n;
+  *normal = sum / (float)cnt;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k < cnt) { const Contact kc = pick4(raw, (keep >> (2 * k)) & 3u); la[k] = local_a(kc); lb[k] = local_b(kc); }
+  }
+  return cnt;
+}
+
+// PARTS: the world holds bodies of up to two components - the accepted partners whose tight boxes meet are pooled (k_narrow_pairs_parts'
+// first step), the pool goes through pair_manifold2, a row entry is partner | contacts << 27 and p_cnt the body's CONTACTS (p_ent its entries).
+template <bool PARTS>
 __global__ __launch_bounds__(kCoopBlock) void k_pair_grid_n(Bodies B, uint32_t n, uint32_t n_owned, Lbvh T, const SceneBounds* sb, float pad_abs, uint32_t* rows_p,
-                                                            uint32_t* p_cnt, uint32_t* overflow, uint32_t* too_wide, uint32_t* pair_stat, float min_frac) {
+                                                            uint32_t* p_cnt, uint32_t* overflow, uint32_t* too_wide, uint32_t* pair_stat, float min_frac, uint32_t* p_ent) {
   __shared__ uint32_t s_acc[kPnQueries][kRowCap];   // accepted partners of a query (body slots)
+  __shared__ uint32_t s_ncon[PARTS ? kPnQueries : 1];
   __shared__ uint32_t s_pool[kPnQueries * kRowCap]; // the block's partners that may touch: partner slot | query << 26
   __shared__ uint32_t s_qi[kPnQueries], s_np[kPnQueries];
   __shared__ uint32_t s_pool_n, s_sum;
@@ -342,7 +422,7 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid_n(Bodies B, uint32_t n
   const bool live = kq < n;  // whole groups are live or not
   const uint32_t i = live ? T.sidx[kq] : 0u;
   if (threadIdx.x == 0) { s_pool_n = 0u; s_sum = 0u; }
-  if (sub == 0) { s_qi[qg] = i; s_np[qg] = 0u; }
+  if (sub == 0) { s_qi[qg] = i; s_np[qg] = 0u; if (PARTS) s_ncon[qg] = 0u; }
   __syncthreads();
   uint32_t n_accepted = 0;
   const uint32_t oi = live ? order_id(T.ext, i) : 0u;
@@ -389,13 +469,26 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid_n(Bodies B, uint32_t n
 #else
       if (na) {
 #endif
-        V3 vA;
-        const Comp A = load_comp_moving(B, i, &vA);
-        for (uint32_t a = (uint32_t)sub; a < na; a += kCoopLanes) {
-          const uint32_t j = s_acc[qg][a];
-          V3 vB;
-          const Comp Bc = load_comp_moving(B, j, &vB);
-          if (!comp_pair_far(A, vA, Bc, vB)) s_pool[atomicAdd(&s_pool_n, 1u)] = j | (qg << 26);
+        if (PARTS) {
+          // the candidate was accepted on i's tight box against j's FAT box; a contact is a touching inside both bodies' TIGHT swept boxes of
+          // this tick (k_narrow_pairs_parts: three candidates in four leave here)
+          const float4 ca = B.tb_c[i], ra = B.tb_r[i];
+          for (uint32_t a = (uint32_t)sub; a < na; a += kCoopLanes) {
+            const uint32_t j = s_acc[qg][a];
+            const float4 cb = B.tb_c[j], rb = B.tb_r[j];
+            const float slack = 1e-3f + 1e-5f * (fabs_rs(ca.x) + fabs_rs(ca.y) + fabs_rs(ca.z) + fabs_rs(cb.x) + fabs_rs(cb.y) + fabs_rs(cb.z));
+            if (!(fabs_rs(ca.x - cb.x) > ra.x + rb.x + slack || fabs_rs(ca.y - cb.y) > ra.y + rb.y + slack || fabs_rs(ca.z - cb.z) > ra.z + rb.z + slack))
+              s_pool[atomicAdd(&s_pool_n, 1u)] = j | (qg << 26);
+          }
+        } else {
+          V3 vA;
+          const Comp A = load_comp_moving(B, i, &vA);
+          for (uint32_t a = (uint32_t)sub; a < na; a += kCoopLanes) {
+            const uint32_t j = s_acc[qg][a];
+            V3 vB;
+            const Comp Bc = load_comp_moving(B, j, &vB);
+            if (!comp_pair_far(A, vA, Bc, vB)) s_pool[atomicAdd(&s_pool_n, 1u)] = j | (qg << 26);
+          }
         }
       }
     }
@@ -409,10 +502,17 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid_n(Bodies B, uint32_t n
 #endif
   for (uint32_t e = threadIdx.x; e < pool_n; e += kCoopBlock) {
     const uint32_t w = s_pool[e], j = w & 0x03FFFFFFu, g2 = w >> 26, ia = s_qi[g2];
-    V3 vA, vB;
-    const Comp A = load_comp_moving(B, ia, &vA), Bc = load_comp_moving(B, j, &vB);
-    LocalContact lc;
-    if (comp_pair_local(A, vA, Bc, vB, &lc)) rows_p[(size_t)ia * kRowCap + atomicAdd(&s_np[g2], 1u)] = j;
+    if (PARTS) {
+      const PartsOf Pi = load_parts2(B, ia), Pj = load_parts2(B, j);
+      V3 la[4], lb[4], nrm;
+      const int nc = pair_manifold2(Pi, Pj, la, lb, &nrm);
+      if (nc) { rows_p[(size_t)ia * kRowCap + atomicAdd(&s_np[g2], 1u)] = j | ((uint32_t)nc << 27); atomicAdd(&s_ncon[g2], (uint32_t)nc); }
+    } else {
+      V3 vA, vB;
+      const Comp A = load_comp_moving(B, ia, &vA), Bc = load_comp_moving(B, j, &vB);
+      LocalContact lc;
+      if (comp_pair_local(A, vA, Bc, vB, &lc)) rows_p[(size_t)ia * kRowCap + atomicAdd(&s_np[g2], 1u)] = j;
+    }
   }
   {  // accepted partners (World::step's candidate statistic): one atomic per block, spread over many words
     uint32_t v = (live && sub == 0) ? n_accepted : 0u;
@@ -421,8 +521,102 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid_n(Bodies B, uint32_t n
     if (lane == 0 && v) atomicAdd(&s_sum, v);
   }
   __syncthreads();
-  if (live && sub == 0) p_cnt[i] = s_np[qg];
+  if (live && sub == 0) {
+    if (PARTS) { p_cnt[i] = s_ncon[qg]; p_ent[i] = s_np[qg]; }
+    else p_cnt[i] = s_np[qg];
+  }
   if (threadIdx.x == 0 && s_sum) atomicAdd(&pair_stat[blockIdx.x & (kPairStatWords - 1u)], s_sum);
+}
+
+// ContactConstraint::new for the rows of a world with bodies of up to two components: k_contacts_rows' work with a manifold of up to four
+// contacts per row entry (consecutive single-contact records that share its normal and tangents: ContactConstraint::solve, solver.rs:219-248,
+// handles the contacts of a constraint one after the other on the same velocities - k_setup_pairs) and up to four parked contacts per
+// (body, face) slot.  A block per 256 bodies; the entries of its bodies as a list in LDS in canonical order, an entry per thread.
+struct ContactsParts {
+  const StepCounts* sc;
+  uint32_t n, cap_c, cap_t, t_stride;
+  const uint32_t *rows_p, *t_cnt, *p_cnt, *p_ent, *base, *tcn, *tpos;
+  const NContact* t_out;  // t_stride per slot; .lb.w of the first = the slot's contact count
+  float dt, baumgarte, slop;
+  CRec* cons; uint2* ab; uint32_t* degb; RevEnt* rev; uint32_t rev_cap; uint32_t* rev_flag; uint32_t* flag;
+  const uint32_t* ext;
+};
+constexpr uint32_t kCpEntCap = 2048;  // entries of a block staged per pass
+__global__ __launch_bounds__(kBlock) void k_contacts_rows_parts(Bodies B, TerrainDev M, ContactsParts A) {
+  __shared__ uint32_t s_j[kCpEntCap];            // the pass's entries in canonical order: partner | contacts << 27 ...
+  __shared__ uint16_t s_b[kCpEntCap], s_off[kCpEntCap];  // ... the owner (the block's body) and the entry's first constraint behind the body's terrain constraints
+  __shared__ uint32_t s_cb[kBlock];              // body -> id of its first partner constraint
+  __shared__ uint32_t s_wave[kBlock / 64];
+  if (A.sc->fail) return;  // (the scan's closing thread found a flag up or a capacity exceeded: the host re-runs the phase)
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const uint32_t i0 = blockIdx.x * (uint32_t)kBlock, i = i0 + (uint32_t)t;
+  uint32_t ne = 0, run = 0, base_i = 0;
+  if (i < A.n) { ne = A.p_ent[i]; run = A.tcn[i]; base_i = A.base[i]; }
+  uint32_t inc = ne;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+  if (lane == 63) s_wave[wv] = inc;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+  for (int k = 0; k < kBlock / 64; ++k) { const uint32_t v = s_wave[k]; if (k < wv) before += v; total += v; }
+  const uint32_t excl = before + inc - ne;
+  s_cb[t] = base_i + run;
+  const uint32_t* rp = A.rows_p + (size_t)i * kRowCap;
+  // ---- the terrain contacts' constraints (world.rs:243-251): the body's own thread
+  if (run) {
+    const uint32_t nt = A.t_cnt[i], tp = A.tpos[i];
+    const V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
+    const BodyDyn Ad = load_dyn(B.srec, i), S = static_dyn();
+    const BodyPack Pa = load_pack(B, i, false);
+    uint32_t c = base_i;
+    for (uint32_t a = 0; a < nt; ++a) {
+      const NContact in0 = A.t_out[(size_t)A.t_stride * (tp + a)];
+      const uint32_t nc = f2u(in0.lb.w);
+      for (uint32_t k = 0; k < nc; ++k, ++c) {
+        const NContact in = k == 0 ? in0 : A.t_out[(size_t)A.t_stride * (tp + a) + k];
+        // Static{ center: terrain.center(), friction: 0.0 } world.rs:247
+        const CRec r = make_constraint(i, kNone, Ad, xyz(Pa.ei), Pa.ei.w, Pa.dl.w, S, mx, 0.0f, 0.0f, xyz(in.n), xyz(in.la), xyz(in.lb), A.dt, A.baumgarte, A.slop);
+        store_crec(&A.cons[c], r);
+        A.ab[c] = make_uint2(i, kNone);
+      }
+    }
+  }
+  for (uint32_t w0 = 0; w0 < total; w0 += kCpEntCap) {
+    __syncthreads();
+    // the body's entries to their places: ascending order id (the canonical insertion order), each behind the contacts of the ones before it
+    for (uint32_t a = 0; a < ne; ++a) {
+      const uint32_t w = rp[a], oa = order_id(A.ext, w & 0x07FFFFFFu);
+      uint32_t rank = 0, off = 0;
+      for (uint32_t q = 0; q < ne; ++q) { const uint32_t x = rp[q]; if (order_id(A.ext, x & 0x07FFFFFFu) < oa) { ++rank; off += x >> 27; } }
+      const uint32_t pos = excl + rank - w0;
+      if (pos < kCpEntCap) { s_j[pos] = w; s_b[pos] = (uint16_t)t; s_off[pos] = (uint16_t)off; }
+    }
+    __syncthreads();
+    const uint32_t m = min(total - w0, kCpEntCap);
+    for (uint32_t e = (uint32_t)t; e < m; e += (uint32_t)kBlock) {
+      const uint32_t w = s_j[e], j = w & 0x07FFFFFFu, nc = w >> 27, b = s_b[e], ia = i0 + b;
+      const PartsOf Pi = load_parts2(B, ia), Pj = load_parts2(B, j);
+      V3 la[4], lb[4], nrm;
+      const uint32_t got = (uint32_t)pair_manifold2(Pi, Pj, la, lb, &nrm);
+      if (got != nc) { *A.flag = 1u; continue; }  // the pair search's evaluation of the same manifold and this one disagree
+      const BodyPack Pa = load_pack(B, ia, false), Pb = load_pack(B, j, false);
+      const BodyDyn Ad = load_dyn(B.srec, ia), Bd = load_dyn(B.srec, j);
+      const uint32_t c0 = s_cb[b] + s_off[e];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if ((uint32_t)k < nc) {
+          const uint32_t c = c0 + (uint32_t)k;
+          const CRec r = make_constraint(ia, j, Ad, xyz(Pa.ei), Pa.ei.w, Pa.dl.w, Bd, xyz(Pb.ei), Pb.ei.w, Pb.dl.w, nrm, la[k], lb[k], A.dt, A.baumgarte, A.slop);
+          store_crec(&A.cons[c], r);
+          A.ab[c] = make_uint2(ia, j);
+          // body j's row of the constraints it takes part in as `b` (k_chain_rows); as `a` a body owns a contiguous id range
+          const uint32_t pos = atomicAdd(&A.degb[j], 1u);
+          if (pos < A.rev_cap) A.rev[(size_t)j * A.rev_cap + pos] = RevEnt{c, ia, order_id(A.ext, ia), 0u};
+          else *A.rev_flag = 1u;
+        }
+      }
+    }
+  }
 }
 
 }  // namespace mgf

@@ -17,6 +17,8 @@ cases = [
     ("capsules 8x6x8 dense, heightfield 4x4 (32 faces: rows)", scenes.capsule_field(8, 6, 8, quads=4, pitch=1.6), 240),
     ("mixed 30% spheres 10x6x10, heightfield 16x16", scenes.capsule_field(10, 6, 10, quads=16, pitch=1.6, sphere_fraction=0.3), 240),
     ("mixed 30% spheres 10x6x10, heightfield 5x5 (rows)", scenes.capsule_field(10, 6, 10, quads=5, pitch=1.6, sphere_fraction=0.3), 240),
+    ("two-part bodies 8x5x8 + 40 plain spheres over the box", scenes.dumbbell_field(8, 5, 8, n_plain=40), 300),
+    ("two-part bodies 10x4x10 over the box", scenes.dumbbell_field(10, 4, 10), 240),
 ]
 for name, sc, ticks in cases:
     dt, it = float(sc["dt"]), sc["iters"]
@@ -42,7 +44,19 @@ for name, sc, ticks in cases:
     print(f"{name}: {ticks} ticks bit-identical (front_rows 1 / 0 / oracle), {sa.n_constraints} constraints ({sa.n_terrain_constraints} terrain) at the end", flush=True)
     del a, b
 
-if not quick:
+if not quick and "--config5" in sys.argv:
+    sc = scenes.dumbbell_field(64, 16, 64)
+    dt, it = float(sc["dt"]), sc["iters"]
+    a, b = mgf_amd.World.from_scene(ctx, sc), mgf_amd.World.from_scene(ctx, sc)
+    b.set_option("front_rows", 0)
+    for s in range(50, 401, 50):
+        t0 = time.perf_counter(); sa = a.step_many(dt, it, 50); ta = (time.perf_counter() - t0) / 50
+        t0 = time.perf_counter(); sb = b.step_many(dt, it, 50); tb = (time.perf_counter() - t0) / 50
+        assert same_state(a.state(), b.state()), s
+        assert int(sa[49]["n_constraints"]) == int(sb[49]["n_constraints"]) and int(sa[49]["n_pair_candidates"]) == int(sb[49]["n_pair_candidates"]) and int(sa[49]["n_terrain_candidates"]) == int(sb[49]["n_terrain_candidates"]), s
+        print(f"config 5 tick {s}: bit-identical, {int(sa[49]['n_constraints'])} constraints ({int(sa[49]['n_terrain_constraints'])} terrain), {int(sa[49]['n_pair_candidates'])} accepted partners; ms/tick front_rows {ta*1e3:.3f} vs lists {tb*1e3:.3f}", flush=True)
+    del a, b
+if not quick and "--config5" not in sys.argv:
     sc = scenes.capsule_field(128, 32, 32, quads=158)
     dt, it = float(sc["dt"]), sc["iters"]
     a, b = mgf_amd.World.from_scene(ctx, sc), mgf_amd.World.from_scene(ctx, sc)
