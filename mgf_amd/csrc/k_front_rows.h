@@ -334,73 +334,72 @@ constexpr uint32_t kPnQueries = kCoopBlock / kCoopLanes;  // 64 queries per bloc
 // per part pair in order (parts of i outer), local points relative to the bodies' centres (LocalContacts, compound.rs:192-207),
 // ContactPruner::push (manifold.rs:72-102), Manifold::from(pruner) (:131-148) - the same operations on the same values.  An ordinary
 // body is a body of one part (its collider).  Returns the contacts kept (0..4); la / lb = their local points, *normal = the manifold's.
-struct PartsOf { Comp part[2]; int n; V3 centre, v; };
-__device__ __forceinline__ PartsOf load_parts2(const Bodies& B, uint32_t i) {
-  PartsOf P;
-  const uint32_t pc = B.pcount ? B.pcount[i] : 0u;
-  const float4 c0 = B.col0[i];
-  P.v = xyz(B.delta[i]);
-  P.part[1].kind = KIND_SPHERE; P.part[1].p = mk3(0, 0, 0); P.part[1].d = mk3(0, 0, 0); P.part[1].r = 0.0f;
-  if (pc == 0u) {
-    const float4 c1 = B.col1[i];
-    P.part[0].kind = (int)f2u(c1.w); P.part[0].p = xyz(c0); P.part[0].r = c0.w; P.part[0].d = xyz(c1);
-    P.n = 1; P.centre = comp_center(P.part[0]);
-  } else {
-    P.n = (int)min(pc, 2u); P.centre = xyz(c0);
-    const float4 a0 = B.wp0[kMaxParts * (size_t)i], b0 = B.wp1[kMaxParts * (size_t)i];
-    P.part[0].kind = (int)f2u(b0.w); P.part[0].p = xyz(a0); P.part[0].r = a0.w; P.part[0].d = xyz(b0);
-    if (pc > 1u) {
-      const float4 a1 = B.wp0[kMaxParts * (size_t)i + 1], b1 = B.wp1[kMaxParts * (size_t)i + 1];
-      P.part[1].kind = (int)f2u(b1.w); P.part[1].p = xyz(a1); P.part[1].r = a1.w; P.part[1].d = xyz(b1);
-    }
+// The manifold of a pair of bodies in k_narrow_pairs_parts' steps, the raw contacts of the part pairs staged in LDS (a lane per part pair,
+// then a lane per pair of bodies for the pruner): one call site of the pair test, no per-lane arrays (a lane that ran the four part pairs by
+// itself kept them in scratch memory, and a block's few hundred pairs filled a quarter of its lanes).
+constexpr uint32_t kPpRound = 128;  // pairs of bodies per round of a block (4 raw slots of 48 bytes each: 24 KB)
+// one part pair (slot = 2 a + b, parts of i outer) -> its raw slot: a.xyz, t | b.xyz, hit | n.xyz
+__device__ __forceinline__ void parts_item(const Bodies& B, uint32_t i, uint32_t j, uint32_t slot, NContact* out) {
+  NContact raw;
+  raw.la = raw.lb = raw.n = make_float4(0, 0, 0, 0);
+  const uint32_t a = slot >> 1, b = slot & 1u;
+  const uint32_t pci = B.pcount ? B.pcount[i] : 0u, pcj = B.pcount ? B.pcount[j] : 0u;
+  if ((pci == 0u ? a == 0u : a < pci) && (pcj == 0u ? b == 0u : b < pcj)) {
+    float4 a0, a1, b0, b1;
+    if (pci == 0u) { a0 = B.col0[i]; a1 = B.col1[i]; } else { a0 = B.wp0[kMaxParts * (size_t)i + a]; a1 = B.wp1[kMaxParts * (size_t)i + a]; }
+    if (pcj == 0u) { b0 = B.col0[j]; b1 = B.col1[j]; } else { b0 = B.wp0[kMaxParts * (size_t)j + b]; b1 = B.wp1[kMaxParts * (size_t)j + b]; }
+    Comp Pa, Pb;
+    Pa.kind = (int)f2u(a1.w); Pa.p = xyz(a0); Pa.r = a0.w; Pa.d = xyz(a1);
+    Pb.kind = (int)f2u(b1.w); Pb.p = xyz(b0); Pb.r = b0.w; Pb.d = xyz(b1);
+    const V3 vA = xyz(B.delta[i]), vB = xyz(B.delta[j]);
+    Contact c;
+    if (!comp_pair_far(Pa, vA, Pb, vB) && comp_pair_contact(Pa, vA, Pb, vB, &c)) { raw.la = mk4(c.a, c.t); raw.lb = mk4(c.b, 1.0f); raw.n = mk4(c.n, 0.0f); }
   }
+  *out = raw;
+}
+// ContactPruner::push (manifold.rs:72-102) over the four raw slots of a pair, in order: the contacts kept (their slots, two bits each, in
+// *keep), the earliest time, the manifold's normal (Manifold::from(pruner), :131-148).  `mine` is LDS: indexed at run time.
+struct PairCentres { V3 ci, cj, vA, vB; };
+__device__ __forceinline__ PairCentres pair_centres(const Bodies& B, uint32_t i, uint32_t j) {
+  PairCentres P;
+  const uint32_t pci = B.pcount ? B.pcount[i] : 0u, pcj = B.pcount ? B.pcount[j] : 0u;
+  P.ci = pci ? xyz(B.col0[i]) : comp_center(load_comp(B, i)); P.cj = pcj ? xyz(B.col0[j]) : comp_center(load_comp(B, j));
+  P.vA = xyz(B.delta[i]); P.vB = xyz(B.delta[j]);
   return P;
 }
-__device__ __forceinline__ Contact pick4(const Contact* raw, uint32_t k) { return k == 0u ? raw[0] : (k == 1u ? raw[1] : (k == 2u ? raw[2] : raw[3])); }
-__device__ inline int pair_manifold2(const PartsOf& Pi, const PartsOf& Pj, V3* la, V3* lb, V3* normal) {
-  Contact raw[4];
-  bool have[4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int slot = a * 2 + b;
-      have[slot] = false;
-      raw[slot] = mkc(mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), 0.0f);
-      if (a < Pi.n && b < Pj.n && !comp_pair_far(Pi.part[a], Pi.v, Pj.part[b], Pj.v)) have[slot] = comp_pair_contact(Pi.part[a], Pi.v, Pj.part[b], Pj.v, &raw[slot]);
-    }
-  }
-  auto local_a = [&](const Contact& c) -> V3 { return c.a + -(Pi.centre + Pi.v * c.t); };
-  auto local_b = [&](const Contact& c) -> V3 { return c.b + -(Pj.centre + Pj.v * c.t); };
+__device__ __forceinline__ LocalContact parts_local(const PairCentres& P, const NContact& raw) {
+  Contact c; c.a = xyz(raw.la); c.b = xyz(raw.lb); c.n = xyz(raw.n); c.t = raw.la.w;
+  LocalContact nc; nc.la = c.a + -(P.ci + P.vA * c.t); nc.lb = c.b + -(P.cj + P.vB * c.t); nc.g = c;
+  return nc;
+}
+__device__ __forceinline__ int parts_prune(const PairCentres& P, const NContact* mine, uint32_t* keep_out, float* min_t_out, V3* normal) {
   float min_t = kInf;
   int cnt = 0;
   uint32_t keep = 0u;  // (keep >> 2k) & 3: the slot of the k-th kept contact
-#pragma unroll
-  for (int slot = 0; slot < 4; ++slot) {
-    if (!have[slot]) continue;
-    const Contact nc = raw[slot];
-    if (nc.t < min_t - kCollisionEps) { cnt = 1; keep = (uint32_t)slot; min_t = nc.t; continue; }
-    if (nc.t > min_t + kCollisionEps) continue;
+  for (uint32_t slot = 0; slot < 4u; ++slot) {
+    const NContact raw = mine[slot];
+    if (raw.lb.w == 0.0f) continue;
+    const LocalContact nc = parts_local(P, raw);
+    if (nc.g.t < min_t - kCollisionEps) { cnt = 1; keep = slot; min_t = nc.g.t; continue; }
+    if (nc.g.t > min_t + kCollisionEps) continue;
     bool merged = false;
     for (int k = 0; k < cnt && !merged; ++k) {
-      const Contact kc = pick4(raw, (keep >> (2 * k)) & 3u);
-      const V3 ra = nc.a - kc.a, rb = nc.b - kc.b;
+      const LocalContact kc = parts_local(P, mine[(keep >> (2 * k)) & 3u]);
+      const V3 ra = nc.g.a - kc.g.a, rb = nc.g.b - kc.g.b;
       if (mag2(ra) <= kPersistentThresholdSq || mag2(rb) <= kPersistentThresholdSq) {
-        const float prev = mag2(local_a(kc)) + mag2(local_b(kc)), cur = mag2(local_a(nc)) + mag2(local_b(nc));
-        if (prev < cur) keep = (keep & ~(3u << (2 * k))) | ((uint32_t)slot << (2 * k));
+        const float prev = mag2(kc.la) + mag2(kc.lb), cur = mag2(nc.la) + mag2(nc.lb);
+        if (prev < cur) keep = (keep & ~(3u << (2 * k))) | (slot << (2 * k));
         merged = true;
       }
     }
-    if (!merged) { keep = (keep & ~(3u << (2 * cnt))) | ((uint32_t)slot << (2 * cnt)); ++cnt; }
+    if (!merged) { keep = (keep & ~(3u << (2 * cnt))) | (slot << (2 * cnt)); ++cnt; }
   }
-  if (cnt == 0) return 0;
-  V3 sum = mk3(0.0f, 0.0f, 0.0f);
-  for (int k = 0; k < cnt; ++k) sum = sum + pick4(raw, (keep >> (2 * k)) & 3u).n;
-  *normal = sum / (float)cnt;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (k < cnt) { const Contact kc = pick4(raw, (keep >> (2 * k)) & 3u); la[k] = local_a(kc); lb[k] = local_b(kc); }
+  if (cnt) {
+    V3 sum = mk3(0.0f, 0.0f, 0.0f);
+    for (int k = 0; k < cnt; ++k) sum = sum + xyz(mine[(keep >> (2 * k)) & 3u].n);
+    *normal = sum / (float)cnt;
   }
+  *keep_out = keep; *min_t_out = min_t;
   return cnt;
 }
 
@@ -411,6 +410,7 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid_n(Bodies B, uint32_t n
                                                             uint32_t* p_cnt, uint32_t* overflow, uint32_t* too_wide, uint32_t* pair_stat, float min_frac, uint32_t* p_ent) {
   __shared__ uint32_t s_acc[kPnQueries][kRowCap];   // accepted partners of a query (body slots)
   __shared__ uint32_t s_ncon[PARTS ? kPnQueries : 1];
+  __shared__ NContact s_raw[PARTS ? 4 * kPpRound : 1];  // the raw contacts of a round's pairs, four slots each
   __shared__ uint32_t s_pool[kPnQueries * kRowCap]; // the block's partners that may touch: partner slot | query << 26
   __shared__ uint32_t s_qi[kPnQueries], s_np[kPnQueries];
   __shared__ uint32_t s_pool_n, s_sum;
@@ -500,14 +500,26 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid_n(Bodies B, uint32_t n
 #else
   const uint32_t pool_n = s_pool_n;
 #endif
-  for (uint32_t e = threadIdx.x; e < pool_n; e += kCoopBlock) {
-    const uint32_t w = s_pool[e], j = w & 0x03FFFFFFu, g2 = w >> 26, ia = s_qi[g2];
-    if (PARTS) {
-      const PartsOf Pi = load_parts2(B, ia), Pj = load_parts2(B, j);
-      V3 la[4], lb[4], nrm;
-      const int nc = pair_manifold2(Pi, Pj, la, lb, &nrm);
-      if (nc) { rows_p[(size_t)ia * kRowCap + atomicAdd(&s_np[g2], 1u)] = j | ((uint32_t)nc << 27); atomicAdd(&s_ncon[g2], (uint32_t)nc); }
-    } else {
+  if (PARTS) {
+    for (uint32_t r0 = 0; r0 < pool_n; r0 += kPpRound) {  // (the same trips for every thread of the block)
+      const uint32_t m = min(pool_n - r0, kPpRound);
+      for (uint32_t x = threadIdx.x; x < 4u * m; x += kCoopBlock) {  // a lane per part pair, part-pair-major: consecutive lanes run the same pair of shapes
+        const uint32_t slot = x / m, e = x - slot * m, w = s_pool[r0 + e];
+        parts_item(B, s_qi[w >> 26], w & 0x03FFFFFFu, slot, &s_raw[4u * e + slot]);
+      }
+      __syncthreads();
+      for (uint32_t e = threadIdx.x; e < m; e += kCoopBlock) {  // a lane per pair of bodies: the pruner
+        const uint32_t w = s_pool[r0 + e], j = w & 0x03FFFFFFu, g2 = w >> 26, ia = s_qi[g2];
+        const PairCentres P = pair_centres(B, ia, j);
+        uint32_t keep; float min_t; V3 nrm;
+        const int nc = parts_prune(P, &s_raw[4u * e], &keep, &min_t, &nrm);
+        if (nc) { rows_p[(size_t)ia * kRowCap + atomicAdd(&s_np[g2], 1u)] = j | ((uint32_t)nc << 27); atomicAdd(&s_ncon[g2], (uint32_t)nc); }
+      }
+      __syncthreads();
+    }
+  } else {
+    for (uint32_t e = threadIdx.x; e < pool_n; e += kCoopBlock) {
+      const uint32_t w = s_pool[e], j = w & 0x03FFFFFFu, g2 = w >> 26, ia = s_qi[g2];
       V3 vA, vB;
       const Comp A = load_comp_moving(B, ia, &vA), Bc = load_comp_moving(B, j, &vB);
       LocalContact lc;
@@ -541,11 +553,13 @@ struct ContactsParts {
   CRec* cons; uint2* ab; uint32_t* degb; RevEnt* rev; uint32_t rev_cap; uint32_t* rev_flag; uint32_t* flag;
   const uint32_t* ext;
 };
-constexpr uint32_t kCpEntCap = 2048;  // entries of a block staged per pass
+constexpr uint32_t kCpEntCap = 1024;  // entries of a block staged per pass
 __global__ __launch_bounds__(kBlock) void k_contacts_rows_parts(Bodies B, TerrainDev M, ContactsParts A) {
+  __shared__ uint32_t s_tj[kCpEntCap], s_to[kCpEntCap];  // the bodies' rows as they are, and the partners' order ids
   __shared__ uint32_t s_j[kCpEntCap];            // the pass's entries in canonical order: partner | contacts << 27 ...
   __shared__ uint16_t s_b[kCpEntCap], s_off[kCpEntCap];  // ... the owner (the block's body) and the entry's first constraint behind the body's terrain constraints
   __shared__ uint32_t s_cb[kBlock];              // body -> id of its first partner constraint
+  __shared__ NContact s_raw[4 * kPpRound];       // the raw contacts of a round's entries, four slots each
   __shared__ uint32_t s_wave[kBlock / 64];
   if (A.sc->fail) return;  // (the scan's closing thread found a flag up or a capacity exceeded: the host re-runs the phase)
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -563,7 +577,11 @@ __global__ __launch_bounds__(kBlock) void k_contacts_rows_parts(Bodies B, Terrai
   s_cb[t] = base_i + run;
   const uint32_t* rp = A.rows_p + (size_t)i * kRowCap;
   // ---- the terrain contacts' constraints (world.rs:243-251): the body's own thread
+#if defined(MGF_CP_ABL) && MGF_CP_ABL == 1
+  if (false) {
+#else
   if (run) {
+#endif
     const uint32_t nt = A.t_cnt[i], tp = A.tpos[i];
     const V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
     const BodyDyn Ad = load_dyn(B.srec, i), S = static_dyn();
@@ -581,32 +599,52 @@ __global__ __launch_bounds__(kBlock) void k_contacts_rows_parts(Bodies B, Terrai
       }
     }
   }
+#if defined(MGF_CP_ABL) && MGF_CP_ABL == 2
+  if (total) return;
+#endif
   for (uint32_t w0 = 0; w0 < total; w0 += kCpEntCap) {
     __syncthreads();
-    // the body's entries to their places: ascending order id (the canonical insertion order), each behind the contacts of the ones before it
+    // the body's entries to their places: ascending order id (the canonical insertion order), each behind the contacts of the ones before it.
+    // (The row and its partners' order ids once, into LDS: ranked from global memory a body of eight entries made 128 dependent look-ups.)
+    const bool staged = excl >= w0 && excl + ne <= w0 + kCpEntCap;  // (a body across a window's edge ranks from global memory)
+    if (staged) for (uint32_t a = 0; a < ne; ++a) { const uint32_t w = rp[a]; s_tj[excl - w0 + a] = w; s_to[excl - w0 + a] = order_id(A.ext, w & 0x07FFFFFFu); }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (a lane reads what it wrote itself)
     for (uint32_t a = 0; a < ne; ++a) {
-      const uint32_t w = rp[a], oa = order_id(A.ext, w & 0x07FFFFFFu);
+      const uint32_t w = staged ? s_tj[excl - w0 + a] : rp[a], oa = staged ? s_to[excl - w0 + a] : order_id(A.ext, w & 0x07FFFFFFu);
       uint32_t rank = 0, off = 0;
-      for (uint32_t q = 0; q < ne; ++q) { const uint32_t x = rp[q]; if (order_id(A.ext, x & 0x07FFFFFFu) < oa) { ++rank; off += x >> 27; } }
+      for (uint32_t q = 0; q < ne; ++q) {
+        const uint32_t x = staged ? s_tj[excl - w0 + q] : rp[q], ox = staged ? s_to[excl - w0 + q] : order_id(A.ext, x & 0x07FFFFFFu);
+        if (ox < oa) { ++rank; off += x >> 27; }
+      }
       const uint32_t pos = excl + rank - w0;
       if (pos < kCpEntCap) { s_j[pos] = w; s_b[pos] = (uint16_t)t; s_off[pos] = (uint16_t)off; }
     }
     __syncthreads();
     const uint32_t m = min(total - w0, kCpEntCap);
-    for (uint32_t e = (uint32_t)t; e < m; e += (uint32_t)kBlock) {
-      const uint32_t w = s_j[e], j = w & 0x07FFFFFFu, nc = w >> 27, b = s_b[e], ia = i0 + b;
-      const PartsOf Pi = load_parts2(B, ia), Pj = load_parts2(B, j);
-      V3 la[4], lb[4], nrm;
-      const uint32_t got = (uint32_t)pair_manifold2(Pi, Pj, la, lb, &nrm);
-      if (got != nc) { *A.flag = 1u; continue; }  // the pair search's evaluation of the same manifold and this one disagree
-      const BodyPack Pa = load_pack(B, ia, false), Pb = load_pack(B, j, false);
-      const BodyDyn Ad = load_dyn(B.srec, ia), Bd = load_dyn(B.srec, j);
-      const uint32_t c0 = s_cb[b] + s_off[e];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if ((uint32_t)k < nc) {
-          const uint32_t c = c0 + (uint32_t)k;
-          const CRec r = make_constraint(ia, j, Ad, xyz(Pa.ei), Pa.ei.w, Pa.dl.w, Bd, xyz(Pb.ei), Pb.ei.w, Pb.dl.w, nrm, la[k], lb[k], A.dt, A.baumgarte, A.slop);
+    for (uint32_t r0 = 0; r0 < m; r0 += kPpRound) {  // (the same trips for every thread of the block)
+      const uint32_t mr = min(m - r0, kPpRound);
+      __syncthreads();
+      for (uint32_t x = (uint32_t)t; x < 4u * mr; x += (uint32_t)kBlock) {  // a lane per part pair
+        const uint32_t slot = x / mr, e = x - slot * mr;
+        parts_item(B, i0 + s_b[r0 + e], s_j[r0 + e] & 0x07FFFFFFu, slot, &s_raw[4u * e + slot]);
+      }
+      __syncthreads();
+#if defined(MGF_CP_ABL) && MGF_CP_ABL == 3
+      if (true) continue;
+#endif
+      for (uint32_t e = (uint32_t)t; e < mr; e += (uint32_t)kBlock) {  // a lane per entry: the pruner, then a record per contact kept
+        const uint32_t w = s_j[r0 + e], j = w & 0x07FFFFFFu, nc = w >> 27, b = s_b[r0 + e], ia = i0 + b;
+        const PairCentres P = pair_centres(B, ia, j);
+        uint32_t keep; float min_t; V3 nrm;
+        const uint32_t got = (uint32_t)parts_prune(P, &s_raw[4u * e], &keep, &min_t, &nrm);
+        if (got != nc) { *A.flag = 1u; continue; }  // the pair search's evaluation of the same manifold and this one disagree
+        const BodyPack Pa = load_pack(B, ia, false), Pb = load_pack(B, j, false);
+        const BodyDyn Ad = load_dyn(B.srec, ia), Bd = load_dyn(B.srec, j);
+        const uint32_t c0 = s_cb[b] + s_off[r0 + e];
+        for (uint32_t k = 0; k < nc; ++k) {
+          const uint32_t c = c0 + k;
+          const LocalContact kc = parts_local(P, s_raw[4u * e + ((keep >> (2u * k)) & 3u)]);
+          const CRec r = make_constraint(ia, j, Ad, xyz(Pa.ei), Pa.ei.w, Pa.dl.w, Bd, xyz(Pb.ei), Pb.ei.w, Pb.dl.w, nrm, kc.la, kc.lb, A.dt, A.baumgarte, A.slop);
           store_crec(&A.cons[c], r);
           A.ab[c] = make_uint2(ia, j);
           // body j's row of the constraints it takes part in as `b` (k_chain_rows); as `a` a body owns a contiguous id range
