@@ -413,8 +413,13 @@ MGF_API int64_t mgf_tiles_counter(const mgf_tiles* t, const char* key);
  * 6 = block-local dataflow with message channels between the blocks (every body a block touches in LDS);
  * (modes 1, 4, 5, 6 are persistent launches whose workgroups wait for one another: they need the device's compute units to
  * themselves - one process per GPU, one context's stream at a time.  Where two processes' launches overlap on one device each
- * may hold part of the compute units; a launch then gives up after about half a second and the call returns MGF_ERR_HIP
- * "dataflow solver gave up waiting" instead of hanging - the world's velocities are then undefined);
+ * may hold part of the compute units; a launch then gives up after about half a second.  Solver::solve cannot fail (solver.rs:72-78), so
+ * neither does the call: mgf_world_step / _step_many / _solve put the velocities (and accumulated impulses) back as the launch found
+ * them and solve the list again with the launch-per-frontier executor - bit-identical - counted in "solver_abort_fallbacks"; a tile set
+ * repeats the tick on every rank ("retry_lost_ticks").  MGF_ERR_HIP "dataflow solver gave up waiting" can still surface only where
+ * nothing can be solved again from inside the call: "stream_ordered" = 1 (no wait inside the call), or a tile set with
+ * "retry_lost_ticks" = 0 - the state is then that of a tick whose solve did not happen.  Processes that know they share a device say
+ * so with "flow_max_blocks");
  * "constraint_order" [0] 1 = the reference's own insertion order, replayed on the host (world.rs:233-291);
  * "pair_brick" [1] (grid broadphase with an 8x8x8-cell box staged in LDS; 0 = every look-up from global memory);
  * "body_pack" [1] (the constraint setup reads collider, motion and info from the packed per-tick copy);
@@ -423,6 +428,12 @@ MGF_API int64_t mgf_tiles_counter(const mgf_tiles* t, const char* key);
  * "flow6_fcap", "flow6_const_lds", "flow6_poll_waves", "flow6_test_cap" (mode 6: foreign-body slots, constants in LDS,
  * polling waves, a test limit that forces the stand-by kernel); "two_pass_candidates" [0]; "broadphase_tree" [0]; "terrain_tree" [0]; "no_fused_narrowphase" [0] (a world of spheres only runs the sphere-sphere test inside the grid broadphase and lists contacts only; 1 = list every accepted partner); "stream_ordered" [0]; "phase_timing" [0] (HIP events at the tick's phase boundaries: mgf_step_stats::ms_*), "time_solver_kernels" [0] (events around the solver launches: ms_solver_kernels); "spin_wait" [1] (the tick's one wait polls an event instead of blocking); "pipeline" [1] (mgf_world_step_many enqueues the next tick before it waits for this one); "cell_fill" [16] (bodies per Morton cell, in eighths, beyond which the broadphase grid gets another level); "no_fused_terrain_rows" [0], "no_fused_scene_bounds" [0] (mgf_world_step and mgf_world_begin_tick list the terrain faces of a body and gather the scene bounds inside the integration kernel; 1 = always the separate kernels); "list_capacity";
  * "fused_contacts" [1] (a world of spheres over a small mesh: rows -> constraint records without candidate lists; 0 = the candidate-list kernels);
+ * "front_rows" [1] (r06: a world of single-component bodies that are not all spheres - capsules, mixed - or of bodies of up to two components:
+ * the pair search runs the pair test on the partners it accepts, the bodies near the mesh get their faces and the body-triangle test in
+ * launches of their own, the constraint records are written from the rows; 0 = candidate lists and one narrowphase launch per shape-pair
+ * type); "front_rows_check" [0] (tests: the faces the cheap conservative reject ahead of the body-triangle tests drops are tested all the
+ * same - a contact among them is reported as an internal error); "side_stream" [1] (the terrain kernels of that front end run on a
+ * second stream of the context beside the pair search; 0 = everything on the context's stream);
  * "cells_in_integrate" [1] (the fused tick's k_integrate works out the bodies' Morton cells over the previous tick's scene bounds);
  * "flow_max_blocks" [0] (the persistent solver launches of this world take at most this many workgroups - one per CU; 0 = all CUs.  Processes that
  * share a device each take a part, so that their launches are resident together); "flow_spin_limit" [0] (tests: 1 = every other workgroup of a
@@ -435,7 +446,8 @@ MGF_API mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_t v
 /* Diagnostics: how often a slow path was taken.  name in {"row_overflows", "capacity_retries", "flow5_fallbacks",
  * "grid_too_wide", "flow5_blocks", "flow5_class0|1|2", "terrain_grid", "terrain_row_capacity", "rev_row_capacity", "body_kinds",
  * "flow6_fallbacks", "flow6_fail_reason", "flow6_max_slots", "flow6_max_foreign", "pair_brick_slow_queries", "pair_brick_off_ticks",
- * "max_fat_half_extent_x_milli", "solver_abort_fallbacks" (Solver::solve calls whose persistent launch gave up and that were solved again from
+ * "max_fat_half_extent_x_milli", "scene_rmax_milli_x|y|z", "scene_ext_milli_x|y|z", "grid_levels", "front_rows", "front_near", "front_faces",
+ * "front_slots" (the list-free front end of the last tick: bodies near the mesh, faces accepted, faces that passed the cheap reject), "solver_abort_fallbacks" (Solver::solve calls whose persistent launch gave up and that were solved again from
  * the pre-launch state: Solver::solve has no failure mode, solver.rs:72-78), "device_ptrs_out" (1 while mgf_world_device_ptr's pointers pin
  * the store to the caller's order)}. */
 MGF_API mgf_status mgf_world_counter(const mgf_world* w, const char* name, int64_t* out);

@@ -264,9 +264,10 @@ __global__ __launch_bounds__(kScanBlock) void k_scan(ScanJob J) {
   __shared__ uint32_t s_wave[W][kScanBlock / 64];
   __shared__ uint32_t s_prev[W];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  // (few tiles - all of the launch's workgroups resident at once, whatever the order they start in: the block's own index; a launch of more
-  // than a thousand takes tickets, so that a tile's predecessors are always running)
-  if (t == 0) s_tile = gridDim.x <= 1024u ? blockIdx.x : atomicAdd(J.ticket, 1u);
+  // (a ticket, always: a tile's predecessors are then running whatever the order workgroups start in and however few fit on the device at once
+  // - a part with fewer CUs, a CU mask, a device shared with another process; r05 took the block's own index for launches of up to 1024
+  // workgroups, which relies on all of them being resident or dispatched in order: ADVICE r5)
+  if (t == 0) s_tile = atomicAdd(J.ticket, 1u);
   if (J.sb_part && blockIdx.x == gridDim.x - 1 && wv == kScanBlock / 64 - 1) {  // (one wave of the launch, beside its first loads: a partial record per lane)
     static_assert(kBoundSlots == 64, "a lane per partial record");
     int v[9];

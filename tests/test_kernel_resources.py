@@ -1,5 +1,5 @@
 """What the build must keep true of the tick's kernels (read from the notes of libmgf_hip.so's gfx950 code object, no GPU needed): no scratch
-memory - DESIGN.md says so - and no register spills in k_contacts_spheres, whose one device fault of round 5 went away with them
+memory - DESIGN.md says so - and no register spills in k_contacts_rows<true> (round 5's k_contacts_spheres), whose one device fault of round 5 went away with them
 (EXPERIMENTS.md: the listing of a block's later windows, inlined a second time, spilled scalar registers inside nested branches)."""
 import os
 import re
@@ -9,7 +9,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TICK_KERNELS = ("k_integrate", "k_tick_clear", "k_scan", "k_scatter_leaves", "k_pair_brick", "k_pair_grid", "k_terrain_contacts", "k_contacts_spheres",
+TICK_KERNELS = ("k_integrate", "k_tick_clear", "k_scan", "k_scatter_leaves", "k_pair_brick", "k_pair_grid", "k_terrain_contacts", "k_contacts_rows", "k_near_list", "k_terrain_near", "k_terrain_tests",
                 "k_flow6_blocks", "k_flow6_links", "k_publish", "k_setup_pairs", "k_lists_spheres", "k_narrow_pairs<", "k_narrow_terrain<", "k_count_contacts",
                 "k_rows_to_csr", "k_morton_count", "k_zero_many", "k_reset_step", "k_tile_select", "k_export_bodies", "k_import_ghosts", "k_export_vel",
                 "k_import_ghost_vel", "k_compact_", "k_tick_snapshot")
@@ -36,6 +36,6 @@ def test_no_kernel_of_the_tick_uses_scratch_memory():
     assert solver and all(v[2] == "0" and v[4] == "0" and v[5] == "0" for v in solver.values()), solver
 
 
-def test_k_contacts_spheres_spills_nothing():
-    v = _rows()["k_contacts_spheres"]
+def test_k_contacts_rows_of_spheres_spills_nothing():
+    v = _rows()["k_contacts_rows<true>"]
     assert v[2] == "0" and v[4] == "0" and v[5] == "0", v
