@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--solver-mode", type=int, default=None, help="override the library's default solver mode (development)")
     ap.add_argument("--refresh-every", type=int, default=None, help="solver iterations between ghost velocity refreshes (tiles)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="library option for an experiment (mgf_world_set_option), repeatable")
+    ap.add_argument("--no-one-gpu-reference", action="store_true", help="N > 1: do not measure the same scene's 8 tiles on ONE GPU of this box first (rank 0, before "
+                    "the ranks connect: ~15 s); same_workload_on_one_gpu then comes from the committed profiles/ and says so")
+    ap.add_argument("--no-settled-tiles", action="store_true", help="tiles: skip the second window after tick 400 (the pile has collapsed and come to rest)")
     ap.add_argument("--no-migrate", action="store_true", help="tiles: keep every body on its initial tile (development)")
     ap.add_argument("--transport", default="native", choices=["native", "torch"],
                     help="native = mgf_tiles_* (RCCL under the C-ABI); torch = the Python driver over torch.distributed (--scene weak only)")
@@ -470,6 +473,13 @@ def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, w
     dt = float(tile_scenes[0]["dt"])
     transport = args.transport
     ranks_seen = None
+    # The same scene's 8 tiles on ONE GPU of THIS box (rank 0's device, the other ranks idle at the barrier): what the N > 1 value is an
+    # efficiency against - measured here and now, not read from profiles/ (an efficiency across boxes is not a same-node figure)
+    one_gpu_here = None
+    if world_size > 1 and scene_kind in ("config4", "config5_tiles") and transport == "native" and not args.no_one_gpu_reference and not args.standin:
+        if rank == 0:
+            one_gpu_here = _one_gpu_reference_here(args, scene_kind)
+        barrier()
     if transport == "torch":
         if scene_kind != "weak" or per_rank != 1:
             raise SystemExit("--transport torch drives one tile per rank (--scene weak)")
@@ -602,6 +612,48 @@ def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, w
             dist.all_reduce(xus, op=dist.ReduceOp.SUM)
         for r, row in enumerate(exchange["per_rank"]):
             row["exchange_us_per_tick"] = round(float(xus[r].item()), 2)
+    step_latency = None
+    if transport == "native" and exchange is not None:
+        # which step of the protocol costs what (the replay's HIP events around every exchange, by kind): per rank, p50 / p99 / max of a call
+        kinds = ("bodies", "velocities", "handover")
+        mine_l = [float(tiles.counter(f"exchange_{w}_{k}")) for k in kinds for w in ("calls", "p50_ns", "p99_ns", "max_ns", "mean_ns")]
+        lat = torch.zeros((world_size, len(mine_l)), dtype=torch.float64, device=red_dev)
+        lat[rank] = torch.tensor(mine_l, dtype=torch.float64, device=red_dev)
+        if dist is not None:
+            dist.all_reduce(lat, op=dist.ReduceOp.SUM)
+        lat = lat.cpu().numpy()
+        step_latency = {"unit": "us per exchange call (one grouped ncclSend/ncclRecv - or the device copies between a rank's own tiles - for all of a rank's faces), "
+                                "stream time between HIP events, the wait for the neighbouring rank included; the instrumented replay of the timed ticks",
+                        "per_rank": [{"rank": r, **{k: {"calls": int(lat[r][5 * i]), "p50": round(lat[r][5 * i + 1] / 1e3, 2), "p99": round(lat[r][5 * i + 2] / 1e3, 2),
+                                                       "max": round(lat[r][5 * i + 3] / 1e3, 2), "mean": round(lat[r][5 * i + 4] / 1e3, 2)} for i, k in enumerate(kinds)}}
+                                     for r in range(world_size)]}
+        exchange["step_latency_us"] = step_latency
+    # a second window where the pile has collapsed and come to rest (ticks 400 ..): twice the constraints, hand-overs all the time - the
+    # window above is the falling pile (no settled tile window in any bench line)
+    settled = None
+    if transport == "native" and scene_kind in ("config4", "config5_tiles") and not args.no_settled_tiles:
+        tiles.set_option("exchange_timing", 0)
+        for w in rworlds:
+            w.set_option("time_solver_kernels", 0)
+        at = warmup + args.steps
+        while at < 400:
+            step(); at += 1
+        barrier()
+        ts0 = time.perf_counter()
+        s_ticks = [step() for _ in range(args.steps)]
+        barrier()
+        s_el = time.perf_counter() - ts0
+        s_units, s_cons, _sl, _sk = tally(s_ticks)
+        if dist is not None:
+            tt = torch.tensor([s_el], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            s_el = float(tt.item())
+            uu = torch.tensor([s_units, s_cons], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(uu, op=dist.ReduceOp.SUM)
+            s_units, s_cons = float(uu[0].item()), float(uu[1].item())
+        settled = {"value": s_units / s_el, "unit": "constraint-iters/s", "ms_per_step": s_el * 1e3 / args.steps, "steps": args.steps, "warmup": at,
+                   "constraints_per_step": s_cons / args.steps, "tile_tick_ms": s_el * 1e3 / (args.steps * per_rank),
+                   "note": "the same tile set stepped on to tick 400: the pile has collapsed and come to rest"}
     rank_ms = torch.zeros(world_size, dtype=torch.float64, device=red_dev)
     rank_ms[rank] = elapsed * 1e3 / (args.steps * per_rank)  # (a rank's own wall clock between the two barriers, per tile-tick)
     if dist is not None:
@@ -618,13 +670,22 @@ def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, w
         return None
     n_total = nx * ny * nz * total_tiles
     one_gpu = _same_workload_one_gpu("config4" if scene_kind == "config4" else "config5") if scene_kind in ("config4", "config5_tiles") and world_size > 1 else None
+    if one_gpu_here and "value" in one_gpu_here:  # (measured on this box a minute ago: that is the reference; the committed figure rides along)
+        one_gpu_here["committed_figure_of_another_box"] = {k: one_gpu[k] for k in ("value", "ms_per_step", "source")} if one_gpu else None
+        if one_gpu and one_gpu.get("undivided_world"):
+            one_gpu_here["undivided_world"] = one_gpu["undivided_world"]
+        one_gpu = one_gpu_here
+    elif one_gpu is not None:
+        one_gpu["measured_on_this_box"] = False
+        one_gpu["why_not"] = (one_gpu_here or {}).get("error") or ("--no-one-gpu-reference" if args.no_one_gpu_reference else "stand-in transport / development driver")
     eff = None
     if one_gpu:
         v = units_all / elapsed
         eff = {"vs_8_tiles_on_one_gpu": round(v / (world_size * one_gpu["value"]), 4),
                "vs_undivided_world_on_one_gpu": round(v / (world_size * one_gpu["undivided_world"]["value"]), 4) if one_gpu.get("undivided_world") else None,
                "definition": "(this line's value / N) / (the same scene's value on ONE GPU): 1.0 = perfect strong scaling; the one-GPU figures are committed "
-                             "measurements (same_workload_on_one_gpu.source), the 8-tile one through the same tile protocol"}
+                             "measurements (same_workload_on_one_gpu.source), the 8-tile one through the same tile protocol"
+                             + (" - the 8-tile figure MEASURED ON THIS BOX by rank 0 before the ranks connected" if one_gpu.get("measured_on_this_box") else "")}
     if scene_kind == "config5_tiles":
         name = (f"BASELINE config 5 (this build's own definition of a rigid body of two components - the reference has none, SURVEY H8): {n_total} bodies, each a "
                 f"sphere (r = 0.5) + a capsule (|d| = 1, r = 0.3), {total_tiles * nx}x{ny}x{nz} lattice of pitch 2.2 in one open box, cut into {total_tiles} x-slab "
@@ -661,7 +722,8 @@ def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, w
                            + " with the events on",
         "replay_did_the_timed_windows_work_rank0": replay_same,
         "same_workload_on_one_gpu": one_gpu, "efficiency_vs_same_workload_on_one_gpu": eff,
-        "exchange": exchange, "seam_penetration": seam,
+        "prediction": _tile_prediction(scene_kind, world_size, total_tiles, elapsed * 1e3 / args.steps, one_gpu),
+        "exchange": exchange, "seam_penetration": seam, "settled": settled,
     }
 
 
@@ -681,6 +743,60 @@ def _seam_penetration(tiles_x, radius=0.5):
         return {"pairs": int(len(d)), "mean": float(d.mean()) if len(d) else None, "p99": float(np.percentile(d, 99)) if len(d) else None, "max": float(d.max()) if len(d) else None}
     return {"unit": "sphere radii x 2 (depth = 2r - distance of centres, r = 0.5)", "across_tile_faces": stat(depth[across]), "inside_tiles": stat(depth[~across]),
             "note": "state at the end of the timed window; a pile that has not come to rest yet shows little depth on either side"}
+
+
+def _one_gpu_reference_here(args, scene_kind):
+    """python bench.py --gpus 1 --scene <the same> in a process of its own on this rank's device (the environment of the launcher's ranks taken out)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
+                                                           "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "MGF_BENCH_DEVICE") and not k.startswith("TORCHELASTIC")}
+    env["MGF_BENCH_DEVICE"] = os.environ.get("MGF_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0"))
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--scene", scene_kind, "--no-cpu-baseline", "--no-settled-tiles", "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--iters", str(args.iters)]
+    if args.refresh_every is not None:
+        cmd += ["--refresh-every", str(args.refresh_every)]
+    for o in args.opt:
+        cmd += ["--opt", o]
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+        return {"value": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "tile_tick_ms": d.get("tile_tick_ms_rank0"),
+                "measured_on_this_box": True, "took_s": round(time.perf_counter() - t0, 1),
+                "source": "measured by rank 0 on its own device before the ranks connected: " + " ".join(cmd[1:])}
+    except Exception as e:  # (a reference beside the measurement: never at the price of the line)
+        return {"error": repr(e)[:300]}
+
+
+# The N = 2 / 4 / 8 prediction of DESIGN.md section 8 for BASELINE config 4 (and 5) as 8 x-slab tiles, so that the first run on a real node is
+# judged against numbers written down BEFORE it: per tick = (tiles per rank) x (one tile's tick on one GPU) + the exchange steps of the
+# protocol, each a grouped ncclSend/ncclRecv at an ASSUMED point-to-point latency, + the rows across a rank face at an ASSUMED link rate.
+TILE_PREDICTION_ASSUMPTIONS = {
+    "p2p_latency_us": 20.0,        # one grouped ncclSend/ncclRecv of a few KB..MB between neighbouring GPUs, launch to completion on the stream (RCCL 2.26 over xGMI; never measured here)
+    "link_GBps": 60.0,             # achieved one-way rate of one xGMI link for MB-sized rows (153.6 GB/s bidirectional per link on paper)
+    "allreduce_us": 30.0,          # the tick's status agreement (4-byte all-reduce over N ranks)
+    "exchange_steps_per_tick": {"ghost_bodies": 1, "ghost_velocities": 4, "handover": 0.4, "status_allreduce": 1},
+    "bytes_per_rank_face_per_tick": {"config4": 3.4e6, "config5_tiles": 0.5e6},  # one direction: ghost records + 4 velocity refreshes (profiles/r05_config4_8tiles_1gpu_bench.json: 95 MB between the 14 face directions of 8 tiles)
+}
+
+
+def _tile_prediction(scene_kind, world_size, total_tiles, measured_ms, one_gpu):
+    if scene_kind not in ("config4", "config5_tiles") or not one_gpu or "ms_per_step" not in one_gpu:
+        return None
+    A = TILE_PREDICTION_ASSUMPTIONS
+    tile_tick = one_gpu["ms_per_step"] / total_tiles  # one tile's tick where 8 share a GPU: kernels, back to back
+    per = total_tiles // world_size
+    steps = A["exchange_steps_per_tick"]
+    lat_us = (steps["ghost_bodies"] + steps["ghost_velocities"] + steps["handover"]) * A["p2p_latency_us"] + steps["status_allreduce"] * A["allreduce_us"]
+    wire_us = A["bytes_per_rank_face_per_tick"][scene_kind] / (A["link_GBps"] * 1e3)
+    comm_ms = 0.0 if world_size == 1 else (lat_us + wire_us) / 1e3
+    pred_ms = per * tile_tick + comm_ms
+    return {"predicted_ms_per_step": round(pred_ms, 4), "predicted_efficiency_vs_8_tiles_on_one_gpu": round(one_gpu["ms_per_step"] / (world_size * pred_ms), 4),
+            "measured_ms_per_step": round(measured_ms, 4), "measured_over_predicted": round(measured_ms / pred_ms, 3),
+            "model": "tiles_per_rank x tile_tick_ms + [exchange steps x p2p latency + status all-reduce + bytes per rank face / link rate]; exchanges are on the critical "
+                     "path (every phase waits for its rows); DESIGN.md section 8",
+            "tile_tick_ms": round(tile_tick, 4), "tiles_per_rank": per, "comm_ms_per_tick": round(comm_ms, 4), "assumptions": A}
 
 
 def _same_workload_one_gpu(cfg):

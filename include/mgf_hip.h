@@ -405,7 +405,8 @@ MGF_API int64_t mgf_tiles_migrated(const mgf_tiles* t, int32_t tile, int32_t dir
 /* What the neighbour exchanges of a tile set have cost since its creation (no reference counterpart: world.rs has one World): key =
    "exchange_bytes_out" / "exchange_bytes_in" (rows that crossed a face between RANKS), "exchange_bytes_local" (rows copied between this
    rank's own tiles), "exchange_calls", "exchange_ns" (stream time between the events around the exchanges, the wait for the neighbouring
-   rank included; counted while mgf_tiles_set_option "exchange_timing" is 1), "host_waits", "ticks", "ticks_retried"; -1 for an unknown key. */
+   rank included; counted while mgf_tiles_set_option "exchange_timing" is 1) and, by kind of exchange, "exchange_{calls|mean_ns|p50_ns|p99_ns|max_ns}_{bodies|
+   velocities|handover}" (the calls' own durations: which step of the protocol costs what on the links), "host_waits", "ticks", "ticks_retried"; -1 for an unknown key. */
 MGF_API int64_t mgf_tiles_counter(const mgf_tiles* t, const char* key);
 /* Options (development and test knobs; defaults in brackets): "time_solver_kernels" [0] HIP events around the
  * solver kernels; "solver_mode" [6] 1 = persistent dataflow launch, 0 = one launch per dependency frontier,

@@ -11,11 +11,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def run_rank(rank, n_ranks, total_tiles, dims, drift, ticks, fail_rank, fail_tick, uid_q, out_q, device=None, rccl_lib=None, world_opts=None):
+def run_rank(rank, n_ranks, total_tiles, dims, drift, ticks, fail_rank, fail_tick, uid_q, out_q, device=None, rccl_lib=None, world_opts=None, extra_env=None):
     """device: the rank's device (default: its own, `rank`); rccl_lib: the library the C-ABI binds instead of librccl (MGF_RCCL_LIB -
     the tests' stand-in that lets several ranks share one device, tests/fake_rccl)."""
     try:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        for k, v in (extra_env or {}).items():
+            os.environ[k] = v
         if rccl_lib:
             os.environ["MGF_RCCL_LIB"] = rccl_lib
             os.environ.setdefault("MGF_FAKE_RCCL_TIMEOUT_S", "90")
