@@ -537,7 +537,7 @@ def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, w
                     "note": "bytes cross RANK faces (RCCL send/recv) unless said otherwise; exchange_us_per_tick = stream time between the HIP events around every "
                             "exchange (ghost bodies, ghost velocity refreshes, hand-overs), the wait for the neighbouring rank included - taken, like the "
                             "roofline's launches, in a replay of the timed ticks (option exchange_timing)"}
-        try:
+        def seam_now(worlds_now):
             if whole5 is not None:  # the bodies' sphere parts: centre = x + R(q) (p_sphere - x) of the initial pose
                 cb5 = whole5["compound"]
                 loc = cb5["comps"]["p"][0::2].astype(np.float64)
@@ -546,22 +546,23 @@ def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, w
                 com = (loc * m5[0::2, None] + cap_mid * m5[1::2, None]) / (m5[0::2, None] + m5[1::2, None])
                 loc = loc - com
                 mine_x = []
-                for k, w in enumerate(worlds):
+                for k, w in enumerate(worlds_now):
                     st5, tg = w.state(), w.tags().astype(np.int64)
                     q = st5["q"].astype(np.float64)
                     sq, vq, l = q[:, 0:1], q[:, 1:4], loc[tg]
                     rot = l + 2.0 * np.cross(vq, np.cross(vq, l) + sq * l)
                     mine_x.append((first + k, (st5["x"].astype(np.float64) + rot).astype(np.float32)))
             else:
-                mine_x = [(first + k, np.asarray(w.state()["x"], dtype=np.float32)) for k, w in enumerate(worlds)]
+                mine_x = [(first + k, np.asarray(w.state()["x"], dtype=np.float32)) for k, w in enumerate(worlds_now)]
             if dist is not None:
                 gathered = [None] * world_size
                 dist.all_gather_object(gathered, mine_x)
                 all_x = [t for g in gathered for t in g]
             else:
                 all_x = mine_x
-            if rank == 0:
-                seam = _seam_penetration(all_x)
+            return _seam_penetration(all_x) if rank == 0 else None
+        try:
+            seam = seam_now(worlds)
         except Exception as e:  # (a figure beside the measurement: never at the price of the line)
             seam = {"error": repr(e)}
     def tally(tt):
@@ -654,6 +655,10 @@ def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, w
         settled = {"value": s_units / s_el, "unit": "constraint-iters/s", "ms_per_step": s_el * 1e3 / args.steps, "steps": args.steps, "warmup": at,
                    "constraints_per_step": s_cons / args.steps, "tile_tick_ms": s_el * 1e3 / (args.steps * per_rank),
                    "note": "the same tile set stepped on to tick 400: the pile has collapsed and come to rest"}
+        try:
+            settled["seam_penetration"] = seam_now(rworlds)
+        except Exception as e:
+            settled["seam_penetration"] = {"error": repr(e)}
     rank_ms = torch.zeros(world_size, dtype=torch.float64, device=red_dev)
     rank_ms[rank] = elapsed * 1e3 / (args.steps * per_rank)  # (a rank's own wall clock between the two barriers, per tile-tick)
     if dist is not None:

@@ -233,3 +233,65 @@ def test_integration_md_declares_every_export():
     assert not extra, f"INTEGRATION.md declares functions the header does not export: {extra}"
     wrong = {k: (rust[k], c[k]) for k in c if rust[k] != c[k]}
     assert not wrong, f"parameter counts differ (INTEGRATION.md, header): {wrong}"
+
+
+def _c_structs(header):
+    """typedef struct NAME { fields } NAME;  ->  {NAME: [(c type, field name, array length or None), ...]}"""
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    header = re.sub(r"//[^\n]*", "", header)
+    out = {}
+    for m in re.finditer(r"typedef\s+struct\s+(\w+)?\s*\{(.*?)\}\s*(\w+)\s*;", header, re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            ty, names = decl.rsplit(" ", 1)[0], decl.rsplit(" ", 1)[1]
+            # `float a, b, c` style declarations: the type is everything before the first name
+            parts = [p.strip() for p in decl.split(",")]
+            first = parts[0]
+            ty = first[:first.rfind(" ")].strip()
+            for name in [first[first.rfind(" ") + 1:]] + parts[1:]:
+                am = re.match(r"(\w+)\[(\w+)\]$", name)
+                fields.append((ty, am.group(1), am.group(2)) if am else (ty, name, None))
+        out[m.group(3)] = fields
+    return out
+
+
+def _rust_structs(text):
+    """#[repr(C)] ... pub struct NAME { pub a: T, pub b: [T; N], ... }  ->  {NAME: [(rust type, field, array length or None), ...]}"""
+    out = {}
+    for m in re.finditer(r"#\[repr\(C\)\][^\n]*?pub struct (\w+)\s*\{(.*?)\n?\}", text, re.S):
+        body = re.sub(r"//[^\n]*", "", m.group(2))
+        fields = []
+        for fm in re.finditer(r"pub (\w+)\s*:\s*(\[[^\]]+\]|[\w:\*\s]+?)\s*(?:,|$)", body, re.S):
+            ty = " ".join(fm.group(2).split())
+            am = re.match(r"\[\s*([\w:]+)\s*;\s*(\w+)\s*\]$", ty)
+            fields.append((am.group(1), fm.group(1), am.group(2)) if am else (ty, fm.group(1), None))
+        out[m.group(1)] = fields
+    return out
+
+
+_RUST_OF_C = {"float": "f32", "int32_t": "i32", "uint32_t": "u32", "int64_t": "i64", "uint64_t": "u64", "double": "f64", "uint8_t": "u8", "int": "i32"}
+
+
+def test_integration_md_repr_c_structs_match_the_header_field_for_field():
+    """the Rust shim of INTEGRATION.md can never be compiled here (no rustc), so the one check its `#[repr(C)]` structs
+    can get is mechanical: every struct the header defines appears there with the same fields - names, order, types (f32 for float, i32
+    for int32_t, nested mgf_* structs by name, arrays by length) - because a swapped pair of floats would compile on both sides and
+    read garbage across the boundary."""
+    c = _c_structs(open(os.path.join(ROOT, "include", "mgf_hip.h")).read())
+    rust = _rust_structs(open(os.path.join(ROOT, "INTEGRATION.md")).read())
+    assert len(c) >= 15, sorted(c)
+    missing = sorted(set(c) - set(rust))
+    assert not missing, f"structs of the header without a #[repr(C)] twin in INTEGRATION.md: {missing}"
+    consts = dict(re.findall(r"#define\s+(MGF_\w+)\s+(\d+)", open(os.path.join(ROOT, "include", "mgf_hip.h")).read()))
+    for name, cf in c.items():
+        rf = rust[name]
+        assert [f[1] for f in cf] == [f[1] for f in rf], f"{name}: field names / order differ: header {[f[1] for f in cf]} vs INTEGRATION.md {[f[1] for f in rf]}"
+        for (cty, fname, clen), (rty, _rn, rlen) in zip(cf, rf):
+            want = _RUST_OF_C.get(cty, cty)
+            assert rty == want, f"{name}.{fname}: header type {cty} (Rust {want}) vs INTEGRATION.md {rty}"
+            cl = consts.get(clen, clen) if clen else None
+            rl = consts.get(rlen, rlen) if rlen else None
+            assert cl == rl, f"{name}.{fname}: array length {clen} vs {rlen}"
