@@ -102,10 +102,21 @@ struct NoTail {
 // the PREVIOUS tick's scene bounds (`grid`: the scene moves a fraction of a cell per tick; the quantisation clamps, and the pair search
 // finds every body whatever the box is - only how evenly the cells fill depends on it) and its arrival rank inside the cell.
 struct CellSort { const SceneBounds* grid; int shift; float min_frac; uint32_t* cell_of; uint32_t* rank; uint32_t* cell_cnt; };
+// (r06) WIDE bodies: the few whose fat box is much larger than everybody else's - a body that left the scene and has been falling for a
+// thousand ticks sweeps 4 m per tick.  SceneBounds::rmax, the largest fat half extent, is the reach of EVERY query of the cell grid, and
+// the bounds are what the cells are laid over: one such body made a million-sphere world four times slower (EXPERIMENTS.md, round 5).
+// With `limit` set (the host: 1.5 x the largest half extent of the bodies that were NOT wide in the last tick) k_integrate keeps the
+// bodies above it out of the scene bounds and rmax and lists them (fat box, slot, order id; at most `cap`: more is a failed tick, run
+// again without the list); the grid's pair search never accepts a listed body as a partner (its leaf record carries no order id:
+// scatter_leaf) and k_pair_wide finds its partners-to-be from ITS side, by one launch over the few of them.  The accepted set is the
+// reference's (the same predicate on the same boxes, bvh.rs:283-310), whatever the limit.
+constexpr uint32_t kWideCap = 64;
+struct WideSpec { float limit[3]; float4* list; uint32_t* count; const uint32_t* ext; };
+__device__ __forceinline__ bool is_wide(const float* limit, float4 fr) { return fr.x > limit[0] || fr.y > limit[1] || fr.z > limit[2]; }
 __device__ __forceinline__ uint32_t morton_cell_of(V3 c, const SceneBounds* sb, float min_frac, int shift);  // k_broadphase.h
 template <class Tail>
 __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, float dt, float fat_margin, int do_complete,
-                                                      int do_integrate, SceneBounds* sb, const uint32_t* guard, Tail tail, int* sb_part, CellSort cs) {
+                                                      int do_integrate, SceneBounds* sb, const uint32_t* guard, Tail tail, int* sb_part, CellSort cs, WideSpec wd) {
   if (guard && *guard) return;  // a speculative tick behind a failed one (see k_reset_step)
   __shared__ float4 s_tail[Tail::kLdsWords];
   __shared__ uint32_t s_near[2];  // bodies of this block that list a terrain face, where their records start in the tick's list
@@ -188,6 +199,11 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
       }
       blo[0] = bhi[0] = f_ord(fb.c.x); blo[1] = bhi[1] = f_ord(fb.c.y); blo[2] = bhi[2] = f_ord(fb.c.z);
       brm[0] = f_ord(fb.r.x); brm[1] = f_ord(fb.r.y); brm[2] = f_ord(fb.r.z);
+      if (wd.list && is_wide(wd.limit, mk4(fb.r, 0.0f))) {  // a wide body: listed, and not part of the scene's bounds
+        const uint32_t at = atomicAdd(wd.count, 1u);
+        if (at < kWideCap) { wd.list[2 * at] = mk4(fb.c, u2f(i)); wd.list[2 * at + 1] = mk4(fb.r, u2f(wd.ext ? wd.ext[i] : i)); }
+        blo[0] = blo[1] = blo[2] = 0x7FFFFFFF; bhi[0] = bhi[1] = bhi[2] = (int)0x80000000; brm[0] = brm[1] = brm[2] = 0;
+      }
       if (cs.grid) {
         const uint32_t cell = morton_cell_of(fb.c, cs.grid, cs.min_frac, cs.shift);
         cs.cell_of[i] = cell;

@@ -187,6 +187,7 @@ struct StepCounts {
 constexpr uint32_t kFailCandCap = 1u, kFailConsCap = 2u, kFailRowOverflow = 4u, kFailGridWide = 8u, kFailTerrainRow = 16u, kFailTerrainWide = 32u,
                    kFailRevRow = 64u,  // a body's row of `b` occurrences overflowed (k_setup_pairs / k_chain_rows)
                    kFailSkipped = 128u,  // a speculative tick behind a failed one: nothing was done (k_reset_step)
+                   kFailWide = 512u,     // more wide bodies than their list holds (k_integrate, WideSpec): the tick is run again without the list
                    kFailFlow6 = 256u;    // the block-local solver's tables did not fit (k_flow6_*): the solve did nothing; the tick is re-run with the global dataflow solver
 
 // The list sizes of the tick, checked against the capacities the lists were allocated with, at the end of the scans that
@@ -197,6 +198,7 @@ struct ScanEpilogue {
   const uint32_t *row_overflow, *grid_wide, *terrain_wide, *guard;  // kinds 1, 3 (each may be null but guard)
   StepCounts* sc;
   const uint32_t *sum_t, *sum_ct; // kind 3: terrain candidates and terrain contacts (k_terrain_contacts' counters)
+  const uint32_t* wide_n;         // kinds 1, 3: the wide bodies listed (null: no list this tick)
   uint32_t sum_t_parts, sum_t_stride;  // kind 3: the terrain candidates are the sum of this many partial counts, that many words apart (0: the one word)
 };
 __device__ __forceinline__ void caps_candidates(const ScanEpilogue& E, uint32_t mt, uint32_t mp) {
@@ -208,6 +210,7 @@ __device__ __forceinline__ void caps_candidates(const ScanEpilogue& E, uint32_t 
   if (E.row_overflow && (*E.row_overflow & 2u)) r.fail |= kFailTerrainRow;
   if (E.grid_wide && *E.grid_wide) r.fail |= kFailGridWide;
   if (E.terrain_wide && *E.terrain_wide) r.fail |= kFailTerrainWide;
+  if (E.wide_n && *E.wide_n > kWideCap) r.fail |= kFailWide;
   if (*E.guard) r.fail |= kFailSkipped;
   r.Mt = r.fail ? 0u : r.need_Mt; r.Mp = r.fail ? 0u : r.need_Mp; r.C = 0; r.Ct = 0;
   for (int k = 0; k < 6; ++k) r.bins[k] = 0;
@@ -228,6 +231,7 @@ __device__ __forceinline__ void caps_contacts(const ScanEpilogue& E, uint32_t c)
   if (E.row_overflow && (*E.row_overflow & 2u)) r.fail |= kFailTerrainRow;
   if (E.grid_wide && *E.grid_wide) r.fail |= kFailGridWide;
   if (E.terrain_wide && *E.terrain_wide) r.fail |= kFailTerrainWide;
+  if (E.wide_n && *E.wide_n > kWideCap) r.fail |= kFailWide;
   if (*E.guard) r.fail |= kFailSkipped;
   if (!r.fail && mt > E.cap_a) r.fail |= kFailCandCap;
   if (!r.fail && c > E.cap_b) r.fail |= kFailConsCap;
@@ -457,10 +461,13 @@ __device__ __forceinline__ void pair_query_region(const V3& qc, const V3& qr, fl
 // Bodies -> leaf records in cell order (counting sort, second half).
 __device__ __forceinline__ void scatter_leaf(uint32_t body, const Lbvh& T, const float4* fb_c, const float4* fb_r, const uint32_t* cell_of,
                                              const uint32_t* rank, uint32_t* brank, const float4* col0, const float4* delta, const float4* tb_c,
-                                             const float4* tb_r, const SceneBounds* sb, float pad_abs, float min_frac, const SceneBounds* box = nullptr) {
+                                             const float4* tb_r, const SceneBounds* sb, float pad_abs, float min_frac, const SceneBounds* box = nullptr,
+                                             float3 wide_limit = make_float3(0.0f, 0.0f, 0.0f), uint32_t n_owned = 0u) {
   if (body >= T.n) return;
   uint32_t p = T.cell_lo[cell_of[body]] + rank[body];
   LeafRec lr; lr.c = mk4(xyz(fb_c[body]), u2f(body)); lr.r = mk4(xyz(fb_r[body]), u2f(order_id(T.ext, body)));
+  // (a wide body - WideSpec, k_bodies.h - is never a partner of the grid's pair search: no order id is below 0xFFFFFFFF.  k_pair_wide pairs it.)
+  if (wide_limit.x > 0.0f && body < n_owned) { const float lim[3] = {wide_limit.x, wide_limit.y, wide_limit.z}; if (is_wide(lim, fb_r[body])) lr.r.w = u2f(0xFFFFFFFFu); }
   T.leaves[p] = lr;
   if (T.lcol) { T.lcol[2 * p] = col0[body]; T.lcol[2 * p + 1] = delta[body]; }
   if (T.ltb) {
@@ -477,8 +484,9 @@ __device__ __forceinline__ void scatter_leaf(uint32_t body, const Lbvh& T, const
 }
 __global__ __launch_bounds__(kBlock) void k_scatter_leaves(Lbvh T, const float4* fb_c, const float4* fb_r, const uint32_t* cell_of,
                                                            const uint32_t* rank, uint32_t* brank, const float4* col0, const float4* delta, const float4* tb_c,
-                                                           const float4* tb_r, const SceneBounds* sb, float pad_abs, float min_frac, const SceneBounds* box = nullptr) {
-  scatter_leaf(blockIdx.x * kBlock + threadIdx.x, T, fb_c, fb_r, cell_of, rank, brank, col0, delta, tb_c, tb_r, sb, pad_abs, min_frac, box);
+                                                           const float4* tb_r, const SceneBounds* sb, float pad_abs, float min_frac, const SceneBounds* box = nullptr,
+                                                           float3 wide_limit = make_float3(0.0f, 0.0f, 0.0f), uint32_t n_owned = 0u) {
+  scatter_leaf(blockIdx.x * kBlock + threadIdx.x, T, fb_c, fb_r, cell_of, rank, brank, col0, delta, tb_c, tb_r, sb, pad_abs, min_frac, box, wide_limit, n_owned);
 }
 
 // One block per 256 consecutive cells: the 4 internal levels above them.

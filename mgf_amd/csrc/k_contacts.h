@@ -921,9 +921,9 @@ template <int GEN>
 __global__ __launch_bounds__(kBlock) void k_scatter_leaves_tc(Lbvh T, const float4* fb_c, const float4* fb_r, const uint32_t* cell_of,
                                                               const uint32_t* rank, uint32_t* brank, const float4* col0, const float4* delta, const float4* tb_c,
                                                               const float4* tb_r, const SceneBounds* sb, float pad_abs, float min_frac, TerrainContacts A, uint32_t tc_blocks,
-                                                              const SceneBounds* box) {
+                                                              const SceneBounds* box, float3 wide_limit, uint32_t n_owned) {
   if (blockIdx.x < tc_blocks) { terrain_contacts_job<GEN>(A, blockIdx.x, tc_blocks); return; }  // (first: they take longest)
-  scatter_leaf((blockIdx.x - tc_blocks) * kBlock + threadIdx.x, T, fb_c, fb_r, cell_of, rank, brank, col0, delta, tb_c, tb_r, sb, pad_abs, min_frac, box);
+  scatter_leaf((blockIdx.x - tc_blocks) * kBlock + threadIdx.x, T, fb_c, fb_r, cell_of, rank, brank, col0, delta, tb_c, tb_r, sb, pad_abs, min_frac, box, wide_limit, n_owned);
 }
 struct ContactsSpheres {
   const StepCounts* sc;

@@ -540,6 +540,70 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid_n(Bodies B, uint32_t n
   if (threadIdx.x == 0 && s_sum) atomicAdd(&pair_stat[blockIdx.x & (kPairStatWords - 1u)], s_sum);
 }
 
+// ---- the partners-to-be of the WIDE bodies (WideSpec, k_bodies.h) ------------------------------------------------------------------
+// The grid's pair search finds pair (i, j) - j the body of the smaller order id - from i's side: i's tight box against the fat boxes of
+// the bodies in the cells around it, as far as the largest fat half extent of the scene reaches.  A wide j is kept out of that reach and
+// out of the partners (its leaf record carries no order id); here it looks for its i's itself: a workgroup per listed body, the cells its
+// FAT box can reach (a body whose tight box meets fat_j has its own fat box's centre within fat_j grown by rmax), the reference's
+// acceptance test (bvh.rs:297, world.rs:266) on every record there with a larger order id.  An accepted pair goes where the pair search
+// would have put it - behind the entries of i's row (the order inside a row never mattered) - through the pair test first where the rows
+// hold contacts.  One launch of kWideCap workgroups behind the pair search, whose rows and counts it appends to.
+struct PairWide {
+  const float4* list; const uint32_t* count;
+  Lbvh T; const SceneBounds* sb; const SceneBounds* box; float pad_abs, min_frac;
+  uint32_t n, n_owned;
+  uint32_t contacts;   // 1: the rows hold contacts (the pair test runs here), 0: accepted partners
+  uint32_t* rows_p; uint32_t* p_cnt; uint32_t* overflow; uint32_t* too_wide; uint32_t* pair_stat;
+  const uint32_t* guard;
+};
+__global__ __launch_bounds__(kBlock) void k_pair_wide(Bodies B, PairWide A) {
+  __shared__ uint32_t s_acc;
+  if (*A.guard) return;
+  const uint32_t nw = min(*A.count, kWideCap);
+  if (blockIdx.x >= nw) return;
+  if (threadIdx.x == 0) s_acc = 0u;
+  __syncthreads();
+  const float4 fc = A.list[2 * blockIdx.x], fr = A.list[2 * blockIdx.x + 1];
+  const uint32_t j = f2u(fc.w), oj = f2u(fr.w);
+  Box fat; fat.c = xyz(fc); fat.r = xyz(fr);
+  const uint32_t P = 2u * A.T.levels;
+  const uint32_t nb[3] = {(P + 2u) / 3u, (P + 1u) / 3u, P / 3u};
+  uint32_t ca[3], d[3];
+  pair_query_region(fat.c, fat.r, pair_query_pad(fat.c, fat.r, A.pad_abs), A.sb, nb, ca, d, A.min_frac, A.box);
+  const unsigned long long ncell = (unsigned long long)d[0] * d[1] * d[2];
+  if (ncell > (1ull << 22)) { if (threadIdx.x == 0) *A.too_wide = 1u; return; }  // (four million cells: the host takes the tree walk)
+  const int shift = kMortonBits - (int)P;
+  V3 vB = mk3(0, 0, 0);
+  Comp Bc; Bc.kind = KIND_SPHERE; Bc.p = mk3(0, 0, 0); Bc.d = mk3(0, 0, 0); Bc.r = 0.0f;
+  if (A.contacts) Bc = load_comp_moving(B, j, &vB);
+  uint32_t accepted = 0;
+  for (uint32_t idx = threadIdx.x; idx < (uint32_t)ncell; idx += (uint32_t)kBlock) {
+    const uint32_t cz = idx % d[2], t = idx / d[2], cy = t % d[1], cx = t / d[1];
+    const uint32_t code = (expand10((ca[0] + cx) << (10u - nb[0])) << 2) | (expand10((ca[1] + cy) << (10u - nb[1])) << 1) | expand10((ca[2] + cz) << (10u - nb[2]));
+    const uint32_t cell = code >> shift;
+    for (uint32_t p = A.T.cell_lo[cell], p1 = A.T.cell_lo[cell + 1]; p < p1; ++p) {
+      const uint32_t i = A.T.sidx[p];
+      if (i == j || order_id(A.T.ext, i) <= oj) continue;  // world.rs:266: partners have the smaller order id (j is owned: listed by k_integrate)
+      const float4 tc = A.T.ltb[2 * (size_t)p], tr = A.T.ltb[2 * (size_t)p + 1];
+      Box q; q.c = xyz(tc); q.r = xyz(tr);
+      if (!box_overlaps(q, fat)) continue;  // the reference's own acceptance test (bvh.rs:297): i's tight box, j's fat box
+      ++accepted;
+      if (A.contacts) {
+        V3 vA;
+        const Comp Ac = load_comp_moving(B, i, &vA);
+        LocalContact lc;
+        if (!comp_pair_local(Ac, vA, Bc, vB, &lc)) continue;
+      }
+      const uint32_t pos = atomicAdd(&A.p_cnt[i], 1u);
+      if (pos < (uint32_t)kRowCap) A.rows_p[(size_t)i * kRowCap + pos] = j;
+      else atomicOr(A.overflow, 1u);
+    }
+  }
+  if (accepted) atomicAdd(&s_acc, accepted);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_acc && A.pair_stat) atomicAdd(&A.pair_stat[blockIdx.x & (kPairStatWords - 1u)], s_acc);
+}
+
 // ContactConstraint::new for the rows of a world with bodies of up to two components: k_contacts_rows' work with a manifold of up to four
 // contacts per row entry (consecutive single-contact records that share its normal and tangents: ContactConstraint::solve, solver.rs:219-248,
 // handles the contacts of a constraint one after the other on the same velocities - k_setup_pairs) and up to four parked contacts per
