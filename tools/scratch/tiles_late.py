@@ -32,4 +32,4 @@ for s in range(1, 1701):
               f"constraints {int(st[3].n_constraints)}, hand-overs {sum(T.migrated(k) for k in range(P))}, owned {[len(w) for w in worlds]}", flush=True)
         last = cur
         xs = np.concatenate([w.state()["x"] for w in worlds])
-        print(f"         bounds x [{xs[:,0].min():.1f}, {xs[:,0].max():.1f}] y [{xs[:,1].min():.1f}, {xs[:,1].max():.1f}] z [{xs[:,2].min():.1f}, {xs[:,2].max():.1f}]; bodies above y = 140: {(xs[:,1] > 140).sum()}, wide bodies {[w.counter("wide_bodies") for w in worlds]}, wide ticks {sum(w.counter("wide_ticks") for w in worlds)}", flush=True)
+        print(f"         bounds x [{xs[:,0].min():.1f}, {xs[:,0].max():.1f}] y [{xs[:,1].min():.1f}, {xs[:,1].max():.1f}] z [{xs[:,2].min():.1f}, {xs[:,2].max():.1f}]; bodies above y = 140: {(xs[:,1] > 140).sum()}, wide bodies {[w.counter('wide_bodies') for w in worlds]}, wide ticks {sum(w.counter('wide_ticks') for w in worlds)}", flush=True)
