@@ -35,6 +35,16 @@
 //                      k_scatter_leaves_tc's launch), k_scan over p_cnt + tcn with the tick's counts in its epilogue
 //                      (caps_contacts), then a block per 256 bodies: its partner contacts as an LDS list in canonical order,
 //                      ContactConstraint::new for each
+//   k_near_list / k_terrain_near<L> / k_terrain_tests / k_pair_grid_n<PARTS> / k_contacts_rows<false> / k_contacts_rows_parts (r06, k_front_rows.h)
+//                      the same list-free front end for worlds that are NOT spheres only - capsules, mixed kinds, bodies of two
+//                      components: the bodies near the mesh, their faces from the face grid with a cheap conservative reject
+//                      (comp_tri_far) and a slot each, the body-triangle tests a lane per slot (on the context's second stream,
+//                      beside the pair search); the pair search pools the accepted partners of a block's queries that may touch
+//                      and runs the pair test - or the two-part manifold, raw contacts staged in LDS - a lane each, the rows
+//                      hold contacts only; records from the rows.  k_contacts_rows<true> is r05's k_contacts_spheres.
+//   k_pair_wide (r06)  the few bodies whose fat box is far larger than the rest's (WideSpec, k_bodies.h: kept out of the scene
+//                      bounds and rmax by k_integrate, never partners of the grid's pair search) find their partners-to-be
+//                      from their own side: a workgroup per listed body
 //   k_solver_snapshot / k_solver_restore (r05)
 //                      the velocities / impulses a persistent solver launch finds, and back, if it gives up (solver_abort_fallback)
 //   k_chain_rows       order-preserving dependency links of the tick's constraint list (compact arrays, ConsLinks);
@@ -63,5 +73,5 @@
 // -ffp-contract=off.
 #pragma once
 // The kernels live in the k_*.h parts, each including the one before it:
-//   k_bodies.h -> k_broadphase.h -> k_contacts.h -> k_links.h -> k_solver_flow.h -> k_tiles.h -> k_api.h
+//   k_bodies.h -> k_broadphase.h -> k_contacts.h -> k_front_rows.h -> k_links.h -> k_solver_flow.h -> k_tiles.h -> k_api.h
 #include "k_api.h"

@@ -39,7 +39,7 @@ fi
 # 60 x 8 x 5 launches are the last 2400 of the run
 run_tiles() {  # name, scene, warm-up
   local N=$1 SC=$2 W=$3
-  local BT="python $R/bench.py --gpus 1 --scene $SC --no-cpu-baseline"
+  local BT="python $R/bench.py --gpus 1 --scene $SC --no-cpu-baseline --no-settled-tiles"  # (the profiled launches are the LAST ones of the run: the replay of the timed falling-pile ticks, not the settled window behind it)
   rocprofv3 --kernel-trace -d $O/${TAG}_${N}_trace -o bench -- $BT > $O/${TAG}_${N}_trace.log 2>&1
   rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_${N}_fetch -o bench -- $BT > $O/${TAG}_${N}_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_${N}_write -o bench -- $BT > $O/${TAG}_${N}_write.log 2>&1
