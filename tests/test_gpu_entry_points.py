@@ -204,6 +204,7 @@ def test_device_pointers_and_ghost_len(ctx):
     w2.begin_tick(float(scene["dt"]))
     ids = torch.tensor([1, 5, 9], dtype=torch.int32, device="cuda")
     recs = torch.zeros((3, 72), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()  # (the fill runs on torch's stream, the library writes on its own)
     w2.export_bodies(ids.data_ptr(), 3, recs.data_ptr())
     w.begin_tick(float(scene["dt"]))
     w.import_ghosts(recs.data_ptr(), 3)

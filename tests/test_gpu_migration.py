@@ -231,6 +231,8 @@ def test_arrivals_of_more_parts_than_the_world_has_slots_for_raise_them(ctx, tar
     assert len(dst) == n0 + len(ids) and dst.counter("body_kinds") & 12 == 12
     back = torch.empty_like(rec)
     d_new = torch.arange(n0, n0 + len(ids), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()  # (arange is a kernel on torch's stream; the library reads the ids on its own, non-blocking one: without this the export
+    #                           raced it and now and then exported whatever ids the memory held - the suite's one flaky test of round 6)
     dst.export_migrants(d_new.data_ptr(), len(ids), back.data_ptr())
     torch.cuda.synchronize()
     assert torch.equal(rec.view(torch.int32), back.view(torch.int32))  # every part slot arrived
