@@ -30,7 +30,7 @@ def run(P, opts, ticks=400, every=100):
             print(f"{P} tiles {opts} tick {s}: {n_total} bodies, hand-overs {out[-1][3]}, mean height {out[-1][1]:.4f}", flush=True)
     return out
 a = run(8, {})
-b = run(8, {"solver_mode": 1})
+b = run(8, {"solver_mode": 1, "front_rows": 0, "wide_list": 0})
 assert [r[2] for r in a] == [r[2] for r in b], "8 tiles: default against the global solver differ"
 c = run(4, {})
 for ra, rc in zip(a, c):

@@ -10,6 +10,7 @@ ctx = mgf_amd.Context(0)
 for name, sc in (("config3", scenes.capsule_field(128, 32, 32, quads=158)), ("config5", scenes.dumbbell_field(64, 16, 64))):
     a, b = mgf_amd.World.from_scene(ctx, sc), mgf_amd.World.from_scene(ctx, sc)
     a.set_option("solver_mode", 1)
+    a.set_option("front_rows", 0); a.set_option("wide_list", 0); a.set_option("side_stream", 0)  # (r06: the list-based front end on one stream too - the plainest tick against the default one)
     dt, it = float(sc["dt"]), sc["iters"]
     t0 = time.time()
     for s in range(every, ticks + 1, every):
