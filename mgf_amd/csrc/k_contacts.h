@@ -730,7 +730,10 @@ __global__ __launch_bounds__(kBlock) void k_setup_pairs(Bodies B, const StepCoun
 //                        evenly to the threads.
 // What this replaces - k_scan<2> (row offsets), k_lists_spheres, k_scan<1>, k_setup_pairs<true> - built t_cand / p_cand / ..._pre /
 // ..._owner lists that nobody downstream reads.
-constexpr uint32_t kCsEntCap = 1024;  // partner contacts of a block staged per pass (a settled pile's block has ~900)
+#ifndef MGF_CS_ENT_CAP
+#define MGF_CS_ENT_CAP 1536
+#endif
+constexpr uint32_t kCsEntCap = MGF_CS_ENT_CAP;  // partner contacts of a block staged per pass (a settled pile's block has ~900-1 100: with 1 024 most of its blocks listed a second window - r06: k_contacts_rows 93 -> 81 us there)
 constexpr uint32_t kCsSumStride = 32; // words between the two global counters (their own cache lines)
 #ifndef MGF_TC_LANES
 #define MGF_TC_LANES 4
@@ -969,13 +972,20 @@ __device__ __forceinline__ void cs_list_row(const uint32_t* rp, uint32_t np, con
   }
 }
 // ... for the windows behind the first (a block with more than kCsEntCap partner contacts: bodies pressed into each other - a collapsing
-// pile): the same listing, NOT inlined.  (r05: with the twelve-entry network inlined a second time inside the
-// window loop, the kernel faulted on a null-based address the first time a tile of the collapsing million-sphere pile reached a second
-// window - tools/soak_tiles.py, tick 156 - while small worlds in the same state passed; out of line it does not: tests/test_gpu_contacts_dense.py,
-// the 600-tick tile soak.)
+// pile): the PLAIN loops, out of line.  (r05: with the twelve-entry network inlined a second time inside the window loop the kernel faulted
+// on a null-based address the first time a tile of the collapsing million-sphere pile reached a second window - tools/soak_tiles.py, tick 156 -
+// while small worlds in the same state passed; never root-caused.  r05 moved the second copy out of line; r06 takes the network
+// out of the later windows altogether - the plain loops were measured sound there in round 5 - and sizes the first window so that a pile at
+// rest does not need a second one: the path the fault was on is no longer the common one.  tests/test_gpu_contacts_dense.py, the tile soaks.)
 __device__ __attribute__((noinline)) void cs_list_row_again(const uint32_t* rp, uint32_t np, const uint32_t* ext, uint32_t first, uint32_t w0, uint32_t owner,
                                                             uint32_t* s_j, uint16_t* s_b) {
-  cs_list_row(rp, np, ext, first, w0, owner, s_j, s_b);
+  for (uint32_t a = 0; a < np; ++a) {
+    const uint32_t j = rp[a], oa = order_id(ext, j);
+    uint32_t before = 0;
+    for (uint32_t q = 0; q < np; ++q) before += order_id(ext, rp[q]) < oa ? 1u : 0u;
+    const uint32_t pos = first + before - w0;
+    if (pos < kCsEntCap) { s_j[pos] = j; s_b[pos] = (uint16_t)owner; }
+  }
 }
 // the collider of a body of the rows from its packed copy: SPH = a world of spheres only (word 1 is not read)
 template <bool SPH>
