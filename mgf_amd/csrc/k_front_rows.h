@@ -627,9 +627,13 @@ __global__ __launch_bounds__(kBlock) void k_contacts_rows_parts(Bodies B, Terrai
   __shared__ uint32_t s_wave[kBlock / 64];
   if (A.sc->fail) return;  // (the scan's closing thread found a flag up or a capacity exceeded: the host re-runs the phase)
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const uint32_t i0 = blockIdx.x * (uint32_t)kBlock, i = i0 + (uint32_t)t;
+  // (the launch is TWICE the bodies' blocks: the second half does the terrain constraints of the same bodies, the first the entries - two
+  // chains of dependent round trips side by side instead of one behind the other on a world too small to hide either)
+  const uint32_t nbb = gridDim.x / 2u;
+  const bool terrain_half = blockIdx.x >= nbb;
+  const uint32_t i0 = (terrain_half ? blockIdx.x - nbb : blockIdx.x) * (uint32_t)kBlock, i = i0 + (uint32_t)t;
   uint32_t ne = 0, run = 0, base_i = 0;
-  if (i < A.n) { ne = A.p_ent[i]; run = A.tcn[i]; base_i = A.base[i]; }
+  if (i < A.n) { ne = terrain_half ? 0u : A.p_ent[i]; run = A.tcn[i]; base_i = A.base[i]; }
   uint32_t inc = ne;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
@@ -641,11 +645,7 @@ __global__ __launch_bounds__(kBlock) void k_contacts_rows_parts(Bodies B, Terrai
   s_cb[t] = base_i + run;
   const uint32_t* rp = A.rows_p + (size_t)i * kRowCap;
   // ---- the terrain contacts' constraints (world.rs:243-251): the body's own thread
-#if defined(MGF_CP_ABL) && MGF_CP_ABL == 1
-  if (false) {
-#else
-  if (run) {
-#endif
+  if (run && terrain_half) {
     const uint32_t nt = A.t_cnt[i], tp = A.tpos[i];
     const V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
     const BodyDyn Ad = load_dyn(B.srec, i), S = static_dyn();
@@ -663,9 +663,6 @@ __global__ __launch_bounds__(kBlock) void k_contacts_rows_parts(Bodies B, Terrai
       }
     }
   }
-#if defined(MGF_CP_ABL) && MGF_CP_ABL == 2
-  if (total) return;
-#endif
   for (uint32_t w0 = 0; w0 < total; w0 += kCpEntCap) {
     __syncthreads();
     // the body's entries to their places: ascending order id (the canonical insertion order), each behind the contacts of the ones before it.
@@ -693,9 +690,6 @@ __global__ __launch_bounds__(kBlock) void k_contacts_rows_parts(Bodies B, Terrai
         parts_item(B, i0 + s_b[r0 + e], s_j[r0 + e] & 0x07FFFFFFu, slot, &s_raw[4u * e + slot]);
       }
       __syncthreads();
-#if defined(MGF_CP_ABL) && MGF_CP_ABL == 3
-      if (true) continue;
-#endif
       for (uint32_t e = (uint32_t)t; e < mr; e += (uint32_t)kBlock) {  // a lane per entry: the pruner, then a record per contact kept
         const uint32_t w = s_j[r0 + e], j = w & 0x07FFFFFFu, nc = w >> 27, b = s_b[r0 + e], ia = i0 + b;
         const PairCentres P = pair_centres(B, ia, j);
