@@ -434,7 +434,12 @@ MGF_API int64_t mgf_tiles_counter(const mgf_tiles* t, const char* key);
  * launches of their own, the constraint records are written from the rows; 0 = candidate lists and one narrowphase launch per shape-pair
  * type); "front_rows_check" [0] (tests: the faces the cheap conservative reject ahead of the body-triangle tests drops are tested all the
  * same - a contact among them is reported as an internal error); "side_stream" [1] (the terrain kernels of that front end run on a
- * second stream of the context beside the pair search; 0 = everything on the context's stream);
+ * second stream of the context beside the pair search; 0 = everything on the context's stream; 3 = the fork and the join without the second
+ * stream: what the two events cost by themselves);
+ * "wide_list" [1] (r06: the few bodies whose fat box is far larger than the rest's - a body that left the scene and falls at 200 m/s - are kept
+ * out of the scene bounds and of the reach of every query of the cell grid, and paired by a launch of their own; the accepted set is the
+ * reference's either way (bvh.rs:283-310); engaged by the host from the tick after such a body shows, for worlds of single-component bodies;
+ * 0 = never);
  * "cells_in_integrate" [1] (the fused tick's k_integrate works out the bodies' Morton cells over the previous tick's scene bounds);
  * "flow_max_blocks" [0] (the persistent solver launches of this world take at most this many workgroups - one per CU; 0 = all CUs.  Processes that
  * share a device each take a part, so that their launches are resident together); "flow_spin_limit" [0] (tests: 1 = every other workgroup of a
@@ -448,7 +453,9 @@ MGF_API mgf_status mgf_world_set_option(mgf_world* w, const char* key, int64_t v
  * "grid_too_wide", "flow5_blocks", "flow5_class0|1|2", "terrain_grid", "terrain_row_capacity", "rev_row_capacity", "body_kinds",
  * "flow6_fallbacks", "flow6_fail_reason", "flow6_max_slots", "flow6_max_foreign", "pair_brick_slow_queries", "pair_brick_off_ticks",
  * "max_fat_half_extent_x_milli", "scene_rmax_milli_x|y|z", "scene_ext_milli_x|y|z", "grid_levels", "front_rows", "front_near", "front_faces",
- * "front_slots" (the list-free front end of the last tick: bodies near the mesh, faces accepted, faces that passed the cheap reject), "solver_abort_fallbacks" (Solver::solve calls whose persistent launch gave up and that were solved again from
+ * "front_slots" (the list-free front end of the last tick: bodies near the mesh, faces accepted, faces that passed the cheap reject),
+ * "wide_bodies" (listed in the last tick), "wide_ticks", "wide_overflows" (ticks run again because more bodies were wide than the list holds),
+ * "flow6_skipped" (plans that declined the block-local solver because the last launch that did not fit says it still would not), "solver_abort_fallbacks" (Solver::solve calls whose persistent launch gave up and that were solved again from
  * the pre-launch state: Solver::solve has no failure mode, solver.rs:72-78), "device_ptrs_out" (1 while mgf_world_device_ptr's pointers pin
  * the store to the caller's order)}. */
 MGF_API mgf_status mgf_world_counter(const mgf_world* w, const char* name, int64_t* out);

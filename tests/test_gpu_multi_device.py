@@ -249,6 +249,15 @@ def test_bench_gpus_2_spawns_its_own_ranks_and_prints_one_line():
         assert "NOT A MEASUREMENT" in d["data"] and d["rccl_lib"].endswith(".so")
     else:
         assert d["data"] == "synthetic"
+    # r06: what makes the first real run self-diagnosing - a settled window with its seam, per-kind latency of the exchange calls for every rank,
+    # the one-GPU reference (measured on this box on a real node; the committed figure, saying so, over the stand-in), the written-down prediction
+    assert d["settled"]["ms_per_step"] > 0 and d["settled"]["warmup"] >= 400 and "seam_penetration" in d["settled"]
+    lat = d["exchange"]["step_latency_us"]["per_rank"]
+    assert len(lat) == 2 and all(r["bodies"]["calls"] == 4 and r["velocities"]["calls"] == 16 and r["velocities"]["p99"] >= r["velocities"]["p50"] > 0 for r in lat)
+    one = d["same_workload_on_one_gpu"]
+    assert one and ("measured_on_this_box" in one) and (one["measured_on_this_box"] or one.get("why_not"))
+    pr = d["prediction"]
+    assert pr and pr["tiles_per_rank"] == 4 and pr["predicted_ms_per_step"] > 0 and pr["assumptions"]["p2p_latency_us"] > 0 and pr["measured_over_predicted"] > 0
 
 
 @pytest.mark.timeout(900)
