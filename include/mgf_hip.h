@@ -151,6 +151,12 @@ MGF_API mgf_status mgf_contacts(mgf_ctx* ctx, const mgf_shape* a, const mgf_vec3
 MGF_API mgf_status mgf_contacts_batch(mgf_ctx* ctx, int64_t n, const mgf_shape* a, const mgf_vec3* vel_a,
                                       const mgf_shape* b, const mgf_vec3* vel_b, const uint8_t* has_vel,
                                       mgf_contact* out, int32_t* counts);
+/* (r06, no reference counterpart: a test entry point) n independent (moving component, triangle) problems - tris: three vertices each - through the
+ * cheap conservative reject the tick's front end runs ahead of the body-triangle tests AND through those tests (Contacts<Moving<Component>> for
+ * Triangle, collision.rs:610-1086, compound.rs:180-190): far[i] = 1 if the reject drops the problem, counts[i] = contacts the tests report.  A
+ * problem with far[i] = 1 and counts[i] > 0 would be a contact the tick loses; tests/test_gpu_tri_reject.py looks for one in millions. */
+MGF_API mgf_status mgf_tri_reject_batch(mgf_ctx* ctx, int64_t n, const mgf_moving_component* bodies, const mgf_vec3* tris,
+                                        uint8_t* far, int32_t* counts);
 /* LocalContacts<Moving<Component>> for Moving<Component> (compound.rs:192-207). */
 MGF_API mgf_status mgf_local_contacts_pair(mgf_ctx* ctx, const mgf_moving_component* a, const mgf_moving_component* b,
                                            mgf_local_contact* out, int32_t cap, int32_t* count);

@@ -108,7 +108,7 @@ assert CONSTRAINT_DTYPE.itemsize == 96
 # every symbol include/mgf_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "mgf_ctx_create", "mgf_ctx_destroy", "mgf_ctx_set_stream", "mgf_last_error", "mgf_default_params", "mgf_version", "mgf_exclusive_scan_u32",
-    "mgf_contacts", "mgf_contacts_batch", "mgf_local_contacts_pair", "mgf_ray_capsule", "mgf_inertia_tensor",
+    "mgf_contacts", "mgf_contacts_batch", "mgf_tri_reject_batch", "mgf_local_contacts_pair", "mgf_ray_capsule", "mgf_inertia_tensor",
     "mgf_mesh_new", "mgf_mesh_free", "mgf_mesh_push_vert", "mgf_mesh_push_face", "mgf_mesh_set_pos", "mgf_mesh_build",
     "mgf_local_contacts_mesh",
     "mgf_bvh_new", "mgf_bvh_with_capacity", "mgf_bvh_free", "mgf_bvh_empty", "mgf_bvh_clear", "mgf_bvh_insert",
@@ -161,6 +161,7 @@ def load_library():
         "mgf_exclusive_scan_u32": (i32, [vp, vp, i64, vp]),
         "mgf_contacts": (i32, [vp, P(Shape), P(Vec3), P(Shape), P(Vec3), P(Contact), i32, P(i32)]),
         "mgf_contacts_batch": (i32, [vp, i64, vp, vp, vp, vp, vp, vp, vp]),
+        "mgf_tri_reject_batch": (i32, [vp, i64, vp, vp, vp, vp]),
         "mgf_local_contacts_pair": (i32, [vp, P(MovingComponent), P(MovingComponent), P(LocalContact), i32, P(i32)]),
         "mgf_ray_capsule": (i32, [vp, P(Vec3), P(Vec3), P(Shape), P(Vec3), P(f32), P(i32)]),
         "mgf_inertia_tensor": (i32, [P(Component), f32, P(f32)]),
@@ -420,6 +421,20 @@ def contacts_batch(ctx, problems):
     _check(load_library().mgf_contacts_batch(ctx._h, n, A, va.ctypes.data, B, vb.ctypes.data, hv.ctypes.data, out,
                                              counts.ctypes.data))
     return [[_contact_dict(out[2 * i + k]) for k in range(counts[i])] for i in range(n)]
+
+
+def tri_reject_batch(ctx, tag, p, d, r, delta, tris):
+    """n (moving component, triangle) problems as arrays - tag (n,), p, d, delta (n, 3), r (n,), tris (n, 3, 3) - through the front end's cheap
+    reject and through the body-triangle tests: returns (far (n,) uint8, counts (n,) int32)  (mgf_tri_reject_batch)."""
+    n = len(tag)
+    rec = np.zeros(n, dtype=np.dtype([("tag", np.int32), ("p", np.float32, 3), ("d", np.float32, 3), ("r", np.float32), ("delta", np.float32, 3)]))
+    rec["tag"], rec["p"], rec["d"], rec["r"], rec["delta"] = tag, p, d, r, delta
+    assert rec.dtype.itemsize == C.sizeof(MovingComponent)
+    t = np.ascontiguousarray(tris, dtype=np.float32).reshape(n, 9)
+    far = np.zeros(n, np.uint8)
+    counts = np.zeros(n, np.int32)
+    _check(load_library().mgf_tri_reject_batch(ctx._h, n, rec.ctypes.data, t.ctypes.data, far.ctypes.data, counts.ctypes.data))
+    return far, counts
 
 
 def _moving(tag, p, d, r, delta):

@@ -667,6 +667,11 @@ __device__ inline int comp_tri_local(const Comp& A, V3 vA, const Triangle& tri, 
 // beyond one of those four planes, on the same side, never touches it.  The candidates that fail here are the ones that would have
 // walked through every branch of tri_mcapsule to report nothing.
 __device__ __forceinline__ bool comp_tri_far(const Comp& A, V3 vA, const Triangle& tri) {
+  // A capsule that does not move at all is never dropped: with v = 0 the reference's ray-capsule test (collision.rs:275-359) takes its
+  // parallel branch and, where the ray's origin lies beyond an end of the edge, evaluates (-b - sqrt(discr)) / |v|^2 = 0 / 0 -> max(NaN, 0) = 0:
+  // "a hit at t = 0" whatever the distance - a static capsule reports a contact with a triangle it is a radius and a half away from
+  // (tests/test_gpu_tri_reject.py found it; a sphere is guarded: tri_msphere returns at |v| = 0, collision.rs:640).
+  if (A.kind != KIND_SPHERE && mag2(vA) == 0.0f) return false;
   const V3 p0 = A.p, p1 = A.kind == KIND_SPHERE ? A.p : A.p + A.d;
   // (... of the reference's ARITHMETIC, which is f32 relative to the far end of an edge: ray_capsule forms |m|^2 |D|^2 - (m.D)^2 with m from
   // the edge's start - 200 m away on the floor of config 5's box - and whether a capsule 0.31 from the floor's diagonal touches it comes out
@@ -680,8 +685,23 @@ __device__ __forceinline__ bool comp_tri_far(const Comp& A, V3 vA, const Triangl
   const float nn = dot(n, n);
   if (!(nn > 0.0f)) return false;  // (a degenerate face: the reference's tests decide)
   {
+    // ... and a needle or a sliver (an angle under 2 degrees): tri_contains' determinant |ab|^2 |ac|^2 - (ab.ac)^2 is then the rounding of its two
+    // terms and the reference finds points well outside the face "inside" - its tests decide (the fuzz found contacts 6 m from a 800 m sliver)
+    const float a0 = dot(e0, e0), a1 = dot(e1, e1), a2 = dot(e2, e2);
+    if (!(nn >= 1e-3f * fmax_rs(fmax_rs(a0 * a1, a1 * a2), a2 * a0))) return false;
+  }
+  // The reference's first test of a capsule (collision.rs:698-719, "the axis already crosses the face") finds the crossing at t = (d - n.a) /
+  // (n . normalize(axis)) - a LENGTH along the axis - and accepts 0 <= t <= 1 as if t were the parameter: a capsule shorter than 1 that points
+  // at the face from 0.2 above it "crosses" it where its axis, carried on to length 1, would (the contact: c.a + c.d t, over the face's inside).
+  // The tests on the face's plane below therefore take the axis carried on to length 1 (and 2 % for rounding) where it is shorter.
+  V3 p1x = p1;
+  if (A.kind != KIND_SPHERE) {
+    const float len2 = mag2(A.d);
+    if (len2 < 1.02f * 1.02f && len2 > 0.0f) p1x = p0 + A.d * (1.02f / __builtin_sqrtf(len2));
+  }
+  {
     const float l = lim * __builtin_sqrtf(nn);
-    const float d0 = dot(p0 - tri.a, n), d1 = dot(p1 - tri.a, n);
+    const float d0 = dot(p0 - tri.a, n), d1 = dot(p1x - tri.a, n);
     if ((d0 > l && d1 > l) || (d0 < -l && d1 < -l)) return true;
   }
   // cross(edge, n) points away from the triangle whatever its winding (n turns with it)
@@ -694,8 +714,8 @@ __device__ __forceinline__ bool comp_tri_far(const Comp& A, V3 vA, const Triangl
   // cross is an end point over the face's inside or a pair of points of the segment and an edge.  (A body that lies on the NEXT face, half a
   // radius from this one's edge, passes the four planes above and touches nothing here: two candidates in three of a capsule field at rest.)
   {
-    const float d0 = dot(p0 - tri.a, n), d1 = dot(p1 - tri.a, n);
-    if (!((d0 > 0.0f && d1 > 0.0f) || (d0 < 0.0f && d1 < 0.0f))) return false;  // (the axis meets the plane: the reference's tests decide)
+    const float d0 = dot(p0 - tri.a, n), d1 = dot(p1 - tri.a, n), d1x = dot(p1x - tri.a, n);
+    if (!((d0 > 0.0f && d1x > 0.0f) || (d0 < 0.0f && d1x < 0.0f))) return false;  // (the axis - carried on - meets the plane: the reference's tests decide)
     const float lim2 = lim * lim;
     // an end point whose projection lies inside the face (or on its rim: then an edge is as near) is |d| / |n| from it
     const bool in0 = dot(p0 - tri.a, m0) <= 0.0f && dot(p0 - tri.b, m1) <= 0.0f && dot(p0 - tri.c, m2) <= 0.0f;

@@ -164,6 +164,21 @@ __global__ __launch_bounds__(kBlock) void k_manifolds(int64_t n, const unsigned 
 }
 
 struct MovingIn { int tag; float p[3], d[3], r; float delta[3]; };
+// The cheap conservative reject ahead of the body-triangle tests (comp_tri_far, dev_geom.h) beside the tests themselves, for batches of
+// independent (moving component, triangle) problems: far[i] = the reject's verdict, counts[i] = the contacts the reference's tests report
+// (collision.rs:610-1086 through Mesh::contacts' frame) - a problem with far[i] and counts[i] > 0 would be a contact the tick's r06 front
+// end loses (tests/test_gpu_tri_reject.py fuzzes it).
+__global__ void k_tri_reject_batch(int64_t n, const MovingIn* bodies, const float* tris, uint8_t* far, int32_t* counts) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const MovingIn m = bodies[t];
+  Comp A; A.kind = m.tag; A.p = ld3(m.p); A.d = m.tag == KIND_SPHERE ? mk3(0.0f, 0.0f, 0.0f) : ld3(m.d); A.r = m.r;
+  const V3 vA = ld3(m.delta);
+  const Triangle tri = mkt(ld3(tris + 9 * t), ld3(tris + 9 * t + 3), ld3(tris + 9 * t + 6));
+  LocalContact lc[2];
+  far[t] = comp_tri_far(A, vA, tri) ? 1 : 0;
+  counts[t] = comp_tri_local(A, vA, tri, mk3(0.0f, 0.0f, 0.0f), lc);
+}
 // ---- Compound (compound.rs:230-352): components + internal reference-built BVH + pose -------------------
 struct CompIn { int tag; float p[3], d[3], r; };
 struct CompoundDev {
