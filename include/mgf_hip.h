@@ -228,16 +228,19 @@ MGF_API mgf_status mgf_world_add_bodies(mgf_world* w, const mgf_component* comps
                                         uint64_t* first_id);
 /* Bodies of several components (BASELINE config 5).  NOT in the reference - physics.rs:200 takes one Component - so the
  * definition is this build's (oracle: RigidBodyVec::add_compound_body): body b is made of comps[offsets[b] ..
- * offsets[b + 1]) (1..4 components, world coordinates at creation) with masses comp_mass[..]; mass = sum, x = centre of
+ * offsets[b + 1]) (1..32 components, world coordinates at creation) with masses comp_mass[..]; mass = sum, x = centre of
  * mass, q = identity, inertia = sum of the components' tensors about the centre of mass (the reference's Inertia,
  * physics.rs:30-93); the parts are fixed in the body frame and rebuilt from (x, q) every tick like a single collider
- * (physics.rs:243-251).  Contacts: every pair of parts (Contacts, compound.rs:180-190), local points relative to the
- * bodies' centres, ContactPruner + Manifold::from(pruner) (manifold.rs:72-148) - up to 4 contacts per pair of bodies, each
- * a consecutive single-contact constraint record with the manifold's normal (equivalent to solver.rs:219-248).
- * Ghost and migrant records carry four part slots, so such bodies cross tiles like the others (kind bits 2 and 3 of "body_kinds").
- * LIMIT: a body of more than 4 components (or of none) is refused with MGF_ERR_INVALID and nothing is added - four parts keep a
- * pair of bodies at <= 16 raw contacts, which the pruner's list of kept slots holds in full; a body with an internal BVH over
- * many parts (compound.rs:232-352 is the static case) is not built. */
+ * (physics.rs:243-251).  Contacts: every pair of parts in order, the first body's outer (Contacts, compound.rs:180-190), local points
+ * relative to the bodies' centres, ContactPruner + Manifold::from(pruner) (manifold.rs:72-148) - up to 16 contacts per pair of bodies,
+ * each a consecutive single-contact constraint record with the manifold's normal (equivalent to solver.rs:219-248).
+ * Bodies of up to 4 components keep their parts in four slots per body; ghost and migrant records carry those four, so such bodies cross
+ * tiles like the others (kind bits 2 and 3 of "body_kinds").  Bodies of 5..32 components (r06) keep theirs in a pool of the
+ * world; a wave takes a candidate pair of bodies and its lanes the part pairs (the reference's Compound, compound.rs:232-352, a STATIC
+ * shape, walks a BVH over its components instead - one CPU thread's way of skipping distant parts).
+ * LIMITS: a body of more than 32 components (or of none) is refused with MGF_ERR_INVALID and nothing is added; bodies of more than 4
+ * components are refused beside static obstacles and in tile sets (MGF_ERR_INVALID); a tick in which two bodies meet in more than 48
+ * part pairs, or in a manifold of more than 16 contacts, fails with MGF_ERR_CAPACITY. */
 MGF_API mgf_status mgf_world_add_compound_bodies(mgf_world* w, const mgf_component* comps, const float* comp_mass,
                                                  const int64_t* offsets /* n + 1 */, int64_t n, const float* restitution,
                                                  const float* friction, const mgf_vec3* world_force, uint64_t* first_id);

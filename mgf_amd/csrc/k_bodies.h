@@ -49,8 +49,16 @@ struct Bodies {
   float4* lp1;    //             d.xyz (capsule axis), kind bits
   float4* wp0;    // world part at the start of the tick's motion, same layout
   float4* wp1;
+  // (r06) a body of MORE than kMaxParts components (up to kBigParts) keeps its parts in the world's pool arrays - local and world parts, the
+  // layout of lp* / wp* - at an offset that sits in the body's first local part slot (lp0[kMaxParts * i].x, as bits): whatever moves a
+  // body's row (re-sorting the store, clones) moves the offset along, the pool itself never moves.  Null unless the world has such a body.
+  float4* xl0;
+  float4* xl1;
+  float4* xw0;
+  float4* xw1;
 };
 constexpr int kMaxParts = 4;   // part slots per body in the part arrays (round 3: 2 -> 4)
+constexpr int kBigParts = 32;  // the most components a body may have (r06; the reference's Compound, compound.rs:232-352, has no limit - it is static)
 constexpr int kTileParts = 4;  // part slots of a ghost / migrant record of the tile protocol (its record sizes are part of the ABI; r04: 2 -> 4 =
                                // kMaxParts, every body the store can hold crosses tiles)
 
@@ -60,6 +68,15 @@ struct SceneBounds { int lo[3]; int hi[3]; uint32_t n_refits; uint32_t pad; int 
 __device__ __forceinline__ int f_ord(float f) { int i = __builtin_bit_cast(int, f); return i >= 0 ? i : (i ^ 0x7FFFFFFF); }
 __host__ __device__ __forceinline__ float ord_f(int i) { int j = i >= 0 ? i : (i ^ 0x7FFFFFFF); return __builtin_bit_cast(float, j); }
 
+// Part k of body i (pc = its part count, > 0): the local or the world record pair, from the body's four slots or - a body of more than
+// kMaxParts components - from the pool.
+__device__ __forceinline__ size_t part_at(const Bodies& B, uint32_t i, uint32_t k, uint32_t pc) {
+  return pc > (uint32_t)kMaxParts ? (size_t)__builtin_bit_cast(uint32_t, B.lp0[(size_t)kMaxParts * i].x) + k : (size_t)kMaxParts * i + k;
+}
+__device__ __forceinline__ void world_part(const Bodies& B, uint32_t i, uint32_t k, uint32_t pc, float4& a, float4& b) {
+  const size_t at = part_at(B, i, k, pc);
+  if (pc > (uint32_t)kMaxParts) { a = B.xw0[at]; b = B.xw1[at]; } else { a = B.wp0[at]; b = B.wp1[at]; }
+}
 __device__ __forceinline__ M3 load_imb(const float4* imb, uint32_t i) {
   float4 a = imb[3 * i], b = imb[3 * i + 1], c = imb[3 * i + 2];
   return m3_cols(xyz(a), xyz(b), xyz(c));
@@ -160,13 +177,17 @@ __global__ __launch_bounds__(kBlock) void k_integrate(Bodies B, uint32_t n, floa
       const uint32_t pc = B.pcount ? B.pcount[i] : 0u;
       if (pc) {  // a body of several parts: the collider slot carries the centre (a radius-0 sphere), the parts collide
         col.kind = KIND_SPHERE; col.p = x; col.d = mk3(0.0f, 0.0f, 0.0f); col.r = 0.0f;
+        const bool big = pc > (uint32_t)kMaxParts;  // (its parts live in the pool: Bodies::xl0)
+        const size_t at0 = part_at(B, i, 0u, pc);
+        const float4 *L0 = big ? B.xl0 : B.lp0, *L1 = big ? B.xl1 : B.lp1;
+        float4 *W0 = big ? B.xw0 : B.wp0, *W1 = big ? B.xw1 : B.wp1;
         for (uint32_t k = 0; k < pc; ++k) {
-          float4 l0 = B.lp0[kMaxParts * i + k], l1 = B.lp1[kMaxParts * i + k];
+          float4 l0 = L0[at0 + k], l1 = L1[at0 + k];
           Comp part; part.kind = (int)f2u(l1.w); part.r = l0.w;
           part.p = x + rotate(q, xyz(l0));
           part.d = part.kind == KIND_SPHERE ? mk3(0.0f, 0.0f, 0.0f) : rotate(q, xyz(l1));
-          B.wp0[kMaxParts * i + k] = mk4(part.p, part.r);
-          B.wp1[kMaxParts * i + k] = mk4(part.d, l1.w);
+          W0[at0 + k] = mk4(part.p, part.r);
+          W1[at0 + k] = mk4(part.d, l1.w);
           Box pb = swept_bounds(part, d);
           tb = k == 0 ? pb : box_combine(tb, pb);
         }

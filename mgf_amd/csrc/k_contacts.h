@@ -104,7 +104,8 @@ __device__ __forceinline__ bool load_part(const Bodies& B, uint32_t i, uint32_t 
   const uint32_t pc = B.pcount ? B.pcount[i] : 0u;
   if (pc == 0) { if (k) return false; *out = load_comp(B, i); *centre = comp_center(*out); return true; }
   if (k >= pc) return false;
-  const float4 a = B.wp0[kMaxParts * i + k], b = B.wp1[kMaxParts * i + k];
+  float4 a, b;
+  world_part(B, i, k, pc, a, b);
   out->kind = (int)f2u(b.w); out->p = xyz(a); out->r = a.w; out->d = xyz(b);
   *centre = xyz(B.col0[i]);
   return true;
@@ -315,6 +316,136 @@ __global__ __launch_bounds__(kBlock) void k_narrow_terrain_parts(Bodies B, Terra
     }
   }
   t_nc[p] = cnt;
+}
+
+// ---- (r06) worlds with a body of MORE than kMaxParts components (up to kBigParts; SURVEY 8f-1: the reference's Compound over any number of
+// components, compound.rs:232-352, is a static shape with a BVH inside; a dynamic body of many parts is this build's definition, stated by the
+// oracle: every pair of parts in order - parts of i outer - through Contacts, ContactPruner::push, Manifold::from).  A body's internal tree is
+// how one CPU thread avoids part pairs that are far apart; here a WAVE takes a candidate pair of bodies and its lanes the part pairs, sixty-four
+// at a time in the oracle's order: the bounding-sphere reject (comp_pair_far) ends most of them, the contacts of the rest are packed in lane
+// order - which is the order the pruner has to see - into a short list in LDS, and lane 0 runs the pruner over it.  Output as
+// k_narrow_pairs_parts<kMaxParts>: up to 16 contacts per candidate.  More than kBigRaw raw contacts or a manifold of more than 16: *over.
+constexpr uint32_t kBigRaw = 48;   // raw contacts of one pair of bodies the wave's list holds
+constexpr uint32_t kBigKeep = 16;  // contacts of one manifold (the stride of p_out)
+static_assert(kBigParts <= 64, "k_narrow_terrain_big: a lane per part");
+__global__ __launch_bounds__(kBlock) void k_narrow_pairs_big(Bodies B, const uint32_t* m_ptr, const uint32_t* p_owner, const uint32_t* p_cand, uint32_t* p_nc,
+                                                             NContact* p_out /* kBigKeep per candidate */, uint32_t* over) {
+  __shared__ NContact s_raw[kBlock / 64][kBigRaw];
+  __shared__ uint32_t s_keep[kBlock / 64][kBigKeep];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t m = *m_ptr, nwaves = gridDim.x * (kBlock / 64);
+  for (uint32_t p = blockIdx.x * (kBlock / 64) + (uint32_t)wv; p < m; p += nwaves) {
+    const uint32_t i = p_owner[p], j = p_cand[p];
+    {  // the tight boxes of this tick (k_narrow_pairs_parts' first step)
+      const float4 ca = B.tb_c[i], ra = B.tb_r[i], cb = B.tb_c[j], rb = B.tb_r[j];
+      const float slack = 1e-3f + 1e-5f * (fabs_rs(ca.x) + fabs_rs(ca.y) + fabs_rs(ca.z) + fabs_rs(cb.x) + fabs_rs(cb.y) + fabs_rs(cb.z));
+      if (fabs_rs(ca.x - cb.x) > ra.x + rb.x + slack || fabs_rs(ca.y - cb.y) > ra.y + rb.y + slack || fabs_rs(ca.z - cb.z) > ra.z + rb.z + slack) {
+        if (lane == 0) p_nc[p] = 0u;
+        continue;
+      }
+    }
+    const uint32_t pci = B.pcount[i], pcj = B.pcount[j];
+    const uint32_t na = pci ? pci : 1u, nb = pcj ? pcj : 1u, total = na * nb;
+    const V3 vA = xyz(B.delta[i]), vB = xyz(B.delta[j]);
+    uint32_t nraw = 0;
+    for (uint32_t w0 = 0; w0 < total; w0 += 64u) {
+      const uint32_t w = w0 + (uint32_t)lane;
+      bool hit = false;
+      NContact raw;
+      raw.la = raw.lb = raw.n = make_float4(0, 0, 0, 0);
+      if (w < total) {
+        const uint32_t a = w / nb, b = w - a * nb;
+        float4 a0, a1, b0, b1;
+        if (pci) world_part(B, i, a, pci, a0, a1); else { a0 = B.col0[i]; a1 = B.col1[i]; }
+        if (pcj) world_part(B, j, b, pcj, b0, b1); else { b0 = B.col0[j]; b1 = B.col1[j]; }
+        Comp Pa, Pb;
+        Pa.kind = (int)f2u(a1.w); Pa.p = xyz(a0); Pa.r = a0.w; Pa.d = xyz(a1);
+        Pb.kind = (int)f2u(b1.w); Pb.p = xyz(b0); Pb.r = b0.w; Pb.d = xyz(b1);
+        Contact c;
+        if (!comp_pair_far(Pa, vA, Pb, vB) && comp_pair_contact(Pa, vA, Pb, vB, &c)) {
+          hit = true;
+          raw.la = mk4(c.a, c.t); raw.lb = mk4(c.b, 1.0f); raw.n = mk4(c.n, 0.0f);
+        }
+      }
+      const unsigned long long mask = __ballot(hit);
+      const uint32_t at = nraw + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      if (hit && at < kBigRaw) s_raw[wv][at] = raw;
+      nraw += (uint32_t)__popcll(mask);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (a wave's LDS accesses are served in order; it reads only what it wrote)
+    if (lane != 0) continue;
+    if (nraw > kBigRaw) { atomicOr(over, 1u); p_nc[p] = 0u; continue; }
+    // ContactPruner::push (manifold.rs:72-102) over the raw contacts in order, Manifold::from(pruner) (:131-148): k_narrow_pairs_parts' third
+    // step with the kept contacts' list positions in LDS
+    const V3 ci = pci ? xyz(B.col0[i]) : comp_center(load_comp(B, i)), cj = pcj ? xyz(B.col0[j]) : comp_center(load_comp(B, j));
+    auto local_of = [&](const NContact& r) -> LocalContact {
+      Contact c; c.a = xyz(r.la); c.b = xyz(r.lb); c.n = xyz(r.n); c.t = r.la.w;
+      LocalContact nc; nc.la = c.a + -(ci + vA * c.t); nc.lb = c.b + -(cj + vB * c.t); nc.g = c;
+      return nc;
+    };
+    float min_t = kInf;
+    uint32_t cnt = 0;
+    bool too_many = false;
+    for (uint32_t e = 0; e < nraw; ++e) {
+      const LocalContact nc = local_of(s_raw[wv][e]);
+      if (nc.g.t < min_t - kCollisionEps) { cnt = 1; s_keep[wv][0] = e; min_t = nc.g.t; continue; }
+      if (nc.g.t > min_t + kCollisionEps) continue;
+      bool merged = false;
+      for (uint32_t k = 0; k < cnt && !merged; ++k) {
+        const LocalContact kc = local_of(s_raw[wv][s_keep[wv][k]]);
+        const V3 ra = nc.g.a - kc.g.a, rb = nc.g.b - kc.g.b;
+        if (mag2(ra) <= kPersistentThresholdSq || mag2(rb) <= kPersistentThresholdSq) {
+          const float prev = mag2(kc.la) + mag2(kc.lb), cur = mag2(nc.la) + mag2(nc.lb);
+          if (prev < cur) s_keep[wv][k] = e;
+          merged = true;
+        }
+      }
+      if (!merged) { if (cnt < kBigKeep) s_keep[wv][cnt++] = e; else too_many = true; }
+    }
+    if (too_many) { atomicOr(over, 2u); p_nc[p] = 0u; continue; }
+    p_nc[p] = cnt;
+    if (cnt == 0) continue;
+    V3 sum = mk3(0.0f, 0.0f, 0.0f);
+    for (uint32_t k = 0; k < cnt; ++k) sum = sum + xyz(s_raw[wv][s_keep[wv][k]].n);
+    const V3 avg = sum / (float)cnt;
+    for (uint32_t k = 0; k < cnt; ++k) {
+      const LocalContact kc = local_of(s_raw[wv][s_keep[wv][k]]);
+      NContact o; o.la = mk4(kc.la, min_t); o.lb = mk4(kc.lb, 0.0f); o.n = mk4(avg, 0.0f);
+      p_out[(size_t)kBigKeep * p + k] = o;
+    }
+  }
+}
+// ... and against the faces of the mesh: a wave per (body, face) candidate, a lane per part; every contact is its own constraint, in the
+// order of the parts (k_narrow_terrain_parts' output, `stride` = 2 x the most parts of any body of the world).  A part whose reach ends
+// short of the face (comp_tri_far) is not walked through the reference's tests.
+__global__ __launch_bounds__(kBlock) void k_narrow_terrain_big(Bodies B, TerrainDev M, const uint32_t* m_ptr, const uint32_t* t_owner, const uint32_t* t_cand,
+                                                               uint32_t* t_nc, NContact* t_out, uint32_t stride) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t m = *m_ptr, nwaves = gridDim.x * (kBlock / 64);
+  const V3 mx = mk3(M.x[0], M.x[1], M.x[2]);
+  for (uint32_t p = blockIdx.x * (kBlock / 64) + (uint32_t)wv; p < m; p += nwaves) {
+    const uint32_t i = t_owner[p], f = t_cand[p];
+    if (f & 0x80000000u) continue;  // (a component of a static obstacle: k_narrow_obstacles)
+    const uint32_t pc = B.pcount[i], np = pc ? pc : 1u;
+    int nc = 0;
+    LocalContact lc[2];
+    if ((uint32_t)lane < np) {
+      Comp Pa;
+      V3 ci;
+      (void)load_part(B, i, (uint32_t)lane, &Pa, &ci);
+      const V3 vA = xyz(B.delta[i]);
+      const uint4 fi = M.faces[f];
+      const Triangle tri = mkt(xyz(M.verts[fi.x]) + mx, xyz(M.verts[fi.y]) + mx, xyz(M.verts[fi.z]) + mx);  // mesh.rs:122-126
+      if (!comp_tri_far(Pa, vA, tri)) nc = comp_tri_local_at(Pa, vA, tri, mx, ci, lc);
+    }
+    const unsigned long long m1 = __ballot(nc >= 1), m2 = __ballot(nc == 2), lt = (1ull << lane) - 1ull;
+    const uint32_t at = (uint32_t)__popcll(m1 & lt) + (uint32_t)__popcll(m2 & lt);
+    for (int k = 0; k < nc; ++k) {
+      NContact o; o.la = mk4(lc[k].la, lc[k].g.t); o.lb = mk4(lc[k].lb, 0.0f); o.n = mk4(lc[k].g.n, 0.0f);
+      t_out[(size_t)stride * p + at + (uint32_t)k] = o;
+    }
+    if (lane == 0) t_nc[p] = (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
+  }
 }
 
 // Bin candidate ids by pair type (only launched for scenes that mix spheres and capsules).

@@ -310,6 +310,66 @@ def jack_field(nx, ny, nz, seed=SEED, iters=10, pitch=2.6, y0=1.6):
     return sc
 
 
+def caterpillar_field(nx, ny, nz, n_plain=0, small_every=0, seed=SEED, iters=10, pitch=(5.8, 2.4, 5.8), y0=2.0):
+    """Bodies of SIXTEEN components each (round 6, SURVEY 8f-1: more parts than a body's four slots hold - the pool of Bodies::xl0): a
+    "caterpillar" - a zigzag spine of ten spheres (r = 0.32, 0.5 apart) with six capsule legs (|d| = 0.7, r = 0.12) pointing down and outwards
+    from three of them - randomly turned about the vertical and tilted a little, nx*ny*nz of them on a lattice above the floor of an open box,
+    `n_plain` ordinary spheres dropped on top.  small_every = k > 0: every k-th body keeps only its first three components (a body of the
+    four-slot kind among the pooled ones).  Like dumbbell_field and jack_field this is the build's own definition of a body of several
+    components (mgf_world_add_compound_bodies; oracle: RigidBodyVec::add_compound_body)."""
+    n = nx * ny * nz
+    px, py, pz = pitch
+    i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    base = np.stack([(i.ravel() - (nx - 1) / 2.0) * px, y0 + j.ravel() * py, (k.ravel() - (nz - 1) / 2.0) * pz], axis=1)
+    jit = np.stack([uniform(seed, n, -0.1, 0.1, stream=71 + s) for s in range(3)], axis=1)
+    c = (base + jit).astype(np.float64)
+    c = c[seeded_permutation(seed, n, stream=78)]
+    phi = uniform(seed, n, 0.0, 2.0 * np.pi, stream=74).astype(np.float64)
+    tilt = uniform(seed, n, -0.25, 0.25, stream=75).astype(np.float64)
+    # the body frame: e0 along the spine (turned by phi about y, tilted out of the horizontal), e1 sideways, e2 up
+    e0 = np.stack([np.cos(phi) * np.cos(tilt), np.sin(tilt), np.sin(phi) * np.cos(tilt)], axis=1)
+    e1 = np.stack([-np.sin(phi), np.zeros(n), np.cos(phi)], axis=1)
+    e2 = np.cross(e0, e1)
+    local = []  # (tag, p, d, r, mass) in the body frame
+    for s_ in range(10):
+        local.append((0, ((s_ - 4.5) * 0.5, 0.0, 0.15 if s_ % 2 else -0.15), (0.0, 0.0, 0.0), 0.32, 0.5))
+    for s_ in (1, 4, 7):
+        for side in (-1.0, 1.0):
+            root = ((s_ - 4.5) * 0.5, side * 0.2, -0.1)
+            d = np.array([0.0, side * 0.45, -0.55]); d *= 0.7 / np.linalg.norm(d)
+            local.append((1, root, tuple(d), 0.12, 0.2))
+    P = len(local)
+    counts = np.full(n, P, np.int64)
+    if small_every:
+        counts[::small_every] = 3
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    comps = np.zeros(int(offsets[-1]), dtype=COMPONENT_DTYPE)
+    mass = np.zeros(int(offsets[-1]), np.float32)
+    frame = lambda v: e0 * v[0] + e1 * v[1] + e2 * v[2]  # noqa: E731
+    for b in range(n):
+        for a in range(int(counts[b])):
+            tag, p_, d_, r_, m_ = local[a]
+            at = int(offsets[b]) + a
+            comps["tag"][at] = tag
+            comps["p"][at] = (c[b] + frame(p_)[b]).astype(np.float32)
+            comps["d"][at] = frame(d_)[b].astype(np.float32) if tag else 0.0
+            comps["r"][at] = r_
+            mass[at] = m_
+    half = max(nx * px, nz * pz) / 2.0 + 2.5
+    terrain = box_terrain(half, ny * py + 8.0, (0.0, 0.0, 0.0))
+    pc = np.zeros((n_plain, 3), np.float32)
+    if n_plain:
+        pc[:, 0] = uniform(seed, n_plain, -half + 1.5, half - 1.5, stream=76)
+        pc[:, 2] = uniform(seed, n_plain, -half + 1.5, half - 1.5, stream=77)
+        pc[:, 1] = y0 + ny * py + 1.0 + 1.2 * np.arange(n_plain)
+    sc = _scene(f"caterpillar_field_{nx}x{ny}x{nz}+{n_plain}", _spheres(pc, 0.5), terrain, iters=iters)
+    v0c = np.stack([uniform(seed, n, -0.5, 0.5, stream=81 + s) for s in range(3)], axis=1)
+    sc["compound"] = dict(comps=comps, comp_mass=mass, offsets=offsets, restitution=np.full(n, 0.3, np.float32), friction=np.full(n, 0.6, np.float32),
+                          force=np.tile(np.float32([0.0, -9.8, 0.0]), (n, 1)))
+    sc["v0"] = np.concatenate([np.zeros((n_plain, 3), np.float32), v0c.astype(np.float32)])
+    return sc
+
+
 def split_by_slabs(scene, world_size, half_x):
     """x-slab tiles of a scene built by dumbbell_field: tile r gets the bodies whose centre lies in its slab of
     [-half_x, half_x), in their original order; `tags` are the bodies' indices in the undivided scene."""

@@ -196,13 +196,16 @@ def test_hip_two_part_bodies_across_tiles_equal_oracle_tiles(ctx, P, drift, jack
 
 
 @pytest.mark.gpu
-def test_hip_bodies_of_more_than_four_parts_are_refused(ctx):
+def test_hip_bodies_of_more_than_thirty_two_parts_are_refused(ctx):
     import mgf_amd
-    sc = scenes.dumbbell_field(2, 1, 3)
+    sc = scenes.dumbbell_field(6, 1, 3)
     gw = mgf_amd.World.from_scene(ctx, sc)
     gw.add_compound_bodies(sc["compound"]["comps"][:3], 1.0, [0, 3], 0.3, 0.6, [0, -9.8, 0])      # three parts: fine since round 3
+    gw.add_compound_bodies(sc["compound"]["comps"][:5], 1.0, [0, 5], 0.3, 0.6, [0, -9.8, 0])      # five: fine since round 6 (tests/test_gpu_many_part_bodies.py)
+    n = len(gw)
     with pytest.raises(mgf_amd.MgfError):
-        gw.add_compound_bodies(sc["compound"]["comps"][:5], 1.0, [0, 5], 0.3, 0.6, [0, -9.8, 0])  # five: over the limit
+        gw.add_compound_bodies(sc["compound"]["comps"][:33], 1.0, [0, 33], 0.3, 0.6, [0, -9.8, 0])  # thirty-three: over the limit
+    assert len(gw) == n  # (nothing was added)
 
 
 # ---- bodies of FOUR components (round 3) ---------------------------------------------------------------------------------------
