@@ -239,7 +239,7 @@ MGF_API mgf_status mgf_world_add_bodies(mgf_world* w, const mgf_component* comps
  * world; a wave takes a candidate pair of bodies and its lanes the part pairs (the reference's Compound, compound.rs:232-352, a STATIC
  * shape, walks a BVH over its components instead - one CPU thread's way of skipping distant parts).
  * LIMITS: a body of more than 32 components (or of none) is refused with MGF_ERR_INVALID and nothing is added; bodies of more than 4
- * components are refused beside static obstacles and in tile sets (MGF_ERR_INVALID); a tick in which two bodies meet in more than 48
+ * components are refused beside static obstacles and in tile sets (MGF_ERR_INVALID); a tick in which two bodies meet in more than 64
  * part pairs, or in a manifold of more than 16 contacts, fails with MGF_ERR_CAPACITY. */
 MGF_API mgf_status mgf_world_add_compound_bodies(mgf_world* w, const mgf_component* comps, const float* comp_mass,
                                                  const int64_t* offsets /* n + 1 */, int64_t n, const float* restitution,

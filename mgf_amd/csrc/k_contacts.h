@@ -325,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void k_narrow_terrain_parts(Bodies B, Terra
 // at a time in the oracle's order: the bounding-sphere reject (comp_pair_far) ends most of them, the contacts of the rest are packed in lane
 // order - which is the order the pruner has to see - into a short list in LDS, and lane 0 runs the pruner over it.  Output as
 // k_narrow_pairs_parts<kMaxParts>: up to 16 contacts per candidate.  More than kBigRaw raw contacts or a manifold of more than 16: *over.
-constexpr uint32_t kBigRaw = 48;   // raw contacts of one pair of bodies the wave's list holds
+constexpr uint32_t kBigRaw = 64;   // raw contacts of one pair of bodies the wave's list holds
 constexpr uint32_t kBigKeep = 16;  // contacts of one manifold (the stride of p_out)
 static_assert(kBigParts <= 64, "k_narrow_terrain_big: a lane per part");
 __global__ __launch_bounds__(kBlock) void k_narrow_pairs_big(Bodies B, const uint32_t* m_ptr, const uint32_t* p_owner, const uint32_t* p_cand, uint32_t* p_nc,
@@ -440,9 +440,12 @@ __global__ __launch_bounds__(kBlock) void k_narrow_terrain_big(Bodies B, Terrain
     }
     const unsigned long long m1 = __ballot(nc >= 1), m2 = __ballot(nc == 2), lt = (1ull << lane) - 1ull;
     const uint32_t at = (uint32_t)__popcll(m1 & lt) + (uint32_t)__popcll(m2 & lt);
-    for (int k = 0; k < nc; ++k) {
-      NContact o; o.la = mk4(lc[k].la, lc[k].g.t); o.lb = mk4(lc[k].lb, 0.0f); o.n = mk4(lc[k].g.n, 0.0f);
-      t_out[(size_t)stride * p + at + (uint32_t)k] = o;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {  // (unrolled: an index the compiler does not know keeps the pair in scratch memory)
+      if (k < nc) {
+        NContact o; o.la = mk4(lc[k].la, lc[k].g.t); o.lb = mk4(lc[k].lb, 0.0f); o.n = mk4(lc[k].g.n, 0.0f);
+        t_out[(size_t)stride * p + at + (uint32_t)k] = o;
+      }
     }
     if (lane == 0) t_nc[p] = (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
   }
