@@ -727,7 +727,7 @@ def bench_tiles(args, ctx, mgf_amd, scenes, configure, mode, scene_kind, rank, w
                            + " with the events on",
         "replay_did_the_timed_windows_work_rank0": replay_same,
         "same_workload_on_one_gpu": one_gpu, "efficiency_vs_same_workload_on_one_gpu": eff,
-        "prediction": _tile_prediction(scene_kind, world_size, total_tiles, elapsed * 1e3 / args.steps, one_gpu),
+        "prediction": _tile_prediction(scene_kind, world_size, total_tiles, elapsed * 1e3 / args.steps, one_gpu, refresh_every, args.iters),
         "exchange": exchange, "seam_penetration": seam, "settled": settled,
     }
 
@@ -781,20 +781,21 @@ TILE_PREDICTION_ASSUMPTIONS = {
     "p2p_latency_us": 20.0,        # one grouped ncclSend/ncclRecv of a few KB..MB between neighbouring GPUs, launch to completion on the stream (RCCL 2.26 over xGMI; never measured here)
     "link_GBps": 60.0,             # achieved one-way rate of one xGMI link for MB-sized rows (153.6 GB/s bidirectional per link on paper)
     "allreduce_us": 30.0,          # the tick's status agreement (4-byte all-reduce over N ranks)
-    "exchange_steps_per_tick": {"ghost_bodies": 1, "ghost_velocities": 4, "handover": 0.4, "status_allreduce": 1},
-    "bytes_per_rank_face_per_tick": {"config4": 3.4e6, "config5_tiles": 0.5e6},  # one direction: ghost records + 4 velocity refreshes (profiles/r05_config4_8tiles_1gpu_bench.json: 95 MB between the 14 face directions of 8 tiles)
+    "exchange_steps_per_tick": {"ghost_bodies": 1, "ghost_velocities": "ceil(iters / R) - 1 (R = 4, 10 iterations: 2)", "handover": 0.4, "status_allreduce": 1},
+    "bytes_per_rank_face_per_tick": {"config4": 3.4e6, "config5_tiles": 0.5e6},  # one direction, AT R = 2: ghost records (288 B) + 4 velocity refreshes (32 B each) per ghost (profiles/r05_config4_8tiles_1gpu_bench.json: 95 MB between the 14 face directions of 8 tiles); scaled to the run's R below
 }
 
 
-def _tile_prediction(scene_kind, world_size, total_tiles, measured_ms, one_gpu):
+def _tile_prediction(scene_kind, world_size, total_tiles, measured_ms, one_gpu, refresh_every=4, iters=10):
     if scene_kind not in ("config4", "config5_tiles") or not one_gpu or "ms_per_step" not in one_gpu:
         return None
     A = TILE_PREDICTION_ASSUMPTIONS
     tile_tick = one_gpu["ms_per_step"] / total_tiles  # one tile's tick where 8 share a GPU: kernels, back to back
     per = total_tiles // world_size
     steps = A["exchange_steps_per_tick"]
-    lat_us = (steps["ghost_bodies"] + steps["ghost_velocities"] + steps["handover"]) * A["p2p_latency_us"] + steps["status_allreduce"] * A["allreduce_us"]
-    wire_us = A["bytes_per_rank_face_per_tick"][scene_kind] / (A["link_GBps"] * 1e3)
+    refreshes = max(0, -(-int(iters) // max(1, int(refresh_every))) - 1)  # a velocity exchange between consecutive solver launches
+    lat_us = (steps["ghost_bodies"] + refreshes + steps["handover"]) * A["p2p_latency_us"] + steps["status_allreduce"] * A["allreduce_us"]
+    wire_us = A["bytes_per_rank_face_per_tick"][scene_kind] * (288.0 + 32.0 * refreshes) / (288.0 + 32.0 * 4) / (A["link_GBps"] * 1e3)
     comm_ms = 0.0 if world_size == 1 else (lat_us + wire_us) / 1e3
     pred_ms = per * tile_tick + comm_ms
     return {"predicted_ms_per_step": round(pred_ms, 4), "predicted_efficiency_vs_8_tiles_on_one_gpu": round(one_gpu["ms_per_step"] / (world_size * pred_ms), 4),

@@ -1075,7 +1075,7 @@ class Tiles:
     """This process's x-slab tiles of one scene behind mgf_tiles_* (the whole tile protocol under the C-ABI; mgf_amd.tiles is
     the same protocol in Python).  worlds[i] owns the slab x_ranges[i]; the tiles are first_tile .. of n_tiles_total."""
 
-    def __init__(self, ctx, worlds, x_ranges, first_tile=0, n_tiles_total=None, halo=1.0, refresh_every=2, migrate=True):
+    def __init__(self, ctx, worlds, x_ranges, first_tile=0, n_tiles_total=None, halo=1.0, refresh_every=4, migrate=True):  # (refresh_every: tiles.DEFAULT_REFRESH_EVERY)
         self._ctx, self.worlds = ctx, list(worlds)
         n = len(self.worlds)
         total = n if n_tiles_total is None else int(n_tiles_total)

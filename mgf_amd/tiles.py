@@ -40,7 +40,11 @@ MIGRANT_FLOATS = 148
 # resting penetration of the sphere pairs straddling the slab face 0.043 (R=1), 0.046 (R=2), 0.055 (R=10)
 # against 0.044 for pairs inside a tile - R=2 halves the exchanges and solver launches and keeps the seam at
 # the interior's level.
-DEFAULT_REFRESH_EVERY = 2
+# (r06) 4: measured at full size (BASELINE config 4 as 8 tiles, the pile collapsing and at rest - ticks 260, 380, 460 - and config 5's two-part
+# bodies, EXPERIMENTS.md round 6): the depth of the pairs across tile faces at R = 4 is within 6 % of R = 2's (p99; mean within 3 %) and below
+# the interior's; R = 5 is 30-60 % deeper, R = 3 no faster than 2.  Ten iterations are then three solver launches (4 + 4 + 2) and two
+# velocity exchanges instead of five and four: the tile tick -5 % (falling) to -10 % (at rest).
+DEFAULT_REFRESH_EVERY = 4
 
 
 class HipEngine:
