@@ -35,8 +35,8 @@ run config3_20 20 k_solve_flow6 config3 150 --scene config3 --steps 20
 run config5    60 k_solve_flow6 config5 80  --scene config5
 run config5_20 20 k_solve_flow6 config5 80  --scene config5 --steps 20
 fi
-# the tile launches (2 iterations of one 131 072-body tile between ghost refreshes; 8 tiles on this GPU): the instrumented ticks'
-# 60 x 8 x 5 launches are the last 2400 of the run
+# the tile launches (4 + 4 + 2 iterations of one 131 072-body tile, a ghost velocity refresh between them - R = 4; 8 tiles on this GPU): the
+# instrumented ticks' 60 x 8 x 3 launches are the last 1440 of the run (TILE_LAUNCHES: 2400 at R = 2)
 run_tiles() {  # name, scene, warm-up
   local N=$1 SC=$2 W=$3
   local BT="python $R/bench.py --gpus 1 --scene $SC --no-cpu-baseline --no-settled-tiles"  # (the profiled launches are the LAST ones of the run: the replay of the timed falling-pile ticks, not the settled window behind it)
@@ -44,8 +44,8 @@ run_tiles() {  # name, scene, warm-up
   rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_${N}_fetch -o bench -- $BT > $O/${TAG}_${N}_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_${N}_write -o bench -- $BT > $O/${TAG}_${N}_write.log 2>&1
   ( cd $R
-    python tools/rocprof_summary.py gpurun_out/${TAG}_${N}_trace/bench_results.db 480 --tick-start k_integrate --timed k_solve_flow6 2400 > gpurun_out/${TAG}_${N}_kernel_stats.txt
-    python tools/pmc_summary.py gpurun_out/${TAG}_${N}_fetch/bench_results.db gpurun_out/${TAG}_${N}_write/bench_results.db --timed k_solve_flow6 2400 gpurun_out/${TAG}_${N}_pmc.json tiles $W 60 > gpurun_out/${TAG}_${N}_pmc_hbm_traffic.txt
+    python tools/rocprof_summary.py gpurun_out/${TAG}_${N}_trace/bench_results.db 480 --tick-start k_integrate --timed k_solve_flow6 ${TILE_LAUNCHES:-1440} > gpurun_out/${TAG}_${N}_kernel_stats.txt
+    python tools/pmc_summary.py gpurun_out/${TAG}_${N}_fetch/bench_results.db gpurun_out/${TAG}_${N}_write/bench_results.db --timed k_solve_flow6 ${TILE_LAUNCHES:-1440} gpurun_out/${TAG}_${N}_pmc.json tiles $W 60 > gpurun_out/${TAG}_${N}_pmc_hbm_traffic.txt
     rm -rf gpurun_out/${TAG}_${N}_trace gpurun_out/${TAG}_${N}_fetch gpurun_out/${TAG}_${N}_write
     python tools/publish_profiles.py $TAG > /dev/null )
 }
@@ -62,4 +62,5 @@ python tools/config4_undivided.py > /dev/null 2>&1; cp $O/config4_undivided_1gpu
 fi
 python bench.py --gpus 1 --scene config4 --no-cpu-baseline > $O/${TAG}_config4_8tiles_1gpu_bench.json 2> /dev/null
 python bench.py --gpus 1 --scene config5_tiles --no-cpu-baseline > $O/${TAG}_config5_8tiles_1gpu_bench.json 2> /dev/null
+for RR in 2 3 4 5; do python bench.py --gpus 1 --scene config4 --no-cpu-baseline --refresh-every $RR > $O/${TAG}_config4_tiles_refresh_every_$RR.json 2> /dev/null; done  # (the seam against R, the pile at rest)
 ls $O | grep ${TAG}_

@@ -42,8 +42,8 @@ for name in ("config4_tiles", "config5_tiles"):
     r = rec(name)
     if r:
         r["note"] = (f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --gpus 1 --scene {name.replace('config4_tiles', 'config4')} "
-                     "--no-cpu-baseline` (8 x-slab tiles on one GPU, tools/collect_profiles.sh); average over the LAST 2400 launches of k_solve_flow6 = the 60 "
-                     "instrumented ticks x 8 tiles x 5 launches of 2 iterations; counter unit KiB; hbm_bytes_per_launch = 2*FETCH + WRITE "
+                     "--no-cpu-baseline` (8 x-slab tiles on one GPU, tools/collect_profiles.sh); average over the LAST 1440 launches of k_solve_flow6 = the 60 "
+                     "instrumented ticks x 8 tiles x 3 launches of 4 + 4 + 2 iterations (R = 4); counter unit KiB; hbm_bytes_per_launch = 2*FETCH + WRITE "
                      "(gfx950 FETCH_SIZE reads 1/2 of 16-B/lane loads, MI355X_MICROARCH.md HBM section)")
         put(f"pmc_{name}_k_solve_flow6.json", [r])
 print(n, "files copied under profiles/ with tag", tag)
