@@ -15,7 +15,8 @@ src = os.path.join(ROOT, "gpurun_out")
 dst = os.path.join(ROOT, "profiles")
 keep = ("_bench.json", "_bench_under_trace.json", "_kernel_stats.txt", "_pmc_hbm_traffic.txt", "_bench_default.json", "_bench_driver_command.json",
         "_config4_8tiles_1gpu_bench.json", "_config4_undivided_1gpu.json", "_config5_8tiles_1gpu_bench.json", "_config5_undivided_1gpu.json",
-        "_gputests.txt", "_soak_solver_modes.txt", "_soak_scenes.txt", "_soak_tiles.txt")
+        "_gputests.txt", "_soak_solver_modes.txt", "_soak_scenes.txt", "_soak_tiles.txt",
+        "_refresh_every_2.json", "_refresh_every_3.json", "_refresh_every_4.json", "_refresh_every_5.json")
 n = 0
 for p in sorted(glob.glob(os.path.join(src, tag + "_*"))):
     if os.path.isfile(p) and p.endswith(keep) and os.path.getsize(p) > 0:
