@@ -129,6 +129,9 @@ typedef struct mgf_tiles mgf_tiles;
 
 /* ---- context ---------------------------------------------------------------------- */
 MGF_API mgf_status mgf_ctx_create(int device, mgf_ctx** out);
+/* Waits for the context's stream and drops the creator's reference.  Handles made from the context (worlds, meshes, trees, compounds, tile sets)
+ * hold references of their own: those still alive keep the struct and its streams until they are freed, in whatever order a garbage collector
+ * or a scope frees them; every other call on such a handle fails with MGF_ERR_INVALID ("the context was destroyed"). */
 MGF_API void mgf_ctx_destroy(mgf_ctx* ctx);
 /* Enqueue all work of this context on a caller-owned hipStream_t (e.g. the stream the caller's RCCL
  * transfers are ordered on) instead of the context's own stream.  The caller keeps ownership. */

@@ -314,7 +314,9 @@ class Context:
         _check(load_library().mgf_ctx_set_stream(self._h, C.c_void_p(int(hip_stream))))
 
     def close(self):
-        """Destroy the context; handles created from it are released first (they must not outlive it)."""
+        """Destroy the context; handles created from it are released first.  (A handle that outlives it all the same - an interpreter's
+        finalisation clears the weak references before it runs the finalisers, in any order - keeps the C side's struct and streams alive until
+        it is freed: mgf_ctx_destroy only drops the creator's reference.)"""
         if getattr(self, "_h", None):
             for child in list(self._children):
                 child.__del__()

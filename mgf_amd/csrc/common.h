@@ -41,6 +41,10 @@ struct mgf_ctx {
   void* pinned = nullptr;    // small pinned staging area for read-backs
   size_t pinned_bytes = 0;
   int num_cus = 256;
+  // (r06) handles made from a context keep it alive: mgf_ctx_destroy marks it closed and drops the creator's reference, the streams and the struct go
+  // with the last handle - whatever order a garbage collector (or a Rust scope) frees them in.  Calls on a closed context fail with MGF_ERR_INVALID.
+  int refs = 1;
+  bool closed = false;
   hipStream_t aux = nullptr; // a second stream for work that runs BESIDE the tick's main chain of launches (r06: the terrain kernels of a capsule world beside its pair search), created on first use
 };
 

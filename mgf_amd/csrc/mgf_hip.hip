@@ -80,10 +80,11 @@ extern "C" mgf_status mgf_ctx_set_stream(mgf_ctx* ctx, void* stream) {
   ctx->own_stream = false;
   return MGF_OK;
 }
-extern "C" void mgf_ctx_destroy(mgf_ctx* ctx) {
-  if (!ctx) return;
+static void ctx_retain(mgf_ctx* ctx) { if (ctx) ++ctx->refs; }
+static void ctx_release(mgf_ctx* ctx) {
+  if (!ctx || --ctx->refs > 0) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   ctx->stream = nullptr;
   if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); ctx->aux = nullptr; }
@@ -91,9 +92,20 @@ extern "C" void mgf_ctx_destroy(mgf_ctx* ctx) {
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   delete ctx;
 }
+// The creator's reference goes; handles made from the context that are still alive keep its streams and its struct until they are freed
+// (tools/r06/exit_probe.py: an interpreter's finalisation freed a context ahead of its worlds - mgf_world_free then read a deleted struct).
+extern "C" void mgf_ctx_destroy(mgf_ctx* ctx) {
+  if (!ctx || ctx->closed) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  ctx->closed = true;
+  if (!ctx->own_stream) ctx->stream = nullptr;  // (the caller's stream - mgf_ctx_set_stream - may be gone before the last handle is freed)
+  ctx_release(ctx);
+}
 
 static mgf_status ctx_bind(mgf_ctx* ctx) {
   if (!ctx) return fail(MGF_ERR_HIP, "no device context: this entry point computes on the GPU (mgf-hip has no CPU fallback)");
+  if (ctx->closed) return fail(MGF_ERR_INVALID, "the context was destroyed (mgf_ctx_destroy): its handles can only be freed");
   MGF_HIP_TRY(hipSetDevice(ctx->device));
   (void)hipGetLastError();  // drop any stale sticky error from unrelated earlier calls
   return MGF_OK;

@@ -259,3 +259,29 @@ def test_pair_contacts_at_the_edge_of_reach_survive_the_conservative_reject(ctx)
             n_late += 1 if w_["t"] > 0.8 else 0
         n_hit += len(want)
     assert n_hit > 100 and n_late > 10, (n_hit, n_late)
+
+
+def test_handles_outlive_a_destroyed_context():
+    """mgf_ctx_destroy only drops the creator's reference (r06: an interpreter's finalisation freed a context ahead of its worlds, and
+    mgf_world_free read a deleted struct): a world and its mesh freed AFTER their context - straight through the C-ABI, the order a garbage
+    collector may choose - and every other call on them refused."""
+    lib = mgf_amd._capi.load_library()
+    c = mgf_amd.Context(0)
+    sc = scenes.capsule_field(6, 4, 6, quads=8, pitch=1.6)
+    w = mgf_amd.World.from_scene(c, sc)
+    m = mgf_amd.Mesh(c)
+    for _ in range(5):
+        w.step(float(sc["dt"]), sc["iters"])   # (the second stream and its events exist)
+    n = len(w)
+    h = c._h
+    c._h = None                                # (the wrapper must not close the children first: that is the order under test)
+    lib.mgf_ctx_destroy(h)
+    with pytest.raises(mgf_amd.MgfError) as e:
+        w.step(float(sc["dt"]), sc["iters"])
+    assert "destroyed" in str(e.value)
+    assert len(w) == n                         # (host-side queries still answer)
+    del w, m                                   # mgf_world_free, mgf_mesh_free: the last one takes the context's streams along
+    c2 = mgf_amd.Context(0)                    # ... and the device is as usable as before
+    w2 = mgf_amd.World.from_scene(c2, sc)
+    assert w2.step(float(sc["dt"]), sc["iters"]).n_constraints >= 0
+    c2.close()
