@@ -145,11 +145,7 @@ __global__ __launch_bounds__(kBlock) void k_terrain_near(Bodies B, TerrainNear A
             const float gap = fmin_rs(fmin_rs(q.r.x + fb.r.x - fabs_rs(q.c.x - fb.c.x), q.r.y + fb.r.y - fabs_rs(q.c.y - fb.c.y)),
                                       q.r.z + fb.r.z - fabs_rs(q.c.z - fb.c.z));
             const float tol = 1e-4f * (mag_q + fabs_rs(fb.c.x) + fabs_rs(fb.c.y) + fabs_rs(fb.c.z) + fb.r.x + fb.r.y + fb.r.z);
-#if defined(MGF_TN_ABL) && MGF_TN_ABL == 1
-            if (false) {
-#else
             if (!(gap > tol)) {
-#endif
               uint32_t node = A.G.leaf_of_face[face];
               while (node != A.M.root) {
                 node = A.G.parent[node];
@@ -174,9 +170,6 @@ __global__ __launch_bounds__(kBlock) void k_terrain_near(Bodies B, TerrainNear A
     __syncthreads();
     // ---- the cheap reject on every hit (comp_tri_far), by the group's own lanes
     uint32_t H = s_cnt[g];
-#if defined(MGF_TN_ABL) && MGF_TN_ABL == 3
-    H = 0;
-#endif
     if (H > kTnHitCap) { if (s == 0) atomicOr(A.overflow, 2u); H = 0u; }
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
@@ -185,11 +178,7 @@ __global__ __launch_bounds__(kBlock) void k_terrain_near(Bodies B, TerrainNear A
         const uint32_t rank = s_hits[g][a];
         const uint4 fi = A.M.faces[A.face_of_rank[rank]];
         const Triangle tri = mkt(xyz(A.M.verts[fi.x]) + mx, xyz(A.M.verts[fi.y]) + mx, xyz(A.M.verts[fi.z]) + mx);  // mesh.rs:122-126
-#if defined(MGF_TN_ABL) && MGF_TN_ABL == 2
-        if (false) s_hits[g][a] = rank | kTnFarBit;
-#else
         if (comp_tri_far(Ac, vA, tri)) s_hits[g][a] = rank | kTnFarBit;
-#endif
       }
     }
     __syncthreads();
@@ -416,7 +405,6 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid_n(Bodies B, uint32_t n
   __shared__ uint32_t s_pool_n, s_sum;
   const int lane = threadIdx.x & 63;
   const int sub = lane & 7;
-  const int gbase = lane & ~7;
   const uint32_t qg = threadIdx.x >> 3;
   const uint32_t kq = xcd_logical_block_coop() * kPnQueries + qg;
   const bool live = kq < n;  // whole groups are live or not
@@ -447,7 +435,7 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid_n(Bodies B, uint32_t n
     } else {
 #if defined(MGF_PN_ACCEPT) && MGF_PN_ACCEPT == 0
       PairSrcGlobal S; S.T = T;
-      n_accepted = pair_query_accept(S, q, oi, n_owned, ca, d, nb, kMortonBits - (int)P, sub, gbase, s_acc[qg]);
+      n_accepted = pair_query_accept(S, q, oi, n_owned, ca, d, nb, kMortonBits - (int)P, sub, lane & ~7, s_acc[qg]);
 #else
       // (the search of k_pair_brick's slow path: a lane walks its z-columns of cells on its own, four leaf records in flight, hits appended
       // through an LDS counter - no ballot per record: in the dense part of a scene a cell holds ten bodies)
@@ -464,11 +452,7 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid_n(Bodies B, uint32_t n
       // join the block's pool
       const uint32_t na = min(n_accepted, (uint32_t)kRowCap);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the group reads the staging row its lanes wrote)
-#if defined(MGF_PN_ABL) && MGF_PN_ABL >= 2
-      if (false) {
-#else
       if (na) {
-#endif
         if (PARTS) {
           // the candidate was accepted on i's tight box against j's FAT box; a contact is a touching inside both bodies' TIGHT swept boxes of
           // this tick (k_narrow_pairs_parts: three candidates in four leave here)
@@ -495,11 +479,7 @@ __global__ __launch_bounds__(kCoopBlock) void k_pair_grid_n(Bodies B, uint32_t n
   }
   __syncthreads();
   // ---- the pool through the pair test, a lane each: contacts go to their query's row
-#if defined(MGF_PN_ABL) && MGF_PN_ABL >= 1
-  const uint32_t pool_n = 0;
-#else
   const uint32_t pool_n = s_pool_n;
-#endif
   if (PARTS) {
     for (uint32_t r0 = 0; r0 < pool_n; r0 += kPpRound) {  // (the same trips for every thread of the block)
       const uint32_t m = min(pool_n - r0, kPpRound);
