@@ -7,7 +7,8 @@ from mgf_amd import scenes
 ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 every = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 ctx = mgf_amd.Context(0)
-for name, sc in (("config3", scenes.capsule_field(128, 32, 32, quads=158)), ("config5", scenes.dumbbell_field(64, 16, 64))):
+for name, sc in (("config3", scenes.capsule_field(128, 32, 32, quads=158)), ("config5", scenes.dumbbell_field(64, 16, 64)),
+                 ("8192 bodies of 16 components", scenes.caterpillar_field(32, 8, 32))):  # (r06: bodies whose parts live in the pool)
     a, b = mgf_amd.World.from_scene(ctx, sc), mgf_amd.World.from_scene(ctx, sc)
     a.set_option("solver_mode", 1)
     a.set_option("front_rows", 0); a.set_option("wide_list", 0); a.set_option("side_stream", 0)  # (r06: the list-based front end on one stream too - the plainest tick against the default one)
