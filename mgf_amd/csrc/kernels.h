@@ -45,6 +45,11 @@
 //   k_pair_wide (r06)  the few bodies whose fat box is far larger than the rest's (WideSpec, k_bodies.h: kept out of the scene
 //                      bounds and rmax by k_integrate, never partners of the grid's pair search) find their partners-to-be
 //                      from their own side: a workgroup per listed body
+//   k_narrow_pairs_big / k_narrow_terrain_big (r06)
+//                      worlds with a body of 5..32 components (its parts in the world's pool: Bodies::xl0): a wave per candidate pair of
+//                      bodies, its lanes the part pairs in the oracle's order behind the bounding-sphere reject, the contacts packed in
+//                      lane order into LDS and the pruner run by lane 0; a wave per (body, face), a lane per part behind comp_tri_far
+//   k_tri_reject_batch the test entry mgf_tri_reject_batch: comp_tri_far's verdict beside the reference's contact count, per problem
 //   k_solver_snapshot / k_solver_restore (r05)
 //                      the velocities / impulses a persistent solver launch finds, and back, if it gives up (solver_abort_fallback)
 //   k_chain_rows       order-preserving dependency links of the tick's constraint list (compact arrays, ConsLinks);
