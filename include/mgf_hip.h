@@ -223,7 +223,7 @@ MGF_API mgf_status mgf_world_set_terrain(mgf_world* w, const mgf_mesh* mesh);   
  * Every tick each owned body's parts go through Compound::contacts (:334-352) after the body's terrain contacts - obstacles in the
  * order they were added, the body's parts in order - and every contact becomes a constraint against
  * Static{center: the compound's displacement (Shape::center, :289-291), friction: 0}: world.rs:243-251 with the compound in the Mesh's
- * place (the reference's demo world holds a Mesh only; the oracle states the definition, World::obstacles).  At most 256 obstacles. */
+ * place (the reference's demo world holds a Mesh only; the oracle states the definition, World::obstacles).  At most 256 obstacles of at most 2^18 components each. */
 MGF_API mgf_status mgf_world_add_obstacle(mgf_world* w, const mgf_compound* c);
 /* World::add_body / RigidBodyVec::add_body (physics.rs:200-218), bulk; MGF_ERR_SINGULAR as the unwrap. */
 MGF_API mgf_status mgf_world_add_bodies(mgf_world* w, const mgf_component* comps, int64_t n, const float* mass,
@@ -242,8 +242,8 @@ MGF_API mgf_status mgf_world_add_bodies(mgf_world* w, const mgf_component* comps
  * world; a wave takes a candidate pair of bodies and its lanes the part pairs (the reference's Compound, compound.rs:232-352, a STATIC
  * shape, walks a BVH over its components instead - one CPU thread's way of skipping distant parts).
  * LIMITS: a body of more than 32 components (or of none) is refused with MGF_ERR_INVALID and nothing is added; bodies of more than 4
- * components are refused beside static obstacles and in tile sets (MGF_ERR_INVALID); a tick in which two bodies meet in more than 64
- * part pairs, or in a manifold of more than 16 contacts, fails with MGF_ERR_CAPACITY. */
+ * components are refused in tile sets (MGF_ERR_INVALID: the tile records carry four part slots); a tick in which two bodies meet in more
+ * than 64 part pairs, or in a manifold of more than 16 contacts, fails with MGF_ERR_CAPACITY. */
 MGF_API mgf_status mgf_world_add_compound_bodies(mgf_world* w, const mgf_component* comps, const float* comp_mass,
                                                  const int64_t* offsets /* n + 1 */, int64_t n, const float* restitution,
                                                  const float* friction, const mgf_vec3* world_force, uint64_t* first_id);

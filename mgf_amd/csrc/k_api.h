@@ -288,27 +288,17 @@ __global__ __launch_bounds__(kBlock) void k_compound_intersections(CompoundDev D
 
 // ---- static Compounds as obstacles of the world (round 3; the oracle's World::obstacles) -------------------------------------
 // A candidate of the "terrain" lists is a mesh face or - flagged - a component of an obstacle met by one part of the body:
-// kObstacleFlag | obstacle << 23 | part << 20 | component.  Appended to a body's terrain row behind its faces: obstacles in insertion
+// kObstacleFlag | obstacle << 23 | part << 18 | component (r06: five bits of part - bodies of up to 32 components - and eighteen of component).  Appended to a body's terrain row behind its faces: obstacles in insertion
 // order, the body's parts in order, the components in the order Compound::contacts visits them (compound.rs:334-352: its BVH
 // queried with the part's bounds turned into the obstacle's frame).
-constexpr uint32_t kObstacleFlag = 0x80000000u, kObstacleMax = 256u, kObstacleCompMax = 1u << 20;
-__device__ __forceinline__ int body_parts(const Bodies& B, uint32_t i, Comp* out /* kMaxParts */, V3* centre) {
-  const uint32_t pc = B.pcount ? B.pcount[i] : 0u;
-  if (pc == 0) { out[0] = load_comp(B, i); *centre = comp_center(out[0]); return 1; }
-  for (uint32_t k = 0; k < pc && k < (uint32_t)kMaxParts; ++k) {
-    const float4 a = B.wp0[kMaxParts * i + k], b = B.wp1[kMaxParts * i + k];
-    out[k].kind = (int)f2u(b.w); out[k].p = xyz(a); out[k].r = a.w; out[k].d = xyz(b);
-  }
-  *centre = xyz(B.col0[i]);
-  return (int)min(pc, (uint32_t)kMaxParts);
-}
+constexpr uint32_t kObstacleFlag = 0x80000000u, kObstacleMax = 256u, kObstacleCompMax = 1u << 18, kObstaclePartShift = 18u;
+static_assert(kBigParts <= 32, "five bits of part in an obstacle candidate");
 __global__ __launch_bounds__(kBlock) void k_obstacle_rows(Bodies B, uint32_t n_owned, const CompoundDev* obs, uint32_t n_obs, uint32_t cap_row, uint32_t* rows_t,
                                                           uint32_t* t_cnt, uint32_t* overflow) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n_owned) return;
-  Comp part[kMaxParts];
-  V3 ci;
-  const int np = body_parts(B, i, part, &ci);
+  const uint32_t pc = B.pcount ? B.pcount[i] : 0u;
+  const int np = pc ? (int)pc : 1;
   const V3 vel = xyz(B.delta[i]);
   uint32_t nt = t_cnt[i];
   uint32_t* row = rows_t + (size_t)i * cap_row;
@@ -317,10 +307,12 @@ __global__ __launch_bounds__(kBlock) void k_obstacle_rows(Bodies B, uint32_t n_o
     const V3 disp = ld3(D.disp);
     const Quat rot = mkq(D.rot[0], mk3(D.rot[1], D.rot[2], D.rot[3])), conj = mkq(rot.s, -rot.v);
     for (int pa = 0; pa < np; ++pa) {
-      Box rb = box_rotate(swept_bounds(part[pa], vel), conj);  // compound.rs:340-344
+      Comp part; V3 ci;
+      (void)load_part(B, i, (uint32_t)pa, &part, &ci);
+      Box rb = box_rotate(swept_bounds(part, vel), conj);  // compound.rs:340-344
       rb.c = rotate(conj, rb.c + -disp) + disp;
       terrain_traverse(D.tree, rb, [&](uint32_t comp) {
-        if (nt < cap_row) row[nt] = kObstacleFlag | (k << 23) | ((uint32_t)pa << 20) | comp;
+        if (nt < cap_row) row[nt] = kObstacleFlag | (k << 23) | ((uint32_t)pa << kObstaclePartShift) | comp;
         ++nt;
       });
     }
@@ -337,9 +329,8 @@ __global__ __launch_bounds__(kBlock) void k_obstacle_candidates(Bodies B, uint32
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n_owned) return;
   if (FILL && sc->fail) return;
-  Comp part[kMaxParts];
-  V3 ci;
-  const int np = body_parts(B, i, part, &ci);
+  const uint32_t pc = B.pcount ? B.pcount[i] : 0u;
+  const int np = pc ? (int)pc : 1;
   const V3 vel = xyz(B.delta[i]);
   auto walk = [&](auto&& hit) {
     for (uint32_t k = 0; k < n_obs; ++k) {
@@ -347,9 +338,11 @@ __global__ __launch_bounds__(kBlock) void k_obstacle_candidates(Bodies B, uint32
       const V3 disp = ld3(D.disp);
       const Quat rot = mkq(D.rot[0], mk3(D.rot[1], D.rot[2], D.rot[3])), conj = mkq(rot.s, -rot.v);
       for (int pa = 0; pa < np; ++pa) {
-        Box rb = box_rotate(swept_bounds(part[pa], vel), conj);  // compound.rs:340-344
+        Comp part; V3 ci;
+        (void)load_part(B, i, (uint32_t)pa, &part, &ci);
+        Box rb = box_rotate(swept_bounds(part, vel), conj);  // compound.rs:340-344
         rb.c = rotate(conj, rb.c + -disp) + disp;
-        terrain_traverse(D.tree, rb, [&](uint32_t comp) { hit(kObstacleFlag | (k << 23) | ((uint32_t)pa << 20) | comp); });
+        terrain_traverse(D.tree, rb, [&](uint32_t comp) { hit(kObstacleFlag | (k << 23) | ((uint32_t)pa << kObstaclePartShift) | comp); });
       }
     }
   };
@@ -368,17 +361,17 @@ __global__ __launch_bounds__(kBlock) void k_narrow_obstacles(Bodies B, const Com
   if (p >= *m_ptr) return;
   const uint32_t f = t_cand[p];
   if (!(f & kObstacleFlag)) return;
-  const uint32_t i = t_owner[p], k = (f >> 23) & 0xFFu, pa = (f >> 20) & 7u, ci_ = f & (kObstacleCompMax - 1u);
-  Comp part[kMaxParts];
+  const uint32_t i = t_owner[p], k = (f >> 23) & 0xFFu, pa = (f >> kObstaclePartShift) & 31u, ci_ = f & (kObstacleCompMax - 1u);
+  Comp part;
   V3 centre;
-  body_parts(B, i, part, &centre);
+  (void)load_part(B, i, pa, &part, &centre);
   const V3 vel = xyz(B.delta[i]);
   const CompoundDev D = obs[k];
   const Quat rot = mkq(D.rot[0], mk3(D.rot[1], D.rot[2], D.rot[3]));
   Comp shape = comp_rotate_about(to_comp(D.comps[ci_]), rot, mk3(0.0f, 0.0f, 0.0f));
   shape.p = shape.p + ld3(D.disp);
   Contact c[2];
-  const int m = contacts_dispatch(comp_shape(part[pa]), true, vel, comp_shape(shape), false, mk3(0, 0, 0), c);
+  const int m = contacts_dispatch(comp_shape(part), true, vel, comp_shape(shape), false, mk3(0, 0, 0), c);
   const V3 oc = ld3(D.disp);  // Shape::center for Compound compound.rs:289-291
   uint32_t cnt = 0;
   for (int e = 0; e < m && e < 2; ++e) {

@@ -48,6 +48,7 @@ SCENES = {
     "spheres": lambda: scenes.sphere_pile(8, 5, 8),
     "capsules_and_spheres": lambda: scenes.capsule_field_dense(7, 3, 7, y0=2.5, sphere_fraction=0.4),
     "bodies_of_several_parts": lambda: scenes.jack_field(4, 2, 4, y0=3.0),
+    "bodies_of_sixteen_parts": lambda: scenes.caterpillar_field(3, 2, 3, small_every=4, y0=3.0),  # (r06: parts from the pool, five bits of part in an obstacle candidate)
 }
 
 
