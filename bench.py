@@ -782,7 +782,9 @@ TILE_PREDICTION_ASSUMPTIONS = {
     "link_GBps": 60.0,             # achieved one-way rate of one xGMI link for MB-sized rows (153.6 GB/s bidirectional per link on paper)
     "allreduce_us": 30.0,          # the tick's status agreement (4-byte all-reduce over N ranks)
     "exchange_steps_per_tick": {"ghost_bodies": 1, "ghost_velocities": "ceil(iters / R) - 1 (R = 4, 10 iterations: 2)", "handover": 0.4, "status_allreduce": 1},
-    "bytes_per_rank_face_per_tick": {"config4": 3.4e6, "config5_tiles": 0.5e6},  # one direction, AT R = 2: ghost records (288 B) + 4 velocity refreshes (32 B each) per ghost (profiles/r05_config4_8tiles_1gpu_bench.json: 95 MB between the 14 face directions of 8 tiles); scaled to the run's R below
+    "bytes_per_rank_face_per_tick": {"config4": 3.4e6, "config5_tiles": 0.5e6},  # one direction, AT R = 2 WITH ROUND 5's RECORDS: ghost records (288 B) + 4 velocity refreshes (32 B each) per ghost (profiles/r05_config4_8tiles_1gpu_bench.json: 95 MB between the 14 face directions of 8 tiles); scaled below to the run's R and to round 6's records
+    "ghost_record_bytes": {"config4": 160, "config5_tiles": 288},  # r06: a world of single-component bodies sends the first 40 floats of the 72
+    "velocity_record_bytes": 24,                                    # r06: 6 floats (the two zeros stay at home)
 }
 
 
@@ -795,7 +797,7 @@ def _tile_prediction(scene_kind, world_size, total_tiles, measured_ms, one_gpu, 
     steps = A["exchange_steps_per_tick"]
     refreshes = max(0, -(-int(iters) // max(1, int(refresh_every))) - 1)  # a velocity exchange between consecutive solver launches
     lat_us = (steps["ghost_bodies"] + refreshes + steps["handover"]) * A["p2p_latency_us"] + steps["status_allreduce"] * A["allreduce_us"]
-    wire_us = A["bytes_per_rank_face_per_tick"][scene_kind] * (288.0 + 32.0 * refreshes) / (288.0 + 32.0 * 4) / (A["link_GBps"] * 1e3)
+    wire_us = A["bytes_per_rank_face_per_tick"][scene_kind] * (A["ghost_record_bytes"][scene_kind] + A["velocity_record_bytes"] * refreshes) / (288.0 + 32.0 * 4) / (A["link_GBps"] * 1e3)
     comm_ms = 0.0 if world_size == 1 else (lat_us + wire_us) / 1e3
     pred_ms = per * tile_tick + comm_ms
     return {"predicted_ms_per_step": round(pred_ms, 4), "predicted_efficiency_vs_8_tiles_on_one_gpu": round(one_gpu["ms_per_step"] / (world_size * pred_ms), 4),

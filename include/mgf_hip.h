@@ -393,7 +393,10 @@ MGF_API mgf_status mgf_world_finish(mgf_world* w, mgf_step_stats* stats);
  * mgf_tiles_connect(rank, n_ranks) - rank r's tile range follows rank r - 1's - and mgf_tiles_preflight sums a 1 from every
  * rank over the communicator (0 = not connected).  librccl is loaded at run time, on the first of these calls.
  * stats (optional) receives one record per local tile.  Results are bit-identical to mgf_amd/tiles.py and to the oracle's
- * tile mode, and independent of how the tiles are spread over processes. */
+ * tile mode, and independent of how the tiles are spread over processes.
+ * (Between its own tiles and ranks mgf_tiles_step moves narrower records than the calls above hand to a caller: a world without bodies
+ * of several components sends the first 40 floats of a ghost record - the receiver learns the width from the kinds its neighbour announces
+ * with its counts - and velocity records are 6 floats, v3 w3.) */
 MGF_API mgf_status mgf_tiles_create(mgf_ctx* ctx, int32_t n_local, mgf_world* const* worlds, const float* x_lo, const float* x_hi,
                                     int32_t first_tile, int32_t n_tiles_total, float halo, int32_t refresh_every, int32_t migrate,
                                     mgf_tiles** out);

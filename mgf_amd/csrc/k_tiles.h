@@ -10,6 +10,10 @@ namespace mgf {
 // kTileParts x (p3 r d3 kind) world parts of a body of several components (zeros for an ordinary body).
 // ------------------------------------------------------------------------------------------
 constexpr int kGhostFloats = 40 + 8 * kTileParts;
+// (r06) between the tiles of mgf_tiles_step a world WITHOUT bodies of several components sends the first kGhostFloatsPlain floats only - the part
+// slots of its records would be zeros, 32 of 72 floats; the receiver learns the width from the kinds the sender announces with its counts.  The
+// C-ABI's own export / import calls (mgf_world_export_ghosts, ..) keep the one width their callers size their buffers for.
+constexpr int kGhostFloatsPlain = 40;
 
 // ---- what a tile sends: selection ------------------------------------------------------------------------------------------------
 // Every launch of the tile protocol's own kernels takes up to kTileBatch tiles (blockIdx.y = the tile): a rank that holds several tiles
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_select_scatter(SelBatch A) {
 }
 // (written word by word: 16-byte stores - 288 bytes apart between lanes - were TWICE as slow as the 72 scalar ones, 95 against 49 us for
 // the 64 000 records of eight tiles; the import's 16-byte loads are the faster ones, 31 against 75 us)
-__device__ __forceinline__ void export_body(const Bodies& B, uint32_t i, float* o) {
+__device__ __forceinline__ void export_body(const Bodies& B, uint32_t i, float* o, uint32_t rec = (uint32_t)kGhostFloats) {
   constexpr bool vec = false;
   float4 x = B.x[i], q = B.q[i], s0 = B.srec[4 * i], s1 = B.srec[4 * i + 1], s2 = B.srec[4 * i + 2], s3 = B.srec[4 * i + 3];
   float4 d = B.delta[i], e = B.einfo[i], c0 = B.col0[i], c1 = B.col1[i];
@@ -139,6 +143,7 @@ __device__ __forceinline__ void export_body(const Bodies& B, uint32_t i, float* 
   };
 #pragma unroll
   for (uint32_t k = 0; k < 10; ++k) put(k, r[k]);
+  if (rec <= (uint32_t)kGhostFloatsPlain) return;  // (a world of single-component bodies: no part slots in its records)
   for (uint32_t k = 0; k < (uint32_t)kTileParts; ++k) {
     float4 a = make_float4(0, 0, 0, 0), b = a;
     if (k < pc) { a = B.wp0[kMaxParts * i + k]; b = B.wp1[kMaxParts * i + k]; }
@@ -146,15 +151,15 @@ __device__ __forceinline__ void export_body(const Bodies& B, uint32_t i, float* 
   }
 }
 // both faces' records of every tile of the batch: the left face's first (ids_r == null: one list)
-struct ExpTile { Bodies B; const uint32_t *ids_l, *ids_r; uint32_t nl, nr; float* out; };
+struct ExpTile { Bodies B; const uint32_t *ids_l, *ids_r; uint32_t nl, nr; float* out; uint32_t rec, pad; };  // rec: floats per record (kGhostFloats or kGhostFloatsPlain)
 struct ExpBatch { ExpTile t[kTileBatch]; };
 __global__ __launch_bounds__(kBlock) void k_export_bodies(ExpBatch A) {
   const ExpTile& E = A.t[blockIdx.y];
   const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= E.nl + E.nr) return;
-  export_body(E.B, t < E.nl ? E.ids_l[t] : E.ids_r[t - E.nl], E.out + (size_t)t * kGhostFloats);
+  export_body(E.B, t < E.nl ? E.ids_l[t] : E.ids_r[t - E.nl], E.out + (size_t)t * E.rec, E.rec);
 }
-__device__ __forceinline__ void import_ghost(Bodies B, uint32_t i, const float* src, float fat_margin, int blo[3], int bhi[3], int brm[3]) {
+__device__ __forceinline__ void import_ghost(Bodies B, uint32_t i, const float* src, float fat_margin, int blo[3], int bhi[3], int brm[3], uint32_t rec = (uint32_t)kGhostFloats) {
   // the record's first 40 floats, as ten 16-byte words when the buffer is 16-byte aligned (the tile set's own buffers are)
   const bool vec = (reinterpret_cast<uintptr_t>(src) & 15u) == 0u;
   auto get = [&](uint32_t k) -> float4 {
@@ -178,12 +183,13 @@ __device__ __forceinline__ void import_ghost(Bodies B, uint32_t i, const float* 
   B.col1[i] = mk4(k.d, o[16]);
   if (B.bpk) { B.bpk[4 * i] = mk4(k.p, k.r); B.bpk[4 * i + 1] = mk4(d, o[35]); B.bpk[4 * i + 2] = mk4(x + d, o[34]); B.bpk[4 * i + 3] = mk4(k.d, o[16]); }
   Box tb = swept_bounds(k, d);
-  const uint32_t pc = min(f2u(o[36]), (uint32_t)kTileParts);
+  const bool parts_in = rec > (uint32_t)kGhostFloatsPlain;  // (the record carries part slots)
+  const uint32_t pc = parts_in ? min(f2u(o[36]), (uint32_t)kTileParts) : 0u;
   if (B.pcount) {
     B.pcount[i] = pc;
     for (uint32_t pk = 0; pk < (uint32_t)kMaxParts; ++pk) {  // a ghost is never integrated here: its world parts are all that matters
       float4 a = make_float4(0, 0, 0, 0), b = a;
-      if (pk < (uint32_t)kTileParts) { a = get(10 + 2 * pk); b = get(11 + 2 * pk); }
+      if (parts_in && pk < (uint32_t)kTileParts) { a = get(10 + 2 * pk); b = get(11 + 2 * pk); }
       B.wp0[kMaxParts * i + pk] = a; B.wp1[kMaxParts * i + pk] = b;
       B.lp0[kMaxParts * i + pk] = a; B.lp1[kMaxParts * i + pk] = b;
       if (pk < pc) {
@@ -203,18 +209,20 @@ __device__ __forceinline__ void import_ghost(Bodies B, uint32_t i, const float* 
   B.imb[3 * i] = make_float4(0, 0, 0, 0); B.imb[3 * i + 1] = make_float4(0, 0, 0, 0); B.imb[3 * i + 2] = make_float4(0, 0, 0, 0);
 }
 // (in2 / m1: the rows from m1 on come from a second buffer - the two neighbours' send buffers read in place, no copy in between)
-struct ImpTile { Bodies B; uint32_t n_owned, m, m1; float fat_margin; const float *in, *in2; int* sb_part; };
+struct ImpTile { Bodies B; uint32_t n_owned, m, m1; float fat_margin; const float *in, *in2; int* sb_part; uint32_t rec1, rec2; };  // rec1 / rec2: floats per record of `in` / `in2`
 struct ImpBatch { ImpTile t[kTileBatch]; };
 __global__ __launch_bounds__(kBlock) void k_import_ghosts(ImpBatch A) {
   const ImpTile& I = A.t[blockIdx.y];
   if (blockIdx.x * kBlock >= I.m) return;
   const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   int blo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, bhi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000}, brm[3] = {0, 0, 0};
-  if (t < I.m) import_ghost(I.B, I.n_owned + t, t < I.m1 ? I.in + (size_t)t * kGhostFloats : I.in2 + (size_t)(t - I.m1) * kGhostFloats, I.fat_margin, blo, bhi, brm);
+  if (t < I.m) import_ghost(I.B, I.n_owned + t, t < I.m1 ? I.in + (size_t)t * I.rec1 : I.in2 + (size_t)(t - I.m1) * I.rec2, I.fat_margin, blo, bhi, brm, t < I.m1 ? I.rec1 : I.rec2);
   if (I.sb_part) bounds_block_accumulate(blo, bhi, brm, I.sb_part);  // the scene bounds gathered by this tick's k_integrate take the ghosts in
 }
-// velocity record: 8 floats (v3, w3, 0, 0); both slab faces of a tile in one list of records, the left face's first
-struct VelTile { float4* srec; const uint32_t *ids_l, *ids_r; uint32_t nl, nr; float4* out; };   // export: srec -> out
+// velocity record: 8 floats (v3, w3, 0, 0); both slab faces of a tile in one list of records, the left face's first.  (r06) rec = 6: the
+// two zeros stay at home - between the tiles of mgf_tiles_step; the C-ABI's calls keep 8.
+constexpr uint32_t kVelFloats = 8, kVelFloatsPacked = 6;
+struct VelTile { float4* srec; const uint32_t *ids_l, *ids_r; uint32_t nl, nr; float4* out; uint32_t rec, pad; };   // export: srec -> out
 struct VelBatch { VelTile t[kTileBatch]; };
 __global__ __launch_bounds__(kBlock) void k_export_vel(VelBatch A) {
   const VelTile& V = A.t[blockIdx.y];
@@ -222,16 +230,29 @@ __global__ __launch_bounds__(kBlock) void k_export_vel(VelBatch A) {
   if (t >= V.nl + V.nr) return;
   const uint32_t i = t < V.nl ? V.ids_l[t] : V.ids_r[t - V.nl];
   const float4 s0 = V.srec[4 * (size_t)i], s1 = V.srec[4 * (size_t)i + 1];
+  if (V.rec == kVelFloatsPacked) {
+    float2* o = reinterpret_cast<float2*>(reinterpret_cast<float*>(V.out) + (size_t)kVelFloatsPacked * t);  // (24-byte records: 8-byte aligned)
+    o[0] = make_float2(s0.x, s0.y); o[1] = make_float2(s0.z, s0.w); o[2] = make_float2(s1.x, s1.y);
+    return;
+  }
   V.out[2 * (size_t)t] = s0;
   V.out[2 * (size_t)t + 1] = make_float4(s1.x, s1.y, 0.0f, 0.0f);
 }
-struct GVelTile { float4* srec; uint32_t n_owned, m, m1; const float4 *in, *in2; };  // import: the rows from m1 on come from in2
+struct GVelTile { float4* srec; uint32_t n_owned, m, m1; const float4 *in, *in2; uint32_t rec, pad; };  // import: the rows from m1 on come from in2
 struct GVelBatch { GVelTile t[kTileBatch]; };
 __global__ __launch_bounds__(kBlock) void k_import_ghost_vel(GVelBatch A) {
   const GVelTile& G = A.t[blockIdx.y];
   const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
   if (t >= G.m) return;
   const size_t i = (size_t)G.n_owned + t;
+  if (G.rec == kVelFloatsPacked) {
+    const float2* r = reinterpret_cast<const float2*>(t < G.m1 ? reinterpret_cast<const float*>(G.in) + (size_t)kVelFloatsPacked * t
+                                                               : reinterpret_cast<const float*>(G.in2) + (size_t)kVelFloatsPacked * (t - G.m1));
+    const float2 a = r[0], b = r[1], c = r[2];
+    G.srec[4 * i] = make_float4(a.x, a.y, b.x, b.y);
+    *reinterpret_cast<float2*>(&G.srec[4 * i + 1]) = c;
+    return;
+  }
   const float4* r = t < G.m1 ? G.in + 2 * (size_t)t : G.in2 + 2 * (size_t)(t - G.m1);
   G.srec[4 * i] = r[0];
   *reinterpret_cast<float2*>(&G.srec[4 * i + 1]) = make_float2(r[1].x, r[1].y);

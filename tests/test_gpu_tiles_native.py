@@ -265,3 +265,38 @@ def test_a_tick_lost_to_a_solver_launch_that_gave_up_is_repeated(ctx):
     with pytest.raises(mgf_amd.MgfError):
         for _ in range(80):
             T.step(dt, iters)
+
+
+def test_ghost_records_of_two_widths_across_one_face(ctx):
+    """r06: a world without bodies of several components sends 40-float ghost records, one with such bodies 72 (k_tiles.h); the receiver learns
+    the width from the kinds its neighbour announces.  A tile of two-part bodies beside a tile of plain spheres, driven into each other: records
+    of both widths cross the face in opposite directions, then bodies change owner and the plain tile's width changes in mid-run - against the
+    oracle's tiles, bit for bit."""
+    from mgf_amd.tiles import step_tiles_inprocess
+    sc = scenes.dumbbell_field(3, 2, 4, n_plain=24)
+    cb = sc["compound"]
+    cb["comps"]["p"][:, 0] -= np.float32(cb["comps"]["p"][:, 0].max() + 1.2)      # every two-part body left of x = 0 ...
+    n_plain = len(sc["comps"])
+    sc["comps"]["p"][:, 0] = np.float32(0.8) + np.float32(0.9) * (np.arange(n_plain) % 4).astype(np.float32)   # ... every plain sphere right of it
+    sc["comps"]["p"][:, 1] = np.float32(1.0) + np.float32(1.1) * (np.arange(n_plain) // 4).astype(np.float32)
+    sc["comps"]["p"][:, 2] = np.float32(-2.0) + np.float32(1.3) * (np.arange(n_plain) % 3).astype(np.float32)
+    sc["v0"][:n_plain] = np.float32([-2.0, 0.0, 0.0])
+    sc["v0"][n_plain:] = np.float32([3.0, 0.0, 0.0])
+    tile_scenes = scenes.split_by_slabs(sc, 2, 12.0)
+    assert len(tile_scenes[0]["comps"]) == 0 and len(tile_scenes[0]["compound"]["offsets"]) - 1 == 24          # compound only
+    assert len(tile_scenes[1]["comps"]) == n_plain and len(tile_scenes[1]["compound"]["offsets"]) - 1 == 0     # plain only
+    T, worlds = _native(ctx, tile_scenes, halo=2.0)
+    ot = _oracle_tiles(tile_scenes, halo=2.0)
+    assert worlds[0].counter("body_kinds") & 4 and not worlds[1].counter("body_kinds") & 4
+    dt, iters = float(sc["dt"]), sc["iters"]
+    ghosts = moved = 0
+    for tick in range(90):
+        sg, so = T.step(dt, iters), step_tiles_inprocess(ot)
+        assert [int(s.n_constraints) for s in sg] == [int(s["n_constraints"]) for s in so], tick
+        ghosts += sum(int(s.n_ghost_constraints) for s in sg)
+        if tick % 10 == 9:
+            _assert_equal(worlds, ot, f"tick {tick}")
+    moved = T.migrated(0) + T.migrated(1)
+    assert ghosts > 20 and moved > 0, (ghosts, moved)   # (contacts across the face, and bodies that changed tile)
+    assert worlds[1].counter("body_kinds") & 4           # (the plain tile has taken two-part bodies in: its records are 72 floats wide now)
+    _assert_equal(worlds, ot, "end")
