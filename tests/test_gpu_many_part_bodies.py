@@ -97,3 +97,48 @@ def test_limits_of_many_part_bodies(ctx):
     with pytest.raises(mgf_amd.MgfError) as e:
         w2.step(1.0 / 60.0, 10)
     assert "part pairs" in str(e.value)
+
+
+def test_random_clumps_pressed_into_each_other(ctx):
+    """the pruner under load: clumps of 5..32 random spheres and capsules, a few of them thrown into one another so that pairs of bodies meet in
+    dozens of part pairs at several collision times - contacts merged, replaced and dropped by ContactPruner::push in the order the wave packed them
+    (k_narrow_pairs_big) - one tick each, constraint lists and states against the oracle; a trial that exceeds the lists' capacity must say so"""
+    import mgf_amd
+    rng = np.random.default_rng(616)
+    dtype = scenes.COMPONENT_DTYPE
+    full = over = manifolds = 0
+    for trial in range(80):
+        nb = int(rng.integers(2, 5))
+        comps, offsets, masses = [], [0], []
+        centres = rng.normal(0.0, 0.9, (nb, 3)) + np.array([0.0, 6.0, 0.0])
+        for b in range(nb):
+            np_ = int(rng.integers(5, 33))
+            k = np.zeros(np_, dtype)
+            k["tag"] = (rng.random(np_) < 0.4).astype(np.int32)
+            k["p"] = (centres[b] + rng.normal(0.0, 0.8, (np_, 3))).astype(np.float32)
+            k["d"] = (rng.normal(0.0, 0.5, (np_, 3)) * (k["tag"][:, None] == 1)).astype(np.float32)
+            k["r"] = rng.uniform(0.08, 0.3, np_).astype(np.float32)
+            comps.append(k); offsets.append(offsets[-1] + np_); masses.append(rng.uniform(0.2, 1.0, np_).astype(np.float32))
+        sc = scenes._scene(f"clumps_{trial}", np.zeros(0, dtype), scenes.box_terrain(12.0, 14.0, (0.0, 0.0, 0.0)))
+        sc["compound"] = dict(comps=np.concatenate(comps), comp_mass=np.concatenate(masses), offsets=np.asarray(offsets, np.int64),
+                              restitution=np.full(nb, 0.3, np.float32), friction=np.full(nb, 0.6, np.float32), force=np.tile(np.float32([0.0, -9.8, 0.0]), (nb, 1)))
+        sc["v0"] = rng.normal(0.0, 3.0, (nb, 3)).astype(np.float32)
+        gw, ow = mgf_amd.World.from_scene(ctx, sc), oracle_world(sc)
+        dt, iters = float(sc["dt"]), sc["iters"]
+        try:
+            sg = gw.step(dt, iters)
+        except mgf_amd.MgfError as e:
+            assert "part pairs" in str(e)   # (more than 64 raw contacts or a manifold above 16: refused, not mangled)
+            over += 1
+            continue
+        so = ow.step(dt, iters)
+        assert (sg.n_constraints, sg.n_pair_candidates) == (so.n_constraints, so.n_pair_candidates), trial
+        got, want = gw.constraints(), ow.constraints()
+        compare_constraints(got, want, check_impulse=True)
+        g, o = gw.state(), ow.state()
+        for key in ("x", "q", "v", "omega"):
+            assert values_equal(g[key], o[key]), (trial, key)
+        full += 1
+        ab = list(zip(want["a"].tolist(), want["b"].tolist()))
+        manifolds += sum(1 for i in range(1, len(ab)) if ab[i] == ab[i - 1] and ab[i][1] >= 0)
+    assert full >= 40 and manifolds > 100, (full, over, manifolds)
