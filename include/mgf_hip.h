@@ -453,7 +453,7 @@ MGF_API int64_t mgf_tiles_counter(const mgf_tiles* t, const char* key);
  * stream: what the two events cost by themselves);
  * "wide_list" [1] (r06: the few bodies whose fat box is far larger than the rest's - a body that left the scene and falls at 200 m/s - are kept
  * out of the scene bounds and of the reach of every query of the cell grid, and paired by a launch of their own; the accepted set is the
- * reference's either way (bvh.rs:283-310); engaged by the host from the tick after such a body shows, for worlds of single-component bodies;
+ * reference's either way (bvh.rs:283-310); engaged by the host from the tick after such a body shows;
  * 0 = never);
  * "cells_in_integrate" [1] (the fused tick's k_integrate works out the bodies' Morton cells over the previous tick's scene bounds);
  * "flow_max_blocks" [0] (the persistent solver launches of this world take at most this many workgroups - one per CU; 0 = all CUs.  Processes that

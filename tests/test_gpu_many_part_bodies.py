@@ -142,3 +142,28 @@ def test_random_clumps_pressed_into_each_other(ctx):
         ab = list(zip(want["a"].tolist(), want["b"].tolist()))
         manifolds += sum(1 for i in range(1, len(ab)) if ab[i] == ab[i - 1] and ab[i][1] >= 0)
     assert full >= 40 and manifolds > 100, (full, over, manifolds)
+
+
+def test_a_sixteen_part_body_that_runs_away(ctx):
+    """the wide-body list (WideSpec, k_pair_wide) knows boxes, not kinds: a caterpillar thrown through the field at 600 m/s - its fat box three times
+    the others', which are five metres long themselves - and one falling far below the scene, against the oracle and against the same world with the list switched off"""
+    import mgf_amd
+    sc = scenes.caterpillar_field(4, 2, 4, n_plain=6)
+    n_plain = len(sc["comps"])
+    sc["v0"][n_plain + 3] = np.float32([600.0, 40.0, -200.0])     # (through the field: ten metres a tick)
+    sc["v0"][n_plain + 7] = np.float32([0.0, -700.0, 0.0])
+    cb = sc["compound"]
+    lo, hi = int(cb["offsets"][7]), int(cb["offsets"][8])
+    cb["comps"]["p"][lo:hi, 1] -= np.float32(1500.0)               # (far below the floor: it never comes back)
+    dt, iters = float(sc["dt"]), sc["iters"]
+    a, b, ow = mgf_amd.World.from_scene(ctx, sc), mgf_amd.World.from_scene(ctx, sc), oracle_world(sc)
+    b.set_option("wide_list", 0)
+    for tick in range(80):
+        sa, sb, so = a.step(dt, iters), b.step(dt, iters), ow.step(dt, iters)
+        assert (sa.n_constraints, sa.n_pair_candidates) == (so.n_constraints, so.n_pair_candidates) == (sb.n_constraints, sb.n_pair_candidates), tick
+        if tick % 8 == 7:
+            compare_constraints(a.constraints(), ow.constraints(), check_impulse=True)
+    assert a.counter("wide_ticks") > 20 and b.counter("wide_ticks") == 0
+    g, h, o = a.state(), b.state(), ow.state()
+    for k in ("x", "q", "v", "omega"):
+        assert values_equal(g[k], o[k]) and values_equal(h[k], o[k]), k

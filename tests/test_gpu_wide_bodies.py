@@ -35,11 +35,14 @@ def _with_runaways(scene, where):
     return sc
 
 
-@pytest.mark.parametrize("kind", ["spheres", "capsules"])
+@pytest.mark.parametrize("kind", ["spheres", "capsules", "two_part_bodies"])
 def test_runaway_bodies_change_nothing_but_the_bounds(ctx, kind):
     import mgf_amd
     from mgf_amd import scenes
-    base = scenes.sphere_pile(16, 16, 16) if kind == "spheres" else scenes.capsule_field(8, 6, 8, quads=12, pitch=1.6)
+    # (two_part_bodies: plain spheres run away among bodies of two components - a tick with wide bodies there takes the list-based kernels instead
+    # of the r06 front end, whose pair search writes manifolds k_pair_wide does not)
+    base = (scenes.sphere_pile(16, 16, 16) if kind == "spheres" else scenes.capsule_field(8, 6, 8, quads=12, pitch=1.6) if kind == "capsules"
+            else scenes.dumbbell_field(8, 5, 8, n_plain=40))
     n = len(base["comps"])
     # one far below and fast, one INSIDE the pile and fast (a wide body that meets others: partner and query), one fast pair side by side
     sc = _with_runaways(base, [(n - 1, (0.0, -2500.0, 0.0), (0.0, -220.0, 0.0)), (n // 2, (1.0, 6.0, 0.5), (150.0, 20.0, -90.0)),
