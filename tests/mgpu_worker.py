@@ -30,8 +30,14 @@ def run_rank(rank, n_ranks, total_tiles, dims, drift, ticks, fail_rank, fail_tic
         per = total_tiles // n_ranks
         first = rank * per
         ctx = mgf_amd.Context(rank if device is None else device)
-        nx, ny, nz = dims
-        tile_scenes = [scenes.sphere_pile_tile(nx, ny, nz, first + k, total_tiles, drift=drift) for k in range(per)]
+        halo = 1.0
+        if dims == "two_kinds":  # (r06: two-part bodies on the left ranks, plain spheres on the right: ghost records of two widths across a RANK face)
+            from tests.util import two_kinds_tile_scenes
+            tile_scenes = two_kinds_tile_scenes(total_tiles)[first:first + per]
+            halo = 2.0
+        else:
+            nx, ny, nz = dims
+            tile_scenes = [scenes.sphere_pile_tile(nx, ny, nz, first + k, total_tiles, drift=drift) for k in range(per)]
         worlds = []
         for sc in tile_scenes:
             w = mgf_amd.World.from_scene(ctx, sc)
@@ -39,7 +45,7 @@ def run_rank(rank, n_ranks, total_tiles, dims, drift, ticks, fail_rank, fail_tic
             for key, val in (world_opts or {}).items():
                 w.set_option(key, val)
             worlds.append(w)
-        T = mgf_amd.Tiles(ctx, worlds, [sc["x_range"] for sc in tile_scenes], first_tile=first, n_tiles_total=total_tiles)
+        T = mgf_amd.Tiles(ctx, worlds, [sc["x_range"] for sc in tile_scenes], first_tile=first, n_tiles_total=total_tiles, halo=halo)
         if rank == 0:
             uid = mgf_amd.rccl_unique_id()
             for _ in range(n_ranks - 1):

@@ -54,8 +54,12 @@ def _launch(n_ranks, total_tiles, dims, drift, ticks, fail_rank=-1, fail_tick=-1
 def _check_against_oracle_tiles(res, n_ranks, P, dims, drift, ticks, expect_moves=True):
     from mgf_amd.tiles import Tile, step_tiles_inprocess
     from tests.oracle_engine import OracleEngine
-    tile_scenes = [scenes.sphere_pile_tile(*dims, r, P, drift=drift) for r in range(P)]
-    ot = [Tile(OracleEngine(sc), sc["x_range"], r, P, sc["dt"], sc["iters"]) for r, sc in enumerate(tile_scenes)]
+    if dims == "two_kinds":
+        from tests.util import two_kinds_tile_scenes
+        tile_scenes, kw = two_kinds_tile_scenes(P), dict(halo=2.0)
+    else:
+        tile_scenes, kw = [scenes.sphere_pile_tile(*dims, r, P, drift=drift) for r in range(P)], {}
+    ot = [Tile(OracleEngine(sc), sc["x_range"], r, P, sc["dt"], sc["iters"], **kw) for r, sc in enumerate(tile_scenes)]
     for _ in range(ticks):
         step_tiles_inprocess(ot)
     got = {}
@@ -117,6 +121,15 @@ def test_real_librccl_with_two_ranks_on_one_device():
                 + "\n\n-- librccl's debug log (NCCL_DEBUG=WARN), the lines about the communicator --\n" + "\n".join(said) + "\n")
     assert any("Duplicate GPU" in ln for ln in said) or any("mgf status" in c for c in last), (said, last)   # (a refusal, not some other failure)
     pytest.skip(reason)
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_ghost_records_of_two_widths_across_a_rank_face(P):
+    """r06: a rank whose worlds hold no body of several components sends 40-float ghost records, its neighbour 72 - the receiver sizes its
+    ncclRecv from the kinds word that travels with the counts.  Two ranks on one device over the stand-in transport (which fails a send met by
+    a receive of another size): two-part bodies on rank 0, plain spheres on rank 1, driven into each other - the oracle's tiles, bit for bit."""
+    res = _launch(2, P, "two_kinds", None, 90, shared_device=True)
+    _check_against_oracle_tiles(res, 2, P, "two_kinds", None, 90)
 
 
 # ---- several ranks on ONE device (any box): the whole multi-rank path of mgf_tiles_step, processes and all, over the stand-in transport

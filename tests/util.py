@@ -51,3 +51,19 @@ def compare_constraints(got, want, check_impulse=False):
         if not values_equal(got[f], want[f]):
             d = np.abs(got[f].astype(np.float64) - want[f].astype(np.float64))
             raise AssertionError(f"constraint field {f} differs: max abs diff {d.max()} at {np.unravel_index(d.argmax(), d.shape)}")
+
+
+def two_kinds_tile_scenes(P):
+    """tiles for the tests of ghost records of two widths (r06): every two-part body left of x = 0, every plain sphere right of it, driven into each
+    other - cut into P x-slabs of [-12, 12) (P = 2: one kind per tile; P = 4: two tiles of two-part bodies, one of spheres, one empty)"""
+    from mgf_amd import scenes
+    sc = scenes.dumbbell_field(3, 2, 4, n_plain=24)
+    cb = sc["compound"]
+    cb["comps"]["p"][:, 0] -= np.float32(cb["comps"]["p"][:, 0].max() + 1.2)
+    n_plain = len(sc["comps"])
+    sc["comps"]["p"][:, 0] = np.float32(0.8) + np.float32(0.9) * (np.arange(n_plain) % 4).astype(np.float32)
+    sc["comps"]["p"][:, 1] = np.float32(1.0) + np.float32(1.1) * (np.arange(n_plain) // 4).astype(np.float32)
+    sc["comps"]["p"][:, 2] = np.float32(-2.0) + np.float32(1.3) * (np.arange(n_plain) % 3).astype(np.float32)
+    sc["v0"][:n_plain] = np.float32([-2.0, 0.0, 0.0])
+    sc["v0"][n_plain:] = np.float32([3.0, 0.0, 0.0])
+    return scenes.split_by_slabs(sc, P, 12.0)
